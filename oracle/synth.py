@@ -1,0 +1,53 @@
+"""Deterministic synthetic tensors shared by the fixture generator and the tests.  TEST INFRASTRUCTURE ONLY.
+
+Fixtures store only the reference's OUTPUTS; inputs and weights are regenerated on
+either box from numpy's PCG64 stream (same numpy in the build container and on the
+GPU box), keyed by a string so that adding a tensor never shifts another one.
+"""
+
+from __future__ import annotations
+
+import zlib
+
+import numpy as np
+import torch
+from torch import Tensor
+
+
+def _rng(key: str, seed: int) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64([seed, zlib.crc32(key.encode())]))
+
+
+def normal(key: str, shape, seed: int = 0, std: float = 1.0) -> Tensor:
+    a = _rng(key, seed).standard_normal(tuple(shape)).astype(np.float32) * np.float32(std)
+    return torch.from_numpy(a)
+
+
+def uniform(key: str, shape, seed: int = 0, lo: float = 0.0, hi: float = 1.0) -> Tensor:
+    a = _rng(key, seed).random(tuple(shape), dtype=np.float64) * (hi - lo) + lo
+    return torch.from_numpy(a.astype(np.float32))
+
+
+def integers(key: str, shape, hi: int, seed: int = 0) -> Tensor:
+    return torch.from_numpy(_rng(key, seed).integers(0, hi, tuple(shape), dtype=np.int64))
+
+
+def dit_params(shapes: dict[str, tuple[int, ...]], seed: int = 0, mod_std: float = 0.02) -> dict[str, Tensor]:
+    """Non-degenerate DiT weights (the reference's zero-init of the adaLN layers would turn every
+    block into the identity and hide bugs): fan-in scaled normals for matrices, O(1) norm
+    weights around 1, small non-zero biases / modulation rows.
+    """
+    out: dict[str, Tensor] = {}
+    for name, shp in shapes.items():
+        if name.endswith(".scale") or name.endswith("norm_1.weight") or name.endswith("norm_2.weight"):
+            out[name] = 1.0 + normal(name, shp, seed, 0.1)
+        elif name.endswith(".bias"):
+            out[name] = normal(name, shp, seed, 0.05)
+        elif "modulation" in name or "adaLN" in name:
+            out[name] = normal(name, shp, seed, mod_std * 4)
+        elif name.endswith("embedding.weight"):
+            out[name] = normal(name, shp, seed, 0.5)
+        else:
+            fan_in = int(np.prod(shp[1:]))
+            out[name] = normal(name, shp, seed, fan_in**-0.5)
+    return out

@@ -1,0 +1,361 @@
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REAL REFERENCE.
+
+Runs only in the build container (``/root/reference`` does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference (LouisRouss/DiffuLab @ 2026-01-28) ships no tests and no golden vectors
+(SURVEY.md §4), so these files are what pins the oracle.  Only OUTPUTS of the reference are
+stored; inputs / weights are regenerated from ``oracle.synth`` (numpy PCG64) by the tests.
+Nothing of the reference's source text is copied here: the script only *calls* it.
+
+Import shims: python 3.10 lacks typing.NotRequired; jaxtyping and the heavy
+optional deps of the package ``__init__``s are not installed -> stub them before import.
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+import types
+import typing
+
+sys.dont_write_bytecode = True
+REF = "/root/reference/src"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import typing_extensions  # noqa: E402
+
+
+def install_shims() -> None:
+    for name in ("NotRequired", "Required"):
+        if not hasattr(typing, name):
+            setattr(typing, name, getattr(typing_extensions, name))
+
+    class _Any:
+        def __class_getitem__(cls, item):
+            return typing.Any
+
+    jt = types.ModuleType("jaxtyping")
+    for n in ("Float", "Int", "Bool"):
+        setattr(jt, n, _Any)
+    sys.modules["jaxtyping"] = jt
+
+    def ns(name: str, path: str) -> types.ModuleType:
+        m = types.ModuleType(name)
+        m.__path__ = [path]  # type: ignore[attr-defined]
+        sys.modules[name] = m
+        return m
+
+    root = os.path.join(REF, "diffulab")
+    ns("diffulab", root)
+    ns("diffulab.networks", f"{root}/networks")
+    ns("diffulab.networks.embedders", f"{root}/networks/embedders")
+    ns("diffulab.networks.vision_towers", f"{root}/networks/vision_towers")
+    ns("diffulab.training", f"{root}/training")
+    ns("diffulab.training.losses", f"{root}/training/losses")
+    ns("diffulab.diffuse", f"{root}/diffuse")
+    vt = types.ModuleType("diffulab.networks.vision_towers.common")
+
+    class VisionTower:  # only used as a type annotation on the path
+        pass
+
+    vt.VisionTower = VisionTower
+    sys.modules["diffulab.networks.vision_towers.common"] = vt
+    import importlib
+
+    lc = importlib.import_module("diffulab.training.losses.common")
+    sys.modules["diffulab.training.losses"].LossFunction = lc.LossFunction
+
+
+install_shims()
+
+from diffulab.diffuse.diffuser import Diffuser  # noqa: E402
+from diffulab.diffuse.modelizations.flow import Flow  # noqa: E402
+from diffulab.diffuse.modelizations.gaussian_diffusion import GaussianDiffusion  # noqa: E402
+from diffulab.diffuse.modelizations.utils import space_timesteps  # noqa: E402
+from diffulab.diffuse.samplers.flow import Euler, EulerMaruyama  # noqa: E402
+from diffulab.diffuse.samplers.gaussian_diffusion import DDIM, DDPM  # noqa: E402
+from diffulab.networks.denoisers.mmdit import DiTBlock, MMDiT  # noqa: E402
+from diffulab.networks.utils.nn import get_cos_sin_ndim_grid, timestep_embedding  # noqa: E402
+
+from oracle import synth  # noqa: E402
+from oracle.dit import DiTConfig, param_shapes  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def save(name: str, **arrs) -> None:
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB, {len(out)} arrays)")
+
+
+# ------------------------------------------------------------------ (i)+(ii) schedules and draws
+def gen_schedules() -> None:
+    o: dict[str, object] = {}
+    for n in (4, 50, 100):
+        o[f"flow_ts_n{n}"] = np.array(Flow(n_steps=n).timesteps, dtype=np.float64)
+        for sh in (4.63, 6.93):
+            f = Flow(n_steps=n, shift=sh)
+            # quirk: Diffusion.__init__ calls set_steps(n, schedule) BEFORE Flow.__init__ stores `shift`
+            # (flow.py:72-81 vs :118), so a constructor shift never reaches `timesteps`; only set_steps(shift=) does.
+            o[f"flow_ts_ctor_n{n}_shift{sh}"] = np.array(f.timesteps, dtype=np.float64)
+            f.set_steps(n, shift=sh)
+            o[f"flow_ts_n{n}_shift{sh}"] = np.array(f.timesteps, dtype=np.float64)
+    for seed in (0, 1, 2):
+        for B in (4, 64):
+            for tag, kw in (("uniform", {}), ("logit", {"logits_normal": True}),
+                            ("logit_shift", {"logits_normal": True, "shift": 4.63}),
+                            ("xpred", {"prediction_type": "x"})):
+                torch.manual_seed(seed)
+                o[f"draw_flow_{tag}_s{seed}_b{B}"] = Flow(n_steps=10, **kw).draw_timesteps(B)
+            torch.manual_seed(seed)
+            o[f"draw_ddpm_s{seed}_b{B}"] = GaussianDiffusion(n_steps=1000).draw_timesteps(B)
+    for sched in ("linear", "cosine"):
+        g = GaussianDiffusion(n_steps=1000, schedule=sched)
+        s = g.sampler
+        for nm in ("betas", "alphas_bar", "sqrt_alphas_bar"):
+            o[f"gd_{sched}_{nm}"] = getattr(g, nm)
+        for nm in ("alphas_bar_prev", "posterior_variance", "posterior_log_variance_clipped",
+                   "posterior_mean_coef1", "posterior_mean_coef2"):
+            o[f"gd_{sched}_{nm}"] = getattr(s, nm)
+    for n in (50, 100, 250):
+        g = GaussianDiffusion(n_steps=1000)
+        g.set_steps(n)
+        o[f"respace_{n}_betas"] = g.betas
+        o[f"respace_{n}_map"] = np.array(g.timestep_map, dtype=np.int64)
+        o[f"respace_{n}_postvar"] = g.sampler.posterior_variance
+    g = GaussianDiffusion(n_steps=1000)
+    g.set_steps(30, section_counts="10,10,10")
+    o["respace_sections_map"] = np.array(g.timestep_map, dtype=np.int64)
+    o["space_1000_10"] = np.array(sorted(space_timesteps(1000, 10)), dtype=np.int64)
+    try:
+        space_timesteps(1000, 10, ddim=True)
+        o["space_ddim_raises"] = np.array(0)
+    except ValueError:
+        o["space_ddim_raises"] = np.array(1)
+    o["space_ddim_full"] = np.array(sorted(space_timesteps(1000, 1000, ddim=True)), dtype=np.int64)
+    save("schedules", **o)
+
+
+# ------------------------------------------------------------------ (iii) embeddings / rope
+def gen_prims() -> None:
+    t = synth.uniform("prims.t", (8,), lo=0.0, hi=1.0)
+    ti = torch.tensor([0, 1, 17, 500, 999], dtype=torch.int32)
+    pos = torch.stack(torch.meshgrid([torch.arange(16), torch.arange(16)], indexing="ij"), dim=-1).view(-1, 2)[None]
+    cos, sin = get_cos_sin_ndim_grid(pos, base=10_000, axes_dim=[32, 32])
+    pos2 = torch.stack(torch.meshgrid([torch.arange(3), torch.arange(5)], indexing="ij"), dim=-1).view(-1, 2)[None]
+    cos2, sin2 = get_cos_sin_ndim_grid(pos2, base=2000, axes_dim=[8, 24])
+    save("prims", temb_f=timestep_embedding(t, 256), temb_i=timestep_embedding(ti, 128), temb_odd=timestep_embedding(t, 9),
+         rope_cos_16x16=cos[0], rope_sin_16x16=sin[0], rope_cos_3x5=cos2[0], rope_sin_3x5=sin2[0])
+
+
+# ------------------------------------------------------------------ (iv)+(v) DiT block / model
+SMALL = DiTConfig(input_channels=4, output_channels=4, inner_dim=128, embedding_dim=64, num_heads=2, mlp_ratio=4,
+                  patch_size=2, depth=2, n_classes=10, classifier_free=True)
+S2 = DiTConfig()  # DiT-S/2 measurement config
+
+
+def build_ref(cfg: DiTConfig, seed: int) -> MMDiT:
+    m = MMDiT(simple_dit=True, input_channels=cfg.input_channels, output_channels=cfg.output_channels,
+              inner_dim=cfg.inner_dim, embedding_dim=cfg.embedding_dim, num_heads=cfg.num_heads,
+              mlp_ratio=cfg.mlp_ratio, patch_size=cfg.patch_size, depth=cfg.depth, n_classes=cfg.n_classes,
+              classifier_free=cfg.classifier_free)
+    P = synth.dit_params(param_shapes(cfg), seed=seed)
+    sd = m.state_dict()
+    assert set(sd) == set(P), (set(sd) ^ set(P))
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(P[k].shape), k
+    m.load_state_dict(P)
+    return m
+
+
+def gen_block() -> None:
+    cfg = SMALL
+    m = build_ref(cfg, seed=3)
+    blk: DiTBlock = m.layers[1]
+    B, gh, gw = 2, 4, 4
+    x = synth.normal("blk.x", (B, gh * gw, cfg.inner_dim)).requires_grad_(True)
+    emb = synth.normal("blk.emb", (B, cfg.embedding_dim)).requires_grad_(True)
+    pos = torch.stack(torch.meshgrid([torch.arange(gh), torch.arange(gw)], indexing="ij"), dim=-1).view(-1, 2)[None]
+    cs = get_cos_sin_ndim_grid(pos.repeat(B, 1, 1), base=cfg.rope_base, axes_dim=cfg.rope_axes_dim)
+    taps = {}
+    hooks = [blk.attention.register_forward_hook(lambda mod, i, o: taps.__setitem__("attn_proj", o)),
+             blk.norm_1.register_forward_hook(lambda mod, i, o: taps.__setitem__("norm1", o)),
+             blk.mlp_input[1].register_forward_hook(lambda mod, i, o: taps.__setitem__("mlp_hidden", o))]
+    y = blk(x, emb, cs)
+    w = synth.normal("blk.dy", tuple(y.shape))
+    (y * w).sum().backward()
+    for h in hooks:
+        h.remove()
+    o = {"y": y, "dx": x.grad, "demb": emb.grad, **{"tap_" + k: v for k, v in taps.items()}}
+    for n, p in blk.named_parameters():
+        o["g_" + n] = p.grad
+    save("dit_block", **o)
+
+
+def flow_loss_ref(m: MMDiT, x0, t, y, noise, p=0.0):
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=50)
+    return d.compute_loss({"x": x0.clone(), "y": y, "p": p}, timesteps=t, noise=noise)["loss"]
+
+
+def gen_small_model() -> None:
+    cfg = SMALL
+    m = build_ref(cfg, seed=5)
+    B, H = 3, 8
+    x0 = synth.normal("small.x0", (B, cfg.input_channels, H, H))
+    noise = synth.normal("small.noise", (B, cfg.input_channels, H, H))
+    t = synth.uniform("small.t", (B,), lo=0.02, hi=0.98)
+    y = synth.integers("small.y", (B,), cfg.n_classes)
+    # plain forward at z_t (oracle test recomputes z_t itself)
+    z = (1 - t.view(-1, 1, 1, 1)) * x0 + t.view(-1, 1, 1, 1) * noise
+    pred = m(x=z, timesteps=t, y=y, p=0.0)["x"]
+    loss = flow_loss_ref(m, x0, t, y, noise)
+    loss.backward()
+    o = {"pred": pred, "loss": loss}
+    for n, p in m.named_parameters():
+        o["g_" + n] = p.grad
+    # unconditional (all labels dropped, p=1) forward for CFG parity
+    o["pred_uncond"] = m(x=z, timesteps=t, y=y, p=1.0)["x"]
+    # DDPM loss on the same net (timesteps are int32 indices fed unscaled, Appendix C.7)
+    m.zero_grad()
+    gd = Diffuser(m, sampling_method="ddpm", model_type="gaussian_diffusion", n_steps=1000)
+    ti = torch.tensor([3, 500, 999], dtype=torch.int32)
+    l2 = gd.compute_loss({"x": x0.clone(), "y": y, "p": 0.0}, timesteps=ti, noise=noise)["loss"]
+    l2.backward()
+    o["ddpm_loss"] = l2
+    o["ddpm_g_conv_proj.weight"] = m.conv_proj.weight.grad
+    o["ddpm_xt"] = gd.diffusion.add_noise(x0, ti, noise)[0]
+    save("dit_small", **o)
+
+
+def gen_s2_model() -> None:
+    cfg = S2
+    m = build_ref(cfg, seed=7)
+    B = 2
+    x0 = synth.normal("s2.x0", (B, 4, 32, 32))
+    noise = synth.normal("s2.noise", (B, 4, 32, 32))
+    t = synth.uniform("s2.t", (B,), lo=0.05, hi=0.95)
+    y = synth.integers("s2.y", (B,), 1000)
+    z = (1 - t.view(-1, 1, 1, 1)) * x0 + t.view(-1, 1, 1, 1) * noise
+    pred = m(x=z, timesteps=t, y=y, p=0.0)["x"]
+    loss = flow_loss_ref(m, x0, t, y, noise)
+    loss.backward()
+    o = {"pred": pred, "loss": loss}
+    names, norms = [], []
+    for n, p in m.named_parameters():
+        names.append(n)
+        norms.append(p.grad.double().norm().item())
+        if p.grad.numel() <= 4096:
+            o["g_" + n] = p.grad
+        else:
+            o["gs_" + n] = p.grad.flatten()[:: max(1, p.grad.numel() // 512)][:512]  # strided sample
+    o["grad_names"] = np.array(names)
+    o["grad_norms"] = np.array(norms)
+    save("dit_s2", **o)
+
+
+# ------------------------------------------------------------------ (vi) samplers
+def gen_samplers() -> None:
+    o = {}
+    shp = (3, 4, 8, 8)
+    xt, v, nz = synth.normal("smp.xt", shp), synth.normal("smp.v", shp), synth.normal("smp.noise", shp)
+    r = Euler().step(xt, v, 0.75, 0.5)
+    o["euler_x_prev"], o["euler_x0"] = r["x_prev"], r["estimated_x0"]
+    em = EulerMaruyama(eta=0.7)
+    em.set_steps(Flow(n_steps=10).timesteps)
+    torch.manual_seed(11)
+    r = em.step(xt, v, 0.6, 0.5)
+    for k in ("x_prev", "x_prev_mean", "x_prev_std", "estimated_x0", "logprob"):
+        o["em_" + k] = r[k]
+    torch.manual_seed(11)
+    o["em_noise"] = torch.randn_like(xt)
+    r = em.step(xt, v, 1.0, 0.9, x_prev=nz)  # t_curr > tmax branch, given x_prev
+    o["em2_logprob"], o["em2_mean"] = r["logprob"], r["x_prev_mean"]
+    tt = torch.tensor([0, 7, 999], dtype=torch.int32)
+    for mt in ("epsilon", "xstart", "xprev"):
+        for vt in ("fixed_small", "fixed_large"):
+            for clamp in (False, True):
+                s = DDPM(mean_type=mt, var_type=vt)
+                s.set_steps(GaussianDiffusion(n_steps=1000).betas)
+                torch.manual_seed(13)
+                r = s.step(v, tt, xt, clamp_x=clamp)
+                tag = f"ddpm_{mt}_{vt}_{int(clamp)}_"
+                for k in ("x_prev", "estimated_x0", "x_prev_mean", "x_prev_std", "logprob"):
+                    o[tag + k] = r[k]
+    torch.manual_seed(13)
+    o["ddpm_noise"] = torch.randn_like(xt)
+    for eta in (0.0, 0.5):
+        s = DDIM()
+        s.set_steps(GaussianDiffusion(n_steps=1000).betas)
+        torch.manual_seed(17)
+        r = s.step(v, tt, xt, eta=eta)
+        for k in r:
+            o[f"ddim_eta{eta}_{k}"] = r[k]
+    torch.manual_seed(17)
+    o["ddim_noise"] = torch.randn_like(xt)
+    # full sampler loops on the small DiT: 4-step Euler with CFG, 5-step respaced DDPM
+    m = build_ref(SMALL, seed=5).eval()
+    y = synth.integers("smp.y", (2,), SMALL.n_classes)
+    x_init = synth.normal("smp.init", (2, 4, 8, 8))
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=4)
+    out = d.generate({"x": x_init.clone(), "y": y}, use_tqdm=False, guidance_scale=2.0, return_intermediates=True)
+    o["loop_euler_x"], o["loop_euler_xt"], o["loop_euler_x0"] = out["x"], out["xt"], out["estimated_x0"]
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=3, extra_args={"shift": 4.63})
+    d.set_steps(3, shift=4.63)
+    o["loop_euler_shift_x"] = d.generate({"x": x_init.clone(), "y": y}, use_tqdm=False)["x"]
+    g = Diffuser(m, sampling_method="ddpm", model_type="gaussian_diffusion", n_steps=1000)
+    g.set_steps(5)
+    torch.manual_seed(19)
+    with torch.no_grad():
+        out = g.generate({"x": x_init.clone(), "y": y}, use_tqdm=False, guidance_scale=1.5, clamp_x=True)
+    o["loop_ddpm_x"] = out["x"]
+    # replay the global-generator stream of that loop: per step the p=1 forward draws rand(B) for the label
+    # drop (nn.py:149) BEFORE DDPM.step draws randn_like (ddpm.py:302)
+    torch.manual_seed(19)
+    nz = []
+    for _ in range(5):
+        torch.rand(2)
+        nz.append(torch.randn(2, 4, 8, 8))
+    o["loop_ddpm_noise"] = torch.stack(nz)
+    save("samplers", **o)
+
+
+# ------------------------------------------------------------------ (viii) loss curve, DiT-S/2 + AdamW
+def gen_loss_curve() -> None:
+    cfg = S2
+    m = build_ref(cfg, seed=7)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8)
+    B, steps = 4, 12
+    x0 = synth.normal("curve.x0", (B, 4, 32, 32))
+    y = synth.integers("curve.y", (B,), 1000)
+    losses = []
+    for s in range(steps):
+        noise = synth.normal(f"curve.noise{s}", (B, 4, 32, 32))
+        t = synth.uniform(f"curve.t{s}", (B,), lo=0.02, hi=0.98)
+        opt.zero_grad()
+        loss = flow_loss_ref(m, x0, t, y, noise)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+        print(f"  step {s}: {loss.item():.6f}")
+    save("loss_curve", losses=np.array(losses, dtype=np.float64),
+         final_qkv0=m.layers[0].attention.qkv.weight.detach().flatten()[::577][:256])
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "s2", "samplers", "curve"]
+    fns = {"schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model,
+           "s2": gen_s2_model, "samplers": gen_samplers, "curve": gen_loss_curve}
+    for w in which:
+        print("==", w)
+        fns[w]()

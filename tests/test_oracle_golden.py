@@ -1,0 +1,295 @@
+"""Pin the CPU oracle against every golden vector generated from the real reference
+(tests/golden/make_golden.py).  CPU only; this is what lets the GPU parity tests trust the oracle.
+
+Tolerances: integer / index data bit-exact; fp64 tables bit-exact (same torch ops in the same order);
+fp32 tensors <= 2e-6 relative-L2 (different-but-equivalent op order, e.g. explicit softmax vs SDPA).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffusion as od
+from oracle import dit as odit
+from oracle import synth
+
+SMALL = odit.DiTConfig(input_channels=4, output_channels=4, inner_dim=128, embedding_dim=64, num_heads=2,
+                       mlp_ratio=4, patch_size=2, depth=2, n_classes=10, classifier_free=True)
+S2 = odit.DiTConfig()
+
+
+def rel(a, b):
+    a = (a.detach() if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))).double()
+    b = (b.detach() if isinstance(b, torch.Tensor) else torch.as_tensor(np.asarray(b))).double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def t2n(x):
+    return x.detach().numpy()
+
+
+# ------------------------------------------------------------------ schedules / draws (bit-exact)
+def test_flow_timesteps(golden):
+    g = golden("schedules")
+    for n in (4, 50, 100):
+        assert np.array_equal(np.array(od.flow_timesteps(n)), g[f"flow_ts_n{n}"])
+        for sh in (4.63, 6.93):
+            assert np.array_equal(np.array(od.flow_timesteps(n, sh)), g[f"flow_ts_n{n}_shift{sh}"])
+            # constructor-time shift never reaches the sampling grid in the reference (flow.py:72-81 vs :118)
+            assert np.array_equal(np.array(od.flow_timesteps(n)), g[f"flow_ts_ctor_n{n}_shift{sh}"])
+
+
+def test_known_answers_survey_appendix_b():
+    assert od.flow_timesteps(4) == [1.0, 0.75, 0.5, 0.25, 0.0]
+    assert od.flow_timesteps(4, 4.63) == [1.0, 0.9328408327736736, 0.822380106571936, 0.6068152031454783, 0.0]
+    torch.manual_seed(0)
+    assert od.flow_draw_timesteps(4).tolist() == [0.49625658988952637, 0.7682217955589294, 0.08847743272781372,
+                                                  0.13203048706054688]
+    torch.manual_seed(0)
+    assert od.ddpm_draw_timesteps(4, 1000).tolist() == [44, 239, 933, 760]
+    T = od.GaussianTables()
+    assert T.alphas_bar[-1].item() == 4.0358297653756754e-05
+    assert T.posterior_variance[1].item() == 5.4531876613021935e-05
+    assert T.posterior_log_variance_clipped[0].item() == -9.81672513529567
+    assert sorted(od.space_timesteps(1000, 10))[:3] == [0, 111, 222]
+    e = odit.timestep_embedding(torch.tensor([0.5]), 8)[0]
+    assert np.allclose(e.numpy(), [0.87758255, 0.99875027, 0.9999875, 0.99999988, 0.47942555, 0.04997917,
+                                   0.00499998, 0.0005], atol=1e-7)
+
+
+def test_draw_timesteps_bit_exact(golden):
+    g = golden("schedules")
+    for seed in (0, 1, 2):
+        for B in (4, 64):
+            for tag, kw in (("uniform", {}), ("logit", {"logits_normal": True}),
+                            ("logit_shift", {"logits_normal": True, "shift": 4.63}), ("xpred", {"x_prediction": True})):
+                torch.manual_seed(seed)
+                assert np.array_equal(t2n(od.flow_draw_timesteps(B, **kw)), g[f"draw_flow_{tag}_s{seed}_b{B}"]), tag
+            torch.manual_seed(seed)
+            got = od.ddpm_draw_timesteps(B, 1000)
+            assert got.dtype == torch.int32 and np.array_equal(t2n(got), g[f"draw_ddpm_s{seed}_b{B}"])
+
+
+def test_gaussian_tables_bit_exact(golden):
+    g = golden("schedules")
+    for sched in ("linear", "cosine"):
+        T = od.GaussianTables(1000, schedule=sched)
+        for nm in ("betas", "alphas_bar", "sqrt_alphas_bar", "alphas_bar_prev", "posterior_variance",
+                   "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"):
+            assert np.array_equal(t2n(getattr(T, nm)), g[f"gd_{sched}_{nm}"]), (sched, nm)
+
+
+def test_respacing_bit_exact(golden):
+    g = golden("schedules")
+    for n in (50, 100, 250):
+        T = od.GaussianTables(1000, n_steps=n)
+        assert np.array_equal(np.array(T.timestep_map), g[f"respace_{n}_map"])
+        assert np.array_equal(t2n(T.betas), g[f"respace_{n}_betas"])
+        assert np.array_equal(t2n(T.posterior_variance), g[f"respace_{n}_postvar"])
+    T = od.GaussianTables(1000, n_steps=30, section_counts="10,10,10")
+    assert np.array_equal(np.array(T.timestep_map), g["respace_sections_map"])
+    assert np.array_equal(np.array(sorted(od.space_timesteps(1000, 10))), g["space_1000_10"])
+    assert int(g["space_ddim_raises"]) == 1
+    with pytest.raises(ValueError):
+        od.space_timesteps(1000, 10, ddim=True)
+    assert np.array_equal(np.array(sorted(od.space_timesteps(1000, 1000, ddim=True))), g["space_ddim_full"])
+
+
+# ------------------------------------------------------------------ primitives
+def test_embeddings_and_rope(golden):
+    g = golden("prims")
+    t = synth.uniform("prims.t", (8,), lo=0.0, hi=1.0)
+    ti = torch.tensor([0, 1, 17, 500, 999], dtype=torch.int32)
+    assert np.array_equal(t2n(odit.timestep_embedding(t, 256)), g["temb_f"])
+    assert np.array_equal(t2n(odit.timestep_embedding(ti, 128)), g["temb_i"])
+    assert np.array_equal(t2n(odit.timestep_embedding(t, 9)), g["temb_odd"])
+    c, s = odit.rope_tables(16, 16, [32, 32], 10_000)
+    assert np.array_equal(t2n(c), g["rope_cos_16x16"]) and np.array_equal(t2n(s), g["rope_sin_16x16"])
+    c, s = odit.rope_tables(3, 5, [8, 24], 2000)
+    assert np.array_equal(t2n(c), g["rope_cos_3x5"]) and np.array_equal(t2n(s), g["rope_sin_3x5"])
+
+
+# ------------------------------------------------------------------ DiT block fwd+bwd
+def test_dit_block_fwd_bwd(golden):
+    g = golden("dit_block")
+    cfg = SMALL
+    P = {k: v.requires_grad_(True) for k, v in synth.dit_params(odit.param_shapes(cfg), seed=3).items()}
+    B, gh, gw = 2, 4, 4
+    x = synth.normal("blk.x", (B, gh * gw, cfg.inner_dim)).requires_grad_(True)
+    emb = synth.normal("blk.emb", (B, cfg.embedding_dim)).requires_grad_(True)
+    cos, sin = odit.rope_tables(gh, gw, cfg.rope_axes_dim, cfg.rope_base)
+    taps = {}
+    y = odit.dit_block(P, "layers.1.", x, emb, cos, sin, cfg, taps)
+    (y * synth.normal("blk.dy", tuple(y.shape))).sum().backward()
+    assert rel(y, g["y"]) < 2e-6
+    assert rel(taps["attn_proj"], g["tap_attn_proj"]) < 2e-6
+    assert rel(taps["mlp_hidden"], g["tap_mlp_hidden"]) < 2e-6
+    assert rel(x.grad, g["dx"]) < 2e-6 and rel(emb.grad, g["demb"]) < 2e-6
+    for k in g:
+        if k.startswith("g_"):
+            assert rel(P["layers.1." + k[2:]].grad, g[k]) < 3e-6, k
+
+
+# ------------------------------------------------------------------ full models
+def _flow_loss(P, cfg, x0, t, y, noise):
+    z = od.flow_add_noise(x0, t, noise)
+    pred = odit.dit_forward(P, z, t, y, cfg)
+    return pred, od.flow_loss(pred, x0, noise)
+
+
+def test_small_model_flow_and_ddpm(golden):
+    g = golden("dit_small")
+    cfg = SMALL
+    P = {k: v.requires_grad_(True) for k, v in synth.dit_params(odit.param_shapes(cfg), seed=5).items()}
+    B, H = 3, 8
+    x0 = synth.normal("small.x0", (B, 4, H, H))
+    noise = synth.normal("small.noise", (B, 4, H, H))
+    t = synth.uniform("small.t", (B,), lo=0.02, hi=0.98)
+    y = synth.integers("small.y", (B,), cfg.n_classes)
+    pred, loss = _flow_loss(P, cfg, x0, t, y, noise)
+    loss.backward()
+    assert rel(pred, g["pred"]) < 2e-6
+    assert abs(loss.item() - float(g["loss"])) / float(g["loss"]) < 1e-6
+    for k in g:
+        if k.startswith("g_"):
+            assert rel(P[k[2:]].grad, g[k]) < 5e-6, k
+    # all labels dropped == p=1 in the reference (Appendix C.12)
+    y_un = odit.drop_labels(y, 1.0, cfg.n_classes)
+    assert (y_un == cfg.n_classes).all()
+    with torch.no_grad():
+        pu = odit.dit_forward(P, od.flow_add_noise(x0, t, noise), t, y_un, cfg)
+    assert rel(pu, g["pred_uncond"]) < 2e-6
+    # DDPM head: int32 indices fed unscaled to the timestep embedding
+    for p in P.values():
+        p.grad = None
+    T = od.GaussianTables(1000)
+    ti = torch.tensor([3, 500, 999], dtype=torch.int32)
+    xt = od.ddpm_add_noise(T, x0, ti, noise)
+    assert rel(xt, g["ddpm_xt"]) < 1e-7
+    l2 = od.mse_loss(odit.dit_forward(P, xt, ti, y, cfg), noise)
+    l2.backward()
+    assert abs(l2.item() - float(g["ddpm_loss"])) / float(g["ddpm_loss"]) < 1e-6
+    assert rel(P["conv_proj.weight"].grad, g["ddpm_g_conv_proj.weight"]) < 5e-6
+
+
+@pytest.mark.timeout(600)
+def test_dit_s2_fwd_bwd(golden):
+    g = golden("dit_s2")
+    cfg = S2
+    P = {k: v.requires_grad_(True) for k, v in synth.dit_params(odit.param_shapes(cfg), seed=7).items()}
+    assert sum(v.numel() for v in P.values()) == 39_922_576
+    B = 2
+    x0 = synth.normal("s2.x0", (B, 4, 32, 32))
+    noise = synth.normal("s2.noise", (B, 4, 32, 32))
+    t = synth.uniform("s2.t", (B,), lo=0.05, hi=0.95)
+    y = synth.integers("s2.y", (B,), 1000)
+    pred, loss = _flow_loss(P, cfg, x0, t, y, noise)
+    loss.backward()
+    assert rel(pred, g["pred"]) < 5e-6
+    assert abs(loss.item() - float(g["loss"])) / float(g["loss"]) < 1e-6
+    norms = dict(zip(g["grad_names"].tolist(), g["grad_norms"].tolist()))
+    for n, ref in norms.items():
+        got = P[n].grad.double().norm().item()
+        assert abs(got - ref) <= 2e-5 * max(ref, 1e-12), (n, got, ref)
+    for k in g:
+        if k.startswith("g_"):
+            assert rel(P[k[2:]].grad, g[k]) < 2e-5, k
+        elif k.startswith("gs_"):
+            gr = P[k[3:]].grad
+            assert rel(gr.flatten()[:: max(1, gr.numel() // 512)][:512], g[k]) < 2e-5, k
+
+
+# ------------------------------------------------------------------ samplers
+def test_sampler_steps(golden):
+    g = golden("samplers")
+    shp = (3, 4, 8, 8)
+    xt, v, nz = synth.normal("smp.xt", shp), synth.normal("smp.v", shp), synth.normal("smp.noise", shp)
+    r = od.euler_step(xt, v, 0.75, 0.5)
+    assert np.array_equal(t2n(r["x_prev"]), g["euler_x_prev"]) and np.array_equal(t2n(r["estimated_x0"]), g["euler_x0"])
+    tmax = od.flow_timesteps(10)[1]
+    r = od.euler_maruyama_step(xt, v, 0.6, 0.5, tmax, 0.7, noise=torch.from_numpy(g["em_noise"]))
+    for k in ("x_prev", "x_prev_mean", "x_prev_std", "estimated_x0", "logprob"):
+        assert rel(r[k], g["em_" + k]) < 1e-6, k
+    r = od.euler_maruyama_step(xt, v, 1.0, 0.9, tmax, 0.7, x_prev=nz)
+    assert rel(r["logprob"], g["em2_logprob"]) < 1e-6 and rel(r["x_prev_mean"], g["em2_mean"]) < 1e-6
+    T = od.GaussianTables(1000)
+    tt = torch.tensor([0, 7, 999], dtype=torch.int32)
+    dn = torch.from_numpy(g["ddpm_noise"])
+    for mt in ("epsilon", "xstart", "xprev"):
+        for vt in ("fixed_small", "fixed_large"):
+            for clamp in (False, True):
+                r = od.ddpm_step(T, v, tt, xt, dn, mt, vt, clamp)
+                tag = f"ddpm_{mt}_{vt}_{int(clamp)}_"
+                for k in ("x_prev", "estimated_x0", "x_prev_mean", "x_prev_std", "logprob"):
+                    assert rel(r[k], g[tag + k]) < 1e-6, tag + k
+    for eta in (0.0, 0.5):
+        r = od.ddim_step(T, v, tt, xt, torch.from_numpy(g["ddim_noise"]), eta)
+        keys = [k[len(f"ddim_eta{eta}_"):] for k in g if k.startswith(f"ddim_eta{eta}_")]
+        assert set(keys) == set(r.keys())
+        for k in keys:
+            a, b = r[k], g[f"ddim_eta{eta}_{k}"]
+            if k == "logprob":  # contains -inf/nan rows at t==0 where sigma==0 in the reference too
+                a, b = torch.nan_to_num(a, 0, 0, 0), np.nan_to_num(b, nan=0, posinf=0, neginf=0)
+            assert rel(a, b) < 1e-6, (eta, k)
+
+
+def test_sampler_loops(golden):
+    g = golden("samplers")
+    cfg = SMALL
+    P = synth.dit_params(odit.param_shapes(cfg), seed=5)
+    y = synth.integers("smp.y", (2,), cfg.n_classes)
+    x = synth.normal("smp.init", (2, 4, 8, 8))
+    y_un = torch.full_like(y, cfg.n_classes)
+
+    def vel(x, t, yy):
+        tt = torch.full((x.shape[0],), t, dtype=torch.float32)
+        return odit.dit_forward(P, x, tt, yy, cfg)
+
+    with torch.no_grad():
+        ts = od.flow_timesteps(4)
+        xs, x0s, xc = [x], [], x
+        for tc, tp in zip(ts[:-1], ts[1:]):
+            vv = od.cfg_combine(vel(xc, tc, y), vel(xc, tc, y_un), 2.0)
+            r = od.euler_step(xc, vv, tc, tp)
+            xc = r["x_prev"]
+            xs.append(xc)
+            x0s.append(r["estimated_x0"])
+        assert rel(xc, g["loop_euler_x"]) < 5e-6
+        assert rel(torch.stack(xs, 1), g["loop_euler_xt"]) < 5e-6
+        assert rel(torch.stack(x0s, 1), g["loop_euler_x0"]) < 5e-6
+        ts = od.flow_timesteps(3, 4.63)
+        xc = x
+        for tc, tp in zip(ts[:-1], ts[1:]):
+            xc = od.euler_step(xc, vel(xc, tc, y), tc, tp)["x_prev"]
+        assert rel(xc, g["loop_euler_shift_x"]) < 5e-6
+        # respaced DDPM, CFG 1.5, clamp
+        T = od.GaussianTables(1000, n_steps=5)
+        tmap = torch.tensor(T.timestep_map, dtype=torch.int32)
+        nz = torch.from_numpy(g["loop_ddpm_noise"])
+        xc = x
+        for i, t in enumerate(reversed(range(5))):
+            ti = torch.full((2,), t, dtype=torch.int32)
+            tm = tmap[ti.long()]
+            e = od.cfg_combine(odit.dit_forward(P, xc, tm, y, cfg), odit.dit_forward(P, xc, tm, y_un, cfg), 1.5)
+            xc = od.ddpm_step(T, e, ti, xc, nz[i], clamp_x=True)["x_prev"]
+        assert rel(xc, g["loop_ddpm_x"]) < 1e-5
+
+
+# ------------------------------------------------------------------ loss curve (AdamW, DiT-S/2)
+@pytest.mark.timeout(900)
+def test_loss_curve_first_steps(golden):
+    g = golden("loss_curve")
+    cfg = S2
+    P = {k: v.requires_grad_(True) for k, v in synth.dit_params(odit.param_shapes(cfg), seed=7).items()}
+    opt = torch.optim.AdamW(list(P.values()), lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8)
+    B = 4
+    x0 = synth.normal("curve.x0", (B, 4, 32, 32))
+    y = synth.integers("curve.y", (B,), 1000)
+    for s in range(3):  # 3 of the 12 stored steps keep the CPU suite short; the GPU test walks all of them
+        noise = synth.normal(f"curve.noise{s}", (B, 4, 32, 32))
+        t = synth.uniform(f"curve.t{s}", (B,), lo=0.02, hi=0.98)
+        opt.zero_grad()
+        _, loss = _flow_loss(P, cfg, x0, t, y, noise)
+        loss.backward()
+        opt.step()
+        assert abs(loss.item() - g["losses"][s]) / g["losses"][s] < 2e-5, s
