@@ -1,0 +1,351 @@
+// Multi-head self-attention for DiT token grids (gfx950): softmax(q k^T * scale) v, head_dim 64, no mask.
+//
+// One workgroup per (batch, head).  N <= 512 tokens, so the whole K and V of a head (N x 64 bf16 = 32 KiB each
+// at N = 256) are DMA'd once into LDS (global_load_lds_dwordx4, bank swizzle applied on the source address)
+// and stay resident; every wave owns a 32-row block.  All matmuls are MFMA 32x32x16 bf16 computed in the
+// TRANSPOSED orientation (S^T = K Q^T, O^T = V^T P^T ...): the 32x32 accumulator then holds, per lane, one
+// query column and 16 keys, so (a) softmax row statistics are in-register + one cross-half shuffle and
+// (b) the exponentiated tile is ALREADY in the B-operand register layout of the next MFMA (k-slot j of lane
+// half hi <-> key (j&3) + 8(j>>2) + 4hi), i.e. P never round-trips through LDS.  The matching A operands
+// (V^T, K^T, Q^T, dO^T) come from the row-major LDS tiles through ds_read_b64_tr_b16 transposing reads.
+//
+// Backward (FlashAttention-2 style recompute from lse) runs two phases over the same resident tiles:
+//   A: wave owns 32 queries, sweeps key blocks  -> dQ
+//   B: wave owns 32 keys,    sweeps query blocks -> dK, dV
+// S and dP are recomputed in both phases (7 instead of 5 matmuls) which removes every cross-wave reduction.
+#include "common.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+#define DH 64
+#define ROWB 128  // bytes per LDS tile row (64 bf16)
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+
+// 16-byte-slot swizzle of a [rows][64 bf16] tile: conflict-free for ds_read_b128 by 16 consecutive rows
+// (bijection of (row>>1)&7) AND for ds_read_b64_tr_b16 blocks of 4 consecutive rows (bit 2 separates rows r, r+2).
+__device__ __forceinline__ int swz8(int row) {
+  const int v = (row >> 1) & 7;
+  return ((v & 1) << 2) | (v >> 1);
+}
+__device__ __forceinline__ int tile_off(int row, int slot) { return row * ROWB + ((slot ^ swz8(row)) << 4); }
+
+// DMA rows [0, nrows) of a row-major [nrows][64] bf16 matrix (row pitch `pitch` elements) into an LDS tile.
+__device__ __forceinline__ void tile_dma(const bf16_t* __restrict__ g, int64_t pitch, char* tile, int nrows, int wave,
+                                         int nwaves, int lane) {
+  const int nchunk = nrows >> 3;  // 8 rows = 1 KiB per wave-instruction
+  for (int c = wave; c < nchunk; c += nwaves) {
+    const int r = c * 8 + (lane >> 3);
+    const int q = (lane & 7) ^ swz8(r);
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(g + (int64_t)r * pitch + q * 8), (lds_void_t*)(tile + c * 1024), 16, 0, 0);
+  }
+}
+
+// A/B fragment with k = head-dim: row `row` of the tile, k-slots 16*ks + 8*hi .. +7
+__device__ __forceinline__ bf16x8_t frag_rows(const char* tile, int row, int ks, int hi) {
+  return *(const bf16x8_t*)(tile + tile_off(row, ks * 2 + hi));
+}
+// A fragment with k = tile rows (transposing read): output row i = head-dim column colbase + (lane&31),
+// k-slot j of half hi <-> tile row rbase + (j&3) + 8*(j>>2) + 4*hi
+__device__ __forceinline__ bf16x8_t frag_cols(const char* tile, int rbase, int colbase, int lane) {
+  const int li = lane & 15, g = lane >> 4;
+  const int col = colbase + (g & 1) * 16 + (li & 3) * 4;
+  const int r0 = rbase + (g >> 1) * 4 + (li >> 2);
+  union {
+    s16x4_t h[2];
+    bf16x8_t v;
+  } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4_t*)(tile + r0 * ROWB + (((col >> 3) ^ swz8(r0)) << 4) + (col & 7) * 2));
+  const int r1 = r0 + 8;
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4_t*)(tile + r1 * ROWB + (((col >> 3) ^ swz8(r1)) << 4) + (col & 7) * 2));
+  return u.v;
+}
+__device__ __forceinline__ bf16x8_t pack_frag(const float* p) {
+  union {
+    u32x4_t u;
+    bf16x8_t v;
+  } r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.u[i] = pack2bf(p[2 * i], p[2 * i + 1]);
+  return r.v;
+}
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+// ====================================================================================== forward
+__global__ __launch_bounds__(512) void attn_fwd_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                  const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
+                                                  float* __restrict__ lse, int H, int N, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* kt = smem;
+  char* vt = smem + N * ROWB;
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const bf16_t* qg = q + (int64_t)bh * N * DH;
+  const bf16_t* kg = k + (int64_t)bh * N * DH;
+  const bf16_t* vg = v + (int64_t)bh * N * DH;
+  tile_dma(kg, DH, kt, N, wave, nwaves, lane);
+  tile_dma(vg, DH, vt, N, wave, nwaves, lane);
+
+  const int q0 = wave * 32;
+  bf16x8_t qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qg + (int64_t)(q0 + (lane & 31)) * DH + ks * 16 + hi * 8);
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float c = scale * LOG2E;
+  f32x16_t o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[0][r] = o[1][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int kb = 0; kb < N; kb += 64) {
+    f32x16_t s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s[t] = MFMA(frag_rows(kt, kb + t * 32 + (lane & 31), ks, hi), qf[ks], s[t]);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[t][r] *= c;
+        mx = fmaxf(mx, s[t][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    float ps = 0.f;
+    float p[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[t][r] = exp2f(s[t][r] - m_new);
+        ps += p[t][r];
+      }
+    l_run = l_run * alpha + ps;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o[0][r] *= alpha;
+      o[1][r] *= alpha;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kg2 = 0; kg2 < 2; ++kg2) {
+        const bf16x8_t pf = pack_frag(&p[t][kg2 * 8]);
+        const int rbase = kb + t * 32 + kg2 * 16;
+        o[0] = MFMA(frag_cols(vt, rbase, 0, lane), pf, o[0]);
+        o[1] = MFMA(frag_cols(vt, rbase, 32, lane), pf, o[1]);
+      }
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qrow = q0 + (lane & 31);
+  bf16_t* op = out + ((int64_t)b * N + qrow) * (H * DH) + h * DH;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      u32x2_t w;
+      w[0] = pack2bf(o[dt][g4 * 4 + 0] * inv, o[dt][g4 * 4 + 1] * inv);
+      w[1] = pack2bf(o[dt][g4 * 4 + 2] * inv, o[dt][g4 * 4 + 3] * inv);
+      *(u32x2_t*)(op + dt * 32 + g4 * 8 + hi * 4) = w;
+    }
+  if (hi == 0) lse[(int64_t)bh * N + qrow] = (m_run + log2f(l_tot)) * LN2;
+}
+
+extern "C" int dl_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int64_t B, int64_t H,
+                           int64_t N, int64_t dh, float scale, dl_stream_t stream) {
+  DL_CHECK_ARG(q && k && v && out && lse && B > 0 && H > 0, "dl_attn_fwd: null operand");
+  DL_CHECK_ARG(dh == DH, "dl_attn_fwd: head_dim %lld unsupported (64 only)", (long long)dh);
+  DL_CHECK_ARG(N % 64 == 0 && N >= 64 && N <= 512, "dl_attn_fwd: N=%lld must be a multiple of 64 in [64, 512]", (long long)N);
+  const int lds = (int)(2 * N * ROWB);
+  (void)hipFuncSetAttribute((const void*)attn_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(attn_fwd_k, (int)(B * H), (int)(N / 32) * 64, lds, (hipStream_t)stream, (const bf16_t*)q,
+                     (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, lse, (int)H, (int)N, scale);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ====================================================================================== backward
+__global__ __launch_bounds__(512) void attn_bwd_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                  const bf16_t* __restrict__ v, const bf16_t* __restrict__ out,
+                                                  const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                  bf16_t* __restrict__ dq, bf16_t* __restrict__ dk,
+                                                  bf16_t* __restrict__ dv, int H, int N, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* qt = smem;
+  char* kt = qt + N * ROWB;
+  char* vt = kt + N * ROWB;
+  char* dot = vt + N * ROWB;
+  float* lse2 = (float*)(dot + N * ROWB);  // lse * log2(e)
+  float* delta = lse2 + N;                 // rowsum(dO * O)
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int64_t hoff = (int64_t)bh * N * DH;
+  const int64_t tok_pitch = (int64_t)H * DH;
+  const bf16_t* og = out + (int64_t)b * N * tok_pitch + h * DH;
+  const bf16_t* dog = dout + (int64_t)b * N * tok_pitch + h * DH;
+  tile_dma(q + hoff, DH, qt, N, wave, nwaves, lane);
+  tile_dma(k + hoff, DH, kt, N, wave, nwaves, lane);
+  tile_dma(v + hoff, DH, vt, N, wave, nwaves, lane);
+  tile_dma(dog, tok_pitch, dot, N, wave, nwaves, lane);
+  // delta and lse2: two threads per row, 32 head-dim columns each
+  for (int row = threadIdx.x >> 1; row < N; row += blockDim.x >> 1) {
+    const int half = threadIdx.x & 1;
+    const bf16_t* po = og + (int64_t)row * tok_pitch + half * 32;
+    const bf16_t* pd = dog + (int64_t)row * tok_pitch + half * 32;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a[8], d[8];
+      unpack8(*(const u32x4_t*)(po + i * 8), a);
+      unpack8(*(const u32x4_t*)(pd + i * 8), d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += a[e] * d[e];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    if (half == 0) {
+      delta[row] = acc;
+      lse2[row] = lse[(int64_t)bh * N + row] * LOG2E;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float c = scale * LOG2E;
+  const int own = wave * 32;  // phase A: first query row; phase B: first key row
+
+  // ------------------------------------------------------------------ phase A: dQ for queries own..own+31
+  {
+    bf16x8_t qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = frag_rows(qt, own + (lane & 31), ks, hi);
+      dof[ks] = frag_rows(dot, own + (lane & 31), ks, hi);
+    }
+    const float my_lse = lse2[own + (lane & 31)], my_delta = delta[own + (lane & 31)];
+    f32x16_t dqa[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqa[0][r] = dqa[1][r] = 0.f;
+    for (int kb = 0; kb < N; kb += 32) {
+      f32x16_t st, dpt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = dpt[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        st = MFMA(frag_rows(kt, kb + (lane & 31), ks, hi), qf[ks], st);
+        dpt = MFMA(frag_rows(vt, kb + (lane & 31), ks, hi), dof[ks], dpt);
+      }
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = exp2f(st[r] * c - my_lse);
+        ds[r] = p * (dpt[r] - my_delta);
+      }
+#pragma unroll
+      for (int kg2 = 0; kg2 < 2; ++kg2) {
+        const bf16x8_t df = pack_frag(&ds[kg2 * 8]);
+        dqa[0] = MFMA(frag_cols(kt, kb + kg2 * 16, 0, lane), df, dqa[0]);
+        dqa[1] = MFMA(frag_cols(kt, kb + kg2 * 16, 32, lane), df, dqa[1]);
+      }
+    }
+    bf16_t* dqp = dq + hoff + (int64_t)(own + (lane & 31)) * DH;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        u32x2_t w;
+        w[0] = pack2bf(dqa[dt][g4 * 4 + 0] * scale, dqa[dt][g4 * 4 + 1] * scale);
+        w[1] = pack2bf(dqa[dt][g4 * 4 + 2] * scale, dqa[dt][g4 * 4 + 3] * scale);
+        *(u32x2_t*)(dqp + dt * 32 + g4 * 8 + hi * 4) = w;
+      }
+  }
+
+  // ------------------------------------------------------------------ phase B: dK, dV for keys own..own+31
+  {
+    bf16x8_t kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = frag_rows(kt, own + (lane & 31), ks, hi);
+      vf[ks] = frag_rows(vt, own + (lane & 31), ks, hi);
+    }
+    f32x16_t dka[2], dva[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dka[0][r] = dka[1][r] = dva[0][r] = dva[1][r] = 0.f;
+    for (int qb = 0; qb < N; qb += 32) {
+      f32x16_t s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = MFMA(frag_rows(qt, qb + (lane & 31), ks, hi), kf[ks], s);
+        dp = MFMA(frag_rows(dot, qb + (lane & 31), ks, hi), vf[ks], dp);
+      }
+      float p[16], ds[16];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4_t l4 = *(const f32x4_t*)(lse2 + qb + g4 * 8 + hi * 4);
+        const f32x4_t d4 = *(const f32x4_t*)(delta + qb + g4 * 8 + hi * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = g4 * 4 + e;
+          p[r] = exp2f(s[r] * c - l4[e]);
+          ds[r] = p[r] * (dp[r] - d4[e]);
+        }
+      }
+#pragma unroll
+      for (int kg2 = 0; kg2 < 2; ++kg2) {
+        const bf16x8_t pf = pack_frag(&p[kg2 * 8]);
+        const bf16x8_t df = pack_frag(&ds[kg2 * 8]);
+        const int rbase = qb + kg2 * 16;
+        dva[0] = MFMA(frag_cols(dot, rbase, 0, lane), pf, dva[0]);
+        dva[1] = MFMA(frag_cols(dot, rbase, 32, lane), pf, dva[1]);
+        dka[0] = MFMA(frag_cols(qt, rbase, 0, lane), df, dka[0]);
+        dka[1] = MFMA(frag_cols(qt, rbase, 32, lane), df, dka[1]);
+      }
+    }
+    bf16_t* dkp = dk + hoff + (int64_t)(own + (lane & 31)) * DH;
+    bf16_t* dvp = dv + hoff + (int64_t)(own + (lane & 31)) * DH;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        u32x2_t w;
+        w[0] = pack2bf(dka[dt][g4 * 4 + 0] * scale, dka[dt][g4 * 4 + 1] * scale);
+        w[1] = pack2bf(dka[dt][g4 * 4 + 2] * scale, dka[dt][g4 * 4 + 3] * scale);
+        *(u32x2_t*)(dkp + dt * 32 + g4 * 8 + hi * 4) = w;
+        w[0] = pack2bf(dva[dt][g4 * 4 + 0], dva[dt][g4 * 4 + 1]);
+        w[1] = pack2bf(dva[dt][g4 * 4 + 2], dva[dt][g4 * 4 + 3]);
+        *(u32x2_t*)(dvp + dt * 32 + g4 * 8 + hi * 4) = w;
+      }
+  }
+}
+
+extern "C" int dl_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                           const float* lse, void* dq, void* dk, void* dv, int64_t B, int64_t H, int64_t N,
+                           int64_t dh, float scale, dl_stream_t stream) {
+  DL_CHECK_ARG(q && k && v && out && dout && lse && dq && dk && dv && B > 0 && H > 0, "dl_attn_bwd: null operand");
+  DL_CHECK_ARG(dh == DH, "dl_attn_bwd: head_dim %lld unsupported (64 only)", (long long)dh);
+  DL_CHECK_ARG(N % 64 == 0 && N >= 64 && N <= 256, "dl_attn_bwd: N=%lld must be a multiple of 64 in [64, 256]", (long long)N);
+  const int lds = (int)(4 * N * ROWB + 2 * N * sizeof(float));
+  (void)hipFuncSetAttribute((const void*)attn_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(attn_bwd_k, (int)(B * H), (int)(N / 32) * 64, lds, (hipStream_t)stream, (const bf16_t*)q,
+                     (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dq,
+                     (bf16_t*)dk, (bf16_t*)dv, (int)H, (int)N, scale);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}

@@ -1,0 +1,90 @@
+// Shared device/host helpers for libdiffulab_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/diffulab_hip.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits in HBM
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+#define DL_WAVE 64
+
+// ---------------------------------------------------------------- host side error plumbing
+void dl_set_error(const char* fmt, ...);
+#define DL_CHECK_ARG(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      dl_set_error(__VA_ARGS__);           \
+      return DL_ERR_INVALID;               \
+    }                                      \
+  } while (0)
+#define DL_LAUNCH_CHECK()                                                      \
+  do {                                                                         \
+    hipError_t e__ = hipGetLastError();                                        \
+    if (e__ != hipSuccess) {                                                   \
+      dl_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return DL_ERR_LAUNCH;                                                    \
+    }                                                                          \
+  } while (0)
+
+// ---------------------------------------------------------------- bf16 helpers (device)
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ float bflo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bfhi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+// round-to-nearest-even (NaN kept quiet)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const u32x4_t& p, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = bflo(p[i]);
+    f[2 * i + 1] = bfhi(p[i]);
+  }
+}
+__device__ __forceinline__ u32x4_t pack8(const float (&f)[8]) {
+  u32x4_t p;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p[i] = pack2bf(f[2 * i], f[2 * i + 1]);
+  return p;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// d/dx [x * sigmoid(x)]
+__device__ __forceinline__ float dsilu_f(float x) {
+  float s = 1.0f / (1.0f + __expf(-x));
+  return s * (1.0f + x * (1.0f - s));
+}
+
+// XCD-aware remap of a linear workgroup id: hardware deals block b to XCD b % 8, so give every XCD a
+// contiguous chunk of the logical grid (bijective also when nwg % 8 != 0).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,207 @@
+// Stem / head / conditioning kernels of the DiT: patchify (im2row), unpatchify, sinusoidal timestep
+// embedding, label-embedding combine, small reductions.  All tiny and HBM/latency bound.
+#include "common.h"
+
+// ---------------------------------------------------------------- patchify: x f32 [B,C,H,W] -> tok bf16 [M, ld]
+// one thread per (token, feature); feature order CPP: f = (c*p + p1)*p + p2 ; PPC: f = (p1*p + p2)*C + c
+__global__ void patchify_k(const float* __restrict__ x, bf16_t* __restrict__ tok, int B, int C, int H, int W, int p,
+                           int ld, int order) {
+  const int gh = H / p, gw = W / p, F = C * p * p;
+  const int64_t total = (int64_t)B * gh * gw * ld, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int f = (int)(i % ld);
+    const int64_t t = i / ld;
+    float val = 0.f;
+    if (f < F) {
+      const int wq = (int)(t % gw), hq = (int)((t / gw) % gh), b = (int)(t / ((int64_t)gw * gh));
+      int c, p1, p2;
+      if (order == DL_PATCH_CPP) {
+        p2 = f % p;
+        p1 = (f / p) % p;
+        c = f / (p * p);
+      } else {
+        c = f % C;
+        p2 = (f / C) % p;
+        p1 = f / (C * p);
+      }
+      val = x[(((int64_t)b * C + c) * H + hq * p + p1) * W + wq * p + p2];
+    }
+    tok[i] = f2bf(val);
+  }
+}
+extern "C" int dl_patchify(const float* x, void* tok, int64_t B, int64_t C, int64_t H, int64_t W, int64_t p, int64_t ld,
+                           int order, dl_stream_t stream) {
+  DL_CHECK_ARG(x && tok && B > 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0 && ld >= C * p * p,
+               "dl_patchify: bad dims (C=%lld H=%lld W=%lld p=%lld ld=%lld)", (long long)C, (long long)H, (long long)W,
+               (long long)p, (long long)ld);
+  const int64_t total = B * (H / p) * (W / p) * ld;
+  int64_t g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(patchify_k, (int)g, 256, 0, (hipStream_t)stream, x, (bf16_t*)tok, (int)B, (int)C, (int)H, (int)W,
+                     (int)p, (int)ld, order);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ---------------------------------------------------------------- unpatchify: tok f32 [M, ld] (p1 p2 c) -> img f32 [B,C,H,W]
+__global__ void unpatchify_k(const float* __restrict__ tok, float* __restrict__ img, int B, int C, int H, int W, int p,
+                             int ld) {
+  const int gh = H / p, gw = W / p;
+  const int64_t total = (int64_t)B * C * H * W, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int xw = (int)(i % W), yh = (int)((i / W) % H), c = (int)((i / ((int64_t)W * H)) % C);
+    const int b = (int)(i / ((int64_t)W * H * C));
+    const int hq = yh / p, p1 = yh % p, wq = xw / p, p2 = xw % p;
+    img[i] = tok[(((int64_t)b * gh + hq) * gw + wq) * ld + (p1 * p + p2) * C + c];
+  }
+}
+extern "C" int dl_unpatchify(const float* tok, float* img, int64_t B, int64_t C, int64_t H, int64_t W, int64_t p,
+                             int64_t ld, dl_stream_t stream) {
+  DL_CHECK_ARG(tok && img && B > 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0 && ld >= C * p * p, "dl_unpatchify: bad dims");
+  const int64_t total = B * C * H * W;
+  int64_t g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(unpatchify_k, (int)g, 256, 0, (hipStream_t)stream, tok, img, (int)B, (int)C, (int)H, (int)W,
+                     (int)p, (int)ld);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ---------------------------------------------------------------- sinusoidal timestep embedding
+__global__ void timestep_embedding_k(const float* __restrict__ t, bf16_t* __restrict__ out, int B, int dim,
+                                     float neg_log_p_over_half) {
+  const int half = dim >> 1;
+  const int64_t total = (int64_t)B * half;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / half), j = (int)(i % half);
+    const float f = expf((float)j * neg_log_p_over_half);  // exp(-ln(P) * j / half), fp32 like nn.py:107
+    const float a = t[b] * f;
+    out[(int64_t)b * dim + j] = f2bf(cosf(a));
+    out[(int64_t)b * dim + half + j] = f2bf(sinf(a));
+  }
+}
+extern "C" int dl_timestep_embedding(const float* t, void* out, int64_t B, int64_t dim, float max_period,
+                                     dl_stream_t stream) {
+  DL_CHECK_ARG(t && out && B > 0 && dim > 0 && dim % 2 == 0, "dl_timestep_embedding: dim must be even");
+  const int half = (int)(dim / 2);
+  int64_t g = (B * half + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(timestep_embedding_k, (int)g, 256, 0, (hipStream_t)stream, t, (bf16_t*)out, (int)B, (int)dim,
+                     (float)(-log((double)max_period) / (double)half));
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ---------------------------------------------------------------- emb = e + table[idx]; act = silu(emb)
+__global__ void cond_combine_fwd_k(const float* __restrict__ e, const float* __restrict__ table,
+                                   const int64_t* __restrict__ idx, float* __restrict__ emb, bf16_t* __restrict__ act,
+                                   int B, int E) {
+  const int64_t total = (int64_t)B * E;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / E), c = (int)(i % E);
+    float v = e[i];
+    if (idx) v += table[idx[b] * E + c];
+    emb[i] = v;
+    act[i] = f2bf(silu_f(v));
+  }
+}
+extern "C" int dl_cond_combine_fwd(const float* e, const float* table, const int64_t* idx, float* emb, void* act,
+                                   int64_t B, int64_t E, dl_stream_t stream) {
+  DL_CHECK_ARG(e && emb && act && B > 0 && E > 0 && (!idx || table), "dl_cond_combine_fwd: bad args");
+  int64_t g = (B * E + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(cond_combine_fwd_k, (int)g, 256, 0, (hipStream_t)stream, e, table, idx, emb, (bf16_t*)act, (int)B,
+                     (int)E);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+__global__ void cond_combine_bwd_k(const float* __restrict__ dact, const float* __restrict__ emb,
+                                   const int64_t* __restrict__ idx, float* __restrict__ demb,
+                                   bf16_t* __restrict__ demb16, float* __restrict__ dtable, int B, int E) {
+  const int64_t total = (int64_t)B * E;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / E), c = (int)(i % E);
+    const float g = dact[i] * dsilu_f(emb[i]);
+    demb[i] = g;
+    if (demb16) demb16[i] = f2bf(g);
+    if (dtable && idx) unsafeAtomicAdd(&dtable[idx[b] * E + c], g);
+  }
+}
+extern "C" int dl_cond_combine_bwd(const float* dact, const float* emb, const int64_t* idx, float* demb, void* demb_bf16,
+                                   float* dtable, int64_t B, int64_t E, dl_stream_t stream) {
+  DL_CHECK_ARG(dact && emb && demb && B > 0 && E > 0, "dl_cond_combine_bwd: bad args");
+  int64_t g = (B * E + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(cond_combine_bwd_k, (int)g, 256, 0, (hipStream_t)stream, dact, emb, idx, demb, (bf16_t*)demb_bf16,
+                     dtable, (int)B, (int)E);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+__global__ void silu_bwd_k(const float* __restrict__ dy, const bf16_t* __restrict__ pre, bf16_t* __restrict__ dx,
+                           int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dx[i] = f2bf(dy[i] * dsilu_f(bf2f(pre[i])));
+}
+extern "C" int dl_silu_bwd(const float* dy, const void* pre, void* dx, int64_t n, dl_stream_t stream) {
+  DL_CHECK_ARG(dy && pre && dx && n > 0, "dl_silu_bwd: bad args");
+  int64_t g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(silu_bwd_k, (int)g, 256, 0, (hipStream_t)stream, dy, (const bf16_t*)pre, (bf16_t*)dx, n);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ---------------------------------------------------------------- column sums: out[c] += sum_r x[r, c]
+// block = 256 threads = 64 columns x 4 row-lanes; grid.x over column blocks, grid.y over row slabs
+template <typename T>
+__device__ __forceinline__ float ldf(const T* p);
+template <>
+__device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+
+template <typename T>
+__global__ void colsum_k(const T* __restrict__ x, int64_t ld, float* __restrict__ out, int64_t R, int C,
+                         int rows_per_slab) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_slab;
+  const int64_t r1 = r0 + rows_per_slab < R ? r0 + rows_per_slab : R;
+  float acc = 0.f;
+  if (c < C)
+    for (int64_t r = r0 + rl; r < r1; r += 4) acc += ldf<T>(x + r * ld + c);
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < C) unsafeAtomicAdd(&out[c], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+extern "C" int dl_colsum(const void* x, int dtype, int64_t ld, float* out, int64_t R, int64_t C, dl_stream_t stream) {
+  DL_CHECK_ARG(x && out && R > 0 && C > 0 && ld >= C, "dl_colsum: bad args");
+  int slabs = (int)((R + 255) / 256);
+  if (slabs > 512) slabs = 512;
+  const int rps = (int)((R + slabs - 1) / slabs);
+  dim3 grid(cdiv(C, 64), slabs);
+  if (dtype == DL_F32)
+    hipLaunchKernelGGL(colsum_k<float>, grid, 256, 0, (hipStream_t)stream, (const float*)x, ld, out, R, (int)C, rps);
+  else
+    hipLaunchKernelGGL(colsum_k<bf16_t>, grid, 256, 0, (hipStream_t)stream, (const bf16_t*)x, ld, out, R, (int)C, rps);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+__global__ void reduce_rows_k(const float* __restrict__ partial, float* __restrict__ out, int G, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += partial[(int64_t)g * n + i];
+    out[i] += s;
+  }
+}
+extern "C" int dl_reduce_rows_f32(const float* partial, float* out, int64_t G, int64_t n, dl_stream_t stream) {
+  DL_CHECK_ARG(partial && out && G > 0 && n > 0, "dl_reduce_rows_f32: bad args");
+  int64_t g = (n + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(reduce_rows_k, (int)g, 256, 0, (hipStream_t)stream, partial, out, (int)G, n);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}

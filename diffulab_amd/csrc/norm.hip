@@ -1,0 +1,576 @@
+// HBM-bound row kernels of the DiT block: adaLN (LayerNorm + modulate) fwd/bwd, gated-residual bwd,
+// QK-RMSNorm + N-D RoPE + head split fwd/bwd, SwiGLU fwd/bwd.
+// One 64-lane wave owns one token row; every lane moves 16-byte (8 x bf16) chunks; row statistics are
+// wavefront shuffles (no LDS); per-sample column reductions (adaLN gradients) are register accumulators
+// reduced across the workgroup's waves through LDS once per workgroup.
+#include "common.h"
+
+#define MAXJ 2  // chunks of 8 per lane -> D <= 1024 (NJ=4 spills; wider rows need an LDS-staged variant)
+
+template <int NJ>
+__device__ __forceinline__ void load_row(const bf16_t* __restrict__ p, int D8, int lane, float (&v)[NJ][8]) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = lane + 64 * j;
+    if (c < D8) {
+      unpack8(*(const u32x4_t*)(p + c * 8), v[j]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+    }
+  }
+}
+template <int NJ>
+__device__ __forceinline__ void load_row_f32(const float* __restrict__ p, int D8, int lane, float (&v)[NJ][8], float fill) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = lane + 64 * j;
+    if (p && c < D8) {
+      *(f32x4_t*)&v[j][0] = *(const f32x4_t*)(p + c * 8);
+      *(f32x4_t*)&v[j][4] = *(const f32x4_t*)(p + c * 8 + 4);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[j][e] = fill;
+    }
+  }
+}
+template <int NJ>
+__device__ __forceinline__ void store_row(bf16_t* __restrict__ p, int D8, int lane, const float (&v)[NJ][8]) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = lane + 64 * j;
+    if (c < D8) *(u32x4_t*)(p + c * 8) = pack8(v[j]);
+  }
+}
+
+// ======================================================================== LayerNorm + modulate, forward
+template <int NJ>
+__global__ __launch_bounds__(256) void ln_mod_fwd_k(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ b, const bf16_t* __restrict__ scale,
+                                                    const bf16_t* __restrict__ shift, int64_t ld_mod,
+                                                    int64_t rows_per_mod, float eps, bf16_t* __restrict__ out,
+                                                    float* __restrict__ mean_o, float* __restrict__ rstd_o, int64_t M,
+                                                    int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D8 = D >> 3;
+  const float invD = 1.0f / (float)D;
+  float wv[NJ][8], bv[NJ][8];
+  load_row_f32<NJ>(w, D8, lane, wv, 1.0f);
+  load_row_f32<NJ>(b, D8, lane, bv, 0.0f);
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+    float xv[NJ][8], sc[NJ][8], sh[NJ][8];
+    load_row<NJ>(x + row * D, D8, lane, xv);
+    const int64_t g = row / rows_per_mod;
+    load_row<NJ>(scale + g * ld_mod, D8, lane, sc);
+    load_row<NJ>(shift + g * ld_mod, D8, lane, sh);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += xv[j][e];
+    const float mu = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const bool on = (lane + 64 * j) < D8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = on ? (xv[j][e] - mu) : 0.f;
+        q += d * d;
+      }
+    }
+    const float rs = rsqrtf(wave_sum(q) * invD + eps);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float y = (xv[j][e] - mu) * rs * wv[j][e] + bv[j][e];
+        xv[j][e] = y * (1.0f + sc[j][e]) + sh[j][e];
+      }
+    store_row<NJ>(out + row * D, D8, lane, xv);
+    if (lane == 0) {
+      mean_o[row] = mu;
+      rstd_o[row] = rs;
+    }
+  }
+}
+
+extern "C" int dl_ln_modulate_fwd(const void* x, const float* w, const float* b, const void* scale, const void* shift,
+                                  int64_t ld_mod, int64_t rows_per_mod, float eps, void* out, float* mean,
+                                  float* rstd, int64_t M, int64_t D, dl_stream_t stream) {
+  DL_CHECK_ARG(x && scale && shift && out && mean && rstd && M > 0, "dl_ln_modulate_fwd: null operand");
+  DL_CHECK_ARG((w == nullptr) == (b == nullptr), "dl_ln_modulate_fwd: w and b must both be given or both NULL");
+  DL_CHECK_ARG(D % 8 == 0 && D <= 512 * MAXJ && ld_mod % 8 == 0 && rows_per_mod > 0, "dl_ln_modulate_fwd: D=%lld",
+               (long long)D);
+  DL_CHECK_ARG((((uintptr_t)x | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)out) & 15) == 0,
+               "dl_ln_modulate_fwd: 16-byte alignment");
+  const int nj = cdiv(D, 512);
+  int grid = cdiv(M, 4);
+  if (grid > 4096) grid = 4096;
+#define LAUNCH(NJ)                                                                                              \
+  hipLaunchKernelGGL(ln_mod_fwd_k<NJ>, grid, 256, 0, (hipStream_t)stream, (const bf16_t*)x, w, b,                \
+                     (const bf16_t*)scale, (const bf16_t*)shift, ld_mod, rows_per_mod, eps, (bf16_t*)out, mean, \
+                     rstd, M, (int)D)
+  if (nj == 1) LAUNCH(1);
+  else LAUNCH(2);
+#undef LAUNCH
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ======================================================================== LayerNorm + modulate, backward
+// One workgroup (8 waves) per modulation group (= one sample's tokens).  LDS: [8 waves][4 sums][D] floats.
+#define LNB_WAVES 8
+template <int NJ>
+__global__ __launch_bounds__(512) void ln_mod_bwd_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
+                                                    const float* __restrict__ w, const float* __restrict__ b,
+                                                    const bf16_t* __restrict__ scale, int64_t ld_mod,
+                                                    int64_t rows_per_mod, const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
+                                                    bf16_t* __restrict__ dx, bf16_t* __restrict__ dscale,
+                                                    bf16_t* __restrict__ dshift, int64_t ld_dmod,
+                                                    float* __restrict__ dwb, int64_t M, int D) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = (float*)smem;  // [LNB_WAVES][4][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D8 = D >> 3;
+  const float invD = 1.0f / (float)D;
+  const int64_t g = blockIdx.x;
+  float wv[NJ][8], bv[NJ][8], sc[NJ][8];
+  load_row_f32<NJ>(w, D8, lane, wv, 1.0f);
+  load_row_f32<NJ>(b, D8, lane, bv, 0.0f);
+  load_row<NJ>(scale + g * ld_mod, D8, lane, sc);
+  float a_dsc[NJ][8], a_dsh[NJ][8], a_dw[NJ][8], a_db[NJ][8];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a_dsc[j][e] = a_dsh[j][e] = a_dw[j][e] = a_db[j][e] = 0.f;
+
+  const int64_t row_end = (g + 1) * rows_per_mod < M ? (g + 1) * rows_per_mod : M;
+  for (int64_t row = g * rows_per_mod + wave; row < row_end; row += LNB_WAVES) {
+    float dv[NJ][8], xv[NJ][8];
+    load_row<NJ>(dout + row * D, D8, lane, dv);
+    load_row<NJ>(x + row * D, D8, lane, xv);
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const bool on = (lane + 64 * j) < D8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = on ? (xv[j][e] - mu) * rs : 0.f;
+        const float y = xh * wv[j][e] + bv[j][e];
+        const float d = dv[j][e];
+        a_dsc[j][e] += d * y;
+        a_dsh[j][e] += d;
+        const float dy = d * (1.0f + sc[j][e]);
+        a_dw[j][e] += dy * xh;
+        a_db[j][e] += dy;
+        const float dxh = dy * wv[j][e];
+        s1 += dxh;
+        s2 += dxh * xh;
+        xv[j][e] = xh;
+        dv[j][e] = dxh;
+      }
+    }
+    const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
+    float rv[NJ][8];
+    if (dres) {
+      load_row<NJ>(dres + row * D, D8, lane, rv);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rv[j][e] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rv[j][e] += rs * (dv[j][e] - c1 - xv[j][e] * c2);
+    store_row<NJ>(dx + row * D, D8, lane, rv);
+  }
+
+  // cross-wave reduction of the four column sums
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = lane + 64 * j;
+    if (c < D8) {
+      float* base = red + (size_t)wave * 4 * D + c * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        base[e] = a_dsc[j][e];
+        base[D + e] = a_dsh[j][e];
+        base[2 * D + e] = a_dw[j][e];
+        base[3 * D + e] = a_db[j][e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * D; i += 512) {
+    float s = 0.f;
+#pragma unroll
+    for (int wv_ = 0; wv_ < LNB_WAVES; ++wv_) s += red[(size_t)wv_ * 4 * D + i];
+    const int which = i / D, col = i - which * D;
+    if (which == 0) dscale[g * ld_dmod + col] = f2bf(s);
+    else if (which == 1) dshift[g * ld_dmod + col] = f2bf(s);
+    else if (dwb) dwb[(size_t)g * 2 * D + (which - 2) * D + col] = s;
+  }
+}
+
+extern "C" int dl_ln_modulate_bwd(const void* dout, const void* x, const float* w, const float* b, const void* scale,
+                                  int64_t ld_mod, int64_t rows_per_mod, const float* mean, const float* rstd,
+                                  const void* dres, void* dx, void* dscale, void* dshift, int64_t ld_dmod,
+                                  float* dwb_partial, int64_t M, int64_t D, dl_stream_t stream) {
+  DL_CHECK_ARG(dout && x && scale && mean && rstd && dx && dscale && dshift && M > 0, "dl_ln_modulate_bwd: null operand");
+  DL_CHECK_ARG((w == nullptr) == (b == nullptr), "dl_ln_modulate_bwd: w and b must both be given or both NULL");
+  DL_CHECK_ARG(D % 8 == 0 && D <= 512 * MAXJ && ld_mod % 8 == 0 && rows_per_mod > 0 && M % rows_per_mod == 0,
+               "dl_ln_modulate_bwd: D=%lld M=%lld rows_per_mod=%lld", (long long)D, (long long)M, (long long)rows_per_mod);
+  DL_CHECK_ARG((((uintptr_t)dout | (uintptr_t)x | (uintptr_t)scale | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0,
+               "dl_ln_modulate_bwd: 16-byte alignment");
+  const int nj = cdiv(D, 512);
+  const int groups = (int)(M / rows_per_mod);
+  const size_t lds = (size_t)LNB_WAVES * 4 * D * sizeof(float);
+  DL_CHECK_ARG(lds <= 160 * 1024, "dl_ln_modulate_bwd: D too large for the LDS reduction");
+#define LAUNCH(NJ)                                                                                                   \
+  do {                                                                                                               \
+    (void)hipFuncSetAttribute((const void*)ln_mod_bwd_k<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+    hipLaunchKernelGGL(ln_mod_bwd_k<NJ>, groups, 512, lds, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)x, \
+                       w, b, (const bf16_t*)scale, ld_mod, rows_per_mod, mean, rstd, (const bf16_t*)dres,             \
+                       (bf16_t*)dx, (bf16_t*)dscale, (bf16_t*)dshift, ld_dmod, dwb_partial, M, (int)D);               \
+  } while (0)
+  if (nj == 1) LAUNCH(1);
+  else LAUNCH(2);
+#undef LAUNCH
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ======================================================================== gated residual, backward
+template <int NJ>
+__global__ __launch_bounds__(512) void gate_bwd_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ t,
+                                                  const bf16_t* __restrict__ gate, int64_t ld_mod,
+                                                  int64_t rows_per_mod, bf16_t* __restrict__ dt,
+                                                  bf16_t* __restrict__ dgate, int64_t ld_dmod, int64_t M, int D) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = (float*)smem;  // [LNB_WAVES][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D8 = D >> 3;
+  const int64_t g = blockIdx.x;
+  float gv[NJ][8], acc[NJ][8];
+  load_row<NJ>(gate + g * ld_mod, D8, lane, gv);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+  const int64_t row_end = (g + 1) * rows_per_mod < M ? (g + 1) * rows_per_mod : M;
+  for (int64_t row = g * rows_per_mod + wave; row < row_end; row += LNB_WAVES) {
+    float dv[NJ][8], tv[NJ][8];
+    load_row<NJ>(dout + row * D, D8, lane, dv);
+    load_row<NJ>(t + row * D, D8, lane, tv);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        acc[j][e] += dv[j][e] * tv[j][e];
+        dv[j][e] *= gv[j][e];
+      }
+    store_row<NJ>(dt + row * D, D8, lane, dv);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = lane + 64 * j;
+    if (c < D8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[(size_t)wave * D + c * 8 + e] = acc[j][e];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += 512) {
+    float s = 0.f;
+#pragma unroll
+    for (int wv_ = 0; wv_ < LNB_WAVES; ++wv_) s += red[(size_t)wv_ * D + i];
+    dgate[g * ld_dmod + i] = f2bf(s);
+  }
+}
+
+extern "C" int dl_gate_bwd(const void* dout, const void* t, const void* gate, int64_t ld_mod, int64_t rows_per_mod,
+                           void* dt, void* dgate, int64_t ld_dmod, int64_t M, int64_t D, dl_stream_t stream) {
+  DL_CHECK_ARG(dout && t && gate && dt && dgate && M > 0, "dl_gate_bwd: null operand");
+  DL_CHECK_ARG(D % 8 == 0 && D <= 512 * MAXJ && ld_mod % 8 == 0 && rows_per_mod > 0 && M % rows_per_mod == 0,
+               "dl_gate_bwd: bad dims");
+  DL_CHECK_ARG((((uintptr_t)dout | (uintptr_t)t | (uintptr_t)gate | (uintptr_t)dt) & 15) == 0, "dl_gate_bwd: alignment");
+  const int nj = cdiv(D, 512);
+  const int groups = (int)(M / rows_per_mod);
+  const size_t lds = (size_t)LNB_WAVES * D * sizeof(float);
+#define LAUNCH(NJ)                                                                                               \
+  hipLaunchKernelGGL(gate_bwd_k<NJ>, groups, 512, lds, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)t, \
+                     (const bf16_t*)gate, ld_mod, rows_per_mod, (bf16_t*)dt, (bf16_t*)dgate, ld_dmod, M, (int)D)
+  if (nj == 1) LAUNCH(1);
+  else LAUNCH(2);
+#undef LAUNCH
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ======================================================================== QK RMSNorm + RoPE + head split
+// forward: one wave per token; lane c owns elements [8c, 8c+8) of the q, k and v thirds of the qkv row.
+template <int NJ>
+__global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(const bf16_t* __restrict__ qkv, const float* __restrict__ sq,
+                                                          const float* __restrict__ sk, const float* __restrict__ cs,
+                                                          const float* __restrict__ sn, bf16_t* __restrict__ qo,
+                                                          bf16_t* __restrict__ ko, bf16_t* __restrict__ vo,
+                                                          float* __restrict__ rrms, int64_t M, int N, int H, int dh,
+                                                          int rot, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D = H * dh, D8 = D >> 3;
+  const float invD = 1.0f / (float)D;
+  float wq[NJ][8], wk[NJ][8];
+  load_row_f32<NJ>(sq, D8, lane, wq, 1.0f);
+  load_row_f32<NJ>(sk, D8, lane, wk, 1.0f);
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+    const bf16_t* p = qkv + row * 3 * D;
+    float q[NJ][8], k[NJ][8], v[NJ][8];
+    load_row<NJ>(p, D8, lane, q);
+    load_row<NJ>(p + D, D8, lane, k);
+    load_row<NJ>(p + 2 * D, D8, lane, v);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s1 += q[j][e] * q[j][e];
+        s2 += k[j][e] * k[j][e];
+      }
+    const float rq = rsqrtf(wave_sum(s1) * invD + eps), rk = rsqrtf(wave_sum(s2) * invD + eps);
+    const int64_t b = row / N;
+    const int n = (int)(row - b * N);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c >= D8) continue;
+      const int col = c * 8, h = col / dh, d0 = col - h * dh;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        q[j][e] = q[j][e] * rq * wq[j][e];
+        k[j][e] = k[j][e] * rk * wk[j][e];
+      }
+      if (d0 < rot) {  // rot is a multiple of 8: a chunk is either fully rotary or fully pass-through
+        const f32x4_t cc = *(const f32x4_t*)(cs + (int64_t)n * (rot >> 1) + (d0 >> 1));
+        const f32x4_t ss = *(const f32x4_t*)(sn + (int64_t)n * (rot >> 1) + (d0 >> 1));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float qa = q[j][2 * i], qb = q[j][2 * i + 1], ka = k[j][2 * i], kb = k[j][2 * i + 1];
+          q[j][2 * i] = qa * cc[i] - qb * ss[i];
+          q[j][2 * i + 1] = qa * ss[i] + qb * cc[i];
+          k[j][2 * i] = ka * cc[i] - kb * ss[i];
+          k[j][2 * i + 1] = ka * ss[i] + kb * cc[i];
+        }
+      }
+      const int64_t o = (((int64_t)b * H + h) * N + n) * dh + d0;
+      *(u32x4_t*)(qo + o) = pack8(q[j]);
+      *(u32x4_t*)(ko + o) = pack8(k[j]);
+      *(u32x4_t*)(vo + o) = pack8(v[j]);
+    }
+    if (lane == 0) {
+      rrms[row * 2] = rq;
+      rrms[row * 2 + 1] = rk;
+    }
+  }
+}
+
+extern "C" int dl_qk_norm_rope_fwd(const void* qkv, const float* scale_q, const float* scale_k, const float* cos,
+                                   const float* sin, void* q, void* k, void* v, float* rrms, int64_t B, int64_t N,
+                                   int64_t H, int64_t dh, int64_t rot, float eps, dl_stream_t stream) {
+  DL_CHECK_ARG(qkv && scale_q && scale_k && cos && sin && q && k && v && rrms && B > 0 && N > 0,
+               "dl_qk_norm_rope_fwd: null operand");
+  const int64_t D = H * dh;
+  DL_CHECK_ARG(dh % 8 == 0 && rot % 8 == 0 && rot <= dh && D <= 512 * MAXJ, "dl_qk_norm_rope_fwd: dh=%lld rot=%lld",
+               (long long)dh, (long long)rot);
+  const int64_t M = B * N;
+  int grid = cdiv(M, 4);
+  if (grid > 4096) grid = 4096;
+  const int nj = cdiv(D, 512);
+#define LAUNCH(NJ)                                                                                                  \
+  hipLaunchKernelGGL(qk_norm_rope_fwd_k<NJ>, grid, 256, 0, (hipStream_t)stream, (const bf16_t*)qkv, scale_q, scale_k, \
+                     cos, sin, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, rrms, M, (int)N, (int)H, (int)dh, (int)rot, eps)
+  if (nj == 1) LAUNCH(1);
+  else LAUNCH(2);
+#undef LAUNCH
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// backward: dq,dk,dv [B,H,N,dh] -> dqkv [B*N, 3D]; scale gradients accumulated per wave, reduced across the
+// workgroup in LDS and added atomically to dscale[2][D].
+template <int NJ>
+__global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dk,
+                                                          const bf16_t* __restrict__ dv, const bf16_t* __restrict__ qkv,
+                                                          const float* __restrict__ sq, const float* __restrict__ sk,
+                                                          const float* __restrict__ cs, const float* __restrict__ sn,
+                                                          const float* __restrict__ rrms, bf16_t* __restrict__ dqkv,
+                                                          float* __restrict__ dscale, int64_t M, int N, int H, int dh,
+                                                          int rot) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = (float*)smem;  // [4 waves][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D = H * dh, D8 = D >> 3;
+  const float invD = 1.0f / (float)D;
+  float wq[NJ][8], wk[NJ][8], aq[NJ][8], ak[NJ][8];
+  load_row_f32<NJ>(sq, D8, lane, wq, 1.0f);
+  load_row_f32<NJ>(sk, D8, lane, wk, 1.0f);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) aq[j][e] = ak[j][e] = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+    const int64_t b = row / N;
+    const int n = (int)(row - b * N);
+    const bf16_t* p = qkv + row * 3 * D;
+    float xq[NJ][8], xk[NJ][8], gq[NJ][8], gk[NJ][8], gv[NJ][8];
+    load_row<NJ>(p, D8, lane, xq);
+    load_row<NJ>(p + D, D8, lane, xk);
+    const float rq = rrms[row * 2], rk = rrms[row * 2 + 1];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c >= D8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gq[j][e] = gk[j][e] = gv[j][e] = 0.f;
+        continue;
+      }
+      const int col = c * 8, h = col / dh, d0 = col - h * dh;
+      const int64_t o = (((int64_t)b * H + h) * N + n) * dh + d0;
+      unpack8(*(const u32x4_t*)(dq + o), gq[j]);
+      unpack8(*(const u32x4_t*)(dk + o), gk[j]);
+      unpack8(*(const u32x4_t*)(dv + o), gv[j]);
+      if (d0 < rot) {  // transpose of the rotation
+        const f32x4_t cc = *(const f32x4_t*)(cs + (int64_t)n * (rot >> 1) + (d0 >> 1));
+        const f32x4_t ss = *(const f32x4_t*)(sn + (int64_t)n * (rot >> 1) + (d0 >> 1));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float qa = gq[j][2 * i], qb = gq[j][2 * i + 1], ka = gk[j][2 * i], kb = gk[j][2 * i + 1];
+          gq[j][2 * i] = qa * cc[i] + qb * ss[i];
+          gq[j][2 * i + 1] = -qa * ss[i] + qb * cc[i];
+          gk[j][2 * i] = ka * cc[i] + kb * ss[i];
+          gk[j][2 * i + 1] = -ka * ss[i] + kb * cc[i];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        aq[j][e] += gq[j][e] * xq[j][e] * rq;  // dscale
+        ak[j][e] += gk[j][e] * xk[j][e] * rk;
+        gq[j][e] *= wq[j][e];                  // s * dy
+        gk[j][e] *= wk[j][e];
+        s1 += gq[j][e] * xq[j][e];
+        s2 += gk[j][e] * xk[j][e];
+      }
+    }
+    const float mq = wave_sum(s1) * invD * rq * rq * rq, mk = wave_sum(s2) * invD * rk * rk * rk;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        gq[j][e] = rq * gq[j][e] - xq[j][e] * mq;
+        gk[j][e] = rk * gk[j][e] - xk[j][e] * mk;
+      }
+    bf16_t* o = dqkv + row * 3 * D;
+    store_row<NJ>(o, D8, lane, gq);
+    store_row<NJ>(o + D, D8, lane, gk);
+    store_row<NJ>(o + 2 * D, D8, lane, gv);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = lane + 64 * j;
+    if (c < D8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(size_t)wave * 2 * D + c * 8 + e] = aq[j][e];
+        red[(size_t)wave * 2 * D + D + c * 8 + e] = ak[j][e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += 256) {
+    const float s = red[i] + red[2 * D + i] + red[4 * D + i] + red[6 * D + i];
+    unsafeAtomicAdd(&dscale[i], s);
+  }
+}
+
+extern "C" int dl_qk_norm_rope_bwd(const void* dq, const void* dk, const void* dv, const void* qkv,
+                                   const float* scale_q, const float* scale_k, const float* cos, const float* sin,
+                                   const float* rrms, void* dqkv, float* dscale, int64_t B, int64_t N, int64_t H,
+                                   int64_t dh, int64_t rot, dl_stream_t stream) {
+  DL_CHECK_ARG(dq && dk && dv && qkv && scale_q && scale_k && cos && sin && rrms && dqkv && dscale && B > 0 && N > 0,
+               "dl_qk_norm_rope_bwd: null operand");
+  const int64_t D = H * dh;
+  DL_CHECK_ARG(dh % 8 == 0 && rot % 8 == 0 && rot <= dh && D <= 512 * MAXJ, "dl_qk_norm_rope_bwd: bad dims");
+  const int64_t M = B * N;
+  int grid = cdiv(M, 4 * 16);  // >= 16 rows per wave so the atomics are amortised
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  const int nj = cdiv(D, 512);
+  const size_t lds = (size_t)4 * 2 * D * sizeof(float);
+#define LAUNCH(NJ)                                                                                                   \
+  hipLaunchKernelGGL(qk_norm_rope_bwd_k<NJ>, grid, 256, lds, (hipStream_t)stream, (const bf16_t*)dq, (const bf16_t*)dk, \
+                     (const bf16_t*)dv, (const bf16_t*)qkv, scale_q, scale_k, cos, sin, rrms, (bf16_t*)dqkv, dscale, M, \
+                     (int)N, (int)H, (int)dh, (int)rot)
+  if (nj == 1) LAUNCH(1);
+  else LAUNCH(2);
+#undef LAUNCH
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ======================================================================== SwiGLU
+__global__ void swiglu_fwd_k(const bf16_t* __restrict__ u, bf16_t* __restrict__ h, int64_t M, int F8) {
+  const int64_t total = M * F8, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t row = i / F8;
+    const int c = (int)(i - row * F8);
+    const bf16_t* p = u + row * (int64_t)F8 * 16 + c * 8;
+    float a[8], b[8];
+    unpack8(*(const u32x4_t*)p, a);
+    unpack8(*(const u32x4_t*)(p + (int64_t)F8 * 8), b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e]) * b[e];
+    *(u32x4_t*)(h + row * (int64_t)F8 * 8 + c * 8) = pack8(a);
+  }
+}
+__global__ void swiglu_bwd_k(const bf16_t* __restrict__ dh, const bf16_t* __restrict__ u, bf16_t* __restrict__ du,
+                             int64_t M, int F8) {
+  const int64_t total = M * F8, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t row = i / F8;
+    const int c = (int)(i - row * F8);
+    const int64_t uo = row * (int64_t)F8 * 16 + c * 8;
+    float a[8], b[8], g[8], da[8], db[8];
+    unpack8(*(const u32x4_t*)(u + uo), a);
+    unpack8(*(const u32x4_t*)(u + uo + (int64_t)F8 * 8), b);
+    unpack8(*(const u32x4_t*)(dh + row * (int64_t)F8 * 8 + c * 8), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      da[e] = g[e] * b[e] * dsilu_f(a[e]);
+      db[e] = g[e] * silu_f(a[e]);
+    }
+    *(u32x4_t*)(du + uo) = pack8(da);
+    *(u32x4_t*)(du + uo + (int64_t)F8 * 8) = pack8(db);
+  }
+}
+extern "C" int dl_swiglu_fwd(const void* u, void* h, int64_t M, int64_t F, dl_stream_t stream) {
+  DL_CHECK_ARG(u && h && M > 0 && F > 0 && F % 8 == 0, "dl_swiglu_fwd: bad args");
+  int64_t g = (M * (F / 8) + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(swiglu_fwd_k, (int)g, 256, 0, (hipStream_t)stream, (const bf16_t*)u, (bf16_t*)h, M, (int)(F / 8));
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_swiglu_bwd(const void* dh, const void* u, void* du, int64_t M, int64_t F, dl_stream_t stream) {
+  DL_CHECK_ARG(dh && u && du && M > 0 && F > 0 && F % 8 == 0, "dl_swiglu_bwd: bad args");
+  int64_t g = (M * (F / 8) + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(swiglu_bwd_k, (int)g, 256, 0, (hipStream_t)stream, (const bf16_t*)dh, (const bf16_t*)u,
+                     (bf16_t*)du, M, (int)(F / 8));
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}

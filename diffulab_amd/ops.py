@@ -1,0 +1,256 @@
+"""Tensor-level wrappers over the C ABI (``include/diffulab_hip.h``).
+
+Torch is plumbing only here: it owns the device buffers and the stream; every computation below is a
+hand-written HIP kernel in ``libdiffulab_hip.so``.  All functions write into caller-provided outputs
+(so the engines can run allocation-free / graph-capturable) and return the output for convenience.
+There is no fallback path: a missing library or a CPU tensor raises.
+"""
+
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from ._lib import lib
+
+BF16, F32 = 0, 1
+ACT_NONE, ACT_SILU = 0, 1
+LOSS_FLOW, LOSS_EPS = 0, 1
+MEAN_TYPES = {"epsilon": 0, "xstart": 1, "xprev": 2}
+PATCH_CPP, PATCH_PPC = 0, 1
+
+
+def _s() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Tensor | None) -> int | None:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("diffulab_amd ops need device tensors (no CPU fallback exists)")
+    return t.data_ptr()
+
+
+def _call(name: str, *args) -> None:
+    lib().call(name, *args)
+
+
+# ------------------------------------------------------------------ diffusion heads
+def flow_add_noise(x: Tensor, noise: Tensor, t: Tensor, out: Tensor | None = None) -> Tensor:
+    out = torch.empty_like(x) if out is None else out
+    B = x.shape[0]
+    _call("dl_flow_add_noise", _p(x), _p(noise), _p(t), _p(out), B, x.numel() // B, _s())
+    return out
+
+
+def ddpm_add_noise(x: Tensor, noise: Tensor, t: Tensor, sqrt_ab: Tensor, ab: Tensor, out: Tensor | None = None) -> Tensor:
+    out = torch.empty_like(x) if out is None else out
+    B = x.shape[0]
+    _call("dl_ddpm_add_noise", _p(x), _p(noise), _p(t), _p(sqrt_ab), _p(ab), _p(out), B, x.numel() // B, _s())
+    return out
+
+
+def mse_loss_fwd(pred: Tensor, a: Tensor, b: Tensor | None, mode: int) -> Tensor:
+    n = pred.numel()
+    npart = lib().call("dl_mse_loss_partials", n)
+    partial = torch.empty(npart, device=pred.device, dtype=torch.float32)
+    loss = torch.empty((), device=pred.device, dtype=torch.float32)
+    _call("dl_mse_loss_fwd", _p(pred), _p(a), _p(b), _p(partial), _p(loss), n, mode, _s())
+    return loss
+
+
+def mse_loss_bwd(pred: Tensor, a: Tensor, b: Tensor | None, gscale: float, mode: int, out: Tensor | None = None) -> Tensor:
+    out = torch.empty_like(pred) if out is None else out
+    _call("dl_mse_loss_bwd", _p(pred), _p(a), _p(b), float(gscale), _p(out), pred.numel(), mode, _s())
+    return out
+
+
+def flow_x_to_v(z: Tensor, xhat: Tensor, t: Tensor) -> Tensor:
+    v = torch.empty_like(z)
+    B = z.shape[0]
+    _call("dl_flow_x_to_v", _p(z), _p(xhat), _p(t), _p(v), B, z.numel() // B, _s())
+    return v
+
+
+def flow_x_to_v_bwd(dv: Tensor, t: Tensor) -> Tensor:
+    dx = torch.empty_like(dv)
+    B = dv.shape[0]
+    _call("dl_flow_x_to_v_bwd", _p(dv), _p(t), _p(dx), B, dv.numel() // B, _s())
+    return dx
+
+
+# ------------------------------------------------------------------ sampler steps
+def euler_step(x: Tensor, v: Tensor, v_uncond: Tensor | None, guidance: float, t_curr: float, t_prev: float,
+               want_x0: bool = True) -> tuple[Tensor, Tensor | None]:
+    xp = torch.empty_like(x)
+    x0 = torch.empty_like(x) if want_x0 else None
+    _call("dl_euler_step", _p(x), _p(v), _p(v_uncond), float(guidance), float(t_curr), float(t_curr - t_prev), _p(xp),
+          _p(x0), x.numel(), _s())
+    return xp, x0
+
+
+def euler_maruyama_step(x, v, v_uncond, guidance, noise, x_prev_in, t_curr, t_prev, sigma):
+    dt = t_curr - t_prev
+    std = sigma * dt**0.5
+    xp, mean, x0, lp = (torch.empty_like(x) for _ in range(4))
+    _call("dl_euler_maruyama_step", _p(x), _p(v), _p(v_uncond), float(guidance), _p(noise), _p(x_prev_in), float(t_curr),
+          float(dt), float(sigma), float(std), _p(xp), _p(mean), _p(x0), _p(lp), x.numel(), _s())
+    return xp, mean, x0, lp, std
+
+
+def ddpm_step(pred, pred_uncond, guidance, xt, noise, t, tables, mean_type: int, clamp_x: bool):
+    B = xt.shape[0]
+    xp, x0, mean, std, lp = (torch.empty_like(xt) for _ in range(5))
+    _call("dl_ddpm_step", _p(pred), _p(pred_uncond), float(guidance), _p(xt), _p(noise), _p(t), _p(tables),
+          tables.shape[1], mean_type, int(clamp_x), _p(xp), _p(x0), _p(mean), _p(std), _p(lp), B, xt.numel() // B, _s())
+    return xp, x0, mean, std, lp
+
+
+def ddim_step(pred, pred_uncond, guidance, xt, noise, t, tables, coefs, mean_type: int, clamp_x: bool, eta: float):
+    B = xt.shape[0]
+    xp, x0, mean = (torch.empty_like(xt) for _ in range(3))
+    std = torch.empty_like(xt) if eta > 0 else None
+    lp = torch.empty_like(xt) if eta > 0 else None
+    _call("dl_ddim_step", _p(pred), _p(pred_uncond), float(guidance), _p(xt), _p(noise), _p(t), _p(tables),
+          tables.shape[1], mean_type, _p(coefs), int(clamp_x), float(eta), _p(xp), _p(x0), _p(mean), _p(std), _p(lp), B,
+          xt.numel() // B, _s())
+    return xp, x0, mean, std, lp
+
+
+# ------------------------------------------------------------------ GEMMs
+def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias: Tensor | None = None, act: int = ACT_NONE,
+            pre_out: Tensor | None = None, resid: Tensor | None = None, gate: Tensor | None = None,
+            rows_per_gate: int = 1, M: int | None = None, N: int | None = None, K: int | None = None) -> Tensor:
+    """out[M,N] = epilogue(a[M,K] @ b[N,K]^T); a/b bf16 2-D (row stride = .stride(0)); out bf16 or f32."""
+    M = a.shape[0] if M is None else M
+    N = b.shape[0] if N is None else N
+    K = a.shape[1] if K is None else K
+    _call("dl_gemm_nt", _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, _p(bias), act,
+          F32 if out.dtype == torch.float32 else BF16, _p(pre_out), _p(resid), resid.stride(0) if resid is not None else 0,
+          _p(gate), gate.stride(0) if gate is not None else 0, rows_per_gate, _s())
+    return out
+
+
+def gemm_tn(a: Tensor, b: Tensor, out: Tensor, *, M: int | None = None, N: int | None = None) -> Tensor:
+    """out[M,N] (f32) += a[R,M]^T @ b[R,N]."""
+    M = a.shape[1] if M is None else M
+    N = b.shape[1] if N is None else N
+    _call("dl_gemm_tn", _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, a.shape[0], _s())
+    return out
+
+
+# ------------------------------------------------------------------ block kernels
+def ln_modulate_fwd(x, w, b, scale, shift, rows_per_mod, eps, out, mean, rstd):
+    M, D = x.shape
+    _call("dl_ln_modulate_fwd", _p(x), _p(w), _p(b), _p(scale), _p(shift), scale.stride(0), rows_per_mod, float(eps),
+          _p(out), _p(mean), _p(rstd), M, D, _s())
+    return out
+
+
+def ln_modulate_bwd(dout, x, w, b, scale, rows_per_mod, mean, rstd, dres, dx, dscale, dshift, dwb_partial):
+    M, D = x.shape
+    _call("dl_ln_modulate_bwd", _p(dout), _p(x), _p(w), _p(b), _p(scale), scale.stride(0), rows_per_mod, _p(mean),
+          _p(rstd), _p(dres), _p(dx), _p(dscale), _p(dshift), dscale.stride(0), _p(dwb_partial), M, D, _s())
+    return dx
+
+
+def gate_bwd(dout, t, gate, rows_per_mod, dt, dgate):
+    M, D = dout.shape
+    _call("dl_gate_bwd", _p(dout), _p(t), _p(gate), gate.stride(0), rows_per_mod, _p(dt), _p(dgate), dgate.stride(0), M,
+          D, _s())
+
+
+def qk_norm_rope_fwd(qkv, scale_q, scale_k, cos, sin, q, k, v, rrms, B, N, H, dh, rot, eps=1e-6):
+    _call("dl_qk_norm_rope_fwd", _p(qkv), _p(scale_q), _p(scale_k), _p(cos), _p(sin), _p(q), _p(k), _p(v), _p(rrms), B, N,
+          H, dh, rot, float(eps), _s())
+
+
+def qk_norm_rope_bwd(dq, dk, dv, qkv, scale_q, scale_k, cos, sin, rrms, dqkv, dscale, B, N, H, dh, rot):
+    _call("dl_qk_norm_rope_bwd", _p(dq), _p(dk), _p(dv), _p(qkv), _p(scale_q), _p(scale_k), _p(cos), _p(sin), _p(rrms),
+          _p(dqkv), _p(dscale), B, N, H, dh, rot, _s())
+
+
+def attn_fwd(q, k, v, out, lse, B, H, N, dh, scale):
+    _call("dl_attn_fwd", _p(q), _p(k), _p(v), _p(out), _p(lse), B, H, N, dh, float(scale), _s())
+
+
+def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, N, dh, scale):
+    _call("dl_attn_bwd", _p(q), _p(k), _p(v), _p(out), _p(dout), _p(lse), _p(dq), _p(dk), _p(dv), B, H, N, dh,
+          float(scale), _s())
+
+
+def swiglu_fwd(u, h):
+    _call("dl_swiglu_fwd", _p(u), _p(h), u.shape[0], h.shape[1], _s())
+
+
+def swiglu_bwd(dh, u, du):
+    _call("dl_swiglu_bwd", _p(dh), _p(u), _p(du), u.shape[0], dh.shape[1], _s())
+
+
+# ------------------------------------------------------------------ stem / head / conditioning
+def patchify(x, tok, p, order):
+    B, C, H, W = x.shape
+    _call("dl_patchify", _p(x), _p(tok), B, C, H, W, p, tok.stride(0), order, _s())
+
+
+def unpatchify(tok, img, p):
+    B, C, H, W = img.shape
+    _call("dl_unpatchify", _p(tok), _p(img), B, C, H, W, p, tok.stride(0), _s())
+
+
+def timestep_embedding(t, out, max_period=10000.0):
+    _call("dl_timestep_embedding", _p(t), _p(out), out.shape[0], out.shape[1], float(max_period), _s())
+
+
+def cond_combine_fwd(e, table, idx, emb, act):
+    _call("dl_cond_combine_fwd", _p(e), _p(table), _p(idx), _p(emb), _p(act), e.shape[0], e.shape[1], _s())
+
+
+def cond_combine_bwd(dact, emb, idx, demb, demb16, dtable):
+    _call("dl_cond_combine_bwd", _p(dact), _p(emb), _p(idx), _p(demb), _p(demb16), _p(dtable), emb.shape[0], emb.shape[1],
+          _s())
+
+
+def silu_bwd(dy, pre, dx):
+    _call("dl_silu_bwd", _p(dy), _p(pre), _p(dx), dy.numel(), _s())
+
+
+def colsum(x, out, R=None, C=None):
+    R = x.shape[0] if R is None else R
+    C = x.shape[1] if C is None else C
+    _call("dl_colsum", _p(x), F32 if x.dtype == torch.float32 else BF16, x.stride(0), _p(out), R, C, _s())
+
+
+def reduce_rows_f32(partial, out, G, n):
+    _call("dl_reduce_rows_f32", _p(partial), _p(out), G, n, _s())
+
+
+# ------------------------------------------------------------------ optimizer side
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    _call("dl_adamw_step", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+          float(wd), float(1.0 - beta1**step), float(1.0 - beta2**step), float(grad_scale), _s())
+
+
+def cast_weight(src, dst, dst_t):
+    R, C = src.shape
+    _call("dl_cast_weight", _p(src), R, C, _p(dst), dst.stride(0) if dst is not None else 0, _p(dst_t),
+          dst_t.stride(0) if dst_t is not None else 0, _s())
+
+
+def cast_f32_to_bf16(src, dst):
+    _call("dl_cast_f32_to_bf16", _p(src), _p(dst), src.numel(), _s())
+
+
+def cast_bf16_to_f32(src, dst):
+    _call("dl_cast_bf16_to_f32", _p(src), _p(dst), src.numel(), _s())
+
+
+def ema_update(ema, p, beta):
+    _call("dl_ema_update", _p(ema), _p(p), float(beta), p.numel(), _s())
+
+
+def probe_tr16() -> Tensor:
+    out = torch.zeros(256, dtype=torch.int16, device="cuda")
+    _call("dl_probe_tr16", _p(out), _s())
+    return out

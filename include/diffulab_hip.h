@@ -1,0 +1,204 @@
+/*
+ * libdiffulab_hip.so -- C ABI of the MI355X (gfx950) denoising hot path of DiffuLab.
+ *
+ * The reference (LouisRouss/DiffuLab) is pure Python on stock ATen ops and has NO FFI of its own
+ * (SURVEY.md §2.1); this header is therefore the boundary the build introduces, and every entry point
+ * names the reference site (path relative to /root/reference/src/diffulab, file:line) whose arithmetic
+ * it replaces.  INTEGRATION.md shows the ctypes stubs a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 (DL_OK) or a negative DL_ERR_*; dl_last_error() gives the thread-local text;
+ *     nothing throws across the ABI.
+ *   - all pointers are DEVICE pointers owned by the caller (torch allocations in the Python host);
+ *     the library allocates no device memory and keeps no global mutable state.
+ *   - `stream` is the caller's hipStream_t (torch.cuda.current_stream().cuda_stream); launches are async.
+ *   - "bf16" tensors are raw uint16 bfloat16 bits, row-major; `ld*` are row strides in ELEMENTS.
+ *   - token tensors are [M, D] with M = batch * tokens; `rows_per_*` = tokens per batch element for
+ *     per-sample broadcast operands (modulation / gates), 1 for per-token operands (DDT-style).
+ */
+#ifndef DIFFULAB_HIP_H
+#define DIFFULAB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DL_API __attribute__((visibility("default")))
+
+typedef void* dl_stream_t;
+
+enum { DL_OK = 0, DL_ERR_INVALID = -1, DL_ERR_LAUNCH = -2, DL_ERR_UNSUPPORTED = -3 };
+enum { DL_BF16 = 0, DL_F32 = 1 };
+enum { DL_ACT_NONE = 0, DL_ACT_SILU = 1 };
+enum { DL_LOSS_FLOW = 0, DL_LOSS_EPS = 1 };                       /* target = a - b | target = a */
+enum { DL_MEAN_EPSILON = 0, DL_MEAN_XSTART = 1, DL_MEAN_XPREV = 2 };
+enum { DL_PATCH_CPP = 0, DL_PATCH_PPC = 1 };                      /* feature order (c p1 p2) | (p1 p2 c) */
+
+/* ------------------------------------------------------------------ library */
+DL_API int dl_version(void);
+DL_API const char* dl_last_error(void);
+/* name_len bytes of `arch` receive e.g. "gfx950:sramecc+:xnack-" */
+DL_API int dl_device_info(int device, int* cu_count, int* lds_bytes_per_cu, int64_t* hbm_bytes, char* arch,
+                          int arch_len);
+
+/* ------------------------------------------------------------------ diffusion heads (f32 images [B, chw]) */
+/* Flow.add_noise, diffuse/modelizations/flow.py:401-408:  z = (1 - t[b]) x + t[b] eps */
+DL_API int dl_flow_add_noise(const float* x, const float* noise, const float* t, float* z, int64_t batch,
+                             int64_t chw, dl_stream_t stream);
+/* GaussianDiffusion.add_noise, gaussian_diffusion.py:338-341 + diffuse/utils.py:16:
+ * xt = sqrt_ab[t] x + sqrtf(1 - ab[t]) eps ; tables are the .float() casts of the fp64 tables */
+DL_API int dl_ddpm_add_noise(const float* x, const float* noise, const int32_t* t, const float* sqrt_ab,
+                             const float* ab, float* xt, int64_t batch, int64_t chw, dl_stream_t stream);
+/* Flow.compute_loss flow.py:306-309 (mode DL_LOSS_FLOW, a=noise, b=x0) and GaussianDiffusion.compute_loss
+ * gaussian_diffusion.py:306 (mode DL_LOSS_EPS, a=noise): loss = mean((target - pred)^2).
+ * `partial` is caller scratch of dl_mse_loss_partials(n) floats; reduction order is fixed (deterministic). */
+DL_API int64_t dl_mse_loss_partials(int64_t n);
+DL_API int dl_mse_loss_fwd(const float* pred, const float* a, const float* b, float* partial, float* loss,
+                           int64_t n, int mode, dl_stream_t stream);
+/* dpred = gscale * 2 (pred - target) / n   (gscale: upstream d(total)/d(loss), host scalar) */
+DL_API int dl_mse_loss_bwd(const float* pred, const float* a, const float* b, float gscale, float* dpred,
+                           int64_t n, int mode, dl_stream_t stream);
+/* Flow.compute_loss x-prediction branch flow.py:300-303: v = (z - xhat) / t[b] ; backward dxhat = -dv / t[b] */
+DL_API int dl_flow_x_to_v(const float* z, const float* xhat, const float* t, float* v, int64_t batch,
+                          int64_t chw, dl_stream_t stream);
+DL_API int dl_flow_x_to_v_bwd(const float* dv, const float* t, float* dxhat, int64_t batch, int64_t chw,
+                              dl_stream_t stream);
+
+/* ------------------------------------------------------------------ sampler steps */
+/* Euler.step euler.py:37-41 fused with the CFG combine flow.py:257-259 (v_uncond may be NULL):
+ * v = v_uncond + g (v - v_uncond); x_prev = x - v dt; x0 = x - v t_curr   (x0_est may be NULL) */
+DL_API int dl_euler_step(const float* x, const float* v, const float* v_uncond, float guidance, float t_curr,
+                         float dt, float* x_prev, float* x0_est, int64_t n, dl_stream_t stream);
+/* EulerMaruyama.step euler_meruyama.py:39-57.  sigma, std = sigma*sqrt(dt) are host scalars (python floats in
+ * the reference).  Exactly one of noise / x_prev_in is non-NULL.  logprob may be NULL. */
+DL_API int dl_euler_maruyama_step(const float* x, const float* v, const float* v_uncond, float guidance,
+                                  const float* noise, const float* x_prev_in, float t_curr, float dt, float sigma,
+                                  float std, float* x_prev, float* mean, float* x0_est, float* logprob,
+                                  int64_t n, dl_stream_t stream);
+/* DDPM.step ddpm.py:330-363 (+ CFG combine gaussian_diffusion.py:253-255), fixed variances.
+ * tables: f32 [6][T] = sqrt_ab, ab, posterior_mean_coef1, coef2, variance, log_variance (already
+ * selected for fixed_small / fixed_large by the host).  noise replaces randn_like (ddpm.py:302). */
+DL_API int dl_ddpm_step(const float* pred, const float* pred_uncond, float guidance, const float* xt,
+                        const float* noise, const int32_t* t, const float* tables, int32_t T, int mean_type,
+                        int clamp_x, float* x_prev, float* x0_est, float* mean, float* std, float* logprob,
+                        int64_t batch, int64_t chw, dl_stream_t stream);
+/* DDIM.step ddim.py:68-103.  tables: f32 [3][T] = sqrt_ab, ab, ab_prev.  std/logprob may be NULL (eta == 0). */
+DL_API int dl_ddim_step(const float* pred, const float* pred_uncond, float guidance, const float* xt,
+                        const float* noise, const int32_t* t, const float* tables, int32_t T, int mean_type,
+                        const float* ddpm_coefs /* f32 [2][T] coef1, coef2; only for DL_MEAN_XPREV */,
+                        int clamp_x, float eta, float* x_prev, float* x0_est, float* mean, float* std,
+                        float* logprob, int64_t batch, int64_t chw, dl_stream_t stream);
+
+/* ------------------------------------------------------------------ GEMMs (bf16 in, f32 MFMA accumulate) */
+/* nn.Linear forward / dgrad (mmdit.py:81,102,260-264; nn.py:530; mmdit.py:542-548):
+ *   acc[m,n] = sum_k A[m,k] * B[n,k]           A:[M,K] lda, B:[N,K] ldb (torch Linear weight layout)
+ *   pre      = acc + bias[n]                    (bias f32, may be NULL)
+ *   if pre_out: pre_out[m,n] = bf16(pre)        (saved pre-activation, ld = ldc)
+ *   val      = act(pre)
+ *   if resid: val = resid[m,n] + gate[m / rows_per_gate, n] * val      (gate may be NULL -> 1)
+ *   C[m,n]   = val  (bf16 or f32 per out_dtype)
+ * K must be a multiple of 64 (callers zero-pad tiny K); M, N arbitrary. */
+DL_API int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                      int64_t N, int64_t K, const float* bias, int act, int out_dtype, void* pre_out,
+                      const void* resid, int64_t ldr, const void* gate, int64_t ldg, int64_t rows_per_gate,
+                      dl_stream_t stream);
+/* nn.Linear wgrad:  C[m,n] += sum_r A[r,m] * B[r,n]   A:[R,M] lda, B:[R,N] ldb, C f32 [M,N] ldc (atomic
+ * accumulate across the split of R; caller zeroes C once per optimizer step).  R multiple of 64. */
+DL_API int dl_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                      int64_t N, int64_t R, dl_stream_t stream);
+
+/* ------------------------------------------------------------------ adaLN / norms */
+/* modulate(LayerNorm(x)) mmdit.py:299,305,547 + nn.py:539:  out = (LN(x) * w + b) * (1 + scale) + shift.
+ * w/b f32 [D] or NULL (norm_final has no affine); scale/shift bf16 rows with stride ld_mod, one row per
+ * rows_per_mod tokens.  mean/rstd f32 [M] saved for the backward. */
+DL_API int dl_ln_modulate_fwd(const void* x, const float* w, const float* b, const void* scale, const void* shift,
+                              int64_t ld_mod, int64_t rows_per_mod, float eps, void* out, float* mean,
+                              float* rstd, int64_t M, int64_t D, dl_stream_t stream);
+/* backward of the above, fused with the residual-stream add:
+ *   dx[m,:]    = dres[m,:] + dLN(...)           (dres may be NULL)
+ *   dscale[g,:] = sum_{m in g} dout * (xhat*w+b) ; dshift[g,:] = sum dout          (bf16 rows, stride ld_dmod)
+ *   dwb_partial f32 [groups, 2, D]: per-group partial sums of dw, db (NULL when w == NULL);
+ * one workgroup per group of rows_per_mod rows. */
+DL_API int dl_ln_modulate_bwd(const void* dout, const void* x, const float* w, const float* b, const void* scale,
+                              int64_t ld_mod, int64_t rows_per_mod, const float* mean, const float* rstd,
+                              const void* dres, void* dx, void* dscale, void* dshift, int64_t ld_dmod,
+                              float* dwb_partial, int64_t M, int64_t D, dl_stream_t stream);
+/* x_new = x + gate * t backward (mmdit.py:296-307): dt = gate * dout ; dgate[g,:] = sum_{m in g} dout * t */
+DL_API int dl_gate_bwd(const void* dout, const void* t, const void* gate, int64_t ld_mod, int64_t rows_per_mod,
+                       void* dt, void* dgate, int64_t ld_dmod, int64_t M, int64_t D, dl_stream_t stream);
+/* QKNorm (nn.py:427-431,473-475: RMS over the FULL inner dim, eps 1e-6) + N-D RoPE on interleaved pairs
+ * (nn.py:345-353,377-400) + head split 'b n (h d) -> b h n d' (mmdit.py:85-91).
+ * qkv bf16 [B*N, 3D]; cos/sin f32 [N, rot/2]; q,k,v out bf16 [B,H,N,dh]; rrms f32 [B*N, 2] saved. */
+DL_API int dl_qk_norm_rope_fwd(const void* qkv, const float* scale_q, const float* scale_k, const float* cos,
+                               const float* sin, void* q, void* k, void* v, float* rrms, int64_t B, int64_t N,
+                               int64_t H, int64_t dh, int64_t rot, float eps, dl_stream_t stream);
+/* dscale f32 [2, D] is atomically accumulated (caller zeroes once per step). */
+DL_API int dl_qk_norm_rope_bwd(const void* dq, const void* dk, const void* dv, const void* qkv,
+                               const float* scale_q, const float* scale_k, const float* cos, const float* sin,
+                               const float* rrms, void* dqkv, float* dscale, int64_t B, int64_t N, int64_t H,
+                               int64_t dh, int64_t rot, dl_stream_t stream);
+/* F.scaled_dot_product_attention mmdit.py:92-100, no mask: out = softmax(q k^T * scale) v, written as
+ * 'b h n d -> b n (h d)'.  lse f32 [B,H,N] = natural-log-sum-exp of the scaled scores (for the backward).
+ * dh must be 64; N a multiple of 64, N <= 512 (K and V of one head stay resident in LDS). */
+DL_API int dl_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int64_t B, int64_t H,
+                       int64_t N, int64_t dh, float scale, dl_stream_t stream);
+DL_API int dl_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                       const float* lse, void* dq, void* dk, void* dv, int64_t B, int64_t H, int64_t N,
+                       int64_t dh, float scale, dl_stream_t stream);
+/* PackedSwiGLU nn.py:484-486: h = silu(u[:, :F]) * u[:, F:] ; u bf16 [M, 2F] */
+DL_API int dl_swiglu_fwd(const void* u, void* h, int64_t M, int64_t F, dl_stream_t stream);
+DL_API int dl_swiglu_bwd(const void* dh, const void* u, void* du, int64_t M, int64_t F, dl_stream_t stream);
+
+/* ------------------------------------------------------------------ stem / head / conditioning */
+/* im2row for conv_proj (mmdit.py:757-765, order DL_PATCH_CPP) and the transpose of unpatchify
+ * (mmdit.py:778-787, order DL_PATCH_PPC): x f32 [B,C,H,W] -> tok bf16 [B*gh*gw, ld] (cols >= C*p*p zeroed) */
+DL_API int dl_patchify(const float* x, void* tok, int64_t B, int64_t C, int64_t H, int64_t W, int64_t p,
+                       int64_t ld, int order, dl_stream_t stream);
+/* unpatchify mmdit.py:778-787: tok f32 [B*gh*gw, ld] (p1 p2 c) -> img f32 [B,C,H,W] */
+DL_API int dl_unpatchify(const float* tok, float* img, int64_t B, int64_t C, int64_t H, int64_t W, int64_t p,
+                         int64_t ld, dl_stream_t stream);
+/* timestep_embedding nn.py:106-114: out[b,:] = [cos(t f_i) | sin(t f_i)], bf16 [B, dim] (dim even) */
+DL_API int dl_timestep_embedding(const float* t, void* out, int64_t B, int64_t dim, float max_period,
+                                 dl_stream_t stream);
+/* emb = e + table[idx] (mmdit.py:867-868, nn.py:162-163; idx NULL -> no label term), act = silu(emb) as
+ * bf16 (input of every Modulation / adaLN linear, nn.py:531, mmdit.py:540) */
+DL_API int dl_cond_combine_fwd(const float* e, const float* table, const int64_t* idx, float* emb, void* act,
+                               int64_t B, int64_t E, dl_stream_t stream);
+/* demb = dact * silu'(emb) (f32 + bf16 copies); dtable[idx[b],:] += demb[b,:] (atomic; dtable may be NULL) */
+DL_API int dl_cond_combine_bwd(const float* dact, const float* emb, const int64_t* idx, float* demb,
+                               void* demb_bf16, float* dtable, int64_t B, int64_t E, dl_stream_t stream);
+/* dx = dy * silu'(pre) ; pre bf16 (saved pre-activation), dy f32, dx bf16 */
+DL_API int dl_silu_bwd(const float* dy, const void* pre, void* dx, int64_t n, dl_stream_t stream);
+/* out[c] += sum_r x[r,c]  (bias gradients); x bf16 or f32 per dtype */
+DL_API int dl_colsum(const void* x, int dtype, int64_t ld, float* out, int64_t R, int64_t C,
+                     dl_stream_t stream);
+/* out[j] += sum_g partial[g, j]   (second stage of the LayerNorm affine gradients) */
+DL_API int dl_reduce_rows_f32(const float* partial, float* out, int64_t G, int64_t n, dl_stream_t stream);
+
+/* ------------------------------------------------------------------ optimizer side */
+/* torch.optim.AdamW single-tensor math (configs/optimizer/adamw.yaml) over a flat f32 buffer:
+ *   p *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= (lr/bc1) m / (sqrt(v)/sqrt(bc2) + eps) */
+DL_API int dl_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
+                         float grad_scale, dl_stream_t stream);
+/* bf16 shadow of an f32 [R,C] weight: dst [R, ld_dst] (cols >= C zeroed up to ld_dst) and/or the transpose
+ * dstT [C, ld_t] (cols >= R zeroed up to ld_t).  Either destination may be NULL. */
+DL_API int dl_cast_weight(const float* src, int64_t R, int64_t C, void* dst, int64_t ld_dst, void* dstT,
+                          int64_t ld_t, dl_stream_t stream);
+/* plain casts */
+DL_API int dl_cast_f32_to_bf16(const float* src, void* dst, int64_t n, dl_stream_t stream);
+DL_API int dl_cast_bf16_to_f32(const void* src, float* dst, int64_t n, dl_stream_t stream);
+/* ema = ema + (1 - beta) (p - ema)  == lerp used by ema_pytorch (base_trainer.py:152-153) */
+DL_API int dl_ema_update(float* ema, const float* p, float beta, int64_t n, dl_stream_t stream);
+
+/* ------------------------------------------------------------------ debugging probes (tests only) */
+/* raw ds_read_b64_tr_b16 lane map: fills out[64*4] with what each lane receives when lane l passes
+ * address 8*l over an LDS image holding the uint16 values 0..255 */
+DL_API int dl_probe_tr16(uint16_t* out, dl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFULAB_HIP_H */

@@ -1,0 +1,424 @@
+"""GPU parity tests, kernel by kernel, THROUGH THE C ABI (diffulab_amd.ops -> libdiffulab_hip.so).
+
+Each HIP kernel is compared with the CPU oracle (oracle/) or, for plain linear algebra, with an fp32 torch
+evaluation of the same bf16-rounded inputs.  Tolerances (stated per test):
+  * f32 elementwise heads / sampler steps: 1e-6 relative (fma contraction only);
+  * bf16-output kernels: relative L2 <= 4e-3 (one bf16 rounding of the result, 2^-9 per element);
+  * integer / index behaviour (label gather, timestep gather): exact.
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import diffusion as od  # noqa: E402
+from oracle import dit as odit  # noqa: E402
+from oracle import synth  # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import ctypes
+
+    from diffulab_amd import _lib, ops as _ops
+
+    assert _lib.available(), "libdiffulab_hip.so missing on the GPU box"
+    L = _lib.lib()
+    arch = ctypes.create_string_buffer(64)
+    cu, lds, hbm = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+    L.call("dl_device_info", 0, ctypes.byref(cu), ctypes.byref(lds), ctypes.byref(hbm), arch, 64)
+    print("device:", arch.value.decode(), cu.value, "CUs", lds.value, "B LDS", hbm.value / 2**30, "GiB")
+    assert arch.value.decode().startswith("gfx950")
+    return _ops
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def bf(x):  # bf16-rounded fp32 copy on CPU
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def dev_bf(x):
+    return x.to(torch.bfloat16).to(DEV).contiguous()
+
+
+# ------------------------------------------------------------------ hardware semantics the kernels rely on
+def test_probe_tr16_lane_map(ops):
+    """ds_read_b64_tr_b16: inside each 16-lane group, lane i receives element (i%4) of the 8 bytes addressed
+    by lane 4j + i/4, for j = 0..3 (a 4x16 transpose).  gemm_tn and attention are built on this."""
+    got = ops.probe_tr16().cpu().numpy().astype(np.int64).reshape(64, 4)
+    os.makedirs("gpurun_out", exist_ok=True)
+    np.savetxt("gpurun_out/probe_tr16.txt", got, fmt="%d")
+    exp = np.zeros((64, 4), dtype=np.int64)
+    for lane in range(64):
+        g, i = lane // 16, lane % 16
+        for j in range(4):
+            src_lane = g * 16 + 4 * j + i // 4
+            exp[lane, j] = src_lane * 4 + (i % 4)
+    assert np.array_equal(got, exp), got[:20]
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(256, 384, 384), (300, 1152, 384), (64, 16, 384), (2, 384, 256), (512, 384, 1536),
+                                   (1024, 3072, 384), (130, 72, 64)])
+def test_gemm_nt_plain(ops, M, N, K):
+    a = synth.normal(f"nt.a{M}", (M, K))
+    b = synth.normal(f"nt.b{N}", (N, K), std=K**-0.5)
+    out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt(dev_bf(a), dev_bf(b), out)
+    ref = bf(a) @ bf(b).t()
+    assert rel(out.float(), ref) < 4e-3
+    out32 = torch.empty(M, N, device=DEV, dtype=torch.float32)
+    ops.gemm_nt(dev_bf(a), dev_bf(b), out32)
+    assert rel(out32, ref) < 2e-5  # f32 accumulate, order differs only
+
+
+def test_gemm_nt_epilogues(ops):
+    M, N, K, rows = 512, 384, 384, 128
+    a, b = synth.normal("ep.a", (M, K)), synth.normal("ep.b", (N, K), std=K**-0.5)
+    bias = synth.normal("ep.bias", (N,))
+    resid = synth.normal("ep.res", (M, N))
+    gate = synth.normal("ep.gate", (M // rows, 2 * N))  # strided gate rows (ld = 2N)
+    acc = bf(a) @ bf(b).t() + bias
+    # bias + silu + pre_out
+    out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    pre = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt(dev_bf(a), dev_bf(b), out, bias=bias.to(DEV), act=ops.ACT_SILU, pre_out=pre)
+    assert rel(pre.float(), acc) < 4e-3
+    assert rel(out.float(), odit.silu(acc)) < 4e-3
+    # gated residual
+    g_dev = dev_bf(gate)
+    ops.gemm_nt(dev_bf(a), dev_bf(b), out, resid=dev_bf(resid), gate=g_dev[:, N:], rows_per_gate=rows)
+    ref = bf(resid) + bf(gate)[:, N:].repeat_interleave(rows, 0) * (bf(a) @ bf(b).t())
+    assert rel(out.float(), ref) < 4e-3
+    # plain residual (no gate), f32 out
+    o32 = torch.empty(M, N, device=DEV, dtype=torch.float32)
+    ops.gemm_nt(dev_bf(a), dev_bf(b), o32, resid=dev_bf(resid))
+    assert rel(o32, bf(resid) + bf(a) @ bf(b).t()) < 2e-5
+
+
+@pytest.mark.parametrize("R,M,N", [(1024, 384, 1152), (128, 16, 384), (256, 2304, 64), (4096, 384, 384), (64, 136, 264)])
+def test_gemm_tn(ops, R, M, N):
+    a = synth.normal(f"tn.a{R}{M}", (R, M))
+    b = synth.normal(f"tn.b{R}{N}", (R, N))
+    init = synth.normal(f"tn.c{M}{N}", (M, N))
+    c = init.to(DEV).clone()
+    ops.gemm_tn(dev_bf(a), dev_bf(b), c)
+    ref = init + bf(a).t() @ bf(b)
+    assert rel(c, ref) < 2e-5
+
+
+# ------------------------------------------------------------------ adaLN
+@pytest.mark.parametrize("D,affine", [(384, True), (768, True), (384, False), (128, True)])
+def test_ln_modulate_fwd_bwd(ops, D, affine):
+    B, N = 3, 64
+    M = B * N
+    x = bf(synth.normal("ln.x", (M, D))).requires_grad_(True)
+    mod = bf(synth.normal("ln.mod", (B, 3 * D), std=0.3))
+    sc, sh = mod[:, :D].clone().requires_grad_(True), mod[:, D : 2 * D].clone().requires_grad_(True)
+    w = (1 + synth.normal("ln.w", (D,), std=0.1)).requires_grad_(affine)
+    b = synth.normal("ln.b", (D,), std=0.1).requires_grad_(affine)
+    eps = 1e-5 if affine else 1e-6
+    xb = x.reshape(B, N, D)
+    y = odit.layer_norm(xb, w if affine else None, b if affine else None, eps) * (1 + sc[:, None]) + sh[:, None]
+    dy = bf(synth.normal("ln.dy", (M, D)))
+    dres = bf(synth.normal("ln.dres", (M, D)))
+    y.reshape(M, D).backward(dy)
+
+    mod_d = dev_bf(mod)
+    out = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    mean = torch.empty(M, device=DEV)
+    rstd = torch.empty(M, device=DEV)
+    wd, bd = (w.detach().to(DEV), b.detach().to(DEV)) if affine else (None, None)
+    ops.ln_modulate_fwd(dev_bf(x.detach()), wd, bd, mod_d[:, :D], mod_d[:, D : 2 * D], N, eps, out, mean, rstd)
+    assert rel(out.float(), y.reshape(M, D)) < 4e-3
+    dx = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    dmod = torch.zeros(B, 3 * D, device=DEV, dtype=torch.bfloat16)
+    dwb = torch.zeros(B, 2, D, device=DEV) if affine else None
+    ops.ln_modulate_bwd(dev_bf(dy), dev_bf(x.detach()), wd, bd, mod_d[:, :D], N, mean, rstd, dev_bf(dres), dx,
+                        dmod[:, :D], dmod[:, D : 2 * D], dwb)
+    assert rel(dx.float(), x.grad + dres) < 5e-3
+    assert rel(dmod[:, :D].float(), sc.grad) < 5e-3
+    assert rel(dmod[:, D : 2 * D].float(), sh.grad) < 5e-3
+    if affine:
+        acc = torch.zeros(2 * D, device=DEV)
+        ops.reduce_rows_f32(dwb, acc, B, 2 * D)
+        assert rel(acc[:D], w.grad) < 1e-4 and rel(acc[D:], b.grad) < 1e-4
+    # no residual input
+    ops.ln_modulate_bwd(dev_bf(dy), dev_bf(x.detach()), wd, bd, mod_d[:, :D], N, mean, rstd, None, dx, dmod[:, :D],
+                        dmod[:, D : 2 * D], dwb)
+    assert rel(dx.float(), x.grad) < 5e-3
+
+
+def test_gate_bwd(ops):
+    B, N, D = 3, 64, 384
+    M = B * N
+    dout, t = bf(synth.normal("g.do", (M, D))), bf(synth.normal("g.t", (M, D)))
+    gate = bf(synth.normal("g.g", (B, 2 * D)))
+    dt = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    dg = torch.zeros(B, 2 * D, device=DEV, dtype=torch.bfloat16)
+    gd = dev_bf(gate)
+    ops.gate_bwd(dev_bf(dout), dev_bf(t), gd[:, D:], N, dt, dg[:, D:])
+    assert rel(dt.float(), dout * gate[:, D:].repeat_interleave(N, 0)) < 4e-3
+    assert rel(dg[:, D:].float(), (dout * t).reshape(B, N, D).sum(1)) < 4e-3
+
+
+# ------------------------------------------------------------------ QK norm + rope
+@pytest.mark.parametrize("H,gh,gw", [(6, 8, 8), (2, 4, 16), (12, 8, 8)])
+def test_qk_norm_rope_fwd_bwd(ops, H, gh, gw):
+    B, dh = 2, 64
+    N, D = gh * gw, H * dh
+    M = B * N
+    qkv = bf(synth.normal("qk.qkv", (M, 3 * D))).requires_grad_(True)
+    sq = (1 + synth.normal("qk.sq", (D,), std=0.1)).requires_grad_(True)
+    sk = (1 + synth.normal("qk.sk", (D,), std=0.1)).requires_grad_(True)
+    cos, sin = odit.rope_tables(gh, gw, [32, 32], 10_000.0)
+    q, k, v = qkv.reshape(B, N, 3 * D).split(D, dim=-1)
+    qr = odit.apply_rope(odit.rms_norm(q, sq).reshape(B, N, H, dh), cos, sin).transpose(1, 2)
+    kr = odit.apply_rope(odit.rms_norm(k, sk).reshape(B, N, H, dh), cos, sin).transpose(1, 2)
+    vr = v.reshape(B, N, H, dh).transpose(1, 2)
+    dq, dk, dv = (bf(synth.normal(f"qk.d{n}", (B, H, N, dh))) for n in "qkv")
+    (qr * dq).sum().add((kr * dk).sum()).add((vr * dv).sum()).backward()
+
+    qo, ko, vo = (torch.empty(B, H, N, dh, device=DEV, dtype=torch.bfloat16) for _ in range(3))
+    rrms = torch.empty(M, 2, device=DEV)
+    ops.qk_norm_rope_fwd(dev_bf(qkv.detach()), sq.detach().to(DEV), sk.detach().to(DEV), cos.to(DEV), sin.to(DEV), qo,
+                         ko, vo, rrms, B, N, H, dh, 64)
+    assert rel(qo.float(), qr) < 4e-3 and rel(ko.float(), kr) < 4e-3
+    assert torch.equal(vo.float().cpu(), vr.detach())
+    dqkv = torch.empty(M, 3 * D, device=DEV, dtype=torch.bfloat16)
+    dscale = torch.zeros(2, D, device=DEV)
+    ops.qk_norm_rope_bwd(dev_bf(dq), dev_bf(dk), dev_bf(dv), dev_bf(qkv.detach()), sq.detach().to(DEV),
+                         sk.detach().to(DEV), cos.to(DEV), sin.to(DEV), rrms, dqkv, dscale, B, N, H, dh, 64)
+    assert rel(dqkv.float(), qkv.grad) < 5e-3
+    assert rel(dscale[0], sq.grad) < 1e-4 and rel(dscale[1], sk.grad) < 1e-4
+
+
+# ------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,H,N", [(2, 6, 256), (1, 2, 64), (3, 3, 128)])
+def test_attention_fwd_bwd(ops, B, H, N):
+    dh = 64
+    q, k, v = (bf(synth.normal(f"at.{n}{N}", (B, H, N, dh))).requires_grad_(True) for n in "qkv")
+    scale = dh**-0.5
+    o = odit.attention(q, k, v, scale)  # [B,H,N,dh]
+    o_tok = o.transpose(1, 2).reshape(B, N, H * dh)
+    do = bf(synth.normal(f"at.do{N}", (B, N, H * dh)))
+    o_tok.backward(do)
+    lse_ref = torch.logsumexp(q.detach() @ k.detach().transpose(-1, -2) * scale, dim=-1)
+
+    out = torch.empty(B, N, H * dh, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(B, H, N, device=DEV)
+    qd, kd, vd = dev_bf(q.detach()), dev_bf(k.detach()), dev_bf(v.detach())
+    ops.attn_fwd(qd, kd, vd, out, lse, B, H, N, dh, scale)
+    assert rel(out.float(), o_tok) < 5e-3
+    assert rel(lse, lse_ref) < 1e-4
+    dq, dk, dv = (torch.empty(B, H, N, dh, device=DEV, dtype=torch.bfloat16) for _ in range(3))
+    ops.attn_bwd(qd, kd, vd, out, dev_bf(do), lse, dq, dk, dv, B, H, N, dh, scale)
+    assert rel(dv.float(), v.grad) < 8e-3
+    assert rel(dq.float(), q.grad) < 8e-3
+    assert rel(dk.float(), k.grad) < 8e-3
+
+
+def test_attention_peaked_rows(ops):
+    """online-softmax rescale branch: one key dominates per query at a late key tile (guide rule 26)."""
+    B, H, N, dh = 1, 1, 256, 64
+    q, k, v = (bf(synth.normal(f"pk.{n}", (B, H, N, dh))) for n in "qkv")
+    k[0, 0, 200] = q[0, 0, 7] * 4.0  # score spike for query 7 at key 200 (4th key tile)
+    k = bf(k)
+    scale = dh**-0.5
+    ref = odit.attention(q, k, v, scale).transpose(1, 2).reshape(B, N, dh)
+    out = torch.empty(B, N, dh, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(B, H, N, device=DEV)
+    ops.attn_fwd(dev_bf(q), dev_bf(k), dev_bf(v), out, lse, B, H, N, dh, scale)
+    assert (out.float().cpu() - ref).abs().max() < 3e-2
+    assert rel(out.float(), ref) < 5e-3
+
+
+# ------------------------------------------------------------------ swiglu / small ops
+def test_swiglu(ops):
+    M, F = 192, 1536
+    u = bf(synth.normal("sw.u", (M, 2 * F))).requires_grad_(True)
+    h = odit.silu(u[:, :F]) * u[:, F:]
+    dh = bf(synth.normal("sw.dh", (M, F)))
+    h.backward(dh)
+    ho = torch.empty(M, F, device=DEV, dtype=torch.bfloat16)
+    ops.swiglu_fwd(dev_bf(u.detach()), ho)
+    assert rel(ho.float(), h) < 4e-3
+    du = torch.empty(M, 2 * F, device=DEV, dtype=torch.bfloat16)
+    ops.swiglu_bwd(dev_bf(dh), dev_bf(u.detach()), du)
+    assert rel(du.float(), u.grad) < 4e-3
+
+
+def test_patchify_unpatchify(ops):
+    cfg = odit.DiTConfig(input_channels=3, output_channels=3, patch_size=2)
+    B, C, H, W, p = 2, 3, 8, 12, 2
+    x = synth.normal("pt.x", (B, C, H, W))
+    gh, gw = H // p, W // p
+    tok = torch.full((B * gh * gw, 64), 7.0, device=DEV, dtype=torch.bfloat16)
+    ops.patchify(x.to(DEV), tok, p, ops.PATCH_CPP)
+    ref = x.reshape(B, C, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, C * p * p)
+    assert torch.equal(tok[:, : C * p * p].float().cpu(), bf(ref))
+    assert (tok[:, C * p * p :] == 0).all()
+    t32 = synth.normal("pt.tok", (B * gh * gw, 16))
+    img = torch.empty(B, C, H, W, device=DEV)
+    ops.unpatchify(t32.to(DEV), img, p)
+    assert torch.equal(img.cpu(), odit.unpatchify(t32[:, :12].reshape(B, gh * gw, 12), gh, gw, cfg))
+    # PPC order == transpose of unpatchify
+    ops.patchify(img, tok, p, ops.PATCH_PPC)
+    assert torch.equal(tok[:, :12].float().cpu(), bf(t32[:, :12]))
+
+
+def test_timestep_embedding_and_cond(ops):
+    B, E = 5, 384
+    t = synth.uniform("te.t", (B,))
+    out = torch.empty(B, 256, device=DEV, dtype=torch.bfloat16)
+    ops.timestep_embedding(t.to(DEV), out)
+    assert (out.float().cpu() - odit.timestep_embedding(t, 256)).abs().max() < 4e-3  # one bf16 rounding of [-1,1]
+    ti = torch.tensor([0.0, 1.0, 17.0, 500.0, 999.0])
+    ops.timestep_embedding(ti.to(DEV), out)
+    assert (out.float().cpu() - odit.timestep_embedding(ti, 256)).abs().max() < 4.5e-3  # + fp32 sincos argument error
+    e = synth.normal("te.e", (B, E)).requires_grad_(True)
+    table = synth.normal("te.tab", (11, E)).requires_grad_(True)
+    idx = torch.tensor([3, 10, 3, 0, 7])
+    emb_ref = e + table[idx]
+    act_ref = odit.silu(emb_ref)
+    dact = synth.normal("te.dact", (B, E))
+    act_ref.backward(dact)
+    emb = torch.empty(B, E, device=DEV)
+    act = torch.empty(B, E, device=DEV, dtype=torch.bfloat16)
+    ops.cond_combine_fwd(e.detach().to(DEV), table.detach().to(DEV), idx.to(DEV), emb, act)
+    assert rel(emb, emb_ref) < 1e-6 and rel(act.float(), act_ref) < 4e-3
+    demb = torch.empty(B, E, device=DEV)
+    demb16 = torch.empty(B, E, device=DEV, dtype=torch.bfloat16)
+    dtab = torch.zeros(11, E, device=DEV)
+    ops.cond_combine_bwd(dact.to(DEV), emb, idx.to(DEV), demb, demb16, dtab)
+    assert rel(demb, e.grad) < 1e-5 and rel(dtab, table.grad) < 1e-5
+    # colsum (+= semantics) on both dtypes, strided
+    xs = synth.normal("cs.x", (300, 2 * E))
+    acc = torch.ones(E, device=DEV)
+    ops.colsum(xs.to(DEV)[:, E:], acc, 300, E)
+    assert rel(acc, 1 + xs[:, E:].sum(0)) < 1e-5
+    acc.zero_()
+    ops.colsum(dev_bf(xs)[:, :E], acc, 300, E)
+    assert rel(acc, bf(xs)[:, :E].sum(0)) < 1e-5
+    pre = bf(synth.normal("sb.pre", (B, E))).requires_grad_(True)
+    odit.silu(pre).backward(dact)
+    dx = torch.empty(B, E, device=DEV, dtype=torch.bfloat16)
+    ops.silu_bwd(dact.to(DEV), dev_bf(pre.detach()), dx)
+    assert rel(dx.float(), pre.grad) < 4e-3
+
+
+# ------------------------------------------------------------------ diffusion heads & sampler steps
+def test_noising_and_losses(ops):
+    B, shp = 5, (5, 4, 32, 32)
+    x, nz = synth.normal("h.x", shp), synth.normal("h.n", shp)
+    t = synth.uniform("h.t", (B,))
+    z = ops.flow_add_noise(x.to(DEV), nz.to(DEV), t.to(DEV))
+    assert rel(z, od.flow_add_noise(x, t, nz)) < 1e-6
+    T = od.GaussianTables(1000)
+    ti = torch.tensor([0, 3, 500, 998, 999], dtype=torch.int32)
+    xt = ops.ddpm_add_noise(x.to(DEV), nz.to(DEV), ti.to(DEV), T.sqrt_alphas_bar.float().to(DEV), T.alphas_bar.float().to(DEV))
+    assert rel(xt, od.ddpm_add_noise(T, x, ti, nz)) < 1e-6
+    pred = synth.normal("h.p", shp).requires_grad_(True)
+    l_ref = od.flow_loss(pred, x, nz)
+    l_ref.backward()
+    loss = ops.mse_loss_fwd(pred.detach().to(DEV), nz.to(DEV), x.to(DEV), ops.LOSS_FLOW)
+    assert abs(loss.item() - l_ref.item()) < 1e-6 * abs(l_ref.item())
+    dp = ops.mse_loss_bwd(pred.detach().to(DEV), nz.to(DEV), x.to(DEV), 1.0, ops.LOSS_FLOW)
+    assert rel(dp, pred.grad) < 1e-6
+    pred.grad = None
+    l2 = od.mse_loss(pred, nz)
+    l2.backward()
+    loss = ops.mse_loss_fwd(pred.detach().to(DEV), nz.to(DEV), None, ops.LOSS_EPS)
+    assert abs(loss.item() - l2.item()) < 1e-6 * abs(l2.item())
+    dp = ops.mse_loss_bwd(pred.detach().to(DEV), nz.to(DEV), None, 0.5, ops.LOSS_EPS)
+    assert rel(dp, 0.5 * pred.grad) < 1e-6
+    # odd sizes (not a multiple of 4) take the scalar path
+    xo, no_, to_ = synth.normal("h.xo", (3, 1, 5, 7)), synth.normal("h.no", (3, 1, 5, 7)), synth.uniform("h.to", (3,))
+    assert rel(ops.flow_add_noise(xo.to(DEV), no_.to(DEV), to_.to(DEV)), od.flow_add_noise(xo, to_, no_)) < 1e-6
+    v = ops.flow_x_to_v(z, pred.detach().to(DEV), t.clamp(min=0.05).to(DEV))
+    assert rel(v, od.flow_x_to_v(z.cpu(), pred.detach(), t.clamp(min=0.05))) < 1e-6
+
+
+def test_sampler_steps_against_reference_fixtures(ops, golden):
+    """the committed reference outputs (tests/golden/samplers.npz) are the expected values here."""
+    g = golden("samplers")
+    shp = (3, 4, 8, 8)
+    xt, v, nz = (synth.normal(k, shp).to(DEV) for k in ("smp.xt", "smp.v", "smp.noise"))
+    xp, x0 = ops.euler_step(xt, v, None, 0.0, 0.75, 0.5)
+    assert rel(xp, torch.from_numpy(g["euler_x_prev"])) < 1e-6 and rel(x0, torch.from_numpy(g["euler_x0"])) < 1e-6
+    # CFG fused into the step == combine then step
+    vu = synth.normal("smp.vu", shp)
+    xp, _ = ops.euler_step(xt, v, vu.to(DEV), 2.0, 0.75, 0.5)
+    assert rel(xp, od.euler_step(xt.cpu(), od.cfg_combine(v.cpu(), vu, 2.0), 0.75, 0.5)["x_prev"]) < 1e-6
+    tmax = od.flow_timesteps(10)[1]
+    sigma = ((0.6 / (1 - min(0.6, tmax))) ** 0.5) * 0.7
+    xp, mean, x0, lp, std = ops.euler_maruyama_step(xt, v, None, 0.0, torch.from_numpy(g["em_noise"]).to(DEV), None, 0.6,
+                                                    0.5, sigma)
+    for got, key in ((xp, "x_prev"), (mean, "x_prev_mean"), (x0, "estimated_x0"), (lp, "logprob")):
+        assert rel(got, torch.from_numpy(g["em_" + key])) < 2e-6, key
+    assert abs(std - float(g["em_x_prev_std"])) < 1e-7
+    sigma2 = ((1.0 / (1 - min(1.0, tmax))) ** 0.5) * 0.7
+    _, mean, _, lp, _ = ops.euler_maruyama_step(xt, v, None, 0.0, None, nz, 1.0, 0.9, sigma2)
+    assert rel(lp, torch.from_numpy(g["em2_logprob"])) < 2e-6 and rel(mean, torch.from_numpy(g["em2_mean"])) < 2e-6
+    T = od.GaussianTables(1000)
+    tt = torch.tensor([0, 7, 999], dtype=torch.int32).to(DEV)
+    dn = torch.from_numpy(g["ddpm_noise"]).to(DEV)
+    for vt in ("fixed_small", "fixed_large"):
+        if vt == "fixed_small":
+            var, lv = T.posterior_variance, T.posterior_log_variance_clipped
+        else:
+            var = torch.cat([T.posterior_variance[1:2], T.betas[1:]])
+            lv = torch.log(var)
+        tab = torch.stack([T.sqrt_alphas_bar, T.alphas_bar, T.posterior_mean_coef1, T.posterior_mean_coef2, var, lv]).float().to(DEV)
+        for mt in ("epsilon", "xstart", "xprev"):
+            for clamp in (False, True):
+                outs = ops.ddpm_step(v, None, 0.0, xt, dn, tt, tab, ops.MEAN_TYPES[mt], clamp)
+                tag = f"ddpm_{mt}_{vt}_{int(clamp)}_"
+                for got, key in zip(outs, ("x_prev", "estimated_x0", "x_prev_mean", "x_prev_std", "logprob")):
+                    assert rel(got, torch.from_numpy(g[tag + key])) < 3e-6, tag + key
+    tab3 = torch.stack([T.sqrt_alphas_bar, T.alphas_bar, T.alphas_bar_prev]).float().to(DEV)
+    for eta in (0.0, 0.5):
+        xp, x0, mean, std, lp = ops.ddim_step(v, None, 0.0, xt, torch.from_numpy(g["ddim_noise"]).to(DEV), tt, tab3, None,
+                                              ops.MEAN_TYPES["epsilon"], False, eta)
+        assert rel(xp, torch.from_numpy(g[f"ddim_eta{eta}_x_prev"])) < 3e-6
+        assert rel(x0, torch.from_numpy(g[f"ddim_eta{eta}_estimated_x0"])) < 3e-6
+        assert rel(mean, torch.from_numpy(g[f"ddim_eta{eta}_x_prev_mean"])) < 3e-6
+        if eta > 0:
+            assert rel(std, torch.from_numpy(g[f"ddim_eta{eta}_x_prev_std"])) < 3e-6
+            ref_lp = np.nan_to_num(g[f"ddim_eta{eta}_logprob"], nan=0, posinf=0, neginf=0)
+            assert rel(torch.nan_to_num(lp, 0, 0, 0), torch.from_numpy(ref_lp)) < 3e-6
+
+
+# ------------------------------------------------------------------ optimizer side
+def test_adamw_and_casts(ops):
+    n = 10007
+    p0, g = synth.normal("ad.p", (n,)), synth.normal("ad.g", (n,))
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8)
+    pad = 4 - n % 4
+    p = torch.cat([p0, torch.zeros(pad)]).to(DEV)[:n]
+    m, v = torch.zeros(n + pad, device=DEV)[:n], torch.zeros(n + pad, device=DEV)[:n]
+    for step in range(1, 4):
+        pr.grad = g * step
+        opt.step()
+        ops.adamw_step(p, (g * step).to(DEV), m, v, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+        assert rel(p, pr.detach()) < 1e-6, step
+    w = synth.normal("cw.w", (100, 72))
+    d = torch.full((100, 128), 5.0, device=DEV, dtype=torch.bfloat16)
+    dT = torch.full((72, 128), 5.0, device=DEV, dtype=torch.bfloat16)
+    ops.cast_weight(w.to(DEV), d, dT)
+    assert torch.equal(d[:, :72].float().cpu(), bf(w)) and (d[:, 72:] == 0).all()
+    assert torch.equal(dT[:, :100].float().cpu(), bf(w).t()) and (dT[:, 100:] == 0).all()
+    e = torch.zeros(n, device=DEV)
+    ops.ema_update(e, p, 0.9)
+    assert rel(e, 0.1 * p) < 1e-6
