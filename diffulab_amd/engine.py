@@ -1,0 +1,425 @@
+"""Host-side runtime of the DiT hot path: parameter arena, bf16 weight shadows, activation workspace and
+the forward / backward launch sequences over the C ABI.
+
+MI355X-first choices:
+  * all parameters live in ONE flat f32 HBM buffer (and one flat gradient buffer): the optimizer is a single
+    fused launch and the data-parallel reduction is a handful of large RCCL collectives on contiguous memory;
+  * the adaLN linears of every block (and of the last layer) are stored back to back so the modulation of the
+    whole network is ONE GEMM per step (the conditioning vector is layer-invariant);
+  * every activation is preallocated (288 GB of HBM3E: keep, don't recompute) so a step performs no
+    allocation and the launch sequence is static (hipGraph-capturable);
+  * residual stream and GEMM operands are bf16, accumulation / norm statistics / gradients of parameters f32.
+
+Reference sites restated by the sequences below: mmdit.py:853-928 (simple_dit_forward / forward),
+mmdit.py:288-309 (DiTBlock), mmdit.py:75-104 (DiTAttention), mmdit.py:542-549 (ModulatedLastLayer).
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import torch
+from torch import Tensor
+
+from . import ops
+
+
+def _rup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class DiTDims:
+    input_channels: int = 4
+    output_channels: int = 4
+    inner_dim: int = 384
+    embedding_dim: int = 384
+    num_heads: int = 6
+    mlp_ratio: int = 4
+    patch_size: int = 2
+    depth: int = 12
+    rope_base: float = 10_000.0
+    frequency_embedding: int = 256
+    n_classes: int | None = 1000
+    classifier_free: bool = True
+    rope_axes_dim: list[int] = field(default_factory=list)
+
+    def __post_init__(self) -> None:
+        if not self.rope_axes_dim:
+            hd = self.inner_dim // self.num_heads
+            self.rope_axes_dim = [hd // 2, hd // 2]
+
+    @property
+    def head_dim(self) -> int:
+        return self.inner_dim // self.num_heads
+
+    def validate(self) -> None:
+        D, E = self.inner_dim, self.embedding_dim
+        if self.head_dim != 64:
+            raise NotImplementedError(f"HIP attention kernels are built for head_dim 64 (got {self.head_dim})")
+        if D % 64 or E % 64 or self.frequency_embedding % 64:
+            raise NotImplementedError("inner_dim, embedding_dim and frequency_embedding must be multiples of 64")
+        if D > 1024:
+            raise NotImplementedError("row kernels support inner_dim <= 1024")
+        if sum(self.rope_axes_dim) > self.head_dim or sum(self.rope_axes_dim) % 8:
+            raise NotImplementedError("rotary width must be a multiple of 8 and <= head_dim")
+        if len(self.rope_axes_dim) != 2:
+            raise NotImplementedError("simple_dit uses a 2-axis (row, col) RoPE")
+
+
+def rope_grid_tables(gh: int, gw: int, axes_dim: list[int], base: float) -> tuple[Tensor, Tensor]:
+    """cos/sin tables [gh*gw, sum(axes)/2] of the 2-D grid, angles in fp64 then cast to fp32 exactly like
+    nn.py:276-307 applied to the meshgrid(indexing='ij') ids of mmdit.py:871-886 (row axis first)."""
+    pos = (torch.arange(gh, dtype=torch.float64).repeat_interleave(gw), torch.arange(gw, dtype=torch.float64).repeat(gh))
+    cs, sn = [], []
+    for p, d in zip(pos, axes_dim):
+        inv = 1.0 / (torch.tensor(float(base), dtype=torch.float64) ** (torch.arange(0, d, 2, dtype=torch.float64) / d))
+        ang = p[:, None] * inv[None, :]
+        cs.append(ang.cos().float())
+        sn.append(ang.sin().float())
+    return torch.cat(cs, 1).contiguous(), torch.cat(sn, 1).contiguous()
+
+
+class ParamLayout:
+    """name -> (offset, shape) inside the flat f32 arena.  Order: adaLN weights of all blocks + last layer
+    (one [L*6D+2D, E] matrix), their biases, then everything else; every entry starts on a 256-byte boundary."""
+
+    def __init__(self, d: DiTDims) -> None:
+        D, E, p = d.inner_dim, d.embedding_dim, d.patch_size
+        self.entries: dict[str, tuple[int, tuple[int, ...]]] = {}
+        self.size = 0
+
+        def add(name: str, shape: tuple[int, ...], align: int = 64) -> None:
+            self.size = _rup(self.size, align)
+            self.entries[name] = (self.size, shape)
+            self.size += math.prod(shape)
+
+        # -- contiguous adaLN matrix / bias (rows are multiples of 64*... so no padding is inserted between them)
+        for i in range(d.depth):
+            add(f"layers.{i}.modulation.lin.weight", (6 * D, E), align=1 if i else 64)
+        add("last_layer.adaLN_modulation.1.weight", (2 * D, E), align=1)
+        for i in range(d.depth):
+            add(f"layers.{i}.modulation.lin.bias", (6 * D,), align=1 if i else 64)
+        add("last_layer.adaLN_modulation.1.bias", (2 * D,), align=1)
+        self.mod_rows = d.depth * 6 * D + 2 * D
+        if d.n_classes is not None:
+            add("label_embed.embedding.weight", (d.n_classes + (1 if d.classifier_free else 0), E))
+        add("time_embed.0.weight", (E, d.frequency_embedding))
+        add("time_embed.0.bias", (E,))
+        add("time_embed.2.weight", (E, E))
+        add("time_embed.2.bias", (E,))
+        add("conv_proj.weight", (D, d.input_channels, p, p))
+        add("last_layer.linear.weight", (p * p * d.output_channels, D))
+        add("last_layer.linear.bias", (p * p * d.output_channels,))
+        for i in range(d.depth):
+            pre = f"layers.{i}."
+            add(pre + "norm_1.weight", (D,))
+            add(pre + "norm_1.bias", (D,), align=1)  # [w; b] adjacent: one reduce writes both gradients
+            add(pre + "norm_2.weight", (D,))
+            add(pre + "norm_2.bias", (D,), align=1)
+            add(pre + "attention.qk_norm.query_norm.scale", (D,))
+            add(pre + "attention.qk_norm.key_norm.scale", (D,), align=1)
+            add(pre + "attention.qkv.weight", (3 * D, D))
+            add(pre + "attention.proj_out.weight", (D, D))
+            add(pre + "mlp_input.0.weight", (2 * d.mlp_ratio * D, D))
+            add(pre + "mlp_input.2.weight", (D, d.mlp_ratio * D))
+        self.size = _rup(self.size, 64)
+
+    def view(self, flat: Tensor, name: str) -> Tensor:
+        off, shape = self.entries[name]
+        return flat[off : off + math.prod(shape)].view(shape)
+
+
+class DiTEngine:
+    def __init__(self, dims: DiTDims, device: torch.device | str = "cuda") -> None:
+        dims.validate()
+        self.d = dims
+        self.dev = torch.device(device)
+        self.layout = ParamLayout(dims)
+        self.params: Tensor | None = None
+        self.grads: Tensor | None = None
+        self._shadow_key: tuple | None = None
+        self.manual_version = 0
+        self._ws_key: tuple | None = None
+        self._rope: dict[tuple[int, int], tuple[Tensor, Tensor]] = {}
+        self._build_shadows()
+
+    # ------------------------------------------------------------------ parameters
+    def bind(self, params: Tensor, grads: Tensor | None) -> None:
+        assert params.dtype == torch.float32 and params.numel() == self.layout.size and params.is_cuda
+        self.params, self.grads = params, grads
+        self._shadow_key = None
+
+    def P(self, name: str) -> Tensor:
+        return self.layout.view(self.params, name)
+
+    def G(self, name: str) -> Tensor:
+        return self.layout.view(self.grads, name)
+
+    def _build_shadows(self) -> None:
+        """bf16 copies consumed by the MFMA GEMMs: W [out, rup64(in)] for forward, W^T [in, rup64(out)] for dgrad."""
+        d, dev = self.d, self.dev
+        D, E = d.inner_dim, d.embedding_dim
+        self.sh: dict[str, Tensor] = {}
+        self._casts: list[tuple[str, tuple[int, int], str | None, str | None]] = []
+
+        def reg(name: str, R: int, C: int, fwd: bool = True, dgrad: bool = True) -> None:
+            f = t = None
+            if fwd:
+                f = name + "|f"
+                self.sh[f] = torch.zeros(R, _rup(C, 64), device=dev, dtype=torch.bfloat16)
+            if dgrad:
+                t = name + "|t"
+                self.sh[t] = torch.zeros(C, _rup(R, 64), device=dev, dtype=torch.bfloat16)
+            self._casts.append((name, (R, C), f, t))
+
+        self.mod_name = "layers.0.modulation.lin.weight"  # start of the stacked [mod_rows, E] matrix
+        reg("@mod", self.layout.mod_rows, E)
+        reg("time_embed.0.weight", E, d.frequency_embedding, dgrad=False)
+        reg("time_embed.2.weight", E, E)
+        reg("conv_proj.weight", D, d.input_channels * d.patch_size**2, dgrad=False)
+        reg("last_layer.linear.weight", d.patch_size**2 * d.output_channels, D)
+        for i in range(d.depth):
+            pre = f"layers.{i}."
+            reg(pre + "attention.qkv.weight", 3 * D, D)
+            reg(pre + "attention.proj_out.weight", D, D)
+            reg(pre + "mlp_input.0.weight", 2 * d.mlp_ratio * D, D)
+            reg(pre + "mlp_input.2.weight", D, d.mlp_ratio * D)
+
+    def _src(self, name: str, shape: tuple[int, int]) -> Tensor:
+        if name == "@mod":
+            off = self.layout.entries[self.mod_name][0]
+            return self.params[off : off + shape[0] * shape[1]].view(shape)
+        return self.P(name).view(shape)
+
+    def refresh_shadows(self, force: bool = False) -> None:
+        key = (self.params.data_ptr(), self.params._version, self.manual_version)
+        if not force and key == self._shadow_key:
+            return
+        for name, shape, f, t in self._casts:
+            ops.cast_weight(self._src(name, shape), self.sh[f] if f else None, self.sh[t] if t else None)
+        self._shadow_key = key
+
+    def params_changed(self) -> None:
+        """call after writing the parameter arena through a raw pointer (fused AdamW)."""
+        self.manual_version += 1
+
+    # ------------------------------------------------------------------ workspace
+    def _alloc(self, B: int, H: int, W: int, train: bool) -> None:
+        key = (B, H, W, train)
+        if key == self._ws_key:
+            return
+        d, dev = self.d, self.dev
+        D, E, p, L = d.inner_dim, d.embedding_dim, d.patch_size, d.depth
+        gh, gw = H // p, W // p
+        N = gh * gw
+        M = B * N
+        if N % 64 or N > 256:
+            raise NotImplementedError(f"token grid {gh}x{gw}: HIP attention needs N % 64 == 0 and N <= 256 (got {N})")
+        Bp = _rup(B, 64)
+        Fo = p * p * d.output_channels
+        bf, f32 = torch.bfloat16, torch.float32
+
+        def z(*shape, dtype=bf):
+            return torch.zeros(*shape, device=dev, dtype=dtype)
+
+        w: dict[str, object] = {}
+        w["tokP"] = z(M, 64)                      # patchified input, K padded to 64
+        w["temb"] = z(Bp, d.frequency_embedding)
+        w["pre1"] = z(Bp, E)
+        w["h1"] = z(Bp, E)
+        w["e"] = z(Bp, E, dtype=f32)
+        w["emb"] = z(Bp, E, dtype=f32)
+        w["se"] = z(Bp, E)
+        w["mod"] = z(Bp, self.layout.mod_rows)
+        nl = L if train else 1                    # inference reuses one block's buffers for every layer
+        w["x"] = [z(M, D) for _ in range((L + 1) if train else 2)]
+        per = []
+        for _ in range(nl):
+            per.append({
+                "mean1": z(M, dtype=f32), "rstd1": z(M, dtype=f32), "xm1": z(M, D), "qkv": z(M, 3 * D),
+                "q": z(B, d.num_heads, N, 64), "k": z(B, d.num_heads, N, 64), "v": z(B, d.num_heads, N, 64),
+                "rrms": z(M, 2, dtype=f32), "a": z(M, D), "lse": z(B, d.num_heads, N, dtype=f32), "t1": z(M, D),
+                "x1": z(M, D), "mean2": z(M, dtype=f32), "rstd2": z(M, dtype=f32), "xm2": z(M, D),
+                "u": z(M, 2 * d.mlp_ratio * D), "h": z(M, d.mlp_ratio * D), "t2": z(M, D),
+            })
+        w["layers"] = per
+        w["meanf"], w["rstdf"] = z(M, dtype=f32), z(M, dtype=f32)
+        w["xf"] = z(M, D)
+        w["otok"] = z(M, _rup(Fo, 8), dtype=f32)
+        w["pred"] = z(B, d.output_channels, H, W, dtype=f32)
+        if train:
+            w["dO"] = z(M, 64)
+            w["dxa"], w["dxb"] = z(M, D), z(M, D)
+            w["dt"], w["dxm"], w["da"] = z(M, D), z(M, D), z(M, D)
+            w["dh"], w["du"] = z(M, d.mlp_ratio * D), z(M, 2 * d.mlp_ratio * D)
+            w["dq"], w["dk"], w["dv"] = (z(B, d.num_heads, N, 64) for _ in range(3))
+            w["dqkv"] = z(M, 3 * D)
+            w["dmod"] = z(Bp, self.layout.mod_rows)
+            w["dwb"] = z(B, 2, D, dtype=f32)
+            w["dse"] = z(Bp, E, dtype=f32)
+            w["demb"] = z(Bp, E, dtype=f32)
+            w["demb16"] = z(Bp, E)
+            w["dh1"] = z(Bp, E, dtype=f32)
+            w["dpre1"] = z(Bp, E)
+            w["scr_last"] = z(_rup(Fo, 8), D, dtype=f32)
+            w["scr_conv"] = z(D, 64, dtype=f32)
+        self.ws, self._ws_key = w, key
+        self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)
+        if (gh, gw) not in self._rope:
+            c, s = rope_grid_tables(gh, gw, d.rope_axes_dim, d.rope_base)
+            self._rope[(gh, gw)] = (c.to(dev), s.to(dev))
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: Tensor, t: Tensor, y_eff: Tensor | None, train: bool = True) -> Tensor:
+        """x f32 [B,C,H,W]; t f32 [B] (flow: in [0,1]; ddpm: indices as floats, both fed unscaled like the
+        reference); y_eff int64 [B] labels AFTER the classifier-free drop, or None.  Returns pred f32 [B,Co,H,W]
+        (a workspace buffer: consume it before the next forward)."""
+        d = self.d
+        B, C, H, W = x.shape
+        assert C == d.input_channels and x.dtype == torch.float32 and x.is_cuda
+        self._alloc(B, H, W, train)
+        self.refresh_shadows()
+        w, sh = self.ws, self.sh
+        _, _, _, gh, gw, N, M, Bp, Fo = self.geo
+        D, E, L, Hh = d.inner_dim, d.embedding_dim, d.depth, d.num_heads
+        cos, sin = self._rope[(gh, gw)]
+        rot = sum(d.rope_axes_dim)
+        self._train = train
+        self._yeff = y_eff
+
+        # stem + conditioning
+        ops.patchify(x, w["tokP"], d.patch_size, ops.PATCH_CPP)
+        xs = w["x"]
+        ops.gemm_nt(w["tokP"], sh["conv_proj.weight|f"], xs[0], M=M, N=D, K=64)
+        ops.timestep_embedding(t, w["temb"][:B])
+        ops.gemm_nt(w["temb"], sh["time_embed.0.weight|f"], w["h1"], bias=self.P("time_embed.0.bias"), act=ops.ACT_SILU,
+                    pre_out=w["pre1"], M=B, N=E, K=d.frequency_embedding)
+        ops.gemm_nt(w["h1"], sh["time_embed.2.weight|f"], w["e"], bias=self.P("time_embed.2.bias"), M=B, N=E, K=E)
+        table = self.P("label_embed.embedding.weight") if d.n_classes is not None else None
+        ops.cond_combine_fwd(w["e"][:B], table, y_eff if table is not None else None, w["emb"][:B], w["se"][:B])
+        mod_bias = self.params[self.layout.entries["layers.0.modulation.lin.bias"][0] :][: self.layout.mod_rows]
+        ops.gemm_nt(w["se"], sh["@mod|f"], w["mod"], bias=mod_bias, M=B, N=self.layout.mod_rows, K=E)
+        mod = w["mod"]
+
+        for i in range(L):
+            a = w["layers"][i if train else 0]
+            xin = xs[i] if train else xs[i & 1]
+            xout = xs[i + 1] if train else xs[(i + 1) & 1]
+            pre = f"layers.{i}."
+            mo = i * 6 * D
+            ops.ln_modulate_fwd(xin, self.P(pre + "norm_1.weight"), self.P(pre + "norm_1.bias"), mod[:, mo : mo + D],
+                                mod[:, mo + D : mo + 2 * D], N, 1e-5, a["xm1"], a["mean1"], a["rstd1"])
+            ops.gemm_nt(a["xm1"], sh[pre + "attention.qkv.weight|f"], a["qkv"])
+            ops.qk_norm_rope_fwd(a["qkv"], self.P(pre + "attention.qk_norm.query_norm.scale"),
+                                 self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["q"], a["k"], a["v"],
+                                 a["rrms"], B, N, Hh, 64, rot)
+            ops.attn_fwd(a["q"], a["k"], a["v"], a["a"], a["lse"], B, Hh, N, 64, 64**-0.5)
+            ops.gemm_nt(a["a"], sh[pre + "attention.proj_out.weight|f"], a["x1"], pre_out=a["t1"], resid=xin,
+                        gate=mod[:, mo + 2 * D : mo + 3 * D], rows_per_gate=N)
+            ops.ln_modulate_fwd(a["x1"], self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"),
+                                mod[:, mo + 3 * D : mo + 4 * D], mod[:, mo + 4 * D : mo + 5 * D], N, 1e-5, a["xm2"],
+                                a["mean2"], a["rstd2"])
+            ops.gemm_nt(a["xm2"], sh[pre + "mlp_input.0.weight|f"], a["u"])
+            ops.swiglu_fwd(a["u"], a["h"])
+            ops.gemm_nt(a["h"], sh[pre + "mlp_input.2.weight|f"], xout, pre_out=a["t2"], resid=a["x1"],
+                        gate=mod[:, mo + 5 * D : mo + 6 * D], rows_per_gate=N)
+
+        xl = xs[L] if train else xs[L & 1]
+        mo = L * 6 * D
+        ops.ln_modulate_fwd(xl, None, None, mod[:, mo : mo + D], mod[:, mo + D : mo + 2 * D], N, 1e-6, w["xf"], w["meanf"],
+                            w["rstdf"])
+        ops.gemm_nt(w["xf"], sh["last_layer.linear.weight|f"], w["otok"], bias=self.P("last_layer.linear.bias"), M=M,
+                    N=Fo, K=D)
+        ops.unpatchify(w["otok"], w["pred"], d.patch_size)
+        return w["pred"]
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dpred: Tensor) -> None:
+        """accumulates d(loss)/d(param) into the flat gradient arena (+=) for the last train-mode forward."""
+        assert self._train and self.grads is not None
+        d, w, sh = self.d, self.ws, self.sh
+        B, H, W, gh, gw, N, M, Bp, Fo = self.geo
+        D, E, L, Hh = d.inner_dim, d.embedding_dim, d.depth, d.num_heads
+        F = d.mlp_ratio * D
+        cos, sin = self._rope[(gh, gw)]
+        rot = sum(d.rope_axes_dim)
+        mod, dmod, xs = w["mod"], w["dmod"], w["x"]
+        Fo8 = _rup(Fo, 8)
+
+        # head: last linear + final adaLN
+        ops.patchify(dpred, w["dO"], d.patch_size, ops.PATCH_PPC)
+        gl = self.G("last_layer.linear.weight")
+        if Fo == Fo8:
+            ops.gemm_tn(w["dO"], w["xf"], gl, M=Fo, N=D)
+        else:
+            w["scr_last"].zero_()
+            ops.gemm_tn(w["dO"], w["xf"], w["scr_last"], M=Fo8, N=D)
+            ops.reduce_rows_f32(w["scr_last"], gl, 1, Fo * D)
+        ops.colsum(w["dO"], self.G("last_layer.linear.bias"), M, Fo)
+        ops.gemm_nt(w["dO"], sh["last_layer.linear.weight|t"], w["dxm"], M=M, N=D, K=64)
+        mo = L * 6 * D
+        dx, dx_alt = w["dxa"], w["dxb"]
+        ops.ln_modulate_bwd(w["dxm"], xs[L], None, None, mod[:, mo : mo + D], N, w["meanf"], w["rstdf"], None, dx,
+                            dmod[:, mo : mo + D], dmod[:, mo + D : mo + 2 * D], None)
+
+        for i in reversed(range(L)):
+            a = w["layers"][i]
+            pre = f"layers.{i}."
+            mo = i * 6 * D
+            # MLP branch
+            ops.gate_bwd(dx, a["t2"], mod[:, mo + 5 * D : mo + 6 * D], N, w["dt"], dmod[:, mo + 5 * D : mo + 6 * D])
+            ops.gemm_nt(w["dt"], sh[pre + "mlp_input.2.weight|t"], w["dh"])
+            ops.gemm_tn(w["dt"], a["h"], self.G(pre + "mlp_input.2.weight"))
+            ops.swiglu_bwd(w["dh"], a["u"], w["du"])
+            ops.gemm_nt(w["du"], sh[pre + "mlp_input.0.weight|t"], w["dxm"])
+            ops.gemm_tn(w["du"], a["xm2"], self.G(pre + "mlp_input.0.weight"))
+            ops.ln_modulate_bwd(w["dxm"], a["x1"], self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"),
+                                mod[:, mo + 3 * D : mo + 4 * D], N, a["mean2"], a["rstd2"], dx, dx_alt,
+                                dmod[:, mo + 3 * D : mo + 4 * D], dmod[:, mo + 4 * D : mo + 5 * D], w["dwb"])
+            ops.reduce_rows_f32(w["dwb"], self.G(pre + "norm_2.weight"), B, 2 * D)
+            dx, dx_alt = dx_alt, dx
+            # attention branch
+            ops.gate_bwd(dx, a["t1"], mod[:, mo + 2 * D : mo + 3 * D], N, w["dt"], dmod[:, mo + 2 * D : mo + 3 * D])
+            ops.gemm_nt(w["dt"], sh[pre + "attention.proj_out.weight|t"], w["da"])
+            ops.gemm_tn(w["dt"], a["a"], self.G(pre + "attention.proj_out.weight"))
+            ops.attn_bwd(a["q"], a["k"], a["v"], a["a"], w["da"], a["lse"], w["dq"], w["dk"], w["dv"], B, Hh, N, 64,
+                         64**-0.5)
+            ops.qk_norm_rope_bwd(w["dq"], w["dk"], w["dv"], a["qkv"], self.P(pre + "attention.qk_norm.query_norm.scale"),
+                                 self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], w["dqkv"],
+                                 self.G(pre + "attention.qk_norm.query_norm.scale"), B, N, Hh, 64, rot)
+            ops.gemm_nt(w["dqkv"], sh[pre + "attention.qkv.weight|t"], w["dxm"])
+            ops.gemm_tn(w["dqkv"], a["xm1"], self.G(pre + "attention.qkv.weight"))
+            ops.ln_modulate_bwd(w["dxm"], xs[i], self.P(pre + "norm_1.weight"), self.P(pre + "norm_1.bias"),
+                                mod[:, mo : mo + D], N, a["mean1"], a["rstd1"], dx, dx_alt, dmod[:, mo : mo + D],
+                                dmod[:, mo + D : mo + 2 * D], w["dwb"])
+            ops.reduce_rows_f32(w["dwb"], self.G(pre + "norm_1.weight"), B, 2 * D)
+            dx, dx_alt = dx_alt, dx
+
+        # stem: conv_proj weight gradient (no gradient flows to the input latents)
+        Fi = d.input_channels * d.patch_size**2
+        gc = self.G("conv_proj.weight").view(D, Fi)
+        if Fi % 8 == 0:
+            ops.gemm_tn(dx, w["tokP"], gc, M=D, N=Fi)
+        else:
+            w["scr_conv"].zero_()
+            ops.gemm_tn(dx, w["tokP"], w["scr_conv"], M=D, N=_rup(Fi, 8))
+            gc.add_(w["scr_conv"][:, :Fi])  # ragged edge (e.g. RGB p=2 -> 12 features): torch slice-add, not on the hot path
+
+        # conditioning path: every adaLN linear at once, then the time MLP and the label table
+        R = self.layout.mod_rows
+        g_modw = self.grads[self.layout.entries[self.mod_name][0] :][: R * E].view(R, E)
+        g_modb = self.grads[self.layout.entries["layers.0.modulation.lin.bias"][0] :][:R]
+        ops.gemm_tn(dmod, w["se"], g_modw)
+        ops.colsum(dmod, g_modb, B, R)
+        ops.gemm_nt(dmod, sh["@mod|t"], w["dse"], M=B, N=E, K=R)
+        table = d.n_classes is not None
+        ops.cond_combine_bwd(w["dse"][:B], w["emb"][:B], self._yeff if table else None, w["demb"][:B], w["demb16"][:B],
+                             self.G("label_embed.embedding.weight") if table else None)
+        ops.colsum(w["demb"], self.G("time_embed.2.bias"), B, E)
+        ops.gemm_tn(w["demb16"], w["h1"], self.G("time_embed.2.weight"))
+        ops.gemm_nt(w["demb16"], sh["time_embed.2.weight|t"], w["dh1"], M=B, N=E, K=E)
+        ops.silu_bwd(w["dh1"][:B], w["pre1"][:B], w["dpre1"][:B])
+        ops.gemm_tn(w["dpre1"], w["temb"], self.G("time_embed.0.weight"))
+        ops.colsum(w["dpre1"], self.G("time_embed.0.bias"), B, E)
