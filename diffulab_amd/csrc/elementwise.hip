@@ -145,19 +145,20 @@ extern "C" int dl_mse_loss_fwd(const float* pred, const float* a, const float* b
   return DL_OK;
 }
 __global__ void mse_bwd_k(const float* __restrict__ pred, const float* __restrict__ a, const float* __restrict__ b,
-                          float coef, float* __restrict__ dpred, int64_t n, int mode) {
+                          float coef, const float* __restrict__ gdev, float* __restrict__ dpred, int64_t n, int mode) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (gdev) coef *= *gdev;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float tgt = (mode == DL_LOSS_FLOW) ? (a[i] - b[i]) : a[i];
     dpred[i] = coef * (pred[i] - tgt);
   }
 }
-extern "C" int dl_mse_loss_bwd(const float* pred, const float* a, const float* b, float gscale, float* dpred,
-                               int64_t n, int mode, dl_stream_t stream) {
+extern "C" int dl_mse_loss_bwd(const float* pred, const float* a, const float* b, float gscale,
+                               const float* gscale_dev, float* dpred, int64_t n, int mode, dl_stream_t stream) {
   DL_CHECK_ARG(pred && a && dpred && n > 0, "dl_mse_loss_bwd: bad args");
   DL_CHECK_ARG(mode == DL_LOSS_EPS || b, "dl_mse_loss_bwd: flow mode needs b (x0)");
   const float coef = (float)(2.0 * (double)gscale / (double)n);
-  hipLaunchKernelGGL(mse_bwd_k, ew_grid(n), 256, 0, (hipStream_t)stream, pred, a, b, coef, dpred, n, mode);
+  hipLaunchKernelGGL(mse_bwd_k, ew_grid(n), 256, 0, (hipStream_t)stream, pred, a, b, coef, gscale_dev, dpred, n, mode);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

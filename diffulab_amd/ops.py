@@ -60,9 +60,10 @@ def mse_loss_fwd(pred: Tensor, a: Tensor, b: Tensor | None, mode: int) -> Tensor
     return loss
 
 
-def mse_loss_bwd(pred: Tensor, a: Tensor, b: Tensor | None, gscale: float, mode: int, out: Tensor | None = None) -> Tensor:
+def mse_loss_bwd(pred: Tensor, a: Tensor, b: Tensor | None, gscale: float, mode: int, out: Tensor | None = None,
+                 gscale_dev: Tensor | None = None) -> Tensor:
     out = torch.empty_like(pred) if out is None else out
-    _call("dl_mse_loss_bwd", _p(pred), _p(a), _p(b), float(gscale), _p(out), pred.numel(), mode, _s())
+    _call("dl_mse_loss_bwd", _p(pred), _p(a), _p(b), float(gscale), _p(gscale_dev), _p(out), pred.numel(), mode, _s())
     return out
 
 

@@ -57,9 +57,10 @@ DL_API int dl_ddpm_add_noise(const float* x, const float* noise, const int32_t* 
 DL_API int64_t dl_mse_loss_partials(int64_t n);
 DL_API int dl_mse_loss_fwd(const float* pred, const float* a, const float* b, float* partial, float* loss,
                            int64_t n, int mode, dl_stream_t stream);
-/* dpred = gscale * 2 (pred - target) / n   (gscale: upstream d(total)/d(loss), host scalar) */
-DL_API int dl_mse_loss_bwd(const float* pred, const float* a, const float* b, float gscale, float* dpred,
-                           int64_t n, int mode, dl_stream_t stream);
+/* dpred = gscale * (*gscale_dev) * 2 (pred - target) / n   (upstream d(total)/d(loss): host scalar times an
+ * optional DEVICE scalar, so autograd's incoming gradient never forces a device->host sync) */
+DL_API int dl_mse_loss_bwd(const float* pred, const float* a, const float* b, float gscale,
+                           const float* gscale_dev, float* dpred, int64_t n, int mode, dl_stream_t stream);
 /* Flow.compute_loss x-prediction branch flow.py:300-303: v = (z - xhat) / t[b] ; backward dxhat = -dv / t[b] */
 DL_API int dl_flow_x_to_v(const float* z, const float* xhat, const float* t, float* v, int64_t batch,
                           int64_t chw, dl_stream_t stream);

@@ -238,6 +238,36 @@ def gen_small_model() -> None:
     save("dit_small", **o)
 
 
+def gen_small16() -> None:
+    """same small net on a 16x16 latent grid (64 tokens): the smallest shape the HIP attention kernel accepts, so
+    the GPU path itself can be compared with reference outputs (not only with the oracle)."""
+    cfg = SMALL
+    m = build_ref(cfg, seed=5)
+    B, H = 4, 16
+    x0 = synth.normal("s16.x0", (B, cfg.input_channels, H, H))
+    noise = synth.normal("s16.noise", (B, cfg.input_channels, H, H))
+    t = synth.uniform("s16.t", (B,), lo=0.02, hi=0.98)
+    y = synth.integers("s16.y", (B,), cfg.n_classes)
+    z = (1 - t.view(-1, 1, 1, 1)) * x0 + t.view(-1, 1, 1, 1) * noise
+    o = {"pred": m(x=z, timesteps=t, y=y, p=0.0)["x"]}
+    loss = flow_loss_ref(m, x0, t, y, noise)
+    loss.backward()
+    o["loss"] = loss
+    for n, p in m.named_parameters():
+        o["g_" + n] = p.grad
+    m.eval()
+    x_init = synth.normal("s16.init", (B, 4, H, H))
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=4)
+    out = d.generate({"x": x_init.clone(), "y": y}, use_tqdm=False, guidance_scale=2.0, return_intermediates=True)
+    o["loop_euler_x"], o["loop_euler_x0"] = out["x"], out["estimated_x0"]
+    g = Diffuser(m, sampling_method="ddpm", model_type="gaussian_diffusion", n_steps=1000)
+    g.set_steps(5)
+    torch.manual_seed(23)
+    with torch.no_grad():
+        o["loop_ddpm_x"] = g.generate({"x": x_init.clone(), "y": y}, use_tqdm=False, guidance_scale=1.5, clamp_x=True)["x"]
+    save("dit_small16", **o)
+
+
 def gen_s2_model() -> None:
     cfg = S2
     m = build_ref(cfg, seed=7)
@@ -353,8 +383,8 @@ def gen_loss_curve() -> None:
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "s2", "samplers", "curve"]
-    fns = {"schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model,
+    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "curve"]
+    fns = {"schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
            "s2": gen_s2_model, "samplers": gen_samplers, "curve": gen_loss_curve}
     for w in which:
         print("==", w)

@@ -1,0 +1,224 @@
+"""GPU parity of the whole denoising hot path (DiT forward/backward under the flow / DDPM heads, sampler loops)
+through the reference-shaped plugin API (`diffulab_amd.Diffuser` / `MMDiT`), i.e. through the C ABI.
+
+Expected values: (1) committed reference outputs (tests/golden/*.npz, produced by importing the real reference),
+(2) the CPU oracle on seeded inputs.  The HIP path computes in bf16 with f32 accumulation, so tolerances are the
+bf16 ones of SURVEY.md §8c: activations / gradients relative-L2 <= 2e-2 per tensor, loss <= 2e-3 relative.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import diffusion as od  # noqa: E402
+from oracle import dit as odit  # noqa: E402
+from oracle import synth  # noqa: E402
+
+DEV = "cuda"
+SMALL = dict(input_channels=4, output_channels=4, inner_dim=128, embedding_dim=64, num_heads=2, mlp_ratio=4,
+             patch_size=2, depth=2, n_classes=10, classifier_free=True)
+
+
+def rel(a, b):
+    a = a.detach().double().cpu() if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a)).double()
+    b = b.detach().double().cpu() if isinstance(b, torch.Tensor) else torch.as_tensor(np.asarray(b)).double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def build(cfg_kwargs, seed):
+    from diffulab_amd import MMDiT
+
+    m = MMDiT(simple_dit=True, **cfg_kwargs)
+    P = synth.dit_params(odit.param_shapes(odit.DiTConfig(**cfg_kwargs)), seed=seed)
+    m.load_state_dict(P)
+    return m.to(DEV), P
+
+
+def test_state_dict_contract_and_init():
+    """key names/shapes == reference Appendix A; adaLN-zero init makes every block the identity (mmdit.py:737-745)."""
+    from diffulab_amd import MMDiT
+
+    m = MMDiT(simple_dit=True, **SMALL)
+    shapes = odit.param_shapes(odit.DiTConfig(**SMALL))
+    sd = m.state_dict()
+    assert set(sd) == set(shapes) and all(tuple(sd[k].shape) == shapes[k] for k in shapes)
+    assert float(m.layers[0].modulation.lin.weight.abs().sum()) == 0.0
+    assert float(m.last_layer.adaLN_modulation[1].weight.abs().sum()) == 0.0
+    m = m.to(DEV)
+    x = synth.normal("init.x", (4, 4, 16, 16)).to(DEV)
+    t = synth.uniform("init.t", (4,)).to(DEV)
+    y = synth.integers("init.y", (4,), 10).to(DEV)
+    with torch.no_grad():
+        out = m(x=x, timesteps=t, y=y)["x"]
+    P = {k: v.detach().cpu().float() for k, v in m.state_dict().items()}
+    ref = odit.dit_forward(P, x.cpu(), t.cpu(), y.cpu(), odit.DiTConfig(**SMALL))
+    assert rel(out, ref) < 1e-2
+    # after .to() the parameters are views of one flat arena and survive a state_dict round trip
+    assert m._is_flat()
+    m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+    assert m._is_flat()
+
+
+def test_small_model_against_reference_fixture(golden):
+    """flow loss / prediction / every parameter gradient vs the REFERENCE's outputs (dit_small16.npz)."""
+    from diffulab_amd import Diffuser
+
+    g = golden("dit_small16")
+    m, _ = build(SMALL, seed=5)
+    B, H = 4, 16
+    x0 = synth.normal("s16.x0", (B, 4, H, H))
+    noise = synth.normal("s16.noise", (B, 4, H, H))
+    t = synth.uniform("s16.t", (B,), lo=0.02, hi=0.98)
+    y = synth.integers("s16.y", (B,), 10)
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=50)
+    inputs = {"x": x0.to(DEV), "y": y.to(DEV), "p": 0.0}
+    losses = d.compute_loss(inputs, timesteps=t, noise=noise.to(DEV))
+    assert rel(inputs["x"], od.flow_add_noise(x0, t, noise)) < 1e-6  # model_inputs["x"] is overwritten with z_t
+    loss = losses["loss"]
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) / float(g["loss"]) < 2e-3
+    with torch.no_grad():
+        pred = m(x=inputs["x"], timesteps=t.to(DEV), y=y.to(DEV))["x"]
+    assert rel(pred, g["pred"]) < 1e-2
+    worst = 0.0
+    for name, p in m.named_parameters():
+        r = rel(p.grad, g["g_" + name])
+        worst = max(worst, r)
+        assert r < 2e-2, (name, r)
+    print("worst grad rel-L2", worst)
+    # accumulation semantics: a second backward doubles the gradient; zero_grad() clears the arena
+    g1 = m.conv_proj.weight.grad.clone()
+    inputs = {"x": x0.to(DEV), "y": y.to(DEV), "p": 0.0}
+    d.compute_loss(inputs, timesteps=t, noise=noise.to(DEV))["loss"].backward()
+    assert rel(m.conv_proj.weight.grad, 2 * g1) < 1e-3
+    m.zero_grad()
+    assert float(m._flat_grad.abs().sum()) == 0.0
+
+
+def test_ddpm_head_and_label_drop_against_oracle():
+    from diffulab_amd import Diffuser
+
+    m, P = build(SMALL, seed=5)
+    cfg = odit.DiTConfig(**SMALL)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    B, H = 4, 16
+    x0 = synth.normal("dd.x0", (B, 4, H, H))
+    noise = synth.normal("dd.noise", (B, 4, H, H))
+    y = synth.integers("dd.y", (B,), 10)
+    ti = torch.tensor([3, 500, 999, 0], dtype=torch.int32)
+    d = Diffuser(m, sampling_method="ddpm", model_type="gaussian_diffusion", n_steps=1000)
+    loss = d.compute_loss({"x": x0.to(DEV), "y": y.to(DEV), "p": 0.0}, timesteps=ti, noise=noise.to(DEV))["loss"]
+    loss.backward()
+    T = od.GaussianTables(1000)
+    ref = od.mse_loss(odit.dit_forward(Pr, od.ddpm_add_noise(T, x0, ti, noise), ti, y, cfg), noise)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) / ref.item() < 2e-3
+    for name, p in m.named_parameters():
+        assert rel(p.grad, Pr[name].grad) < 2.5e-2, name
+    # p = 1 drops every label (Appendix C.12): equals the oracle fed the null class
+    with torch.no_grad():
+        z = synth.normal("dd.z", (B, 4, H, H))
+        tf = synth.uniform("dd.t", (B,))
+        out = m(x=z.to(DEV), timesteps=tf.to(DEV), y=y.to(DEV), p=1.0)["x"]
+        ref_un = odit.dit_forward(P, z, tf, torch.full_like(y, 10), cfg)
+    assert rel(out, ref_un) < 1e-2
+
+
+def test_sampler_loops_against_reference_fixture(golden, monkeypatch):
+    from diffulab_amd import Diffuser
+
+    g = golden("dit_small16")
+    m, _ = build(SMALL, seed=5)
+    m.eval()
+    B, H = 4, 16
+    y = synth.integers("s16.y", (B,), 10).to(DEV)
+    x_init = synth.normal("s16.init", (B, 4, H, H))
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=4)
+    out = d.generate({"x": x_init.to(DEV), "y": y}, use_tqdm=False, guidance_scale=2.0, return_intermediates=True)
+    assert out["xt"].shape == (B, 5, 4, H, H)
+    assert rel(out["x"], g["loop_euler_x"]) < 2e-2
+    assert rel(out["estimated_x0"], g["loop_euler_x0"]) < 2e-2
+    # DDPM, respaced to 5 steps, CFG 1.5, clamp: replay the reference's CPU generator stream
+    # (per step: rand(B) for the p=1 label drop, then randn_like -- make_golden.gen_small16)
+    torch.manual_seed(23)
+    noises = []
+    for _ in range(5):
+        torch.rand(B)
+        noises.append(torch.randn(B, 4, H, H))
+    it = iter(noises)
+    monkeypatch.setattr(torch, "randn_like", lambda ref, **kw: next(it).to(ref.device))
+    gd = Diffuser(m, sampling_method="ddpm", model_type="gaussian_diffusion", n_steps=1000)
+    gd.set_steps(5)
+    with torch.no_grad():
+        out = gd.generate({"x": x_init.to(DEV), "y": y}, use_tqdm=False, guidance_scale=1.5, clamp_x=True)
+    assert rel(out["x"], g["loop_ddpm_x"]) < 3e-2
+
+
+@pytest.mark.timeout(900)
+def test_dit_s2_against_reference_fixture(golden):
+    """BASELINE config dims (DiT-S/2, 4x32x32 latents, 256 tokens): loss, prediction and gradient norms vs reference."""
+    from diffulab_amd import Diffuser
+
+    g = golden("dit_s2")
+    cfgk = dict(input_channels=4, output_channels=4, inner_dim=384, embedding_dim=384, num_heads=6, mlp_ratio=4,
+                patch_size=2, depth=12, n_classes=1000, classifier_free=True)
+    m, _ = build(cfgk, seed=7)
+    B = 2
+    x0 = synth.normal("s2.x0", (B, 4, 32, 32))
+    noise = synth.normal("s2.noise", (B, 4, 32, 32))
+    t = synth.uniform("s2.t", (B,), lo=0.05, hi=0.95)
+    y = synth.integers("s2.y", (B,), 1000)
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=50)
+    inputs = {"x": x0.to(DEV), "y": y.to(DEV), "p": 0.0}
+    loss = d.compute_loss(inputs, timesteps=t, noise=noise.to(DEV))["loss"]
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) / float(g["loss"]) < 2e-3
+    with torch.no_grad():
+        pred = m(x=inputs["x"], timesteps=t.to(DEV), y=y.to(DEV))["x"]
+    assert rel(pred, g["pred"]) < 2e-2
+    norms = dict(zip(g["grad_names"].tolist(), g["grad_norms"].tolist()))
+    params = dict(m.named_parameters())
+    bad = []
+    for n, ref in norms.items():
+        got = params[n].grad.double().norm().item()
+        if abs(got - ref) > 3e-2 * max(ref, 1e-12):
+            bad.append((n, got, ref))
+    assert not bad, bad[:8]
+    for k in g:
+        if k.startswith("g_"):
+            assert rel(params[k[2:]].grad, g[k]) < 3e-2, k
+        elif k.startswith("gs_"):
+            gr = params[k[3:]].grad
+            assert rel(gr.flatten()[:: max(1, gr.numel() // 512)][:512], g[k]) < 3e-2, k
+
+
+@pytest.mark.timeout(900)
+def test_loss_curve_against_reference(golden):
+    """12 AdamW steps of DiT-S/2 on fixed synthetic data: the loss curve of the HIP path vs the reference's
+    (north_star: 1e-4 rel is an fp32 target; this bf16 path is held to 5e-3 per step)."""
+    from diffulab_amd import Diffuser
+    from diffulab_amd.training import FusedAdamW
+
+    g = golden("loss_curve")
+    cfgk = dict(input_channels=4, output_channels=4, inner_dim=384, embedding_dim=384, num_heads=6, mlp_ratio=4,
+                patch_size=2, depth=12, n_classes=1000, classifier_free=True)
+    m, _ = build(cfgk, seed=7)
+    opt = FusedAdamW(m.parameters(), lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8)
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=50)
+    B = 4
+    x0 = synth.normal("curve.x0", (B, 4, 32, 32)).to(DEV)
+    y = synth.integers("curve.y", (B,), 1000).to(DEV)
+    got = []
+    for s in range(len(g["losses"])):
+        noise = synth.normal(f"curve.noise{s}", (B, 4, 32, 32)).to(DEV)
+        t = synth.uniform(f"curve.t{s}", (B,), lo=0.02, hi=0.98)
+        opt.zero_grad()
+        loss = d.compute_loss({"x": x0, "y": y, "p": 0.0}, timesteps=t, noise=noise)["loss"]
+        loss.backward()
+        opt.step()
+        got.append(loss.item())
+    got, ref = np.array(got), g["losses"]
+    print("loss curve rel err per step:", np.abs(got - ref) / ref)
+    assert np.all(np.abs(got - ref) / ref < 5e-3)
