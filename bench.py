@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""Headline benchmark: train images/sec/node, DiT-S/2 rectified-flow training on 256x256-image latents (4x32x32).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training step of the reference's BaseTrainer.training_step (base_trainer.py:138-153) on one
+per-GPU batch of synthetic latents: zero_grad -> draw_timesteps (CPU generator, H2D) -> noise + flow loss head ->
+DiT forward -> backward -> [N>1: RCCL gradient all-reduce overlapped with backward] -> AdamW.  Weak scaling: the
+per-GPU batch is fixed (256), `value` is the whole-job images/s.  Nothing under /root/reference is read.
+
+Extra objects on the JSON line:
+  roofline     -- dominant kernel (gemm_nt_k, the bf16 MFMA GEMM behind every linear): algorithmic FLOPs of its
+                  launches / their HIP-event durations, measured on a profiled replay of the same step; plus the
+                  whole-step figure (47.2 GFLOP/img x img/s) as `step_achieved`.
+  cpu_baseline -- the CPU oracle (a port of the reference path, oracle/) timed on this host's cores on a bounded
+                  sample (B=32, 1 warm-up + 2 timed steps), rank 0 at N=1 only.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
+S2 = dict(simple_dit=True, input_channels=4, output_channels=4, inner_dim=384, embedding_dim=384, num_heads=6,
+          mlp_ratio=4, patch_size=2, depth=12, n_classes=1000, classifier_free=True)
+
+
+def train_flops_per_image(D=384, E=384, L=12, N=256, pC=16) -> float:
+    """F_fwd = L(32 N D^2 + 4 N^2 D + 12 E D) + 4 N pC D + 2(256 E + E^2) + 4 E D ; train = 3 F_fwd"""
+    fwd = L * (32 * N * D * D + 4 * N * N * D + 12 * E * D) + 4 * N * pC * D + 2 * (256 * E + E * E) + 4 * E * D
+    return 3.0 * fwd
+
+
+def _host_threads() -> int:
+    """cores this process may really use: affinity mask and cgroup cpu quota, capped (an oversubscribed torch
+    thread pool on a 256-thread host is orders of magnitude slower than a right-sized one)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
+def cpu_baseline(batch: int = 8, budget_s: float = 25.0) -> dict:
+    """CPU oracle (port of the reference path) on a bounded sample: B=8 DiT-S/2 flow train steps, one warm-up
+    then as many timed steps as fit in ~budget_s (at least one)."""
+    from oracle import diffusion as od
+    from oracle import dit as odit
+    from oracle import synth
+
+    torch.set_num_threads(_host_threads())
+    cfg = odit.DiTConfig()
+    P = {k: v.requires_grad_(True) for k, v in synth.dit_params(odit.param_shapes(cfg), seed=7).items()}
+    opt = torch.optim.AdamW(list(P.values()), lr=1e-4, weight_decay=0.01)
+    x0 = synth.normal("cpu.x0", (batch, 4, 32, 32))
+    y = synth.integers("cpu.y", (batch,), 1000)
+    times: list[float] = []
+    start = time.perf_counter()
+    s = 0
+    while True:
+        noise = synth.normal(f"cpu.n{s}", (batch, 4, 32, 32))
+        t = torch.sigmoid(synth.normal(f"cpu.t{s}", (batch,)))
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        pred = odit.dit_forward(P, od.flow_add_noise(x0, t, noise), t, y, cfg)
+        od.flow_loss(pred, x0, noise).backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+        s += 1
+        if s >= 2 and (time.perf_counter() - start > budget_s or s >= 6):
+            break
+        if s == 1 and times[0] > budget_s:  # pathological host: keep the single (cold) measurement
+            break
+    timed = times[1:] if len(times) > 1 else times
+    dt = sum(timed) / len(timed)
+    return {"value": round(batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fp32 DiT-S/2 flow train step, B={batch}, {len(times) - len(timed)} warm-up + {len(timed)} timed steps"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from diffulab_amd import Diffuser, MMDiT, ops
+    from diffulab_amd.training import FusedAdamW
+    from diffulab_amd.training.dp import GradReducer, broadcast_arena
+
+    torch.manual_seed(1234 + rank)
+    model = MMDiT(**S2).to(dev)
+    model.flatten_parameters()
+    broadcast_arena(model._flat)
+    diffuser = Diffuser(model, sampling_method="euler", model_type="rectified_flow", n_steps=50,
+                        extra_args={"logits_normal": True})
+    opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8)
+    reducer = GradReducer(model._flat_grad)
+    model.engine.reducer = reducer if world > 1 else None
+    opt.grad_scale = reducer.grad_scale
+
+    B = args.batch
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x_data = torch.randn(B, 4, 32, 32, generator=gen).to(dev)  # synthetic ImageNet-256 SD-VAE-f8 shaped latents
+    y_data = torch.randint(0, 1000, (B,), generator=gen).to(dev)
+    loss_host = torch.zeros((), pin_memory=True)
+
+    def step() -> None:
+        opt.zero_grad()
+        t = diffuser.draw_timesteps(B).to(dev, non_blocking=True)  # CPU generator draw + H2D, as the reference
+        losses = diffuser.compute_loss({"x": x_data, "y": y_data, "p": 0.1}, timesteps=t)
+        loss_host.copy_(losses["loss"].detach(), non_blocking=True)  # tracker read-back without a per-step sync
+        sum(losses.values()).backward()
+        opt.step()
+
+    def sync() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    ms = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+    final_loss = float(loss_host)
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        # profiled replay of the same step: HIP events around every gemm_nt_k launch on the launch stream
+        rec: list[tuple[torch.cuda.Event, torch.cuda.Event, float]] = []
+        orig = ops.gemm_nt
+
+        def timed_gemm(a, b, out, **kw):
+            M = kw.get("M") or a.shape[0]
+            N = kw.get("N") or b.shape[0]
+            K = kw.get("K") or a.shape[1]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(a, b, out, **kw)
+            e1.record()
+            rec.append((e0, e1, 2.0 * M * N * K))
+            return r
+
+        ops.gemm_nt = timed_gemm
+        import diffulab_amd.engine as eng_mod
+
+        eng_mod.ops.gemm_nt = timed_gemm
+        saved_reducer, model.engine.reducer = model.engine.reducer, None
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        ops.gemm_nt = orig
+        eng_mod.ops.gemm_nt = orig
+        model.engine.reducer = saved_reducer
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
+        tot_fl = sum(f for _, _, f in rec)
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        step_ach = (value / world) * train_flops_per_image() / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_nt_k", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "launches_per_step": len(rec) // 2, "avg_launch_us": round(tot_ms * 1e3 / len(rec), 2),
+                "gemm_nt_ms_per_step": round(tot_ms / 2, 3), "step_achieved": round(step_ach, 1),
+                "step_frac": round(step_ach / PEAK_BF16_TFLOPS, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        out = {
+            "metric": "train images/sec/node (DiT-S/2 flow-matching, 256x256 latents)",
+            "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "DiT-S/2 (MMDiT simple_dit 384/6 heads/12 blocks, patch 2, 39.9M params) rectified-flow "
+                                   "train step on 4x32x32 latents (256 tokens), AdamW, label-drop 0.1",
+                       "global_batch": world * B, "per_gpu_batch": B, "tokens_per_image": 256,
+                       "parallelism": f"dp{world}", "flops_per_image": train_flops_per_image(), "final_loss": final_loss},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -25,6 +25,16 @@ from torch import Tensor
 from . import ops
 
 
+_PARAM_EPOCH = 0
+
+
+def bump_param_epoch() -> None:
+    """to be called by anything that writes parameters through a raw pointer (fused AdamW / EMA kernels):
+    torch version counters do not see those writes, and the bf16 weight shadows are keyed on this epoch."""
+    global _PARAM_EPOCH
+    _PARAM_EPOCH += 1
+
+
 def _rup(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -143,7 +153,11 @@ class DiTEngine:
         self.manual_version = 0
         self._ws_key: tuple | None = None
         self._rope: dict[tuple[int, int], tuple[Tensor, Tensor]] = {}
+        self.reducer = None  # optional training.dp.GradReducer: gets ready(lo, hi) as gradient ranges complete
         self._build_shadows()
+        ent = self.layout.entries
+        starts = [ent[f"layers.{i}.norm_1.weight"][0] for i in range(dims.depth)] + [self.layout.size]
+        self.layer_ranges = [(starts[i], starts[i + 1]) for i in range(dims.depth)]
 
     # ------------------------------------------------------------------ parameters
     def bind(self, params: Tensor, grads: Tensor | None) -> None:
@@ -194,7 +208,8 @@ class DiTEngine:
         return self.P(name).view(shape)
 
     def refresh_shadows(self, force: bool = False) -> None:
-        key = (self.params.data_ptr(), self.params._version, self.manual_version)
+        ver = 0 if self.params.is_inference() else self.params._version
+        key = (self.params.data_ptr(), ver, self.manual_version, _PARAM_EPOCH)
         if not force and key == self._shadow_key:
             return
         for name, shape, f, t in self._casts:
@@ -222,7 +237,8 @@ class DiTEngine:
         bf, f32 = torch.bfloat16, torch.float32
 
         def z(*shape, dtype=bf):
-            return torch.zeros(*shape, device=dev, dtype=dtype)
+            with torch.inference_mode(False):  # workspaces outlive an inference_mode() sampler loop
+                return torch.zeros(*shape, device=dev, dtype=dtype)
 
         w: dict[str, object] = {}
         w["tokP"] = z(M, 64)                      # patchified input, K padded to 64
@@ -280,7 +296,7 @@ class DiTEngine:
         B, C, H, W = x.shape
         assert C == d.input_channels and x.dtype == torch.float32 and x.is_cuda
         self._alloc(B, H, W, train)
-        self.refresh_shadows()
+        self.refresh_shadows(force=train)  # a training forward always follows a parameter update
         w, sh = self.ws, self.sh
         _, _, _, gh, gw, N, M, Bp, Fo = self.geo
         D, E, L, Hh = d.inner_dim, d.embedding_dim, d.depth, d.num_heads
@@ -396,6 +412,8 @@ class DiTEngine:
                                 dmod[:, mo + D : mo + 2 * D], w["dwb"])
             ops.reduce_rows_f32(w["dwb"], self.G(pre + "norm_1.weight"), B, 2 * D)
             dx, dx_alt = dx_alt, dx
+            if self.reducer is not None:  # this block's gradient range is final: overlap its all-reduce
+                self.reducer.ready(*self.layer_ranges[i])
 
         # stem: conv_proj weight gradient (no gradient flows to the input latents)
         Fi = d.input_channels * d.patch_size**2
@@ -423,3 +441,6 @@ class DiTEngine:
         ops.silu_bwd(w["dh1"][:B], w["pre1"][:B], w["dpre1"][:B])
         ops.gemm_tn(w["dpre1"], w["temb"], self.G("time_embed.0.weight"))
         ops.colsum(w["dpre1"], self.G("time_embed.0.bias"), B, E)
+        if self.reducer is not None:
+            self.reducer.ready(0, self.layer_ranges[0][0])
+            self.reducer.finish()

@@ -215,9 +215,11 @@ class MMDiT(Denoiser):
             object.__setattr__(self, "_engine", DiTEngine(self.dims, dev))
         lay = self._engine.layout
         assert set(named) == set(lay.entries), set(named) ^ set(lay.entries)
-        flat = torch.zeros(lay.size, device=dev, dtype=torch.float32)
-        grad = torch.zeros(lay.size, device=dev, dtype=torch.float32)
-        with torch.no_grad():
+        # the arena must be ordinary (version-tracked) tensors even when the first forward happens inside
+        # torch.inference_mode() (Flow.denoise is decorated with it)
+        with torch.inference_mode(False), torch.no_grad():
+            flat = torch.zeros(lay.size, device=dev, dtype=torch.float32)
+            grad = torch.zeros(lay.size, device=dev, dtype=torch.float32)
             for name, p in named.items():
                 v = lay.view(flat, name)
                 v.copy_(p.detach().to(device=dev, dtype=torch.float32))
@@ -225,9 +227,10 @@ class MMDiT(Denoiser):
                     lay.view(grad, name).copy_(p.grad.to(device=dev, dtype=torch.float32))
                 p.data = v
                 p.grad = lay.view(grad, name)
+            anchor = torch.zeros(1, device=dev, requires_grad=True)
         object.__setattr__(self, "_flat", flat)
         object.__setattr__(self, "_flat_grad", grad)
-        object.__setattr__(self, "_anchor", torch.zeros(1, device=dev, requires_grad=True))
+        object.__setattr__(self, "_anchor", anchor)
         self._engine.bind(flat, grad)
 
     def _prepare_grads(self) -> None:

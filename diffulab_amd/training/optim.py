@@ -12,28 +12,33 @@ import torch
 from torch import Tensor
 
 from .. import ops
+from ..engine import bump_param_epoch
 
 
 def _arena_of(params: list[Tensor], use_grad: bool) -> Tensor | None:
-    base = None
+    """flat f32 tensor spanning the storage all `params` (or their grads) are views of, else None.
+    (`p.data` is not a view object, so `_base` cannot be used: compare the underlying storages.)"""
+    store = None
     for p in params:
         t = p.grad if use_grad else p.data
-        if t is None:
+        if t is None or t.dtype != torch.float32 or not t.is_contiguous():
             return None
-        b = t._base
-        if b is None or b.dim() != 1 or b.dtype != torch.float32:
+        s = t.untyped_storage()
+        if store is None:
+            store = s
+        elif s.data_ptr() != store.data_ptr():
             return None
-        if base is None:
-            base = b
-        elif b.data_ptr() != base.data_ptr():
-            return None
-    return base
+    if store is None:
+        return None
+    t0 = params[0].grad if use_grad else params[0].data
+    return torch.empty(0, dtype=torch.float32, device=t0.device).set_(store, 0, (store.nbytes() // 4,))
 
 
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas: tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-2) -> None:
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.grad_scale = 1.0  # data parallel: 1/world (gradients are SUM-reduced), folded into the update kernel
 
     def _flat(self, group) -> tuple[Tensor, Tensor] | None:
         ps = [p for p in group["params"] if p.requires_grad]
@@ -71,8 +76,9 @@ class FusedAdamW(torch.optim.Optimizer):
                 if not st:
                     st["step"], st["m"], st["v"] = 0, torch.zeros_like(pb), torch.zeros_like(pb)
                 st["step"] += 1
-                ops.adamw_step(pb, gb, st["m"], st["v"], group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"])
-                pb[:0].zero_()  # bumps the arena's version counter (raw-pointer writes do not): shadows get refreshed
+                ops.adamw_step(pb, gb, st["m"], st["v"], group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"],
+                               self.grad_scale)
+                bump_param_epoch()  # raw-pointer writes bump no torch version counter: tell the engines
             else:
                 for p in group["params"]:
                     if p.grad is None:
@@ -82,6 +88,6 @@ class FusedAdamW(torch.optim.Optimizer):
                         st["step"], st["m"], st["v"] = 0, torch.zeros_like(p.data), torch.zeros_like(p.data)
                     st["step"] += 1
                     ops.adamw_step(p.data, p.grad, st["m"], st["v"], group["lr"], b1, b2, group["eps"],
-                                   group["weight_decay"], st["step"])
-                    p.data[:0].zero_() if p.data.dim() else None
+                                   group["weight_decay"], st["step"], self.grad_scale)
+            bump_param_epoch()
         return loss
