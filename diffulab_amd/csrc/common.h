@@ -38,16 +38,15 @@ void dl_set_error(const char* fmt, ...);
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ float bflo(uint32_t p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bfhi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
-// round-to-nearest-even (NaN kept quiet)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// float -> bf16, round-to-nearest-even: the native __bf16 cast lowers to ONE v_cvt_pk_bf16_f32 on gfx950 (a
+// hand-rolled integer rounding costs ~10 VALU per pair and made the GEMM epilogues VALU-bound: 7 VALU per MFMA
+// in the first rocprof PMC pass)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ void unpack8(const u32x4_t& p, float (&f)[8]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {

@@ -190,18 +190,21 @@ extern "C" int dl_colsum(const void* x, int dtype, int64_t ld, float* out, int64
   return DL_OK;
 }
 
+// out[j] += sum_g partial[g, j]: 64 columns x 4 row-lanes per block (same shape as colsum, no atomics: one block per column group)
 __global__ void reduce_rows_k(const float* __restrict__ partial, float* __restrict__ out, int G, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int g = 0; g < G; ++g) s += partial[(int64_t)g * n + i];
-    out[i] += s;
-  }
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
+  float acc = 0.f;
+  if (c < n)
+    for (int g = rl; g < G; g += 4) acc += partial[(int64_t)g * n + c];
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < n) out[c] += red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
 }
 extern "C" int dl_reduce_rows_f32(const float* partial, float* out, int64_t G, int64_t n, dl_stream_t stream) {
   DL_CHECK_ARG(partial && out && G > 0 && n > 0, "dl_reduce_rows_f32: bad args");
-  int64_t g = (n + 255) / 256;
-  if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(reduce_rows_k, (int)g, 256, 0, (hipStream_t)stream, partial, out, (int)G, n);
+  hipLaunchKernelGGL(reduce_rows_k, cdiv(n, 64), 256, 0, (hipStream_t)stream, partial, out, (int)G, n);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

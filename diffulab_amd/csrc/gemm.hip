@@ -11,6 +11,8 @@
 //   tn: rows are 256 B (128 m); 16-B slot' = slot ^ (4 * (row & 3))   -> the 4 rows of one ds_read_b64_tr_b16
 //       group land on 4 distinct 32-B bank groups
 // Workgroup ids are remapped so that each XCD (own L2) walks a contiguous run of tiles sharing the A panel.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define BM 128
@@ -208,6 +210,230 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restr
   }
 }
 
+// =====================================================================================================
+// gemm_nt_big_k: the token-GEMM workhorse (M = batch*tokens is huge, K = 384..3072, N = 384..3072).
+//
+// Why a second kernel: a 128x128 tile moves 64 FLOP per byte through the CU's vector-memory path
+// (global_load_lds tops out at 64 B/clk/CU), which is EXACTLY the MFMA rate, and with one stage of prefetch
+// the rocprof PMC run of the kernel above shows the waves parked on vmcnt/barrier 60-70 % of the time.
+//   * 256 x TN tiles (TN = 128 | 192): 85 | 110 FLOP per staged byte;
+//   * persistent: one 512-thread workgroup per CU (8 waves, 4(M) x 2(N), each 64 x TN/2) walks a list of
+//     tiles; the (tile, k-step) space is flattened and fed through an NST-deep LDS ring with COUNTED
+//     s_waitcnt vmcnt(N) (never 0 in steady state): NST-1 operand stages (up to ~96 KiB per CU) stay in
+//     flight across barriers, tile boundaries and the epilogue stores;
+//   * XCD-aware schedule: at every slot the 32 workgroups of one XCD own 32 consecutive tiles (n fastest),
+//     i.e. they share A row-panels in that XCD's L2;
+//   * operands are swapped in the MFMA (A-operand = weight rows, B-operand = activation rows) so that each
+//     lane ends up with 4 consecutive output columns of one row; one v_permlane32_swap per register pair
+//     widens that to 8 columns = one 16-byte store/load per lane (no LDS round trip in the epilogue).
+// EPI = 0: plain bf16 store (its store count is known, so the ring keeps flowing through the epilogue);
+// EPI = 1: every epilogue option (drains the ring once per tile).
+// Requires M % 256 == 0, N % TN == 0, K % 64 == 0.
+// =====================================================================================================
+#define TBM 256
+#define BIG_THREADS 512
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int TN_, int NST, int EPI>
+__global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __restrict__ A, int64_t lda,
+                                                                  const bf16_t* __restrict__ Bm, int64_t ldb,
+                                                                  void* __restrict__ C, int64_t ldc, int M, int N,
+                                                                  int K, NtEpilogue ep) {
+  constexpr int STAGE = (TBM + TN_) * 128;   // bytes per ring slot
+  constexpr int CH = (TBM + TN_) / 8 / 8;    // DMA chunks (1 KiB) per wave per stage: 6 | 7
+  constexpr int JN = TN_ / 64;               // 32-wide MFMA column tiles per wave: 2 | 3
+  constexpr int ESTORES = 4 * JN;            // 16-byte stores per wave in the EPI==0 epilogue
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = N / TN_, ntiles = (M / TBM) * tiles_n;
+  const int nk = K / BK;
+  const int G = gridDim.x;  // multiple of 8
+  const int slot0 = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int cnt = (ntiles - slot0 + G - 1) / G;  // tiles owned by this workgroup (slot0 < ntiles by launch)
+  const int total = cnt * nk;
+
+  // ---- per-lane constant parts of the DMA chunks this wave issues per stage
+  int64_t src_off[CH];
+  int lds_off[CH];
+  bool is_a[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = wave * CH + i;
+    is_a[i] = c < TBM / 8;
+    const int cc = is_a[i] ? c : c - TBM / 8;
+    const int r = cc * 8 + (lane >> 3);
+    const int q = (lane & 7) ^ ((r >> 1) & 7);
+    src_off[i] = (int64_t)r * (is_a[i] ? lda : ldb) + q * 8;
+    lds_off[i] = (is_a[i] ? 0 : TBM * 128) + cc * 1024;
+  }
+  // DMA cursor: runs NST-1 stages ahead of the compute cursor
+  int s_tile = slot0, s_kt = 0, s_it = 0;
+  const bf16_t* s_ta = A + (int64_t)((s_tile / tiles_n) * TBM) * lda;
+  const bf16_t* s_tb = Bm + (int64_t)((s_tile % tiles_n) * TN_) * ldb;
+  auto stage_next = [&]() {
+    char* base = smem + (s_it % NST) * STAGE;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) glds16((is_a[i] ? s_ta : s_tb) + src_off[i] + s_kt * BK, base + lds_off[i]);
+    ++s_it;
+    if (++s_kt == nk) {
+      s_kt = 0;
+      s_tile += G;
+      s_ta = A + (int64_t)((s_tile / tiles_n) * TBM) * lda;
+      s_tb = Bm + (int64_t)((s_tile % tiles_n) * TN_) * ldb;
+    }
+  };
+
+  int xrow[2], wrow[JN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) xrow[i] = wm * 64 + i * 32 + (lane & 31);
+#pragma unroll
+  for (int j = 0; j < JN; ++j) wrow[j] = wn * (TN_ / 2) + j * 32 + (lane & 31);
+
+  f32x16_t acc[JN][2];
+#pragma unroll
+  for (int j = 0; j < JN; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < total) stage_next();
+
+  int tile = slot0, kt = 0;
+  bool after_epi = false;
+  for (int it = 0; it < total; ++it) {
+    // stage `it` must have landed; the NST-2 younger stages (and the previous tile's stores) may stay in flight
+    if (it + NST - 2 < total) {
+      if (EPI == 0 && after_epi) wait_vmcnt<(NST - 2) * CH + ESTORES>();
+      else wait_vmcnt<(NST - 2) * CH>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would drain vmcnt (the DMA counts as an LDS write)
+    if (s_it < total) stage_next();  // into the slot whose stage was consumed in iteration it-1
+    const char* sa = smem + (it % NST) * STAGE;
+    const char* sb = sa + TBM * 128;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8_t xf[2], wf[JN];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        xf[i] = *(const bf16x8_t*)(sa + xrow[i] * 128 + ((((kk << 1) | hi) ^ ((xrow[i] >> 1) & 7)) << 4));
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+        wf[j] = *(const bf16x8_t*)(sb + wrow[j] * 128 + ((((kk << 1) | hi) ^ ((wrow[j] >> 1) & 7)) << 4));
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+    }
+    after_epi = false;
+    if (++kt == nk) {
+      kt = 0;
+      after_epi = true;
+      // ---- epilogue of `tile` straight from registers: acc[j][i][r] = C[m][n] with
+      //      m = m0 + wm*64 + i*32 + (lane&31),  n = n0 + wn*TN/2 + j*32 + 8*(r>>2) + 4*hi + (r&3)
+      const int m0 = (tile / tiles_n) * TBM, n0 = (tile % tiles_n) * TN_;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + (lane & 31);
+        const bf16_t* gate_row = (EPI && ep.gate) ? ep.gate + (int64_t)(m / (int)ep.rows_per_gate) * ep.ldg : nullptr;
+#pragma unroll
+        for (int j = 0; j < JN; ++j) {
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              // half exchange: afterwards lanes 0-31 hold columns +0..7, lanes 32-63 columns +8..15 of this 16-group
+              const unsigned x = __float_as_uint(acc[j][i][8 * gp + e]), y = __float_as_uint(acc[j][i][8 * gp + 4 + e]);
+              auto sw = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+              v[e] = __uint_as_float(sw[0]);
+              v[4 + e] = __uint_as_float(sw[1]);
+              acc[j][i][8 * gp + e] = 0.f;
+              acc[j][i][8 * gp + 4 + e] = 0.f;
+            }
+            const int n = n0 + wn * (TN_ / 2) + j * 32 + 16 * gp + 8 * hi;
+            if (EPI) {
+              if (ep.bias) {
+                const f32x4_t b0 = *(const f32x4_t*)(ep.bias + n), b1 = *(const f32x4_t*)(ep.bias + n + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  v[e] += b0[e];
+                  v[4 + e] += b1[e];
+                }
+              }
+              if (ep.pre_out) *(u32x4_t*)(ep.pre_out + (int64_t)m * ldc + n) = pack8(v);
+              if (ep.act == DL_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+              }
+              if (ep.resid) {
+                float rr[8];
+                unpack8(*(const u32x4_t*)(ep.resid + (int64_t)m * ep.ldr + n), rr);
+                if (gate_row) {
+                  float gg[8];
+                  unpack8(*(const u32x4_t*)(gate_row + n), gg);
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) v[e] = rr[e] + gg[e] * v[e];
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) v[e] += rr[e];
+                }
+              }
+              if (ep.out_f32) {
+                float* cp = (float*)C + (int64_t)m * ldc + n;
+                *(f32x4_t*)cp = *(f32x4_t*)&v[0];
+                *(f32x4_t*)(cp + 4) = *(f32x4_t*)&v[4];
+              } else {
+                *(u32x4_t*)((bf16_t*)C + (int64_t)m * ldc + n) = pack8(v);
+              }
+            } else {
+              *(u32x4_t*)((bf16_t*)C + (int64_t)m * ldc + n) = pack8(v);
+            }
+          }
+        }
+      }
+      if (EPI) wait_vmcnt<0>();  // unknown number of epilogue memory ops: drain so the counted waits stay exact
+      tile += G;
+    }
+  }
+}
+
+template <int TN_, int NST>
+static int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                      int64_t N, int64_t K, const NtEpilogue& ep, bool plain, hipStream_t stream) {
+  constexpr int LDS = NST * (TBM + TN_) * 128;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+    (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  }
+  const int ntiles = (int)((M / TBM) * (N / TN_));
+  int grid = n_cu < ntiles ? n_cu : ntiles;
+  grid &= ~7;
+  if (plain)
+    hipLaunchKernelGGL((gemm_nt_big_k<TN_, NST, 0>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)A, lda,
+                       (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep);
+  else
+    hipLaunchKernelGGL((gemm_nt_big_k<TN_, NST, 1>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)A, lda,
+                       (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
 extern "C" int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                           int64_t N, int64_t K, const float* bias, int act, int out_dtype, void* pre_out,
                           const void* resid, int64_t ldr, const void* gate, int64_t ldg, int64_t rows_per_gate,
@@ -224,6 +450,20 @@ extern "C" int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb
   DL_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31), "dl_gemm_nt: dims too large");
   NtEpilogue ep{bias, act, out_dtype == DL_F32, (bf16_t*)pre_out, (const bf16_t*)resid, ldr, (const bf16_t*)gate,
                 ldg, rows_per_gate > 0 ? rows_per_gate : 1};
+  {
+    // big-tile persistent kernels for the token GEMMs; variant picked by an env knob while tuning
+    static int variant = -1;
+    if (variant < 0) {
+      const char* e = getenv("DL_GEMM_NT_VARIANT");
+      variant = e ? atoi(e) : 2;  // 2 = 256x192 tiles, 2-stage ring (best measured); 1 = 256x128, 3-stage; 0 = small-tile kernel only
+    }
+    const bool plain = !bias && act == DL_ACT_NONE && out_dtype == DL_BF16 && !pre_out && !resid;
+    const bool aligned = !bias || ((uintptr_t)bias & 15) == 0;
+    if (variant == 1 && aligned && M % TBM == 0 && N % 128 == 0 && (M / TBM) * (N / 128) >= 64)
+      return launch_big<128, 3>(A, lda, B, ldb, C, ldc, M, N, K, ep, plain, (hipStream_t)stream);
+    if (variant == 2 && aligned && M % TBM == 0 && N % 192 == 0 && (M / TBM) * (N / 192) >= 64)
+      return launch_big<192, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, plain, (hipStream_t)stream);
+  }
   const int nwg = cdiv(M, BM) * cdiv(N, BN);
   hipLaunchKernelGGL(gemm_nt_k, nwg, NT_THREADS, NT_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)A, lda,
                      (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep);
@@ -348,6 +588,130 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_tn_k(const bf16_t* __restr
     }
 }
 
+// =====================================================================================================
+// gemm_tn_big_k: wgrad of the token linears (reduction over R = batch*tokens, output [Mo, No] small).
+// Same reasoning as gemm_nt_big_k: a 128x128 output tile stages 64 FLOP/B; here 384 x 128 tiles
+// (96 FLOP/B), 8 waves as 4(M) x 2(N), each 96 x 64 = 3x2 MFMA 32x32x16 tiles, one workgroup per CU,
+// the reduction split over workgroups (<= one per CU per launch) and combined with f32 atomics.
+// Operand images in LDS are the row-major [64 r][384|128] slabs written by the DMA (1 KiB chunks run over
+// row boundaries for the 768-byte A rows: the per-lane source address is derived from the linear image
+// offset); fragments come out through ds_read_b64_tr_b16 with the 32-byte-chunk XOR swizzle of gemm_tn_k.
+// Requires Mo % 384 == 0, No % 128 == 0, R % 64 == 0.
+// =====================================================================================================
+#define WBM 384
+#define WBN 128
+#define W_STAGE ((WBM + WBN) * 2 * BK)  // 65536 B per stage
+__global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __restrict__ A, int64_t lda,
+                                                                  const bf16_t* __restrict__ Bm, int64_t ldb,
+                                                                  float* __restrict__ C, int64_t ldc, int M, int N,
+                                                                  int R, int steps_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // block -> (A-panel unit = (split, m-tile), n-tile): the tiles_n workgroups that read the same A panel get block
+  // ids congruent mod 8, i.e. land on ONE XCD and share the panel in its L2 (one HBM read instead of tiles_n)
+  const int tiles_n = N / WBN, tiles_m = M / WBM;
+  const int grp = blockIdx.x / (8 * tiles_n), rem = blockIdx.x - grp * 8 * tiles_n;
+  const int unit = grp * 8 + (rem & 7), nt = rem >> 3;
+  const int split = unit / tiles_m, mt = unit - split * tiles_m;
+  const int m0 = mt * WBM, n0 = nt * WBN;
+  const int nsteps_total = R / BK;
+  const int s_begin = split * steps_per_split;
+  int s_end = s_begin + steps_per_split;
+  s_end = s_end < nsteps_total ? s_end : nsteps_total;
+  if (s_begin >= s_end) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // DMA: 48 A chunks + 16 B chunks of 1 KiB per stage, 8 per wave (waves 0-5: A, waves 6-7: B)
+  int64_t src_off[8];
+  int lds_off[8];
+  const bool is_a = wave < 6;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = is_a ? wave * 8 + i : (wave - 6) * 8 + i;
+    const int pitch = is_a ? WBM * 2 : WBN * 2;
+    const int o = c * 1024 + lane * 16;
+    const int r = o / pitch, s = (o - r * pitch) >> 4;
+    const int q = s ^ ((r & 3) << 2);
+    src_off[i] = (int64_t)r * (is_a ? lda : ldb) + q * 8;
+    lds_off[i] = (is_a ? 0 : WBM * 2 * BK) + c * 1024;
+  }
+  const bf16_t* gsrc = is_a ? A + m0 : Bm + n0;
+  const int64_t gld = is_a ? lda : ldb;
+  auto stage = [&](int st, int buf) {
+    char* base = smem + buf * W_STAGE;
+    const bf16_t* p = gsrc + (int64_t)st * BK * gld;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) glds16(p + src_off[i], base + lds_off[i]);
+  };
+
+  const int li = lane & 15, g = lane >> 4;
+  // byte offset of the transposing read for MFMA tile column base `cb`, sub-step kk, half, in an image of `pitch` bytes/row
+  auto tr_off = [&](int cb, int kk, int half, int pitch) -> int {
+    const int r = kk * 16 + (g >> 1) * 8 + half * 4 + (li >> 2);
+    const int col = cb + (g & 1) * 16 + (li & 3) * 4;
+    const int slot = (col >> 3) ^ ((r & 3) << 2);
+    return r * pitch + slot * 16 + (col & 7) * 2;
+  };
+
+  f32x16_t acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  stage(s_begin, 0);
+  for (int st = s_begin; st < s_end; ++st) {
+    const int it = st - s_begin;
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (st + 1 < s_end) stage(st + 1, (it + 1) & 1);
+    const char* ta = smem + (it & 1) * W_STAGE;
+    const char* tb = ta + WBM * 2 * BK;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8_t af[3], bfg[2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        union {
+          s16x4_t h[2];
+          bf16x8_t v;
+        } u;
+        u.h[0] = lds_tr16(ta + tr_off(wm * 96 + i * 32, kk, 0, WBM * 2));
+        u.h[1] = lds_tr16(ta + tr_off(wm * 96 + i * 32, kk, 1, WBM * 2));
+        af[i] = u.v;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        union {
+          s16x4_t h[2];
+          bf16x8_t v;
+        } u;
+        u.h[0] = lds_tr16(tb + tr_off(wn * 64 + j * 32, kk, 0, WBN * 2));
+        u.h[1] = lds_tr16(tb + tr_off(wn * 64 + j * 32, kk, 1, WBN * 2));
+        bfg[j] = u.v;
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfg[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 96 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        unsafeAtomicAdd(&C[(int64_t)m * ldc + n], acc[i][j][r]);
+      }
+    }
+}
+
 extern "C" int dl_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                           int64_t N, int64_t R, dl_stream_t stream) {
   DL_CHECK_ARG(A && B && C && M > 0 && N > 0 && R > 0, "dl_gemm_tn: null/empty operand");
@@ -355,6 +719,36 @@ extern "C" int dl_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb
   DL_CHECK_ARG(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N && ldc >= N,
                "dl_gemm_tn: M,N,lda,ldb must be multiples of 8 (M=%lld N=%lld)", (long long)M, (long long)N);
   DL_CHECK_ARG((((uintptr_t)A | (uintptr_t)B) & 15) == 0, "dl_gemm_tn: 16-byte alignment");
+  {
+    static int variant = -1, n_cu = 0;
+    if (variant < 0) {
+      const char* e = getenv("DL_GEMM_TN_VARIANT");
+      variant = e ? atoi(e) : 1;
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+      if (n_cu <= 0) n_cu = 256;
+      (void)hipFuncSetAttribute((const void*)gemm_tn_big_k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE);
+    }
+    const int nsteps = (int)(R / BK);
+    if (variant == 1 && M % WBM == 0 && N % WBN == 0 && nsteps >= 64) {
+      // one workgroup per CU at most (128 KiB of LDS each): units (= m-tiles x splits) are padded to a multiple of
+      // 8 for the XCD mapping, so pick the split count from the padded budget
+      const int tiles_m = (int)(M / WBM), tiles_n = (int)(N / WBN);
+      int padded_max = (n_cu / tiles_n) & ~7;
+      if (padded_max < 8) padded_max = 8;
+      int splits = padded_max / tiles_m;
+      if (splits < 1) splits = 1;
+      if (splits > nsteps / 8) splits = nsteps / 8;
+      const int sps = (nsteps + splits - 1) / splits;
+      splits = (nsteps + sps - 1) / sps;
+      const int units = (tiles_m * splits + 7) & ~7;  // surplus units exit at once
+      hipLaunchKernelGGL(gemm_tn_big_k, units * (int)(N / WBN), BIG_THREADS, 2 * W_STAGE, (hipStream_t)stream, (const bf16_t*)A,
+                         lda, (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)R, sps);
+      DL_LAUNCH_CHECK();
+      return DL_OK;
+    }
+  }
   const int ntile = cdiv(M, BM) * cdiv(N, BN);
   const int nsteps = (int)(R / BK);
   int splits = (1024 + ntile - 1) / ntile;  // aim at >= 4 workgroups per CU

@@ -69,7 +69,7 @@ def test_probe_tr16_lane_map(ops):
 
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(256, 384, 384), (300, 1152, 384), (64, 16, 384), (2, 384, 256), (512, 384, 1536),
-                                   (1024, 3072, 384), (130, 72, 64)])
+                                   (1024, 3072, 384), (130, 72, 64), (8192, 384, 1536), (16384, 1152, 384), (12288, 384, 384)])
 def test_gemm_nt_plain(ops, M, N, K):
     a = synth.normal(f"nt.a{M}", (M, K))
     b = synth.normal(f"nt.b{N}", (N, K), std=K**-0.5)
@@ -82,8 +82,9 @@ def test_gemm_nt_plain(ops, M, N, K):
     assert rel(out32, ref) < 2e-5  # f32 accumulate, order differs only
 
 
-def test_gemm_nt_epilogues(ops):
-    M, N, K, rows = 512, 384, 384, 128
+@pytest.mark.parametrize("M", [512, 8192])  # 8192 rows take the persistent big-tile kernel
+def test_gemm_nt_epilogues(ops, M):
+    N, K, rows = 384, 384, 128
     a, b = synth.normal("ep.a", (M, K)), synth.normal("ep.b", (N, K), std=K**-0.5)
     bias = synth.normal("ep.bias", (N,))
     resid = synth.normal("ep.res", (M, N))
@@ -106,7 +107,7 @@ def test_gemm_nt_epilogues(ops):
     assert rel(o32, bf(resid) + bf(a) @ bf(b).t()) < 2e-5
 
 
-@pytest.mark.parametrize("R,M,N", [(1024, 384, 1152), (128, 16, 384), (256, 2304, 64), (4096, 384, 384), (64, 136, 264)])
+@pytest.mark.parametrize("R,M,N", [(1024, 384, 1152), (128, 16, 384), (256, 2304, 64), (4096, 384, 384), (64, 136, 264), (8192, 1152, 384), (16384, 384, 1536)])
 def test_gemm_tn(ops, R, M, N):
     a = synth.normal(f"tn.a{R}{M}", (R, M))
     b = synth.normal(f"tn.b{R}{N}", (R, N))
