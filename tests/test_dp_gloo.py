@@ -1,0 +1,53 @@
+"""Data-parallel reducer on 2 CPU ranks (gloo): the N>1 path of bench.py / the trainer without a GPU.
+
+Checks the contract of SURVEY.md §8e: after `GradReducer` the flat gradient arena holds the SUM over ranks (the
+1/world average is applied by the optimizer kernel), ranges may arrive in any block order, buckets are contiguous,
+`sync=False` (gradient-accumulation micro-step) reduces nothing, and `broadcast_arena` makes ranks start equal."""
+
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank: int, world: int, port: int, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from diffulab_amd.training.dp import GradReducer, broadcast_arena
+
+    n = 1000
+    params = torch.full((n,), float(rank + 1))
+    broadcast_arena(params)
+    ok = bool((params == 1.0).all())
+    grads = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    red = GradReducer(grads, bucket_bytes=4 * 300)  # ~300-element buckets -> several collectives
+    ranges = [(700, 1000), (400, 700), (100, 400)]   # blocks finish last-to-first
+    for lo, hi in ranges:
+        red.ready(lo, hi)
+    red.ready(0, 100)
+    red.finish()
+    expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    ok &= bool(torch.equal(grads, expect)) and abs(red.grad_scale - 1.0 / world) < 1e-12
+    # accumulation micro-step: no communication, gradients untouched
+    g2 = torch.ones(n) * (rank + 1)
+    red2 = GradReducer(g2)
+    red2.sync = False
+    red2.ready(0, n)
+    red2.finish()
+    ok &= bool((g2 == rank + 1).all())
+    out[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_two_ranks_gloo():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    assert all(out[r] for r in range(world)), dict(out)

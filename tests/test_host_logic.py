@@ -1,0 +1,110 @@
+"""CPU tests of the host-side logic of the product package (no kernels are called): schedule tables, timestep draws,
+respacing, module/state_dict contract, flat-arena layout, optimizer/arena plumbing.  Expected values are the committed
+reference outputs (tests/golden/schedules.npz) -- bit-exact."""
+
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from diffulab_amd.diffuse.modelizations.flow import Flow
+from diffulab_amd.diffuse.modelizations.gaussian_diffusion import GaussianDiffusion
+from diffulab_amd.diffuse.modelizations.utils import space_timesteps
+from diffulab_amd.engine import DiTDims, ParamLayout, rope_grid_tables
+from diffulab_amd.networks.denoisers import MMDiT
+
+
+def t2n(x):
+    return x.detach().numpy()
+
+
+def test_flow_grid_and_draws_match_reference(golden):
+    g = golden("schedules")
+    for n in (4, 50, 100):
+        assert np.array_equal(np.array(Flow(n_steps=n).timesteps), g[f"flow_ts_n{n}"])
+        for sh in (4.63, 6.93):
+            f = Flow(n_steps=n, shift=sh)
+            assert np.array_equal(np.array(f.timesteps), g[f"flow_ts_ctor_n{n}_shift{sh}"])  # ctor shift: draws only
+            f.set_steps(n, shift=sh)
+            assert np.array_equal(np.array(f.timesteps), g[f"flow_ts_n{n}_shift{sh}"])
+    for seed in (0, 1, 2):
+        for B in (4, 64):
+            for tag, kw in (("uniform", {}), ("logit", {"logits_normal": True}),
+                            ("logit_shift", {"logits_normal": True, "shift": 4.63}), ("xpred", {"prediction_type": "x"})):
+                torch.manual_seed(seed)
+                assert np.array_equal(t2n(Flow(n_steps=10, **kw).draw_timesteps(B)), g[f"draw_flow_{tag}_s{seed}_b{B}"])
+            torch.manual_seed(seed)
+            got = GaussianDiffusion(n_steps=1000).draw_timesteps(B)
+            assert got.dtype == torch.int32 and np.array_equal(t2n(got), g[f"draw_ddpm_s{seed}_b{B}"])
+    with pytest.raises(NotImplementedError):
+        Flow(n_steps=4).set_steps(4, schedule="cosine")
+    with pytest.raises(AssertionError):
+        Flow(n_steps=4, prediction_type="eps")
+
+
+def test_gaussian_tables_and_respacing_match_reference(golden):
+    g = golden("schedules")
+    for sched in ("linear", "cosine"):
+        d = GaussianDiffusion(n_steps=1000, schedule=sched)
+        for nm in ("betas", "alphas_bar", "sqrt_alphas_bar"):
+            assert np.array_equal(t2n(getattr(d, nm)), g[f"gd_{sched}_{nm}"]), nm
+        for nm in ("alphas_bar_prev", "posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1",
+                   "posterior_mean_coef2"):
+            assert np.array_equal(t2n(getattr(d.sampler, nm)), g[f"gd_{sched}_{nm}"]), nm
+    for n in (50, 100, 250):
+        d = GaussianDiffusion(n_steps=1000)
+        d.set_steps(n)
+        assert np.array_equal(np.array(d.timestep_map), g[f"respace_{n}_map"])
+        assert np.array_equal(t2n(d.betas), g[f"respace_{n}_betas"])
+        assert np.array_equal(t2n(d.sampler.posterior_variance), g[f"respace_{n}_postvar"])
+    d = GaussianDiffusion(n_steps=1000)
+    d.set_steps(30, section_counts="10,10,10")
+    assert np.array_equal(np.array(d.timestep_map), g["respace_sections_map"])
+    assert np.array_equal(np.array(sorted(space_timesteps(1000, 10))), g["space_1000_10"])
+    with pytest.raises(ValueError):
+        space_timesteps(1000, 10, ddim=True)
+    with pytest.raises(ValueError):
+        space_timesteps(10, "6,6")
+    with pytest.raises(ValueError):
+        GaussianDiffusion(n_steps=10, sampling_method="euler")
+    with pytest.raises(NotImplementedError):
+        GaussianDiffusion(n_steps=10, schedule="sigmoid")
+
+
+def test_rope_tables_match_reference(golden):
+    g = golden("prims")
+    c, s = rope_grid_tables(16, 16, [32, 32], 10_000.0)
+    assert np.array_equal(t2n(c), g["rope_cos_16x16"]) and np.array_equal(t2n(s), g["rope_sin_16x16"])
+    c, s = rope_grid_tables(3, 5, [8, 24], 2000.0)
+    assert np.array_equal(t2n(c), g["rope_cos_3x5"]) and np.array_equal(t2n(s), g["rope_sin_3x5"])
+
+
+def test_module_contract_and_layout():
+    kw = dict(simple_dit=True, input_channels=4, inner_dim=384, embedding_dim=384, num_heads=6, patch_size=2, depth=12,
+              n_classes=1000, classifier_free=True)
+    m = MMDiT(**kw)
+    assert sum(p.numel() for p in m.parameters()) == 39_922_576  # SURVEY.md Appendix B (DiT-S/2 dims)
+    lay = ParamLayout(m.dims)
+    named = dict(m.named_parameters())
+    assert set(named) == set(lay.entries)
+    spans = sorted((off, off + int(np.prod(shape))) for off, shape in lay.entries.values())
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), "overlapping parameters in the arena"
+    assert all(off % 4 == 0 for off, _ in lay.entries.values())
+    # the adaLN matrices are one contiguous [L*6D+2D, E] block
+    first = lay.entries["layers.0.modulation.lin.weight"][0]
+    last_off, last_shape = lay.entries["last_layer.adaLN_modulation.1.weight"]
+    assert last_off + int(np.prod(last_shape)) - first == lay.mod_rows * 384
+    # reference init: zero adaLN, xavier elsewhere
+    assert float(m.layers[3].modulation.lin.weight.detach().abs().sum()) == 0.0
+    assert float(m.layers[3].attention.qkv.weight.detach().abs().sum()) > 0.0
+    # deep copies (EMA) keep parameters, drop the engine
+    m2 = copy.deepcopy(m)
+    assert m2._engine is None and torch.equal(m2.conv_proj.weight, m.conv_proj.weight)
+    # unsupported reference modes fail loudly, never silently fall back
+    with pytest.raises(NotImplementedError):
+        MMDiT(simple_dit=False)
+    with pytest.raises(NotImplementedError):
+        DiTDims(inner_dim=384, num_heads=4).validate()
+    with pytest.raises(RuntimeError):
+        m(x=torch.zeros(1, 4, 32, 32), timesteps=torch.zeros(1), y=torch.zeros(1, dtype=torch.long))  # CPU: no fallback
