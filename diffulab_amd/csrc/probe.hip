@@ -1,0 +1,104 @@
+// Microarchitecture probes (tests / tuning only): sustained MFMA rate with and without the LDS fragment traffic and
+// the workgroup barrier of the GEMM main loop.  mode 0: MFMA only; 1: + ds_read_b128 fragments (256x192 tile pattern);
+// 2: + one s_barrier per k-step; 3: + direct-to-LDS DMA of a 56 KiB stage per k-step from `src` (L2-resident).
+#include "common.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void mfma_probe_k(const bf16_t* __restrict__ src, float* __restrict__ out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  for (int i = threadIdx.x; i < 114688 / 4; i += 512) ((uint32_t*)smem)[i] = 0x3c003c00u + i;  // small finite bf16s
+  __syncthreads();
+  f32x16_t acc[3][2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+  bf16x8_t xf[2], wf[3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xf[i][e] = (__bf16)(0.001f * (lane + e + i));
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wf[j][e] = (__bf16)(0.002f * (lane - e + j));
+  const bf16_t* gsrc = src + (int64_t)blockIdx.x * 57344 / 2;
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 3) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (MODE >= 2) __builtin_amdgcn_s_barrier();
+    u32x4_t stg[7];
+    if (MODE == 4) {  // register staging: global -> VGPR now, VGPR -> LDS after this k-step's MFMAs
+#pragma unroll
+      for (int c = 0; c < 7; ++c) stg[c] = *(const u32x4_t*)(gsrc + ((wave * 7 + c) * 1024 + lane * 16) / 2);
+    }
+    if (MODE == 3) {
+      char* base = smem + ((it + 1) & 1) * 57344;
+#pragma unroll
+      for (int c = 0; c < 7; ++c)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc + ((wave * 7 + c) * 1024 + lane * 16) / 2),
+                                         (lds_void_t*)(base + (wave * 7 + c) * 1024), 16, 0, 0);
+    }
+    const char* sa = smem + (it & 1) * 57344;
+    const char* sb = sa + 32768;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (MODE >= 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = wm * 64 + i * 32 + (lane & 31);
+          xf[i] = *(const bf16x8_t*)(sa + r * 128 + ((((kk << 1) | hi) ^ ((r >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int r = wn * 96 + j * 32 + (lane & 31);
+          wf[j] = *(const bf16x8_t*)(sb + r * 128 + ((((kk << 1) | hi) ^ ((r >> 1) & 7)) << 4));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+    }
+    if (MODE == 4) {
+      char* base = smem + ((it + 1) & 1) * 57344;
+#pragma unroll
+      for (int c = 0; c < 7; ++c) *(u32x4_t*)(base + (wave * 7 + c) * 1024 + lane * 16) = stg[c];
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[j][i][r];
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
+extern "C" int dl_probe_mfma(int mode, int iters, const void* src, float* out, dl_stream_t stream) {
+  DL_CHECK_ARG(out && iters > 0 && mode >= 0 && mode <= 4 && (mode < 3 || src), "dl_probe_mfma: bad args");
+  const int lds = 114688;
+#define GO(MODE)                                                                                               \
+  do {                                                                                                         \
+    (void)hipFuncSetAttribute((const void*)mfma_probe_k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+    hipLaunchKernelGGL(mfma_probe_k<MODE>, 256, 512, lds, (hipStream_t)stream, (const bf16_t*)src, out, iters);   \
+  } while (0)
+  if (mode == 0) GO(0);
+  else if (mode == 1) GO(1);
+  else if (mode == 2) GO(2);
+  else if (mode == 3) GO(3);
+  else GO(4);
+#undef GO
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}

@@ -198,6 +198,10 @@ DL_API int dl_ema_update(float* ema, const float* p, float beta, int64_t n, dl_s
 /* raw ds_read_b64_tr_b16 lane map: fills out[64*4] with what each lane receives when lane l passes
  * address 8*l over an LDS image holding the uint16 values 0..255 */
 DL_API int dl_probe_tr16(uint16_t* out, dl_stream_t stream);
+/* sustained MFMA 32x32x16 bf16 rate of the GEMM main-loop skeleton on 256 workgroups x 8 waves, `iters` k-steps of
+ * 24 MFMAs per wave: mode 0 MFMA only, 1 + LDS fragment reads, 2 + one workgroup barrier per k-step, 3 + the 56 KiB
+ * direct-to-LDS DMA per k-step from `src` (>= 256*57344 bytes).  out: f32 [256*512] (sink). */
+DL_API int dl_probe_mfma(int mode, int iters, const void* src, float* out, dl_stream_t stream);
 
 #ifdef __cplusplus
 }
