@@ -39,6 +39,10 @@ struct NtEpilogue {
   const bf16_t* gate;
   int64_t ldg;
   int64_t rows_per_gate;
+  // fused SwiGLU (EPI 2: forward, EPI 3: backward): `aux` is h (fwd, written) / u (bwd, read), F = hidden width
+  bf16_t* aux;
+  int64_t ld_aux;
+  int F;
 };
 
 __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restrict__ A, int64_t lda,
@@ -238,6 +242,10 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <int JN, int TN_, int EPI>
+__device__ __forceinline__ void nt_epilogue_regs(f32x16_t (&acc)[JN][2], int m_base, int n_base, int lane, void* C,
+                                                 int64_t ldc, const NtEpilogue& ep);
+
 template <int TN_, int NST, int EPI>
 __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __restrict__ A, int64_t lda,
                                                                   const bf16_t* __restrict__ Bm, int64_t ldb,
@@ -344,87 +352,15 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
       after_epi = true;
       // ---- epilogue of `tile` straight from registers: acc[j][i][r] = C[m][n] with
       //      m = m0 + wm*64 + i*32 + (lane&31),  n = n0 + wn*TN/2 + j*32 + 8*(r>>2) + 4*hi + (r&3)
-      const int m0 = (tile / tiles_n) * TBM, n0 = (tile % tiles_n) * TN_;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + i * 32 + (lane & 31);
-        const bf16_t* gate_row = (EPI && ep.gate) ? ep.gate + (int64_t)(m / (int)ep.rows_per_gate) * ep.ldg : nullptr;
-#pragma unroll
-        for (int j = 0; j < JN; ++j) {
-#pragma unroll
-          for (int gp = 0; gp < 2; ++gp) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              // half exchange: afterwards lanes 0-31 hold columns +0..7, lanes 32-63 columns +8..15 of this 16-group
-              const unsigned x = __float_as_uint(acc[j][i][8 * gp + e]), y = __float_as_uint(acc[j][i][8 * gp + 4 + e]);
-              auto sw = __builtin_amdgcn_permlane32_swap(x, y, false, false);
-              v[e] = __uint_as_float(sw[0]);
-              v[4 + e] = __uint_as_float(sw[1]);
-              acc[j][i][8 * gp + e] = 0.f;
-              acc[j][i][8 * gp + 4 + e] = 0.f;
-            }
-            const int n = n0 + wn * (TN_ / 2) + j * 32 + 16 * gp + 8 * hi;
-            if (EPI) {
-              if (ep.bias) {
-                const f32x4_t b0 = *(const f32x4_t*)(ep.bias + n), b1 = *(const f32x4_t*)(ep.bias + n + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  v[e] += b0[e];
-                  v[4 + e] += b1[e];
-                }
-              }
-              if (ep.pre_out) *(u32x4_t*)(ep.pre_out + (int64_t)m * ldc + n) = pack8(v);
-              if (ep.act == DL_ACT_SILU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-              }
-              if (ep.resid) {
-                float rr[8];
-                unpack8(*(const u32x4_t*)(ep.resid + (int64_t)m * ep.ldr + n), rr);
-                if (gate_row) {
-                  float gg[8];
-                  unpack8(*(const u32x4_t*)(gate_row + n), gg);
-#pragma unroll
-                  for (int e = 0; e < 8; ++e) v[e] = rr[e] + gg[e] * v[e];
-                } else {
-#pragma unroll
-                  for (int e = 0; e < 8; ++e) v[e] += rr[e];
-                }
-              }
-              if (ep.out_f32) {
-                float* cp = (float*)C + (int64_t)m * ldc + n;
-                *(f32x4_t*)cp = *(f32x4_t*)&v[0];
-                *(f32x4_t*)(cp + 4) = *(f32x4_t*)&v[4];
-              } else {
-                *(u32x4_t*)((bf16_t*)C + (int64_t)m * ldc + n) = pack8(v);
-              }
-            } else {
-              *(u32x4_t*)((bf16_t*)C + (int64_t)m * ldc + n) = pack8(v);
-            }
-          }
-        }
-      }
+      nt_epilogue_regs<JN, TN_, EPI>(acc, (tile / tiles_n) * TBM + wm * 64, (tile % tiles_n) * TN_ + wn * (TN_ / 2), lane, C,
+                                     ldc, ep);
       if (EPI) wait_vmcnt<0>();  // unknown number of epilogue memory ops: drain so the counted waits stay exact
       tile += G;
     }
   }
 }
 
-// =====================================================================================================
-// gemm_nt_pp_k: "ping-pong" variant of the persistent 256x192 kernel.
-//
-// PMC of gemm_nt_big_k: MFMA busy 28-43 % although neither LDS, nor HBM, nor the instruction mix is near a limit:
-// all 8 waves run the same phase (barrier -> DMA issue -> LDS reads -> MFMAs), so the matrix pipes idle while every
-// wave is in its load phase.  Here the 8 waves form two groups of 4 (one wave of each group per SIMD) running the
-// same code HALF A K-STEP APART, separated by workgroup barriers:
-//      group A:  LOAD(k)  | MFMA(k)   | LOAD(k+1) | MFMA(k+1) | ...
-//      group B:  MFMA(k-1)| LOAD(k)   | MFMA(k)   | LOAD(k+1) | ...
-// LOAD = all 20 fragment reads of a k-step into registers (80 VGPRs) + (group A only) the DMA of the next stage +
-// the epilogue of the tile that just finished (accumulators are idle during LOAD, so the stores, conversions and
-// permlane swaps hide under the other group's MFMAs); MFMA = 24 back-to-back matrix ops from registers at
-// raised priority.  One SIMD therefore always has a wave in its MFMA phase.
-// =====================================================================================================
+// register epilogue shared by the big-tile kernels (see gemm_nt_big_k header)
 template <int JN, int TN_, int EPI>
 __device__ __forceinline__ void nt_epilogue_regs(f32x16_t (&acc)[JN][2], int m_base, int n_base, int lane, void* C,
                                                  int64_t ldc, const NtEpilogue& ep) {
@@ -432,7 +368,95 @@ __device__ __forceinline__ void nt_epilogue_regs(f32x16_t (&acc)[JN][2], int m_b
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m_base + i * 32 + (lane & 31);
+    if (EPI == 2) {
+      // fused PackedSwiGLU forward (nn.py:484-486).  The weight shadow is row-permuted so that, inside every 16-column
+      // group of the tile, columns 0..7 are x1[8q..8q+7] and columns 8..15 are x3[8q..8q+7] (q = group index): BEFORE
+      // the half exchange a lane then holds x1 and x3 of the SAME 4 hidden units (acc regs 8gp+e and 8gp+4+e).
+#pragma unroll
+      for (int j = 0; j < JN; ++j) {
+        const int q0 = (n_base + j * 32) >> 4;  // first of the two 16-column groups of this 32-wide MFMA tile
+        float hv[2][4];
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x1 = acc[j][i][8 * gp + e], x3 = acc[j][i][8 * gp + 4 + e];
+            hv[gp][e] = silu_f(x1) * x3;
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x1), __float_as_uint(x3), false, false);
+            v[e] = __uint_as_float(sw[0]);      // lanes 0-31: x1[8q+0..3] | lanes 32-63: x3[8q+0..3]
+            v[4 + e] = __uint_as_float(sw[1]);  // lanes 0-31: x1[8q+4..7] | lanes 32-63: x3[8q+4..7]
+            acc[j][i][8 * gp + e] = 0.f;
+            acc[j][i][8 * gp + 4 + e] = 0.f;
+          }
+          // pre-activations in the reference layout u = [x1 | x3] (needed by the backward)
+          *(u32x4_t*)((bf16_t*)C + (int64_t)m * ldc + (hi ? ep.F : 0) + 8 * (q0 + gp)) = pack8(v);
+        }
+        float h8[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(hv[0][e]), __float_as_uint(hv[1][e]), false, false);
+          h8[e] = __uint_as_float(sw[0]);      // lanes 0-31: h[8q0+0..3]   | lanes 32-63: h[8(q0+1)+0..3]
+          h8[4 + e] = __uint_as_float(sw[1]);  // lanes 0-31: h[8q0+4..7]   | lanes 32-63: h[8(q0+1)+4..7]
+        }
+        *(u32x4_t*)(ep.aux + (int64_t)m * ep.ld_aux + 8 * (q0 + hi)) = pack8(h8);
+      }
+      continue;
+    }
+    if (EPI == 3) {
+      // fused PackedSwiGLU backward: acc = dh tile; du1 = dh * x3 * silu'(x1), du3 = dh * silu(x1) with u = [x1 | x3]
+      // all loads of this row group are issued first (one exposed memory latency per group, not one per chunk)
+      u32x4_t la[JN][2], lb[JN][2];
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const int c = n_base + j * 32 + 16 * gp + 8 * hi;
+          la[j][gp] = *(const u32x4_t*)(ep.aux + (int64_t)m * ep.ld_aux + c);
+          lb[j][gp] = *(const u32x4_t*)(ep.aux + (int64_t)m * ep.ld_aux + ep.F + c);
+        }
+#pragma unroll
+      for (int j = 0; j < JN; ++j) {
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned x = __float_as_uint(acc[j][i][8 * gp + e]), y = __float_as_uint(acc[j][i][8 * gp + 4 + e]);
+            auto sw = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+            v[e] = __uint_as_float(sw[0]);
+            v[4 + e] = __uint_as_float(sw[1]);
+            acc[j][i][8 * gp + e] = 0.f;
+            acc[j][i][8 * gp + 4 + e] = 0.f;
+          }
+          const int c = n_base + j * 32 + 16 * gp + 8 * hi;
+          float a[8], b[8], d1[8], d3[8];
+          unpack8(la[j][gp], a);
+          unpack8(lb[j][gp], b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            d1[e] = v[e] * b[e] * dsilu_f(a[e]);
+            d3[e] = v[e] * silu_f(a[e]);
+          }
+          *(u32x4_t*)((bf16_t*)C + (int64_t)m * ldc + c) = pack8(d1);
+          *(u32x4_t*)((bf16_t*)C + (int64_t)m * ldc + ep.F + c) = pack8(d3);
+        }
+      }
+      continue;
+    }
     const bf16_t* gate_row = (EPI && ep.gate) ? ep.gate + (int64_t)(m / (int)ep.rows_per_gate) * ep.ldg : nullptr;
+    // residual / gate rows of this row group are fetched up front (one exposed memory latency per group, not per chunk)
+    u32x4_t lr[JN][2], lg[JN][2];
+    if (EPI == 1 && ep.resid) {
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const int n = n_base + j * 32 + 16 * gp + 8 * hi;
+          lr[j][gp] = *(const u32x4_t*)(ep.resid + (int64_t)m * ep.ldr + n);
+          if (gate_row) lg[j][gp] = *(const u32x4_t*)(gate_row + n);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
 #pragma unroll
@@ -464,10 +488,10 @@ __device__ __forceinline__ void nt_epilogue_regs(f32x16_t (&acc)[JN][2], int m_b
           }
           if (ep.resid) {
             float rr[8];
-            unpack8(*(const u32x4_t*)(ep.resid + (int64_t)m * ep.ldr + n), rr);
+            unpack8(lr[j][gp], rr);
             if (gate_row) {
               float gg[8];
-              unpack8(*(const u32x4_t*)(gate_row + n), gg);
+              unpack8(lg[j][gp], gg);
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = rr[e] + gg[e] * v[e];
             } else {
@@ -490,143 +514,9 @@ __device__ __forceinline__ void nt_epilogue_regs(f32x16_t (&acc)[JN][2], int m_b
   }
 }
 
-__device__ __forceinline__ void wg_barrier() {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("" ::: "memory");
-}
-
-template <int EPI>
-__global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_pp_k(const bf16_t* __restrict__ A, int64_t lda,
-                                                                 const bf16_t* __restrict__ Bm, int64_t ldb,
-                                                                 void* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                                 NtEpilogue ep) {
-  constexpr int TN_ = 192, JN = 3;
-  constexpr int STAGE = (TBM + TN_) * 128;  // 57344 B, two slots
-  constexpr int CHG = (TBM + TN_) / 8 / 4;  // 14 DMA chunks per wave of the loading group (group A)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, hi = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int grp = wave >> 2;  // waves w and w+4 share a SIMD: one of each group per SIMD
-  const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = N / TN_, ntiles = (M / TBM) * tiles_n;
-  const int nk = K / BK;
-  const int G = gridDim.x;
-  const int slot0 = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-  const int cnt = (ntiles - slot0 + G - 1) / G;
-  const int total = cnt * nk;
-
-  // DMA bookkeeping (only group A issues): wave w (0..3) copies chunks 14w .. 14w+13 of the 56-chunk stage
-  int64_t src_off[CHG];
-  int lds_off[CHG];
-  bool is_a[CHG];
-#pragma unroll
-  for (int i = 0; i < CHG; ++i) {
-    const int c = (wave & 3) * CHG + i;
-    is_a[i] = c < TBM / 8;
-    const int cc = is_a[i] ? c : c - TBM / 8;
-    const int r = cc * 8 + (lane >> 3);
-    const int q = (lane & 7) ^ ((r >> 1) & 7);
-    src_off[i] = (int64_t)r * (is_a[i] ? lda : ldb) + q * 8;
-    lds_off[i] = (is_a[i] ? 0 : TBM * 128) + cc * 1024;
-  }
-  int s_tile = slot0, s_kt = 0, s_it = 0;
-  const bf16_t* s_ta = A + (int64_t)((s_tile / tiles_n) * TBM) * lda;
-  const bf16_t* s_tb = Bm + (int64_t)((s_tile % tiles_n) * TN_) * ldb;
-  auto stage_next = [&]() {
-    char* base = smem + (s_it & 1) * STAGE;
-#pragma unroll
-    for (int i = 0; i < CHG; ++i) glds16((is_a[i] ? s_ta : s_tb) + src_off[i] + s_kt * BK, base + lds_off[i]);
-    ++s_it;
-    if (++s_kt == nk) {
-      s_kt = 0;
-      s_tile += G;
-      s_ta = A + (int64_t)((s_tile / tiles_n) * TBM) * lda;
-      s_tb = Bm + (int64_t)((s_tile % tiles_n) * TN_) * ldb;
-    }
-  };
-
-  int xoff[2], woff[JN];  // row byte offsets; the k-slot swizzle is applied per sub-step
-  int xsw[2], wsw[JN];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = wm * 64 + i * 32 + (lane & 31);
-    xoff[i] = r * 128;
-    xsw[i] = (r >> 1) & 7;
-  }
-#pragma unroll
-  for (int j = 0; j < JN; ++j) {
-    const int r = wn * (TN_ / 2) + j * 32 + (lane & 31);
-    woff[j] = TBM * 128 + r * 128;
-    wsw[j] = (r >> 1) & 7;
-  }
-
-  f32x16_t acc[JN][2];
-#pragma unroll
-  for (int j = 0; j < JN; ++j)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-
-  // prologue: stage 0 (group A), then B falls one phase behind
-  if (grp == 0 && total > 0) {
-    stage_next();
-    wait_vmcnt<0>();
-  }
-  wg_barrier();
-  if (grp == 1) wg_barrier();
-
-  int tile = slot0, kt = 0;
-  bool pending = false;
-  int done_tile = slot0;
-  for (int it = 0; it < total; ++it) {
-    // ---------------- LOAD phase (the other group is in its MFMA phase)
-    if (pending) {
-      nt_epilogue_regs<JN, TN_, EPI>(acc, (done_tile / tiles_n) * TBM + wm * 64, (done_tile % tiles_n) * TN_ + wn * (TN_ / 2),
-                                     lane, C, ldc, ep);
-      pending = false;
-    }
-    if (grp == 0 && s_it < total) stage_next();  // next stage into the slot both groups finished reading
-    const char* st = smem + (it & 1) * STAGE;
-    bf16x8_t xf[4][2], wf[4][JN];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) xf[kk][i] = *(const bf16x8_t*)(st + xoff[i] + ((((kk << 1) | hi) ^ xsw[i]) << 4));
-#pragma unroll
-      for (int j = 0; j < JN; ++j) wf[kk][j] = *(const bf16x8_t*)(st + woff[j] + ((((kk << 1) | hi) ^ wsw[j]) << 4));
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    wg_barrier();
-    // ---------------- MFMA phase
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for (int j = 0; j < JN; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][j], xf[kk][i], acc[j][i], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    if (++kt == nk) {
-      kt = 0;
-      pending = true;
-      done_tile = tile;
-      tile += G;
-    }
-    if (grp == 0) wait_vmcnt<0>();  // the stage issued at the top of this iteration has had a full phase pair to land
-    wg_barrier();
-  }
-  if (grp == 0) wg_barrier();
-  if (pending)
-    nt_epilogue_regs<JN, TN_, EPI>(acc, (done_tile / tiles_n) * TBM + wm * 64, (done_tile % tiles_n) * TN_ + wn * (TN_ / 2), lane,
-                                   C, ldc, ep);
-}
-
 template <int TN_, int NST>
 static int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
-                      int64_t N, int64_t K, const NtEpilogue& ep, bool plain, hipStream_t stream) {
+                      int64_t N, int64_t K, const NtEpilogue& ep, int epi, hipStream_t stream) {
   constexpr int LDS = NST * (TBM + TN_) * 128;
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -636,18 +526,41 @@ static int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, vo
     if (n_cu <= 0) n_cu = 256;
     (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   }
   const int ntiles = (int)((M / TBM) * (N / TN_));
   int grid = n_cu < ntiles ? n_cu : ntiles;
   grid &= ~7;
-  if (plain)
-    hipLaunchKernelGGL((gemm_nt_big_k<TN_, NST, 0>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)A, lda,
-                       (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep);
-  else
-    hipLaunchKernelGGL((gemm_nt_big_k<TN_, NST, 1>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)A, lda,
-                       (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep);
+#define BIG_GO(E)                                                                                                     \
+  hipLaunchKernelGGL((gemm_nt_big_k<TN_, NST, E>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)A, lda, (const bf16_t*)B, \
+                     ldb, C, ldc, (int)M, (int)N, (int)K, ep)
+  if (epi == 0) BIG_GO(0);
+  else if (epi == 1) BIG_GO(1);
+  else if (epi == 2) BIG_GO(2);
+  else BIG_GO(3);
+#undef BIG_GO
   DL_LAUNCH_CHECK();
   return DL_OK;
+}
+
+// picks the big-tile variant; returns 1 if no big kernel applies (caller falls back), else the launch status (<= 0)
+static int dispatch_big(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+                        int64_t K, const NtEpilogue& ep, int epi, hipStream_t stream) {
+  static int variant = -1;
+  if (variant < 0) {
+    const char* e = getenv("DL_GEMM_NT_VARIANT");
+    variant = e ? atoi(e) : 4;  // 4 = 256x384 tiles where N % 384 == 0, else 256x192 (best measured); 2 = 256x192 only;
+                                // 1 = 256x128 3-stage ring; 0 = small-tile kernel only
+  }
+  if (M % TBM) return 1;
+  if (variant == 1 && N % 128 == 0 && (M / TBM) * (N / 128) >= 64)
+    return launch_big<128, 3>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
+  if (variant == 4 && (epi == 0 || epi == 2) && N % 384 == 0 && (M / TBM) * (N / 384) >= 64)
+    return launch_big<384, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
+  if ((variant == 2 || variant == 4) && N % 192 == 0 && (M / TBM) * (N / 192) >= 64)
+    return launch_big<192, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
+  return 1;
 }
 
 extern "C" int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
@@ -665,51 +578,52 @@ extern "C" int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb
                "dl_gemm_nt: gate needs resid, rows_per_gate>0, aligned rows");
   DL_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31), "dl_gemm_nt: dims too large");
   NtEpilogue ep{bias, act, out_dtype == DL_F32, (bf16_t*)pre_out, (const bf16_t*)resid, ldr, (const bf16_t*)gate,
-                ldg, rows_per_gate > 0 ? rows_per_gate : 1};
+                ldg, rows_per_gate > 0 ? rows_per_gate : 1, nullptr, 0, 0};
   {
-    // big-tile persistent kernels for the token GEMMs; variant picked by an env knob while tuning
-    static int variant = -1;
-    if (variant < 0) {
-      const char* e = getenv("DL_GEMM_NT_VARIANT");
-      variant = e ? atoi(e) : 4;  // 4 = 256x384 tiles where N % 384 == 0, else 256x192 (best measured); 2 = 256x192 only;
-                                  // 1 = 256x128 3-stage ring; 3 = 256x192 ping-pong; 0 = small-tile kernel only
-    }
     const bool plain = !bias && act == DL_ACT_NONE && out_dtype == DL_BF16 && !pre_out && !resid;
-    const bool aligned = !bias || ((uintptr_t)bias & 15) == 0;
-    if (variant == 1 && aligned && M % TBM == 0 && N % 128 == 0 && (M / TBM) * (N / 128) >= 64)
-      return launch_big<128, 3>(A, lda, B, ldb, C, ldc, M, N, K, ep, plain, (hipStream_t)stream);
-    if (variant == 3 && aligned && M % TBM == 0 && N % 192 == 0 && (M / TBM) * (N / 192) >= 64) {
-      static int n_cu = 0;
-      if (n_cu == 0) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (n_cu <= 0) n_cu = 256;
-        (void)hipFuncSetAttribute((const void*)gemm_nt_pp_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TBM + 192) * 128);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_pp_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TBM + 192) * 128);
-      }
-      const int ntiles = (int)((M / TBM) * (N / 192));
-      int grid = n_cu < ntiles ? n_cu : ntiles;
-      grid &= ~7;
-      if (plain)
-        hipLaunchKernelGGL(gemm_nt_pp_k<0>, grid, BIG_THREADS, 2 * (TBM + 192) * 128, (hipStream_t)stream, (const bf16_t*)A,
-                           lda, (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep);
-      else
-        hipLaunchKernelGGL(gemm_nt_pp_k<1>, grid, BIG_THREADS, 2 * (TBM + 192) * 128, (hipStream_t)stream, (const bf16_t*)A,
-                           lda, (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep);
-      DL_LAUNCH_CHECK();
-      return DL_OK;
+    if (!bias || ((uintptr_t)bias & 15) == 0) {
+      const int rc = dispatch_big(A, lda, B, ldb, C, ldc, M, N, K, ep, plain ? 0 : 1, (hipStream_t)stream);
+      if (rc <= 0) return rc;
     }
-    if (variant == 4 && aligned && M % TBM == 0 && N % 384 == 0 && (M / TBM) * (N / 384) >= 64)
-      return launch_big<384, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, plain, (hipStream_t)stream);
-    if ((variant == 2 || variant == 4) && aligned && M % TBM == 0 && N % 192 == 0 && (M / TBM) * (N / 192) >= 64)
-      return launch_big<192, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, plain, (hipStream_t)stream);
   }
   const int nwg = cdiv(M, BM) * cdiv(N, BN);
   hipLaunchKernelGGL(gemm_nt_k, nwg, NT_THREADS, NT_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)A, lda,
                      (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep);
   DL_LAUNCH_CHECK();
   return DL_OK;
+}
+
+/* fused MLP-up + PackedSwiGLU forward: U = X W1^T (reference layout [x1 | x3]) and H = silu(x1) * x3 in one pass.
+ * Wp is the row-permuted bf16 shadow produced by dl_cast_weight_swiglu.  Returns DL_ERR_UNSUPPORTED when the shape has
+ * no big-tile kernel (caller then runs dl_gemm_nt + dl_swiglu_fwd). */
+extern "C" int dl_gemm_nt_swiglu(const void* X, int64_t ldx, const void* Wp, int64_t ldw, void* U, int64_t ldu, void* H,
+                                 int64_t ldh, int64_t M, int64_t F, int64_t K, dl_stream_t stream) {
+  DL_CHECK_ARG(X && Wp && U && H && M > 0 && F > 0 && K > 0, "dl_gemm_nt_swiglu: null/empty operand");
+  DL_CHECK_ARG(K % BK == 0 && F % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldu % 8 == 0 && ldh % 8 == 0,
+               "dl_gemm_nt_swiglu: K %% 64, F/ld %% 8");
+  NtEpilogue ep{nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 1, (bf16_t*)H, ldh, (int)F};
+  const int rc = dispatch_big(X, ldx, Wp, ldw, U, ldu, M, 2 * F, K, ep, 2, (hipStream_t)stream);
+  if (rc == 1) {
+    dl_set_error("dl_gemm_nt_swiglu: no fused kernel for M=%lld F=%lld", (long long)M, (long long)F);
+    return DL_ERR_UNSUPPORTED;
+  }
+  return rc;
+}
+
+/* fused MLP-down dgrad + PackedSwiGLU backward: dH = dT W2 (never materialised), dU = [dH * x3 * silu'(x1) | dH * silu(x1)].
+ * W2t = transposed bf16 shadow [F, K=D]; U = saved pre-activations [M, 2F]. */
+extern "C" int dl_gemm_nt_dswiglu(const void* dT, int64_t ldt, const void* W2t, int64_t ldw, const void* U, int64_t ldu,
+                                  void* dU, int64_t lddu, int64_t M, int64_t F, int64_t K, dl_stream_t stream) {
+  DL_CHECK_ARG(dT && W2t && U && dU && M > 0 && F > 0 && K > 0, "dl_gemm_nt_dswiglu: null/empty operand");
+  DL_CHECK_ARG(K % BK == 0 && F % 8 == 0 && ldt % 8 == 0 && ldw % 8 == 0 && ldu % 8 == 0 && lddu % 8 == 0,
+               "dl_gemm_nt_dswiglu: K %% 64, F/ld %% 8");
+  NtEpilogue ep{nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 1, (bf16_t*)U, ldu, (int)F};
+  const int rc = dispatch_big(dT, ldt, W2t, ldw, dU, lddu, M, F, K, ep, 3, (hipStream_t)stream);
+  if (rc == 1) {
+    dl_set_error("dl_gemm_nt_dswiglu: no fused kernel for M=%lld F=%lld", (long long)M, (long long)F);
+    return DL_ERR_UNSUPPORTED;
+  }
+  return rc;
 }
 
 // =====================================================================================================

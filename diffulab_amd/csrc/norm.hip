@@ -131,11 +131,12 @@ __global__ __launch_bounds__(512) void ln_mod_bwd_k(const bf16_t* __restrict__ d
                                                     bf16_t* __restrict__ dshift, int64_t ld_dmod,
                                                     float* __restrict__ dwb, int64_t M, int D) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = (float*)smem;  // [LNB_WAVES][4][D]
+  float* red = (float*)smem;  // [4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D8 = D >> 3;
   const float invD = 1.0f / (float)D;
   const int64_t g = blockIdx.x;
+  for (int i = threadIdx.x; i < 4 * D; i += 512) red[i] = 0.f;
   float wv[NJ][8], bv[NJ][8], sc[NJ][8];
   load_row_f32<NJ>(w, D8, lane, wv, 1.0f);
   load_row_f32<NJ>(b, D8, lane, bv, 0.0f);
@@ -190,26 +191,26 @@ __global__ __launch_bounds__(512) void ln_mod_bwd_k(const bf16_t* __restrict__ d
     store_row<NJ>(dx + row * D, D8, lane, rv);
   }
 
-  // cross-wave reduction of the four column sums
+  // cross-wave reduction of the four column sums: LDS float atomics into ONE [4][D] slab (6 KiB at D = 384), so the
+  // kernel co-resides with a GEMM workgroup that holds 128 KiB of the CU's LDS (the side-stream wgrad overlap)
+  __syncthreads();  // zero-fill below happened before the row loop
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int c = lane + 64 * j;
     if (c < D8) {
-      float* base = red + (size_t)wave * 4 * D + c * 8;
+      float* base = red + c * 8;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        base[e] = a_dsc[j][e];
-        base[D + e] = a_dsh[j][e];
-        base[2 * D + e] = a_dw[j][e];
-        base[3 * D + e] = a_db[j][e];
+        atomicAdd(base + e, a_dsc[j][e]);
+        atomicAdd(base + D + e, a_dsh[j][e]);
+        atomicAdd(base + 2 * D + e, a_dw[j][e]);
+        atomicAdd(base + 3 * D + e, a_db[j][e]);
       }
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 4 * D; i += 512) {
-    float s = 0.f;
-#pragma unroll
-    for (int wv_ = 0; wv_ < LNB_WAVES; ++wv_) s += red[(size_t)wv_ * 4 * D + i];
+    const float s = red[i];
     const int which = i / D, col = i - which * D;
     if (which == 0) dscale[g * ld_dmod + col] = f2bf(s);
     else if (which == 1) dshift[g * ld_dmod + col] = f2bf(s);
@@ -229,8 +230,7 @@ extern "C" int dl_ln_modulate_bwd(const void* dout, const void* x, const float* 
                "dl_ln_modulate_bwd: 16-byte alignment");
   const int nj = cdiv(D, 512);
   const int groups = (int)(M / rows_per_mod);
-  const size_t lds = (size_t)LNB_WAVES * 4 * D * sizeof(float);
-  DL_CHECK_ARG(lds <= 160 * 1024, "dl_ln_modulate_bwd: D too large for the LDS reduction");
+  const size_t lds = (size_t)4 * D * sizeof(float);
 #define LAUNCH(NJ)                                                                                                   \
   do {                                                                                                               \
     (void)hipFuncSetAttribute((const void*)ln_mod_bwd_k<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \

@@ -199,6 +199,7 @@ class DiTEngine:
             reg(pre + "attention.qkv.weight", 3 * D, D)
             reg(pre + "attention.proj_out.weight", D, D)
             reg(pre + "mlp_input.0.weight", 2 * d.mlp_ratio * D, D)
+            self.sh[pre + "mlp_input.0.weight|g"] = torch.zeros(2 * d.mlp_ratio * D, D, device=dev, dtype=torch.bfloat16)
             reg(pre + "mlp_input.2.weight", D, d.mlp_ratio * D)
 
     def _src(self, name: str, shape: tuple[int, int]) -> Tensor:
@@ -214,7 +215,15 @@ class DiTEngine:
             return
         for name, shape, f, t in self._casts:
             ops.cast_weight(self._src(name, shape), self.sh[f] if f else None, self.sh[t] if t else None)
+        for i in range(self.d.depth):  # row-permuted copy of the packed SwiGLU weight for the fused MLP-up kernel
+            name = f"layers.{i}.mlp_input.0.weight"
+            ops.cast_weight_swiglu(self.P(name), self.sh[name + "|g"])
         self._shadow_key = key
+
+    def _side_stream(self) -> "torch.cuda.Stream":
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
 
     def params_changed(self) -> None:
         """call after writing the parameter arena through a raw pointer (fused AdamW)."""
@@ -268,10 +277,12 @@ class DiTEngine:
         if train:
             w["dO"] = z(M, 64)
             w["dxa"], w["dxb"] = z(M, D), z(M, D)
-            w["dt"], w["dxm"], w["da"] = z(M, D), z(M, D), z(M, D)
-            w["dh"], w["du"] = z(M, d.mlp_ratio * D), z(M, 2 * d.mlp_ratio * D)
+            w["dxm"], w["da"] = z(M, D), z(M, D)
+            w["dh"] = z(M, d.mlp_ratio * D)
+            # per-block inputs of the weight-gradient GEMMs (consumed asynchronously on the side stream)
+            w["wg"] = [{"dt2": z(M, D), "du": z(M, 2 * d.mlp_ratio * D), "dt1": z(M, D), "dqkv": z(M, 3 * D)}
+                       for _ in range(L)]
             w["dq"], w["dk"], w["dv"] = (z(B, d.num_heads, N, 64) for _ in range(3))
-            w["dqkv"] = z(M, 3 * D)
             w["dmod"] = z(Bp, self.layout.mod_rows)
             w["dwb"] = z(B, 2, D, dtype=f32)
             w["dse"] = z(Bp, E, dtype=f32)
@@ -337,8 +348,9 @@ class DiTEngine:
             ops.ln_modulate_fwd(a["x1"], self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"),
                                 mod[:, mo + 3 * D : mo + 4 * D], mod[:, mo + 4 * D : mo + 5 * D], N, 1e-5, a["xm2"],
                                 a["mean2"], a["rstd2"])
-            ops.gemm_nt(a["xm2"], sh[pre + "mlp_input.0.weight|f"], a["u"])
-            ops.swiglu_fwd(a["u"], a["h"])
+            if not ops.gemm_nt_swiglu(a["xm2"], sh[pre + "mlp_input.0.weight|g"], a["u"], a["h"]):
+                ops.gemm_nt(a["xm2"], sh[pre + "mlp_input.0.weight|f"], a["u"])  # small / ragged shapes: unfused pair
+                ops.swiglu_fwd(a["u"], a["h"])
             ops.gemm_nt(a["h"], sh[pre + "mlp_input.2.weight|f"], xout, pre_out=a["t2"], resid=a["x1"],
                         gate=mod[:, mo + 5 * D : mo + 6 * D], rows_per_gate=N)
 
@@ -380,40 +392,56 @@ class DiTEngine:
         ops.ln_modulate_bwd(w["dxm"], xs[L], None, None, mod[:, mo : mo + D], N, w["meanf"], w["rstdf"], None, dx,
                             dmod[:, mo : mo + D], dmod[:, mo + D : mo + 2 * D], None)
 
+        # The four weight-gradient GEMMs of a block are off the dependency chain (nothing downstream reads them), so they
+        # run on a SIDE HIP stream: they overlap the HBM-bound kernels of the main chain (gate/SwiGLU/adaLN/QK-norm
+        # backward), which leave the matrix pipes idle.  Their inputs (dt2, du, dt1, dqkv) live in per-block buffers so the
+        # main chain never overwrites something the side stream still reads.
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        side.wait_stream(main)
+
+        def wgrad(x_grad: Tensor, x_in: Tensor, gname: str) -> None:
+            ev = main.record_event()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                ops.gemm_tn(x_grad, x_in, self.G(gname))
+
         for i in reversed(range(L)):
             a = w["layers"][i]
+            g = w["wg"][i]
             pre = f"layers.{i}."
             mo = i * 6 * D
             # MLP branch
-            ops.gate_bwd(dx, a["t2"], mod[:, mo + 5 * D : mo + 6 * D], N, w["dt"], dmod[:, mo + 5 * D : mo + 6 * D])
-            ops.gemm_nt(w["dt"], sh[pre + "mlp_input.2.weight|t"], w["dh"])
-            ops.gemm_tn(w["dt"], a["h"], self.G(pre + "mlp_input.2.weight"))
-            ops.swiglu_bwd(w["dh"], a["u"], w["du"])
-            ops.gemm_nt(w["du"], sh[pre + "mlp_input.0.weight|t"], w["dxm"])
-            ops.gemm_tn(w["du"], a["xm2"], self.G(pre + "mlp_input.0.weight"))
+            ops.gate_bwd(dx, a["t2"], mod[:, mo + 5 * D : mo + 6 * D], N, g["dt2"], dmod[:, mo + 5 * D : mo + 6 * D])
+            wgrad(g["dt2"], a["h"], pre + "mlp_input.2.weight")
+            ops.gemm_nt(g["dt2"], sh[pre + "mlp_input.2.weight|t"], w["dh"])
+            ops.swiglu_bwd(w["dh"], a["u"], g["du"])  # (dl_gemm_nt_dswiglu fuses these two, but measured slower: DESIGN.md)
+            wgrad(g["du"], a["xm2"], pre + "mlp_input.0.weight")
+            ops.gemm_nt(g["du"], sh[pre + "mlp_input.0.weight|t"], w["dxm"])
             ops.ln_modulate_bwd(w["dxm"], a["x1"], self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"),
                                 mod[:, mo + 3 * D : mo + 4 * D], N, a["mean2"], a["rstd2"], dx, dx_alt,
                                 dmod[:, mo + 3 * D : mo + 4 * D], dmod[:, mo + 4 * D : mo + 5 * D], w["dwb"])
             ops.reduce_rows_f32(w["dwb"], self.G(pre + "norm_2.weight"), B, 2 * D)
             dx, dx_alt = dx_alt, dx
             # attention branch
-            ops.gate_bwd(dx, a["t1"], mod[:, mo + 2 * D : mo + 3 * D], N, w["dt"], dmod[:, mo + 2 * D : mo + 3 * D])
-            ops.gemm_nt(w["dt"], sh[pre + "attention.proj_out.weight|t"], w["da"])
-            ops.gemm_tn(w["dt"], a["a"], self.G(pre + "attention.proj_out.weight"))
+            ops.gate_bwd(dx, a["t1"], mod[:, mo + 2 * D : mo + 3 * D], N, g["dt1"], dmod[:, mo + 2 * D : mo + 3 * D])
+            wgrad(g["dt1"], a["a"], pre + "attention.proj_out.weight")
+            ops.gemm_nt(g["dt1"], sh[pre + "attention.proj_out.weight|t"], w["da"])
             ops.attn_bwd(a["q"], a["k"], a["v"], a["a"], w["da"], a["lse"], w["dq"], w["dk"], w["dv"], B, Hh, N, 64,
                          64**-0.5)
             ops.qk_norm_rope_bwd(w["dq"], w["dk"], w["dv"], a["qkv"], self.P(pre + "attention.qk_norm.query_norm.scale"),
-                                 self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], w["dqkv"],
+                                 self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], g["dqkv"],
                                  self.G(pre + "attention.qk_norm.query_norm.scale"), B, N, Hh, 64, rot)
-            ops.gemm_nt(w["dqkv"], sh[pre + "attention.qkv.weight|t"], w["dxm"])
-            ops.gemm_tn(w["dqkv"], a["xm1"], self.G(pre + "attention.qkv.weight"))
+            wgrad(g["dqkv"], a["xm1"], pre + "attention.qkv.weight")
+            ops.gemm_nt(g["dqkv"], sh[pre + "attention.qkv.weight|t"], w["dxm"])
             ops.ln_modulate_bwd(w["dxm"], xs[i], self.P(pre + "norm_1.weight"), self.P(pre + "norm_1.bias"),
                                 mod[:, mo : mo + D], N, a["mean1"], a["rstd1"], dx, dx_alt, dmod[:, mo : mo + D],
                                 dmod[:, mo + D : mo + 2 * D], w["dwb"])
             ops.reduce_rows_f32(w["dwb"], self.G(pre + "norm_1.weight"), B, 2 * D)
             dx, dx_alt = dx_alt, dx
-            if self.reducer is not None:  # this block's gradient range is final: overlap its all-reduce
-                self.reducer.ready(*self.layer_ranges[i])
+            if self.reducer is not None:  # this block's gradient range is final once BOTH streams are past this point
+                self.reducer.ready(*self.layer_ranges[i], extra_events=(side.record_event(),))
+        main.wait_stream(side)
 
         # stem: conv_proj weight gradient (no gradient flows to the input latents)
         Fi = d.input_channels * d.patch_size**2

@@ -133,6 +133,28 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias: Tensor | None = None, ac
     return out
 
 
+def gemm_nt_swiglu(x: Tensor, w_perm: Tensor, u: Tensor, h: Tensor) -> bool:
+    """fused MLP-up GEMM + SwiGLU; False when the shape has no fused kernel (caller falls back to gemm_nt + swiglu_fwd)"""
+    rc = lib().cdll.dl_gemm_nt_swiglu(_p(x), x.stride(0), _p(w_perm), w_perm.stride(0), _p(u), u.stride(0), _p(h),
+                                      h.stride(0), x.shape[0], h.shape[1], x.shape[1], _s())
+    if rc == -3:
+        return False
+    if rc != 0:
+        raise RuntimeError(f"dl_gemm_nt_swiglu failed ({rc}): {lib().cdll.dl_last_error().decode()}")
+    return True
+
+
+def gemm_nt_dswiglu(dt: Tensor, w2t: Tensor, u: Tensor, du: Tensor) -> bool:
+    """fused MLP-down dgrad + SwiGLU backward; False when unsupported for the shape"""
+    rc = lib().cdll.dl_gemm_nt_dswiglu(_p(dt), dt.stride(0), _p(w2t), w2t.stride(0), _p(u), u.stride(0), _p(du),
+                                       du.stride(0), dt.shape[0], u.shape[1] // 2, dt.shape[1], _s())
+    if rc == -3:
+        return False
+    if rc != 0:
+        raise RuntimeError(f"dl_gemm_nt_dswiglu failed ({rc}): {lib().cdll.dl_last_error().decode()}")
+    return True
+
+
 def gemm_tn(a: Tensor, b: Tensor, out: Tensor, *, M: int | None = None, N: int | None = None) -> Tensor:
     """out[M,N] (f32) += a[R,M]^T @ b[R,N]."""
     M = a.shape[1] if M is None else M
@@ -237,6 +259,10 @@ def cast_weight(src, dst, dst_t):
     R, C = src.shape
     _call("dl_cast_weight", _p(src), R, C, _p(dst), dst.stride(0) if dst is not None else 0, _p(dst_t),
           dst_t.stride(0) if dst_t is not None else 0, _s())
+
+
+def cast_weight_swiglu(src, dst):
+    _call("dl_cast_weight_swiglu", _p(src), src.shape[0] // 2, src.shape[1], _p(dst), dst.stride(0), _s())
 
 
 def cast_f32_to_bf16(src, dst):

@@ -27,13 +27,16 @@ class GradReducer:
         self.sync = True  # False inside a gradient-accumulation micro-step (no_sync)
         self.comm_stream = torch.cuda.Stream() if (self.enabled and flat_grad.is_cuda) else None
         self._pending: list[tuple[int, int]] = []
+        self._extra: list = []
         self._works = []
 
     # -- called by the engine's backward, ranges arrive high-to-low as blocks finish
-    def ready(self, lo: int, hi: int) -> None:
+    def ready(self, lo: int, hi: int, extra_events=()) -> None:
+        """[lo, hi) of the arena is final once the current stream AND `extra_events` (side-stream producers) are reached."""
         if not (self.enabled and self.sync):
             return
         self._pending.append((lo, hi))
+        self._extra.extend(extra_events)
         if sum(h - l for l, h in self._pending) >= self.bucket_elems:
             self._flush()
 
@@ -50,6 +53,9 @@ class GradReducer:
             ev.record()  # everything that produced this range is on the compute stream before this point
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
+                for e in self._extra:
+                    self.comm_stream.wait_event(e)
+                self._extra.clear()
                 self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:  # CPU / gloo (tests)
             self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -105,6 +105,17 @@ DL_API int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, vo
                       int64_t N, int64_t K, const float* bias, int act, int out_dtype, void* pre_out,
                       const void* resid, int64_t ldr, const void* gate, int64_t ldg, int64_t rows_per_gate,
                       dl_stream_t stream);
+/* mlp_input[0] + PackedSwiGLU fused (mmdit.py:260-264, nn.py:484-486): U[M,2F] = X Wp^T written in the reference
+ * layout [x1 | x3] (kept for the backward) and H[M,F] = silu(x1) * x3, in ONE pass over the accumulators.
+ * Wp = row-permuted bf16 shadow of the [2F, K] weight made by dl_cast_weight_swiglu.  Only shapes served by the
+ * big-tile kernels (M % 256 == 0, 2F % 192 == 0, >= 64 tiles) -- otherwise DL_ERR_UNSUPPORTED and the caller runs
+ * dl_gemm_nt + dl_swiglu_fwd. */
+DL_API int dl_gemm_nt_swiglu(const void* X, int64_t ldx, const void* Wp, int64_t ldw, void* U, int64_t ldu, void* H,
+                             int64_t ldh, int64_t M, int64_t F, int64_t K, dl_stream_t stream);
+/* mlp_input[2] dgrad + PackedSwiGLU backward fused: dH = dT W2 is never written; dU = [dH x3 silu'(x1) | dH silu(x1)].
+ * W2t = transposed bf16 shadow [F, K]; U = saved pre-activations [M, 2F].  Same shape rule as above. */
+DL_API int dl_gemm_nt_dswiglu(const void* dT, int64_t ldt, const void* W2t, int64_t ldw, const void* U, int64_t ldu,
+                              void* dU, int64_t lddu, int64_t M, int64_t F, int64_t K, dl_stream_t stream);
 /* nn.Linear wgrad:  C[m,n] += sum_r A[r,m] * B[r,n]   A:[R,M] lda, B:[R,N] ldb, C f32 [M,N] ldc (atomic
  * accumulate across the split of R; caller zeroes C once per optimizer step).  R multiple of 64. */
 DL_API int dl_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
@@ -188,6 +199,9 @@ DL_API int dl_adamw_step(float* p, const float* g, float* m, float* v, int64_t n
  * dstT [C, ld_t] (cols >= R zeroed up to ld_t).  Either destination may be NULL. */
 DL_API int dl_cast_weight(const float* src, int64_t R, int64_t C, void* dst, int64_t ld_dst, void* dstT,
                           int64_t ld_t, dl_stream_t stream);
+/* bf16 shadow of the packed-SwiGLU weight [2F, C] with the row order dl_gemm_nt_swiglu expects: inside every group of
+ * 16 output rows, rows 0..7 are x1 rows 8q..8q+7 and rows 8..15 are x3 rows 8q..8q+7 (q = group index). */
+DL_API int dl_cast_weight_swiglu(const float* src, int64_t F, int64_t C, void* dst, int64_t ld_dst, dl_stream_t stream);
 /* plain casts */
 DL_API int dl_cast_f32_to_bf16(const float* src, void* dst, int64_t n, dl_stream_t stream);
 DL_API int dl_cast_bf16_to_f32(const void* src, float* dst, int64_t n, dl_stream_t stream);

@@ -69,7 +69,7 @@ def test_probe_tr16_lane_map(ops):
 
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(256, 384, 384), (300, 1152, 384), (64, 16, 384), (2, 384, 256), (512, 384, 1536),
-                                   (1024, 3072, 384), (130, 72, 64), (8192, 384, 1536), (16384, 1152, 384), (12288, 384, 384)])
+                                   (1024, 3072, 384), (130, 72, 64), (8192, 384, 1536), (16384, 1152, 384), (12288, 384, 384), (16384, 384, 768)])
 def test_gemm_nt_plain(ops, M, N, K):
     a = synth.normal(f"nt.a{M}", (M, K))
     b = synth.normal(f"nt.b{N}", (N, K), std=K**-0.5)
@@ -82,7 +82,7 @@ def test_gemm_nt_plain(ops, M, N, K):
     assert rel(out32, ref) < 2e-5  # f32 accumulate, order differs only
 
 
-@pytest.mark.parametrize("M", [512, 8192])  # 8192 rows take the persistent big-tile kernel
+@pytest.mark.parametrize("M", [512, 8192, 16384])  # 8192 rows: persistent 256x192 kernel; 16384 rows: 256x384 tiles
 def test_gemm_nt_epilogues(ops, M):
     N, K, rows = 384, 384, 128
     a, b = synth.normal("ep.a", (M, K)), synth.normal("ep.b", (N, K), std=K**-0.5)
@@ -423,3 +423,37 @@ def test_adamw_and_casts(ops):
     e = torch.zeros(n, device=DEV)
     ops.ema_update(e, p, 0.9)
     assert rel(e, 0.1 * p) < 1e-6
+
+
+def test_fused_swiglu_gemms(ops):
+    """MLP-up GEMM + SwiGLU forward and MLP-down dgrad + SwiGLU backward fused into the GEMM epilogues == the unfused pair."""
+    M, D, F = 16384, 384, 1536
+    x = synth.normal("fs.x", (M, D))
+    w1 = synth.normal("fs.w1", (2 * F, D), std=D**-0.5)
+    w2 = synth.normal("fs.w2", (D, F), std=F**-0.5)
+    dt = synth.normal("fs.dt", (M, D))
+    w1p = torch.empty(2 * F, D, device=DEV, dtype=torch.bfloat16)
+    ops.cast_weight_swiglu(w1.to(DEV), w1p)
+    u = torch.empty(M, 2 * F, device=DEV, dtype=torch.bfloat16)
+    h = torch.empty(M, F, device=DEV, dtype=torch.bfloat16)
+    assert ops.gemm_nt_swiglu(dev_bf(x), w1p, u, h)
+    u_ref = torch.empty_like(u)
+    h_ref = torch.empty_like(h)
+    ops.gemm_nt(dev_bf(x), dev_bf(w1), u_ref)
+    ops.swiglu_fwd(u_ref, h_ref)
+    assert torch.equal(u, u_ref)  # same accumulation order, same rounding
+    assert rel(h.float(), h_ref.float()) < 6e-3  # h is computed from the f32 accumulators here, from bf16 u there
+    cpu_u = bf(x) @ bf(w1).t()
+    assert rel(h.float(), odit.silu(cpu_u[:, :F]) * cpu_u[:, F:]) < 4e-3
+    # backward
+    w2t = dev_bf(w2.t().contiguous())  # [F, D]
+    du = torch.empty(M, 2 * F, device=DEV, dtype=torch.bfloat16)
+    assert ops.gemm_nt_dswiglu(dev_bf(dt), w2t, u, du)
+    dh = torch.empty(M, F, device=DEV, dtype=torch.bfloat16)
+    du_ref = torch.empty_like(du)
+    ops.gemm_nt(dev_bf(dt), w2t, dh)
+    ops.swiglu_bwd(dh, u, du_ref)
+    assert rel(du.float(), du_ref.float()) < 6e-3
+    # small shapes have no fused kernel: the wrappers say so instead of computing something else
+    xs = torch.zeros(256, D, device=DEV, dtype=torch.bfloat16)
+    assert not ops.gemm_nt_swiglu(xs, w1p, u[:256], h[:256])
