@@ -119,24 +119,28 @@ extern "C" int dl_ln_modulate_fwd(const void* x, const float* w, const float* b,
 }
 
 // ======================================================================== LayerNorm + modulate, backward
-// One workgroup (8 waves) per modulation group (= one sample's tokens).  LDS: [8 waves][4 sums][D] floats.
+// Two launches: (1) `split` 256-thread workgroups per modulation group (= one sample's tokens) produce dx rows and
+// per-workgroup partial column sums [4][D] (256 threads / ~140 VGPRs / 6 KiB LDS: small enough to co-reside with a
+// GEMM workgroup that owns most of the CU -- the side-stream wgrad overlap); (2) a tiny kernel folds the partials.
 #define LNB_WAVES 8
+#define LNB1_WAVES 4
 template <int NJ>
-__global__ __launch_bounds__(512) void ln_mod_bwd_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256) void ln_mod_bwd_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
                                                     const float* __restrict__ w, const float* __restrict__ b,
                                                     const bf16_t* __restrict__ scale, int64_t ld_mod,
                                                     int64_t rows_per_mod, const float* __restrict__ mean,
                                                     const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
-                                                    bf16_t* __restrict__ dx, bf16_t* __restrict__ dscale,
-                                                    bf16_t* __restrict__ dshift, int64_t ld_dmod,
-                                                    float* __restrict__ dwb, int64_t M, int D) {
+                                                    bf16_t* __restrict__ dx, float* __restrict__ part, int split,
+                                                    int64_t M, int D) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = (float*)smem;  // [4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D8 = D >> 3;
   const float invD = 1.0f / (float)D;
-  const int64_t g = blockIdx.x;
-  for (int i = threadIdx.x; i < 4 * D; i += 512) red[i] = 0.f;
+  const int64_t g = blockIdx.x / split;
+  const int sp = blockIdx.x - (int)g * split;
+  const int64_t rows_per_wg = rows_per_mod / split;
+  for (int i = threadIdx.x; i < 4 * D; i += 256) red[i] = 0.f;
   float wv[NJ][8], bv[NJ][8], sc[NJ][8];
   load_row_f32<NJ>(w, D8, lane, wv, 1.0f);
   load_row_f32<NJ>(b, D8, lane, bv, 0.0f);
@@ -147,12 +151,45 @@ __global__ __launch_bounds__(512) void ln_mod_bwd_k(const bf16_t* __restrict__ d
 #pragma unroll
     for (int e = 0; e < 8; ++e) a_dsc[j][e] = a_dsh[j][e] = a_dw[j][e] = a_db[j][e] = 0.f;
 
-  const int64_t row_end = (g + 1) * rows_per_mod < M ? (g + 1) * rows_per_mod : M;
-  for (int64_t row = g * rows_per_mod + wave; row < row_end; row += LNB_WAVES) {
-    float dv[NJ][8], xv[NJ][8];
-    load_row<NJ>(dout + row * D, D8, lane, dv);
-    load_row<NJ>(x + row * D, D8, lane, xv);
-    const float mu = mean[row], rs = rstd[row];
+  const int64_t row_begin = g * rows_per_mod + sp * rows_per_wg;
+  const int64_t row_end = row_begin + rows_per_wg < M ? row_begin + rows_per_wg : M;
+  // software prefetch: the packed bf16 rows (dout, x, dres) of the NEXT row are requested before the current row is
+  // processed, so every wave keeps two rows of loads in flight (this kernel often runs at one wave per SIMD next to a GEMM)
+  u32x4_t pd[NJ], px[NJ], pr[NJ];
+  float pmu = 0.f, prs = 0.f;
+  auto fetch = [&](int64_t row) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < D8) {
+        pd[j] = *(const u32x4_t*)(dout + row * D + c * 8);
+        px[j] = *(const u32x4_t*)(x + row * D + c * 8);
+        if (dres) pr[j] = *(const u32x4_t*)(dres + row * D + c * 8);
+      }
+    }
+    pmu = mean[row];
+    prs = rstd[row];
+  };
+  int64_t row = row_begin + wave;
+  if (row < row_end) fetch(row);
+  for (; row < row_end; row += LNB1_WAVES) {
+    float dv[NJ][8], xv[NJ][8], rv[NJ][8];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const bool on = (lane + 64 * j) < D8;
+      if (on) {
+        unpack8(pd[j], dv[j]);
+        unpack8(px[j], xv[j]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (!on) dv[j][e] = xv[j][e] = 0.f;
+        rv[j][e] = 0.f;
+      }
+      if (on && dres) unpack8(pr[j], rv[j]);
+    }
+    const float mu = pmu, rs = prs;
+    if (row + LNB1_WAVES < row_end) fetch(row + LNB1_WAVES);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -175,15 +212,6 @@ __global__ __launch_bounds__(512) void ln_mod_bwd_k(const bf16_t* __restrict__ d
       }
     }
     const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
-    float rv[NJ][8];
-    if (dres) {
-      load_row<NJ>(dres + row * D, D8, lane, rv);
-    } else {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) rv[j][e] = 0.f;
-    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -209,8 +237,15 @@ __global__ __launch_bounds__(512) void ln_mod_bwd_k(const bf16_t* __restrict__ d
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 4 * D; i += 512) {
-    const float s = red[i];
+  for (int i = threadIdx.x; i < 4 * D; i += 256) part[(size_t)blockIdx.x * 4 * D + i] = red[i];
+}
+
+__global__ void ln_mod_bwd_fold_k(const float* __restrict__ part, int split, bf16_t* __restrict__ dscale,
+                                  bf16_t* __restrict__ dshift, int64_t ld_dmod, float* __restrict__ dwb, int D) {
+  const int64_t g = blockIdx.x;
+  for (int i = threadIdx.x; i < 4 * D; i += blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < split; ++p) s += part[((size_t)g * split + p) * 4 * D + i];
     const int which = i / D, col = i - which * D;
     if (which == 0) dscale[g * ld_dmod + col] = f2bf(s);
     else if (which == 1) dshift[g * ld_dmod + col] = f2bf(s);
@@ -218,11 +253,17 @@ __global__ __launch_bounds__(512) void ln_mod_bwd_k(const bf16_t* __restrict__ d
   }
 }
 
+extern "C" int64_t dl_ln_modulate_bwd_scratch(int64_t M, int64_t D, int64_t rows_per_mod) {
+  const int64_t split = (rows_per_mod % 64 == 0) ? rows_per_mod / 64 : 1;
+  return (M / rows_per_mod) * split * 4 * D;  // floats
+}
+
 extern "C" int dl_ln_modulate_bwd(const void* dout, const void* x, const float* w, const float* b, const void* scale,
                                   int64_t ld_mod, int64_t rows_per_mod, const float* mean, const float* rstd,
                                   const void* dres, void* dx, void* dscale, void* dshift, int64_t ld_dmod,
-                                  float* dwb_partial, int64_t M, int64_t D, dl_stream_t stream) {
-  DL_CHECK_ARG(dout && x && scale && mean && rstd && dx && dscale && dshift && M > 0, "dl_ln_modulate_bwd: null operand");
+                                  float* dwb_partial, float* scratch, int64_t M, int64_t D, dl_stream_t stream) {
+  DL_CHECK_ARG(dout && x && scale && mean && rstd && dx && dscale && dshift && scratch && M > 0,
+               "dl_ln_modulate_bwd: null operand");
   DL_CHECK_ARG((w == nullptr) == (b == nullptr), "dl_ln_modulate_bwd: w and b must both be given or both NULL");
   DL_CHECK_ARG(D % 8 == 0 && D <= 512 * MAXJ && ld_mod % 8 == 0 && rows_per_mod > 0 && M % rows_per_mod == 0,
                "dl_ln_modulate_bwd: D=%lld M=%lld rows_per_mod=%lld", (long long)D, (long long)M, (long long)rows_per_mod);
@@ -230,17 +271,17 @@ extern "C" int dl_ln_modulate_bwd(const void* dout, const void* x, const float* 
                "dl_ln_modulate_bwd: 16-byte alignment");
   const int nj = cdiv(D, 512);
   const int groups = (int)(M / rows_per_mod);
+  const int split = (rows_per_mod % 64 == 0) ? (int)(rows_per_mod / 64) : 1;
   const size_t lds = (size_t)4 * D * sizeof(float);
-#define LAUNCH(NJ)                                                                                                   \
-  do {                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)ln_mod_bwd_k<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
-    hipLaunchKernelGGL(ln_mod_bwd_k<NJ>, groups, 512, lds, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)x, \
-                       w, b, (const bf16_t*)scale, ld_mod, rows_per_mod, mean, rstd, (const bf16_t*)dres,             \
-                       (bf16_t*)dx, (bf16_t*)dscale, (bf16_t*)dshift, ld_dmod, dwb_partial, M, (int)D);               \
-  } while (0)
+#define LAUNCH(NJ)                                                                                                       \
+  hipLaunchKernelGGL(ln_mod_bwd_k<NJ>, groups * split, 256, lds, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)x, \
+                     w, b, (const bf16_t*)scale, ld_mod, rows_per_mod, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx,       \
+                     scratch, split, M, (int)D)
   if (nj == 1) LAUNCH(1);
   else LAUNCH(2);
 #undef LAUNCH
+  hipLaunchKernelGGL(ln_mod_bwd_fold_k, groups, 256, 0, (hipStream_t)stream, scratch, split, (bf16_t*)dscale, (bf16_t*)dshift,
+                     ld_dmod, dwb_partial, (int)D);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

@@ -285,6 +285,7 @@ class DiTEngine:
             w["dq"], w["dk"], w["dv"] = (z(B, d.num_heads, N, 64) for _ in range(3))
             w["dmod"] = z(Bp, self.layout.mod_rows)
             w["dwb"] = z(B, 2, D, dtype=f32)
+            w["ln_scr"] = z(ops.lib().call("dl_ln_modulate_bwd_scratch", M, D, N), dtype=f32)
             w["dse"] = z(Bp, E, dtype=f32)
             w["demb"] = z(Bp, E, dtype=f32)
             w["demb16"] = z(Bp, E)
@@ -390,7 +391,7 @@ class DiTEngine:
         mo = L * 6 * D
         dx, dx_alt = w["dxa"], w["dxb"]
         ops.ln_modulate_bwd(w["dxm"], xs[L], None, None, mod[:, mo : mo + D], N, w["meanf"], w["rstdf"], None, dx,
-                            dmod[:, mo : mo + D], dmod[:, mo + D : mo + 2 * D], None)
+                            dmod[:, mo : mo + D], dmod[:, mo + D : mo + 2 * D], None, w["ln_scr"])
 
         # The four weight-gradient GEMMs of a block are off the dependency chain (nothing downstream reads them), so they
         # run on a SIDE HIP stream: they overlap the HBM-bound kernels of the main chain (gate/SwiGLU/adaLN/QK-norm
@@ -420,7 +421,7 @@ class DiTEngine:
             ops.gemm_nt(g["du"], sh[pre + "mlp_input.0.weight|t"], w["dxm"])
             ops.ln_modulate_bwd(w["dxm"], a["x1"], self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"),
                                 mod[:, mo + 3 * D : mo + 4 * D], N, a["mean2"], a["rstd2"], dx, dx_alt,
-                                dmod[:, mo + 3 * D : mo + 4 * D], dmod[:, mo + 4 * D : mo + 5 * D], w["dwb"])
+                                dmod[:, mo + 3 * D : mo + 4 * D], dmod[:, mo + 4 * D : mo + 5 * D], w["dwb"], w["ln_scr"])
             ops.reduce_rows_f32(w["dwb"], self.G(pre + "norm_2.weight"), B, 2 * D)
             dx, dx_alt = dx_alt, dx
             # attention branch
@@ -436,7 +437,7 @@ class DiTEngine:
             ops.gemm_nt(g["dqkv"], sh[pre + "attention.qkv.weight|t"], w["dxm"])
             ops.ln_modulate_bwd(w["dxm"], xs[i], self.P(pre + "norm_1.weight"), self.P(pre + "norm_1.bias"),
                                 mod[:, mo : mo + D], N, a["mean1"], a["rstd1"], dx, dx_alt, dmod[:, mo : mo + D],
-                                dmod[:, mo + D : mo + 2 * D], w["dwb"])
+                                dmod[:, mo + D : mo + 2 * D], w["dwb"], w["ln_scr"])
             ops.reduce_rows_f32(w["dwb"], self.G(pre + "norm_1.weight"), B, 2 * D)
             dx, dx_alt = dx_alt, dx
             if self.reducer is not None:  # this block's gradient range is final once BOTH streams are past this point

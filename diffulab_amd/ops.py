@@ -171,10 +171,19 @@ def ln_modulate_fwd(x, w, b, scale, shift, rows_per_mod, eps, out, mean, rstd):
     return out
 
 
-def ln_modulate_bwd(dout, x, w, b, scale, rows_per_mod, mean, rstd, dres, dx, dscale, dshift, dwb_partial):
+_LN_SCRATCH: dict = {}
+
+
+def ln_modulate_bwd(dout, x, w, b, scale, rows_per_mod, mean, rstd, dres, dx, dscale, dshift, dwb_partial, scratch=None):
     M, D = x.shape
+    if scratch is None:  # tests / ad-hoc callers: a cached workspace per (device, size)
+        n = lib().call("dl_ln_modulate_bwd_scratch", M, D, rows_per_mod)
+        key = (x.device, n)
+        if key not in _LN_SCRATCH:
+            _LN_SCRATCH[key] = torch.empty(n, device=x.device, dtype=torch.float32)
+        scratch = _LN_SCRATCH[key]
     _call("dl_ln_modulate_bwd", _p(dout), _p(x), _p(w), _p(b), _p(scale), scale.stride(0), rows_per_mod, _p(mean),
-          _p(rstd), _p(dres), _p(dx), _p(dscale), _p(dshift), dscale.stride(0), _p(dwb_partial), M, D, _s())
+          _p(rstd), _p(dres), _p(dx), _p(dscale), _p(dshift), dscale.stride(0), _p(dwb_partial), _p(scratch), M, D, _s())
     return dx
 
 

@@ -132,11 +132,12 @@ DL_API int dl_ln_modulate_fwd(const void* x, const float* w, const float* b, con
  *   dx[m,:]    = dres[m,:] + dLN(...)           (dres may be NULL)
  *   dscale[g,:] = sum_{m in g} dout * (xhat*w+b) ; dshift[g,:] = sum dout          (bf16 rows, stride ld_dmod)
  *   dwb_partial f32 [groups, 2, D]: per-group partial sums of dw, db (NULL when w == NULL);
- * one workgroup per group of rows_per_mod rows. */
+ * scratch: caller workspace of dl_ln_modulate_bwd_scratch(M, D, rows_per_mod) floats (per-workgroup partial sums). */
+DL_API int64_t dl_ln_modulate_bwd_scratch(int64_t M, int64_t D, int64_t rows_per_mod); /* floats of `scratch` */
 DL_API int dl_ln_modulate_bwd(const void* dout, const void* x, const float* w, const float* b, const void* scale,
                               int64_t ld_mod, int64_t rows_per_mod, const float* mean, const float* rstd,
                               const void* dres, void* dx, void* dscale, void* dshift, int64_t ld_dmod,
-                              float* dwb_partial, int64_t M, int64_t D, dl_stream_t stream);
+                              float* dwb_partial, float* scratch, int64_t M, int64_t D, dl_stream_t stream);
 /* x_new = x + gate * t backward (mmdit.py:296-307): dt = gate * dout ; dgate[g,:] = sum_{m in g} dout * t */
 DL_API int dl_gate_bwd(const void* dout, const void* t, const void* gate, int64_t ld_mod, int64_t rows_per_mod,
                        void* dt, void* dgate, int64_t ld_dmod, int64_t M, int64_t D, dl_stream_t stream);
