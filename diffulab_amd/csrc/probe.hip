@@ -85,8 +85,39 @@ __global__ __launch_bounds__(512, 2) void mfma_probe_k(const bf16_t* __restrict_
   out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void copy_probe_k(const bf16_t* __restrict__ src, float* __restrict__ out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bf16_t* gsrc = src + (int64_t)blockIdx.x * 57344 / 2;
+  u32x4_t acc = {0, 0, 0, 0};
+  for (int it = 0; it < iters; ++it) {
+    char* base = smem + (it & 1) * 57344;
+    if (MODE == 5) {
+#pragma unroll
+      for (int c = 0; c < 7; ++c)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc + ((wave * 7 + c) * 1024 + lane * 16) / 2),
+                                         (lds_void_t*)(base + (wave * 7 + c) * 1024), 16, 0, 0);
+      if ((it & 3) == 3) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    } else {
+      u32x4_t stg[7];
+#pragma unroll
+      for (int c = 0; c < 7; ++c) stg[c] = __builtin_nontemporal_load((const u32x4_t*)(gsrc + ((wave * 7 + c) * 1024 + lane * 16) / 2));
+#pragma unroll
+      for (int c = 0; c < 7; ++c) {
+        if (MODE == 6) *(u32x4_t*)(base + (wave * 7 + c) * 1024 + lane * 16) = stg[c];
+        else acc ^= stg[c];
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  out[blockIdx.x * 512 + threadIdx.x] = (float)(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) + ((float*)smem)[threadIdx.x];
+}
+
 extern "C" int dl_probe_mfma(int mode, int iters, const void* src, float* out, dl_stream_t stream) {
-  DL_CHECK_ARG(out && iters > 0 && mode >= 0 && mode <= 4 && (mode < 3 || src), "dl_probe_mfma: bad args");
+  DL_CHECK_ARG(out && iters > 0 && mode >= 0 && mode <= 7 && (mode < 3 || src), "dl_probe_mfma: bad args");
   const int lds = 114688;
 #define GO(MODE)                                                                                               \
   do {                                                                                                         \
@@ -97,7 +128,18 @@ extern "C" int dl_probe_mfma(int mode, int iters, const void* src, float* out, d
   else if (mode == 1) GO(1);
   else if (mode == 2) GO(2);
   else if (mode == 3) GO(3);
-  else GO(4);
+  else if (mode == 4) GO(4);
+  else {
+#define GOC(MODE)                                                                                              \
+  do {                                                                                                         \
+    (void)hipFuncSetAttribute((const void*)copy_probe_k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+    hipLaunchKernelGGL(copy_probe_k<MODE>, 256, 512, lds, (hipStream_t)stream, (const bf16_t*)src, out, iters);   \
+  } while (0)
+    if (mode == 5) GOC(5);
+    else if (mode == 6) GOC(6);
+    else GOC(7);
+#undef GOC
+  }
 #undef GO
   DL_LAUNCH_CHECK();
   return DL_OK;

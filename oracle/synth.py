@@ -51,3 +51,20 @@ def dit_params(shapes: dict[str, tuple[int, ...]], seed: int = 0, mod_std: float
             fan_in = int(np.prod(shp[1:]))
             out[name] = normal(name, shp, seed, fan_in**-0.5)
     return out
+
+
+def generic_params(shapes: dict[str, tuple[int, ...]], seed: int = 0) -> dict[str, Tensor]:
+    """Non-degenerate weights for any module tree (used for the UNet): 1-D ``weight`` -> norm gain around 1, ``bias``
+    -> small, ``embedding.weight`` -> N(0, 0.5), everything else -> N(0, 1/fan_in) (the reference's zero-init convs
+    would hide bugs behind exact zeros)."""
+    out: dict[str, Tensor] = {}
+    for name, shp in shapes.items():
+        if name.endswith(".bias"):
+            out[name] = normal(name, shp, seed, 0.05)
+        elif name.endswith("embedding.weight"):
+            out[name] = normal(name, shp, seed, 0.5)
+        elif len(shp) == 1:
+            out[name] = 1.0 + normal(name, shp, seed, 0.1)
+        else:
+            out[name] = normal(name, shp, seed, int(np.prod(shp[1:])) ** -0.5)
+    return out

@@ -80,10 +80,12 @@ from diffulab.diffuse.modelizations.utils import space_timesteps  # noqa: E402
 from diffulab.diffuse.samplers.flow import Euler, EulerMaruyama  # noqa: E402
 from diffulab.diffuse.samplers.gaussian_diffusion import DDIM, DDPM  # noqa: E402
 from diffulab.networks.denoisers.mmdit import DiTBlock, MMDiT  # noqa: E402
+from diffulab.networks.denoisers.unet import AttentionBlock, ResBlock, UNetModel  # noqa: E402
 from diffulab.networks.utils.nn import get_cos_sin_ndim_grid, timestep_embedding  # noqa: E402
 
 from oracle import synth  # noqa: E402
 from oracle.dit import DiTConfig, param_shapes  # noqa: E402
+from oracle import unet as ounet  # noqa: E402
 
 torch.set_num_threads(8)
 
@@ -360,6 +362,79 @@ def gen_samplers() -> None:
     save("samplers", **o)
 
 
+
+# ------------------------------------------------------------------ (vii) UNet pieces and a small UNet
+UNET_SMALL = ounet.UNetConfig(image_size=(16, 16), in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1,
+                              attention_resolutions=(2,), channel_mult=(1, 2), num_heads=2, use_scale_shift_norm=True,
+                              resblock_updown=True, n_classes=10, classifier_free=True)
+
+
+def build_unet_ref(cfg, seed: int) -> UNetModel:
+    m = UNetModel(image_size=list(cfg.image_size), in_channels=cfg.in_channels, model_channels=cfg.model_channels,
+                  out_channels=cfg.out_channels, num_res_blocks=cfg.num_res_blocks,
+                  attention_resolutions=list(cfg.attention_resolutions), channel_mult=", ".join(map(str, cfg.channel_mult)),
+                  num_heads=cfg.num_heads, use_scale_shift_norm=cfg.use_scale_shift_norm,
+                  resblock_updown=cfg.resblock_updown, n_classes=cfg.n_classes, classifier_free=cfg.classifier_free)
+    P = synth.generic_params(ounet.param_shapes(cfg), seed=seed)
+    sd = m.state_dict()
+    assert set(sd) == set(P), (set(sd) ^ set(P))
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(P[k].shape), k
+    m.load_state_dict(P)
+    return m
+
+
+def gen_unet() -> None:
+    o = {}
+    te = 128
+    # ResBlock variants (scale-shift norm): channel change (1x1 skip), up, down
+    for tag, kw, cin, cout in (("plain", {}, 64, 96), ("up", {"up": True}, 64, 64), ("down", {"down": True}, 64, 64)):
+        blk = ResBlock(cin, te, 0.0, out_channels=cout, use_scale_shift_norm=True, **kw)
+        shapes = {n: tuple(p.shape) for n, p in blk.named_parameters()}
+        blk.load_state_dict(synth.generic_params({f"rb_{tag}." + n: s for n, s in shapes.items()}, seed=21)
+                            and {n: synth.generic_params({f"rb_{tag}." + n: shapes[n]}, seed=21)[f"rb_{tag}." + n] for n in shapes})
+        x = synth.normal(f"rb_{tag}.x", (4, cin, 8, 8)).requires_grad_(True)
+        emb = synth.normal(f"rb_{tag}.emb", (4, te)).requires_grad_(True)
+        y = blk(x, emb)
+        (y * synth.normal(f"rb_{tag}.dy", tuple(y.shape))).sum().backward()
+        o[f"rb_{tag}_y"], o[f"rb_{tag}_dx"], o[f"rb_{tag}_demb"] = y, x.grad, emb.grad
+        for n, p in blk.named_parameters():
+            o[f"rb_{tag}_g_{n}"] = p.grad
+    # AttentionBlock at 8x8 (c=128, 2 heads; the MNIST config's 512/1024-wide blocks are covered oracle-vs-HIP on the GPU)
+    ab = AttentionBlock(128, num_heads=2)
+    shapes = {n: tuple(p.shape) for n, p in ab.named_parameters()}
+    ab.load_state_dict({n: synth.generic_params({"ab." + n: shapes[n]}, seed=22)["ab." + n] for n in shapes})
+    x = synth.normal("ab.x", (4, 128, 8, 8)).requires_grad_(True)
+    y = ab(x)
+    (y * synth.normal("ab.dy", tuple(y.shape))).sum().backward()
+    o["ab_y"], o["ab_dx"] = y, x.grad
+    for n, p in ab.named_parameters():
+        if p.grad is not None:
+            o["ab_g_" + n] = p.grad
+    # small UNet, DDPM loss, fwd + bwd
+    cfg = UNET_SMALL
+    m = build_unet_ref(cfg, seed=23)
+    B = 4
+    x0 = synth.normal("un.x0", (B, 1, 16, 16))
+    noise = synth.normal("un.noise", (B, 1, 16, 16))
+    yl = synth.integers("un.y", (B,), 10)
+    ti = torch.tensor([3, 500, 999, 0], dtype=torch.int32)
+    gd = Diffuser(m, sampling_method="ddpm", model_type="gaussian_diffusion", n_steps=1000)
+    xt = gd.diffusion.add_noise(x0, ti, noise)[0]
+    o["un_pred"] = m(x=xt, timesteps=ti, y=yl, p=0.0)["x"]
+    loss = gd.compute_loss({"x": x0.clone(), "y": yl, "p": 0.0}, timesteps=ti, noise=noise)["loss"]
+    loss.backward()
+    o["un_loss"] = loss
+    names, norms = [], []
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            names.append(n)
+            norms.append(p.grad.double().norm().item())
+            if p.grad.numel() <= 20000:
+                o["un_g_" + n] = p.grad
+    o["un_grad_names"], o["un_grad_norms"] = np.array(names), np.array(norms)
+    save("unet", **o)
+
 # ------------------------------------------------------------------ (viii) loss curve, DiT-S/2 + AdamW
 def gen_loss_curve() -> None:
     cfg = S2
@@ -383,9 +458,9 @@ def gen_loss_curve() -> None:
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "curve"]
+    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve"]
     fns = {"schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
-           "s2": gen_s2_model, "samplers": gen_samplers, "curve": gen_loss_curve}
+           "s2": gen_s2_model, "samplers": gen_samplers, "curve": gen_loss_curve, "unet": gen_unet}
     for w in which:
         print("==", w)
         fns[w]()

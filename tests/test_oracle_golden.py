@@ -293,3 +293,64 @@ def test_loss_curve_first_steps(golden):
         loss.backward()
         opt.step()
         assert abs(loss.item() - g["losses"][s]) / g["losses"][s] < 2e-5, s
+
+
+# ------------------------------------------------------------------ UNet (config 1 family)
+def test_unet_blocks_and_small_model(golden):
+    from oracle import unet as ounet
+
+    g = golden("unet")
+    te = 128
+    cfg_ss = ounet.UNetConfig(use_scale_shift_norm=True)
+    for tag, kw, cin, cout in (("plain", {}, 64, 96), ("up", {"up": True}, 64, 64), ("down", {"down": True}, 64, 64)):
+        b = ounet.Block("res", "", cin, cout, **kw)
+        shapes = {"in_layers.0.weight": (cin,), "in_layers.0.bias": (cin,), "in_layers.2.weight": (cout, cin, 3, 3),
+                  "in_layers.2.bias": (cout,), "emb_layers.1.weight": (2 * cout, te), "emb_layers.1.bias": (2 * cout,),
+                  "out_layers.0.weight": (cout,), "out_layers.0.bias": (cout,), "out_layers.3.weight": (cout, cout, 3, 3),
+                  "out_layers.3.bias": (cout,)}
+        if cin != cout:
+            shapes["skip_connection.weight"], shapes["skip_connection.bias"] = (cout, cin, 1, 1), (cout,)
+        P = {n: synth.generic_params({f"rb_{tag}." + n: s}, seed=21)[f"rb_{tag}." + n].requires_grad_(True) for n, s in shapes.items()}
+        x = synth.normal(f"rb_{tag}.x", (4, cin, 8, 8)).requires_grad_(True)
+        emb = synth.normal(f"rb_{tag}.emb", (4, te)).requires_grad_(True)
+        y = ounet.res_block(P, b, x, emb, cfg_ss)
+        (y * synth.normal(f"rb_{tag}.dy", tuple(y.shape))).sum().backward()
+        assert rel(y, g[f"rb_{tag}_y"]) < 2e-6, tag
+        assert rel(x.grad, g[f"rb_{tag}_dx"]) < 5e-6 and rel(emb.grad, g[f"rb_{tag}_demb"]) < 5e-6, tag
+        for n in shapes:
+            assert rel(P[n].grad, g[f"rb_{tag}_g_{n}"]) < 1e-5, (tag, n)
+    # attention block
+    c = 128
+    shapes = {"norm_x.weight": (c,), "norm_x.bias": (c,), "norm_context.weight": (c,), "norm_context.bias": (c,),
+              "to_q.weight": (c, c, 1), "to_q.bias": (c,), "to_kv.weight": (2 * c, c, 1), "to_kv.bias": (2 * c,),
+              "to_out.0.weight": (c, c, 1), "to_out.0.bias": (c,)}
+    P = {n: synth.generic_params({"ab." + n: s}, seed=22)["ab." + n].requires_grad_(True) for n, s in shapes.items()}
+    x = synth.normal("ab.x", (4, c, 8, 8)).requires_grad_(True)
+    y = ounet.attention_block(P, ounet.Block("attn", "", c, c), x, ounet.UNetConfig(num_heads=2))
+    (y * synth.normal("ab.dy", tuple(y.shape))).sum().backward()
+    assert rel(y, g["ab_y"]) < 2e-6 and rel(x.grad, g["ab_dx"]) < 5e-6
+    for n in shapes:
+        assert rel(P[n].grad, g["ab_g_" + n]) < 1e-5, n
+    # small UNet under the DDPM head
+    cfg = ounet.UNetConfig(image_size=(16, 16), in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1,
+                           attention_resolutions=(2,), channel_mult=(1, 2), num_heads=2, use_scale_shift_norm=True,
+                           resblock_updown=True, n_classes=10, classifier_free=True)
+    P = {k: v.requires_grad_(True) for k, v in synth.generic_params(ounet.param_shapes(cfg), seed=23).items()}
+    B = 4
+    x0 = synth.normal("un.x0", (B, 1, 16, 16))
+    noise = synth.normal("un.noise", (B, 1, 16, 16))
+    yl = synth.integers("un.y", (B,), 10)
+    ti = torch.tensor([3, 500, 999, 0], dtype=torch.int32)
+    T = od.GaussianTables(1000)
+    pred = ounet.unet_forward(P, od.ddpm_add_noise(T, x0, ti, noise), ti, yl, cfg)
+    assert rel(pred, g["un_pred"]) < 5e-6
+    loss = od.mse_loss(pred, noise)
+    loss.backward()
+    assert abs(loss.item() - float(g["un_loss"])) / float(g["un_loss"]) < 1e-6
+    norms = dict(zip(g["un_grad_names"].tolist(), g["un_grad_norms"].tolist()))
+    floor = 1e-6 * max(norms.values())  # conv biases in front of a GroupNorm have an exactly-zero gradient: pure noise
+    for n, ref in norms.items():
+        assert abs(P[n].grad.double().norm().item() - ref) <= 2e-5 * max(ref, floor), n
+    for k in g:
+        if k.startswith("un_g_") and norms[k[5:]] > floor:
+            assert rel(P[k[5:]].grad, g[k]) < 2e-5, k
