@@ -350,7 +350,8 @@ def test_unet_blocks_and_small_model(golden):
     norms = dict(zip(g["un_grad_names"].tolist(), g["un_grad_norms"].tolist()))
     floor = 1e-6 * max(norms.values())  # conv biases in front of a GroupNorm have an exactly-zero gradient: pure noise
     for n, ref in norms.items():
-        assert abs(P[n].grad.double().norm().item() - ref) <= 2e-5 * max(ref, floor), n
+        got = P[n].grad.double().norm().item()
+        assert (ref <= floor and got <= 10 * floor) or abs(got - ref) <= 2e-5 * ref, n
     for k in g:
         if k.startswith("un_g_") and norms[k[5:]] > floor:
             assert rel(P[k[5:]].grad, g[k]) < 2e-5, k
