@@ -1,0 +1,518 @@
+// UNet (guided-diffusion style) kernels that are not GEMMs: layout changes, GroupNorm32 (+FiLM +SiLU) fwd/bwd,
+// im2col for the 3x3 convolutions (the contraction itself runs on the MFMA GEMMs of gemm.hip), 2x2 pool / nearest
+// upsample, and the small-sequence attention of AttentionBlock (<= 64 tokens, head_dim up to 512).
+// Activations are NHWC bf16 inside the library ([B*H*W, C] token rows: a 3x3 conv is then im2col + NT GEMM with
+// K = 9*C contiguous per tap); the reference's NCHW f32 tensors are converted at the model boundary.
+// Reference: networks/utils/nn.py:11-88, networks/denoisers/unet.py:215-237,296-322.
+#include "common.h"
+
+static inline int grid_for(int64_t n, int threads = 256, int cap = 4096) {
+  int64_t g = (n + threads - 1) / threads;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------- layout: NCHW f32 <-> NHWC bf16
+__global__ void nchw_to_nhwc_k(const float* __restrict__ x, bf16_t* __restrict__ o, int B, int C, int HW, int ld) {
+  const int64_t n = (int64_t)B * C * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t r = i / C;  // b*HW + p
+    const int p = (int)(r % HW), b = (int)(r / HW);
+    o[r * ld + c] = f2bf(x[((int64_t)b * C + c) * HW + p]);
+  }
+}
+__global__ void nhwc_to_nchw_k(const bf16_t* __restrict__ x, float* __restrict__ o, int B, int C, int HW, int ld) {
+  const int64_t n = (int64_t)B * C * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    const int64_t r = i / HW;
+    const int c = (int)(r % C), b = (int)(r / C);
+    o[i] = bf2f(x[((int64_t)b * HW + p) * ld + c]);
+  }
+}
+extern "C" int dl_nchw_to_nhwc(const float* x, void* out, int64_t B, int64_t C, int64_t HW, int64_t ld, dl_stream_t stream) {
+  DL_CHECK_ARG(x && out && B > 0 && C > 0 && HW > 0 && ld >= C, "dl_nchw_to_nhwc: bad args");
+  hipLaunchKernelGGL(nchw_to_nhwc_k, grid_for(B * C * HW), 256, 0, (hipStream_t)stream, x, (bf16_t*)out, (int)B, (int)C, (int)HW,
+                     (int)ld);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_nhwc_to_nchw(const void* x, float* out, int64_t B, int64_t C, int64_t HW, int64_t ld, dl_stream_t stream) {
+  DL_CHECK_ARG(x && out && B > 0 && C > 0 && HW > 0 && ld >= C, "dl_nhwc_to_nchw: bad args");
+  hipLaunchKernelGGL(nhwc_to_nchw_k, grid_for(B * C * HW), 256, 0, (hipStream_t)stream, (const bf16_t*)x, out, (int)B, (int)C,
+                     (int)HW, (int)ld);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ---------------------------------------------------------------- GroupNorm32 statistics: one workgroup per (b, group)
+__global__ __launch_bounds__(256) void gn_stats_k(const bf16_t* __restrict__ x, float* __restrict__ st, int HW, int C, int G,
+                                                  float eps) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.x / G, g = blockIdx.x % G, cg = C / G;
+  const int64_t base = (int64_t)b * HW * C + g * cg;
+  const int n = HW * cg;
+  float s = 0.f, q = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = bf2f(x[base + (int64_t)(i / cg) * C + (i % cg)]);
+    s += v;
+    q += v * v;
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s;
+    red[1][threadIdx.x >> 6] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float S = red[0][0] + red[0][1] + red[0][2] + red[0][3], Q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const float mu = S / n;
+    const float var = fmaxf(Q / n - mu * mu, 0.f);
+    st[(int64_t)blockIdx.x * 2] = mu;
+    st[(int64_t)blockIdx.x * 2 + 1] = rsqrtf(var + eps);
+  }
+}
+extern "C" int dl_gn_stats(const void* x, float* stats, int64_t B, int64_t HW, int64_t C, int64_t G, float eps,
+                           dl_stream_t stream) {
+  DL_CHECK_ARG(x && stats && B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "dl_gn_stats: bad args");
+  hipLaunchKernelGGL(gn_stats_k, (int)(B * G), 256, 0, (hipStream_t)stream, (const bf16_t*)x, stats, (int)HW, (int)C, (int)G, eps);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// out = act( (xhat*w+b) * (1+scale) + shift ), elementwise over [B*HW, C]
+__global__ void gn_apply_fwd_k(const bf16_t* __restrict__ x, const float* __restrict__ st, const float* __restrict__ w,
+                               const float* __restrict__ bb, const bf16_t* __restrict__ fs, const bf16_t* __restrict__ fh,
+                               int64_t ldf, int silu, bf16_t* __restrict__ out, int64_t n, int HW, int C, int G) {
+  const int cg = C / G;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int b = (int)(i / ((int64_t)HW * C));
+    const float mu = st[((int64_t)b * G + c / cg) * 2], r = st[((int64_t)b * G + c / cg) * 2 + 1];
+    float y = (bf2f(x[i]) - mu) * r * w[c] + bb[c];
+    if (fs) y = y * (1.0f + bf2f(fs[(int64_t)b * ldf + c])) + bf2f(fh[(int64_t)b * ldf + c]);
+    out[i] = f2bf(silu ? silu_f(y) : y);
+  }
+}
+extern "C" int dl_gn_apply_fwd(const void* x, const float* stats, const float* w, const float* b, const void* film_scale,
+                               const void* film_shift, int64_t ld_film, int act_silu, void* out, int64_t B, int64_t HW,
+                               int64_t C, int64_t G, dl_stream_t stream) {
+  DL_CHECK_ARG(x && stats && w && b && out && B > 0 && C % G == 0, "dl_gn_apply_fwd: bad args");
+  DL_CHECK_ARG((film_scale == nullptr) == (film_shift == nullptr), "dl_gn_apply_fwd: scale and shift go together");
+  const int64_t n = B * HW * C;
+  hipLaunchKernelGGL(gn_apply_fwd_k, grid_for(n), 256, 0, (hipStream_t)stream, (const bf16_t*)x, stats, w, b,
+                     (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, (bf16_t*)out, n, (int)HW, (int)C,
+                     (int)G);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// backward pass 1: per (b, c) sums over pixels:  S[b][0][c] = sum dh*y, [1] = sum dh, [2] = sum dy*xhat, [3] = sum dy
+// (dh = dout * act'(h), dy = dh * (1+scale)).  One workgroup per (b, 64-channel slab): 64 channels x 4 pixel lanes.
+__global__ __launch_bounds__(256) void gn_bwd_reduce_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
+                                                       const float* __restrict__ st, const float* __restrict__ w,
+                                                       const float* __restrict__ bb, const bf16_t* __restrict__ fs,
+                                                       const bf16_t* __restrict__ fh, int64_t ldf, int silu,
+                                                       float* __restrict__ S, int HW, int C, int G) {
+  __shared__ float red[4][4][64];
+  const int slabs = (C + 63) / 64;
+  const int b = blockIdx.x / slabs, c = (blockIdx.x % slabs) * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < C) {
+    const int cg = C / G;
+    const float mu = st[((int64_t)b * G + c / cg) * 2], r = st[((int64_t)b * G + c / cg) * 2 + 1];
+    const float wc = w[c], bc = bb[c];
+    const float sc = fs ? bf2f(fs[(int64_t)b * ldf + c]) : 0.f, sh = fs ? bf2f(fh[(int64_t)b * ldf + c]) : 0.f;
+    for (int p = pl; p < HW; p += 4) {
+      const int64_t i = ((int64_t)b * HW + p) * C + c;
+      const float xh = (bf2f(x[i]) - mu) * r;
+      const float y = xh * wc + bc;
+      const float h = y * (1.0f + sc) + sh;
+      const float dh = bf2f(dout[i]) * (silu ? dsilu_f(h) : 1.0f);
+      const float dy = dh * (1.0f + sc);
+      a0 += dh * y;
+      a1 += dh;
+      a2 += dy * xh;
+      a3 += dy;
+    }
+  }
+  red[pl][0][threadIdx.x & 63] = a0;
+  red[pl][1][threadIdx.x & 63] = a1;
+  red[pl][2][threadIdx.x & 63] = a2;
+  red[pl][3][threadIdx.x & 63] = a3;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    const int l = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) S[((int64_t)b * 4 + k) * C + c] = red[0][k][l] + red[1][k][l] + red[2][k][l] + red[3][k][l];
+  }
+}
+// backward pass 2: dx = r * (dy*w - A/n - xhat*Bv/n), A = sum_{c in g} w[c] S[3][c], Bv = sum_{c in g} w[c] S[2][c]
+__global__ void gn_bwd_apply_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x, const float* __restrict__ st,
+                               const float* __restrict__ w, const float* __restrict__ bb, const bf16_t* __restrict__ fs,
+                               const bf16_t* __restrict__ fh, int64_t ldf, int silu, const float* __restrict__ S,
+                               const float* __restrict__ AB, const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, int64_t n,
+                               int HW, int C, int G) {
+  const int cg = C / G;
+  const float inv_n = 1.0f / (float)(HW * cg);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int b = (int)(i / ((int64_t)HW * C));
+    const int g = c / cg;
+    const float mu = st[((int64_t)b * G + g) * 2], r = st[((int64_t)b * G + g) * 2 + 1];
+    const float xh = (bf2f(x[i]) - mu) * r;
+    const float sc = fs ? bf2f(fs[(int64_t)b * ldf + c]) : 0.f, sh = fs ? bf2f(fh[(int64_t)b * ldf + c]) : 0.f;
+    const float h = (xh * w[c] + bb[c]) * (1.0f + sc) + sh;
+    const float dy = bf2f(dout[i]) * (silu ? dsilu_f(h) : 1.0f) * (1.0f + sc);
+    const float A = AB[((int64_t)b * G + g) * 2], Bv = AB[((int64_t)b * G + g) * 2 + 1];
+    dx[i] = f2bf(r * (dy * w[c] - A * inv_n - xh * Bv * inv_n) + (dres ? bf2f(dres[i]) : 0.f));
+  }
+}
+__global__ void gn_group_sums_k(const float* __restrict__ S, const float* __restrict__ w, float* __restrict__ AB, int C, int G) {
+  // one thread per (b, g)
+  const int cg = C / G;
+  const int b = blockIdx.x, g = threadIdx.x;
+  if (g >= G) return;
+  float A = 0.f, Bv = 0.f;
+  for (int c = g * cg; c < (g + 1) * cg; ++c) {
+    A += w[c] * S[((int64_t)b * 4 + 3) * C + c];
+    Bv += w[c] * S[((int64_t)b * 4 + 2) * C + c];
+  }
+  AB[((int64_t)b * G + g) * 2] = A;
+  AB[((int64_t)b * G + g) * 2 + 1] = Bv;
+}
+__global__ void gn_param_grads_k(const float* __restrict__ S, float* __restrict__ dw, float* __restrict__ db,
+                                 bf16_t* __restrict__ dfs, bf16_t* __restrict__ dfh, int64_t ldf, int B, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float gw = 0.f, gb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    gw += S[((int64_t)b * 4 + 2) * C + c];
+    gb += S[((int64_t)b * 4 + 3) * C + c];
+    if (dfs) {
+      dfs[(int64_t)b * ldf + c] = f2bf(S[((int64_t)b * 4 + 0) * C + c]);
+      dfh[(int64_t)b * ldf + c] = f2bf(S[((int64_t)b * 4 + 1) * C + c]);
+    }
+  }
+  dw[c] += gw;
+  db[c] += gb;
+}
+/* scratch: f32 [B*4*C + B*G*2] */
+extern "C" int dl_gn_bwd(const void* dout, const void* x, const float* stats, const float* w, const float* b,
+                         const void* film_scale, const void* film_shift, int64_t ld_film, int act_silu, const void* dres,
+                         void* dx, float* dw, float* db, void* dfilm_scale, void* dfilm_shift, int64_t ld_dfilm, float* scratch, int64_t B,
+                         int64_t HW, int64_t C, int64_t G, dl_stream_t stream) {
+  DL_CHECK_ARG(dout && x && stats && w && b && dx && dw && db && scratch && B > 0 && C % G == 0 && G <= 256, "dl_gn_bwd: bad args");
+  DL_CHECK_ARG((film_scale == nullptr) == (dfilm_scale == nullptr), "dl_gn_bwd: film grads iff film inputs");
+  float* S = scratch;
+  float* AB = scratch + B * 4 * C;
+  const int slabs = (int)((C + 63) / 64);
+  hipLaunchKernelGGL(gn_bwd_reduce_k, (int)B * slabs, 256, 0, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)x, stats, w,
+                     b, (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, S, (int)HW, (int)C, (int)G);
+  hipLaunchKernelGGL(gn_group_sums_k, (int)B, 256, 0, (hipStream_t)stream, S, w, AB, (int)C, (int)G);
+  const int64_t n = B * HW * C;
+  hipLaunchKernelGGL(gn_bwd_apply_k, grid_for(n), 256, 0, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)x, stats, w, b,
+                     (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, S, AB, (const bf16_t*)dres,
+                     (bf16_t*)dx, n, (int)HW, (int)C, (int)G);
+  hipLaunchKernelGGL(gn_param_grads_k, (int)((C + 255) / 256), 256, 0, (hipStream_t)stream, S, dw, db, (bf16_t*)dfilm_scale,
+                     (bf16_t*)dfilm_shift, ld_dfilm, (int)B, (int)C);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ---------------------------------------------------------------- im2col for 3x3 / pad 1: cols[row, (ky*3+kx)*C + c]
+// one thread per (row, tap, 8-channel chunk); rows >= B*H*W and columns >= 9*C are zero-filled (GEMM padding)
+__global__ void im2col3x3_k(const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ cols, int B, int H, int W, int C,
+                            int64_t rows, int64_t ld) {
+  const int ld8 = (int)(ld >> 3), C8 = C >> 3;
+  const int64_t total = rows * ld8;
+  const int64_t M = (int64_t)B * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k8 = (int)(i % ld8);
+    const int64_t row = i / ld8;
+    u32x4_t v = {0, 0, 0, 0};
+    if (row < M && k8 < 9 * C8) {
+      const int tap = k8 / C8, c8 = k8 - tap * C8;
+      const int ky = tap / 3 - 1, kx = tap % 3 - 1;
+      const int xw = (int)(row % W), yh = (int)((row / W) % H);
+      const int yy = yh + ky, xx = xw + kx;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = *(const u32x4_t*)(x + (row + (int64_t)ky * W + kx) * ldx + c8 * 8);
+    }
+    *(u32x4_t*)(cols + row * ld + (int64_t)k8 * 8) = v;
+  }
+}
+// generic (C not a multiple of 8, e.g. the 1-channel stem): scalar version
+__global__ void im2col3x3_scalar_k(const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ cols, int B, int H, int W,
+                                   int C, int64_t rows, int64_t ld) {
+  const int64_t total = rows * ld;
+  const int64_t M = (int64_t)B * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % ld);
+    const int64_t row = i / ld;
+    bf16_t v = 0;
+    if (row < M && k < 9 * C) {
+      const int tap = k / C, c = k - tap * C;
+      const int ky = tap / 3 - 1, kx = tap % 3 - 1;
+      const int xw = (int)(row % W), yh = (int)((row / W) % H);
+      if (yh + ky >= 0 && yh + ky < H && xw + kx >= 0 && xw + kx < W) v = x[(row + (int64_t)ky * W + kx) * ldx + c];
+    }
+    cols[i] = v;
+  }
+}
+extern "C" int dl_im2col3x3(const void* x, int64_t ldx, void* cols, int64_t B, int64_t H, int64_t W, int64_t C, int64_t rows,
+                            int64_t ld, dl_stream_t stream) {
+  DL_CHECK_ARG(x && cols && B > 0 && H > 0 && W > 0 && C > 0 && ldx >= C && rows >= B * H * W && ld >= 9 * C && ld % 8 == 0,
+               "dl_im2col3x3: bad args");
+  if (C % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0)
+    hipLaunchKernelGGL(im2col3x3_k, grid_for(rows * ld / 8), 256, 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)cols,
+                       (int)B, (int)H, (int)W, (int)C, rows, ld);
+  else
+    hipLaunchKernelGGL(im2col3x3_scalar_k, grid_for(rows * ld), 256, 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)cols,
+                       (int)B, (int)H, (int)W, (int)C, rows, ld);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// conv weight [Co, Ci, 3, 3] f32 -> forward shadow [Co, ldf] (k = tap*Ci + ci) and dgrad shadow [Ci, ldd]
+// (k = tap'*Co + co with the kernel rotated by 180 degrees: tap' = 8 - tap); padding columns zeroed
+__global__ void cast_conv3x3_k(const float* __restrict__ w, int Co, int Ci, bf16_t* __restrict__ wf, int64_t ldf,
+                               bf16_t* __restrict__ wd, int64_t ldd) {
+  const int64_t nf = (int64_t)Co * ldf, nd = (int64_t)Ci * ldd;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < nf) {
+      const int k = (int)(i % ldf), co = (int)(i / ldf);
+      float v = 0.f;
+      if (k < 9 * Ci) v = w[((int64_t)co * Ci + (k % Ci)) * 9 + k / Ci];
+      wf[i] = f2bf(v);
+    } else {
+      const int64_t j = i - nf;
+      const int k = (int)(j % ldd), ci = (int)(j / ldd);
+      float v = 0.f;
+      if (k < 9 * Co) v = w[((int64_t)(k % Co) * Ci + ci) * 9 + (8 - k / Co)];
+      wd[j] = f2bf(v);
+    }
+  }
+}
+extern "C" int dl_cast_conv3x3_weight(const float* w, int64_t Co, int64_t Ci, void* wf, int64_t ldf, void* wd, int64_t ldd,
+                                      dl_stream_t stream) {
+  DL_CHECK_ARG(w && wf && wd && Co > 0 && Ci > 0 && ldf >= 9 * Ci && ldd >= 9 * Co, "dl_cast_conv3x3_weight: bad args");
+  hipLaunchKernelGGL(cast_conv3x3_k, grid_for(Co * ldf + Ci * ldd), 256, 0, (hipStream_t)stream, w, (int)Co, (int)Ci, (bf16_t*)wf,
+                     ldf, (bf16_t*)wd, ldd);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+// wgrad lands as [Co, (tap, ci)] f32; fold it into the reference layout [Co, Ci, 3, 3] (+=)
+__global__ void conv3x3_wgrad_fold_k(const float* __restrict__ g, int64_t ldg, float* __restrict__ dw, int Co, int Ci) {
+  const int64_t n = (int64_t)Co * Ci * 9;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % 9);
+    const int64_t r = i / 9;
+    const int ci = (int)(r % Ci), co = (int)(r / Ci);
+    dw[i] += g[(int64_t)co * ldg + tap * Ci + ci];
+  }
+}
+extern "C" int dl_conv3x3_wgrad_fold(const float* g, int64_t ldg, float* dw, int64_t Co, int64_t Ci, dl_stream_t stream) {
+  DL_CHECK_ARG(g && dw && Co > 0 && Ci > 0 && ldg >= 9 * Ci, "dl_conv3x3_wgrad_fold: bad args");
+  hipLaunchKernelGGL(conv3x3_wgrad_fold_k, grid_for(Co * Ci * 9), 256, 0, (hipStream_t)stream, g, ldg, dw, (int)Co, (int)Ci);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ---------------------------------------------------------------- 2x2 reduce / expand (avg-pool & nearest-upsample, fwd & bwd)
+__global__ void reduce2x2_k(const bf16_t* __restrict__ x, bf16_t* __restrict__ o, int B, int Ho, int Wo, int C, float scale) {
+  const int64_t n = (int64_t)B * Ho * Wo * C;
+  const int W = 2 * Wo;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t r = i / C;
+    const int xo = (int)(r % Wo), yo = (int)((r / Wo) % Ho), b = (int)(r / ((int64_t)Wo * Ho));
+    const int64_t base = (((int64_t)b * 2 * Ho + 2 * yo) * W + 2 * xo) * C + c;
+    o[i] = f2bf(scale * (bf2f(x[base]) + bf2f(x[base + C]) + bf2f(x[base + (int64_t)W * C]) + bf2f(x[base + (int64_t)W * C + C])));
+  }
+}
+__global__ void expand2x2_k(const bf16_t* __restrict__ x, bf16_t* __restrict__ o, int B, int Hi, int Wi, int C, float scale) {
+  const int64_t n = (int64_t)B * 4 * Hi * Wi * C;
+  const int W = 2 * Wi, H = 2 * Hi;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t r = i / C;
+    const int xx = (int)(r % W), yy = (int)((r / W) % H), b = (int)(r / ((int64_t)W * H));
+    o[i] = f2bf(scale * bf2f(x[(((int64_t)b * Hi + yy / 2) * Wi + xx / 2) * C + c]));
+  }
+}
+extern "C" int dl_reduce2x2(const void* x, void* out, int64_t B, int64_t Ho, int64_t Wo, int64_t C, float scale, dl_stream_t stream) {
+  DL_CHECK_ARG(x && out && B > 0 && Ho > 0 && Wo > 0 && C > 0, "dl_reduce2x2: bad args");
+  hipLaunchKernelGGL(reduce2x2_k, grid_for(B * Ho * Wo * C), 256, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, (int)B,
+                     (int)Ho, (int)Wo, (int)C, scale);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_expand2x2(const void* x, void* out, int64_t B, int64_t Hi, int64_t Wi, int64_t C, float scale, dl_stream_t stream) {
+  DL_CHECK_ARG(x && out && B > 0 && Hi > 0 && Wi > 0 && C > 0, "dl_expand2x2: bad args");
+  hipLaunchKernelGGL(expand2x2_k, grid_for(B * 4 * Hi * Wi * C), 256, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, (int)B,
+                     (int)Hi, (int)Wi, (int)C, scale);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ---------------------------------------------------------------- small attention (n <= 64 tokens), one workgroup per (b, head)
+// q,k,v,out: token rows [B*n, ld] with head h at columns [h*dh, (h+1)*dh); probs f32 [B,H,n,n] saved for the backward
+#define AS_MAXN 64
+__global__ __launch_bounds__(256) void attn_small_fwd_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                        const bf16_t* __restrict__ v, int64_t ldq, int64_t ldkv,
+                                                        bf16_t* __restrict__ out, int64_t ldo, float* __restrict__ probs, int n,
+                                                        int H, int dh, float scale) {
+  __shared__ float P[AS_MAXN][AS_MAXN + 1];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const bf16_t* qb = q + (int64_t)b * n * ldq + h * dh;
+  const bf16_t* kb = k + (int64_t)b * n * ldkv + h * dh;
+  const bf16_t* vb = v + (int64_t)b * n * ldkv + h * dh;
+  for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+    const int i = idx / n, j = idx % n;
+    float s = 0.f;
+    for (int d = 0; d < dh; d += 8) {
+      float a[8], c[8];
+      unpack8(*(const u32x4_t*)(qb + (int64_t)i * ldq + d), a);
+      unpack8(*(const u32x4_t*)(kb + (int64_t)j * ldkv + d), c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += a[e] * c[e];
+    }
+    P[i][j] = s * scale;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {  // row softmax (n <= 64 rows: one thread per row)
+    float m = -INFINITY;
+    for (int j = 0; j < n; ++j) m = fmaxf(m, P[i][j]);
+    float l = 0.f;
+    for (int j = 0; j < n; ++j) {
+      const float e = __expf(P[i][j] - m);
+      P[i][j] = e;
+      l += e;
+    }
+    const float inv = 1.0f / l;
+    for (int j = 0; j < n; ++j) {
+      P[i][j] *= inv;
+      probs[(((int64_t)b * H + h) * n + i) * n + j] = P[i][j];
+    }
+  }
+  __syncthreads();
+  const int d8 = dh >> 3;
+  for (int idx = threadIdx.x; idx < n * d8; idx += 256) {
+    const int i = idx / d8, dc = (idx % d8) * 8;
+    float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < n; ++j) {
+      float c[8];
+      unpack8(*(const u32x4_t*)(vb + (int64_t)j * ldkv + dc), c);
+      const float p = P[i][j];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += p * c[e];
+    }
+    *(u32x4_t*)(out + ((int64_t)b * n + i) * ldo + h * dh + dc) = pack8(o);
+  }
+}
+__global__ __launch_bounds__(256) void attn_small_bwd_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                        const bf16_t* __restrict__ v, int64_t ldq, int64_t ldkv,
+                                                        const bf16_t* __restrict__ dout, int64_t ldo,
+                                                        const float* __restrict__ probs, bf16_t* __restrict__ dq,
+                                                        bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int n, int H, int dh,
+                                                        float scale) {
+  __shared__ float P[AS_MAXN][AS_MAXN + 1];
+  __shared__ float dS[AS_MAXN][AS_MAXN + 1];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const bf16_t* qb = q + (int64_t)b * n * ldq + h * dh;
+  const bf16_t* kb = k + (int64_t)b * n * ldkv + h * dh;
+  const bf16_t* vb = v + (int64_t)b * n * ldkv + h * dh;
+  const bf16_t* dob = dout + (int64_t)b * n * ldo + h * dh;
+  for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+    const int i = idx / n, j = idx % n;
+    P[i][j] = probs[(((int64_t)b * H + h) * n + i) * n + j];
+    float s = 0.f;  // dP[i][j] = dO[i,:] . v[j,:]
+    for (int d = 0; d < dh; d += 8) {
+      float a[8], c[8];
+      unpack8(*(const u32x4_t*)(dob + (int64_t)i * ldo + d), a);
+      unpack8(*(const u32x4_t*)(vb + (int64_t)j * ldkv + d), c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += a[e] * c[e];
+    }
+    dS[i][j] = s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float dot = 0.f;
+    for (int j = 0; j < n; ++j) dot += P[i][j] * dS[i][j];
+    for (int j = 0; j < n; ++j) dS[i][j] = P[i][j] * (dS[i][j] - dot) * scale;
+  }
+  __syncthreads();
+  const int d8 = dh >> 3;
+  for (int idx = threadIdx.x; idx < n * d8; idx += 256) {
+    const int r = idx / d8, dc = (idx % d8) * 8;
+    float gq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < n; ++j) {
+      float kk[8], qq[8], dd[8];
+      unpack8(*(const u32x4_t*)(kb + (int64_t)j * ldkv + dc), kk);
+      unpack8(*(const u32x4_t*)(qb + (int64_t)j * ldq + dc), qq);
+      unpack8(*(const u32x4_t*)(dob + (int64_t)j * ldo + dc), dd);
+      const float s_rj = dS[r][j], s_jr = dS[j][r], p_jr = P[j][r];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        gq[e] += s_rj * kk[e];  // dQ[r] = sum_j dS[r][j] K[j]
+        gk[e] += s_jr * qq[e];  // dK[r] = sum_j dS[j][r] Q[j]
+        gv[e] += p_jr * dd[e];  // dV[r] = sum_j P[j][r] dO[j]
+      }
+    }
+    const int64_t o = ((int64_t)b * n + r);
+    *(u32x4_t*)(dq + o * ldq + h * dh + dc) = pack8(gq);
+    *(u32x4_t*)(dk + o * ldkv + h * dh + dc) = pack8(gk);
+    *(u32x4_t*)(dv + o * ldkv + h * dh + dc) = pack8(gv);
+  }
+}
+extern "C" int dl_attn_small_fwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldkv, void* out, int64_t ldo,
+                                 float* probs, int64_t B, int64_t n, int64_t H, int64_t dh, float scale, dl_stream_t stream) {
+  DL_CHECK_ARG(q && k && v && out && probs && B > 0 && n > 0 && n <= AS_MAXN && dh % 8 == 0, "dl_attn_small_fwd: n=%lld dh=%lld",
+               (long long)n, (long long)dh);
+  hipLaunchKernelGGL(attn_small_fwd_k, (int)(B * H), 256, 0, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k,
+                     (const bf16_t*)v, ldq, ldkv, (bf16_t*)out, ldo, probs, (int)n, (int)H, (int)dh, scale);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_attn_small_bwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldkv, const void* dout,
+                                 int64_t ldo, const float* probs, void* dq, void* dk, void* dv, int64_t B, int64_t n, int64_t H,
+                                 int64_t dh, float scale, dl_stream_t stream) {
+  DL_CHECK_ARG(q && k && v && dout && probs && dq && dk && dv && B > 0 && n > 0 && n <= AS_MAXN && dh % 8 == 0,
+               "dl_attn_small_bwd: bad args");
+  hipLaunchKernelGGL(attn_small_bwd_k, (int)(B * H), 256, 0, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k,
+                     (const bf16_t*)v, ldq, ldkv, (const bf16_t*)dout, ldo, probs, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, (int)n,
+                     (int)H, (int)dh, scale);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ---------------------------------------------------------------- glue: gradient fan-in add, strided 2-D copy (concat / split / pad)
+__global__ void add_bf16_k(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ o, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    o[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+}
+extern "C" int dl_add_bf16(const void* a, const void* b, void* out, int64_t n, dl_stream_t stream) {
+  DL_CHECK_ARG(a && b && out && n > 0, "dl_add_bf16: bad args");
+  hipLaunchKernelGGL(add_bf16_k, grid_for(n), 256, 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+__global__ void copy2d_bf16_k(const bf16_t* __restrict__ s, int64_t lds, bf16_t* __restrict__ d, int64_t ldd, int64_t rows, int cols) {
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    d[r * ldd + c] = s[r * lds + c];
+  }
+}
+extern "C" int dl_copy2d_bf16(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, dl_stream_t stream) {
+  DL_CHECK_ARG(src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= cols, "dl_copy2d_bf16: bad args");
+  hipLaunchKernelGGL(copy2d_bf16_k, grid_for(rows * cols), 256, 0, (hipStream_t)stream, (const bf16_t*)src, lds, (bf16_t*)dst, ldd,
+                     rows, (int)cols);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}

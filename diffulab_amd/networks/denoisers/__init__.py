@@ -1,4 +1,5 @@
 from .common import Denoiser, ModelInput, ModelOutput
 from .mmdit import MMDiT
+from .unet import UNetModel
 
-__all__ = ["Denoiser", "MMDiT", "ModelInput", "ModelOutput"]
+__all__ = ["Denoiser", "MMDiT", "ModelInput", "ModelOutput", "UNetModel"]

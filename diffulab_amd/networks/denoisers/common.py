@@ -2,9 +2,11 @@
 
 from __future__ import annotations
 
+import copy
 from abc import ABC, abstractmethod
 from typing import Any, TypedDict
 
+import torch
 import torch.nn as nn
 from torch import Tensor
 
@@ -36,3 +38,125 @@ class Denoiser(nn.Module, ABC):
 
     @abstractmethod
     def forward(self, x: Tensor, timesteps: Tensor, *args: Any, **kwargs: Any) -> ModelOutput: ...
+
+
+class EngineFn(torch.autograd.Function):
+    """autograd seam shared by the HIP denoisers: forward/backward of the whole network are the engine's launch sequences;
+    parameter gradients are accumulated straight into the flat gradient arena (``p.grad`` are views of it)."""
+
+    @staticmethod
+    def forward(ctx, module: "FlatArenaDenoiser", x: Tensor, t: Tensor, y_eff: Tensor | None, anchor: Tensor) -> Tensor:
+        ctx.module = module
+        ctx.set_materialize_grads(False)
+        return module._engine.forward(x, t, y_eff, train=True).clone()
+
+    @staticmethod
+    def backward(ctx, dpred: Tensor | None):
+        m = ctx.module
+        if dpred is not None:
+            m._prepare_grads()
+            m._engine.backward(dpred.contiguous().float())
+        return None, None, None, None, None
+
+
+class FlatArenaDenoiser(Denoiser):
+    """Denoiser whose ``nn.Module`` tree only OWNS parameters: every parameter (and gradient) is a view into one flat f32 HBM
+    arena driven by an engine object (``layout.entries`` / ``layout.view`` / ``bind`` / ``forward`` / ``backward``).
+    Subclasses implement ``_make_engine(device)``."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        for k in ("_engine", "_flat", "_flat_grad", "_anchor"):
+            object.__setattr__(self, k, None)
+
+    def _make_engine(self, device: torch.device):  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def __deepcopy__(self, memo):  # EMA wrappers deep-copy the module: copy parameters, not the engine/workspace
+        saved = {k: self.__dict__.get(k) for k in ("_engine", "_flat", "_flat_grad", "_anchor")}
+        for k in saved:
+            object.__setattr__(self, k, None)
+        try:
+            cls = self.__class__
+            new = cls.__new__(cls)
+            memo[id(self)] = new
+            for k, v in self.__dict__.items():
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        finally:
+            for k, v in saved.items():
+                object.__setattr__(self, k, v)
+        return new
+
+    def _named(self) -> dict[str, nn.Parameter]:
+        return dict(self.named_parameters())
+
+    def _is_flat(self) -> bool:
+        if self._flat is None or self._engine is None:
+            return False
+        lay = self._engine.layout
+        base = self._flat.data_ptr()
+        for name, p in self.named_parameters():
+            if p.data_ptr() != base + 4 * lay.entries[name][0]:
+                return False
+        return True
+
+    def flatten_parameters(self, device: torch.device | str | None = None) -> None:
+        """(re)pack every parameter into the flat f32 arena on ``device`` and point ``.data`` / ``.grad`` at views."""
+        named = self._named()
+        dev = torch.device(device) if device is not None else next(iter(named.values())).device
+        if dev.type != "cuda":
+            raise RuntimeError(f"diffulab_amd.{type(self).__name__} runs on an MI355X only: move the module to 'cuda' "
+                               "(no CPU fallback)")
+        if self._engine is None or self._engine.dev != dev:
+            object.__setattr__(self, "_engine", self._make_engine(dev))
+        lay = self._engine.layout
+        assert set(named) == set(lay.entries), set(named) ^ set(lay.entries)
+        # the arena must be ordinary (version-tracked) tensors even when the first forward happens inside
+        # torch.inference_mode() (Flow.denoise is decorated with it)
+        with torch.inference_mode(False), torch.no_grad():
+            flat = torch.zeros(lay.size, device=dev, dtype=torch.float32)
+            grad = torch.zeros(lay.size, device=dev, dtype=torch.float32)
+            for name, p in named.items():
+                v = lay.view(flat, name)
+                v.copy_(p.detach().to(device=dev, dtype=torch.float32))
+                if p.grad is not None:
+                    lay.view(grad, name).copy_(p.grad.to(device=dev, dtype=torch.float32))
+                p.data = v
+                p.grad = lay.view(grad, name)
+            anchor = torch.zeros(1, device=dev, requires_grad=True)
+        object.__setattr__(self, "_flat", flat)
+        object.__setattr__(self, "_flat_grad", grad)
+        object.__setattr__(self, "_anchor", anchor)
+        self._engine.bind(flat, grad)
+
+    def _prepare_grads(self) -> None:
+        """called at the start of every backward: honour optimizer.zero_grad(set_to_none=True) (torch default) by
+        zeroing the arena once and re-attaching the .grad views."""
+        lay, grad = self._engine.layout, self._flat_grad
+        first = next(iter(self.parameters()))
+        if first.grad is None:
+            grad.zero_()
+        base = grad.data_ptr()
+        for name, p in self.named_parameters():
+            if p.grad is None or p.grad.data_ptr() != base + 4 * lay.entries[name][0]:
+                p.grad = lay.view(grad, name)
+
+    def zero_grad(self, set_to_none: bool = False) -> None:  # one memset instead of one kernel per tensor
+        if self._flat_grad is not None and self._is_flat():
+            self._flat_grad.zero_()
+            self._prepare_grads()
+        else:
+            super().zero_grad(set_to_none=set_to_none)
+
+    @property
+    def engine(self):
+        if not self._is_flat():
+            self.flatten_parameters()
+        return self._engine
+
+    def _run(self, x: Tensor, t: Tensor, y_eff: Tensor | None) -> Tensor:
+        eng = self.engine
+        need_grad = torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())
+        if need_grad:
+            return EngineFn.apply(self, x, t, y_eff, self._anchor)
+        return eng.forward(x, t, y_eff, train=False).clone()

@@ -10,7 +10,6 @@ without ``libdiffulab_hip.so`` raises.
 
 from __future__ import annotations
 
-import copy
 import logging
 from typing import Any
 
@@ -19,7 +18,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from ...engine import DiTDims, DiTEngine
-from .common import Denoiser, ModelOutput
+from .common import FlatArenaDenoiser, ModelOutput
 
 
 class _RMSScale(nn.Module):
@@ -82,26 +81,7 @@ class _LastLayer(nn.Module):
         self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(emb, 2 * dim))
 
 
-class _DiTFn(torch.autograd.Function):
-    """autograd seam: forward/backward of the whole denoiser are the engine's launch sequences; parameter
-    gradients are accumulated straight into the flat gradient arena (p.grad are views of it)."""
-
-    @staticmethod
-    def forward(ctx, module: "MMDiT", x: Tensor, t: Tensor, y_eff: Tensor | None, anchor: Tensor) -> Tensor:
-        ctx.module = module
-        ctx.set_materialize_grads(False)
-        return module._engine.forward(x, t, y_eff, train=True).clone()
-
-    @staticmethod
-    def backward(ctx, dpred: Tensor | None):
-        m: MMDiT = ctx.module
-        if dpred is not None:
-            m._prepare_grads()
-            m._engine.backward(dpred.contiguous().float())
-        return None, None, None, None, None
-
-
-class MMDiT(Denoiser):
+class MMDiT(FlatArenaDenoiser):
     def __init__(
         self,
         simple_dit: bool = False,
@@ -157,10 +137,6 @@ class MMDiT(Denoiser):
         self.conv_proj = nn.Conv2d(input_channels, inner_dim, kernel_size=patch_size, stride=patch_size, bias=False)
         self.layers = nn.ModuleList([DiTBlock(inner_dim, embedding_dim, mlp_ratio) for _ in range(depth)])
         self.apply(self._init_weights)
-        object.__setattr__(self, "_engine", None)
-        object.__setattr__(self, "_flat", None)
-        object.__setattr__(self, "_flat_grad", None)
-        object.__setattr__(self, "_anchor", None)
 
     # reference init: xavier on Linear/Conv2d, zero biases, zero adaLN (mmdit.py:735-745)
     @staticmethod
@@ -176,87 +152,8 @@ class MMDiT(Denoiser):
             for p in module.adaLN_modulation.parameters():
                 p.detach().zero_()
 
-    # ------------------------------------------------------------------ flat arena management
-    def __deepcopy__(self, memo):  # EMA wrappers deep-copy the module: copy parameters, not the engine/workspace
-        saved = {k: self.__dict__.get(k) for k in ("_engine", "_flat", "_flat_grad", "_anchor")}
-        for k in saved:
-            object.__setattr__(self, k, None)
-        try:
-            cls = self.__class__
-            new = cls.__new__(cls)
-            memo[id(self)] = new
-            for k, v in self.__dict__.items():
-                new.__dict__[k] = copy.deepcopy(v, memo)
-        finally:
-            for k, v in saved.items():
-                object.__setattr__(self, k, v)
-        return new
-
-    def _named(self) -> dict[str, nn.Parameter]:
-        return dict(self.named_parameters())
-
-    def _is_flat(self) -> bool:
-        if self._flat is None or self._engine is None:
-            return False
-        lay = self._engine.layout
-        base = self._flat.data_ptr()
-        for name, p in self.named_parameters():
-            if p.data_ptr() != base + 4 * lay.entries[name][0]:
-                return False
-        return True
-
-    def flatten_parameters(self, device: torch.device | str | None = None) -> None:
-        """(re)pack every parameter into the flat f32 arena on ``device`` and point ``.data`` / ``.grad`` at views."""
-        named = self._named()
-        dev = torch.device(device) if device is not None else next(iter(named.values())).device
-        if dev.type != "cuda":
-            raise RuntimeError("diffulab_amd.MMDiT runs on an MI355X only: move the module to 'cuda' (no CPU fallback)")
-        if self._engine is None or self._engine.dev != dev:
-            object.__setattr__(self, "_engine", DiTEngine(self.dims, dev))
-        lay = self._engine.layout
-        assert set(named) == set(lay.entries), set(named) ^ set(lay.entries)
-        # the arena must be ordinary (version-tracked) tensors even when the first forward happens inside
-        # torch.inference_mode() (Flow.denoise is decorated with it)
-        with torch.inference_mode(False), torch.no_grad():
-            flat = torch.zeros(lay.size, device=dev, dtype=torch.float32)
-            grad = torch.zeros(lay.size, device=dev, dtype=torch.float32)
-            for name, p in named.items():
-                v = lay.view(flat, name)
-                v.copy_(p.detach().to(device=dev, dtype=torch.float32))
-                if p.grad is not None:
-                    lay.view(grad, name).copy_(p.grad.to(device=dev, dtype=torch.float32))
-                p.data = v
-                p.grad = lay.view(grad, name)
-            anchor = torch.zeros(1, device=dev, requires_grad=True)
-        object.__setattr__(self, "_flat", flat)
-        object.__setattr__(self, "_flat_grad", grad)
-        object.__setattr__(self, "_anchor", anchor)
-        self._engine.bind(flat, grad)
-
-    def _prepare_grads(self) -> None:
-        """called at the start of every backward: honour optimizer.zero_grad(set_to_none=True) (torch default) by
-        zeroing the arena once and re-attaching the .grad views."""
-        lay, grad = self._engine.layout, self._flat_grad
-        first = next(iter(self.parameters()))
-        if first.grad is None:
-            grad.zero_()
-        base = grad.data_ptr()
-        for name, p in self.named_parameters():
-            if p.grad is None or p.grad.data_ptr() != base + 4 * lay.entries[name][0]:
-                p.grad = lay.view(grad, name)
-
-    def zero_grad(self, set_to_none: bool = False) -> None:  # one memset instead of one kernel per tensor
-        if self._flat_grad is not None and self._is_flat():
-            self._flat_grad.zero_()
-            self._prepare_grads()
-        else:
-            super().zero_grad(set_to_none=set_to_none)
-
-    @property
-    def engine(self) -> DiTEngine:
-        if not self._is_flat():
-            self.flatten_parameters()
-        return self._engine
+    def _make_engine(self, device: torch.device) -> DiTEngine:
+        return DiTEngine(self.dims, device)
 
     # ------------------------------------------------------------------ forward (mmdit.py:903-928)
     def forward(
@@ -290,9 +187,4 @@ class MMDiT(Denoiser):
             if p > 0:  # LabelEmbed.drop_labels nn.py:149 -- torch device RNG, same draw as the reference
                 y_eff = torch.where(torch.rand(y_eff.size(), device=dev) < p, self.n_classes, y_eff)
             y_eff = y_eff.contiguous()
-        need_grad = torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())
-        if need_grad:
-            pred = _DiTFn.apply(self, x, t, y_eff, self._anchor)
-        else:
-            pred = eng.forward(x, t, y_eff, train=False).clone()
-        return {"x": pred}
+        return {"x": self._run(x, t, y_eff)}

@@ -286,6 +286,70 @@ def ema_update(ema, p, beta):
     _call("dl_ema_update", _p(ema), _p(p), float(beta), p.numel(), _s())
 
 
+# ------------------------------------------------------------------ UNet kernels (NHWC bf16 token rows)
+def nchw_to_nhwc(x, out, B, C, HW):
+    _call("dl_nchw_to_nhwc", _p(x), _p(out), B, C, HW, out.stride(0), _s())
+
+
+def nhwc_to_nchw(x, out, B, C, HW):
+    _call("dl_nhwc_to_nchw", _p(x), _p(out), B, C, HW, x.stride(0), _s())
+
+
+def gn_stats(x, stats, B, HW, C, G=32, eps=1e-5):
+    _call("dl_gn_stats", _p(x), _p(stats), B, HW, C, G, float(eps), _s())
+
+
+def gn_apply_fwd(x, stats, w, b, film_scale, film_shift, silu, out, B, HW, C, G=32):
+    _call("dl_gn_apply_fwd", _p(x), _p(stats), _p(w), _p(b), _p(film_scale), _p(film_shift),
+          film_scale.stride(0) if film_scale is not None else 0, int(silu), _p(out), B, HW, C, G, _s())
+
+
+def gn_bwd(dout, x, stats, w, b, film_scale, film_shift, silu, dres, dx, dw, db, dfilm_scale, dfilm_shift, scratch, B, HW, C,
+           G=32):
+    _call("dl_gn_bwd", _p(dout), _p(x), _p(stats), _p(w), _p(b), _p(film_scale), _p(film_shift),
+          film_scale.stride(0) if film_scale is not None else 0, int(silu), _p(dres), _p(dx), _p(dw), _p(db), _p(dfilm_scale),
+          _p(dfilm_shift), dfilm_scale.stride(0) if dfilm_scale is not None else 0, _p(scratch), B, HW, C, G, _s())
+
+
+def im2col3x3(x, cols, B, H, W, C):
+    _call("dl_im2col3x3", _p(x), x.stride(0), _p(cols), B, H, W, C, cols.shape[0], cols.stride(0), _s())
+
+
+def cast_conv3x3_weight(w, wf, wd):
+    _call("dl_cast_conv3x3_weight", _p(w), w.shape[0], w.shape[1], _p(wf), wf.stride(0), _p(wd), wd.stride(0), _s())
+
+
+def conv3x3_wgrad_fold(g, dw):
+    _call("dl_conv3x3_wgrad_fold", _p(g), g.stride(0), _p(dw), dw.shape[0], dw.shape[1], _s())
+
+
+def reduce2x2(x, out, B, Ho, Wo, C, scale):
+    _call("dl_reduce2x2", _p(x), _p(out), B, Ho, Wo, C, float(scale), _s())
+
+
+def expand2x2(x, out, B, Hi, Wi, C, scale):
+    _call("dl_expand2x2", _p(x), _p(out), B, Hi, Wi, C, float(scale), _s())
+
+
+def attn_small_fwd(q, k, v, out, probs, B, n, H, dh):
+    _call("dl_attn_small_fwd", _p(q), _p(k), _p(v), q.stride(0), k.stride(0), _p(out), out.stride(0), _p(probs), B, n, H, dh,
+          float(dh) ** -0.5, _s())
+
+
+def attn_small_bwd(q, k, v, dout, probs, dq, dk, dv, B, n, H, dh):
+    assert dq.stride(0) == q.stride(0) and dk.stride(0) == k.stride(0) == dv.stride(0) == v.stride(0)
+    _call("dl_attn_small_bwd", _p(q), _p(k), _p(v), q.stride(0), k.stride(0), _p(dout), dout.stride(0), _p(probs), _p(dq),
+          _p(dk), _p(dv), B, n, H, dh, float(dh) ** -0.5, _s())
+
+
+def add_bf16(a, b, out):
+    _call("dl_add_bf16", _p(a), _p(b), _p(out), a.numel(), _s())
+
+
+def copy2d_bf16(src, dst, rows, cols):
+    _call("dl_copy2d_bf16", _p(src), src.stride(0), _p(dst), dst.stride(0), rows, cols, _s())
+
+
 def probe_tr16() -> Tensor:
     out = torch.zeros(256, dtype=torch.int16, device="cuda")
     _call("dl_probe_tr16", _p(out), _s())

@@ -1,0 +1,601 @@
+"""Host-side runtime of the UNet denoiser (guided-diffusion style ``UNetModel``): parameter arena, bf16 weight shadows and
+the forward / backward launch sequences over the C ABI.
+
+Same MI355X-first choices as the DiT engine (engine.py): one flat f32 parameter arena + one flat gradient arena (one fused
+AdamW launch, a handful of large RCCL all-reduces), the FiLM projections ``emb_layers.1`` of EVERY ResBlock stored back to
+back so the conditioning of the whole network is ONE GEMM per step (silu(emb) is block-invariant), activations kept as NHWC
+bf16 token rows so that 3x3 convolutions are im2col + MFMA GEMM with the residual add fused into the GEMM epilogue, and
+1x1 convolutions are plain GEMMs.
+
+Reference sites restated by the sequences below (``/root/reference/src/diffulab``): networks/denoisers/unet.py:593-745 (block
+wiring), :832-853 (forward), :215-237 (ResBlock._forward), :296-322 (AttentionBlock._forward); networks/utils/nn.py:11-88
+(GroupNorm32, Upsample, Downsample).  Only what ``configs/model/unet.yaml`` builds is covered: ``resblock_updown=True``,
+``use_scale_shift_norm=True``, class-conditional or unconditional, self-attention blocks (no context embedder).
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import torch
+from torch import Tensor
+
+from . import engine as _eng
+from . import ops
+from .engine import _rup
+
+
+@dataclass
+class UNetDims:
+    image_size: tuple[int, int] = (32, 32)
+    in_channels: int = 1
+    model_channels: int = 128
+    out_channels: int = 1
+    num_res_blocks: int = 2
+    attention_resolutions: tuple[int, ...] = (4, 8, 16)  # downsample FACTORS at which attention is inserted (unet.py:611)
+    channel_mult: tuple[int, ...] = (1, 2, 4, 8)
+    num_heads: int = 1
+    use_scale_shift_norm: bool = False
+    resblock_updown: bool = False
+    n_classes: int | None = None
+    classifier_free: bool = False
+
+    def validate(self) -> None:
+        if not self.resblock_updown:
+            raise NotImplementedError("HIP UNet covers resblock_updown=True (configs/model/unet.yaml); conv resampling is not built")
+        if not self.use_scale_shift_norm:
+            raise NotImplementedError("HIP UNet covers use_scale_shift_norm=True (configs/model/unet.yaml)")
+        mc = self.model_channels
+        if mc % 32:
+            raise NotImplementedError("model_channels must be a multiple of 32 (GroupNorm32)")
+        down = 2 ** (len(self.channel_mult) - 1)
+        if self.image_size[0] % down or self.image_size[1] % down:
+            raise NotImplementedError("image size must be divisible by 2^(levels-1)")
+        ds = 1
+        for level, mult in enumerate(self.channel_mult):
+            if ds in self.attention_resolutions:
+                n = (self.image_size[0] // ds) * (self.image_size[1] // ds)
+                if n > 64:
+                    raise NotImplementedError(f"AttentionBlock kernel handles <= 64 tokens (got {n} at downsample {ds})")
+                if (mult * mc) % self.num_heads or (mult * mc // self.num_heads) % 8:
+                    raise NotImplementedError("attention head_dim must be a multiple of 8")
+            if level != len(self.channel_mult) - 1:
+                ds *= 2
+
+
+@dataclass
+class _Blk:
+    kind: str  # "conv" | "res" | "attn"
+    prefix: str
+    cin: int = 0
+    cout: int = 0
+    up: bool = False
+    down: bool = False
+    emb_off: int = 0  # column offset of this ResBlock's [scale | shift] inside the stacked FiLM projection
+
+
+@dataclass
+class _Plan:
+    input_blocks: list[list[_Blk]] = field(default_factory=list)
+    middle: list[_Blk] = field(default_factory=list)
+    output_blocks: list[list[_Blk]] = field(default_factory=list)
+    final_ch: int = 0
+
+    def all_blocks(self) -> list[_Blk]:
+        return [b for grp in self.input_blocks + [self.middle] + self.output_blocks for b in grp]
+
+
+def build_plan(d: UNetDims) -> _Plan:
+    """module wiring of unet.py:593-745 for resblock_updown=True without a context embedder"""
+    mc = d.model_channels
+    plan = _Plan()
+    ch = int(d.channel_mult[0] * mc)
+    plan.input_blocks.append([_Blk("conv", "input_blocks.0.0.", d.in_channels, ch)])
+    chans, ds = [ch], 1
+    for level, mult in enumerate(d.channel_mult):
+        for _ in range(d.num_res_blocks):
+            i = len(plan.input_blocks)
+            layers = [_Blk("res", f"input_blocks.{i}.0.", ch, int(mult * mc))]
+            ch = int(mult * mc)
+            if ds in d.attention_resolutions:
+                layers.append(_Blk("attn", f"input_blocks.{i}.1.", ch, ch))
+            plan.input_blocks.append(layers)
+            chans.append(ch)
+        if level != len(d.channel_mult) - 1:
+            i = len(plan.input_blocks)
+            plan.input_blocks.append([_Blk("res", f"input_blocks.{i}.0.", ch, ch, down=True)])
+            chans.append(ch)
+            ds *= 2
+    plan.middle = [_Blk("res", "middle_block.0.", ch, ch), _Blk("attn", "middle_block.1.", ch, ch),
+                   _Blk("res", "middle_block.2.", ch, ch)]
+    for level, mult in list(enumerate(d.channel_mult))[::-1]:
+        for k in range(d.num_res_blocks + 1):
+            ich = chans.pop()
+            i = len(plan.output_blocks)
+            layers = [_Blk("res", f"output_blocks.{i}.0.", ch + ich, int(mc * mult))]
+            ch = int(mc * mult)
+            if ds in d.attention_resolutions:
+                layers.append(_Blk("attn", f"output_blocks.{i}.{len(layers)}.", ch, ch))
+            if level and k == d.num_res_blocks:
+                layers.append(_Blk("res", f"output_blocks.{i}.{len(layers)}.", ch, ch, up=True))
+                ds //= 2
+            plan.output_blocks.append(layers)
+    plan.final_ch = ch
+    off = 0
+    for b in plan.all_blocks():
+        if b.kind == "res":
+            b.emb_off = off
+            off += 2 * b.cout
+    return plan
+
+
+class UNetLayout:
+    """name -> (offset, shape) inside the flat f32 arena: the FiLM projections of all ResBlocks first (one [R, 4*mc] matrix and
+    its bias), then everything else in module order; entries start on 256-byte boundaries."""
+
+    def __init__(self, d: UNetDims, plan: _Plan) -> None:
+        self.entries: dict[str, tuple[int, tuple[int, ...]]] = {}
+        self.size = 0
+        te = 4 * d.model_channels
+
+        def add(name: str, shape: tuple[int, ...], align: int = 64) -> None:
+            self.size = _rup(self.size, align)
+            self.entries[name] = (self.size, shape)
+            self.size += math.prod(shape)
+
+        res = [b for b in plan.all_blocks() if b.kind == "res"]
+        for i, b in enumerate(res):
+            add(b.prefix + "emb_layers.1.weight", (2 * b.cout, te), align=1 if i else 64)
+        for i, b in enumerate(res):
+            add(b.prefix + "emb_layers.1.bias", (2 * b.cout,), align=1 if i else 64)
+        self.emb_rows = sum(2 * b.cout for b in res)
+        self.emb_w0, self.emb_b0 = res[0].prefix + "emb_layers.1.weight", res[0].prefix + "emb_layers.1.bias"
+        add("time_embed.0.weight", (te, d.model_channels))
+        add("time_embed.0.bias", (te,))
+        add("time_embed.2.weight", (te, te))
+        add("time_embed.2.bias", (te,))
+        if d.n_classes is not None:
+            add("label_embed.embedding.weight", (d.n_classes + (1 if d.classifier_free else 0), te))
+        for b in plan.all_blocks():
+            p = b.prefix
+            if b.kind == "conv":
+                add(p + "weight", (b.cout, b.cin, 3, 3))
+                add(p + "bias", (b.cout,))
+            elif b.kind == "res":
+                add(p + "in_layers.0.weight", (b.cin,))
+                add(p + "in_layers.0.bias", (b.cin,))
+                add(p + "in_layers.2.weight", (b.cout, b.cin, 3, 3))
+                add(p + "in_layers.2.bias", (b.cout,))
+                add(p + "out_layers.0.weight", (b.cout,))
+                add(p + "out_layers.0.bias", (b.cout,))
+                add(p + "out_layers.3.weight", (b.cout, b.cout, 3, 3))
+                add(p + "out_layers.3.bias", (b.cout,))
+                if b.cin != b.cout:
+                    add(p + "skip_connection.weight", (b.cout, b.cin, 1, 1))
+                    add(p + "skip_connection.bias", (b.cout,))
+            else:
+                c = b.cin
+                for n in ("norm_x", "norm_context"):
+                    add(p + n + ".weight", (c,))
+                    add(p + n + ".bias", (c,))
+                add(p + "to_q.weight", (c, c, 1))
+                add(p + "to_q.bias", (c,))
+                add(p + "to_kv.weight", (2 * c, c, 1))
+                add(p + "to_kv.bias", (2 * c,))
+                add(p + "to_out.0.weight", (c, c, 1))
+                add(p + "to_out.0.bias", (c,))
+        add("out.0.weight", (plan.final_ch,))
+        add("out.0.bias", (plan.final_ch,))
+        add("out.2.weight", (d.out_channels, int(d.channel_mult[0] * d.model_channels), 3, 3))
+        add("out.2.bias", (d.out_channels,))
+        self.size = _rup(self.size, 64)
+
+    def view(self, flat: Tensor, name: str) -> Tensor:
+        off, shape = self.entries[name]
+        return flat[off : off + math.prod(shape)].view(shape)
+
+
+class UNetEngine:
+    G = 32  # GroupNorm32
+
+    def __init__(self, dims: UNetDims, device: torch.device | str = "cuda") -> None:
+        dims.validate()
+        self.d = dims
+        self.dev = torch.device(device)
+        self.plan = build_plan(dims)
+        self.layout = UNetLayout(dims, self.plan)
+        self.params: Tensor | None = None
+        self.grads: Tensor | None = None
+        self._shadow_key: tuple | None = None
+        self.manual_version = 0
+        self.reducer = None  # optional training.dp.GradReducer
+        self._scratch: dict[str, Tensor] = {}
+        self._saved: dict | None = None
+        self._build_shadows()
+
+    # ------------------------------------------------------------------ parameters
+    def bind(self, params: Tensor, grads: Tensor | None) -> None:
+        assert params.dtype == torch.float32 and params.numel() == self.layout.size and params.is_cuda
+        self.params, self.grads = params, grads
+        self._shadow_key = None
+
+    def P(self, name: str) -> Tensor:
+        return self.layout.view(self.params, name)
+
+    def Gr(self, name: str) -> Tensor:
+        return self.layout.view(self.grads, name)
+
+    def _build_shadows(self) -> None:
+        d, dev = self.d, self.dev
+        te = 4 * d.model_channels
+        self.sh: dict[str, Tensor] = {}
+        self._lin: list[tuple[str, tuple[int, int], bool, bool]] = []
+        self._conv: list[tuple[str, int, int, bool]] = []
+
+        def z(*shape: int) -> Tensor:
+            return torch.zeros(*shape, device=dev, dtype=torch.bfloat16)
+
+        def lin(name: str, R: int, C: int, fwd: bool = True, dgrad: bool = True) -> None:
+            if fwd:
+                self.sh[name + "|f"] = z(R, _rup(C, 64))
+            if dgrad:
+                self.sh[name + "|t"] = z(C, _rup(R, 64))
+            self._lin.append((name, (R, C), fwd, dgrad))
+
+        def conv(name: str, co: int, ci: int, dgrad: bool = True) -> None:
+            self.sh[name + "|f"] = z(co, _rup(9 * ci, 64))
+            self.sh[name + "|d"] = z(ci, _rup(9 * co, 64))  # tiny when unused (stem: ci = in_channels)
+            self._conv.append((name, co, ci, dgrad))
+
+        lin("@emb", self.layout.emb_rows, te)
+        lin("time_embed.0.weight", te, d.model_channels, dgrad=False)
+        lin("time_embed.2.weight", te, te)
+        for b in self.plan.all_blocks():
+            p = b.prefix
+            if b.kind == "conv":
+                conv(p + "weight", b.cout, b.cin, dgrad=False)
+            elif b.kind == "res":
+                conv(p + "in_layers.2.weight", b.cout, b.cin)
+                conv(p + "out_layers.3.weight", b.cout, b.cout)
+                if b.cin != b.cout:
+                    lin(p + "skip_connection.weight", b.cout, b.cin)
+            else:
+                c = b.cin
+                lin(p + "to_q.weight", c, c)
+                lin(p + "to_kv.weight", 2 * c, c)
+                lin(p + "to_out.0.weight", c, c)
+        conv("out.2.weight", d.out_channels, int(d.channel_mult[0] * d.model_channels))
+
+    def refresh_shadows(self, force: bool = False) -> None:
+        ver = 0 if self.params.is_inference() else self.params._version
+        key = (self.params.data_ptr(), ver, self.manual_version, _eng._PARAM_EPOCH)
+        if not force and key == self._shadow_key:
+            return
+        for name, (R, C), fwd, dgrad in self._lin:
+            if name == "@emb":
+                off = self.layout.entries[self.layout.emb_w0][0]
+                src = self.params[off : off + R * C].view(R, C)
+            else:
+                src = self.P(name).view(R, C)
+            ops.cast_weight(src, self.sh[name + "|f"] if fwd else None, self.sh[name + "|t"] if dgrad else None)
+        for name, co, ci, _ in self._conv:
+            ops.cast_conv3x3_weight(self.P(name), self.sh[name + "|f"], self.sh[name + "|d"])
+        self._shadow_key = key
+
+    # ------------------------------------------------------------------ small helpers
+    def _new(self, *shape: int, dtype=torch.bfloat16, zero: bool = False) -> Tensor:
+        with torch.inference_mode(False):
+            return (torch.zeros if zero else torch.empty)(*shape, device=self.dev, dtype=dtype)
+
+    def _scr(self, key: str, numel: int, dtype=torch.bfloat16) -> Tensor:
+        """grow-only scratch (im2col matrices, wgrad staging): reused by every conv, all launches are on one stream"""
+        t = self._scratch.get(key)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            with torch.inference_mode(False):
+                t = torch.empty(numel, device=self.dev, dtype=dtype)
+            self._scratch[key] = t
+        return t[:numel]
+
+    def _padded(self, x: Tensor, rows: int, cols: int) -> Tensor:
+        """x [M, C] -> zero-padded [rows, cols] copy when the GEMM alignment (K % 64, reduction rows % 64) needs it"""
+        if x.shape[0] == rows and x.shape[1] == cols:
+            return x
+        out = self._new(rows, cols, zero=True)
+        ops.copy2d_bf16(x, out, x.shape[0], min(x.shape[1], cols))
+        return out
+
+    # ------------------------------------------------------------------ primitive forward / backward pairs
+    def _conv3(self, x: Tensor, B: int, H: int, W: int, ci: int, name: str, co: int, resid: Tensor | None = None) -> Tensor:
+        M = B * H * W
+        Mp, ldk = _rup(M, 64), _rup(9 * ci, 64)
+        cols = self._scr("cols", Mp * ldk).view(Mp, ldk)
+        ops.im2col3x3(x, cols, B, H, W, ci)
+        out = self._new(M, _rup(co, 8), zero=bool(co % 8))
+        ops.gemm_nt(cols, self.sh[name + "|f"], out, bias=self.P(name[:-6] + "bias"), resid=resid, M=M, N=co, K=ldk)
+        return out
+
+    def _conv3_bwd(self, dy: Tensor, x: Tensor, B: int, H: int, W: int, ci: int, name: str, co: int,
+                   need_dx: bool = True) -> Tensor | None:
+        M = B * H * W
+        Mp, ldk, co8 = _rup(M, 64), _rup(9 * ci, 64), _rup(co, 8)
+        ops.colsum(dy, self.Gr(name[:-6] + "bias"), M, co)
+        cols = self._scr("cols", Mp * ldk).view(Mp, ldk)
+        ops.im2col3x3(x, cols, B, H, W, ci)
+        dyp = self._padded(dy, Mp, co8)
+        g = self._scr("wg", co8 * ldk, torch.float32).view(co8, ldk)
+        g.zero_()
+        ops.gemm_tn(dyp, cols, g, M=co8, N=ldk)
+        ops.conv3x3_wgrad_fold(g, self.Gr(name))
+        if not need_dx:
+            return None
+        ldd = _rup(9 * co, 64)
+        dcols = self._scr("cols", Mp * ldd).view(Mp, ldd)
+        ops.im2col3x3(dy, dcols, B, H, W, co)
+        dx = self._new(M, ci)
+        ops.gemm_nt(dcols, self.sh[name + "|d"], dx, M=M, N=ci, K=ldd)
+        return dx
+
+    def _lin_fwd(self, x: Tensor, name: str, co: int, ci: int, resid: Tensor | None = None, out: Tensor | None = None) -> Tensor:
+        M = x.shape[0]
+        K = _rup(ci, 64)
+        xp = self._padded(x, M, K)
+        out = self._new(M, co) if out is None else out
+        ops.gemm_nt(xp, self.sh[name + "|f"], out, bias=self.P(name[:-6] + "bias"), resid=resid, M=M, N=co, K=K)
+        return out
+
+    def _lin_bwd(self, dy: Tensor, x: Tensor, name: str, co: int, ci: int, need_dx: bool = True) -> Tensor | None:
+        M = dy.shape[0]
+        Mp = _rup(M, 64)
+        ops.colsum(dy, self.Gr(name[:-6] + "bias"), M, co)
+        dyp, xp = self._padded(dy, Mp, dy.shape[1]), self._padded(x, Mp, x.shape[1])
+        ops.gemm_tn(dyp, xp, self.Gr(name).view(co, ci), M=co, N=ci)
+        if not need_dx:
+            return None
+        K = _rup(co, 64)
+        dyk = self._padded(dy, M, K)
+        dx = self._new(M, ci)
+        ops.gemm_nt(dyk, self.sh[name + "|t"], dx, M=M, N=ci, K=K)
+        return dx
+
+    def _gn(self, x: Tensor, B: int, HW: int, C: int, wname: str, film=None, silu: bool = True, stats: Tensor | None = None):
+        if stats is None:
+            stats = self._new(B, self.G, 2, dtype=torch.float32)
+            ops.gn_stats(x, stats, B, HW, C, self.G)
+        out = self._new(B * HW, C)
+        fs, fh = film if film is not None else (None, None)
+        ops.gn_apply_fwd(x, stats, self.P(wname + "weight"), self.P(wname + "bias"), fs, fh, silu, out, B, HW, C, self.G)
+        return out, stats
+
+    def _gn_bwd(self, dout: Tensor, x: Tensor, stats: Tensor, B: int, HW: int, C: int, wname: str, film=None, dfilm=None,
+                silu: bool = True, dres: Tensor | None = None) -> Tensor:
+        dx = self._new(B * HW, C)
+        fs, fh = film if film is not None else (None, None)
+        dfs, dfh = dfilm if dfilm is not None else (None, None)
+        scr = self._scr("gn", B * 4 * C + B * self.G * 2, torch.float32)
+        ops.gn_bwd(dout, x, stats, self.P(wname + "weight"), self.P(wname + "bias"), fs, fh, silu, dres, dx,
+                   self.Gr(wname + "weight"), self.Gr(wname + "bias"), dfs, dfh, scr, B, HW, C, self.G)
+        return dx
+
+    def _add(self, a: Tensor | None, b: Tensor | None) -> Tensor | None:
+        if a is None:
+            return b
+        if b is None:
+            return a
+        out = self._new(*a.shape)
+        ops.add_bf16(a, b, out)
+        return out
+
+    # ------------------------------------------------------------------ blocks
+    def _res_fwd(self, b: _Blk, x: Tensor, B: int, H: int, W: int, eo: Tensor, save: list | None):
+        p = b.prefix
+        h, st1 = self._gn(x, B, H * W, b.cin, p + "in_layers.0.")
+        H2, W2, x2 = H, W, x
+        if b.up or b.down:
+            H2, W2 = (2 * H, 2 * W) if b.up else (H // 2, W // 2)
+            hp, x2 = self._new(B * H2 * W2, b.cin), self._new(B * H2 * W2, b.cin)
+            if b.up:
+                ops.expand2x2(h, hp, B, H, W, b.cin, 1.0)
+                ops.expand2x2(x, x2, B, H, W, b.cin, 1.0)
+            else:
+                ops.reduce2x2(h, hp, B, H2, W2, b.cin, 0.25)
+                ops.reduce2x2(x, x2, B, H2, W2, b.cin, 0.25)
+            h = hp
+        h2 = self._conv3(h, B, H2, W2, b.cin, p + "in_layers.2.weight", b.cout)
+        film = (eo[:, b.emb_off : b.emb_off + b.cout], eo[:, b.emb_off + b.cout : b.emb_off + 2 * b.cout])
+        h3, st2 = self._gn(h2, B, H2 * W2, b.cout, p + "out_layers.0.", film=film)
+        skip = x2 if b.cin == b.cout else self._lin_fwd(x2, p + "skip_connection.weight", b.cout, b.cin)
+        out = self._conv3(h3, B, H2, W2, b.cout, p + "out_layers.3.weight", b.cout, resid=skip)  # x + h fused (unet.py:237)
+        if save is not None:
+            save.append((x, st1, h, h2, st2, h3, x2, H, W, H2, W2))
+        return out, H2, W2
+
+    def _res_bwd(self, b: _Blk, dout: Tensor, B: int, saved, eo: Tensor, deo: Tensor) -> Tensor:
+        p = b.prefix
+        x, st1, h, h2, st2, h3, x2, H, W, H2, W2 = saved
+        dh3 = self._conv3_bwd(dout, h3, B, H2, W2, b.cout, p + "out_layers.3.weight", b.cout)
+        dx2 = dout if b.cin == b.cout else self._lin_bwd(dout, x2, p + "skip_connection.weight", b.cout, b.cin)
+        o = b.emb_off
+        film = (eo[:, o : o + b.cout], eo[:, o + b.cout : o + 2 * b.cout])
+        dfilm = (deo[:, o : o + b.cout], deo[:, o + b.cout : o + 2 * b.cout])
+        dh2 = self._gn_bwd(dh3, h2, st2, B, H2 * W2, b.cout, p + "out_layers.0.", film=film, dfilm=dfilm)
+        dh = self._conv3_bwd(dh2, h, B, H2, W2, b.cin, p + "in_layers.2.weight", b.cout)
+        if b.up or b.down:
+            dhp, dxs = self._new(B * H * W, b.cin), self._new(B * H * W, b.cin)
+            if b.up:  # backward of nearest upsample: sum of the 2x2 window
+                ops.reduce2x2(dh, dhp, B, H, W, b.cin, 1.0)
+                ops.reduce2x2(dx2, dxs, B, H, W, b.cin, 1.0)
+            else:  # backward of avg-pool: broadcast / 4
+                ops.expand2x2(dh, dhp, B, H2, W2, b.cin, 0.25)
+                ops.expand2x2(dx2, dxs, B, H2, W2, b.cin, 0.25)
+            dh, dx2 = dhp, dxs
+        return self._gn_bwd(dh, x, st1, B, H * W, b.cin, p + "in_layers.0.", dres=dx2)
+
+    def _attn_fwd(self, b: _Blk, x: Tensor, B: int, H: int, W: int, save: list | None) -> Tensor:
+        p, c, n = b.prefix, b.cin, H * W
+        nh = self.d.num_heads
+        nx, st = self._gn(x, B, n, c, p + "norm_x.", silu=False)
+        nc, _ = self._gn(x, B, n, c, p + "norm_context.", silu=False, stats=st)  # context = x: same statistics
+        q = self._lin_fwd(nx, p + "to_q.weight", c, c)
+        kv = self._lin_fwd(nc, p + "to_kv.weight", 2 * c, c)
+        att = self._new(B * n, c)
+        probs = self._new(B, nh, n, n, dtype=torch.float32)
+        ops.attn_small_fwd(q, kv[:, :c], kv[:, c:], att, probs, B, n, nh, c // nh)
+        out = self._lin_fwd(att, p + "to_out.0.weight", c, c, resid=x)
+        if save is not None:
+            save.append((x, st, nx, nc, q, kv, att, probs, H, W))
+        return out
+
+    def _attn_bwd(self, b: _Blk, dout: Tensor, B: int, saved) -> Tensor:
+        p, c = b.prefix, b.cin
+        nh = self.d.num_heads
+        x, st, nx, nc, q, kv, att, probs, H, W = saved
+        n = H * W
+        datt = self._lin_bwd(dout, att, p + "to_out.0.weight", c, c)
+        dq, dkv = self._new(B * n, c), self._new(B * n, 2 * c)
+        ops.attn_small_bwd(q, kv[:, :c], kv[:, c:], datt, probs, dq, dkv[:, :c], dkv[:, c:], B, n, nh, c // nh)
+        dnx = self._lin_bwd(dq, nx, p + "to_q.weight", c, c)
+        dnc = self._lin_bwd(dkv, nc, p + "to_kv.weight", 2 * c, c)
+        dx = self._gn_bwd(dnx, x, st, B, n, c, p + "norm_x.", silu=False, dres=dout)
+        return self._gn_bwd(dnc, x, st, B, n, c, p + "norm_context.", silu=False, dres=dx)
+
+    def _group_fwd(self, blocks: list[_Blk], h: Tensor, B: int, H: int, W: int, eo: Tensor, save: list | None):
+        for b in blocks:
+            if b.kind == "conv":
+                if save is not None:
+                    save.append((h, H, W))
+                h = self._conv3(h, B, H, W, b.cin, b.prefix + "weight", b.cout)
+            elif b.kind == "res":
+                h, H, W = self._res_fwd(b, h, B, H, W, eo, save)
+            else:
+                h = self._attn_fwd(b, h, B, H, W, save)
+        return h, H, W
+
+    def _group_bwd(self, blocks: list[_Blk], dh: Tensor, B: int, save: list, eo: Tensor, deo: Tensor) -> Tensor | None:
+        for b in blocks[::-1]:
+            s = save.pop()
+            if b.kind == "conv":
+                x, H, W = s
+                return self._conv3_bwd(dh, x, B, H, W, b.cin, b.prefix + "weight", b.cout, need_dx=False)
+            dh = self._res_bwd(b, dh, B, s, eo, deo) if b.kind == "res" else self._attn_bwd(b, dh, B, s)
+        return dh
+
+    # ------------------------------------------------------------------ forward (unet.py:832-853)
+    def forward(self, x: Tensor, t: Tensor, y_eff: Tensor | None, train: bool) -> Tensor:
+        """x f32 [B, in_channels, H, W], t f32 [B], y_eff int64 [B] or None -> prediction f32 [B, out_channels, H, W]"""
+        d, plan = self.d, self.plan
+        B, Cin, H, W = x.shape
+        assert (H, W) == tuple(d.image_size) and Cin == d.in_channels
+        self.refresh_shadows(force=train)
+        mc, te = d.model_channels, 4 * d.model_channels
+        Bp = _rup(B, 64)
+        save: list | None = [] if train else None
+
+        # conditioning: emb = time_embed(timestep_embedding(t)) + label_embed(y) ; every ResBlock consumes silu(emb)
+        temb = self._new(Bp, _rup(mc, 64), zero=True)
+        if mc % 64 == 0:
+            ops.timestep_embedding(t, temb[:B])
+        else:  # computed dense, then copied into the zero-padded GEMM operand
+            dense = self._new(B, mc)
+            ops.timestep_embedding(t, dense)
+            ops.copy2d_bf16(dense, temb, B, mc)
+        pre1, h1 = self._new(Bp, te, zero=True), self._new(Bp, te, zero=True)
+        ops.gemm_nt(temb, self.sh["time_embed.0.weight|f"], h1, bias=self.P("time_embed.0.bias"), act=ops.ACT_SILU, pre_out=pre1,
+                    M=B, N=te, K=_rup(mc, 64))
+        e = self._new(B, te, dtype=torch.float32)
+        ops.gemm_nt(h1, self.sh["time_embed.2.weight|f"], e, bias=self.P("time_embed.2.bias"), M=B, N=te, K=_rup(te, 64))
+        table = self.P("label_embed.embedding.weight") if d.n_classes is not None else None
+        emb = self._new(B, te, dtype=torch.float32)
+        se = self._new(Bp, te, zero=True)
+        ops.cond_combine_fwd(e, table, y_eff if table is not None else None, emb, se[:B])
+        R = self.layout.emb_rows
+        off = self.layout.entries[self.layout.emb_b0][0]
+        eo = self._new(B, R)
+        ops.gemm_nt(se, self.sh["@emb|f"], eo, bias=self.params[off : off + R], M=B, N=R, K=_rup(te, 64))
+
+        h = self._new(B * H * W, Cin)
+        ops.nchw_to_nhwc(x, h, B, Cin, H * W)
+        hs: list[tuple[Tensor, int]] = []
+        for grp in plan.input_blocks:
+            h, H, W = self._group_fwd(grp, h, B, H, W, eo, save)
+            hs.append((h, grp[-1].cout))
+        h, H, W = self._group_fwd(plan.middle, h, B, H, W, eo, save)
+        ch = plan.middle[-1].cout
+        for grp in plan.output_blocks:
+            skip, ich = hs.pop()
+            cat = self._new(B * H * W, ch + ich)  # torch.cat([h, hs.pop()], dim=1)
+            ops.copy2d_bf16(h, cat[:, :ch], B * H * W, ch)
+            ops.copy2d_bf16(skip, cat[:, ch:], B * H * W, ich)
+            h, H, W = self._group_fwd(grp, cat, B, H, W, eo, save)
+            ch = grp[-1].cout
+        hf, stf = self._gn(h, B, H * W, ch, "out.0.")
+        o = self._conv3(hf, B, H, W, ch, "out.2.weight", d.out_channels)
+        pred = self._new(B, d.out_channels, H, W, dtype=torch.float32)
+        ops.nhwc_to_nchw(o, pred, B, d.out_channels, H * W)
+        if train:
+            self._saved = dict(B=B, H=H, W=W, save=save, temb=temb, pre1=pre1, h1=h1, emb=emb, se=se, eo=eo, y=y_eff, h=h,
+                               stf=stf, hf=hf)
+        return pred
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dpred: Tensor) -> None:
+        """dpred f32 [B, out_channels, H, W]; accumulates every parameter gradient into the gradient arena"""
+        s, d, plan = self._saved, self.d, self.plan
+        assert s is not None, "backward without a train-mode forward"
+        self._saved = None
+        B, H, W, save, eo = s["B"], s["H"], s["W"], s["save"], s["eo"]
+        mc, te = d.model_channels, 4 * d.model_channels
+        Bp = _rup(B, 64)
+        R = self.layout.emb_rows
+        deo = self._new(Bp, R, zero=True)
+        co8 = _rup(d.out_channels, 8)
+        do = self._new(B * H * W, co8, zero=True)
+        ops.nchw_to_nhwc(dpred, do, B, d.out_channels, H * W)
+        ch0 = plan.final_ch
+        dhf = self._conv3_bwd(do, s["hf"], B, H, W, ch0, "out.2.weight", d.out_channels)
+        dh = self._gn_bwd(dhf, s["h"], s["stf"], B, H * W, ch0, "out.0.")
+        dskips: list[Tensor] = []
+        for grp in plan.output_blocks[::-1]:
+            dcat = self._group_bwd(grp, dh, B, save, eo, deo)
+            ctot = grp[0].cin
+            M = dcat.shape[0]
+            # channel split of the concat: [h | skip]; the skip width is what the matching input block produced
+            ich = self._skip_widths[len(dskips)]
+            ch = ctot - ich
+            dh, dsk = self._new(M, ch), self._new(M, ich)
+            ops.copy2d_bf16(dcat[:, :ch], dh, M, ch)
+            ops.copy2d_bf16(dcat[:, ch:], dsk, M, ich)
+            dskips.append(dsk)
+        dh = self._group_bwd(plan.middle, dh, B, save, eo, deo)
+        for grp in plan.input_blocks[::-1]:
+            dh = self._add(dh, dskips.pop())
+            dh = self._group_bwd(grp, dh, B, save, eo, deo)
+        assert not save and not dskips
+
+        # FiLM projections (one stacked GEMM pair), then the conditioning MLP
+        w0, b0 = self.layout.entries[self.layout.emb_w0][0], self.layout.entries[self.layout.emb_b0][0]
+        ops.gemm_tn(deo, s["se"], self.grads[w0 : w0 + R * te].view(R, te))
+        ops.colsum(deo, self.grads[b0 : b0 + R], B, R)
+        dse = self._new(B, te, dtype=torch.float32)
+        ops.gemm_nt(deo, self.sh["@emb|t"], dse, M=B, N=te, K=_rup(R, 64))
+        table = d.n_classes is not None
+        demb, demb16 = self._new(B, te, dtype=torch.float32), self._new(Bp, te, zero=True)
+        ops.cond_combine_bwd(dse, s["emb"], s["y"] if table else None, demb, demb16[:B],
+                             self.Gr("label_embed.embedding.weight") if table else None)
+        ops.colsum(demb, self.Gr("time_embed.2.bias"), B, te)
+        ops.gemm_tn(demb16, s["h1"], self.Gr("time_embed.2.weight"))
+        dh1 = self._new(B, te, dtype=torch.float32)
+        ops.gemm_nt(demb16, self.sh["time_embed.2.weight|t"], dh1, M=B, N=te, K=_rup(te, 64))
+        dpre1 = self._new(Bp, te, zero=True)
+        ops.silu_bwd(dh1, s["pre1"][:B], dpre1[:B])
+        ops.gemm_tn(dpre1, s["temb"], self.Gr("time_embed.0.weight"), M=te, N=mc)
+        ops.colsum(dpre1, self.Gr("time_embed.0.bias"), B, te)
+        if self.reducer is not None:
+            self.reducer.ready(0, self.layout.size)
+            self.reducer.finish()
+
+    @property
+    def _skip_widths(self) -> list[int]:
+        """skip widths in the order the output blocks' BACKWARD meets them (last output block first)"""
+        w = [grp[-1].cout for grp in self.plan.input_blocks]  # hs in push order; output block k pops hs[-1-k]
+        return w  # backward visits output blocks in reverse: block n-1 popped hs[0], ...

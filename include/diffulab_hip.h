@@ -209,6 +209,62 @@ DL_API int dl_cast_bf16_to_f32(const void* src, float* dst, int64_t n, dl_stream
 /* ema = ema + (1 - beta) (p - ema)  == lerp used by ema_pytorch (base_trainer.py:152-153) */
 DL_API int dl_ema_update(float* ema, const float* p, float beta, int64_t n, dl_stream_t stream);
 
+/* ------------------------------------------------------------------ UNet (networks/denoisers/unet.py, networks/utils/nn.py)
+ * Activations inside the library are NHWC bf16 token rows [B*H*W, C]; a 3x3 convolution (nn.Conv2d padding=1, unet.py:187,
+ * 208,594,745) is dl_im2col3x3 + dl_gemm_nt against the reordered weight shadow; 1x1 / Conv1d(k=1) are plain dl_gemm_nt. */
+/* reference boundary tensors are NCHW f32 (unet.py:832): x [B,C,HW] -> out bf16 [B*HW, ld] (columns >= C untouched) */
+DL_API int dl_nchw_to_nhwc(const float* x, void* out, int64_t B, int64_t C, int64_t HW, int64_t ld, dl_stream_t stream);
+/* x bf16 [B*HW, ld] (first C columns) -> out f32 [B,C,HW] */
+DL_API int dl_nhwc_to_nchw(const void* x, float* out, int64_t B, int64_t C, int64_t HW, int64_t ld, dl_stream_t stream);
+/* GroupNorm32 statistics (nn.py:11-13: fp32, per sample and group over C/G channels x HW): stats f32 [B, G, 2] = mean, rstd */
+DL_API int dl_gn_stats(const void* x, float* stats, int64_t B, int64_t HW, int64_t C, int64_t G, float eps,
+                       dl_stream_t stream);
+/* out = act( (xhat*w + b) * (1 + film_scale[b,c]) + film_shift[b,c] ) ; film_* bf16 [B, ld_film] or NULL (unet.py:215-237:
+ * in_layers GN+SiLU has no FiLM, out_layers GN * (1+scale) + shift then SiLU); act_silu = 0 gives the plain GroupNorm of
+ * AttentionBlock.norm_x / norm_context (unet.py:296-322) */
+DL_API int dl_gn_apply_fwd(const void* x, const float* stats, const float* w, const float* b, const void* film_scale,
+                           const void* film_shift, int64_t ld_film, int act_silu, void* out, int64_t B, int64_t HW,
+                           int64_t C, int64_t G, dl_stream_t stream);
+/* backward of dl_gn_stats + dl_gn_apply_fwd: dx bf16 (= gradient through the norm + dres when dres != NULL: the residual /
+ * skip fan-in of ResBlock and AttentionBlock), dw/db f32 [C] ACCUMULATED (+=), dfilm_* bf16 [B, ld_dfilm] written
+ * (required iff film_* given).  scratch: f32 [B*4*C + B*G*2] */
+DL_API int dl_gn_bwd(const void* dout, const void* x, const float* stats, const float* w, const float* b,
+                     const void* film_scale, const void* film_shift, int64_t ld_film, int act_silu, const void* dres,
+                     void* dx, float* dw, float* db, void* dfilm_scale, void* dfilm_shift, int64_t ld_dfilm, float* scratch, int64_t B,
+                     int64_t HW, int64_t C, int64_t G, dl_stream_t stream);
+/* x bf16 [B*H*W, ldx]; cols bf16 [rows, ld]: cols[r, (ky*3+kx)*C + c] = x[b, y+ky-1, x+kx-1, c] (zero outside the image); rows >= B*H*W and
+ * columns >= 9*C are zero-filled so the buffer can be handed to the 64-aligned GEMMs as is */
+DL_API int dl_im2col3x3(const void* x, int64_t ldx, void* cols, int64_t B, int64_t H, int64_t W, int64_t C, int64_t rows,
+                        int64_t ld, dl_stream_t stream);
+/* Conv2d weight f32 [Co, Ci, 3, 3] -> forward shadow wf bf16 [Co, ldf] (k = tap*Ci + ci) and data-gradient shadow wd bf16
+ * [Ci, ldd] (k = tap*Co + co, kernel rotated by 180 degrees) */
+DL_API int dl_cast_conv3x3_weight(const float* w, int64_t Co, int64_t Ci, void* wf, int64_t ldf, void* wd, int64_t ldd,
+                                  dl_stream_t stream);
+/* weight gradient from dl_gemm_tn lands as g f32 [Co, ldg] in (tap, ci) order: dw[Co, Ci, 3, 3] += g */
+DL_API int dl_conv3x3_wgrad_fold(const float* g, int64_t ldg, float* dw, int64_t Co, int64_t Ci, dl_stream_t stream);
+/* out[b, yo, xo, c] = scale * sum of the 2x2 window of x [B, 2Ho, 2Wo, C]: avg_pool2d forward (scale 0.25, nn.py:86) and
+ * nearest-upsample backward (scale 1) */
+DL_API int dl_reduce2x2(const void* x, void* out, int64_t B, int64_t Ho, int64_t Wo, int64_t C, float scale,
+                        dl_stream_t stream);
+/* out[b, y, x, c] = scale * x[b, y/2, x/2, c] for out [B, 2Hi, 2Wi, C]: nearest upsample forward (scale 1, nn.py:50) and
+ * avg_pool2d backward (scale 0.25) */
+DL_API int dl_expand2x2(const void* x, void* out, int64_t B, int64_t Hi, int64_t Wi, int64_t C, float scale,
+                        dl_stream_t stream);
+/* AttentionBlock core (unet.py:311-318: heads split the channel dim as (h d), scale = dh^-0.5): q/k/v/out are token rows
+ * with head h at columns [h*dh, (h+1)*dh); n <= 64 tokens, dh % 8 == 0; probs f32 [B, H, n, n] is kept for the backward */
+DL_API int dl_attn_small_fwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldkv, void* out,
+                             int64_t ldo, float* probs, int64_t B, int64_t n, int64_t H, int64_t dh, float scale,
+                             dl_stream_t stream);
+DL_API int dl_attn_small_bwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldkv, const void* dout,
+                             int64_t ldo, const float* probs, void* dq, void* dk, void* dv, int64_t B, int64_t n,
+                             int64_t H, int64_t dh, float scale, dl_stream_t stream);
+/* out = a + b (bf16): gradient fan-in of the UNet skip connections (unet.py:846-851: hs.append / torch.cat) */
+DL_API int dl_add_bf16(const void* a, const void* b, void* out, int64_t n, dl_stream_t stream);
+/* dst[r, c] = src[r, c] for a [rows, cols] window of two pitched bf16 matrices: channel concat / split of the skip
+ * connections (torch.cat(dim=1) in NCHW == column blocks in NHWC) and zero-padding to the GEMM alignment */
+DL_API int dl_copy2d_bf16(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols,
+                          dl_stream_t stream);
+
 /* ------------------------------------------------------------------ debugging probes (tests only) */
 /* raw ds_read_b64_tr_b16 lane map: fills out[64*4] with what each lane receives when lane l passes
  * address 8*l over an LDS image holding the uint16 values 0..255 */

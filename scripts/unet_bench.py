@@ -1,0 +1,56 @@
+"""Training-step time of the MNIST-DDPM UNet (configs/train_mnist_ddpm.yaml: UNet 32x32x1, mc=128, B=128) on one MI355X.
+Not the headline benchmark (bench.py is DiT-S/2); a secondary number for the UNet row of SURVEY.md §8."""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from diffulab_amd import Diffuser
+from diffulab_amd.networks.denoisers import UNetModel
+from diffulab_amd.training.optim import FusedAdamW
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    a = ap.parse_args()
+    dev = "cuda"
+    torch.manual_seed(0)
+    m = UNetModel(image_size=[32, 32], in_channels=1, model_channels=128, out_channels=1, num_res_blocks=2,
+                  attention_resolutions=[4, 8, 16], num_heads=2, resblock_updown=True, n_classes=10,
+                  use_scale_shift_norm=True, classifier_free=False).to(dev)
+    gd = Diffuser(m, sampling_method="ddpm", model_type="gaussian_diffusion", n_steps=1000)
+    opt = FusedAdamW(m.parameters(), lr=1e-4)
+    x0 = torch.randn(a.batch, 1, 32, 32, device=dev)
+    y = torch.randint(0, 10, (a.batch,), device=dev)
+
+    def step():
+        opt.zero_grad()
+        loss = gd.compute_loss({"x": x0, "y": y, "p": 0.0}, timesteps=gd.draw_timesteps(a.batch))["loss"]
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    print(json.dumps({"workload": "unet-mnist-ddpm train step", "batch": a.batch, "ms_per_step": dt * 1e3,
+                      "images_per_s": a.batch / dt, "params_M": sum(p.numel() for p in m.parameters()) / 1e6,
+                      "loss": float(loss)}))
+
+
+if __name__ == "__main__":
+    main()
