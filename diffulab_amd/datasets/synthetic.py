@@ -1,0 +1,28 @@
+"""In-memory synthetic dataset with the item format of the reference datasets (datasets/base.py:50-75:
+``{"model_inputs": {"x": image, "y": label}}``).  There is no network on the build / GPU boxes, so MNIST / CIFAR / ImageNet
+latents are replaced by seeded N(0,1) tensors of the same shape (``torch.Generator().manual_seed(1234)``)."""
+
+from __future__ import annotations
+
+import torch
+from torch.utils.data import Dataset
+
+from .base import BatchData
+
+
+class SyntheticDataset(Dataset):
+    def __init__(self, n_samples: int = 1024, shape: tuple[int, ...] | list[int] = (1, 32, 32), n_classes: int | None = 10,
+                 seed: int = 1234) -> None:
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.images = torch.randn(n_samples, *shape, generator=g).clamp_(-3, 3) / 3  # in [-1, 1] like normalised images
+        self.labels = torch.randint(0, n_classes, (n_samples,), generator=g) if n_classes is not None else None
+
+    def __len__(self) -> int:
+        return self.images.shape[0]
+
+    def __getitem__(self, idx: int) -> BatchData:
+        inputs = {"x": self.images[idx]}
+        if self.labels is not None:
+            inputs["y"] = self.labels[idx]
+        return {"model_inputs": inputs}

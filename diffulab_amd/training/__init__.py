@@ -1,4 +1,6 @@
+from .ema import EMA
 from .optim import FusedAdamW
+from .trainers import BaseTrainer, Trainer
 from .utils import AverageMeter
 
-__all__ = ["FusedAdamW", "AverageMeter"]
+__all__ = ["FusedAdamW", "AverageMeter", "EMA", "BaseTrainer", "Trainer"]

@@ -1,0 +1,155 @@
+"""``BaseTrainer``: the training loop of the reference (training/trainers/base_trainer.py:104-399) on the MI355X runtime.
+
+``training_step`` keeps the reference's order of operations (base_trainer.py:138-153): zero_grad -> draw timesteps (CPU generator)
+-> compute_loss -> ``.item()`` of every loss into the tracker -> backward -> optimizer.step -> scheduler -> EMA update.
+Differences are confined to what Accelerate did implicitly (see trainers/common.py): loss / gradient_accumulation_step before
+backward, optimizer / scheduler / EMA only on the synchronising micro-step, gradient all-reduce overlapped with backward.
+"""
+
+from __future__ import annotations
+
+import logging
+from typing import TYPE_CHECKING, Iterable
+
+import torch
+from torch.optim.lr_scheduler import LRScheduler
+from torch.optim.optimizer import Optimizer
+
+from ...datasets.base import BatchData
+from ..ema import EMA
+from ..utils import AverageMeter
+from .common import Trainer
+
+if TYPE_CHECKING:
+    from ...diffuse import Diffuser
+
+
+class BaseTrainer(Trainer):
+    def training_step(
+        self,
+        diffuser: "Diffuser",
+        optimizer: Optimizer,
+        batch: BatchData,
+        tracker: AverageMeter,
+        p_classifier_free_guidance: float = 0,
+        scheduler: LRScheduler | None = None,
+        per_batch_scheduler: bool = False,
+        ema_denoiser: EMA | None = None,
+    ) -> None:
+        first_micro = self._micro % self.gradient_accumulation_step == 0
+        self.begin_micro_step()
+        if first_micro:  # accelerate turns optimizer.zero_grad() into a no-op on non-synchronising micro-steps
+            optimizer.zero_grad()
+        batch = self.shard_batch(batch)
+        model_inputs = self.move_dict_to_device(dict(batch["model_inputs"]))
+        timesteps = diffuser.draw_timesteps(model_inputs["x"].shape[0]).to(self.device)
+        model_inputs.update({"p": p_classifier_free_guidance})
+        extra = self.move_dict_to_device(dict(batch.get("extra", {})))
+        losses = diffuser.compute_loss(model_inputs=model_inputs, timesteps=timesteps, extra_args=extra)
+        for key, loss in losses.items():
+            tracker.update(loss.item(), key=f"train/{key}")
+        loss = sum(losses.values())
+        (loss / self.gradient_accumulation_step).backward()
+        if self.sync_gradients:
+            optimizer.step()
+            if scheduler is not None and per_batch_scheduler:
+                scheduler.step()
+        if ema_denoiser is not None:
+            ema_denoiser.update()  # counts micro-steps: update_after_step / update_every were scaled in __init__ (common.py:97-98)
+        self.end_micro_step()
+
+    @torch.no_grad()
+    def validation_step(self, diffuser: "Diffuser", val_batch: BatchData, tracker: AverageMeter) -> None:
+        val_batch = self.shard_batch(val_batch)
+        model_inputs = self.move_dict_to_device(dict(val_batch["model_inputs"]))
+        timesteps = diffuser.draw_timesteps(model_inputs["x"].shape[0]).to(self.device)
+        extra_args = self.move_dict_to_device(dict(val_batch.get("extra", {})))
+        val_losses = diffuser.compute_loss(model_inputs=model_inputs, timesteps=timesteps, extra_args=extra_args)
+        for key, val_loss in val_losses.items():
+            tracker.update(val_loss.item(), key=f"val/{key}")
+
+    def train(
+        self,
+        diffuser: "Diffuser",
+        optimizer: Optimizer,
+        train_dataloader: Iterable[BatchData],
+        val_dataloader: Iterable[BatchData] | None = None,
+        scheduler: LRScheduler | None = None,
+        per_batch_scheduler: bool = False,
+        log_validation_images: bool = True,
+        train_embedder: bool = False,
+        p_classifier_free_guidance: float = 0.2,
+        val_steps: int = 50,
+        val_step_shift: float | None = None,
+        optimizer_ckpt: str | None = None,
+        denoiser_ckpt: str | None = None,
+        ema_ckpt: str | None = None,
+        epoch_start: int = 0,
+    ) -> None:
+        if val_step_shift is not None:
+            assert diffuser.model_type == "rectified_flow", "Time-shifting during validation is only supported for flow-based models."
+        if not diffuser.denoiser.classifier_free:
+            p_classifier_free_guidance = 0
+        if denoiser_ckpt:
+            diffuser.denoiser.load_state_dict(torch.load(denoiser_ckpt))
+        if optimizer_ckpt:
+            optimizer.load_state_dict(torch.load(optimizer_ckpt, weights_only=False))
+        self.prepare(diffuser, optimizer)
+        if self.use_ema:
+            ema_denoiser = EMA(diffuser.denoiser, beta=self.ema_rate, update_after_step=self.ema_update_after_step,
+                               update_every=self.ema_update_every).to(self.device)
+            if ema_ckpt:
+                ema_denoiser.ema_model.load_state_dict(torch.load(ema_ckpt, weights_only=True))
+        else:
+            ema_denoiser = None
+        for loss in diffuser.extra_losses:
+            loss.set_model(diffuser.denoiser)
+        if getattr(diffuser.denoiser, "context_embedder", None) is not None and not train_embedder:
+            for param in diffuser.denoiser.context_embedder.parameters():
+                param.requires_grad = False
+
+        best_val_loss = float("inf")
+        tracker = AverageMeter()
+        logging.info("Begin training")
+        for epoch in range(epoch_start, self.n_epoch):
+            diffuser.train()
+            for batch in train_dataloader:
+                self.training_step(diffuser=diffuser, optimizer=optimizer, batch=batch, tracker=tracker,
+                                   p_classifier_free_guidance=p_classifier_free_guidance, scheduler=scheduler,
+                                   per_batch_scheduler=per_batch_scheduler, ema_denoiser=ema_denoiser)
+            if scheduler is not None and not per_batch_scheduler:
+                scheduler.step()
+            for key, value in tracker.avg.items():
+                if key.startswith("train/"):
+                    self.log({key: self.gather_mean(value)}, step=epoch + 1)
+            tracker.reset()
+
+            if val_dataloader is not None:
+                diffuser.eval()
+                original_model = diffuser.denoiser
+                if ema_denoiser is not None:
+                    diffuser.denoiser = ema_denoiser.ema_model.eval()
+                    for loss in diffuser.extra_losses:
+                        loss.set_model(ema_denoiser.ema_model)
+                for val_batch in val_dataloader:
+                    self.validation_step(diffuser=diffuser, val_batch=val_batch, tracker=tracker)
+                total_loss = 0.0
+                for key, value in tracker.avg.items():
+                    if key.startswith("val/"):
+                        g = self.gather_mean(value)
+                        self.log({key: g}, step=epoch + 1)
+                        total_loss += g
+                if log_validation_images and self.is_main_process:
+                    logging.info("creating validation images")
+                    self.log_images(diffuser, val_dataloader, epoch, val_steps, step_shift=val_step_shift,
+                                    guidance_scale=4 if original_model.classifier_free else 0)
+                if ema_denoiser is not None:
+                    diffuser.denoiser = original_model
+                    for loss in diffuser.extra_losses:
+                        loss.set_model(original_model)
+                if total_loss < best_val_loss:
+                    best_val_loss = total_loss
+                    self.save_model(optimizer, diffuser, ema_denoiser, scheduler)
+                tracker.reset()
+            self.wait_for_everyone()
+        logging.info("Training complete")

@@ -1,0 +1,194 @@
+"""Trainer base: process group, device placement, gradient accumulation, checkpoints and logging.
+
+Mirrors ``training/trainers/common.py:25-271`` of the reference (same constructor kwargs, ``move_dict_to_device``,
+``save_model`` file names, ``log_images``), with HuggingFace Accelerate replaced by the MI355X-native runtime:
+  * one process per GPU, ``torch.distributed`` over RCCL (backend "nccl") when WORLD_SIZE > 1 -- launched by
+    ``python -m torch.distributed.run`` exactly like ``accelerate launch`` would;
+  * the DDP wrap of ``accelerator.prepare`` becomes ``training.dp.GradReducer`` on the flat gradient arena (bucketed in-place
+    all-reduce on a side stream, 1/world folded into the fused AdamW), parameters broadcast from rank 0 at start;
+  * ``split_batches=True`` semantics (common.py:104): the DataLoader batch is the GLOBAL batch, each rank takes its contiguous slice;
+  * ``accelerator.accumulate`` semantics: the loss is divided by ``gradient_accumulation_step``, gradients are reduced and the
+    optimizer / scheduler / EMA advance only on the last micro-step;
+  * mixed precision: the HIP path always computes in bf16 MFMA with f32 accumulation and f32 master weights, so
+    ``precision_type`` in {"no", "bf16"} is accepted for config compatibility and changes nothing; "fp16" is refused;
+  * ``compile`` / ``dynamo_plugin_kwargs`` are accepted and ignored (no tracing compiler: the launch sequences are static);
+  * wandb (absent, no network) is replaced by a JSON-lines log under ``save_path/metrics.jsonl``.
+"""
+
+from __future__ import annotations
+
+import json
+import os
+from abc import ABC, abstractmethod
+from datetime import datetime
+from pathlib import Path
+from typing import TYPE_CHECKING, Any, Iterable
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+from torch.optim.lr_scheduler import LRScheduler
+from torch.optim.optimizer import Optimizer
+
+from ...datasets.base import BatchData
+from ..dp import GradReducer, broadcast_arena
+from ..ema import EMA
+
+if TYPE_CHECKING:
+    from ...diffuse import Diffuser
+
+
+class Trainer(ABC):
+    def __init__(
+        self,
+        n_epoch: int,
+        gradient_accumulation_step: int = 1,
+        precision_type: str = "no",
+        save_path: str | Path = Path.home() / "experiments" / f"{datetime.now().strftime('%Y%m%d_%H%M%S')}",
+        project_name: str = "my_project",
+        run_config: dict[str, Any] | None = None,
+        init_kwargs: dict[str, Any] = {},
+        use_ema: bool = False,
+        ema_rate: float = 0.999,
+        ema_update_after_step: int = 0,
+        ema_update_every: int = 10,
+        compile: bool = False,
+        dynamo_plugin_kwargs: dict[str, Any] = {},
+    ) -> None:
+        if precision_type not in ("no", "bf16"):
+            raise NotImplementedError(f"precision_type={precision_type!r}: the HIP path computes in bf16 with f32 accumulation")
+        self.n_epoch = n_epoch
+        self.use_ema = use_ema
+        self.ema_rate = ema_rate
+        self.gradient_accumulation_step = max(1, int(gradient_accumulation_step))
+        self.ema_update_after_step = ema_update_after_step * self.gradient_accumulation_step
+        self.ema_update_every = ema_update_every * self.gradient_accumulation_step
+        self.compile = compile
+
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+            self.device = torch.device("cuda", local)
+        else:  # host-logic tests only: every denoiser forward raises without a GPU
+            self.device = torch.device("cpu")
+        if self.world > 1 and not dist.is_initialized():
+            dist.init_process_group(backend="nccl" if self.device.type == "cuda" else "gloo")
+        self.is_main_process = self.rank == 0
+
+        self.save_path = Path(save_path) / project_name
+        if self.is_main_process:
+            self.save_path.mkdir(parents=True, exist_ok=True)
+            if run_config is not None:
+                (self.save_path / "run_config.json").write_text(json.dumps(run_config, indent=1, default=str))
+        self._micro = 0
+        self._reducer: GradReducer | None = None
+
+    # ------------------------------------------------------------------ accelerate-equivalent plumbing
+    def move_dict_to_device(self, batch: dict[str, Any]) -> dict[str, Any]:
+        return {k: v.to(self.device) if isinstance(v, Tensor) else v for k, v in batch.items()}
+
+    def shard_batch(self, batch: dict[str, Any]) -> dict[str, Any]:
+        """split_batches=True (common.py:104): rank r keeps rows [r*B/W, (r+1)*B/W) of every tensor / list entry"""
+        if self.world == 1:
+            return batch
+        out: dict[str, Any] = {}
+        for k, v in batch.items():
+            if isinstance(v, dict):
+                out[k] = self.shard_batch(v)
+            elif isinstance(v, (Tensor, list)) and len(v) % self.world == 0 and len(v) > 0:
+                n = len(v) // self.world
+                out[k] = v[self.rank * n : (self.rank + 1) * n]
+            else:
+                out[k] = v
+        return out
+
+    def prepare(self, diffuser: "Diffuser", optimizer: Optimizer) -> None:
+        """accelerator.prepare(denoiser, ..., optimizer): device placement, rank-0 broadcast, gradient reducer"""
+        den = diffuser.denoiser
+        den.to(self.device)
+        if hasattr(den, "engine") and self.device.type == "cuda":
+            eng = den.engine  # flattens the parameters into the arena
+            if self.world > 1:
+                broadcast_arena(den._flat)
+                self._reducer = GradReducer(den._flat_grad)
+                eng.reducer = self._reducer
+                if hasattr(optimizer, "grad_scale"):
+                    optimizer.grad_scale = self._reducer.grad_scale
+                else:
+                    raise RuntimeError("data-parallel training needs diffulab_amd.training.FusedAdamW (grad_scale = 1/world)")
+
+    @property
+    def sync_gradients(self) -> bool:
+        return (self._micro + 1) % self.gradient_accumulation_step == 0
+
+    def begin_micro_step(self) -> None:
+        if self._reducer is not None:
+            self._reducer.sync = self.sync_gradients
+
+    def end_micro_step(self) -> None:
+        self._micro += 1
+
+    def gather_mean(self, value: float) -> float:
+        if self.world == 1:
+            return float(value)
+        t = torch.tensor([value], device=self.device, dtype=torch.float64)
+        dist.all_reduce(t)
+        return float(t.item() / self.world)
+
+    def log(self, values: dict[str, float], step: int) -> None:
+        if self.is_main_process:
+            with open(self.save_path / "metrics.jsonl", "a") as f:
+                f.write(json.dumps({"step": step, **values}) + "\n")
+
+    def wait_for_everyone(self) -> None:
+        if self.world > 1:
+            dist.barrier()
+
+    # ------------------------------------------------------------------ checkpoints (file names of common.py:156-176)
+    def save_model(self, optimizer: Optimizer, diffuser: "Diffuser", ema_denoiser: EMA | None = None,
+                   scheduler: LRScheduler | None = None) -> None:
+        if not self.is_main_process:
+            return
+        cpu = lambda sd: {k: (v.detach().cpu() if isinstance(v, Tensor) else v) for k, v in sd.items()}  # noqa: E731
+        torch.save(cpu(diffuser.denoiser.state_dict()), self.save_path / "denoiser.pt")
+        torch.save(optimizer.state_dict(), self.save_path / "optimizer.pt")
+        if ema_denoiser is not None:
+            torch.save(cpu(ema_denoiser.ema_model.state_dict()), self.save_path / "ema.pt")
+        if scheduler is not None:
+            torch.save(scheduler.state_dict(), self.save_path / "scheduler.pt")
+        for extra_loss in diffuser.extra_losses:
+            torch.save(cpu(extra_loss.state_dict()), self.save_path / f"{extra_loss.name}.pt")
+
+    @torch.no_grad()
+    def log_images(self, diffuser: "Diffuser", val_dataloader: Iterable[BatchData], epoch: int, val_steps: int = 50,
+                   step_shift: float | None = None, guidance_scale: float = 0) -> None:
+        """common.py:178-271: sample with `val_steps` steps from the labels of one validation batch; the images (mapped from
+        [-1,1] to [0,1]) are written to ``save_path/val_images_epoch{N}.pt`` instead of a wandb panel."""
+        batch = dict(next(iter(val_dataloader))["model_inputs"])
+        batch = self.move_dict_to_device(batch)
+        x: Tensor = batch.pop("x")
+        original_steps = diffuser.n_steps
+        train_shift = None
+        if step_shift is not None:
+            train_shift = diffuser.diffusion.shift
+            diffuser.set_steps(val_steps, shift=step_shift)
+        else:
+            diffuser.set_steps(val_steps)
+        images = diffuser.generate(data_shape=tuple(x.shape), model_inputs=batch, guidance_scale=guidance_scale, use_tqdm=False)["x"]
+        images = (images * 0.5 + 0.5).clamp(0, 1).cpu().float()
+        torch.save(images, self.save_path / f"val_images_epoch{epoch + 1}.pt")
+        if train_shift is not None:
+            diffuser.set_steps(original_steps, shift=train_shift)
+        else:
+            diffuser.set_steps(original_steps)
+
+    @abstractmethod
+    def training_step(self, *args: Any, **kwargs: Any) -> None: ...
+
+    @abstractmethod
+    def validation_step(self, *args: Any, **kwargs: Any) -> None: ...
+
+    @abstractmethod
+    def train(self, *args: Any, **kwargs: Any) -> None: ...
