@@ -11,11 +11,12 @@ DiT forward -> backward -> [N>1: RCCL gradient all-reduce overlapped with backwa
 per-GPU batch is fixed (256), `value` is the whole-job images/s.  Nothing under /root/reference is read.
 
 Extra objects on the JSON line:
-  roofline     -- dominant kernel (gemm_nt_k, the bf16 MFMA GEMM behind every linear): algorithmic FLOPs of its
-                  launches / their HIP-event durations, measured on a profiled replay of the same step; plus the
-                  whole-step figure (47.2 GFLOP/img x img/s) as `step_achieved`.
+  roofline     -- dominant kernel (gemm_nt_big_k, the bf16 MFMA NT GEMM behind every linear's forward and data-gradient):
+                  algorithmic FLOPs of its launches / their HIP-event durations, measured on a profiled replay of the
+                  same step (per-variant and gemm_tn numbers under `kernels`); `traffic` from the committed PMC passes;
+                  plus the whole-step figure (47.2 GFLOP/img x img/s) as `step_achieved`.
   cpu_baseline -- the CPU oracle (a port of the reference path, oracle/) timed on this host's cores on a bounded
-                  sample (B=32, 1 warm-up + 2 timed steps), rank 0 at N=1 only.
+                  sample (B=8, 1 warm-up + the timed steps that fit in ~25 s), rank 0 at N=1 only.
 """
 
 from __future__ import annotations
@@ -93,6 +94,91 @@ def cpu_baseline(batch: int = 8, budget_s: float = 25.0) -> dict:
             "sample": f"oracle fp32 DiT-S/2 flow train step, B={batch}, {len(times) - len(timed)} warm-up + {len(timed)} timed steps"}
 
 
+def _nt_variant(M: int, N: int, K: int, plain: bool) -> str:
+    """which kernel dl_gemm_nt dispatches to (csrc/gemm.hip dispatch_big, default variant)"""
+    if M % 256 == 0:
+        if plain and N % 384 == 0 and (M // 256) * (N // 384) >= 64:
+            return "gemm_nt_big_k<384,2,0>"
+        if N % 192 == 0 and (M // 256) * (N // 192) >= 64:
+            return "gemm_nt_big_k<192,2,%d>" % (0 if plain else 1)
+    return "gemm_nt_k"
+
+
+def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
+    """Profiled replay of the same training step: HIP events around every MFMA GEMM launch, recorded on the stream the
+    launch goes to (the wgrad GEMMs run on the engine's side stream).  The dominant kernel is the NT GEMM family
+    `gemm_nt_big_k` (every linear's forward and data-gradient: 2/3 of the step's FLOPs, all on the critical path);
+    `achieved` = algorithmic FLOPs of its launches (2 M N K each) / their summed launch durations.  `traffic` is the
+    HBM bytes per launch of the same kernels from the committed PMC passes (profiles/r01_d_pmc_traffic.json:
+    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, calibrated on adamw_k), null if that file is absent."""
+    from diffulab_amd import ops
+
+    rec: list[tuple[str, torch.cuda.Event, torch.cuda.Event, float]] = []
+    orig = {n: getattr(ops, n) for n in ("gemm_nt", "gemm_nt_swiglu", "gemm_tn")}
+
+    def timed(kind: str):
+        fn = orig[kind]
+
+        def wrapper(a, b, *rest, **kw):
+            if kind == "gemm_nt":
+                M, N, K = kw.get("M") or a.shape[0], kw.get("N") or b.shape[0], kw.get("K") or a.shape[1]
+                plain = not any(kw.get(k) is not None for k in ("bias", "pre_out", "resid")) and not kw.get("act") \
+                    and rest[0].dtype == torch.bfloat16
+                name, fl = _nt_variant(M, N, K, plain), 2.0 * M * N * K
+            elif kind == "gemm_nt_swiglu":
+                name, fl = "gemm_nt_big_k<384,2,2>", 2.0 * a.shape[0] * b.shape[0] * a.shape[1]
+            else:
+                M, N = kw.get("M") or a.shape[1], kw.get("N") or b.shape[1]
+                name, fl = "gemm_tn", 2.0 * a.shape[0] * M * N
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()  # current stream == the stream the launch goes to
+            r = fn(a, b, *rest, **kw)
+            e1.record()
+            rec.append((name, e0, e1, fl))
+            return r
+
+        return wrapper
+
+    for n in orig:
+        setattr(ops, n, timed(n))
+    saved_reducer, model.engine.reducer = model.engine.reducer, None
+    reps = 2
+    try:
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+    finally:
+        for n, f in orig.items():
+            setattr(ops, n, f)
+        model.engine.reducer = saved_reducer
+    per: dict[str, list[float]] = {}
+    for name, e0, e1, fl in rec:
+        d = per.setdefault(name, [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += e0.elapsed_time(e1)
+        d[2] += fl
+    kernels = {k: {"launches_per_step": v[0] // reps, "avg_launch_us": round(v[1] * 1e3 / v[0], 2),
+                   "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in sorted(per.items())}
+    fam = [v for k, v in per.items() if k.startswith("gemm_nt_big_k")]
+    n_l, ms, fl = sum(v[0] for v in fam), sum(v[1] for v in fam), sum(v[2] for v in fam)
+    ach = fl / (ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")
+    if os.path.exists(tpath):
+        t = json.load(open(tpath))
+        rows = [v for k, v in t.items() if k.startswith("gemm_nt_big_k")]
+        if rows:
+            traffic = round(sum(v["launches"] * (v["fetch_MB"] + v["write_MB"]) for v in rows) * 1e6
+                            / sum(v["launches"] for v in rows))
+    step_ach = images_per_s_per_gpu * train_flops_per_image() / 1e12
+    return {"bound": "mfma", "kernel": "gemm_nt_big_k (all variants; NT GEMM of every linear fwd + dgrad)",
+            "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+            "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_d_pmc_traffic.txt)",
+            "flops_per_launch": round(fl / n_l), "launches_per_step": n_l // reps, "avg_launch_us": round(ms * 1e3 / n_l, 2),
+            "ms_per_step": round(ms / reps, 3), "kernels": kernels,
+            "step_achieved": round(step_ach, 1), "step_frac": round(step_ach / PEAK_BF16_TFLOPS, 4)}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,41 +250,7 @@ def main() -> None:
 
     roof = None
     if rank == 0 and not args.no_roofline:
-        # profiled replay of the same step: HIP events around every gemm_nt_k launch on the launch stream
-        rec: list[tuple[torch.cuda.Event, torch.cuda.Event, float]] = []
-        orig = ops.gemm_nt
-
-        def timed_gemm(a, b, out, **kw):
-            M = kw.get("M") or a.shape[0]
-            N = kw.get("N") or b.shape[0]
-            K = kw.get("K") or a.shape[1]
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = orig(a, b, out, **kw)
-            e1.record()
-            rec.append((e0, e1, 2.0 * M * N * K))
-            return r
-
-        ops.gemm_nt = timed_gemm
-        import diffulab_amd.engine as eng_mod
-
-        eng_mod.ops.gemm_nt = timed_gemm
-        saved_reducer, model.engine.reducer = model.engine.reducer, None
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        ops.gemm_nt = orig
-        eng_mod.ops.gemm_nt = orig
-        model.engine.reducer = saved_reducer
-        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
-        tot_fl = sum(f for _, _, f in rec)
-        ach = tot_fl / (tot_ms * 1e-3) / 1e12
-        step_ach = (value / world) * train_flops_per_image() / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_nt_k", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                "launches_per_step": len(rec) // 2, "avg_launch_us": round(tot_ms * 1e3 / len(rec), 2),
-                "gemm_nt_ms_per_step": round(tot_ms / 2, 3), "step_achieved": round(step_ach, 1),
-                "step_frac": round(step_ach / PEAK_BF16_TFLOPS, 4)}
+        roof = roofline_replay(step, model, value / world)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

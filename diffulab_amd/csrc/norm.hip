@@ -49,8 +49,9 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_k(const bf16_t* __restrict__ x
                                                     const float* __restrict__ b, const bf16_t* __restrict__ scale,
                                                     const bf16_t* __restrict__ shift, int64_t ld_mod,
                                                     int64_t rows_per_mod, float eps, bf16_t* __restrict__ out,
-                                                    float* __restrict__ mean_o, float* __restrict__ rstd_o, int64_t M,
-                                                    int D) {
+                                                    float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                    const bf16_t* __restrict__ t, const bf16_t* __restrict__ gate,
+                                                    int64_t ld_gate, bf16_t* __restrict__ x_out, int64_t M, int D) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D8 = D >> 3;
   const float invD = 1.0f / (float)D;
@@ -61,6 +62,16 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_k(const bf16_t* __restrict__ x
     float xv[NJ][8], sc[NJ][8], sh[NJ][8];
     load_row<NJ>(x + row * D, D8, lane, xv);
     const int64_t g = row / rows_per_mod;
+    if (t) {  // fused gated residual of the previous sub-layer: x <- x + gate * t (mmdit.py:302,308), stored as bf16
+      float tv[NJ][8], gv[NJ][8];
+      load_row<NJ>(t + row * D, D8, lane, tv);
+      load_row<NJ>(gate + g * ld_gate, D8, lane, gv);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[j][e] = bf2f(f2bf(xv[j][e] + gv[j][e] * tv[j][e]));  // statistics of what is stored
+      store_row<NJ>(x_out + row * D, D8, lane, xv);
+    }
     load_row<NJ>(scale + g * ld_mod, D8, lane, sc);
     load_row<NJ>(shift + g * ld_mod, D8, lane, sh);
     float s = 0.f;
@@ -97,8 +108,11 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_k(const bf16_t* __restrict__ x
 
 extern "C" int dl_ln_modulate_fwd(const void* x, const float* w, const float* b, const void* scale, const void* shift,
                                   int64_t ld_mod, int64_t rows_per_mod, float eps, void* out, float* mean,
-                                  float* rstd, int64_t M, int64_t D, dl_stream_t stream) {
+                                  float* rstd, const void* t, const void* gate, int64_t ld_gate, void* x_out, int64_t M,
+                                  int64_t D, dl_stream_t stream) {
   DL_CHECK_ARG(x && scale && shift && out && mean && rstd && M > 0, "dl_ln_modulate_fwd: null operand");
+  DL_CHECK_ARG(!t || (gate && x_out && ld_gate % 8 == 0 && (((uintptr_t)t | (uintptr_t)gate | (uintptr_t)x_out) & 15) == 0),
+               "dl_ln_modulate_fwd: the fused gated residual needs t, gate and x_out (16-byte aligned)");
   DL_CHECK_ARG((w == nullptr) == (b == nullptr), "dl_ln_modulate_fwd: w and b must both be given or both NULL");
   DL_CHECK_ARG(D % 8 == 0 && D <= 512 * MAXJ && ld_mod % 8 == 0 && rows_per_mod > 0, "dl_ln_modulate_fwd: D=%lld",
                (long long)D);
@@ -110,7 +124,7 @@ extern "C" int dl_ln_modulate_fwd(const void* x, const float* w, const float* b,
 #define LAUNCH(NJ)                                                                                              \
   hipLaunchKernelGGL(ln_mod_fwd_k<NJ>, grid, 256, 0, (hipStream_t)stream, (const bf16_t*)x, w, b,                \
                      (const bf16_t*)scale, (const bf16_t*)shift, ld_mod, rows_per_mod, eps, (bf16_t*)out, mean, \
-                     rstd, M, (int)D)
+                     rstd, (const bf16_t*)t, (const bf16_t*)gate, ld_gate, (bf16_t*)x_out, M, (int)D)
   if (nj == 1) LAUNCH(1);
   else LAUNCH(2);
 #undef LAUNCH

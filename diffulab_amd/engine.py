@@ -331,34 +331,41 @@ class DiTEngine:
         ops.gemm_nt(w["se"], sh["@mod|f"], w["mod"], bias=mod_bias, M=B, N=self.layout.mod_rows, K=E)
         mod = w["mod"]
 
+        # The gated residual of every sub-layer (x += gate * f(...)) is applied by the NEXT LayerNorm-modulate kernel, which
+        # has to read the residual stream anyway: the projection / MLP-down GEMMs stay plain stores (fast 256x384 tiles)
+        # and write t1 / t2, which the backward needs for the gate gradients.
+        pend = None  # (x_base, t, gate) of the sub-layer whose residual add is still pending
         for i in range(L):
             a = w["layers"][i if train else 0]
             xin = xs[i] if train else xs[i & 1]
-            xout = xs[i + 1] if train else xs[(i + 1) & 1]
             pre = f"layers.{i}."
             mo = i * 6 * D
-            ops.ln_modulate_fwd(xin, self.P(pre + "norm_1.weight"), self.P(pre + "norm_1.bias"), mod[:, mo : mo + D],
-                                mod[:, mo + D : mo + 2 * D], N, 1e-5, a["xm1"], a["mean1"], a["rstd1"])
+            if pend is None:
+                ops.ln_modulate_fwd(xin, self.P(pre + "norm_1.weight"), self.P(pre + "norm_1.bias"), mod[:, mo : mo + D],
+                                    mod[:, mo + D : mo + 2 * D], N, 1e-5, a["xm1"], a["mean1"], a["rstd1"])
+            else:
+                ops.ln_modulate_fwd(pend[0], self.P(pre + "norm_1.weight"), self.P(pre + "norm_1.bias"), mod[:, mo : mo + D],
+                                    mod[:, mo + D : mo + 2 * D], N, 1e-5, a["xm1"], a["mean1"], a["rstd1"], t=pend[1],
+                                    gate=pend[2], x_out=xin)
             ops.gemm_nt(a["xm1"], sh[pre + "attention.qkv.weight|f"], a["qkv"])
             ops.qk_norm_rope_fwd(a["qkv"], self.P(pre + "attention.qk_norm.query_norm.scale"),
                                  self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["q"], a["k"], a["v"],
                                  a["rrms"], B, N, Hh, 64, rot)
             ops.attn_fwd(a["q"], a["k"], a["v"], a["a"], a["lse"], B, Hh, N, 64, 64**-0.5)
-            ops.gemm_nt(a["a"], sh[pre + "attention.proj_out.weight|f"], a["x1"], pre_out=a["t1"], resid=xin,
-                        gate=mod[:, mo + 2 * D : mo + 3 * D], rows_per_gate=N)
-            ops.ln_modulate_fwd(a["x1"], self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"),
+            ops.gemm_nt(a["a"], sh[pre + "attention.proj_out.weight|f"], a["t1"])
+            ops.ln_modulate_fwd(xin, self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"),
                                 mod[:, mo + 3 * D : mo + 4 * D], mod[:, mo + 4 * D : mo + 5 * D], N, 1e-5, a["xm2"],
-                                a["mean2"], a["rstd2"])
+                                a["mean2"], a["rstd2"], t=a["t1"], gate=mod[:, mo + 2 * D : mo + 3 * D], x_out=a["x1"])
             if not ops.gemm_nt_swiglu(a["xm2"], sh[pre + "mlp_input.0.weight|g"], a["u"], a["h"]):
                 ops.gemm_nt(a["xm2"], sh[pre + "mlp_input.0.weight|f"], a["u"])  # small / ragged shapes: unfused pair
                 ops.swiglu_fwd(a["u"], a["h"])
-            ops.gemm_nt(a["h"], sh[pre + "mlp_input.2.weight|f"], xout, pre_out=a["t2"], resid=a["x1"],
-                        gate=mod[:, mo + 5 * D : mo + 6 * D], rows_per_gate=N)
+            ops.gemm_nt(a["h"], sh[pre + "mlp_input.2.weight|f"], a["t2"])
+            pend = (a["x1"], a["t2"], mod[:, mo + 5 * D : mo + 6 * D])
 
         xl = xs[L] if train else xs[L & 1]
         mo = L * 6 * D
-        ops.ln_modulate_fwd(xl, None, None, mod[:, mo : mo + D], mod[:, mo + D : mo + 2 * D], N, 1e-6, w["xf"], w["meanf"],
-                            w["rstdf"])
+        ops.ln_modulate_fwd(pend[0], None, None, mod[:, mo : mo + D], mod[:, mo + D : mo + 2 * D], N, 1e-6, w["xf"], w["meanf"],
+                            w["rstdf"], t=pend[1], gate=pend[2], x_out=xl)
         ops.gemm_nt(w["xf"], sh["last_layer.linear.weight|f"], w["otok"], bias=self.P("last_layer.linear.bias"), M=M,
                     N=Fo, K=D)
         ops.unpatchify(w["otok"], w["pred"], d.patch_size)

@@ -164,11 +164,11 @@ def gemm_tn(a: Tensor, b: Tensor, out: Tensor, *, M: int | None = None, N: int |
 
 
 # ------------------------------------------------------------------ block kernels
-def ln_modulate_fwd(x, w, b, scale, shift, rows_per_mod, eps, out, mean, rstd):
+def ln_modulate_fwd(x, w, b, scale, shift, rows_per_mod, eps, out, mean, rstd, t=None, gate=None, x_out=None):
+    """out = modulate(LN(x')) with x' = x (+ gate * t, written to x_out, when the gated residual is fused in)"""
     M, D = x.shape
     _call("dl_ln_modulate_fwd", _p(x), _p(w), _p(b), _p(scale), _p(shift), scale.stride(0), rows_per_mod, float(eps),
-          _p(out), _p(mean), _p(rstd), M, D, _s())
-    return out
+          _p(out), _p(mean), _p(rstd), _p(t), _p(gate), gate.stride(0) if gate is not None else 0, _p(x_out), M, D, _s())
 
 
 _LN_SCRATCH: dict = {}

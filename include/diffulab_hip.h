@@ -124,10 +124,14 @@ DL_API int dl_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, fl
 /* ------------------------------------------------------------------ adaLN / norms */
 /* modulate(LayerNorm(x)) mmdit.py:299,305,547 + nn.py:539:  out = (LN(x) * w + b) * (1 + scale) + shift.
  * w/b f32 [D] or NULL (norm_final has no affine); scale/shift bf16 rows with stride ld_mod, one row per
- * rows_per_mod tokens.  mean/rstd f32 [M] saved for the backward. */
+ * rows_per_mod tokens.  mean/rstd f32 [M] saved for the backward.
+ * Optional fused gated residual of the PREVIOUS sub-layer (mmdit.py:302,308: x = x + gate * f(...)): when t != NULL the
+ * row is first updated to x + gate[m / rows_per_mod, :] * t[m, :], written to x_out (bf16) and then normalised, so the
+ * projection / MLP-down GEMMs stay plain stores and the residual stream is touched once per sub-layer. */
 DL_API int dl_ln_modulate_fwd(const void* x, const float* w, const float* b, const void* scale, const void* shift,
                               int64_t ld_mod, int64_t rows_per_mod, float eps, void* out, float* mean,
-                              float* rstd, int64_t M, int64_t D, dl_stream_t stream);
+                              float* rstd, const void* t, const void* gate, int64_t ld_gate, void* x_out, int64_t M,
+                              int64_t D, dl_stream_t stream);
 /* backward of the above, fused with the residual-stream add:
  *   dx[m,:]    = dres[m,:] + dLN(...)           (dres may be NULL)
  *   dscale[g,:] = sum_{m in g} dout * (xhat*w+b) ; dshift[g,:] = sum dout          (bf16 rows, stride ld_dmod)

@@ -160,6 +160,25 @@ def test_ln_modulate_fwd_bwd(ops, D, affine):
     assert rel(dx.float(), x.grad) < 5e-3
 
 
+def test_ln_modulate_fwd_with_fused_gated_residual(ops):
+    """x' = x + gate * t (mmdit.py:302,308) applied and stored by the LayerNorm kernel of the next sub-layer"""
+    B, N, D = 3, 64, 384
+    M = B * N
+    x, t = bf(synth.normal("lg.x", (M, D))), bf(synth.normal("lg.t", (M, D)))
+    mod = bf(synth.normal("lg.mod", (B, 3 * D), std=0.3))
+    w, b = 1 + synth.normal("lg.w", (D,), std=0.1), synth.normal("lg.b", (D,), std=0.1)
+    xn = bf(x + mod[:, 2 * D :].repeat_interleave(N, 0) * t)  # what the kernel stores (bf16) and normalises
+    y = odit.layer_norm(xn.reshape(B, N, D), w, b, 1e-5) * (1 + mod[:, None, :D]) + mod[:, None, D : 2 * D]
+    mod_d = dev_bf(mod)
+    out, x_out = (torch.empty(M, D, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.ln_modulate_fwd(dev_bf(x), w.to(DEV), b.to(DEV), mod_d[:, :D], mod_d[:, D : 2 * D], N, 1e-5, out, mean, rstd,
+                        t=dev_bf(t), gate=mod_d[:, 2 * D :], x_out=x_out)
+    assert rel(x_out.float(), xn) < 1e-3  # f32 fma + one bf16 rounding (vs mul, add, rounding on the CPU: <= 1 bf16 ulp)
+    assert rel(out.float(), y.reshape(M, D)) < 4e-3
+    assert rel(mean, xn.mean(-1)) < 1e-4
+
+
 def test_gate_bwd(ops):
     B, N, D = 3, 64, 384
     M = B * N
