@@ -560,6 +560,12 @@ static int dispatch_big(const void* A, int64_t lda, const void* B, int64_t ldb, 
     return launch_big<384, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
   if ((variant == 2 || variant == 4) && N % 192 == 0 && (M / TBM) * (N / 192) >= 64)
     return launch_big<192, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
+  // power-of-two widths (UNet channel counts 128 / 256 / 512 / 1024): 256x256 tiles, else the 256x128 3-stage ring
+  // (only when the launch fills the chip: the low-resolution UNet levels have few, K-deep tiles and do better on 128x128)
+  if (variant == 4 && epi <= 1 && N % 256 == 0 && (M / TBM) * (N / 256) >= 192)
+    return launch_big<256, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
+  if (variant == 4 && epi <= 1 && N % 128 == 0 && (M / TBM) * (N / 128) >= 192)
+    return launch_big<128, 3>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
   return 1;
 }
 

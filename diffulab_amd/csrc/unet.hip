@@ -116,7 +116,9 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_k(const bf16_t* __restrict_
                                                        const float* __restrict__ st, const float* __restrict__ w,
                                                        const float* __restrict__ bb, const bf16_t* __restrict__ fs,
                                                        const bf16_t* __restrict__ fh, int64_t ldf, int silu,
-                                                       float* __restrict__ S, int HW, int C, int G) {
+                                                       float* __restrict__ S, float* __restrict__ dw, float* __restrict__ db,
+                                                       bf16_t* __restrict__ dfs, bf16_t* __restrict__ dfh, int64_t lddf, int HW,
+                                                       int C, int G) {
   __shared__ float red[4][4][64];
   const int slabs = (C + 63) / 64;
   const int b = blockIdx.x / slabs, c = (blockIdx.x % slabs) * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
@@ -146,8 +148,18 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_k(const bf16_t* __restrict_
   __syncthreads();
   if (pl == 0 && c < C) {
     const int l = threadIdx.x & 63;
+    float v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) S[((int64_t)b * 4 + k) * C + c] = red[0][k][l] + red[1][k][l] + red[2][k][l] + red[3][k][l];
+    for (int k = 0; k < 4; ++k) {
+      v[k] = red[0][k][l] + red[1][k][l] + red[2][k][l] + red[3][k][l];
+      S[((int64_t)b * 4 + k) * C + c] = v[k];
+    }
+    if (dfs) {
+      dfs[(int64_t)b * lddf + c] = f2bf(v[0]);
+      dfh[(int64_t)b * lddf + c] = f2bf(v[1]);
+    }
+    unsafeAtomicAdd(&dw[c], v[2]);  // B contributions per channel
+    unsafeAtomicAdd(&db[c], v[3]);
   }
 }
 // backward pass 2: dx = r * (dy*w - A/n - xhat*Bv/n), A = sum_{c in g} w[c] S[3][c], Bv = sum_{c in g} w[c] S[2][c]
@@ -184,22 +196,6 @@ __global__ void gn_group_sums_k(const float* __restrict__ S, const float* __rest
   AB[((int64_t)b * G + g) * 2] = A;
   AB[((int64_t)b * G + g) * 2 + 1] = Bv;
 }
-__global__ void gn_param_grads_k(const float* __restrict__ S, float* __restrict__ dw, float* __restrict__ db,
-                                 bf16_t* __restrict__ dfs, bf16_t* __restrict__ dfh, int64_t ldf, int B, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float gw = 0.f, gb = 0.f;
-  for (int b = 0; b < B; ++b) {
-    gw += S[((int64_t)b * 4 + 2) * C + c];
-    gb += S[((int64_t)b * 4 + 3) * C + c];
-    if (dfs) {
-      dfs[(int64_t)b * ldf + c] = f2bf(S[((int64_t)b * 4 + 0) * C + c]);
-      dfh[(int64_t)b * ldf + c] = f2bf(S[((int64_t)b * 4 + 1) * C + c]);
-    }
-  }
-  dw[c] += gw;
-  db[c] += gb;
-}
 /* scratch: f32 [B*4*C + B*G*2] */
 extern "C" int dl_gn_bwd(const void* dout, const void* x, const float* stats, const float* w, const float* b,
                          const void* film_scale, const void* film_shift, int64_t ld_film, int act_silu, const void* dres,
@@ -211,14 +207,13 @@ extern "C" int dl_gn_bwd(const void* dout, const void* x, const float* stats, co
   float* AB = scratch + B * 4 * C;
   const int slabs = (int)((C + 63) / 64);
   hipLaunchKernelGGL(gn_bwd_reduce_k, (int)B * slabs, 256, 0, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)x, stats, w,
-                     b, (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, S, (int)HW, (int)C, (int)G);
+                     b, (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, S, dw, db, (bf16_t*)dfilm_scale,
+                     (bf16_t*)dfilm_shift, ld_dfilm, (int)HW, (int)C, (int)G);
   hipLaunchKernelGGL(gn_group_sums_k, (int)B, 256, 0, (hipStream_t)stream, S, w, AB, (int)C, (int)G);
   const int64_t n = B * HW * C;
   hipLaunchKernelGGL(gn_bwd_apply_k, grid_for(n), 256, 0, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)x, stats, w, b,
                      (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, S, AB, (const bf16_t*)dres,
                      (bf16_t*)dx, n, (int)HW, (int)C, (int)G);
-  hipLaunchKernelGGL(gn_param_grads_k, (int)((C + 255) / 256), 256, 0, (hipStream_t)stream, S, dw, db, (bf16_t*)dfilm_scale,
-                     (bf16_t*)dfilm_shift, ld_dfilm, (int)B, (int)C);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
@@ -304,18 +299,19 @@ extern "C" int dl_cast_conv3x3_weight(const float* w, int64_t Co, int64_t Ci, vo
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
-// wgrad lands as [Co, (tap, ci)] f32; fold it into the reference layout [Co, Ci, 3, 3] (+=)
+// wgrad lands TRANSPOSED as [(tap, ci), Co] f32 (cols^T dY: its row count 9*Ci is a multiple of the 384-row tile of the big TN
+// GEMM for every 128-multiple channel count); fold it into the reference layout [Co, Ci, 3, 3] (+=)
 __global__ void conv3x3_wgrad_fold_k(const float* __restrict__ g, int64_t ldg, float* __restrict__ dw, int Co, int Ci) {
   const int64_t n = (int64_t)Co * Ci * 9;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int tap = (int)(i % 9);
     const int64_t r = i / 9;
     const int ci = (int)(r % Ci), co = (int)(r / Ci);
-    dw[i] += g[(int64_t)co * ldg + tap * Ci + ci];
+    dw[i] += g[(int64_t)(tap * Ci + ci) * ldg + co];
   }
 }
 extern "C" int dl_conv3x3_wgrad_fold(const float* g, int64_t ldg, float* dw, int64_t Co, int64_t Ci, dl_stream_t stream) {
-  DL_CHECK_ARG(g && dw && Co > 0 && Ci > 0 && ldg >= 9 * Ci, "dl_conv3x3_wgrad_fold: bad args");
+  DL_CHECK_ARG(g && dw && Co > 0 && Ci > 0 && ldg >= Co, "dl_conv3x3_wgrad_fold: bad args");
   hipLaunchKernelGGL(conv3x3_wgrad_fold_k, grid_for(Co * Ci * 9), 256, 0, (hipStream_t)stream, g, ldg, dw, (int)Co, (int)Ci);
   DL_LAUNCH_CHECK();
   return DL_OK;

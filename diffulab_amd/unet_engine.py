@@ -323,9 +323,9 @@ class UNetEngine:
         cols = self._scr("cols", Mp * ldk).view(Mp, ldk)
         ops.im2col3x3(x, cols, B, H, W, ci)
         dyp = self._padded(dy, Mp, co8)
-        g = self._scr("wg", co8 * ldk, torch.float32).view(co8, ldk)
+        g = self._scr("wg", ldk * co8, torch.float32).view(ldk, co8)  # transposed: 9*Ci rows fit the 384-row wgrad tiles
         g.zero_()
-        ops.gemm_tn(dyp, cols, g, M=co8, N=ldk)
+        ops.gemm_tn(cols, dyp, g, M=ldk, N=co8)
         ops.conv3x3_wgrad_fold(g, self.Gr(name))
         if not need_dx:
             return None

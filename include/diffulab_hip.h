@@ -244,7 +244,7 @@ DL_API int dl_im2col3x3(const void* x, int64_t ldx, void* cols, int64_t B, int64
  * [Ci, ldd] (k = tap*Co + co, kernel rotated by 180 degrees) */
 DL_API int dl_cast_conv3x3_weight(const float* w, int64_t Co, int64_t Ci, void* wf, int64_t ldf, void* wd, int64_t ldd,
                                   dl_stream_t stream);
-/* weight gradient from dl_gemm_tn lands as g f32 [Co, ldg] in (tap, ci) order: dw[Co, Ci, 3, 3] += g */
+/* weight gradient from dl_gemm_tn(cols, dY) lands transposed as g f32 [(tap, ci), ldg >= Co]: dw[Co, Ci, 3, 3] += g^T */
 DL_API int dl_conv3x3_wgrad_fold(const float* g, int64_t ldg, float* dw, int64_t Co, int64_t Ci, dl_stream_t stream);
 /* out[b, yo, xo, c] = scale * sum of the 2x2 window of x [B, 2Ho, 2Wo, C]: avg_pool2d forward (scale 0.25, nn.py:86) and
  * nearest-upsample backward (scale 1) */
