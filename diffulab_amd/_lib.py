@@ -25,7 +25,7 @@ _CTYPES = {
 }
 
 
-_VALUE_RETURNING = {"dl_version", "dl_mse_loss_partials", "dl_ln_modulate_bwd_scratch"}  # every other int-returning entry point returns a status
+_VALUE_RETURNING = {"dl_version", "dl_mse_loss_partials"}  # every other int-returning entry point returns a status
 
 
 def _ctype_of(decl: str):

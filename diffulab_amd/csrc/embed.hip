@@ -190,21 +190,28 @@ extern "C" int dl_colsum(const void* x, int dtype, int64_t ld, float* out, int64
   return DL_OK;
 }
 
-// out[j] += sum_g partial[g, j]: 64 columns x 4 row-lanes per block (same shape as colsum, no atomics: one block per column group)
-__global__ void reduce_rows_k(const float* __restrict__ partial, float* __restrict__ out, int G, int64_t n) {
+// out[j] += sum_g partial[g, j]: 64 columns x 4 row-lanes per block, the G rows cut into slices of 64 (one block per
+// (column group, slice), partial sums meet in `out` through f32 atomics); `clear` zeroes every partial element right after
+// it is read, so an accumulate-into partial buffer needs no separate memset
+__global__ void reduce_rows_k(float* __restrict__ partial, float* __restrict__ out, int G, int64_t n, int clear) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int64_t c = (int64_t)blockIdx.x * 64 + cl;
+  const int g0 = blockIdx.y * 64, g1 = g0 + 64 < G ? g0 + 64 : G;
   float acc = 0.f;
   if (c < n)
-    for (int g = rl; g < G; g += 4) acc += partial[(int64_t)g * n + c];
+    for (int g = g0 + rl; g < g1; g += 4) {
+      acc += partial[(int64_t)g * n + c];
+      if (clear) partial[(int64_t)g * n + c] = 0.f;
+    }
   red[rl][cl] = acc;
   __syncthreads();
-  if (rl == 0 && c < n) out[c] += red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+  if (rl == 0 && c < n) unsafeAtomicAdd(&out[c], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
-extern "C" int dl_reduce_rows_f32(const float* partial, float* out, int64_t G, int64_t n, dl_stream_t stream) {
+extern "C" int dl_reduce_rows_f32(float* partial, float* out, int64_t G, int64_t n, int clear_partial, dl_stream_t stream) {
   DL_CHECK_ARG(partial && out && G > 0 && n > 0, "dl_reduce_rows_f32: bad args");
-  hipLaunchKernelGGL(reduce_rows_k, cdiv(n, 64), 256, 0, (hipStream_t)stream, partial, out, (int)G, n);
+  hipLaunchKernelGGL(reduce_rows_k, dim3(cdiv(n, 64), cdiv(G, 64)), 256, 0, (hipStream_t)stream, partial, out, (int)G, n,
+                     clear_partial);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

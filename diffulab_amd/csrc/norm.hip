@@ -144,8 +144,9 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_k(const bf16_t* __restrict__ d
                                                     const bf16_t* __restrict__ scale, int64_t ld_mod,
                                                     int64_t rows_per_mod, const float* __restrict__ mean,
                                                     const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
-                                                    bf16_t* __restrict__ dx, float* __restrict__ part, int split,
-                                                    int64_t M, int D) {
+                                                    bf16_t* __restrict__ dx, float* __restrict__ dscale,
+                                                    float* __restrict__ dshift, int64_t ld_dmod, float* __restrict__ dwb,
+                                                    int split, int64_t M, int D) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = (float*)smem;  // [4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -251,33 +252,22 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_k(const bf16_t* __restrict__ d
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 4 * D; i += 256) part[(size_t)blockIdx.x * 4 * D + i] = red[i];
-}
-
-__global__ void ln_mod_bwd_fold_k(const float* __restrict__ part, int split, bf16_t* __restrict__ dscale,
-                                  bf16_t* __restrict__ dshift, int64_t ld_dmod, float* __restrict__ dwb, int D) {
-  const int64_t g = blockIdx.x;
-  for (int i = threadIdx.x; i < 4 * D; i += blockDim.x) {
-    float s = 0.f;
-    for (int p = 0; p < split; ++p) s += part[((size_t)g * split + p) * 4 * D + i];
+  // the `split` workgroups of one sample meet in global f32 accumulators (<= split-way contention per address): the
+  // modulation gradients land in the f32 image of dmod, the affine gradients in the per-sample partial [groups, 2, D]
+  for (int i = threadIdx.x; i < 4 * D; i += 256) {
     const int which = i / D, col = i - which * D;
-    if (which == 0) dscale[g * ld_dmod + col] = f2bf(s);
-    else if (which == 1) dshift[g * ld_dmod + col] = f2bf(s);
-    else if (dwb) dwb[(size_t)g * 2 * D + (which - 2) * D + col] = s;
+    const float v = red[i];
+    if (which == 0) unsafeAtomicAdd(dscale + g * ld_dmod + col, v);
+    else if (which == 1) unsafeAtomicAdd(dshift + g * ld_dmod + col, v);
+    else if (dwb) unsafeAtomicAdd(dwb + (size_t)g * 2 * D + (which - 2) * D + col, v);
   }
-}
-
-extern "C" int64_t dl_ln_modulate_bwd_scratch(int64_t M, int64_t D, int64_t rows_per_mod) {
-  const int64_t split = (rows_per_mod % 64 == 0) ? rows_per_mod / 64 : 1;
-  return (M / rows_per_mod) * split * 4 * D;  // floats
 }
 
 extern "C" int dl_ln_modulate_bwd(const void* dout, const void* x, const float* w, const float* b, const void* scale,
                                   int64_t ld_mod, int64_t rows_per_mod, const float* mean, const float* rstd,
-                                  const void* dres, void* dx, void* dscale, void* dshift, int64_t ld_dmod,
-                                  float* dwb_partial, float* scratch, int64_t M, int64_t D, dl_stream_t stream) {
-  DL_CHECK_ARG(dout && x && scale && mean && rstd && dx && dscale && dshift && scratch && M > 0,
-               "dl_ln_modulate_bwd: null operand");
+                                  const void* dres, void* dx, float* dscale, float* dshift, int64_t ld_dmod,
+                                  float* dwb_partial, int64_t M, int64_t D, dl_stream_t stream) {
+  DL_CHECK_ARG(dout && x && scale && mean && rstd && dx && dscale && dshift && M > 0, "dl_ln_modulate_bwd: null operand");
   DL_CHECK_ARG((w == nullptr) == (b == nullptr), "dl_ln_modulate_bwd: w and b must both be given or both NULL");
   DL_CHECK_ARG(D % 8 == 0 && D <= 512 * MAXJ && ld_mod % 8 == 0 && rows_per_mod > 0 && M % rows_per_mod == 0,
                "dl_ln_modulate_bwd: D=%lld M=%lld rows_per_mod=%lld", (long long)D, (long long)M, (long long)rows_per_mod);
@@ -290,12 +280,10 @@ extern "C" int dl_ln_modulate_bwd(const void* dout, const void* x, const float* 
 #define LAUNCH(NJ)                                                                                                       \
   hipLaunchKernelGGL(ln_mod_bwd_k<NJ>, groups * split, 256, lds, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)x, \
                      w, b, (const bf16_t*)scale, ld_mod, rows_per_mod, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx,       \
-                     scratch, split, M, (int)D)
+                     dscale, dshift, ld_dmod, dwb_partial, split, M, (int)D)
   if (nj == 1) LAUNCH(1);
   else LAUNCH(2);
 #undef LAUNCH
-  hipLaunchKernelGGL(ln_mod_bwd_fold_k, groups, 256, 0, (hipStream_t)stream, scratch, split, (bf16_t*)dscale, (bf16_t*)dshift,
-                     ld_dmod, dwb_partial, (int)D);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
@@ -305,7 +293,7 @@ template <int NJ>
 __global__ __launch_bounds__(512) void gate_bwd_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ t,
                                                   const bf16_t* __restrict__ gate, int64_t ld_mod,
                                                   int64_t rows_per_mod, bf16_t* __restrict__ dt,
-                                                  bf16_t* __restrict__ dgate, int64_t ld_dmod, int64_t M, int D) {
+                                                  float* __restrict__ dgate, int64_t ld_dmod, int64_t M, int D) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = (float*)smem;  // [LNB_WAVES][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -344,12 +332,12 @@ __global__ __launch_bounds__(512) void gate_bwd_k(const bf16_t* __restrict__ dou
     float s = 0.f;
 #pragma unroll
     for (int wv_ = 0; wv_ < LNB_WAVES; ++wv_) s += red[(size_t)wv_ * D + i];
-    dgate[g * ld_dmod + i] = f2bf(s);
+    dgate[g * ld_dmod + i] = s;
   }
 }
 
 extern "C" int dl_gate_bwd(const void* dout, const void* t, const void* gate, int64_t ld_mod, int64_t rows_per_mod,
-                           void* dt, void* dgate, int64_t ld_dmod, int64_t M, int64_t D, dl_stream_t stream) {
+                           void* dt, float* dgate, int64_t ld_dmod, int64_t M, int64_t D, dl_stream_t stream) {
   DL_CHECK_ARG(dout && t && gate && dt && dgate && M > 0, "dl_gate_bwd: null operand");
   DL_CHECK_ARG(D % 8 == 0 && D <= 512 * MAXJ && ld_mod % 8 == 0 && rows_per_mod > 0 && M % rows_per_mod == 0,
                "dl_gate_bwd: bad dims");
@@ -359,7 +347,7 @@ extern "C" int dl_gate_bwd(const void* dout, const void* t, const void* gate, in
   const size_t lds = (size_t)LNB_WAVES * D * sizeof(float);
 #define LAUNCH(NJ)                                                                                               \
   hipLaunchKernelGGL(gate_bwd_k<NJ>, groups, 512, lds, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)t, \
-                     (const bf16_t*)gate, ld_mod, rows_per_mod, (bf16_t*)dt, (bf16_t*)dgate, ld_dmod, M, (int)D)
+                     (const bf16_t*)gate, ld_mod, rows_per_mod, (bf16_t*)dt, dgate, ld_dmod, M, (int)D)
   if (nj == 1) LAUNCH(1);
   else LAUNCH(2);
 #undef LAUNCH

@@ -283,9 +283,9 @@ class DiTEngine:
             w["wg"] = [{"dt2": z(M, D), "du": z(M, 2 * d.mlp_ratio * D), "dt1": z(M, D), "dqkv": z(M, 3 * D)}
                        for _ in range(L)]
             w["dq"], w["dk"], w["dv"] = (z(B, d.num_heads, N, 64) for _ in range(3))
-            w["dmod"] = z(Bp, self.layout.mod_rows)
+            w["dmod"] = z(Bp, self.layout.mod_rows)                  # bf16 operand of the modulation GEMMs' backward
+            w["dmod32"] = z(Bp, self.layout.mod_rows, dtype=f32)     # f32 accumulator the block kernels add into
             w["dwb"] = z(B, 2, D, dtype=f32)
-            w["ln_scr"] = z(ops.lib().call("dl_ln_modulate_bwd_scratch", M, D, N), dtype=f32)
             w["dse"] = z(Bp, E, dtype=f32)
             w["demb"] = z(Bp, E, dtype=f32)
             w["demb16"] = z(Bp, E)
@@ -381,7 +381,8 @@ class DiTEngine:
         F = d.mlp_ratio * D
         cos, sin = self._rope[(gh, gw)]
         rot = sum(d.rope_axes_dim)
-        mod, dmod, xs = w["mod"], w["dmod"], w["x"]
+        mod, dmod, xs = w["mod"], w["dmod32"], w["x"]  # dmod: f32 accumulator, cast to bf16 (w["dmod"]) after the loop
+        dmod[:B].zero_()
         Fo8 = _rup(Fo, 8)
 
         # head: last linear + final adaLN
@@ -398,7 +399,7 @@ class DiTEngine:
         mo = L * 6 * D
         dx, dx_alt = w["dxa"], w["dxb"]
         ops.ln_modulate_bwd(w["dxm"], xs[L], None, None, mod[:, mo : mo + D], N, w["meanf"], w["rstdf"], None, dx,
-                            dmod[:, mo : mo + D], dmod[:, mo + D : mo + 2 * D], None, w["ln_scr"])
+                            dmod[:, mo : mo + D], dmod[:, mo + D : mo + 2 * D], None)
 
         # The four weight-gradient GEMMs of a block are off the dependency chain (nothing downstream reads them), so they
         # run on a SIDE HIP stream: they overlap the HBM-bound kernels of the main chain (gate/SwiGLU/adaLN/QK-norm
@@ -428,8 +429,8 @@ class DiTEngine:
             ops.gemm_nt(g["du"], sh[pre + "mlp_input.0.weight|t"], w["dxm"])
             ops.ln_modulate_bwd(w["dxm"], a["x1"], self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"),
                                 mod[:, mo + 3 * D : mo + 4 * D], N, a["mean2"], a["rstd2"], dx, dx_alt,
-                                dmod[:, mo + 3 * D : mo + 4 * D], dmod[:, mo + 4 * D : mo + 5 * D], w["dwb"], w["ln_scr"])
-            ops.reduce_rows_f32(w["dwb"], self.G(pre + "norm_2.weight"), B, 2 * D)
+                                dmod[:, mo + 3 * D : mo + 4 * D], dmod[:, mo + 4 * D : mo + 5 * D], w["dwb"])
+            ops.reduce_rows_f32(w["dwb"], self.G(pre + "norm_2.weight"), B, 2 * D, clear=True)
             dx, dx_alt = dx_alt, dx
             # attention branch
             ops.gate_bwd(dx, a["t1"], mod[:, mo + 2 * D : mo + 3 * D], N, g["dt1"], dmod[:, mo + 2 * D : mo + 3 * D])
@@ -444,8 +445,8 @@ class DiTEngine:
             ops.gemm_nt(g["dqkv"], sh[pre + "attention.qkv.weight|t"], w["dxm"])
             ops.ln_modulate_bwd(w["dxm"], xs[i], self.P(pre + "norm_1.weight"), self.P(pre + "norm_1.bias"),
                                 mod[:, mo : mo + D], N, a["mean1"], a["rstd1"], dx, dx_alt, dmod[:, mo : mo + D],
-                                dmod[:, mo + D : mo + 2 * D], w["dwb"], w["ln_scr"])
-            ops.reduce_rows_f32(w["dwb"], self.G(pre + "norm_1.weight"), B, 2 * D)
+                                dmod[:, mo + D : mo + 2 * D], w["dwb"])
+            ops.reduce_rows_f32(w["dwb"], self.G(pre + "norm_1.weight"), B, 2 * D, clear=True)
             dx, dx_alt = dx_alt, dx
             if self.reducer is not None:  # this block's gradient range is final once BOTH streams are past this point
                 self.reducer.ready(*self.layer_ranges[i], extra_events=(side.record_event(),))
@@ -465,6 +466,8 @@ class DiTEngine:
         R = self.layout.mod_rows
         g_modw = self.grads[self.layout.entries[self.mod_name][0] :][: R * E].view(R, E)
         g_modb = self.grads[self.layout.entries["layers.0.modulation.lin.bias"][0] :][:R]
+        ops.cast_f32_to_bf16(dmod[:B], w["dmod"][:B])
+        dmod = w["dmod"]
         ops.gemm_tn(dmod, w["se"], g_modw)
         ops.colsum(dmod, g_modb, B, R)
         ops.gemm_nt(dmod, sh["@mod|t"], w["dse"], M=B, N=E, K=R)

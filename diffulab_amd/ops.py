@@ -171,20 +171,12 @@ def ln_modulate_fwd(x, w, b, scale, shift, rows_per_mod, eps, out, mean, rstd, t
           _p(out), _p(mean), _p(rstd), _p(t), _p(gate), gate.stride(0) if gate is not None else 0, _p(x_out), M, D, _s())
 
 
-_LN_SCRATCH: dict = {}
-
-
-def ln_modulate_bwd(dout, x, w, b, scale, rows_per_mod, mean, rstd, dres, dx, dscale, dshift, dwb_partial, scratch=None):
+def ln_modulate_bwd(dout, x, w, b, scale, rows_per_mod, mean, rstd, dres, dx, dscale, dshift, dwb_partial):
+    """dscale / dshift: f32 views [groups, D] (row stride = .stride(0)) accumulated into; dwb_partial f32 [groups, 2, D] or None"""
     M, D = x.shape
-    if scratch is None:  # tests / ad-hoc callers: a cached workspace per (device, size)
-        n = lib().call("dl_ln_modulate_bwd_scratch", M, D, rows_per_mod)
-        key = (x.device, n)
-        if key not in _LN_SCRATCH:
-            _LN_SCRATCH[key] = torch.empty(n, device=x.device, dtype=torch.float32)
-        scratch = _LN_SCRATCH[key]
+    assert dscale.dtype == torch.float32 and dshift.dtype == torch.float32
     _call("dl_ln_modulate_bwd", _p(dout), _p(x), _p(w), _p(b), _p(scale), scale.stride(0), rows_per_mod, _p(mean),
-          _p(rstd), _p(dres), _p(dx), _p(dscale), _p(dshift), dscale.stride(0), _p(dwb_partial), _p(scratch), M, D, _s())
-    return dx
+          _p(rstd), _p(dres), _p(dx), _p(dscale), _p(dshift), dscale.stride(0), _p(dwb_partial), M, D, _s())
 
 
 def gate_bwd(dout, t, gate, rows_per_mod, dt, dgate):
@@ -254,8 +246,8 @@ def colsum(x, out, R=None, C=None):
     _call("dl_colsum", _p(x), F32 if x.dtype == torch.float32 else BF16, x.stride(0), _p(out), R, C, _s())
 
 
-def reduce_rows_f32(partial, out, G, n):
-    _call("dl_reduce_rows_f32", _p(partial), _p(out), G, n, _s())
+def reduce_rows_f32(partial, out, G, n, clear=False):
+    _call("dl_reduce_rows_f32", _p(partial), _p(out), G, n, int(clear), _s())
 
 
 # ------------------------------------------------------------------ optimizer side

@@ -133,18 +133,19 @@ DL_API int dl_ln_modulate_fwd(const void* x, const float* w, const float* b, con
                               float* rstd, const void* t, const void* gate, int64_t ld_gate, void* x_out, int64_t M,
                               int64_t D, dl_stream_t stream);
 /* backward of the above, fused with the residual-stream add:
- *   dx[m,:]    = dres[m,:] + dLN(...)           (dres may be NULL)
- *   dscale[g,:] = sum_{m in g} dout * (xhat*w+b) ; dshift[g,:] = sum dout          (bf16 rows, stride ld_dmod)
- *   dwb_partial f32 [groups, 2, D]: per-group partial sums of dw, db (NULL when w == NULL);
- * scratch: caller workspace of dl_ln_modulate_bwd_scratch(M, D, rows_per_mod) floats (per-workgroup partial sums). */
-DL_API int64_t dl_ln_modulate_bwd_scratch(int64_t M, int64_t D, int64_t rows_per_mod); /* floats of `scratch` */
+ *   dx[m,:]     = dres[m,:] + dLN(...)           (dres may be NULL)
+ *   dscale[g,:] += sum_{m in g} dout * (xhat*w+b) ; dshift[g,:] += sum dout     (f32 rows, stride ld_dmod: the f32 image
+ *                  of the modulation-gradient matrix, zeroed by the caller once per step, cast to bf16 once at the end)
+ *   dwb_partial f32 [groups, 2, D] += per-group sums of dw, db (NULL when w == NULL); folded by dl_reduce_rows_f32.
+ * The workgroups that share a sample meet in these accumulators through f32 atomics (no second pass). */
 DL_API int dl_ln_modulate_bwd(const void* dout, const void* x, const float* w, const float* b, const void* scale,
                               int64_t ld_mod, int64_t rows_per_mod, const float* mean, const float* rstd,
-                              const void* dres, void* dx, void* dscale, void* dshift, int64_t ld_dmod,
-                              float* dwb_partial, float* scratch, int64_t M, int64_t D, dl_stream_t stream);
-/* x_new = x + gate * t backward (mmdit.py:296-307): dt = gate * dout ; dgate[g,:] = sum_{m in g} dout * t */
+                              const void* dres, void* dx, float* dscale, float* dshift, int64_t ld_dmod,
+                              float* dwb_partial, int64_t M, int64_t D, dl_stream_t stream);
+/* x_new = x + gate * t backward (mmdit.py:296-307): dt = gate * dout (bf16) ; dgate[g,:] = sum_{m in g} dout * t (f32,
+ * written, row stride ld_dmod) */
 DL_API int dl_gate_bwd(const void* dout, const void* t, const void* gate, int64_t ld_mod, int64_t rows_per_mod,
-                       void* dt, void* dgate, int64_t ld_dmod, int64_t M, int64_t D, dl_stream_t stream);
+                       void* dt, float* dgate, int64_t ld_dmod, int64_t M, int64_t D, dl_stream_t stream);
 /* QKNorm (nn.py:427-431,473-475: RMS over the FULL inner dim, eps 1e-6) + N-D RoPE on interleaved pairs
  * (nn.py:345-353,377-400) + head split 'b n (h d) -> b h n d' (mmdit.py:85-91).
  * qkv bf16 [B*N, 3D]; cos/sin f32 [N, rot/2]; q,k,v out bf16 [B,H,N,dh]; rrms f32 [B*N, 2] saved. */
@@ -191,8 +192,9 @@ DL_API int dl_silu_bwd(const float* dy, const void* pre, void* dx, int64_t n, dl
 /* out[c] += sum_r x[r,c]  (bias gradients); x bf16 or f32 per dtype */
 DL_API int dl_colsum(const void* x, int dtype, int64_t ld, float* out, int64_t R, int64_t C,
                      dl_stream_t stream);
-/* out[j] += sum_g partial[g, j]   (second stage of the LayerNorm affine gradients) */
-DL_API int dl_reduce_rows_f32(const float* partial, float* out, int64_t G, int64_t n, dl_stream_t stream);
+/* out[j] += sum_g partial[g, j]   (second stage of the LayerNorm affine gradients); clear_partial != 0 zeroes `partial`
+ * as it is read, so accumulate-into partial buffers need no memset */
+DL_API int dl_reduce_rows_f32(float* partial, float* out, int64_t G, int64_t n, int clear_partial, dl_stream_t stream);
 
 /* ------------------------------------------------------------------ optimizer side */
 /* torch.optim.AdamW single-tensor math (configs/optimizer/adamw.yaml) over a flat f32 buffer:

@@ -143,7 +143,7 @@ def test_ln_modulate_fwd_bwd(ops, D, affine):
     ops.ln_modulate_fwd(dev_bf(x.detach()), wd, bd, mod_d[:, :D], mod_d[:, D : 2 * D], N, eps, out, mean, rstd)
     assert rel(out.float(), y.reshape(M, D)) < 4e-3
     dx = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
-    dmod = torch.zeros(B, 3 * D, device=DEV, dtype=torch.bfloat16)
+    dmod = torch.zeros(B, 3 * D, device=DEV)  # f32 accumulators (atomics from the workgroups that share a sample)
     dwb = torch.zeros(B, 2, D, device=DEV) if affine else None
     ops.ln_modulate_bwd(dev_bf(dy), dev_bf(x.detach()), wd, bd, mod_d[:, :D], N, mean, rstd, dev_bf(dres), dx,
                         dmod[:, :D], dmod[:, D : 2 * D], dwb)
@@ -152,8 +152,9 @@ def test_ln_modulate_fwd_bwd(ops, D, affine):
     assert rel(dmod[:, D : 2 * D].float(), sh.grad) < 5e-3
     if affine:
         acc = torch.zeros(2 * D, device=DEV)
-        ops.reduce_rows_f32(dwb, acc, B, 2 * D)
+        ops.reduce_rows_f32(dwb, acc, B, 2 * D, clear=True)
         assert rel(acc[:D], w.grad) < 1e-4 and rel(acc[D:], b.grad) < 1e-4
+        assert float(dwb.abs().sum()) == 0.0  # cleared while read
     # no residual input
     ops.ln_modulate_bwd(dev_bf(dy), dev_bf(x.detach()), wd, bd, mod_d[:, :D], N, mean, rstd, None, dx, dmod[:, :D],
                         dmod[:, D : 2 * D], dwb)
@@ -185,7 +186,7 @@ def test_gate_bwd(ops):
     dout, t = bf(synth.normal("g.do", (M, D))), bf(synth.normal("g.t", (M, D)))
     gate = bf(synth.normal("g.g", (B, 2 * D)))
     dt = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
-    dg = torch.zeros(B, 2 * D, device=DEV, dtype=torch.bfloat16)
+    dg = torch.zeros(B, 2 * D, device=DEV)  # f32
     gd = dev_bf(gate)
     ops.gate_bwd(dev_bf(dout), dev_bf(t), gd[:, D:], N, dt, dg[:, D:])
     assert rel(dt.float(), dout * gate[:, D:].repeat_interleave(N, 0)) < 4e-3
