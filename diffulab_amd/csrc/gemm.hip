@@ -48,7 +48,7 @@ struct NtEpilogue {
 __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restrict__ A, int64_t lda,
                                                              const bf16_t* __restrict__ Bm, int64_t ldb,
                                                              void* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                             NtEpilogue ep) {
+                                                             NtEpilogue ep, int ksplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = (N + BN - 1) / BN;
   const int tiles_m = (M + BM - 1) / BM;
@@ -107,9 +107,12 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = K / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
+  // split-K (skinny GEMMs with a deep contraction, f32 plain output only): blockIdx.y owns k-steps [k_lo, k_hi) and the
+  // partial tiles meet in C through f32 atomics (C zeroed by the launcher)
+  const int nk_all = K / BK;
+  const int k_lo = (int)((int64_t)nk_all * blockIdx.y / ksplit), nk = (int)((int64_t)nk_all * (blockIdx.y + 1) / ksplit);
+  if (k_lo < nk) stage(k_lo, k_lo & 1);
+  for (int kt = k_lo; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
@@ -195,7 +198,10 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restr
         for (int e = 0; e < 8; ++e) v[e] = rr[e] + v[e];
       }
     }
-    if (ep.out_f32) {
+    if (ksplit > 1) {
+      float* cp = (float*)C + (int64_t)m * ldc + n;
+      for (int e = 0; e < 8 && n + e < N; ++e) unsafeAtomicAdd(cp + e, v[e]);
+    } else if (ep.out_f32) {
       float* cp = (float*)C + (int64_t)m * ldc + n;
       if (full) {
         *(f32x4_t*)cp = *(f32x4_t*)&v[0];
@@ -593,8 +599,25 @@ extern "C" int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb
     }
   }
   const int nwg = cdiv(M, BM) * cdiv(N, BN);
-  hipLaunchKernelGGL(gemm_nt_k, nwg, NT_THREADS, NT_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)A, lda,
-                     (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep);
+  int ksplit = 1;
+  static int splitk_on = -1;
+  if (splitk_on < 0) {
+    const char* e = getenv("DL_GEMM_NT_SPLITK");
+    splitk_on = e ? atoi(e) : 1;
+  }
+  if (splitk_on && out_dtype == DL_F32 && !bias && act == DL_ACT_NONE && !pre_out && !resid && nwg < 64 && K >= 2048) {
+    ksplit = 256 / nwg;
+    if (ksplit > K / 512) ksplit = (int)(K / 512);
+    if (ksplit > 1) {
+      const hipError_t e = (ldc == N) ? hipMemsetAsync(C, 0, (size_t)M * N * 4, (hipStream_t)stream)
+                                      : hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, (hipStream_t)stream);
+      if (e != hipSuccess) ksplit = 1;
+    } else {
+      ksplit = 1;
+    }
+  }
+  hipLaunchKernelGGL(gemm_nt_k, dim3(nwg, ksplit), NT_THREADS, NT_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)A, lda,
+                     (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep, ksplit);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

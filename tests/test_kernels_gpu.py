@@ -69,7 +69,8 @@ def test_probe_tr16_lane_map(ops):
 
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(256, 384, 384), (300, 1152, 384), (64, 16, 384), (2, 384, 256), (512, 384, 1536),
-                                   (1024, 3072, 384), (130, 72, 64), (8192, 384, 1536), (16384, 1152, 384), (12288, 384, 384), (16384, 384, 768)])
+                                   (1024, 3072, 384), (130, 72, 64), (8192, 384, 1536), (16384, 1152, 384), (12288, 384, 384), (16384, 384, 768),
+                                   (256, 384, 28416), (64, 136, 4096)])  # the last two: split-K path of the f32 output
 def test_gemm_nt_plain(ops, M, N, K):
     a = synth.normal(f"nt.a{M}", (M, K))
     b = synth.normal(f"nt.b{N}", (N, K), std=K**-0.5)
