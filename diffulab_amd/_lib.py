@@ -13,7 +13,7 @@ import re
 from functools import lru_cache
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdiffulab_hip.so")
+LIB_PATH = os.environ.get("DIFFULAB_HIP_LIB") or os.path.join(_HERE, "libdiffulab_hip.so")  # env override: A/B of two builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "diffulab_hip.h")
 
 _CTYPES = {

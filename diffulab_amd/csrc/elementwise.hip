@@ -487,13 +487,13 @@ __global__ void cast_weight_swiglu_k(const float* __restrict__ src, int F, int C
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int c = (int)(i % ld);
     const int np = (int)(i / ld);
-    const int q = np >> 4, s = np & 15;
-    const int srow = (s < 8) ? (8 * q + s) : (F + 8 * q + (s - 8));
+    const int q = np >> 5, s = np & 31;  // 32-row groups: 16 x1 rows then the 16 x3 rows of the same hidden units
+    const int srow = (s < 16) ? (16 * q + s) : (F + 16 * q + (s - 16));
     dst[i] = c < C ? f2bf(src[(int64_t)srow * C + c]) : (bf16_t)0;
   }
 }
 extern "C" int dl_cast_weight_swiglu(const float* src, int64_t F, int64_t C, void* dst, int64_t ld_dst, dl_stream_t stream) {
-  DL_CHECK_ARG(src && dst && F > 0 && F % 8 == 0 && C > 0 && ld_dst >= C, "dl_cast_weight_swiglu: bad args");
+  DL_CHECK_ARG(src && dst && F > 0 && F % 16 == 0 && C > 0 && ld_dst >= C, "dl_cast_weight_swiglu: bad args");
   hipLaunchKernelGGL(cast_weight_swiglu_k, ew_grid(2 * F * ld_dst), 256, 0, (hipStream_t)stream, src, (int)F, (int)C,
                      (bf16_t*)dst, ld_dst);
   DL_LAUNCH_CHECK();

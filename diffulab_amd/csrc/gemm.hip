@@ -375,37 +375,34 @@ __device__ __forceinline__ void nt_epilogue_regs(f32x16_t (&acc)[JN][2], int m_b
   for (int i = 0; i < 2; ++i) {
     const int m = m_base + i * 32 + (lane & 31);
     if (EPI == 2) {
-      // fused PackedSwiGLU forward (nn.py:484-486).  The weight shadow is row-permuted so that, inside every 16-column
-      // group of the tile, columns 0..7 are x1[8q..8q+7] and columns 8..15 are x3[8q..8q+7] (q = group index): BEFORE
-      // the half exchange a lane then holds x1 and x3 of the SAME 4 hidden units (acc regs 8gp+e and 8gp+4+e).
+      // fused PackedSwiGLU forward (nn.py:484-486).  The weight shadow is row-permuted so that every 32-column MFMA tile
+      // holds x1 of 16 consecutive hidden units (columns 0..15) followed by x3 of the SAME units (columns 16..31): a lane
+      // then owns x1 (acc regs 0..7) and x3 (acc regs 8..15) of the same 8 units, and after the half exchange each of the
+      // three stores (x1, x3, h) is the usual 16 B per lane / 32 contiguous bytes per row of the plain epilogue.
 #pragma unroll
       for (int j = 0; j < JN; ++j) {
-        const int q0 = (n_base + j * 32) >> 4;  // first of the two 16-column groups of this 32-wide MFMA tile
-        float hv[2][4];
+        const int u0 = ((n_base + j * 32) >> 1) + 8 * hi;  // first hidden unit this lane stores after the exchange
+        float v1[8], v3[8], hv[8], h8[8];
 #pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float x1 = acc[j][i][8 * gp + e], x3 = acc[j][i][8 * gp + 4 + e];
-            hv[gp][e] = silu_f(x1) * x3;
-            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x1), __float_as_uint(x3), false, false);
-            v[e] = __uint_as_float(sw[0]);      // lanes 0-31: x1[8q+0..3] | lanes 32-63: x3[8q+0..3]
-            v[4 + e] = __uint_as_float(sw[1]);  // lanes 0-31: x1[8q+4..7] | lanes 32-63: x3[8q+4..7]
-            acc[j][i][8 * gp + e] = 0.f;
-            acc[j][i][8 * gp + 4 + e] = 0.f;
-          }
-          // pre-activations in the reference layout u = [x1 | x3] (needed by the backward)
-          *(u32x4_t*)((bf16_t*)C + (int64_t)m * ldc + (hi ? ep.F : 0) + 8 * (q0 + gp)) = pack8(v);
-        }
-        float h8[8];
+        for (int e = 0; e < 8; ++e) hv[e] = silu_f(acc[j][i][e]) * acc[j][i][8 + e];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(hv[0][e]), __float_as_uint(hv[1][e]), false, false);
-          h8[e] = __uint_as_float(sw[0]);      // lanes 0-31: h[8q0+0..3]   | lanes 32-63: h[8(q0+1)+0..3]
-          h8[4 + e] = __uint_as_float(sw[1]);  // lanes 0-31: h[8q0+4..7]   | lanes 32-63: h[8(q0+1)+4..7]
+          auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j][i][e]), __float_as_uint(acc[j][i][4 + e]), false, false);
+          auto s3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j][i][8 + e]), __float_as_uint(acc[j][i][12 + e]), false, false);
+          auto sh = __builtin_amdgcn_permlane32_swap(__float_as_uint(hv[e]), __float_as_uint(hv[4 + e]), false, false);
+          v1[e] = __uint_as_float(s1[0]);
+          v1[4 + e] = __uint_as_float(s1[1]);
+          v3[e] = __uint_as_float(s3[0]);
+          v3[4 + e] = __uint_as_float(s3[1]);
+          h8[e] = __uint_as_float(sh[0]);
+          h8[4 + e] = __uint_as_float(sh[1]);
         }
-        *(u32x4_t*)(ep.aux + (int64_t)m * ep.ld_aux + 8 * (q0 + hi)) = pack8(h8);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+        // pre-activations in the reference layout u = [x1 | x3] (needed by the backward), then h
+        *(u32x4_t*)((bf16_t*)C + (int64_t)m * ldc + u0) = pack8(v1);
+        *(u32x4_t*)((bf16_t*)C + (int64_t)m * ldc + ep.F + u0) = pack8(v3);
+        *(u32x4_t*)(ep.aux + (int64_t)m * ep.ld_aux + u0) = pack8(h8);
       }
       continue;
     }

@@ -207,7 +207,7 @@ DL_API int dl_adamw_step(float* p, const float* g, float* m, float* v, int64_t n
 DL_API int dl_cast_weight(const float* src, int64_t R, int64_t C, void* dst, int64_t ld_dst, void* dstT,
                           int64_t ld_t, dl_stream_t stream);
 /* bf16 shadow of the packed-SwiGLU weight [2F, C] with the row order dl_gemm_nt_swiglu expects: inside every group of
- * 16 output rows, rows 0..7 are x1 rows 8q..8q+7 and rows 8..15 are x3 rows 8q..8q+7 (q = group index). */
+ * 32 output rows, rows 0..15 are x1 rows 16q..16q+15 and rows 16..31 are x3 rows 16q..16q+15 (q = group index; F % 16 == 0). */
 DL_API int dl_cast_weight_swiglu(const float* src, int64_t F, int64_t C, void* dst, int64_t ld_dst, dl_stream_t stream);
 /* plain casts */
 DL_API int dl_cast_f32_to_bf16(const float* src, void* dst, int64_t n, dl_stream_t stream);
