@@ -43,6 +43,9 @@ struct NtEpilogue {
   bf16_t* aux;
   int64_t ld_aux;
   int F;
+  // persistent big-tile kernel only: start-up skew (in units of ~0.5 us per k-step of a tile) between groups of workgroups,
+  // so that the store bursts of their tile epilogues do not hit HBM in lockstep
+  int stagger;
 };
 
 __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restrict__ A, int64_t lda,
@@ -303,6 +306,13 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
     }
   };
 
+  if (ep.stagger > 0) {
+    // every tile costs the same time, so without a skew all 256 workgroups compute together and then store together (a
+    // 50 MB write burst every ~11 us that each wave has to see acknowledged before its next-but-one k-step); four phase
+    // groups spread the bursts over the tile period and let one group's stores drain while the others run MFMAs
+    const int phase = (blockIdx.x >> 3) & 3;
+    for (int w = 0; w < phase * nk * ep.stagger; ++w) __builtin_amdgcn_s_sleep(16);
+  }
   int xrow[2], wrow[JN];
 #pragma unroll
   for (int i = 0; i < 2; ++i) xrow[i] = wm * 64 + i * 32 + (lane & 31);
@@ -519,7 +529,7 @@ __device__ __forceinline__ void nt_epilogue_regs(f32x16_t (&acc)[JN][2], int m_b
 
 template <int TN_, int NST>
 static int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
-                      int64_t N, int64_t K, const NtEpilogue& ep, int epi, hipStream_t stream) {
+                      int64_t N, int64_t K, const NtEpilogue& ep_in, int epi, hipStream_t stream) {
   constexpr int LDS = NST * (TBM + TN_) * 128;
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -535,6 +545,13 @@ static int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, vo
   const int ntiles = (int)((M / TBM) * (N / TN_));
   int grid = n_cu < ntiles ? n_cu : ntiles;
   grid &= ~7;
+  static int stagger = -1;
+  if (stagger < 0) {
+    const char* e = getenv("DL_GEMM_NT_STAGGER");
+    stagger = e ? atoi(e) : 2;
+  }
+  NtEpilogue ep = ep_in;
+  ep.stagger = (ntiles >= 6 * grid) ? stagger : 0;  // pays only when every workgroup walks many tiles (measured: MLP-up)
 #define BIG_GO(E)                                                                                                     \
   hipLaunchKernelGGL((gemm_nt_big_k<TN_, NST, E>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)A, lda, (const bf16_t*)B, \
                      ldb, C, ldc, (int)M, (int)N, (int)K, ep)
