@@ -33,6 +33,24 @@ extern "C" int dl_device_info(int device, int* cu, int* lds, int64_t* hbm, char*
   return DL_OK;
 }
 
+// HIP stream restricted to a subset of the compute units (hipExtStreamCreateWithCUMask): the engines put the weight-gradient
+// GEMMs on such a stream so that they cannot crowd the latency-bound kernels of the main dependency chain off the CUs.
+extern "C" int dl_stream_create_masked(const uint32_t* cu_mask, int words, void** stream_out) {
+  DL_CHECK_ARG(cu_mask && words > 0 && stream_out, "dl_stream_create_masked: bad args");
+  hipStream_t st = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)words, cu_mask);
+  if (e != hipSuccess) {
+    dl_set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+    return DL_ERR_LAUNCH;
+  }
+  *stream_out = (void*)st;
+  return DL_OK;
+}
+extern "C" int dl_stream_destroy(void* stream) {
+  if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) return DL_ERR_LAUNCH;
+  return DL_OK;
+}
+
 static inline int ew_grid(int64_t nvec, int threads = 256) {
   int64_t g = (nvec + threads - 1) / threads;
   if (g > 2048) g = 2048;  // 256 CUs x 8 blocks, grid-stride beyond that

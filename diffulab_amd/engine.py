@@ -17,6 +17,7 @@ mmdit.py:288-309 (DiTBlock), mmdit.py:75-104 (DiTAttention), mmdit.py:542-549 (M
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 
 import torch
@@ -222,7 +223,11 @@ class DiTEngine:
 
     def _side_stream(self) -> "torch.cuda.Stream":
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.dev)
+            mask = os.environ.get("DL_SIDE_CU_MASK", "")  # e.g. "i4" = every 4th CU, "b128" = the first 128 CUs
+            if mask:
+                self._side = ops.masked_stream(mask, self.dev)
+            else:
+                self._side = torch.cuda.Stream(device=self.dev)
         return self._side
 
     def params_changed(self) -> None:

@@ -342,6 +342,28 @@ def copy2d_bf16(src, dst, rows, cols):
     _call("dl_copy2d_bf16", _p(src), src.stride(0), _p(dst), dst.stride(0), rows, cols, _s())
 
 
+def masked_stream(pattern: str, device) -> "torch.cuda.Stream":
+    """torch stream object over a CU-masked HIP stream; pattern "i<k>" enables every k-th CU, "b<n>" the first n CUs"""
+    import ctypes
+
+    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+    if pattern[0] == "i":
+        bits = [i % int(pattern[1:]) == 0 for i in range(n_cu)]
+    elif pattern[0] == "b":
+        bits = [i < int(pattern[1:]) for i in range(n_cu)]
+    else:
+        raise ValueError(f"unknown CU mask pattern {pattern!r}")
+    words = (n_cu + 31) // 32
+    arr = (ctypes.c_uint32 * words)()
+    for i, on in enumerate(bits):
+        if on:
+            arr[i // 32] |= 1 << (i % 32)
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        lib().call("dl_stream_create_masked", arr, words, ctypes.byref(handle))
+    return torch.cuda.ExternalStream(handle.value, device=device)
+
+
 def probe_tr16() -> Tensor:
     out = torch.zeros(256, dtype=torch.int16, device="cuda")
     _call("dl_probe_tr16", _p(out), _s())

@@ -43,6 +43,11 @@ DL_API const char* dl_last_error(void);
 DL_API int dl_device_info(int device, int* cu_count, int* lds_bytes_per_cu, int64_t* hbm_bytes, char* arch,
                           int arch_len);
 
+/* a HIP stream whose kernels may only run on the compute units whose bit is set in cu_mask[words] (bit i of word i/32 = CU i);
+ * the caller owns the handle (wrap it, e.g. torch.cuda.ExternalStream) and destroys it with dl_stream_destroy */
+DL_API int dl_stream_create_masked(const uint32_t* cu_mask, int words, void** stream_out);
+DL_API int dl_stream_destroy(void* stream);
+
 /* ------------------------------------------------------------------ diffusion heads (f32 images [B, chw]) */
 /* Flow.add_noise, diffuse/modelizations/flow.py:401-408:  z = (1 - t[b]) x + t[b] eps */
 DL_API int dl_flow_add_noise(const float* x, const float* noise, const float* t, float* z, int64_t batch,

@@ -231,3 +231,27 @@ def test_loss_curve_against_reference(golden):
     got, ref = np.array(got), g["losses"]
     print("loss curve rel err per step:", np.abs(got - ref) / ref)
     assert np.all(np.abs(got - ref) / ref < 5e-3)
+
+
+def test_cifar_dit_dims_against_oracle():
+    """configs/model/dit.yaml dims (BASELINE.json configs[1]: RGB 32x32, patch 2 -> 12 features per patch, inner 512, 8 heads,
+    not classifier-free) at depth 2: loss and every gradient against the CPU oracle -- covers the ragged patch width (12 -> K
+    padded to 64) and D = 512."""
+    from diffulab_amd import Diffuser
+
+    kw = dict(input_channels=3, output_channels=3, inner_dim=512, embedding_dim=512, num_heads=8, mlp_ratio=4, patch_size=2,
+              depth=2, n_classes=10, classifier_free=False)
+    m, P = build(kw, seed=11)
+    cfg = odit.DiTConfig(**kw)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    B = 4
+    x0, noise = synth.normal("cf.x0", (B, 3, 32, 32)), synth.normal("cf.noise", (B, 3, 32, 32))
+    y, t = synth.integers("cf.y", (B,), 10), synth.uniform("cf.t", (B,), lo=0.05, hi=0.95)
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=100, extra_args={"logits_normal": True})
+    loss = d.compute_loss({"x": x0.to(DEV), "y": y.to(DEV), "p": 0.0}, timesteps=t, noise=noise.to(DEV))["loss"]
+    loss.backward()
+    ref = od.flow_loss(odit.dit_forward(Pr, od.flow_add_noise(x0, t, noise), t, y, cfg), x0, noise)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) / ref.item() < 2e-3
+    for name, p in m.named_parameters():
+        assert rel(p.grad, Pr[name].grad) < 2.5e-2, name
