@@ -48,10 +48,20 @@ struct NtEpilogue {
   int stagger;
 };
 
+// implicit-GEMM view of a 3x3 / pad 1 convolution over NHWC rows: the A operand "cols[p, (tap, ci)]" is never materialised,
+// the direct-to-LDS loads gather x[p + shift(tap), ci] and out-of-image taps read a zero line instead (unet.py:187,208)
+struct ConvGeom {
+  int H, W, Ci;        // Ci % 64 == 0 (NT: a 64-deep k-step lies inside one tap) / Ci % 128 == 0 (TN: a 128-wide column tile does)
+  int64_t ldx;         // row stride of x (elements)
+  int64_t npix;        // B*H*W real rows (rows beyond it are zero)
+  const bf16_t* zero;  // >= 16 bytes of zeros, 16-byte aligned (caller-owned)
+};
+
+template <bool CONV>
 __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restrict__ A, int64_t lda,
                                                              const bf16_t* __restrict__ Bm, int64_t ldb,
                                                              void* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                             NtEpilogue ep, int ksplit) {
+                                                             NtEpilogue ep, int ksplit, ConvGeom cg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = (N + BN - 1) / BN;
   const int tiles_m = (M + BM - 1) / BM;
@@ -65,6 +75,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restr
   const int srow = lane >> 3, sslot = lane & 7;
   const bf16_t* a_src[4];
   const bf16_t* b_src[4];
+  int tap_ok[4];  // CONV: bit t set <=> tap t of this lane's pixel row lies inside the image
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int r = (wave * 4 + c) * 8 + srow;
@@ -73,12 +84,37 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restr
     gm = gm < M ? gm : M - 1;
     int gn = n0 + r;
     gn = gn < N ? gn : N - 1;
-    a_src[c] = A + (int64_t)gm * lda + q * 8;
     b_src[c] = Bm + (int64_t)gn * ldb + q * 8;
+    if (CONV) {
+      a_src[c] = A + (int64_t)gm * cg.ldx + q * 8;
+      const int px = gm % cg.W, py = (gm / cg.W) % cg.H;
+      int ok = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+        if (yy >= 0 && yy < cg.H && xx >= 0 && xx < cg.W) ok |= 1 << t;
+      }
+      tap_ok[c] = ok;
+    } else {
+      a_src[c] = A + (int64_t)gm * lda + q * 8;
+      tap_ok[c] = 0;
+    }
   }
   auto stage = [&](int kt, int buf) {
     char* ba = smem + buf * 32768 + wave * 4096;
     char* bb = ba + 16384;
+    if (CONV) {
+      const int k0 = kt * BK;
+      const int tap = k0 / cg.Ci, ci0 = k0 - tap * cg.Ci;  // wave-uniform
+      const int64_t shift = ((int64_t)(tap / 3 - 1) * cg.W + (tap % 3 - 1)) * cg.ldx + ci0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bf16_t* src = ((tap_ok[c] >> tap) & 1) ? a_src[c] + shift : cg.zero;
+        glds16(src, ba + c * 1024);
+        glds16(b_src[c] + kt * BK, bb + c * 1024);
+      }
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       glds16(a_src[c] + kt * BK, ba + c * 1024);
@@ -630,8 +666,8 @@ extern "C" int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb
       ksplit = 1;
     }
   }
-  hipLaunchKernelGGL(gemm_nt_k, dim3(nwg, ksplit), NT_THREADS, NT_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)A, lda,
-                     (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep, ksplit);
+  hipLaunchKernelGGL(gemm_nt_k<false>, dim3(nwg, ksplit), NT_THREADS, NT_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)A, lda,
+                     (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep, ksplit, ConvGeom{});
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
@@ -677,10 +713,11 @@ __device__ __forceinline__ s16x4_t lds_tr16(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
 }
 
+template <bool CONV>
 __global__ __launch_bounds__(NT_THREADS, 2) void gemm_tn_k(const bf16_t* __restrict__ A, int64_t lda,
                                                              const bf16_t* __restrict__ Bm, int64_t ldb,
                                                              float* __restrict__ C, int64_t ldc, int M, int N, int R,
-                                                             int steps_per_split) {
+                                                             int steps_per_split, ConvGeom cg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = (N + BN - 1) / BN;
   const int tiles_m = (M + BM - 1) / BM;
@@ -708,13 +745,32 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_tn_k(const bf16_t* __restr
     cm = (cm + 8 <= M) ? cm : (M - 8);
     int cn = n0 + q * 8;
     cn = (cn + 8 <= N) ? cn : (N - 8);
-    a_src[c] = A + (int64_t)r * lda + cm;
+    if (CONV) {
+      // the 128 columns of this tile lie inside ONE tap (Ci % 128 == 0): column cm of cols is channel ci0 + (cm - m0)
+      const int tap = m0 / cg.Ci, ci0 = m0 - tap * cg.Ci;
+      a_src[c] = A + ((int64_t)r + (int64_t)(tap / 3 - 1) * cg.W + (tap % 3 - 1)) * cg.ldx + ci0 + (cm - m0);
+    } else {
+      a_src[c] = A + (int64_t)r * lda + cm;
+    }
     b_src[c] = Bm + (int64_t)r * ldb + cn;
   }
   auto stage = [&](int st, int buf) {
     char* ba = smem + buf * 32768 + wave * 4096;
     char* bb = ba + 16384;
     const int64_t r0 = (int64_t)st * BK;
+    if (CONV) {
+      const int tap = m0 / cg.Ci;
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int64_t p = r0 + (wave * 4 + c) * 4 + srow;  // pixel row of this lane
+        const int px = (int)(p % cg.W), py = (int)((p / cg.W) % cg.H);
+        const bool ok = p < cg.npix && py + dy >= 0 && py + dy < cg.H && px + dx >= 0 && px + dx < cg.W;
+        glds16(ok ? a_src[c] + r0 * cg.ldx : cg.zero, ba + c * 1024);
+        glds16(b_src[c] + r0 * ldb, bb + c * 1024);
+      }
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       glds16(a_src[c] + r0 * lda, ba + c * 1024);
@@ -954,8 +1010,54 @@ extern "C" int dl_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb
   if (splits < 1) splits = 1;
   const int sps = (nsteps + splits - 1) / splits;
   splits = (nsteps + sps - 1) / sps;
-  hipLaunchKernelGGL(gemm_tn_k, ntile * splits, NT_THREADS, 65536, (hipStream_t)stream, (const bf16_t*)A, lda,
-                     (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)R, sps);
+  hipLaunchKernelGGL(gemm_tn_k<false>, ntile * splits, NT_THREADS, 65536, (hipStream_t)stream, (const bf16_t*)A, lda,
+                     (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)R, sps, ConvGeom{});
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------- implicit-GEMM 3x3 conv
+/* out[p, co] = bias[co] + sum_{tap, ci} x[p + shift(tap), ci] * Wf[co, tap*Ci + ci] (+ resid[p, co]); x NHWC rows [B*H*W, ldx].
+ * Wf is the (tap, ci)-ordered shadow of dl_cast_conv3x3_weight (the rotated one gives the data gradient). */
+extern "C" int dl_conv3x3_nt(const void* x, int64_t ldx, int64_t Bn, int64_t H, int64_t W, int64_t Ci, const void* Wf,
+                             int64_t ldw, void* out, int64_t ldc, int64_t Co, const float* bias, const void* resid,
+                             int64_t ldr, const void* zero, dl_stream_t stream) {
+  DL_CHECK_ARG(x && Wf && out && zero && Bn > 0 && H > 0 && W > 0 && Co > 0, "dl_conv3x3_nt: bad args");
+  if (Ci % 64 != 0) return DL_ERR_UNSUPPORTED;  // caller materialises cols with dl_im2col3x3 (e.g. the 1-channel stem)
+  DL_CHECK_ARG(ldx % 8 == 0 && ldx >= Ci && ldw % 8 == 0 && ldw >= 9 * Ci && ldc % 8 == 0 && ldc >= Co,
+               "dl_conv3x3_nt: leading dims");
+  DL_CHECK_ARG((((uintptr_t)x | (uintptr_t)Wf | (uintptr_t)out | (uintptr_t)zero | (uintptr_t)resid) & 15) == 0,
+               "dl_conv3x3_nt: 16-byte alignment");
+  const int64_t M = Bn * H * W, K = 9 * Ci;
+  NtEpilogue ep{bias, DL_ACT_NONE, 0, nullptr, (const bf16_t*)resid, ldr, nullptr, 0, 1, nullptr, 0, 0};
+  ConvGeom cg{(int)H, (int)W, (int)Ci, ldx, M, (const bf16_t*)zero};
+  const int nwg = cdiv(M, BM) * cdiv(Co, BN);
+  hipLaunchKernelGGL(gemm_nt_k<true>, dim3(nwg, 1), NT_THREADS, NT_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                     (const bf16_t*)Wf, ldw, out, ldc, (int)M, (int)Co, (int)K, ep, 1, cg);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+/* weight gradient, transposed: g[(tap, ci), co] += sum_p x[p + shift(tap), ci] * dY[p, co]; dY rows [R, ldy] with R a multiple
+ * of 64 and rows >= B*H*W zero; g f32 [9*Ci, ldg] accumulated into (dl_conv3x3_wgrad_fold finishes the job). */
+extern "C" int dl_conv3x3_wgrad_tn(const void* x, int64_t ldx, int64_t Bn, int64_t H, int64_t W, int64_t Ci, const void* dY,
+                                   int64_t ldy, int64_t R, int64_t Co, float* g, int64_t ldg, const void* zero,
+                                   dl_stream_t stream) {
+  DL_CHECK_ARG(x && dY && g && zero && Bn > 0 && H > 0 && W > 0 && Co > 0, "dl_conv3x3_wgrad_tn: bad args");
+  if (Ci % 128 != 0) return DL_ERR_UNSUPPORTED;
+  DL_CHECK_ARG(R % BK == 0 && R >= Bn * H * W && Co % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldy >= Co && ldg >= Co,
+               "dl_conv3x3_wgrad_tn: dims");
+  DL_CHECK_ARG((((uintptr_t)x | (uintptr_t)dY | (uintptr_t)zero) & 15) == 0, "dl_conv3x3_wgrad_tn: 16-byte alignment");
+  const int64_t M = 9 * Ci, N = Co;
+  ConvGeom cg{(int)H, (int)W, (int)Ci, ldx, Bn * H * W, (const bf16_t*)zero};
+  const int ntile = cdiv(M, BM) * cdiv(N, BN);
+  const int nsteps = (int)(R / BK);
+  int splits = (1024 + ntile - 1) / ntile;
+  if (splits > nsteps) splits = nsteps;
+  if (splits < 1) splits = 1;
+  const int sps = (nsteps + splits - 1) / splits;
+  splits = (nsteps + sps - 1) / sps;
+  hipLaunchKernelGGL(gemm_tn_k<true>, ntile * splits, NT_THREADS, 65536, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                     (const bf16_t*)dY, ldy, g, ldg, (int)M, (int)N, (int)R, sps, cg);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

@@ -307,6 +307,28 @@ def im2col3x3(x, cols, B, H, W, C):
     _call("dl_im2col3x3", _p(x), x.stride(0), _p(cols), B, H, W, C, cols.shape[0], cols.stride(0), _s())
 
 
+def _maybe(name: str, *args) -> bool:
+    """call an entry point that may answer DL_ERR_UNSUPPORTED (-3): False then, True on success"""
+    rc = getattr(lib().cdll, name)(*args)
+    if rc == -3:
+        return False
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib().cdll.dl_last_error().decode()}")
+    return True
+
+
+def conv3x3_nt(x, B, H, W, ci, wf, out, co, bias, resid, zero) -> bool:
+    """implicit-GEMM 3x3 conv (forward, or data gradient with the rotated shadow); False -> use im2col3x3 + gemm_nt"""
+    return _maybe("dl_conv3x3_nt", _p(x), x.stride(0), B, H, W, ci, _p(wf), wf.stride(0), _p(out), out.stride(0), co, _p(bias),
+                  _p(resid), resid.stride(0) if resid is not None else 0, _p(zero), _s())
+
+
+def conv3x3_wgrad_tn(x, B, H, W, ci, dy, co, g, zero) -> bool:
+    """implicit-GEMM transposed weight gradient g[(tap, ci), co] +=; False -> use im2col3x3 + gemm_tn"""
+    return _maybe("dl_conv3x3_wgrad_tn", _p(x), x.stride(0), B, H, W, ci, _p(dy), dy.stride(0), dy.shape[0], co, _p(g),
+                  g.stride(0), _p(zero), _s())
+
+
 def cast_conv3x3_weight(w, wf, wd):
     _call("dl_cast_conv3x3_weight", _p(w), w.shape[0], w.shape[1], _p(wf), wf.stride(0), _p(wd), wd.stride(0), _s())
 

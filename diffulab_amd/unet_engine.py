@@ -212,6 +212,7 @@ class UNetEngine:
         self.reducer = None  # optional training.dp.GradReducer
         self._scratch: dict[str, Tensor] = {}
         self._saved: dict | None = None
+        self._zero = torch.zeros(64, device=self.dev, dtype=torch.bfloat16)  # out-of-image taps of the implicit-GEMM convs
         self._build_shadows()
 
     # ------------------------------------------------------------------ parameters
@@ -308,11 +309,14 @@ class UNetEngine:
     # ------------------------------------------------------------------ primitive forward / backward pairs
     def _conv3(self, x: Tensor, B: int, H: int, W: int, ci: int, name: str, co: int, resid: Tensor | None = None) -> Tensor:
         M = B * H * W
+        out = self._new(M, _rup(co, 8), zero=bool(co % 8))
+        bias = self.P(name[:-6] + "bias")
+        if ops.conv3x3_nt(x, B, H, W, ci, self.sh[name + "|f"], out, co, bias, resid, self._zero):
+            return out  # implicit GEMM: no cols matrix
         Mp, ldk = _rup(M, 64), _rup(9 * ci, 64)
         cols = self._scr("cols", Mp * ldk).view(Mp, ldk)
         ops.im2col3x3(x, cols, B, H, W, ci)
-        out = self._new(M, _rup(co, 8), zero=bool(co % 8))
-        ops.gemm_nt(cols, self.sh[name + "|f"], out, bias=self.P(name[:-6] + "bias"), resid=resid, M=M, N=co, K=ldk)
+        ops.gemm_nt(cols, self.sh[name + "|f"], out, bias=bias, resid=resid, M=M, N=co, K=ldk)
         return out
 
     def _conv3_bwd(self, dy: Tensor, x: Tensor, B: int, H: int, W: int, ci: int, name: str, co: int,
@@ -320,19 +324,22 @@ class UNetEngine:
         M = B * H * W
         Mp, ldk, co8 = _rup(M, 64), _rup(9 * ci, 64), _rup(co, 8)
         ops.colsum(dy, self.Gr(name[:-6] + "bias"), M, co)
-        cols = self._scr("cols", Mp * ldk).view(Mp, ldk)
-        ops.im2col3x3(x, cols, B, H, W, ci)
         dyp = self._padded(dy, Mp, co8)
         g = self._scr("wg", ldk * co8, torch.float32).view(ldk, co8)  # transposed: 9*Ci rows fit the 384-row wgrad tiles
         g.zero_()
-        ops.gemm_tn(cols, dyp, g, M=ldk, N=co8)
+        if not ops.conv3x3_wgrad_tn(x, B, H, W, ci, dyp, co8, g, self._zero):
+            cols = self._scr("cols", Mp * ldk).view(Mp, ldk)
+            ops.im2col3x3(x, cols, B, H, W, ci)
+            ops.gemm_tn(cols, dyp, g, M=ldk, N=co8)
         ops.conv3x3_wgrad_fold(g, self.Gr(name))
         if not need_dx:
             return None
+        dx = self._new(M, ci)
+        if ops.conv3x3_nt(dy, B, H, W, co, self.sh[name + "|d"], dx, ci, None, None, self._zero):
+            return dx
         ldd = _rup(9 * co, 64)
         dcols = self._scr("cols", Mp * ldd).view(Mp, ldd)
         ops.im2col3x3(dy, dcols, B, H, W, co)
-        dx = self._new(M, ci)
         ops.gemm_nt(dcols, self.sh[name + "|d"], dx, M=M, N=ci, K=ldd)
         return dx
 
