@@ -47,71 +47,118 @@ extern "C" int dl_nhwc_to_nchw(const void* x, float* out, int64_t B, int64_t C, 
   return DL_OK;
 }
 
-// ---------------------------------------------------------------- GroupNorm32 statistics: one workgroup per (b, group)
+// ---------------------------------------------------------------- GroupNorm32 (nn.py:11-13), NHWC rows, C % 8 == 0
+// All four kernels move 16 bytes (8 channels) per lane.  A thread owns an 8-channel chunk and walks pixels; C/G may be
+// smaller than 8 (C = 32..224), so group indices are taken per element.
+#define GN_MAXG 64
+
+// statistics: one workgroup per sample; thread (pixel lane, chunk) accumulates sum / sum of squares of its 8 channels over
+// its pixels, LDS float atomics fold them per group
 __global__ __launch_bounds__(256) void gn_stats_k(const bf16_t* __restrict__ x, float* __restrict__ st, int HW, int C, int G,
                                                   float eps) {
-  __shared__ float red[2][4];
-  const int b = blockIdx.x / G, g = blockIdx.x % G, cg = C / G;
-  const int64_t base = (int64_t)b * HW * C + g * cg;
-  const int n = HW * cg;
-  float s = 0.f, q = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const float v = bf2f(x[base + (int64_t)(i / cg) * C + (i % cg)]);
-    s += v;
-    q += v * v;
-  }
-  s = wave_sum(s);
-  q = wave_sum(q);
-  if ((threadIdx.x & 63) == 0) {
-    red[0][threadIdx.x >> 6] = s;
-    red[1][threadIdx.x >> 6] = q;
+  __shared__ float rs[GN_MAXG][2];
+  const int b = blockIdx.x, cg = C / G, C8 = C >> 3;
+  const int npl = 256 / C8 > 0 ? 256 / C8 : 1;
+  if (threadIdx.x < 2 * GN_MAXG) (&rs[0][0])[threadIdx.x] = 0.f;
+  __syncthreads();
+  for (int ch0 = 0; ch0 < C8; ch0 += 256) {  // C8 > 256 only for C > 2048
+    const int chunk = ch0 + (int)threadIdx.x % (C8 < 256 ? C8 : 256), pl = threadIdx.x / (C8 < 256 ? C8 : 256);
+    if (chunk < C8 && pl < npl) {
+      float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int p = pl; p < HW; p += npl) {
+        float v[8];
+        unpack8(*(const u32x4_t*)(x + ((int64_t)b * HW + p) * C + chunk * 8), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s[e] += v[e];
+          q[e] += v[e] * v[e];
+        }
+      }
+      if (cg >= 8) {  // the chunk lies inside one group
+        float S = 0.f, Q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          S += s[e];
+          Q += q[e];
+        }
+        atomicAdd(&rs[chunk * 8 / cg][0], S);
+        atomicAdd(&rs[chunk * 8 / cg][1], Q);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          atomicAdd(&rs[(chunk * 8 + e) / cg][0], s[e]);
+          atomicAdd(&rs[(chunk * 8 + e) / cg][1], q[e]);
+        }
+      }
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float S = red[0][0] + red[0][1] + red[0][2] + red[0][3], Q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    const float mu = S / n;
-    const float var = fmaxf(Q / n - mu * mu, 0.f);
-    st[(int64_t)blockIdx.x * 2] = mu;
-    st[(int64_t)blockIdx.x * 2 + 1] = rsqrtf(var + eps);
+  if ((int)threadIdx.x < G) {
+    const float n = (float)HW * cg;
+    const float mu = rs[threadIdx.x][0] / n;
+    const float var = fmaxf(rs[threadIdx.x][1] / n - mu * mu, 0.f);
+    st[((int64_t)b * G + threadIdx.x) * 2] = mu;
+    st[((int64_t)b * G + threadIdx.x) * 2 + 1] = rsqrtf(var + eps);
   }
 }
 extern "C" int dl_gn_stats(const void* x, float* stats, int64_t B, int64_t HW, int64_t C, int64_t G, float eps,
                            dl_stream_t stream) {
-  DL_CHECK_ARG(x && stats && B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "dl_gn_stats: bad args");
-  hipLaunchKernelGGL(gn_stats_k, (int)(B * G), 256, 0, (hipStream_t)stream, (const bf16_t*)x, stats, (int)HW, (int)C, (int)G, eps);
+  DL_CHECK_ARG(x && stats && B > 0 && HW > 0 && C > 0 && G > 0 && G <= GN_MAXG && C % G == 0 && C % 8 == 0 &&
+                   ((uintptr_t)x & 15) == 0,
+               "dl_gn_stats: bad args (C %% 8, C %% G, G <= 64, 16-byte alignment)");
+  hipLaunchKernelGGL(gn_stats_k, (int)B, 256, 0, (hipStream_t)stream, (const bf16_t*)x, stats, (int)HW, (int)C, (int)G, eps);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
 
-// out = act( (xhat*w+b) * (1+scale) + shift ), elementwise over [B*HW, C]
+// out = act( (xhat*w+b) * (1+scale) + shift ), elementwise over [B*HW, C], 8 channels per thread
 __global__ void gn_apply_fwd_k(const bf16_t* __restrict__ x, const float* __restrict__ st, const float* __restrict__ w,
                                const float* __restrict__ bb, const bf16_t* __restrict__ fs, const bf16_t* __restrict__ fh,
-                               int64_t ldf, int silu, bf16_t* __restrict__ out, int64_t n, int HW, int C, int G) {
-  const int cg = C / G;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int b = (int)(i / ((int64_t)HW * C));
-    const float mu = st[((int64_t)b * G + c / cg) * 2], r = st[((int64_t)b * G + c / cg) * 2 + 1];
-    float y = (bf2f(x[i]) - mu) * r * w[c] + bb[c];
-    if (fs) y = y * (1.0f + bf2f(fs[(int64_t)b * ldf + c])) + bf2f(fh[(int64_t)b * ldf + c]);
-    out[i] = f2bf(silu ? silu_f(y) : y);
+                               int64_t ldf, int silu, bf16_t* __restrict__ out, int64_t n8, int HW, int C, int G) {
+  const int cg = C / G, C8 = C >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % C8) * 8;
+    const int b = (int)(i / ((int64_t)HW * C8));
+    float v[8], wv[8], bv[8];
+    unpack8(*(const u32x4_t*)(x + i * 8), v);
+    *(f32x4_t*)&wv[0] = *(const f32x4_t*)(w + c0);
+    *(f32x4_t*)&wv[4] = *(const f32x4_t*)(w + c0 + 4);
+    *(f32x4_t*)&bv[0] = *(const f32x4_t*)(bb + c0);
+    *(f32x4_t*)&bv[4] = *(const f32x4_t*)(bb + c0 + 4);
+    float sc[8], sh[8];
+    if (fs) {
+      unpack8(*(const u32x4_t*)(fs + (int64_t)b * ldf + c0), sc);
+      unpack8(*(const u32x4_t*)(fh + (int64_t)b * ldf + c0), sh);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float* sg = st + ((int64_t)b * G + (c0 + e) / cg) * 2;
+      float y = (v[e] - sg[0]) * sg[1] * wv[e] + bv[e];
+      if (fs) y = y * (1.0f + sc[e]) + sh[e];
+      v[e] = silu ? silu_f(y) : y;
+    }
+    *(u32x4_t*)(out + i * 8) = pack8(v);
   }
 }
 extern "C" int dl_gn_apply_fwd(const void* x, const float* stats, const float* w, const float* b, const void* film_scale,
                                const void* film_shift, int64_t ld_film, int act_silu, void* out, int64_t B, int64_t HW,
                                int64_t C, int64_t G, dl_stream_t stream) {
-  DL_CHECK_ARG(x && stats && w && b && out && B > 0 && C % G == 0, "dl_gn_apply_fwd: bad args");
+  DL_CHECK_ARG(x && stats && w && b && out && B > 0 && C % G == 0 && C % 8 == 0, "dl_gn_apply_fwd: bad args");
   DL_CHECK_ARG((film_scale == nullptr) == (film_shift == nullptr), "dl_gn_apply_fwd: scale and shift go together");
-  const int64_t n = B * HW * C;
-  hipLaunchKernelGGL(gn_apply_fwd_k, grid_for(n), 256, 0, (hipStream_t)stream, (const bf16_t*)x, stats, w, b,
-                     (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, (bf16_t*)out, n, (int)HW, (int)C,
+  DL_CHECK_ARG((((uintptr_t)x | (uintptr_t)out | (uintptr_t)w | (uintptr_t)b | (uintptr_t)film_scale | (uintptr_t)film_shift) & 15) == 0 &&
+                   ld_film % 8 == 0,
+               "dl_gn_apply_fwd: 16-byte alignment");
+  const int64_t n8 = B * HW * C / 8;
+  hipLaunchKernelGGL(gn_apply_fwd_k, grid_for(n8), 256, 0, (hipStream_t)stream, (const bf16_t*)x, stats, w, b,
+                     (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, (bf16_t*)out, n8, (int)HW, (int)C,
                      (int)G);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
 
 // backward pass 1: per (b, c) sums over pixels:  S[b][0][c] = sum dh*y, [1] = sum dh, [2] = sum dy*xhat, [3] = sum dy
-// (dh = dout * act'(h), dy = dh * (1+scale)).  One workgroup per (b, 64-channel slab): 64 channels x 4 pixel lanes.
+// (dh = dout * act'(h), dy = dh * (1+scale)).  One workgroup per (b, 64-channel slab): 8 chunks x 32 pixel lanes, LDS float
+// atomics fold the pixel lanes; dw / db meet in global f32 atomics (B contributions per channel), FiLM gradients are written.
 __global__ __launch_bounds__(256) void gn_bwd_reduce_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
                                                        const float* __restrict__ st, const float* __restrict__ w,
                                                        const float* __restrict__ bb, const bf16_t* __restrict__ fs,
@@ -119,72 +166,85 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_k(const bf16_t* __restrict_
                                                        float* __restrict__ S, float* __restrict__ dw, float* __restrict__ db,
                                                        bf16_t* __restrict__ dfs, bf16_t* __restrict__ dfh, int64_t lddf, int HW,
                                                        int C, int G) {
-  __shared__ float red[4][4][64];
+  __shared__ float red[4][64];
   const int slabs = (C + 63) / 64;
-  const int b = blockIdx.x / slabs, c = (blockIdx.x % slabs) * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (c < C) {
-    const int cg = C / G;
-    const float mu = st[((int64_t)b * G + c / cg) * 2], r = st[((int64_t)b * G + c / cg) * 2 + 1];
-    const float wc = w[c], bc = bb[c];
-    const float sc = fs ? bf2f(fs[(int64_t)b * ldf + c]) : 0.f, sh = fs ? bf2f(fh[(int64_t)b * ldf + c]) : 0.f;
-    for (int p = pl; p < HW; p += 4) {
-      const int64_t i = ((int64_t)b * HW + p) * C + c;
-      const float xh = (bf2f(x[i]) - mu) * r;
-      const float y = xh * wc + bc;
-      const float h = y * (1.0f + sc) + sh;
-      const float dh = bf2f(dout[i]) * (silu ? dsilu_f(h) : 1.0f);
-      const float dy = dh * (1.0f + sc);
-      a0 += dh * y;
-      a1 += dh;
-      a2 += dy * xh;
-      a3 += dy;
-    }
-  }
-  red[pl][0][threadIdx.x & 63] = a0;
-  red[pl][1][threadIdx.x & 63] = a1;
-  red[pl][2][threadIdx.x & 63] = a2;
-  red[pl][3][threadIdx.x & 63] = a3;
+  const int b = blockIdx.x / slabs, cbase = (blockIdx.x % slabs) * 64;
+  const int chunk = threadIdx.x & 7, pl = threadIdx.x >> 3;  // 8 chunks x 32 pixel lanes
+  const int c0_raw = cbase + chunk * 8;
+  (&red[0][0])[threadIdx.x] = 0.f;
   __syncthreads();
-  if (pl == 0 && c < C) {
-    const int l = threadIdx.x & 63;
-    float v[4];
+  {
+    // (slabs beyond C: chunks with c0 >= C compute on channel 0 of the slab and are dropped at the end, so that every
+    // lane of the wave takes part in the shuffles)
+    const bool live = c0_raw < C;
+    const int c0 = live ? c0_raw : cbase;
+    const int cg = C / G;
+    float mu[8], rs[8], wv[8], bv[8], sc[8], sh[8], a0[8], a1[8], a2[8], a3[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      v[k] = red[0][k][l] + red[1][k][l] + red[2][k][l] + red[3][k][l];
-      S[((int64_t)b * 4 + k) * C + c] = v[k];
+    for (int e = 0; e < 8; ++e) {
+      const float* sg = st + ((int64_t)b * G + (c0 + e) / cg) * 2;
+      mu[e] = sg[0];
+      rs[e] = sg[1];
+      wv[e] = w[c0 + e];
+      bv[e] = bb[c0 + e];
+      sc[e] = fs ? bf2f(fs[(int64_t)b * ldf + c0 + e]) : 0.f;
+      sh[e] = fs ? bf2f(fh[(int64_t)b * ldf + c0 + e]) : 0.f;
+      a0[e] = a1[e] = a2[e] = a3[e] = 0.f;
     }
+    for (int p = pl; p < HW; p += 32) {
+      const int64_t i = ((int64_t)b * HW + p) * C + c0;
+      float xv[8], dv[8];
+      unpack8(*(const u32x4_t*)(x + i), xv);
+      unpack8(*(const u32x4_t*)(dout + i), dv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (xv[e] - mu[e]) * rs[e];
+        const float y = xh * wv[e] + bv[e];
+        const float h = y * (1.0f + sc[e]) + sh[e];
+        const float dh = dv[e] * (silu ? dsilu_f(h) : 1.0f);
+        const float dy = dh * (1.0f + sc[e]);
+        a0[e] += dh * y;
+        a1[e] += dh;
+        a2[e] += dy * xh;
+        a3[e] += dy;
+      }
+    }
+    // fold the 8 pixel lanes of this wave (lane bits 3..5) with shuffles, then one LDS atomic per (wave, value)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int m = 8; m < 64; m <<= 1) {
+        a0[e] += __shfl_xor(a0[e], m);
+        a1[e] += __shfl_xor(a1[e], m);
+        a2[e] += __shfl_xor(a2[e], m);
+        a3[e] += __shfl_xor(a3[e], m);
+      }
+    }
+    if ((threadIdx.x & 63) < 8 && live) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        atomicAdd(&red[0][chunk * 8 + e], a0[e]);
+        atomicAdd(&red[1][chunk * 8 + e], a1[e]);
+        atomicAdd(&red[2][chunk * 8 + e], a2[e]);
+        atomicAdd(&red[3][chunk * 8 + e], a3[e]);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 && cbase + (int)threadIdx.x < C) {
+    const int c = cbase + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) S[((int64_t)b * 4 + k) * C + c] = red[k][threadIdx.x];
     if (dfs) {
-      dfs[(int64_t)b * lddf + c] = f2bf(v[0]);
-      dfh[(int64_t)b * lddf + c] = f2bf(v[1]);
+      dfs[(int64_t)b * lddf + c] = f2bf(red[0][threadIdx.x]);
+      dfh[(int64_t)b * lddf + c] = f2bf(red[1][threadIdx.x]);
     }
-    unsafeAtomicAdd(&dw[c], v[2]);  // B contributions per channel
-    unsafeAtomicAdd(&db[c], v[3]);
+    unsafeAtomicAdd(&dw[c], red[2][threadIdx.x]);
+    unsafeAtomicAdd(&db[c], red[3][threadIdx.x]);
   }
 }
-// backward pass 2: dx = r * (dy*w - A/n - xhat*Bv/n), A = sum_{c in g} w[c] S[3][c], Bv = sum_{c in g} w[c] S[2][c]
-__global__ void gn_bwd_apply_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x, const float* __restrict__ st,
-                               const float* __restrict__ w, const float* __restrict__ bb, const bf16_t* __restrict__ fs,
-                               const bf16_t* __restrict__ fh, int64_t ldf, int silu, const float* __restrict__ S,
-                               const float* __restrict__ AB, const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, int64_t n,
-                               int HW, int C, int G) {
-  const int cg = C / G;
-  const float inv_n = 1.0f / (float)(HW * cg);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int b = (int)(i / ((int64_t)HW * C));
-    const int g = c / cg;
-    const float mu = st[((int64_t)b * G + g) * 2], r = st[((int64_t)b * G + g) * 2 + 1];
-    const float xh = (bf2f(x[i]) - mu) * r;
-    const float sc = fs ? bf2f(fs[(int64_t)b * ldf + c]) : 0.f, sh = fs ? bf2f(fh[(int64_t)b * ldf + c]) : 0.f;
-    const float h = (xh * w[c] + bb[c]) * (1.0f + sc) + sh;
-    const float dy = bf2f(dout[i]) * (silu ? dsilu_f(h) : 1.0f) * (1.0f + sc);
-    const float A = AB[((int64_t)b * G + g) * 2], Bv = AB[((int64_t)b * G + g) * 2 + 1];
-    dx[i] = f2bf(r * (dy * w[c] - A * inv_n - xh * Bv * inv_n) + (dres ? bf2f(dres[i]) : 0.f));
-  }
-}
+// per (b, g): A = sum_{c in g} w[c] S[3][c], Bv = sum_{c in g} w[c] S[2][c]
 __global__ void gn_group_sums_k(const float* __restrict__ S, const float* __restrict__ w, float* __restrict__ AB, int C, int G) {
-  // one thread per (b, g)
   const int cg = C / G;
   const int b = blockIdx.x, g = threadIdx.x;
   if (g >= G) return;
@@ -196,13 +256,63 @@ __global__ void gn_group_sums_k(const float* __restrict__ S, const float* __rest
   AB[((int64_t)b * G + g) * 2] = A;
   AB[((int64_t)b * G + g) * 2 + 1] = Bv;
 }
+// backward pass 2: dx = r * (dy*w - A/n - xhat*Bv/n) (+ dres), 8 channels per thread
+__global__ void gn_bwd_apply_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x, const float* __restrict__ st,
+                               const float* __restrict__ w, const float* __restrict__ bb, const bf16_t* __restrict__ fs,
+                               const bf16_t* __restrict__ fh, int64_t ldf, int silu, const float* __restrict__ AB,
+                               const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, int64_t n8, int HW, int C, int G) {
+  const int cg = C / G, C8 = C >> 3;
+  const float inv_n = 1.0f / (float)(HW * cg);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % C8) * 8;
+    const int b = (int)(i / ((int64_t)HW * C8));
+    float xv[8], dv[8], rv[8], sc[8], sh[8];
+    unpack8(*(const u32x4_t*)(x + i * 8), xv);
+    unpack8(*(const u32x4_t*)(dout + i * 8), dv);
+    if (dres) unpack8(*(const u32x4_t*)(dres + i * 8), rv);
+    if (fs) {
+      unpack8(*(const u32x4_t*)(fs + (int64_t)b * ldf + c0), sc);
+      unpack8(*(const u32x4_t*)(fh + (int64_t)b * ldf + c0), sh);
+    }
+    float wv[8], bv[8];
+    *(f32x4_t*)&wv[0] = *(const f32x4_t*)(w + c0);
+    *(f32x4_t*)&wv[4] = *(const f32x4_t*)(w + c0 + 4);
+    *(f32x4_t*)&bv[0] = *(const f32x4_t*)(bb + c0);
+    *(f32x4_t*)&bv[4] = *(const f32x4_t*)(bb + c0 + 4);
+    int g_prev = -1;
+    float mu = 0.f, r = 0.f, A = 0.f, Bv = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (c0 + e) / cg;
+      if (g != g_prev) {  // one f32x2 pair of loads per group run (a single run when C/G >= 8)
+        const float* sg = st + ((int64_t)b * G + g) * 2;
+        const float* ag = AB + ((int64_t)b * G + g) * 2;
+        mu = sg[0];
+        r = sg[1];
+        A = ag[0] * inv_n;
+        Bv = ag[1] * inv_n;
+        g_prev = g;
+      }
+      const float xh = (xv[e] - mu) * r;
+      const float s1 = fs ? 1.0f + sc[e] : 1.0f;
+      const float h = (xh * wv[e] + bv[e]) * s1 + (fs ? sh[e] : 0.f);
+      const float dy = dv[e] * (silu ? dsilu_f(h) : 1.0f) * s1;
+      xv[e] = r * (dy * wv[e] - A - xh * Bv) + (dres ? rv[e] : 0.f);
+    }
+    *(u32x4_t*)(dx + i * 8) = pack8(xv);
+  }
+}
 /* scratch: f32 [B*4*C + B*G*2] */
 extern "C" int dl_gn_bwd(const void* dout, const void* x, const float* stats, const float* w, const float* b,
                          const void* film_scale, const void* film_shift, int64_t ld_film, int act_silu, const void* dres,
                          void* dx, float* dw, float* db, void* dfilm_scale, void* dfilm_shift, int64_t ld_dfilm, float* scratch, int64_t B,
                          int64_t HW, int64_t C, int64_t G, dl_stream_t stream) {
-  DL_CHECK_ARG(dout && x && stats && w && b && dx && dw && db && scratch && B > 0 && C % G == 0 && G <= 256, "dl_gn_bwd: bad args");
+  DL_CHECK_ARG(dout && x && stats && w && b && dx && dw && db && scratch && B > 0 && C % G == 0 && C % 8 == 0 && G <= 256,
+               "dl_gn_bwd: bad args");
   DL_CHECK_ARG((film_scale == nullptr) == (dfilm_scale == nullptr), "dl_gn_bwd: film grads iff film inputs");
+  DL_CHECK_ARG((((uintptr_t)dout | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dres | (uintptr_t)film_scale | (uintptr_t)film_shift) & 15) == 0 &&
+                   ld_film % 8 == 0,
+               "dl_gn_bwd: 16-byte alignment");
   float* S = scratch;
   float* AB = scratch + B * 4 * C;
   const int slabs = (int)((C + 63) / 64);
@@ -210,10 +320,10 @@ extern "C" int dl_gn_bwd(const void* dout, const void* x, const float* stats, co
                      b, (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, S, dw, db, (bf16_t*)dfilm_scale,
                      (bf16_t*)dfilm_shift, ld_dfilm, (int)HW, (int)C, (int)G);
   hipLaunchKernelGGL(gn_group_sums_k, (int)B, 256, 0, (hipStream_t)stream, S, w, AB, (int)C, (int)G);
-  const int64_t n = B * HW * C;
-  hipLaunchKernelGGL(gn_bwd_apply_k, grid_for(n), 256, 0, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)x, stats, w, b,
-                     (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, S, AB, (const bf16_t*)dres,
-                     (bf16_t*)dx, n, (int)HW, (int)C, (int)G);
+  const int64_t n8 = B * HW * C / 8;
+  hipLaunchKernelGGL(gn_bwd_apply_k, grid_for(n8), 256, 0, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)x, stats, w, b,
+                     (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, AB, (const bf16_t*)dres,
+                     (bf16_t*)dx, n8, (int)HW, (int)C, (int)G);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
