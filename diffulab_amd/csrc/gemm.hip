@@ -445,9 +445,11 @@ __device__ __forceinline__ void nt_epilogue_regs(f32x16_t (&acc)[JN][2], int m_b
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
-        // pre-activations in the reference layout u = [x1 | x3] (needed by the backward), then h
-        *(u32x4_t*)((bf16_t*)C + (int64_t)m * ldc + u0) = pack8(v1);
-        *(u32x4_t*)((bf16_t*)C + (int64_t)m * ldc + ep.F + u0) = pack8(v3);
+        // pre-activations in the reference layout u = [x1 | x3] (needed by the backward only: C == NULL in inference), then h
+        if (C) {
+          *(u32x4_t*)((bf16_t*)C + (int64_t)m * ldc + u0) = pack8(v1);
+          *(u32x4_t*)((bf16_t*)C + (int64_t)m * ldc + ep.F + u0) = pack8(v3);
+        }
         *(u32x4_t*)(ep.aux + (int64_t)m * ep.ld_aux + u0) = pack8(h8);
       }
       continue;
@@ -677,9 +679,9 @@ extern "C" int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb
  * no big-tile kernel (caller then runs dl_gemm_nt + dl_swiglu_fwd). */
 extern "C" int dl_gemm_nt_swiglu(const void* X, int64_t ldx, const void* Wp, int64_t ldw, void* U, int64_t ldu, void* H,
                                  int64_t ldh, int64_t M, int64_t F, int64_t K, dl_stream_t stream) {
-  DL_CHECK_ARG(X && Wp && U && H && M > 0 && F > 0 && K > 0, "dl_gemm_nt_swiglu: null/empty operand");
-  DL_CHECK_ARG(K % BK == 0 && F % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldu % 8 == 0 && ldh % 8 == 0,
-               "dl_gemm_nt_swiglu: K %% 64, F/ld %% 8");
+  DL_CHECK_ARG(X && Wp && H && M > 0 && F > 0 && K > 0, "dl_gemm_nt_swiglu: null/empty operand");  // U may be NULL (inference)
+  DL_CHECK_ARG(K % BK == 0 && F % 16 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && (!U || ldu % 8 == 0) && ldh % 8 == 0,
+               "dl_gemm_nt_swiglu: K %% 64, F %% 16, ld %% 8");
   NtEpilogue ep{nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 1, (bf16_t*)H, ldh, (int)F};
   const int rc = dispatch_big(X, ldx, Wp, ldw, U, ldu, M, 2 * F, K, ep, 2, (hipStream_t)stream);
   if (rc == 1) {

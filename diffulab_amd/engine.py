@@ -361,7 +361,7 @@ class DiTEngine:
             ops.ln_modulate_fwd(xin, self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"),
                                 mod[:, mo + 3 * D : mo + 4 * D], mod[:, mo + 4 * D : mo + 5 * D], N, 1e-5, a["xm2"],
                                 a["mean2"], a["rstd2"], t=a["t1"], gate=mod[:, mo + 2 * D : mo + 3 * D], x_out=a["x1"])
-            if not ops.gemm_nt_swiglu(a["xm2"], sh[pre + "mlp_input.0.weight|g"], a["u"], a["h"]):
+            if not ops.gemm_nt_swiglu(a["xm2"], sh[pre + "mlp_input.0.weight|g"], a["u"] if train else None, a["h"]):
                 ops.gemm_nt(a["xm2"], sh[pre + "mlp_input.0.weight|f"], a["u"])  # small / ragged shapes: unfused pair
                 ops.swiglu_fwd(a["u"], a["h"])
             ops.gemm_nt(a["h"], sh[pre + "mlp_input.2.weight|f"], a["t2"])

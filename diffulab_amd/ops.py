@@ -133,9 +133,10 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias: Tensor | None = None, ac
     return out
 
 
-def gemm_nt_swiglu(x: Tensor, w_perm: Tensor, u: Tensor, h: Tensor) -> bool:
-    """fused MLP-up GEMM + SwiGLU; False when the shape has no fused kernel (caller falls back to gemm_nt + swiglu_fwd)"""
-    rc = lib().cdll.dl_gemm_nt_swiglu(_p(x), x.stride(0), _p(w_perm), w_perm.stride(0), _p(u), u.stride(0), _p(h),
+def gemm_nt_swiglu(x: Tensor, w_perm: Tensor, u: Tensor | None, h: Tensor) -> bool:
+    """fused MLP-up GEMM + SwiGLU; u=None skips the pre-activation store (inference).  False when the shape has no fused
+    kernel (caller falls back to gemm_nt + swiglu_fwd)"""
+    rc = lib().cdll.dl_gemm_nt_swiglu(_p(x), x.stride(0), _p(w_perm), w_perm.stride(0), _p(u), u.stride(0) if u is not None else 0, _p(h),
                                       h.stride(0), x.shape[0], h.shape[1], x.shape[1], _s())
     if rc == -3:
         return False

@@ -111,7 +111,8 @@ DL_API int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, vo
                       const void* resid, int64_t ldr, const void* gate, int64_t ldg, int64_t rows_per_gate,
                       dl_stream_t stream);
 /* mlp_input[0] + PackedSwiGLU fused (mmdit.py:260-264, nn.py:484-486): U[M,2F] = X Wp^T written in the reference
- * layout [x1 | x3] (kept for the backward) and H[M,F] = silu(x1) * x3, in ONE pass over the accumulators.
+ * layout [x1 | x3] (kept for the backward; U == NULL skips it: inference / sampler loops) and H[M,F] = silu(x1) * x3, in
+ * ONE pass over the accumulators.
  * Wp = row-permuted bf16 shadow of the [2F, K] weight made by dl_cast_weight_swiglu.  Only shapes served by the
  * big-tile kernels (M % 256 == 0, 2F % 192 == 0, >= 64 tiles) -- otherwise DL_ERR_UNSUPPORTED and the caller runs
  * dl_gemm_nt + dl_swiglu_fwd. */
