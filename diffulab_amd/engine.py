@@ -153,6 +153,7 @@ class DiTEngine:
         self._shadow_key: tuple | None = None
         self.manual_version = 0
         self._ws_key: tuple | None = None
+        self._ws_cache: dict[tuple, tuple] = {}
         self._rope: dict[tuple[int, int], tuple[Tensor, Tensor]] = {}
         self.reducer = None  # optional training.dp.GradReducer: gets ready(lo, hi) as gradient ranges complete
         self._build_shadows()
@@ -239,6 +240,10 @@ class DiTEngine:
         key = (B, H, W, train)
         if key == self._ws_key:
             return
+        if key in self._ws_cache:  # workspaces are kept per shape: captured hipGraphs have their addresses baked in
+            self.ws, self.geo = self._ws_cache[key]
+            self._ws_key = key
+            return
         d, dev = self.d, self.dev
         D, E, p, L = d.inner_dim, d.embedding_dim, d.patch_size, d.depth
         gh, gw = H // p, W // p
@@ -300,12 +305,15 @@ class DiTEngine:
             w["scr_conv"] = z(D, 64, dtype=f32)
         self.ws, self._ws_key = w, key
         self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)
+        if len(self._ws_cache) >= 8:  # bound the cache: drop the oldest shape (its graphs are dropped by the module too)
+            self._ws_cache.pop(next(iter(self._ws_cache)))
+        self._ws_cache[key] = (w, self.geo)
         if (gh, gw) not in self._rope:
             c, s = rope_grid_tables(gh, gw, d.rope_axes_dim, d.rope_base)
             self._rope[(gh, gw)] = (c.to(dev), s.to(dev))
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x: Tensor, t: Tensor, y_eff: Tensor | None, train: bool = True) -> Tensor:
+    def forward(self, x: Tensor, t: Tensor, y_eff: Tensor | None, train: bool = True, refresh: bool = True) -> Tensor:
         """x f32 [B,C,H,W]; t f32 [B] (flow: in [0,1]; ddpm: indices as floats, both fed unscaled like the
         reference); y_eff int64 [B] labels AFTER the classifier-free drop, or None.  Returns pred f32 [B,Co,H,W]
         (a workspace buffer: consume it before the next forward)."""
@@ -313,7 +321,8 @@ class DiTEngine:
         B, C, H, W = x.shape
         assert C == d.input_channels and x.dtype == torch.float32 and x.is_cuda
         self._alloc(B, H, W, train)
-        self.refresh_shadows(force=train)  # a training forward always follows a parameter update
+        if refresh:  # (False while a hipGraph of this forward is being captured: the replay path refreshes eagerly)
+            self.refresh_shadows(force=train)  # a training forward always follows a parameter update
         w, sh = self.ws, self.sh
         _, _, _, gh, gw, N, M, Bp, Fo = self.geo
         D, E, L, Hh = d.inner_dim, d.embedding_dim, d.depth, d.num_heads

@@ -488,12 +488,13 @@ class UNetEngine:
         return dh
 
     # ------------------------------------------------------------------ forward (unet.py:832-853)
-    def forward(self, x: Tensor, t: Tensor, y_eff: Tensor | None, train: bool) -> Tensor:
+    def forward(self, x: Tensor, t: Tensor, y_eff: Tensor | None, train: bool, refresh: bool = True) -> Tensor:
         """x f32 [B, in_channels, H, W], t f32 [B], y_eff int64 [B] or None -> prediction f32 [B, out_channels, H, W]"""
         d, plan = self.d, self.plan
         B, Cin, H, W = x.shape
         assert (H, W) == tuple(d.image_size) and Cin == d.in_channels
-        self.refresh_shadows(force=train)
+        if refresh:
+            self.refresh_shadows(force=train)
         mc, te = d.model_channels, 4 * d.model_channels
         Bp = _rup(B, 64)
         save: list | None = [] if train else None
