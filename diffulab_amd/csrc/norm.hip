@@ -146,31 +146,34 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_k(const bf16_t* __restrict__ d
                                                     const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
                                                     bf16_t* __restrict__ dx, float* __restrict__ dscale,
                                                     float* __restrict__ dshift, int64_t ld_dmod, float* __restrict__ dwb,
+                                                    const bf16_t* __restrict__ gt, const bf16_t* __restrict__ ggate,
+                                                    int64_t ld_gate, bf16_t* __restrict__ gdt, float* __restrict__ dgate,
                                                     int split, int64_t M, int D) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = (float*)smem;  // [4][D]
+  float* red = (float*)smem;  // [5][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D8 = D >> 3;
   const float invD = 1.0f / (float)D;
   const int64_t g = blockIdx.x / split;
   const int sp = blockIdx.x - (int)g * split;
   const int64_t rows_per_wg = rows_per_mod / split;
-  for (int i = threadIdx.x; i < 4 * D; i += 256) red[i] = 0.f;
-  float wv[NJ][8], bv[NJ][8], sc[NJ][8];
+  for (int i = threadIdx.x; i < 5 * D; i += 256) red[i] = 0.f;
+  float wv[NJ][8], bv[NJ][8], sc[NJ][8], gv[NJ][8];
   load_row_f32<NJ>(w, D8, lane, wv, 1.0f);
   load_row_f32<NJ>(b, D8, lane, bv, 0.0f);
   load_row<NJ>(scale + g * ld_mod, D8, lane, sc);
-  float a_dsc[NJ][8], a_dsh[NJ][8], a_dw[NJ][8], a_db[NJ][8];
+  if (gt) load_row<NJ>(ggate + g * ld_gate, D8, lane, gv);
+  float a_dsc[NJ][8], a_dsh[NJ][8], a_dw[NJ][8], a_db[NJ][8], a_dg[NJ][8];
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) a_dsc[j][e] = a_dsh[j][e] = a_dw[j][e] = a_db[j][e] = 0.f;
+    for (int e = 0; e < 8; ++e) a_dsc[j][e] = a_dsh[j][e] = a_dw[j][e] = a_db[j][e] = a_dg[j][e] = 0.f;
 
   const int64_t row_begin = g * rows_per_mod + sp * rows_per_wg;
   const int64_t row_end = row_begin + rows_per_wg < M ? row_begin + rows_per_wg : M;
   // software prefetch: the packed bf16 rows (dout, x, dres) of the NEXT row are requested before the current row is
   // processed, so every wave keeps two rows of loads in flight (this kernel often runs at one wave per SIMD next to a GEMM)
-  u32x4_t pd[NJ], px[NJ], pr[NJ];
+  u32x4_t pd[NJ], px[NJ], pr[NJ], pt[NJ];
   float pmu = 0.f, prs = 0.f;
   auto fetch = [&](int64_t row) {
 #pragma unroll
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_k(const bf16_t* __restrict__ d
         pd[j] = *(const u32x4_t*)(dout + row * D + c * 8);
         px[j] = *(const u32x4_t*)(x + row * D + c * 8);
         if (dres) pr[j] = *(const u32x4_t*)(dres + row * D + c * 8);
+        if (gt) pt[j] = *(const u32x4_t*)(gt + row * D + c * 8);
       }
     }
     pmu = mean[row];
@@ -189,9 +193,11 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_k(const bf16_t* __restrict__ d
   if (row < row_end) fetch(row);
   for (; row < row_end; row += LNB1_WAVES) {
     float dv[NJ][8], xv[NJ][8], rv[NJ][8];
+    u32x4_t tq[NJ];  // this row's t (gate fusion), saved before the prefetch of the next row overwrites pt
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const bool on = (lane + 64 * j) < D8;
+      tq[j] = pt[j];
       if (on) {
         unpack8(pd[j], dv[j]);
         unpack8(px[j], xv[j]);
@@ -232,6 +238,24 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_k(const bf16_t* __restrict__ d
 #pragma unroll
       for (int e = 0; e < 8; ++e) rv[j][e] += rs * (dv[j][e] - c1 - xv[j][e] * c2);
     store_row<NJ>(dx + row * D, D8, lane, rv);
+    if (gt) {
+      // fused backward of the gated residual that FOLLOWS in the chain (x_new = x + gate * t, mmdit.py:302,308): this row
+      // of dx is its upstream gradient -> dt = gate * dx (to the projection / MLP-down dgrad), dgate += dx * t.
+      // dx is taken as stored (bf16), exactly what a separate pass would re-read.
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const bool on = (lane + 64 * j) < D8;
+        float tv[8];
+        if (on) unpack8(tq[j], tv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dxr = bf2f(f2bf(rv[j][e]));
+          a_dg[j][e] += on ? dxr * tv[e] : 0.f;
+          rv[j][e] = dxr * gv[j][e];
+        }
+      }
+      store_row<NJ>(gdt + row * D, D8, lane, rv);
+    }
   }
 
   // cross-wave reduction of the four column sums: LDS float atomics into ONE [4][D] slab (6 KiB at D = 384), so the
@@ -248,17 +272,19 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_k(const bf16_t* __restrict__ d
         atomicAdd(base + D + e, a_dsh[j][e]);
         atomicAdd(base + 2 * D + e, a_dw[j][e]);
         atomicAdd(base + 3 * D + e, a_db[j][e]);
+        if (gt) atomicAdd(base + 4 * D + e, a_dg[j][e]);
       }
     }
   }
   __syncthreads();
   // the `split` workgroups of one sample meet in global f32 accumulators (<= split-way contention per address): the
   // modulation gradients land in the f32 image of dmod, the affine gradients in the per-sample partial [groups, 2, D]
-  for (int i = threadIdx.x; i < 4 * D; i += 256) {
+  for (int i = threadIdx.x; i < (gt ? 5 : 4) * D; i += 256) {
     const int which = i / D, col = i - which * D;
     const float v = red[i];
     if (which == 0) unsafeAtomicAdd(dscale + g * ld_dmod + col, v);
     else if (which == 1) unsafeAtomicAdd(dshift + g * ld_dmod + col, v);
+    else if (which == 4) unsafeAtomicAdd(dgate + g * ld_dmod + col, v);
     else if (dwb) unsafeAtomicAdd(dwb + (size_t)g * 2 * D + (which - 2) * D + col, v);
   }
 }
@@ -266,7 +292,8 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_k(const bf16_t* __restrict__ d
 extern "C" int dl_ln_modulate_bwd(const void* dout, const void* x, const float* w, const float* b, const void* scale,
                                   int64_t ld_mod, int64_t rows_per_mod, const float* mean, const float* rstd,
                                   const void* dres, void* dx, float* dscale, float* dshift, int64_t ld_dmod,
-                                  float* dwb_partial, int64_t M, int64_t D, dl_stream_t stream) {
+                                  float* dwb_partial, const void* gate_t, const void* gate, int64_t ld_gate, void* dt,
+                                  float* dgate, int64_t M, int64_t D, dl_stream_t stream) {
   DL_CHECK_ARG(dout && x && scale && mean && rstd && dx && dscale && dshift && M > 0, "dl_ln_modulate_bwd: null operand");
   DL_CHECK_ARG((w == nullptr) == (b == nullptr), "dl_ln_modulate_bwd: w and b must both be given or both NULL");
   DL_CHECK_ARG(D % 8 == 0 && D <= 512 * MAXJ && ld_mod % 8 == 0 && rows_per_mod > 0 && M % rows_per_mod == 0,
@@ -276,11 +303,14 @@ extern "C" int dl_ln_modulate_bwd(const void* dout, const void* x, const float* 
   const int nj = cdiv(D, 512);
   const int groups = (int)(M / rows_per_mod);
   const int split = (rows_per_mod % 64 == 0) ? (int)(rows_per_mod / 64) : 1;
-  const size_t lds = (size_t)4 * D * sizeof(float);
+  DL_CHECK_ARG(!gate_t || (gate && dt && dgate && ld_gate % 8 == 0 && (((uintptr_t)gate_t | (uintptr_t)gate | (uintptr_t)dt) & 15) == 0),
+               "dl_ln_modulate_bwd: the fused gate backward needs gate_t, gate, dt and dgate (16-byte aligned)");
+  const size_t lds = (size_t)5 * D * sizeof(float);
 #define LAUNCH(NJ)                                                                                                       \
   hipLaunchKernelGGL(ln_mod_bwd_k<NJ>, groups * split, 256, lds, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)x, \
                      w, b, (const bf16_t*)scale, ld_mod, rows_per_mod, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx,       \
-                     dscale, dshift, ld_dmod, dwb_partial, split, M, (int)D)
+                     dscale, dshift, ld_dmod, dwb_partial, (const bf16_t*)gate_t, (const bf16_t*)gate, ld_gate,           \
+                     (bf16_t*)dt, dgate, split, M, (int)D)
   if (nj == 1) LAUNCH(1);
   else LAUNCH(2);
 #undef LAUNCH

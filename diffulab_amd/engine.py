@@ -412,8 +412,14 @@ class DiTEngine:
         ops.gemm_nt(w["dO"], sh["last_layer.linear.weight|t"], w["dxm"], M=M, N=D, K=64)
         mo = L * 6 * D
         dx, dx_alt = w["dxa"], w["dxb"]
+        # every LayerNorm-modulate backward also runs the backward of the gated residual that follows it in the chain
+        # (x_new = x + gate * t): it has the residual-stream gradient dx in registers, so dt = gate * dx and dgate += dx * t
+        # cost one extra row read / write instead of a separate pass over dx
+        ml = (L - 1) * 6 * D
         ops.ln_modulate_bwd(w["dxm"], xs[L], None, None, mod[:, mo : mo + D], N, w["meanf"], w["rstdf"], None, dx,
-                            dmod[:, mo : mo + D], dmod[:, mo + D : mo + 2 * D], None)
+                            dmod[:, mo : mo + D], dmod[:, mo + D : mo + 2 * D], None, gate_t=w["layers"][L - 1]["t2"],
+                            gate=mod[:, ml + 5 * D : ml + 6 * D], dt=w["wg"][L - 1]["dt2"],
+                            dgate=dmod[:, ml + 5 * D : ml + 6 * D])
 
         # The four weight-gradient GEMMs of a block are off the dependency chain (nothing downstream reads them), so they
         # run on a SIDE HIP stream: they overlap the HBM-bound kernels of the main chain (gate/SwiGLU/adaLN/QK-norm
@@ -435,19 +441,19 @@ class DiTEngine:
             pre = f"layers.{i}."
             mo = i * 6 * D
             # MLP branch
-            ops.gate_bwd(dx, a["t2"], mod[:, mo + 5 * D : mo + 6 * D], N, g["dt2"], dmod[:, mo + 5 * D : mo + 6 * D])
-            wgrad(g["dt2"], a["h"], pre + "mlp_input.2.weight")
+            wgrad(g["dt2"], a["h"], pre + "mlp_input.2.weight")  # dt2 / dgate: produced by the LayerNorm backward before
             ops.gemm_nt(g["dt2"], sh[pre + "mlp_input.2.weight|t"], w["dh"])
             ops.swiglu_bwd(w["dh"], a["u"], g["du"])  # (dl_gemm_nt_dswiglu fuses these two, but measured slower: DESIGN.md)
             wgrad(g["du"], a["xm2"], pre + "mlp_input.0.weight")
             ops.gemm_nt(g["du"], sh[pre + "mlp_input.0.weight|t"], w["dxm"])
             ops.ln_modulate_bwd(w["dxm"], a["x1"], self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"),
                                 mod[:, mo + 3 * D : mo + 4 * D], N, a["mean2"], a["rstd2"], dx, dx_alt,
-                                dmod[:, mo + 3 * D : mo + 4 * D], dmod[:, mo + 4 * D : mo + 5 * D], w["dwb"])
+                                dmod[:, mo + 3 * D : mo + 4 * D], dmod[:, mo + 4 * D : mo + 5 * D], w["dwb"],
+                                gate_t=a["t1"], gate=mod[:, mo + 2 * D : mo + 3 * D], dt=g["dt1"],
+                                dgate=dmod[:, mo + 2 * D : mo + 3 * D])
             ops.reduce_rows_f32(w["dwb"], self.G(pre + "norm_2.weight"), B, 2 * D, clear=True)
             dx, dx_alt = dx_alt, dx
             # attention branch
-            ops.gate_bwd(dx, a["t1"], mod[:, mo + 2 * D : mo + 3 * D], N, g["dt1"], dmod[:, mo + 2 * D : mo + 3 * D])
             wgrad(g["dt1"], a["a"], pre + "attention.proj_out.weight")
             ops.gemm_nt(g["dt1"], sh[pre + "attention.proj_out.weight|t"], w["da"])
             ops.attn_bwd(a["q"], a["k"], a["v"], a["a"], w["da"], a["lse"], w["dq"], w["dk"], w["dv"], B, Hh, N, 64,
@@ -457,9 +463,14 @@ class DiTEngine:
                                  self.G(pre + "attention.qk_norm.query_norm.scale"), B, N, Hh, 64, rot)
             wgrad(g["dqkv"], a["xm1"], pre + "attention.qkv.weight")
             ops.gemm_nt(g["dqkv"], sh[pre + "attention.qkv.weight|t"], w["dxm"])
+            nxt = {}
+            if i > 0:  # gated residual of the previous block's MLP branch
+                mp = (i - 1) * 6 * D
+                nxt = dict(gate_t=w["layers"][i - 1]["t2"], gate=mod[:, mp + 5 * D : mp + 6 * D], dt=w["wg"][i - 1]["dt2"],
+                           dgate=dmod[:, mp + 5 * D : mp + 6 * D])
             ops.ln_modulate_bwd(w["dxm"], xs[i], self.P(pre + "norm_1.weight"), self.P(pre + "norm_1.bias"),
                                 mod[:, mo : mo + D], N, a["mean1"], a["rstd1"], dx, dx_alt, dmod[:, mo : mo + D],
-                                dmod[:, mo + D : mo + 2 * D], w["dwb"])
+                                dmod[:, mo + D : mo + 2 * D], w["dwb"], **nxt)
             ops.reduce_rows_f32(w["dwb"], self.G(pre + "norm_1.weight"), B, 2 * D, clear=True)
             dx, dx_alt = dx_alt, dx
             if self.reducer is not None:  # this block's gradient range is final once BOTH streams are past this point

@@ -172,12 +172,16 @@ def ln_modulate_fwd(x, w, b, scale, shift, rows_per_mod, eps, out, mean, rstd, t
           _p(out), _p(mean), _p(rstd), _p(t), _p(gate), gate.stride(0) if gate is not None else 0, _p(x_out), M, D, _s())
 
 
-def ln_modulate_bwd(dout, x, w, b, scale, rows_per_mod, mean, rstd, dres, dx, dscale, dshift, dwb_partial):
-    """dscale / dshift: f32 views [groups, D] (row stride = .stride(0)) accumulated into; dwb_partial f32 [groups, 2, D] or None"""
+def ln_modulate_bwd(dout, x, w, b, scale, rows_per_mod, mean, rstd, dres, dx, dscale, dshift, dwb_partial, gate_t=None,
+                    gate=None, dt=None, dgate=None):
+    """dscale / dshift (/ dgate): f32 views [groups, D] with the same row stride, accumulated into; dwb_partial f32
+    [groups, 2, D] or None.  gate_t / gate / dt / dgate: fused backward of the gated residual that follows (see header)."""
     M, D = x.shape
     assert dscale.dtype == torch.float32 and dshift.dtype == torch.float32
+    assert dgate is None or (dgate.dtype == torch.float32 and dgate.stride(0) == dscale.stride(0))
     _call("dl_ln_modulate_bwd", _p(dout), _p(x), _p(w), _p(b), _p(scale), scale.stride(0), rows_per_mod, _p(mean),
-          _p(rstd), _p(dres), _p(dx), _p(dscale), _p(dshift), dscale.stride(0), _p(dwb_partial), M, D, _s())
+          _p(rstd), _p(dres), _p(dx), _p(dscale), _p(dshift), dscale.stride(0), _p(dwb_partial), _p(gate_t), _p(gate),
+          gate.stride(0) if gate is not None else 0, _p(dt), _p(dgate), M, D, _s())
 
 
 def gate_bwd(dout, t, gate, rows_per_mod, dt, dgate):

@@ -143,11 +143,15 @@ DL_API int dl_ln_modulate_fwd(const void* x, const float* w, const float* b, con
  *   dscale[g,:] += sum_{m in g} dout * (xhat*w+b) ; dshift[g,:] += sum dout     (f32 rows, stride ld_dmod: the f32 image
  *                  of the modulation-gradient matrix, zeroed by the caller once per step, cast to bf16 once at the end)
  *   dwb_partial f32 [groups, 2, D] += per-group sums of dw, db (NULL when w == NULL); folded by dl_reduce_rows_f32.
- * The workgroups that share a sample meet in these accumulators through f32 atomics (no second pass). */
+ * The workgroups that share a sample meet in these accumulators through f32 atomics (no second pass).
+ * Optional fused backward of the gated residual that follows in the backward chain (gate_t != NULL; the same arithmetic as
+ * dl_gate_bwd on the dx just produced): dt[m,:] = gate[g,:] * dx[m,:] (bf16), dgate[g,:] += sum_{m in g} dx[m,:] * gate_t[m,:]
+ * (f32, row stride ld_dmod). */
 DL_API int dl_ln_modulate_bwd(const void* dout, const void* x, const float* w, const float* b, const void* scale,
                               int64_t ld_mod, int64_t rows_per_mod, const float* mean, const float* rstd,
                               const void* dres, void* dx, float* dscale, float* dshift, int64_t ld_dmod,
-                              float* dwb_partial, int64_t M, int64_t D, dl_stream_t stream);
+                              float* dwb_partial, const void* gate_t, const void* gate, int64_t ld_gate, void* dt,
+                              float* dgate, int64_t M, int64_t D, dl_stream_t stream);
 /* x_new = x + gate * t backward (mmdit.py:296-307): dt = gate * dout (bf16) ; dgate[g,:] = sum_{m in g} dout * t (f32,
  * written, row stride ld_dmod) */
 DL_API int dl_gate_bwd(const void* dout, const void* t, const void* gate, int64_t ld_mod, int64_t rows_per_mod,

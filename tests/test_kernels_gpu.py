@@ -156,10 +156,16 @@ def test_ln_modulate_fwd_bwd(ops, D, affine):
         ops.reduce_rows_f32(dwb, acc, B, 2 * D, clear=True)
         assert rel(acc[:D], w.grad) < 1e-4 and rel(acc[D:], b.grad) < 1e-4
         assert float(dwb.abs().sum()) == 0.0  # cleared while read
-    # no residual input
+    # no residual input; fused backward of the gated residual that follows (dt = gate * dx, dgate += dx * t)
+    tg = bf(synth.normal("ln.tg", (M, D)))
+    dt = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    dmod.zero_()
     ops.ln_modulate_bwd(dev_bf(dy), dev_bf(x.detach()), wd, bd, mod_d[:, :D], N, mean, rstd, None, dx, dmod[:, :D],
-                        dmod[:, D : 2 * D], dwb)
+                        dmod[:, D : 2 * D], dwb, gate_t=dev_bf(tg), gate=mod_d[:, 2 * D :], dt=dt, dgate=dmod[:, 2 * D :])
     assert rel(dx.float(), x.grad) < 5e-3
+    dxr = dx.float().cpu()
+    assert rel(dt.float(), dxr * mod[:, 2 * D :].repeat_interleave(N, 0)) < 4e-3
+    assert rel(dmod[:, 2 * D :], (dxr * tg).reshape(B, N, D).sum(1)) < 1e-4
 
 
 def test_ln_modulate_fwd_with_fused_gated_residual(ops):
