@@ -55,7 +55,28 @@ struct ConvGeom {
   int64_t ldx;         // row stride of x (elements)
   int64_t npix;        // B*H*W real rows (rows beyond it are zero)
   const bf16_t* zero;  // >= 16 bytes of zeros, 16-byte aligned (caller-owned)
+  int lw, lh;          // log2(W), log2(H) when both are powers of two (pixel coordinates by shift/mask), else -1
+
+  __device__ __forceinline__ void pixel(int64_t p, int& py, int& px) const {
+    if (lw >= 0) {
+      px = (int)p & (W - 1);
+      py = (int)(p >> lw) & (H - 1);
+    } else {
+      px = (int)(p % W);
+      py = (int)((p / W) % H);
+    }
+  }
 };
+static ConvGeom make_conv_geom(int64_t H, int64_t W, int64_t Ci, int64_t ldx, int64_t npix, const void* zero) {
+  auto lg = [](int64_t v) {
+    int l = 0;
+    while ((1ll << l) < v) ++l;
+    return (1ll << l) == v ? l : -1;
+  };
+  ConvGeom cg{(int)H, (int)W, (int)Ci, ldx, npix, (const bf16_t*)zero, lg(W), lg(H)};
+  if (cg.lw < 0 || cg.lh < 0) cg.lw = cg.lh = -1;
+  return cg;
+}
 
 template <bool CONV>
 __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restrict__ A, int64_t lda,
@@ -87,7 +108,8 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restr
     b_src[c] = Bm + (int64_t)gn * ldb + q * 8;
     if (CONV) {
       a_src[c] = A + (int64_t)gm * cg.ldx + q * 8;
-      const int px = gm % cg.W, py = (gm / cg.W) % cg.H;
+      int px, py;
+      cg.pixel(gm, py, px);
       int ok = 0;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
@@ -766,7 +788,8 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_tn_k(const bf16_t* __restr
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int64_t p = r0 + (wave * 4 + c) * 4 + srow;  // pixel row of this lane
-        const int px = (int)(p % cg.W), py = (int)((p / cg.W) % cg.H);
+        int px, py;
+        cg.pixel(p, py, px);
         const bool ok = p < cg.npix && py + dy >= 0 && py + dy < cg.H && px + dx >= 0 && px + dx < cg.W;
         glds16(ok ? a_src[c] + r0 * cg.ldx : cg.zero, ba + c * 1024);
         glds16(b_src[c] + r0 * ldb, bb + c * 1024);
@@ -857,10 +880,11 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_tn_k(const bf16_t* __restr
 #define WBM 384
 #define WBN 128
 #define W_STAGE ((WBM + WBN) * 2 * BK)  // 65536 B per stage
+template <bool CONV>
 __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __restrict__ A, int64_t lda,
                                                                   const bf16_t* __restrict__ Bm, int64_t ldb,
                                                                   float* __restrict__ C, int64_t ldc, int M, int N,
-                                                                  int R, int steps_per_split) {
+                                                                  int R, int steps_per_split, ConvGeom cg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // block -> (A-panel unit = (split, m-tile), n-tile): the tiles_n workgroups that read the same A panel get block
   // ids congruent mod 8, i.e. land on ONE XCD and share the panel in its L2 (one HBM read instead of tiles_n)
@@ -881,6 +905,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __
   // DMA: 48 A chunks + 16 B chunks of 1 KiB per stage, 8 per wave (waves 0-5: A, waves 6-7: B)
   int64_t src_off[8];
   int lds_off[8];
+  int crow[8], cdy[8], cdx[8];  // CONV: row inside the 64-row step and tap displacement of each chunk of this lane
   const bool is_a = wave < 6;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -891,12 +916,33 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __
     const int q = s ^ ((r & 3) << 2);
     src_off[i] = (int64_t)r * (is_a ? lda : ldb) + q * 8;
     lds_off[i] = (is_a ? 0 : WBM * 2 * BK) + c * 1024;
+    crow[i] = r;
+    cdy[i] = cdx[i] = 0;
+    if (CONV && is_a) {
+      // implicit im2col: column (m0 + 8q) of cols is (tap, ci); Ci % 8 == 0 keeps the 8 columns of a lane inside one tap
+      const int col = m0 + q * 8;
+      const int tap = col / cg.Ci, ci = col - tap * cg.Ci;
+      cdy[i] = tap / 3 - 1;
+      cdx[i] = tap % 3 - 1;
+      src_off[i] = ((int64_t)r + (int64_t)cdy[i] * cg.W + cdx[i]) * cg.ldx + ci;
+    }
   }
-  const bf16_t* gsrc = is_a ? A + m0 : Bm + n0;
-  const int64_t gld = is_a ? lda : ldb;
+  const bf16_t* gsrc = is_a ? (CONV ? A : A + m0) : Bm + n0;
+  const int64_t gld = is_a ? (CONV ? cg.ldx : lda) : ldb;
   auto stage = [&](int st, int buf) {
     char* base = smem + buf * W_STAGE;
     const bf16_t* p = gsrc + (int64_t)st * BK * gld;
+    if (CONV && is_a) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t pix = (int64_t)st * BK + crow[i];
+        int px, py;
+        cg.pixel(pix, py, px);
+        const bool ok = pix < cg.npix && py + cdy[i] >= 0 && py + cdy[i] < cg.H && px + cdx[i] >= 0 && px + cdx[i] < cg.W;
+        glds16(ok ? p + src_off[i] : cg.zero, base + lds_off[i]);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) glds16(p + src_off[i], base + lds_off[i]);
   };
@@ -984,7 +1030,7 @@ extern "C" int dl_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb
       (void)hipGetDevice(&dev);
       (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
       if (n_cu <= 0) n_cu = 256;
-      (void)hipFuncSetAttribute((const void*)gemm_tn_big_k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE);
+      (void)hipFuncSetAttribute((const void*)gemm_tn_big_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE);
     }
     const int nsteps = (int)(R / BK);
     if (variant == 1 && M % WBM == 0 && N % WBN == 0 && nsteps >= 64) {
@@ -999,8 +1045,8 @@ extern "C" int dl_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb
       const int sps = (nsteps + splits - 1) / splits;
       splits = (nsteps + sps - 1) / sps;
       const int units = (tiles_m * splits + 7) & ~7;  // surplus units exit at once
-      hipLaunchKernelGGL(gemm_tn_big_k, units * (int)(N / WBN), BIG_THREADS, 2 * W_STAGE, (hipStream_t)stream, (const bf16_t*)A,
-                         lda, (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)R, sps);
+      hipLaunchKernelGGL(gemm_tn_big_k<false>, units * (int)(N / WBN), BIG_THREADS, 2 * W_STAGE, (hipStream_t)stream,
+                         (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)R, sps, ConvGeom{});
       DL_LAUNCH_CHECK();
       return DL_OK;
     }
@@ -1032,7 +1078,7 @@ extern "C" int dl_conv3x3_nt(const void* x, int64_t ldx, int64_t Bn, int64_t H, 
                "dl_conv3x3_nt: 16-byte alignment");
   const int64_t M = Bn * H * W, K = 9 * Ci;
   NtEpilogue ep{bias, DL_ACT_NONE, 0, nullptr, (const bf16_t*)resid, ldr, nullptr, 0, 1, nullptr, 0, 0};
-  ConvGeom cg{(int)H, (int)W, (int)Ci, ldx, M, (const bf16_t*)zero};
+  const ConvGeom cg = make_conv_geom(H, W, Ci, ldx, M, zero);
   const int nwg = cdiv(M, BM) * cdiv(Co, BN);
   hipLaunchKernelGGL(gemm_nt_k<true>, dim3(nwg, 1), NT_THREADS, NT_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)x, ldx,
                      (const bf16_t*)Wf, ldw, out, ldc, (int)M, (int)Co, (int)K, ep, 1, cg);
@@ -1050,9 +1096,34 @@ extern "C" int dl_conv3x3_wgrad_tn(const void* x, int64_t ldx, int64_t Bn, int64
                "dl_conv3x3_wgrad_tn: dims");
   DL_CHECK_ARG((((uintptr_t)x | (uintptr_t)dY | (uintptr_t)zero) & 15) == 0, "dl_conv3x3_wgrad_tn: 16-byte alignment");
   const int64_t M = 9 * Ci, N = Co;
-  ConvGeom cg{(int)H, (int)W, (int)Ci, ldx, Bn * H * W, (const bf16_t*)zero};
-  const int ntile = cdiv(M, BM) * cdiv(N, BN);
+  const ConvGeom cg = make_conv_geom(H, W, Ci, ldx, Bn * H * W, zero);
   const int nsteps = (int)(R / BK);
+  {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+      if (n_cu <= 0) n_cu = 256;
+      (void)hipFuncSetAttribute((const void*)gemm_tn_big_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE);
+    }
+    if (M % WBM == 0 && N % WBN == 0 && nsteps >= 64) {  // same unit / split budget as dl_gemm_tn
+      const int tiles_m = (int)(M / WBM), tiles_n = (int)(N / WBN);
+      int padded_max = (n_cu / tiles_n) & ~7;
+      if (padded_max < 8) padded_max = 8;
+      int splits = padded_max / tiles_m;
+      if (splits < 1) splits = 1;
+      if (splits > nsteps / 8) splits = nsteps / 8;
+      const int sps = (nsteps + splits - 1) / splits;
+      splits = (nsteps + sps - 1) / sps;
+      const int units = (tiles_m * splits + 7) & ~7;
+      hipLaunchKernelGGL(gemm_tn_big_k<true>, units * tiles_n, BIG_THREADS, 2 * W_STAGE, (hipStream_t)stream, (const bf16_t*)x,
+                         ldx, (const bf16_t*)dY, ldy, g, ldg, (int)M, (int)N, (int)R, sps, cg);
+      DL_LAUNCH_CHECK();
+      return DL_OK;
+    }
+  }
+  const int ntile = cdiv(M, BM) * cdiv(N, BN);
   int splits = (1024 + ntile - 1) / ntile;
   if (splits > nsteps) splits = nsteps;
   if (splits < 1) splits = 1;
