@@ -1067,9 +1067,27 @@ extern "C" int dl_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb
 // ----------------------------------------------------------------------------------------------------- implicit-GEMM 3x3 conv
 /* out[p, co] = bias[co] + sum_{tap, ci} x[p + shift(tap), ci] * Wf[co, tap*Ci + ci] (+ resid[p, co]); x NHWC rows [B*H*W, ldx].
  * Wf is the (tap, ci)-ordered shadow of dl_cast_conv3x3_weight (the rotated one gives the data gradient). */
+// second half of a split-K convolution: out = bf16(acc + bias + resid)
+__global__ void conv_splitk_finalize_k(const float* __restrict__ acc, const float* __restrict__ bias,
+                                       const bf16_t* __restrict__ resid, int64_t ldr, bf16_t* __restrict__ out, int64_t ldc,
+                                       int64_t M, int N) {
+  const int N8 = N >> 3;
+  const int64_t n8 = M * N8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / N8;
+    const int n = (int)(i - m * N8) * 8;
+    float v[8], r[8];
+    *(f32x4_t*)&v[0] = *(const f32x4_t*)(acc + m * N + n);
+    *(f32x4_t*)&v[4] = *(const f32x4_t*)(acc + m * N + n + 4);
+    if (resid) unpack8(*(const u32x4_t*)(resid + m * ldr + n), r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += (bias ? bias[n + e] : 0.f) + (resid ? r[e] : 0.f);
+    *(u32x4_t*)(out + m * ldc + n) = pack8(v);
+  }
+}
 extern "C" int dl_conv3x3_nt(const void* x, int64_t ldx, int64_t Bn, int64_t H, int64_t W, int64_t Ci, const void* Wf,
                              int64_t ldw, void* out, int64_t ldc, int64_t Co, const float* bias, const void* resid,
-                             int64_t ldr, const void* zero, dl_stream_t stream) {
+                             int64_t ldr, const void* zero, float* splitk_scratch, dl_stream_t stream) {
   DL_CHECK_ARG(x && Wf && out && zero && Bn > 0 && H > 0 && W > 0 && Co > 0, "dl_conv3x3_nt: bad args");
   if (Ci % 64 != 0) return DL_ERR_UNSUPPORTED;  // caller materialises cols with dl_im2col3x3 (e.g. the 1-channel stem)
   DL_CHECK_ARG(ldx % 8 == 0 && ldx >= Ci && ldw % 8 == 0 && ldw >= 9 * Ci && ldc % 8 == 0 && ldc >= Co,
@@ -1077,9 +1095,30 @@ extern "C" int dl_conv3x3_nt(const void* x, int64_t ldx, int64_t Bn, int64_t H, 
   DL_CHECK_ARG((((uintptr_t)x | (uintptr_t)Wf | (uintptr_t)out | (uintptr_t)zero | (uintptr_t)resid) & 15) == 0,
                "dl_conv3x3_nt: 16-byte alignment");
   const int64_t M = Bn * H * W, K = 9 * Ci;
-  NtEpilogue ep{bias, DL_ACT_NONE, 0, nullptr, (const bf16_t*)resid, ldr, nullptr, 0, 1, nullptr, 0, 0};
   const ConvGeom cg = make_conv_geom(H, W, Ci, ldx, M, zero);
   const int nwg = cdiv(M, BM) * cdiv(Co, BN);
+  // low-resolution levels: few output tiles with a deep contraction (K = 9*Ci up to 18432) -> split K over blockIdx.y, the
+  // partial tiles meet in the caller's f32 scratch [M, Co] through atomics, a second pass adds bias / residual and rounds
+  int ksplit = 1;
+  if (splitk_scratch && nwg <= 160 && K >= 4608 && Co % 8 == 0) {
+    ksplit = 384 / nwg;
+    if (ksplit > (int)(K / 1152)) ksplit = (int)(K / 1152);
+    if (ksplit < 2) ksplit = 1;
+  }
+  if (ksplit > 1) {
+    if (hipMemsetAsync(splitk_scratch, 0, (size_t)M * Co * 4, (hipStream_t)stream) != hipSuccess) return DL_ERR_LAUNCH;
+    NtEpilogue ep0{};
+    ep0.rows_per_gate = 1;
+    hipLaunchKernelGGL(gemm_nt_k<true>, dim3(nwg, ksplit), NT_THREADS, NT_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                       (const bf16_t*)Wf, ldw, splitk_scratch, Co, (int)M, (int)Co, (int)K, ep0, ksplit, cg);
+    int64_t g = (M * (Co / 8) + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(conv_splitk_finalize_k, (int)g, 256, 0, (hipStream_t)stream, splitk_scratch, bias, (const bf16_t*)resid, ldr,
+                       (bf16_t*)out, ldc, M, (int)Co);
+    DL_LAUNCH_CHECK();
+    return DL_OK;
+  }
+  NtEpilogue ep{bias, DL_ACT_NONE, 0, nullptr, (const bf16_t*)resid, ldr, nullptr, 0, 1, nullptr, 0, 0};
   hipLaunchKernelGGL(gemm_nt_k<true>, dim3(nwg, 1), NT_THREADS, NT_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)x, ldx,
                      (const bf16_t*)Wf, ldw, out, ldc, (int)M, (int)Co, (int)K, ep, 1, cg);
   DL_LAUNCH_CHECK();

@@ -322,10 +322,12 @@ def _maybe(name: str, *args) -> bool:
     return True
 
 
-def conv3x3_nt(x, B, H, W, ci, wf, out, co, bias, resid, zero) -> bool:
-    """implicit-GEMM 3x3 conv (forward, or data gradient with the rotated shadow); False -> use im2col3x3 + gemm_nt"""
+def conv3x3_nt(x, B, H, W, ci, wf, out, co, bias, resid, zero, scratch=None) -> bool:
+    """implicit-GEMM 3x3 conv (forward, or data gradient with the rotated shadow); `scratch` (f32, >= B*H*W*co) lets the
+    low-resolution levels split K.  False -> use im2col3x3 + gemm_nt"""
+    assert scratch is None or (scratch.dtype == torch.float32 and scratch.numel() >= B * H * W * co)
     return _maybe("dl_conv3x3_nt", _p(x), x.stride(0), B, H, W, ci, _p(wf), wf.stride(0), _p(out), out.stride(0), co, _p(bias),
-                  _p(resid), resid.stride(0) if resid is not None else 0, _p(zero), _s())
+                  _p(resid), resid.stride(0) if resid is not None else 0, _p(zero), _p(scratch), _s())
 
 
 def conv3x3_wgrad_tn(x, B, H, W, ci, dy, co, g, zero) -> bool:

@@ -16,6 +16,7 @@ wiring), :832-853 (forward), :215-237 (ResBlock._forward), :296-322 (AttentionBl
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 
 import torch
@@ -298,6 +299,13 @@ class UNetEngine:
             self._scratch[key] = t
         return t[:numel]
 
+    def _splitk(self, M: int, n: int) -> Tensor | None:
+        """f32 scratch for the split-K path of the low-resolution convolutions.  Measured on the MNIST-DDPM config: the atomics
+        and the second pass cost more than the idle CUs (45.6 vs 43.7 ms/step), so it is opt-in (DL_UNET_SPLITK=1)."""
+        if M > 16384 or os.environ.get("DL_UNET_SPLITK", "0") != "1":
+            return None
+        return self._scr("splitk", M * n, torch.float32)
+
     def _padded(self, x: Tensor, rows: int, cols: int) -> Tensor:
         """x [M, C] -> zero-padded [rows, cols] copy when the GEMM alignment (K % 64, reduction rows % 64) needs it"""
         if x.shape[0] == rows and x.shape[1] == cols:
@@ -311,7 +319,7 @@ class UNetEngine:
         M = B * H * W
         out = self._new(M, _rup(co, 8), zero=bool(co % 8))
         bias = self.P(name[:-6] + "bias")
-        if ops.conv3x3_nt(x, B, H, W, ci, self.sh[name + "|f"], out, co, bias, resid, self._zero):
+        if ops.conv3x3_nt(x, B, H, W, ci, self.sh[name + "|f"], out, co, bias, resid, self._zero, self._splitk(M, co)):
             return out  # implicit GEMM: no cols matrix
         Mp, ldk = _rup(M, 64), _rup(9 * ci, 64)
         cols = self._scr("cols", Mp * ldk).view(Mp, ldk)
@@ -335,7 +343,7 @@ class UNetEngine:
         if not need_dx:
             return None
         dx = self._new(M, ci)
-        if ops.conv3x3_nt(dy, B, H, W, co, self.sh[name + "|d"], dx, ci, None, None, self._zero):
+        if ops.conv3x3_nt(dy, B, H, W, co, self.sh[name + "|d"], dx, ci, None, None, self._zero, self._splitk(M, ci)):
             return dx
         ldd = _rup(9 * co, 64)
         dcols = self._scr("cols", Mp * ldd).view(Mp, ldd)
