@@ -1014,8 +1014,14 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __
     }
 }
 
+extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                             int64_t N, int64_t R, int max_workgroups, dl_stream_t stream);
 extern "C" int dl_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                           int64_t N, int64_t R, dl_stream_t stream) {
+  return dl_gemm_tn_ex(A, lda, B, ldb, C, ldc, M, N, R, 0, stream);
+}
+extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                             int64_t N, int64_t R, int max_workgroups, dl_stream_t stream) {
   DL_CHECK_ARG(A && B && C && M > 0 && N > 0 && R > 0, "dl_gemm_tn: null/empty operand");
   DL_CHECK_ARG(R % BK == 0, "dl_gemm_tn: R=%lld must be a multiple of %d", (long long)R, BK);
   DL_CHECK_ARG(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N && ldc >= N,
@@ -1037,7 +1043,10 @@ extern "C" int dl_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb
       // one workgroup per CU at most (128 KiB of LDS each): units (= m-tiles x splits) are padded to a multiple of
       // 8 for the XCD mapping, so pick the split count from the padded budget
       const int tiles_m = (int)(M / WBM), tiles_n = (int)(N / WBN);
-      int padded_max = (n_cu / tiles_n) & ~7;
+      // max_workgroups > 0: the caller runs this GEMM beside other work (the engines' side-stream wgrads) and wants some
+      // CUs left unclaimed by the persistent workgroups, so the latency-bound kernels of the main chain keep full occupancy there
+      const int budget = (max_workgroups > 0 && max_workgroups < n_cu) ? max_workgroups : n_cu;
+      int padded_max = (budget / tiles_n) & ~7;
       if (padded_max < 8) padded_max = 8;
       int splits = padded_max / tiles_m;
       if (splits < 1) splits = 1;

@@ -156,11 +156,11 @@ def gemm_nt_dswiglu(dt: Tensor, w2t: Tensor, u: Tensor, du: Tensor) -> bool:
     return True
 
 
-def gemm_tn(a: Tensor, b: Tensor, out: Tensor, *, M: int | None = None, N: int | None = None) -> Tensor:
-    """out[M,N] (f32) += a[R,M]^T @ b[R,N]."""
+def gemm_tn(a: Tensor, b: Tensor, out: Tensor, *, M: int | None = None, N: int | None = None, max_wgs: int = 0) -> Tensor:
+    """out[M,N] (f32) += a[R,M]^T @ b[R,N].  max_wgs > 0 caps the persistent workgroups (side-stream wgrads)."""
     M = a.shape[1] if M is None else M
     N = b.shape[1] if N is None else N
-    _call("dl_gemm_tn", _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, a.shape[0], _s())
+    _call("dl_gemm_tn_ex", _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, a.shape[0], int(max_wgs), _s())
     return out
 
 

@@ -126,6 +126,10 @@ DL_API int dl_gemm_nt_dswiglu(const void* dT, int64_t ldt, const void* W2t, int6
  * accumulate across the split of R; caller zeroes C once per optimizer step).  R multiple of 64. */
 DL_API int dl_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                       int64_t N, int64_t R, dl_stream_t stream);
+/* same, with a cap on the persistent workgroups of the big-tile kernel (0 = one per CU): a wgrad GEMM that runs on a side
+ * stream beside the main dependency chain leaves CUs free for that chain's latency-bound kernels */
+DL_API int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                         int64_t N, int64_t R, int max_workgroups, dl_stream_t stream);
 
 /* ------------------------------------------------------------------ adaLN / norms */
 /* modulate(LayerNorm(x)) mmdit.py:299,305,547 + nn.py:539:  out = (LN(x) * w + b) * (1 + scale) + shift.
