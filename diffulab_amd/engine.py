@@ -295,7 +295,7 @@ class DiTEngine:
             w["dq"], w["dk"], w["dv"] = (z(B, d.num_heads, N, 64) for _ in range(3))
             w["dmod"] = z(Bp, self.layout.mod_rows)                  # bf16 operand of the modulation GEMMs' backward
             w["dmod32"] = z(Bp, self.layout.mod_rows, dtype=f32)     # f32 accumulator the block kernels add into
-            w["dwb"] = z(B, 2, D, dtype=f32)
+            w["dwb"] = z(2 * L, B, 2, D, dtype=f32)  # per-norm partials: folded on the side stream, cleared while read
             w["dse"] = z(Bp, E, dtype=f32)
             w["demb"] = z(Bp, E, dtype=f32)
             w["demb16"] = z(Bp, E)
@@ -437,6 +437,12 @@ class DiTEngine:
                 side.wait_event(ev)
                 ops.gemm_tn(x_grad, x_in, self.G(gname), max_wgs=side_wgs)
 
+        def fold_norm(partial: Tensor, gname: str) -> None:  # [B, 2, D] per-sample sums -> [w; b] gradients, off the chain
+            ev = main.record_event()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                ops.reduce_rows_f32(partial, self.G(gname), B, 2 * D, clear=True)
+
         # fused MLP-down dgrad + SwiGLU backward (dH never written): 32 % less HBM traffic than the GEMM + elementwise pair
         fused_dswiglu = os.environ.get("DL_FUSED_DSWIGLU", "0") == "1"
         for i in reversed(range(L)):
@@ -453,10 +459,10 @@ class DiTEngine:
             ops.gemm_nt(g["du"], sh[pre + "mlp_input.0.weight|t"], w["dxm"])
             ops.ln_modulate_bwd(w["dxm"], a["x1"], self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"),
                                 mod[:, mo + 3 * D : mo + 4 * D], N, a["mean2"], a["rstd2"], dx, dx_alt,
-                                dmod[:, mo + 3 * D : mo + 4 * D], dmod[:, mo + 4 * D : mo + 5 * D], w["dwb"],
+                                dmod[:, mo + 3 * D : mo + 4 * D], dmod[:, mo + 4 * D : mo + 5 * D], w["dwb"][2 * i + 1],
                                 gate_t=a["t1"], gate=mod[:, mo + 2 * D : mo + 3 * D], dt=g["dt1"],
                                 dgate=dmod[:, mo + 2 * D : mo + 3 * D])
-            ops.reduce_rows_f32(w["dwb"], self.G(pre + "norm_2.weight"), B, 2 * D, clear=True)
+            fold_norm(w["dwb"][2 * i + 1], pre + "norm_2.weight")
             dx, dx_alt = dx_alt, dx
             # attention branch
             wgrad(g["dt1"], a["a"], pre + "attention.proj_out.weight")
@@ -475,8 +481,8 @@ class DiTEngine:
                            dgate=dmod[:, mp + 5 * D : mp + 6 * D])
             ops.ln_modulate_bwd(w["dxm"], xs[i], self.P(pre + "norm_1.weight"), self.P(pre + "norm_1.bias"),
                                 mod[:, mo : mo + D], N, a["mean1"], a["rstd1"], dx, dx_alt, dmod[:, mo : mo + D],
-                                dmod[:, mo + D : mo + 2 * D], w["dwb"], **nxt)
-            ops.reduce_rows_f32(w["dwb"], self.G(pre + "norm_1.weight"), B, 2 * D, clear=True)
+                                dmod[:, mo + D : mo + 2 * D], w["dwb"][2 * i], **nxt)
+            fold_norm(w["dwb"][2 * i], pre + "norm_1.weight")
             dx, dx_alt = dx_alt, dx
             if self.reducer is not None:  # this block's gradient range is final once BOTH streams are past this point
                 self.reducer.ready(*self.layer_ranges[i], extra_events=(side.record_event(),))
