@@ -215,3 +215,81 @@ extern "C" int dl_reduce_rows_f32(float* partial, float* out, int64_t G, int64_t
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ cosine similarity rows (RePA)
+// F.cosine_similarity(p, d, dim=-1) (training/losses/repa.py:196): cos = <p,d> / sqrt(max(|p|^2 |d|^2, eps^2)); one wave per row
+__global__ __launch_bounds__(256) void cosine_rows_fwd_k(const bf16_t* __restrict__ p, int64_t ldp, const float* __restrict__ d,
+                                                         int64_t ldd, float* __restrict__ cosv, float* __restrict__ pn2,
+                                                         float* __restrict__ dn2, int64_t M, int E, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+    float s = 0.f, a = 0.f, b = 0.f;
+    for (int c = lane * 8; c < E; c += 512) {
+      float pv[8];
+      unpack8(*(const u32x4_t*)(p + row * ldp + c), pv);
+      const f32x4_t d0 = *(const f32x4_t*)(d + row * ldd + c), d1 = *(const f32x4_t*)(d + row * ldd + c + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dv = e < 4 ? d0[e] : d1[e - 4];
+        s += pv[e] * dv;
+        a += pv[e] * pv[e];
+        b += dv * dv;
+      }
+    }
+    s = wave_sum(s);
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane == 0) {
+      cosv[row] = s / sqrtf(fmaxf(a * b, eps * eps));
+      pn2[row] = a;
+      dn2[row] = b;
+    }
+  }
+}
+// dp = g * ( d / den - cos * p / |p|^2 ),  den = sqrt(max(|p|^2 |d|^2, eps^2)),  g = gscale * (*gscale_dev)
+__global__ __launch_bounds__(256) void cosine_rows_bwd_k(const bf16_t* __restrict__ p, int64_t ldp, const float* __restrict__ d,
+                                                         int64_t ldd, const float* __restrict__ cosv, const float* __restrict__ pn2,
+                                                         const float* __restrict__ dn2, float gscale,
+                                                         const float* __restrict__ gscale_dev, bf16_t* __restrict__ dp,
+                                                         int64_t lddp, int64_t M, int E, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float g = gscale * (gscale_dev ? *gscale_dev : 1.0f);
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+    const float a = pn2[row], b = dn2[row], cs = cosv[row];
+    const bool clamped = a * b < eps * eps;  // the clamp is active: the denominator is a constant there
+    const float inv_den = 1.0f / sqrtf(fmaxf(a * b, eps * eps));
+    const float k = clamped ? 0.f : cs / fmaxf(a, 1e-30f);
+    for (int c = lane * 8; c < E; c += 512) {
+      float pv[8];
+      unpack8(*(const u32x4_t*)(p + row * ldp + c), pv);
+      const f32x4_t d0 = *(const f32x4_t*)(d + row * ldd + c), d1 = *(const f32x4_t*)(d + row * ldd + c + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pv[e] = g * ((e < 4 ? d0[e] : d1[e - 4]) * inv_den - k * pv[e]);
+      *(u32x4_t*)(dp + row * lddp + c) = pack8(pv);
+    }
+  }
+}
+extern "C" int dl_cosine_rows_fwd(const void* p, int64_t ldp, const float* d, int64_t ldd, float* cosv, float* pn2, float* dn2,
+                                  int64_t M, int64_t E, float eps, dl_stream_t stream) {
+  DL_CHECK_ARG(p && d && cosv && pn2 && dn2 && M > 0 && E > 0 && E % 8 == 0 && ldp % 8 == 0 && ldd % 4 == 0 &&
+                   (((uintptr_t)p | (uintptr_t)d) & 15) == 0,
+               "dl_cosine_rows_fwd: bad args");
+  int grid = cdiv(M, 4);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(cosine_rows_fwd_k, grid, 256, 0, (hipStream_t)stream, (const bf16_t*)p, ldp, d, ldd, cosv, pn2, dn2, M, (int)E,
+                     eps);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_cosine_rows_bwd(const void* p, int64_t ldp, const float* d, int64_t ldd, const float* cosv, const float* pn2,
+                                  const float* dn2, float gscale, const float* gscale_dev, void* dp, int64_t lddp, int64_t M,
+                                  int64_t E, float eps, dl_stream_t stream) {
+  DL_CHECK_ARG(p && d && cosv && pn2 && dn2 && dp && M > 0 && E > 0 && E % 8 == 0 && ldp % 8 == 0 && lddp % 8 == 0 && ldd % 4 == 0,
+               "dl_cosine_rows_bwd: bad args");
+  int grid = cdiv(M, 4);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(cosine_rows_bwd_k, grid, 256, 0, (hipStream_t)stream, (const bf16_t*)p, ldp, d, ldd, cosv, pn2, dn2, gscale,
+                     gscale_dev, (bf16_t*)dp, lddp, M, (int)E, eps);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}

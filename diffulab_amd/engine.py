@@ -386,9 +386,18 @@ class DiTEngine:
         return w["pred"]
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dpred: Tensor) -> None:
-        """accumulates d(loss)/d(param) into the flat gradient arena (+=) for the last train-mode forward."""
+    def feature(self, k: int) -> Tensor:
+        """output of block k of the last train-mode forward: the residual stream after the block, bf16 [B, N, D] (a view of
+        the workspace, valid until the next forward) -- what a forward hook on ``layers[k]`` observes in the reference"""
+        assert self._train, "block outputs are only kept by the train-mode launch sequence"
+        B, _, _, _, _, N, _, _, _ = self.geo
+        return self.ws["x"][k + 1].view(B, N, self.d.inner_dim)
+
+    def backward(self, dpred: Tensor, dfeats: dict[int, Tensor] | None = None) -> None:
+        """accumulates d(loss)/d(param) into the flat gradient arena (+=) for the last train-mode forward.
+        dfeats: {block index k: gradient of an auxiliary loss w.r.t. feature(k)} (RePA), added to the residual-stream gradient."""
         assert self._train and self.grads is not None
+        dfeats = {k: g.reshape(-1, self.d.inner_dim).to(torch.bfloat16).contiguous() for k, g in (dfeats or {}).items()}
         d, w, sh = self.d, self.ws, self.sh
         B, H, W, gh, gw, N, M, Bp, Fo = self.geo
         D, E, L, Hh = d.inner_dim, d.embedding_dim, d.depth, d.num_heads
@@ -416,7 +425,7 @@ class DiTEngine:
         # (x_new = x + gate * t): it has the residual-stream gradient dx in registers, so dt = gate * dx and dgate += dx * t
         # cost one extra row read / write instead of a separate pass over dx
         ml = (L - 1) * 6 * D
-        ops.ln_modulate_bwd(w["dxm"], xs[L], None, None, mod[:, mo : mo + D], N, w["meanf"], w["rstdf"], None, dx,
+        ops.ln_modulate_bwd(w["dxm"], xs[L], None, None, mod[:, mo : mo + D], N, w["meanf"], w["rstdf"], dfeats.get(L - 1), dx,
                             dmod[:, mo : mo + D], dmod[:, mo + D : mo + 2 * D], None, gate_t=w["layers"][L - 1]["t2"],
                             gate=mod[:, ml + 5 * D : ml + 6 * D], dt=w["wg"][L - 1]["dt2"],
                             dgate=dmod[:, ml + 5 * D : ml + 6 * D])
@@ -474,6 +483,8 @@ class DiTEngine:
                                  self.G(pre + "attention.qk_norm.query_norm.scale"), B, N, Hh, 64, rot)
             wgrad(g["dqkv"], a["xm1"], pre + "attention.qkv.weight")
             ops.gemm_nt(g["dqkv"], sh[pre + "attention.qkv.weight|t"], w["dxm"])
+            if i - 1 in dfeats:  # auxiliary-loss gradient on the output of block i-1 (= this block's input)
+                ops.add_bf16(dx, dfeats[i - 1], dx)
             nxt = {}
             if i > 0:  # gated residual of the previous block's MLP branch
                 mp = (i - 1) * 6 * D

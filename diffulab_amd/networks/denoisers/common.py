@@ -47,18 +47,27 @@ class EngineFn(torch.autograd.Function):
     parameter gradients are accumulated straight into the flat gradient arena (``p.grad`` are views of it)."""
 
     @staticmethod
-    def forward(ctx, module: "FlatArenaDenoiser", x: Tensor, t: Tensor, y_eff: Tensor | None, anchor: Tensor) -> Tensor:
-        ctx.module = module
+    def forward(ctx, module: "FlatArenaDenoiser", x: Tensor, t: Tensor, y_eff: Tensor | None, anchor: Tensor, taps: tuple = ()):
+        """taps: indices of blocks whose output (the residual stream after the block, bf16 [B, N, D]) is returned as extra
+        differentiable outputs -- what a forward hook on ``denoiser.layers[i]`` sees in the reference (RePA, repa.py:133-134)"""
+        ctx.module, ctx.taps = module, tuple(taps)
         ctx.set_materialize_grads(False)
-        return module._engine.forward(x, t, y_eff, train=True).clone()
+        pred = module._engine.forward(x, t, y_eff, train=True).clone()
+        ctx.pred_shape = pred.shape
+        if not taps:
+            return pred
+        return (pred, *(module._engine.feature(k) for k in taps))
 
     @staticmethod
-    def backward(ctx, dpred: Tensor | None):
+    def backward(ctx, dpred: Tensor | None, *dfeats):
         m = ctx.module
-        if dpred is not None:
+        grads = {k: g for k, g in zip(ctx.taps, dfeats) if g is not None}
+        if dpred is not None or grads:
             m._prepare_grads()
-            m._engine.backward(dpred.contiguous().float())
-        return None, None, None, None, None
+            if dpred is None:
+                dpred = torch.zeros(ctx.pred_shape, device=m._engine.dev)
+            m._engine.backward(dpred.contiguous().float(), grads)
+        return None, None, None, None, None, None
 
 
 class FlatArenaDenoiser(Denoiser):
@@ -156,11 +165,15 @@ class FlatArenaDenoiser(Denoiser):
             self.flatten_parameters()
         return self._engine
 
-    def _run(self, x: Tensor, t: Tensor, y_eff: Tensor | None) -> Tensor:
+    def _run(self, x: Tensor, t: Tensor, y_eff: Tensor | None, taps: tuple = ()):
+        """prediction (and, with taps, the tapped block outputs)"""
         eng = self.engine
         need_grad = torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())
         if need_grad:
-            return EngineFn.apply(self, x, t, y_eff, self._anchor)
+            return EngineFn.apply(self, x, t, y_eff, self._anchor, tuple(taps))
+        if taps:  # validation with an auxiliary loss on intermediate features: run the keep-everything sequence eagerly
+            pred = eng.forward(x, t, y_eff, train=True).clone()
+            return (pred, *(eng.feature(k).clone() for k in taps))
         return self._infer(eng, x, t, y_eff)
 
     def _infer(self, eng, x: Tensor, t: Tensor, y_eff: Tensor | None) -> Tensor:

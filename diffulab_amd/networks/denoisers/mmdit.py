@@ -187,4 +187,13 @@ class MMDiT(FlatArenaDenoiser):
             if p > 0:  # LabelEmbed.drop_labels nn.py:149 -- torch device RNG, same draw as the reference
                 y_eff = torch.where(torch.rand(y_eff.size(), device=dev) < p, self.n_classes, y_eff)
             y_eff = y_eff.contiguous()
-        return {"x": self._run(x, t, y_eff)}
+        # forward hooks registered on a block (RePA: ``denoiser.layers[i].register_forward_hook``, repa.py:133-134) receive the
+        # block's output as an extra differentiable output of the engine
+        taps = tuple(i for i, layer in enumerate(self.layers) if layer._forward_hooks)
+        if not taps:
+            return {"x": self._run(x, t, y_eff)}
+        pred, *feats = self._run(x, t, y_eff, taps)
+        for i, f in zip(taps, feats):
+            for hook in list(self.layers[i]._forward_hooks.values()):
+                hook(self.layers[i], (), f)
+        return {"x": pred}

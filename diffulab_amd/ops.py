@@ -255,6 +255,17 @@ def reduce_rows_f32(partial, out, G, n, clear=False):
     _call("dl_reduce_rows_f32", _p(partial), _p(out), G, n, int(clear), _s())
 
 
+def cosine_rows_fwd(p, d, cosv, pn2, dn2, eps=1e-8):
+    M, E = p.shape
+    _call("dl_cosine_rows_fwd", _p(p), p.stride(0), _p(d), d.stride(0), _p(cosv), _p(pn2), _p(dn2), M, E, float(eps), _s())
+
+
+def cosine_rows_bwd(p, d, cosv, pn2, dn2, gscale, gscale_dev, dp, eps=1e-8):
+    M, E = p.shape
+    _call("dl_cosine_rows_bwd", _p(p), p.stride(0), _p(d), d.stride(0), _p(cosv), _p(pn2), _p(dn2), float(gscale),
+          _p(gscale_dev), _p(dp), dp.stride(0), M, E, float(eps), _s())
+
+
 # ------------------------------------------------------------------ optimizer side
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
     _call("dl_adamw_step", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),

@@ -554,8 +554,9 @@ class UNetEngine:
         return pred
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dpred: Tensor) -> None:
+    def backward(self, dpred: Tensor, dfeats: dict | None = None) -> None:
         """dpred f32 [B, out_channels, H, W]; accumulates every parameter gradient into the gradient arena"""
+        assert not dfeats, "the UNet engine exposes no intermediate features"
         s, d, plan = self._saved, self.d, self.plan
         assert s is not None, "backward without a train-mode forward"
         self._saved = None

@@ -210,6 +210,15 @@ DL_API int dl_colsum(const void* x, int dtype, int64_t ld, float* out, int64_t R
  * as it is read, so accumulate-into partial buffers need no memset */
 DL_API int dl_reduce_rows_f32(float* partial, float* out, int64_t G, int64_t n, int clear_partial, dl_stream_t stream);
 
+/* RePA alignment loss (training/losses/repa.py:196-198): row-wise F.cosine_similarity(p, d, dim=-1, eps) between the projected
+ * denoiser features p (bf16 [M, E]) and the target encoder features d (f32 [M, E]); |p|^2 and |d|^2 are kept for the backward.
+ * backward: dp = gscale * (*gscale_dev) * d cos / d p  (bf16). */
+DL_API int dl_cosine_rows_fwd(const void* p, int64_t ldp, const float* d, int64_t ldd, float* cosv, float* pn2, float* dn2,
+                              int64_t M, int64_t E, float eps, dl_stream_t stream);
+DL_API int dl_cosine_rows_bwd(const void* p, int64_t ldp, const float* d, int64_t ldd, const float* cosv, const float* pn2,
+                              const float* dn2, float gscale, const float* gscale_dev, void* dp, int64_t lddp, int64_t M,
+                              int64_t E, float eps, dl_stream_t stream);
+
 /* ------------------------------------------------------------------ optimizer side */
 /* torch.optim.AdamW single-tensor math (configs/optimizer/adamw.yaml) over a flat f32 buffer:
  *   p *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= (lr/bc1) m / (sqrt(v)/sqrt(bc2) + eps) */

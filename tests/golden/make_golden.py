@@ -457,9 +457,48 @@ def gen_loss_curve() -> None:
          final_qkv0=m.layers[0].attention.qkv.weight.detach().flatten()[::577][:256])
 
 
+# ------------------------------------------------------------------ (ix) REPA loss hooked into a small DiT
+def gen_repa() -> None:
+    """the reference RepaLoss (training/losses/repa.py) with precomputed target features, hooked on layers[0] of the small DiT,
+    evaluated through Flow.compute_loss(extra_losses=[...]).  Its encoder / resampler imports need torchvision (absent): those
+    three modules are stubbed, the loss code itself is the reference's."""
+    import importlib
+
+    root = os.path.join(REF, "diffulab")
+    rp = types.ModuleType("diffulab.networks.repa")
+    rp.__path__ = [f"{root}/networks/repa"]  # type: ignore[attr-defined]
+    sys.modules["diffulab.networks.repa"] = rp
+    for mod, cls in (("common", "REPA"), ("dinov2", "DinoV2"), ("perceiver_resampler", "PerceiverResampler")):
+        m = types.ModuleType(f"diffulab.networks.repa.{mod}")
+        setattr(m, cls, type(cls, (), {}))
+        sys.modules[f"diffulab.networks.repa.{mod}"] = m
+    RepaLoss = importlib.import_module("diffulab.training.losses.repa").RepaLoss
+    from oracle import repa as orepa
+
+    cfg = SMALL
+    m = build_ref(cfg, seed=5)
+    rl = RepaLoss(repa_encoder="dinov2", alignment_layer=1, denoiser_dimension=cfg.inner_dim, hidden_dim=128, load_dino=False,
+                  embedding_dim=64, coeff=0.5)
+    rl.load_state_dict(synth.generic_params(orepa.param_shapes(cfg.inner_dim, 128, 64), seed=41))
+    rl.set_model(m)
+    B, H = 4, 16
+    x0, noise = synth.normal("rp.x0", (B, 4, H, H)), synth.normal("rp.noise", (B, 4, H, H))
+    y, t = synth.integers("rp.y", (B,), 10), synth.uniform("rp.t", (B,), lo=0.05, hi=0.95)
+    dst = synth.normal("rp.dst", (B, (H // cfg.patch_size) ** 2, 64))
+    flow = Flow(n_steps=4, sampling_method="euler")
+    losses = flow.compute_loss(m, {"x": x0.clone(), "y": y, "p": 0.0}, t, noise, extra_losses=[rl], extra_args={"dst_features": dst})
+    sum(losses.values()).backward()
+    o = {"loss": losses["loss"], "repa": losses["RepaLoss"]}
+    for n, p in rl.named_parameters():
+        o["g_" + n] = p.grad
+    for n, p in m.named_parameters():
+        o["gd_" + n] = p.grad
+    save("repa", **o)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve"]
-    fns = {"schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
+    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve", "repa"]
+    fns = {"repa": gen_repa, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
            "s2": gen_s2_model, "samplers": gen_samplers, "curve": gen_loss_curve, "unet": gen_unet}
     for w in which:
         print("==", w)

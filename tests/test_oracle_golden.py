@@ -355,3 +355,29 @@ def test_unet_blocks_and_small_model(golden):
     for k in g:
         if k.startswith("un_g_") and norms[k[5:]] > floor:
             assert rel(P[k[5:]].grad, g[k]) < 2e-5, k
+
+
+def test_repa_loss_hooked_into_small_dit(golden):
+    """(ix) REPA alignment loss on the output of block 0 of the small DiT next to the flow loss: both losses, the projector
+    gradients and every denoiser gradient (the feature gradient re-enters the residual stream) vs the reference"""
+    from oracle import repa as orepa
+
+    g = golden("repa")
+    cfg = SMALL
+    P = {k: v.requires_grad_(True) for k, v in synth.dit_params(odit.param_shapes(cfg), seed=5).items()}
+    R = {k: v.requires_grad_(True) for k, v in synth.generic_params(orepa.param_shapes(cfg.inner_dim, 128, 64), seed=41).items()}
+    B, H = 4, 16
+    x0, noise = synth.normal("rp.x0", (B, 4, H, H)), synth.normal("rp.noise", (B, 4, H, H))
+    y, t = synth.integers("rp.y", (B,), 10), synth.uniform("rp.t", (B,), lo=0.05, hi=0.95)
+    dst = synth.normal("rp.dst", (B, (H // cfg.patch_size) ** 2, 64))
+    taps: dict = {}
+    pred = odit.dit_forward(P, od.flow_add_noise(x0, t, noise), t, y, cfg, taps=taps)
+    loss = od.flow_loss(pred, x0, noise)
+    repa = orepa.repa_loss(R, taps["layer0"], dst, coeff=0.5)
+    (loss + repa).backward()
+    assert abs(loss.item() - float(g["loss"])) / float(g["loss"]) < 1e-6
+    assert abs(repa.item() - float(g["repa"])) / float(g["repa"]) < 1e-6
+    for n, v in R.items():
+        assert rel(v.grad, g["g_" + n]) < 1e-5, n
+    for n, v in P.items():
+        assert rel(v.grad, g["gd_" + n]) < 2e-5, n
