@@ -12,11 +12,13 @@ from .base import BatchData
 
 class SyntheticDataset(Dataset):
     def __init__(self, n_samples: int = 1024, shape: tuple[int, ...] | list[int] = (1, 32, 32), n_classes: int | None = 10,
-                 seed: int = 1234) -> None:
+                 seed: int = 1234, dst_features_shape: tuple[int, ...] | list[int] | None = None) -> None:
         super().__init__()
         g = torch.Generator().manual_seed(seed)
         self.images = torch.randn(n_samples, *shape, generator=g).clamp_(-3, 3) / 3  # in [-1, 1] like normalised images
         self.labels = torch.randint(0, n_classes, (n_samples,), generator=g) if n_classes is not None else None
+        # REPA: precomputed encoder features per sample (datasets/imagenet.py:177-236 ships them as "dst_features")
+        self.dst_features = torch.randn(n_samples, *dst_features_shape, generator=g) if dst_features_shape else None
 
     def __len__(self) -> int:
         return self.images.shape[0]
@@ -25,4 +27,7 @@ class SyntheticDataset(Dataset):
         inputs = {"x": self.images[idx]}
         if self.labels is not None:
             inputs["y"] = self.labels[idx]
-        return {"model_inputs": inputs}
+        item: BatchData = {"model_inputs": inputs}
+        if self.dst_features is not None:
+            item["extra"] = {"dst_features": self.dst_features[idx]}
+        return item

@@ -40,29 +40,41 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = 1.0  # data parallel: 1/world (gradients are SUM-reduced), folded into the update kernel
 
-    def _flat(self, group) -> tuple[Tensor, Tensor] | None:
+    def _flat(self, group) -> tuple[Tensor, Tensor, list] | None:
+        """(param arena, grad arena, parameters NOT in it) when (most of) the group lives in one flat arena -- e.g. a denoiser's
+        arena plus the few tensors of an auxiliary loss head (REPA projector) in the same param group -- else None"""
         ps = [p for p in group["params"] if p.requires_grad]
-        pb, gb = _arena_of(ps, False), _arena_of(ps, True)
+        by_store: dict[int, list] = {}
+        for p in ps:
+            if p.grad is None or p.data.dtype != torch.float32:
+                continue
+            by_store.setdefault(p.data.untyped_storage().data_ptr(), []).append(p)
+        if not by_store:
+            return None
+        inside = max(by_store.values(), key=lambda v: sum(q.numel() for q in v))
+        pb, gb = _arena_of(inside, False), _arena_of(inside, True)
         if pb is None or gb is None or pb.numel() != gb.numel():
             return None
-        if any(p.data.storage_offset() != p.grad.storage_offset() for p in ps):
+        if any(p.data.storage_offset() != p.grad.storage_offset() for p in inside):
             return None
-        if sum(p.numel() for p in ps) < 0.9 * pb.numel():  # the group must own (almost) the whole arena
+        if sum(p.numel() for p in inside) < 0.9 * pb.numel():  # the group must own (almost) the whole arena
             return None
-        return pb, gb
+        ids = {id(p) for p in inside}
+        return pb, gb, [p for p in group["params"] if id(p) not in ids]
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         for group in self.param_groups:
-            flat = self._flat(group) if all(p.grad is not None for p in group["params"]) else None
+            flat = self._flat(group)
+            rest = group["params"]
             if flat is not None:
                 flat[1].zero_()  # one memset; .grad views stay attached
-            else:
-                for p in group["params"]:
-                    if p.grad is not None:
-                        if set_to_none:
-                            p.grad = None
-                        else:
-                            p.grad.zero_()
+                rest = flat[2]
+            for p in rest:
+                if p.grad is not None:
+                    if set_to_none:
+                        p.grad = None
+                    else:
+                        p.grad.zero_()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -70,8 +82,9 @@ class FusedAdamW(torch.optim.Optimizer):
         for group in self.param_groups:
             b1, b2 = group["betas"]
             flat = self._flat(group)
+            rest = group["params"]
             if flat is not None:
-                pb, gb = flat
+                pb, gb, rest = flat
                 st = self.state.setdefault("arena%d" % pb.data_ptr(), {})
                 if not st:
                     st["step"], st["m"], st["v"] = 0, torch.zeros_like(pb), torch.zeros_like(pb)
@@ -79,8 +92,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 ops.adamw_step(pb, gb, st["m"], st["v"], group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"],
                                self.grad_scale)
                 bump_param_epoch()  # raw-pointer writes bump no torch version counter: tell the engines
-            else:
-                for p in group["params"]:
+            if rest:
+                for p in rest:
                     if p.grad is None:
                         continue
                     st = self.state[p]

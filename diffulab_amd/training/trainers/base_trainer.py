@@ -51,6 +51,7 @@ class BaseTrainer(Trainer):
         loss = sum(losses.values())
         (loss / self.gradient_accumulation_step).backward()
         if self.sync_gradients:
+            self.reduce_extra_grads(diffuser)
             optimizer.step()
             if scheduler is not None and per_batch_scheduler:
                 scheduler.step()
@@ -102,7 +103,8 @@ class BaseTrainer(Trainer):
                 ema_denoiser.ema_model.load_state_dict(torch.load(ema_ckpt, weights_only=True))
         else:
             ema_denoiser = None
-        for loss in diffuser.extra_losses:
+        for loss in diffuser.extra_losses:  # accelerator.prepare(loss) in the reference: device placement, then the hooks
+            loss.to(self.device)
             loss.set_model(diffuser.denoiser)
         if getattr(diffuser.denoiser, "context_embedder", None) is not None and not train_embedder:
             for param in diffuser.denoiser.context_embedder.parameters():

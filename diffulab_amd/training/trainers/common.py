@@ -130,6 +130,21 @@ class Trainer(ABC):
     def end_micro_step(self) -> None:
         self._micro += 1
 
+    def reduce_extra_grads(self, diffuser: "Diffuser") -> None:
+        """data parallel: parameters of auxiliary loss heads (REPA projector) live outside the denoiser's gradient arena, so
+        their gradients are summed here (the 1/world factor is the optimizer's grad_scale, like for the arena)"""
+        if self.world == 1:
+            return
+        for loss in diffuser.extra_losses:
+            grads = [p.grad for p in loss.parameters() if p.grad is not None]
+            if grads:
+                flat = torch.cat([g.reshape(-1) for g in grads])
+                dist.all_reduce(flat)
+                off = 0
+                for g in grads:
+                    g.copy_(flat[off : off + g.numel()].view_as(g))
+                    off += g.numel()
+
     def gather_mean(self, value: float) -> float:
         if self.world == 1:
             return float(value)

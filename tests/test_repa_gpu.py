@@ -77,3 +77,47 @@ def test_repa_loss_with_flow_loss_against_reference_fixture(golden):
     assert abs(v["RepaLoss"].item() - float(g["repa"])) / float(g["repa"]) < 2e-3
     rl._unregister_all()
     assert not m.layers[0]._forward_hooks
+
+
+def test_repa_config_dims_against_oracle():
+    """dims of configs/train_imagenet_flow_matching_repa.yaml (DC-AE latents 32x8x8, patch 1 -> 64 tokens, inner 768, 12 heads,
+    embedding 256) at depth 3, REPA hooked on block 2 with hidden 1024 / target dim 1024 (no resampler): losses and every
+    gradient against the CPU oracle -- covers the D = 768 row kernels and the 64-token attention"""
+    from diffulab_amd import Diffuser, MMDiT
+    from diffulab_amd.training.losses import RepaLoss
+    from oracle import diffusion as od
+
+    kw = dict(input_channels=32, output_channels=32, inner_dim=768, embedding_dim=256, num_heads=12, mlp_ratio=4, patch_size=1,
+              depth=3, n_classes=1000, classifier_free=True)
+    cfg = odit.DiTConfig(**kw)
+    P = synth.dit_params(odit.param_shapes(cfg), seed=13)
+    R = synth.generic_params(orepa.param_shapes(768, 1024, 1024), seed=43)
+    m = MMDiT(simple_dit=True, **kw)
+    m.load_state_dict(P)
+    m = m.to(DEV)
+    rl = RepaLoss(alignment_layer=2, denoiser_dimension=768, hidden_dim=1024, load_dino=False, embedding_dim=1024, coeff=0.5)
+    rl.load_state_dict(R)
+    rl = rl.to(DEV)
+    rl.set_model(m)
+    B = 4
+    x0, noise = synth.normal("rb.x0", (B, 32, 8, 8)), synth.normal("rb.noise", (B, 32, 8, 8))
+    y, t = synth.integers("rb.y", (B,), 1000), synth.uniform("rb.t", (B,), lo=0.05, hi=0.95)
+    dst = synth.normal("rb.dst", (B, 64, 1024))
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=4, extra_losses=[rl])
+    losses = d.compute_loss({"x": x0.to(DEV), "y": y.to(DEV), "p": 0.0}, timesteps=t, noise=noise.to(DEV),
+                            extra_args={"dst_features": dst.to(DEV)})
+    sum(losses.values()).backward()
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    Rr = {k: v.clone().requires_grad_(True) for k, v in R.items()}
+    taps: dict = {}
+    pred = odit.dit_forward(Pr, od.flow_add_noise(x0, t, noise), t, y, cfg, taps=taps)
+    ref_loss = od.flow_loss(pred, x0, noise)
+    ref_repa = orepa.repa_loss(Rr, taps["layer1"], dst, coeff=0.5)
+    (ref_loss + ref_repa).backward()
+    assert abs(losses["loss"].item() - ref_loss.item()) / ref_loss.item() < 2e-3
+    assert abs(losses["RepaLoss"].item() - ref_repa.item()) / ref_repa.item() < 2e-3
+    for n, p in rl.named_parameters():
+        assert rel(p.grad, Rr[n].grad) < 3e-2, n
+    bad = [(n, rel(p.grad, Pr[n].grad)) for n, p in m.named_parameters() if Pr[n].grad.norm() > 0]
+    bad = [(n, e) for n, e in bad if e > 3e-2]
+    assert not bad, bad
