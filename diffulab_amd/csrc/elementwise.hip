@@ -499,6 +499,51 @@ extern "C" int dl_cast_weight(const float* src, int64_t R, int64_t C, void* dst,
   return DL_OK;
 }
 
+// every bf16 weight shadow of a network in ONE launch: a device table of descriptors, one 32x32 tile per workgroup
+__global__ void cast_weights_batched_k(const dl_cast_desc_t* __restrict__ desc, int n_desc) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n_desc - 1;  // last descriptor whose tile_begin <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].tile_begin <= (int64_t)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const dl_cast_desc_t d = desc[lo];
+  const int64_t t = (int64_t)blockIdx.x - d.tile_begin;
+  const int64_t r0 = (t / d.tiles_c) * 32, c0 = (t % d.tiles_c) * 32;
+  const float* src = (const float*)d.src;
+  bf16_t* dst = (bf16_t*)d.dst;
+  bf16_t* dstT = (bf16_t*)d.dst_t;
+  bf16_t* dstP = (bf16_t*)d.dst_swiglu;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t r = r0 + ty + j * 8, c = c0 + tx;
+    const float v = (r < d.R && c < d.C) ? src[r * d.C + c] : 0.0f;
+    tile[ty + j * 8][tx] = v;
+    if (dst && r < d.R && c < d.ld_dst) dst[r * d.ld_dst + c] = f2bf(v);
+    if (dstP && r < d.R && c < d.ld_swiglu) {  // row order of dl_cast_weight_swiglu: 32-row groups [16 x1 | 16 x3]
+      const int64_t F = d.R >> 1;
+      const int64_t rr = r < F ? r : r - F;
+      dstP[((rr >> 4) * 32 + (r < F ? 0 : 16) + (rr & 15)) * d.ld_swiglu + c] = f2bf(v);
+    }
+  }
+  __syncthreads();
+  if (dstT) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t c = c0 + ty + j * 8, r = r0 + tx;
+      if (c < d.C && r < d.ld_t) dstT[c * d.ld_t + r] = f2bf(tile[tx][ty + j * 8]);
+    }
+  }
+}
+extern "C" int dl_cast_weights_batched(const dl_cast_desc_t* desc_dev, int n_desc, int64_t total_tiles, dl_stream_t stream) {
+  DL_CHECK_ARG(desc_dev && n_desc > 0 && total_tiles > 0 && total_tiles < (1ll << 31), "dl_cast_weights_batched: bad args");
+  hipLaunchKernelGGL(cast_weights_batched_k, (int)total_tiles, 256, 0, (hipStream_t)stream, desc_dev, n_desc);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
 // row-permuted bf16 copy of the packed SwiGLU weight (see dl_gemm_nt_swiglu): dst row n' <- src row perm(n')
 __global__ void cast_weight_swiglu_k(const float* __restrict__ src, int F, int C, bf16_t* __restrict__ dst, int64_t ld) {
   const int64_t total = (int64_t)2 * F * ld, stride = (int64_t)gridDim.x * blockDim.x;

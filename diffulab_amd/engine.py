@@ -154,6 +154,8 @@ class DiTEngine:
         self.manual_version = 0
         self._ws_key: tuple | None = None
         self._ws_cache: dict[tuple, tuple] = {}
+        self._cast_table = None
+        self._cast_table_ptr = 0
         self._rope: dict[tuple[int, int], tuple[Tensor, Tensor]] = {}
         self.reducer = None  # optional training.dp.GradReducer: gets ready(lo, hi) as gradient ranges complete
         self._build_shadows()
@@ -215,11 +217,13 @@ class DiTEngine:
         key = (self.params.data_ptr(), ver, self.manual_version, _PARAM_EPOCH)
         if not force and key == self._shadow_key:
             return
-        for name, shape, f, t in self._casts:
-            ops.cast_weight(self._src(name, shape), self.sh[f] if f else None, self.sh[t] if t else None)
-        for i in range(self.d.depth):  # row-permuted copy of the packed SwiGLU weight for the fused MLP-up kernel
-            name = f"layers.{i}.mlp_input.0.weight"
-            ops.cast_weight_swiglu(self.P(name), self.sh[name + "|g"])
+        if self._cast_table is None or self._cast_table_ptr != self.params.data_ptr():
+            ent = []  # one device table for all shadows (incl. the row-permuted MLP-up copy of the fused SwiGLU kernel)
+            for name, shape, f, t in self._casts:
+                g = self.sh.get(name + "|g")
+                ent.append((self._src(name, shape), self.sh[f] if f else None, self.sh[t] if t else None, g))
+            self._cast_table, self._cast_table_ptr = ops.CastTable(ent), self.params.data_ptr()
+        self._cast_table.run()
         self._shadow_key = key
 
     def _side_stream(self) -> "torch.cuda.Stream":

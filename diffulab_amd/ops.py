@@ -278,6 +278,40 @@ def cast_weight(src, dst, dst_t):
           dst_t.stride(0) if dst_t is not None else 0, _s())
 
 
+class CastTable:
+    """device table for dl_cast_weights_batched: every bf16 shadow of a network refreshed by ONE launch.
+    entries: (src f32 [R, C], dst | None, dst_t | None, dst_swiglu | None)"""
+
+    def __init__(self, entries: list[tuple[Tensor, Tensor | None, Tensor | None, Tensor | None]]) -> None:
+        import ctypes
+
+        class Desc(ctypes.Structure):
+            _fields_ = [("src", ctypes.c_void_p), ("R", ctypes.c_int64), ("C", ctypes.c_int64), ("dst", ctypes.c_void_p),
+                        ("ld_dst", ctypes.c_int64), ("dst_t", ctypes.c_void_p), ("ld_t", ctypes.c_int64),
+                        ("dst_swiglu", ctypes.c_void_p), ("ld_swiglu", ctypes.c_int64), ("tile_begin", ctypes.c_int64),
+                        ("tiles_c", ctypes.c_int64)]
+
+        arr = (Desc * len(entries))()
+        tiles = 0
+        self.keep = entries  # the table holds raw pointers: keep the tensors alive
+        for i, (src, dst, dst_t, dst_g) in enumerate(entries):
+            R, C = src.shape
+            assert src.is_contiguous() and src.dtype == torch.float32
+            cmax = max(C, dst.stride(0) if dst is not None else 0, dst_g.stride(0) if dst_g is not None else 0)
+            rmax = max(R, dst_t.stride(0) if dst_t is not None else 0)
+            tc, tr = (cmax + 31) // 32, (rmax + 31) // 32
+            arr[i] = Desc(_p(src), R, C, _p(dst), dst.stride(0) if dst is not None else 0, _p(dst_t),
+                          dst_t.stride(0) if dst_t is not None else 0, _p(dst_g), dst_g.stride(0) if dst_g is not None else 0,
+                          tiles, tc)
+            tiles += tc * tr
+        self.n, self.tiles = len(entries), tiles
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.dev = host.to(entries[0][0].device)
+
+    def run(self) -> None:
+        _call("dl_cast_weights_batched", _p(self.dev), self.n, self.tiles, _s())
+
+
 def cast_weight_swiglu(src, dst):
     _call("dl_cast_weight_swiglu", _p(src), src.shape[0] // 2, src.shape[1], _p(dst), dst.stride(0), _s())
 

@@ -232,6 +232,21 @@ DL_API int dl_cast_weight(const float* src, int64_t R, int64_t C, void* dst, int
 /* bf16 shadow of the packed-SwiGLU weight [2F, C] with the row order dl_gemm_nt_swiglu expects: inside every group of
  * 32 output rows, rows 0..15 are x1 rows 16q..16q+15 and rows 16..31 are x3 rows 16q..16q+15 (q = group index; F % 16 == 0). */
 DL_API int dl_cast_weight_swiglu(const float* src, int64_t F, int64_t C, void* dst, int64_t ld_dst, dl_stream_t stream);
+/* all shadows of a network in one launch: `desc_dev` is a DEVICE array of n_desc descriptors ordered by tile_begin (tiles
+ * are 32x32 blocks over max(R, ld_t) x max(C, ld_dst, ld_swiglu), tiles_c per row of blocks; total_tiles = sum).  dst /
+ * dst_t as in dl_cast_weight, dst_swiglu as in dl_cast_weight_swiglu (R = 2F); any destination may be NULL. */
+typedef struct {
+  const void* src; /* f32 [R, C] */
+  int64_t R, C;
+  void* dst;
+  int64_t ld_dst;
+  void* dst_t;
+  int64_t ld_t;
+  void* dst_swiglu;
+  int64_t ld_swiglu;
+  int64_t tile_begin, tiles_c;
+} dl_cast_desc_t;
+DL_API int dl_cast_weights_batched(const dl_cast_desc_t* desc_dev, int n_desc, int64_t total_tiles, dl_stream_t stream);
 /* plain casts */
 DL_API int dl_cast_f32_to_bf16(const float* src, void* dst, int64_t n, dl_stream_t stream);
 DL_API int dl_cast_bf16_to_f32(const void* src, float* dst, int64_t n, dl_stream_t stream);
