@@ -1,0 +1,36 @@
+"""micro-benchmark of the HBM-bound row kernels at the DiT-S/2 (B=256) shape: [65536, 384] bf16 rows.
+    python scripts/row_kernel_bench.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from diffulab_amd import ops
+
+dev = "cuda"
+B, N, D = 256, 256, 384
+M = B * N
+bf = torch.bfloat16
+x, t = torch.randn(M, D, device=dev).to(bf), torch.randn(M, D, device=dev).to(bf)
+mod = torch.randn(B, 6 * D, device=dev).to(bf)
+w, b = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+out, xo = torch.empty_like(x), torch.empty_like(x)
+mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+
+
+def timeit(fn, iters=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+us = timeit(lambda: ops.ln_modulate_fwd(x, w, b, mod[:, :D], mod[:, D:2 * D], N, 1e-5, out, mean, rstd))
+print(f"ln_mod_fwd plain          : {us:7.1f} us  {2 * M * D * 2 / us / 1e6:5.2f} TB/s")
+us = timeit(lambda: ops.ln_modulate_fwd(x, w, b, mod[:, :D], mod[:, D:2 * D], N, 1e-5, out, mean, rstd, t=t,
+                                        gate=mod[:, 2 * D:3 * D], x_out=xo))
+print(f"ln_mod_fwd + gated resid  : {us:7.1f} us  {4 * M * D * 2 / us / 1e6:5.2f} TB/s")
