@@ -120,3 +120,42 @@ def test_base_trainer_train_loop_checkpoints_and_logs(tmp_path):
     kw = dict(timesteps=torch.tensor([0.3, 0.7], device=DEV), y=torch.tensor([1, 2], device=DEV))
     with torch.no_grad():
         assert rel(m2(x=x, **kw)["x"], m(x=x, **kw)["x"]) < 1e-6
+
+
+def test_grad_reducer_on_rccl_single_rank():
+    """the data-parallel reduction path (comm stream, events from the side-stream wgrads, async RCCL all-reduce of arena ranges,
+    1/world folded into AdamW) executed for real on the GPU with a 1-rank RCCL group: gradients must equal the plain run"""
+    import os
+
+    import torch.distributed as dist
+
+    from diffulab_amd import Diffuser
+    from diffulab_amd.training.dp import GradReducer, broadcast_arena
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        B = 8
+        x0 = synth.normal("rc.x0", (B, 4, 16, 16)).to(DEV)
+        noise = synth.normal("rc.noise", (B, 4, 16, 16)).to(DEV)
+        y = synth.integers("rc.y", (B,), 10).to(DEV)
+        t = synth.uniform("rc.t", (B,), lo=0.05, hi=0.95)
+        ma, mb = small_dit(), small_dit()
+        broadcast_arena(mb.engine.params)
+        red = GradReducer(mb._flat_grad, bucket_bytes=1 << 18)  # small buckets: several collectives per backward
+        red.enabled = True  # world == 1 would switch it off
+        red.comm_stream = torch.cuda.Stream()
+        mb.engine.reducer = red
+        for m in (ma, mb):
+            d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=4)
+            d.compute_loss({"x": x0.clone(), "y": y, "p": 0.0}, timesteps=t, noise=noise)["loss"].backward()
+        torch.cuda.synchronize()
+        assert red.grad_scale == 1.0 and not red._works and not red._pending
+        # (not bit-equal: split-R wgrads and the LayerNorm column sums meet through f32 atomics, whose order varies run to run)
+        assert rel(mb._flat_grad, ma._flat_grad) < 1e-5
+    finally:
+        if created:
+            dist.destroy_process_group()
