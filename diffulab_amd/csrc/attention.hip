@@ -9,10 +9,12 @@
 // half hi <-> key (j&3) + 8(j>>2) + 4hi), i.e. P never round-trips through LDS.  The matching A operands
 // (V^T, K^T, Q^T, dO^T) come from the row-major LDS tiles through ds_read_b64_tr_b16 transposing reads.
 //
-// Backward (FlashAttention-2 style recompute from lse) runs two phases over the same resident tiles:
-//   A: wave owns 32 queries, sweeps key blocks  -> dQ
-//   B: wave owns 32 keys,    sweeps query blocks -> dK, dV
-// S and dP are recomputed in both phases (7 instead of 5 matmuls) which removes every cross-wave reduction.
+// Backward (FlashAttention-2 style recompute from lse) runs two phases:
+//   A: wave owns 32 queries, sweeps key blocks   -> dQ     (K, V resident in LDS; its q / dO fragments come from HBM)
+//   B: wave owns 32 keys,    sweeps query blocks -> dK, dV (Q, dO resident in the SAME LDS; its k / v fragments from HBM)
+// S and dP are recomputed in both phases (7 instead of 5 matmuls) which removes every cross-wave reduction.  Only two of
+// the four tiles are resident at a time (64 KiB at N = 256) and a workgroup is N/64 waves, each owning two 32-row blocks:
+// two workgroups share a CU, so one head's tile loads overlap the other's MFMA phases.
 #include "common.h"
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -180,18 +182,21 @@ extern "C" int dl_attn_fwd(const void* q, const void* k, const void* v, void* ou
 }
 
 // ====================================================================================== backward
-__global__ __launch_bounds__(512) void attn_bwd_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                  const bf16_t* __restrict__ v, const bf16_t* __restrict__ out,
-                                                  const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                  bf16_t* __restrict__ dq, bf16_t* __restrict__ dk,
-                                                  bf16_t* __restrict__ dv, int H, int N, float scale) {
+// global-memory version of frag_rows: row-major [N][64] matrix with row pitch `pitch` elements
+__device__ __forceinline__ bf16x8_t frag_rows_g(const bf16_t* __restrict__ g, int64_t pitch, int row, int ks, int hi) {
+  return *(const bf16x8_t*)(g + (int64_t)row * pitch + (ks * 2 + hi) * 8);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                     const bf16_t* __restrict__ v, const bf16_t* __restrict__ out,
+                                                     const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                     bf16_t* __restrict__ dq, bf16_t* __restrict__ dk,
+                                                     bf16_t* __restrict__ dv, int H, int N, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* qt = smem;
-  char* kt = qt + N * ROWB;
-  char* vt = kt + N * ROWB;
-  char* dot = vt + N * ROWB;
-  float* lse2 = (float*)(dot + N * ROWB);  // lse * log2(e)
-  float* delta = lse2 + N;                 // rowsum(dO * O)
+  char* ta = smem;             // phase A: K   | phase B: Q
+  char* tb = ta + N * ROWB;    // phase A: V   | phase B: dO
+  float* lse2 = (float*)(tb + N * ROWB);  // lse * log2(e)
+  float* delta = lse2 + N;                // rowsum(dO * O)
   const int lane = threadIdx.x & 63, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
   const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
@@ -199,10 +204,8 @@ __global__ __launch_bounds__(512) void attn_bwd_k(const bf16_t* __restrict__ q, 
   const int64_t tok_pitch = (int64_t)H * DH;
   const bf16_t* og = out + (int64_t)b * N * tok_pitch + h * DH;
   const bf16_t* dog = dout + (int64_t)b * N * tok_pitch + h * DH;
-  tile_dma(q + hoff, DH, qt, N, wave, nwaves, lane);
-  tile_dma(k + hoff, DH, kt, N, wave, nwaves, lane);
-  tile_dma(v + hoff, DH, vt, N, wave, nwaves, lane);
-  tile_dma(dog, tok_pitch, dot, N, wave, nwaves, lane);
+  tile_dma(k + hoff, DH, ta, N, wave, nwaves, lane);
+  tile_dma(v + hoff, DH, tb, N, wave, nwaves, lane);
   // delta and lse2: two threads per row, 32 head-dim columns each
   for (int row = threadIdx.x >> 1; row < N; row += blockDim.x >> 1) {
     const int half = threadIdx.x & 1;
@@ -227,15 +230,15 @@ __global__ __launch_bounds__(512) void attn_bwd_k(const bf16_t* __restrict__ q, 
   __syncthreads();
 
   const float c = scale * LOG2E;
-  const int own = wave * 32;  // phase A: first query row; phase B: first key row
 
-  // ------------------------------------------------------------------ phase A: dQ for queries own..own+31
-  {
+  // ------------------------------------------------------------------ phase A: dQ for the two query blocks of this wave
+  for (int ob = 0; ob < 2; ++ob) {
+    const int own = (wave * 2 + ob) * 32;
     bf16x8_t qf[4], dof[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      qf[ks] = frag_rows(qt, own + (lane & 31), ks, hi);
-      dof[ks] = frag_rows(dot, own + (lane & 31), ks, hi);
+      qf[ks] = frag_rows_g(q + hoff, DH, own + (lane & 31), ks, hi);
+      dof[ks] = frag_rows_g(dog, tok_pitch, own + (lane & 31), ks, hi);
     }
     const float my_lse = lse2[own + (lane & 31)], my_delta = delta[own + (lane & 31)];
     f32x16_t dqa[2];
@@ -247,8 +250,8 @@ __global__ __launch_bounds__(512) void attn_bwd_k(const bf16_t* __restrict__ q, 
       for (int r = 0; r < 16; ++r) st[r] = dpt[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        st = MFMA(frag_rows(kt, kb + (lane & 31), ks, hi), qf[ks], st);
-        dpt = MFMA(frag_rows(vt, kb + (lane & 31), ks, hi), dof[ks], dpt);
+        st = MFMA(frag_rows(ta, kb + (lane & 31), ks, hi), qf[ks], st);
+        dpt = MFMA(frag_rows(tb, kb + (lane & 31), ks, hi), dof[ks], dpt);
       }
       float ds[16];
 #pragma unroll
@@ -259,8 +262,8 @@ __global__ __launch_bounds__(512) void attn_bwd_k(const bf16_t* __restrict__ q, 
 #pragma unroll
       for (int kg2 = 0; kg2 < 2; ++kg2) {
         const bf16x8_t df = pack_frag(&ds[kg2 * 8]);
-        dqa[0] = MFMA(frag_cols(kt, kb + kg2 * 16, 0, lane), df, dqa[0]);
-        dqa[1] = MFMA(frag_cols(kt, kb + kg2 * 16, 32, lane), df, dqa[1]);
+        dqa[0] = MFMA(frag_cols(ta, kb + kg2 * 16, 0, lane), df, dqa[0]);
+        dqa[1] = MFMA(frag_cols(ta, kb + kg2 * 16, 32, lane), df, dqa[1]);
       }
     }
     bf16_t* dqp = dq + hoff + (int64_t)(own + (lane & 31)) * DH;
@@ -275,13 +278,21 @@ __global__ __launch_bounds__(512) void attn_bwd_k(const bf16_t* __restrict__ q, 
       }
   }
 
-  // ------------------------------------------------------------------ phase B: dK, dV for keys own..own+31
-  {
+  // ------------------------------------------------------------------ swap the resident tiles: Q and dO replace K and V
+  __syncthreads();  // every wave is done reading K / V
+  tile_dma(q + hoff, DH, ta, N, wave, nwaves, lane);
+  tile_dma(dog, tok_pitch, tb, N, wave, nwaves, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ------------------------------------------------------------------ phase B: dK, dV for the two key blocks of this wave
+  for (int ob = 0; ob < 2; ++ob) {
+    const int own = (wave * 2 + ob) * 32;
     bf16x8_t kf[4], vf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      kf[ks] = frag_rows(kt, own + (lane & 31), ks, hi);
-      vf[ks] = frag_rows(vt, own + (lane & 31), ks, hi);
+      kf[ks] = frag_rows_g(k + hoff, DH, own + (lane & 31), ks, hi);
+      vf[ks] = frag_rows_g(v + hoff, DH, own + (lane & 31), ks, hi);
     }
     f32x16_t dka[2], dva[2];
 #pragma unroll
@@ -292,8 +303,8 @@ __global__ __launch_bounds__(512) void attn_bwd_k(const bf16_t* __restrict__ q, 
       for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s = MFMA(frag_rows(qt, qb + (lane & 31), ks, hi), kf[ks], s);
-        dp = MFMA(frag_rows(dot, qb + (lane & 31), ks, hi), vf[ks], dp);
+        s = MFMA(frag_rows(ta, qb + (lane & 31), ks, hi), kf[ks], s);
+        dp = MFMA(frag_rows(tb, qb + (lane & 31), ks, hi), vf[ks], dp);
       }
       float p[16], ds[16];
 #pragma unroll
@@ -312,10 +323,10 @@ __global__ __launch_bounds__(512) void attn_bwd_k(const bf16_t* __restrict__ q, 
         const bf16x8_t pf = pack_frag(&p[kg2 * 8]);
         const bf16x8_t df = pack_frag(&ds[kg2 * 8]);
         const int rbase = qb + kg2 * 16;
-        dva[0] = MFMA(frag_cols(dot, rbase, 0, lane), pf, dva[0]);
-        dva[1] = MFMA(frag_cols(dot, rbase, 32, lane), pf, dva[1]);
-        dka[0] = MFMA(frag_cols(qt, rbase, 0, lane), df, dka[0]);
-        dka[1] = MFMA(frag_cols(qt, rbase, 32, lane), df, dka[1]);
+        dva[0] = MFMA(frag_cols(tb, rbase, 0, lane), pf, dva[0]);
+        dva[1] = MFMA(frag_cols(tb, rbase, 32, lane), pf, dva[1]);
+        dka[0] = MFMA(frag_cols(ta, rbase, 0, lane), df, dka[0]);
+        dka[1] = MFMA(frag_cols(ta, rbase, 32, lane), df, dka[1]);
       }
     }
     bf16_t* dkp = dk + hoff + (int64_t)(own + (lane & 31)) * DH;
@@ -341,9 +352,9 @@ extern "C" int dl_attn_bwd(const void* q, const void* k, const void* v, const vo
   DL_CHECK_ARG(q && k && v && out && dout && lse && dq && dk && dv && B > 0 && H > 0, "dl_attn_bwd: null operand");
   DL_CHECK_ARG(dh == DH, "dl_attn_bwd: head_dim %lld unsupported (64 only)", (long long)dh);
   DL_CHECK_ARG(N % 64 == 0 && N >= 64 && N <= 256, "dl_attn_bwd: N=%lld must be a multiple of 64 in [64, 256]", (long long)N);
-  const int lds = (int)(4 * N * ROWB + 2 * N * sizeof(float));
+  const int lds = (int)(2 * N * ROWB + 2 * N * sizeof(float));
   (void)hipFuncSetAttribute((const void*)attn_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL(attn_bwd_k, (int)(B * H), (int)(N / 32) * 64, lds, (hipStream_t)stream, (const bf16_t*)q,
+  hipLaunchKernelGGL(attn_bwd_k, (int)(B * H), (int)(N / 64) * 64, lds, (hipStream_t)stream, (const bf16_t*)q,
                      (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dq,
                      (bf16_t*)dk, (bf16_t*)dv, (int)H, (int)N, scale);
   DL_LAUNCH_CHECK();
