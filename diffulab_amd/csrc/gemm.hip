@@ -368,7 +368,9 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
     // every tile costs the same time, so without a skew all 256 workgroups compute together and then store together (a
     // 50 MB write burst every ~11 us that each wave has to see acknowledged before its next-but-one k-step); four phase
     // groups spread the bursts over the tile period and let one group's stores drain while the others run MFMAs
-    const int phase = (blockIdx.x >> 3) & 3;
+    // (the column tiles of one A row-panel sit on one XCD in consecutive slots: they keep a common phase so that they still
+    // read the panel together out of that XCD's L2)
+    const int phase = ((blockIdx.x >> 3) / tiles_n) & 3;
     for (int w = 0; w < phase * nk * ep.stagger; ++w) __builtin_amdgcn_s_sleep(16);
   }
   int xrow[2], wrow[JN];
