@@ -1,0 +1,74 @@
+"""Training-step time of the DiT configurations of BASELINE.json on one MI355X (secondary numbers next to bench.py):
+    python scripts/train_step_bench.py cifar --batch 32     # configs/train_cifar10_flow_matching.yaml (dit.yaml dims, RGB 32x32)
+    python scripts/train_step_bench.py s2 --batch 256       # the headline DiT-S/2 workload (same step as bench.py)
+    python scripts/train_step_bench.py repa --batch 128     # DiT-B/REPA dims (768/12 heads/12 blocks, 32x8x8 latents) + REPA loss
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from diffulab_amd import Diffuser, MMDiT  # noqa: E402
+from diffulab_amd.training import FusedAdamW  # noqa: E402
+from diffulab_amd.training.losses import RepaLoss  # noqa: E402
+
+CFG = {
+    "cifar": (dict(input_channels=3, output_channels=3, inner_dim=512, embedding_dim=512, num_heads=8, mlp_ratio=4, patch_size=2,
+                   depth=10, n_classes=10, classifier_free=False), (3, 32, 32)),
+    "s2": (dict(input_channels=4, output_channels=4, inner_dim=384, embedding_dim=384, num_heads=6, mlp_ratio=4, patch_size=2,
+                depth=12, n_classes=1000, classifier_free=True), (4, 32, 32)),
+    "repa": (dict(input_channels=32, output_channels=32, inner_dim=768, embedding_dim=256, num_heads=12, mlp_ratio=4, patch_size=1,
+                  depth=12, n_classes=1000, classifier_free=True), (32, 8, 8)),
+}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config", choices=list(CFG))
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    a = ap.parse_args()
+    dev = "cuda"
+    kw, shape = CFG[a.config]
+    torch.manual_seed(0)
+    m = MMDiT(simple_dit=True, **kw).to(dev)
+    extra, params = [], list(m.parameters())
+    if a.config == "repa":
+        rl = RepaLoss(alignment_layer=8, denoiser_dimension=768, hidden_dim=1024, load_dino=False, embedding_dim=1024, coeff=0.5).to(dev)
+        rl.set_model(m)
+        extra, params = [rl], params + list(rl.proj.parameters())
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=50, extra_args={"logits_normal": True},
+                 extra_losses=extra)
+    opt = FusedAdamW(params, lr=1e-4, weight_decay=0.01)
+    x0 = torch.randn(a.batch, *shape, device=dev)
+    y = torch.randint(0, kw["n_classes"], (a.batch,), device=dev)
+    dst = torch.randn(a.batch, 64, 1024, device=dev) if a.config == "repa" else None
+    p = 0.1 if kw["classifier_free"] else 0.0
+
+    def step():
+        opt.zero_grad()
+        t = d.draw_timesteps(a.batch).to(dev, non_blocking=True)
+        losses = d.compute_loss({"x": x0, "y": y, "p": p}, timesteps=t, extra_args={"dst_features": dst} if dst is not None else {})
+        sum(losses.values()).backward()
+        opt.step()
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    print(json.dumps({"config": a.config, "batch": a.batch, "ms_per_step": round(dt * 1e3, 3), "images_per_s": round(a.batch / dt, 1),
+                      "params_M": round(sum(q.numel() for q in m.parameters()) / 1e6, 1)}))
+
+
+if __name__ == "__main__":
+    main()
