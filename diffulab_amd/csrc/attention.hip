@@ -1,6 +1,6 @@
 // Multi-head self-attention for DiT token grids (gfx950): softmax(q k^T * scale) v, head_dim 64, no mask.
 //
-// One workgroup per (batch, head).  N <= 512 tokens, so the whole K and V of a head (N x 64 bf16 = 32 KiB each
+// Up to 256 tokens: one workgroup per (batch, head), the whole K and V of a head (N x 64 bf16 = 32 KiB each
 // at N = 256) are DMA'd once into LDS (global_load_lds_dwordx4, bank swizzle applied on the source address)
 // and stay resident; every wave owns a 32-row block.  All matmuls are MFMA 32x32x16 bf16 computed in the
 // TRANSPOSED orientation (S^T = K Q^T, O^T = V^T P^T ...): the 32x32 accumulator then holds, per lane, one
@@ -15,6 +15,8 @@
 // S and dP are recomputed in both phases (7 instead of 5 matmuls) which removes every cross-wave reduction.  Only two of
 // the four tiles are resident at a time (64 KiB at N = 256) and a workgroup is N/64 waves, each owning two 32-row blocks:
 // two workgroups share a CU, so one head's tile loads overlap the other's MFMA phases.
+// Longer sequences (multiples of 256 up to 2048 tokens): `*_tiled_k` below run the same wave-level algorithms with one
+// workgroup per (batch, head, 256-row chunk) that streams the other operand through LDS in 256-row chunks.
 #include "common.h"
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -168,11 +170,115 @@ __global__ __launch_bounds__(512) void attn_fwd_k(const bf16_t* __restrict__ q, 
   if (hi == 0) lse[(int64_t)bh * N + qrow] = (m_run + log2f(l_tot)) * LN2;
 }
 
+// ------------------------------------------------------------------------------ forward, long sequences (N = 512 .. 2048)
+// Same wave-level algorithm, but a workgroup owns a 256-row query chunk of one head and streams K / V through LDS in
+// 256-key chunks (online softmax across chunks); grid = B * H * N/256.
+#define ACH 256
+__global__ __launch_bounds__(512) void attn_fwd_tiled_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                        const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
+                                                        float* __restrict__ lse, int H, int N, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* kt = smem;
+  char* vt = smem + ACH * ROWB;
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+  const int nch = N / ACH;
+  const int bh = blockIdx.x / nch, qc = blockIdx.x - bh * nch, b = bh / H, h = bh - b * H;
+  const bf16_t* qg = q + (int64_t)bh * N * DH;
+  const bf16_t* kg = k + (int64_t)bh * N * DH;
+  const bf16_t* vg = v + (int64_t)bh * N * DH;
+  const int q0 = qc * ACH + wave * 32;
+  bf16x8_t qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qg + (int64_t)(q0 + (lane & 31)) * DH + ks * 16 + hi * 8);
+  const float c = scale * LOG2E;
+  f32x16_t o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[0][r] = o[1][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  for (int kc = 0; kc < nch; ++kc) {
+    __syncthreads();  // the previous chunk is consumed
+    tile_dma(kg + (int64_t)kc * ACH * DH, DH, kt, ACH, wave, nwaves, lane);
+    tile_dma(vg + (int64_t)kc * ACH * DH, DH, vt, ACH, wave, nwaves, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kb = 0; kb < ACH; kb += 64) {
+      f32x16_t s[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s[t] = MFMA(frag_rows(kt, kb + t * 32 + (lane & 31), ks, hi), qf[ks], s[t]);
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[t][r] *= c;
+          mx = fmaxf(mx, s[t][r]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f(m_run - m_new);
+      m_run = m_new;
+      float ps = 0.f;
+      float p[2][16];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          p[t][r] = exp2f(s[t][r] - m_new);
+          ps += p[t][r];
+        }
+      l_run = l_run * alpha + ps;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[0][r] *= alpha;
+        o[1][r] *= alpha;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int kg2 = 0; kg2 < 2; ++kg2) {
+          const bf16x8_t pf = pack_frag(&p[t][kg2 * 8]);
+          const int rbase = kb + t * 32 + kg2 * 16;
+          o[0] = MFMA(frag_cols(vt, rbase, 0, lane), pf, o[0]);
+          o[1] = MFMA(frag_cols(vt, rbase, 32, lane), pf, o[1]);
+        }
+    }
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qrow = q0 + (lane & 31);
+  bf16_t* op = out + ((int64_t)b * N + qrow) * (H * DH) + h * DH;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      u32x2_t w;
+      w[0] = pack2bf(o[dt][g4 * 4 + 0] * inv, o[dt][g4 * 4 + 1] * inv);
+      w[1] = pack2bf(o[dt][g4 * 4 + 2] * inv, o[dt][g4 * 4 + 3] * inv);
+      *(u32x2_t*)(op + dt * 32 + g4 * 8 + hi * 4) = w;
+    }
+  if (hi == 0) lse[(int64_t)bh * N + qrow] = (m_run + log2f(l_tot)) * LN2;
+}
+
 extern "C" int dl_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int64_t B, int64_t H,
                            int64_t N, int64_t dh, float scale, dl_stream_t stream) {
   DL_CHECK_ARG(q && k && v && out && lse && B > 0 && H > 0, "dl_attn_fwd: null operand");
   DL_CHECK_ARG(dh == DH, "dl_attn_fwd: head_dim %lld unsupported (64 only)", (long long)dh);
-  DL_CHECK_ARG(N % 64 == 0 && N >= 64 && N <= 512, "dl_attn_fwd: N=%lld must be a multiple of 64 in [64, 512]", (long long)N);
+  DL_CHECK_ARG(N % 64 == 0 && N >= 64 && (N <= 256 || (N % ACH == 0 && N <= 2048)),
+               "dl_attn_fwd: N=%lld must be a multiple of 64 up to 256, or a multiple of 256 up to 2048", (long long)N);
+  if (N > 256) {  // (the resident-tile kernel runs N/32 waves per workgroup: 8 at most)
+    const int ldt = 2 * ACH * ROWB;
+    (void)hipFuncSetAttribute((const void*)attn_fwd_tiled_k, hipFuncAttributeMaxDynamicSharedMemorySize, ldt);
+    hipLaunchKernelGGL(attn_fwd_tiled_k, (int)(B * H * (N / ACH)), 512, ldt, (hipStream_t)stream, (const bf16_t*)q,
+                       (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, lse, (int)H, (int)N, scale);
+    DL_LAUNCH_CHECK();
+    return DL_OK;
+  }
   const int lds = (int)(2 * N * ROWB);
   (void)hipFuncSetAttribute((const void*)attn_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(attn_fwd_k, (int)(B * H), (int)(N / 32) * 64, lds, (hipStream_t)stream, (const bf16_t*)q,
@@ -346,12 +452,203 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------ backward, long sequences (N = 512 .. 2048)
+// A workgroup owns chunk c (256 rows) of one head: phase A computes dQ of its 256 queries streaming K / V chunks, phase B
+// computes dK / dV of its 256 keys streaming Q / dO chunks; lse and delta of all N rows sit in LDS.  grid = B * H * N/256.
+__global__ __launch_bounds__(256, 2) void attn_bwd_tiled_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                           const bf16_t* __restrict__ v, const bf16_t* __restrict__ out,
+                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                           bf16_t* __restrict__ dq, bf16_t* __restrict__ dk,
+                                                           bf16_t* __restrict__ dv, int H, int N, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ta = smem;
+  char* tb = ta + ACH * ROWB;
+  float* lse2 = (float*)(tb + ACH * ROWB);
+  float* delta = lse2 + N;
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+  const int nch = N / ACH;
+  const int bh = blockIdx.x / nch, cc = blockIdx.x - bh * nch, b = bh / H, h = bh - b * H;
+  const int64_t hoff = (int64_t)bh * N * DH;
+  const int64_t tok_pitch = (int64_t)H * DH;
+  const bf16_t* og = out + (int64_t)b * N * tok_pitch + h * DH;
+  const bf16_t* dog = dout + (int64_t)b * N * tok_pitch + h * DH;
+  for (int row = threadIdx.x >> 1; row < N; row += blockDim.x >> 1) {
+    const int half = threadIdx.x & 1;
+    const bf16_t* po = og + (int64_t)row * tok_pitch + half * 32;
+    const bf16_t* pd = dog + (int64_t)row * tok_pitch + half * 32;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a[8], d[8];
+      unpack8(*(const u32x4_t*)(po + i * 8), a);
+      unpack8(*(const u32x4_t*)(pd + i * 8), d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += a[e] * d[e];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    if (half == 0) {
+      delta[row] = acc;
+      lse2[row] = lse[(int64_t)bh * N + row] * LOG2E;
+    }
+  }
+  const float c = scale * LOG2E;
+
+  // ---- phase A: dQ of queries cc*256 + own..
+  {
+    bf16x8_t qf[2][4], dof[2][4];
+    float my_lse[2], my_delta[2];
+    f32x16_t dqa[2][2];
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+      const int own = cc * ACH + (wave * 2 + ob) * 32;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        qf[ob][ks] = frag_rows_g(q + hoff, DH, own + (lane & 31), ks, hi);
+        dof[ob][ks] = frag_rows_g(dog, tok_pitch, own + (lane & 31), ks, hi);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dqa[ob][0][r] = dqa[ob][1][r] = 0.f;
+    }
+    for (int kc = 0; kc < nch; ++kc) {
+      __syncthreads();
+      tile_dma(k + hoff + (int64_t)kc * ACH * DH, DH, ta, ACH, wave, nwaves, lane);
+      tile_dma(v + hoff + (int64_t)kc * ACH * DH, DH, tb, ACH, wave, nwaves, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kc == 0) {  // lse2 / delta are complete after the first barrier pair
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+          const int own = cc * ACH + (wave * 2 + ob) * 32;
+          my_lse[ob] = lse2[own + (lane & 31)];
+          my_delta[ob] = delta[own + (lane & 31)];
+        }
+      }
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob)
+        for (int kb = 0; kb < ACH; kb += 32) {
+          f32x16_t st, dpt;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st[r] = dpt[r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            st = MFMA(frag_rows(ta, kb + (lane & 31), ks, hi), qf[ob][ks], st);
+            dpt = MFMA(frag_rows(tb, kb + (lane & 31), ks, hi), dof[ob][ks], dpt);
+          }
+          float ds[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float p = exp2f(st[r] * c - my_lse[ob]);
+            ds[r] = p * (dpt[r] - my_delta[ob]);
+          }
+#pragma unroll
+          for (int kg2 = 0; kg2 < 2; ++kg2) {
+            const bf16x8_t df = pack_frag(&ds[kg2 * 8]);
+            dqa[ob][0] = MFMA(frag_cols(ta, kb + kg2 * 16, 0, lane), df, dqa[ob][0]);
+            dqa[ob][1] = MFMA(frag_cols(ta, kb + kg2 * 16, 32, lane), df, dqa[ob][1]);
+          }
+        }
+    }
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+      const int own = cc * ACH + (wave * 2 + ob) * 32;
+      bf16_t* dqp = dq + hoff + (int64_t)(own + (lane & 31)) * DH;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          u32x2_t w;
+          w[0] = pack2bf(dqa[ob][dt][g4 * 4 + 0] * scale, dqa[ob][dt][g4 * 4 + 1] * scale);
+          w[1] = pack2bf(dqa[ob][dt][g4 * 4 + 2] * scale, dqa[ob][dt][g4 * 4 + 3] * scale);
+          *(u32x2_t*)(dqp + dt * 32 + g4 * 8 + hi * 4) = w;
+        }
+    }
+  }
+
+  // ---- phase B: dK, dV of keys cc*256 + own.., one own block at a time (accumulators: 64 regs each)
+  for (int ob = 0; ob < 2; ++ob) {
+    const int own = cc * ACH + (wave * 2 + ob) * 32;
+    bf16x8_t kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = frag_rows_g(k + hoff, DH, own + (lane & 31), ks, hi);
+      vf[ks] = frag_rows_g(v + hoff, DH, own + (lane & 31), ks, hi);
+    }
+    f32x16_t dka[2], dva[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dka[0][r] = dka[1][r] = dva[0][r] = dva[1][r] = 0.f;
+    for (int qc = 0; qc < nch; ++qc) {
+      __syncthreads();
+      tile_dma(q + hoff + (int64_t)qc * ACH * DH, DH, ta, ACH, wave, nwaves, lane);
+      tile_dma(dog + (int64_t)qc * ACH * tok_pitch, tok_pitch, tb, ACH, wave, nwaves, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      for (int qb = 0; qb < ACH; qb += 32) {
+        f32x16_t s2, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s2[r] = dp[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s2 = MFMA(frag_rows(ta, qb + (lane & 31), ks, hi), kf[ks], s2);
+          dp = MFMA(frag_rows(tb, qb + (lane & 31), ks, hi), vf[ks], dp);
+        }
+        float p[16], ds[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4_t l4 = *(const f32x4_t*)(lse2 + qc * ACH + qb + g4 * 8 + hi * 4);
+          const f32x4_t d4 = *(const f32x4_t*)(delta + qc * ACH + qb + g4 * 8 + hi * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = g4 * 4 + e;
+            p[r] = exp2f(s2[r] * c - l4[e]);
+            ds[r] = p[r] * (dp[r] - d4[e]);
+          }
+        }
+#pragma unroll
+        for (int kg2 = 0; kg2 < 2; ++kg2) {
+          const bf16x8_t pf = pack_frag(&p[kg2 * 8]);
+          const bf16x8_t df = pack_frag(&ds[kg2 * 8]);
+          const int rbase = qb + kg2 * 16;
+          dva[0] = MFMA(frag_cols(tb, rbase, 0, lane), pf, dva[0]);
+          dva[1] = MFMA(frag_cols(tb, rbase, 32, lane), pf, dva[1]);
+          dka[0] = MFMA(frag_cols(ta, rbase, 0, lane), df, dka[0]);
+          dka[1] = MFMA(frag_cols(ta, rbase, 32, lane), df, dka[1]);
+        }
+      }
+    }
+    bf16_t* dkp = dk + hoff + (int64_t)(own + (lane & 31)) * DH;
+    bf16_t* dvp = dv + hoff + (int64_t)(own + (lane & 31)) * DH;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        u32x2_t w;
+        w[0] = pack2bf(dka[dt][g4 * 4 + 0] * scale, dka[dt][g4 * 4 + 1] * scale);
+        w[1] = pack2bf(dka[dt][g4 * 4 + 2] * scale, dka[dt][g4 * 4 + 3] * scale);
+        *(u32x2_t*)(dkp + dt * 32 + g4 * 8 + hi * 4) = w;
+        w[0] = pack2bf(dva[dt][g4 * 4 + 0], dva[dt][g4 * 4 + 1]);
+        w[1] = pack2bf(dva[dt][g4 * 4 + 2], dva[dt][g4 * 4 + 3]);
+        *(u32x2_t*)(dvp + dt * 32 + g4 * 8 + hi * 4) = w;
+      }
+  }
+}
+
 extern "C" int dl_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                            const float* lse, void* dq, void* dk, void* dv, int64_t B, int64_t H, int64_t N,
                            int64_t dh, float scale, dl_stream_t stream) {
   DL_CHECK_ARG(q && k && v && out && dout && lse && dq && dk && dv && B > 0 && H > 0, "dl_attn_bwd: null operand");
   DL_CHECK_ARG(dh == DH, "dl_attn_bwd: head_dim %lld unsupported (64 only)", (long long)dh);
-  DL_CHECK_ARG(N % 64 == 0 && N >= 64 && N <= 256, "dl_attn_bwd: N=%lld must be a multiple of 64 in [64, 256]", (long long)N);
+  DL_CHECK_ARG(N % 64 == 0 && N >= 64 && (N <= 256 || (N % ACH == 0 && N <= 2048)),
+               "dl_attn_bwd: N=%lld must be a multiple of 64 up to 256, or a multiple of 256 up to 2048", (long long)N);
+  if (N > 256) {
+    const int ldt = (int)(2 * ACH * ROWB + 2 * N * sizeof(float));
+    (void)hipFuncSetAttribute((const void*)attn_bwd_tiled_k, hipFuncAttributeMaxDynamicSharedMemorySize, ldt);
+    hipLaunchKernelGGL(attn_bwd_tiled_k, (int)(B * H * (N / ACH)), 256, ldt, (hipStream_t)stream, (const bf16_t*)q,
+                       (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dq,
+                       (bf16_t*)dk, (bf16_t*)dv, (int)H, (int)N, scale);
+    DL_LAUNCH_CHECK();
+    return DL_OK;
+  }
   const int lds = (int)(2 * N * ROWB + 2 * N * sizeof(float));
   (void)hipFuncSetAttribute((const void*)attn_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(attn_bwd_k, (int)(B * H), (int)(N / 64) * 64, lds, (hipStream_t)stream, (const bf16_t*)q,

@@ -253,8 +253,9 @@ class DiTEngine:
         gh, gw = H // p, W // p
         N = gh * gw
         M = B * N
-        if N % 64 or N > 256:
-            raise NotImplementedError(f"token grid {gh}x{gw}: HIP attention needs N % 64 == 0 and N <= 256 (got {N})")
+        if N % 64 or (N > 256 and (N % 256 or N > 2048)):
+            raise NotImplementedError(f"token grid {gh}x{gw}: HIP attention needs N % 64 == 0 up to 256 tokens, or N % 256 == 0 "
+                                      f"up to 2048 (got {N})")
         Bp = _rup(B, 64)
         Fo = p * p * d.output_channels
         bf, f32 = torch.bfloat16, torch.float32

@@ -173,7 +173,8 @@ DL_API int dl_qk_norm_rope_bwd(const void* dq, const void* dk, const void* dv, c
                                int64_t dh, int64_t rot, dl_stream_t stream);
 /* F.scaled_dot_product_attention mmdit.py:92-100, no mask: out = softmax(q k^T * scale) v, written as
  * 'b h n d -> b n (h d)'.  lse f32 [B,H,N] = natural-log-sum-exp of the scaled scores (for the backward).
- * dh must be 64; N a multiple of 64, N <= 512 (K and V of one head stay resident in LDS). */
+ * dh must be 64; N a multiple of 64 up to 256 (K and V of one head stay resident in LDS), or a multiple of 256 up to 2048
+ * (one workgroup per 256-row chunk, the other operand streamed through LDS in 256-row chunks). */
 DL_API int dl_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int64_t B, int64_t H,
                        int64_t N, int64_t dh, float scale, dl_stream_t stream);
 DL_API int dl_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,

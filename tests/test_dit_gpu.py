@@ -283,3 +283,24 @@ def test_hipgraph_inference_matches_eager_and_tracks_parameter_updates(monkeypat
         f = m(x=x2, timesteps=t, y=y)["x"]
         monkeypatch.setenv("DL_HIPGRAPH", "0")
         assert torch.equal(f, m(x=x2, timesteps=t, y=y)["x"])
+
+
+def test_dit_on_1024_tokens_against_oracle():
+    """a 64x64 latent grid at patch 2 = 1024 tokens per image (e.g. 512-pixel images through an f8 VAE): the chunked attention
+    kernels inside the full forward / backward, loss and gradients against the CPU oracle"""
+    from diffulab_amd import Diffuser
+
+    m, P = build(SMALL, seed=5)
+    cfg = odit.DiTConfig(**SMALL)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    B, H = 2, 64
+    x0, noise = synth.normal("lg.x0", (B, 4, H, H)), synth.normal("lg.noise", (B, 4, H, H))
+    y, t = synth.integers("lg.y", (B,), 10), synth.uniform("lg.t", (B,), lo=0.05, hi=0.95)
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=4)
+    loss = d.compute_loss({"x": x0.to(DEV), "y": y.to(DEV), "p": 0.0}, timesteps=t, noise=noise.to(DEV))["loss"]
+    loss.backward()
+    ref = od.flow_loss(odit.dit_forward(Pr, od.flow_add_noise(x0, t, noise), t, y, cfg), x0, noise)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) / ref.item() < 2e-3
+    for name, p in m.named_parameters():
+        assert rel(p.grad, Pr[name].grad) < 2.5e-2, name

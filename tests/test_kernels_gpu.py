@@ -232,7 +232,7 @@ def test_qk_norm_rope_fwd_bwd(ops, H, gh, gw):
 
 
 # ------------------------------------------------------------------ attention
-@pytest.mark.parametrize("B,H,N", [(2, 6, 256), (1, 2, 64), (3, 3, 128)])
+@pytest.mark.parametrize("B,H,N", [(2, 6, 256), (1, 2, 64), (3, 3, 128), (1, 2, 512), (2, 1, 1024), (1, 1, 2048)])  # > 256 tokens: chunked (tiled) kernels
 def test_attention_fwd_bwd(ops, B, H, N):
     dh = 64
     q, k, v = (bf(synth.normal(f"at.{n}{N}", (B, H, N, dh))).requires_grad_(True) for n in "qkv")
