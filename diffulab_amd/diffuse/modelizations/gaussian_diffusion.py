@@ -120,6 +120,10 @@ class GaussianDiffusion(Diffusion):
         sab, ab = self._dev[x.device]
         return ops.ddpm_add_noise(x, noise, timesteps.to(device=x.device, dtype=torch.int32).contiguous(), sab, ab), noise
 
+    # The reference leaves autograd on in this loop (gaussian_diffusion.py:344-447 carries no inference_mode / no_grad, unlike
+    # Flow.denoise): outside the trainer's @no_grad image logging it would record a graph through all 1000 steps.  Here the
+    # loop runs under no_grad: same values, and the denoiser takes its inference path (hipGraph replay, no activation keeping).
+    @torch.no_grad()
     def denoise(self, model, model_inputs, data_shape: tuple[int, ...] | None = None, use_tqdm: bool = True,
                 clamp_x: bool = False, guidance_scale: float = 0, sampler_args: dict[str, Any] = {},
                 return_intermediates: bool = False) -> SamplingOutput:
