@@ -78,6 +78,12 @@ __device__ __forceinline__ bf16x8_t pack_frag(const float* p) {
 }
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
+extern "C" int dl_attn_fwd_ex(const void* q, const void* k, const void* v, void* out, float* lse, int64_t B, int64_t H,
+                              int64_t Nq, int64_t Nk, int64_t dh, float scale, const float* key_bias, dl_stream_t stream);
+extern "C" int dl_attn_bwd_ex(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                              const float* lse, void* dq, void* dk, void* dv, int64_t B, int64_t H, int64_t Nq, int64_t Nk,
+                              int64_t dh, float scale, const float* key_bias, dl_stream_t stream);
+
 // ====================================================================================== forward
 __global__ __launch_bounds__(512) void attn_fwd_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                   const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
@@ -176,17 +182,19 @@ __global__ __launch_bounds__(512) void attn_fwd_k(const bf16_t* __restrict__ q, 
 #define ACH 256
 __global__ __launch_bounds__(512) void attn_fwd_tiled_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                         const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
-                                                        float* __restrict__ lse, int H, int N, float scale) {
+                                                        float* __restrict__ lse, int H, int Nq, int Nk, float scale,
+                                                        const float* __restrict__ key_bias) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kt = smem;
   char* vt = smem + ACH * ROWB;
+  float* bs = (float*)(vt + ACH * ROWB);  // additive key bias of the resident chunk, pre-multiplied by log2(e)
   const int lane = threadIdx.x & 63, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
-  const int nch = N / ACH;
-  const int bh = blockIdx.x / nch, qc = blockIdx.x - bh * nch, b = bh / H, h = bh - b * H;
-  const bf16_t* qg = q + (int64_t)bh * N * DH;
-  const bf16_t* kg = k + (int64_t)bh * N * DH;
-  const bf16_t* vg = v + (int64_t)bh * N * DH;
+  const int nchq = Nq / ACH, nch = Nk / ACH;
+  const int bh = blockIdx.x / nchq, qc = blockIdx.x - bh * nchq, b = bh / H, h = bh - b * H;
+  const bf16_t* qg = q + (int64_t)bh * Nq * DH;
+  const bf16_t* kg = k + (int64_t)bh * Nk * DH;
+  const bf16_t* vg = v + (int64_t)bh * Nk * DH;
   const int q0 = qc * ACH + wave * 32;
   bf16x8_t qf[4];
 #pragma unroll
@@ -200,6 +208,8 @@ __global__ __launch_bounds__(512) void attn_fwd_tiled_k(const bf16_t* __restrict
     __syncthreads();  // the previous chunk is consumed
     tile_dma(kg + (int64_t)kc * ACH * DH, DH, kt, ACH, wave, nwaves, lane);
     tile_dma(vg + (int64_t)kc * ACH * DH, DH, vt, ACH, wave, nwaves, lane);
+    for (int i = threadIdx.x; i < ACH; i += blockDim.x)
+      bs[i] = key_bias ? key_bias[(int64_t)b * Nk + kc * ACH + i] * LOG2E : 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kb = 0; kb < ACH; kb += 64) {
@@ -215,12 +225,18 @@ __global__ __launch_bounds__(512) void attn_fwd_tiled_k(const bf16_t* __restrict
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          s[t][r] *= c;
-          mx = fmaxf(mx, s[t][r]);
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4_t b4 = *(const f32x4_t*)(bs + kb + t * 32 + g4 * 8 + hi * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = g4 * 4 + e;
+            s[t][r] = s[t][r] * c + b4[e];
+            mx = fmaxf(mx, s[t][r]);
+          }
         }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
+      float m_new = fmaxf(m_run, mx);
+      if (m_new == -INFINITY) m_new = 0.f;  // every key so far is masked: keep exp2(-inf - m) = 0 well defined
       const float alpha = exp2f(m_run - m_new);
       m_run = m_new;
       float ps = 0.f;
@@ -252,7 +268,7 @@ __global__ __launch_bounds__(512) void attn_fwd_tiled_k(const bf16_t* __restrict
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
   const int qrow = q0 + (lane & 31);
-  bf16_t* op = out + ((int64_t)b * N + qrow) * (H * DH) + h * DH;
+  bf16_t* op = out + ((int64_t)b * Nq + qrow) * (H * DH) + h * DH;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -262,23 +278,32 @@ __global__ __launch_bounds__(512) void attn_fwd_tiled_k(const bf16_t* __restrict
       w[1] = pack2bf(o[dt][g4 * 4 + 2] * inv, o[dt][g4 * 4 + 3] * inv);
       *(u32x2_t*)(op + dt * 32 + g4 * 8 + hi * 4) = w;
     }
-  if (hi == 0) lse[(int64_t)bh * N + qrow] = (m_run + log2f(l_tot)) * LN2;
+  if (hi == 0) lse[(int64_t)bh * Nq + qrow] = (m_run + log2f(l_tot)) * LN2;
 }
 
+/* general form: Nq queries against Nk keys (both multiples of 256, <= 2048) with an optional additive key bias f32 [B, Nk]
+ * (0 = keep, -inf = masked / padded key): cross-attention and key-padding masks */
+extern "C" int dl_attn_fwd_ex(const void* q, const void* k, const void* v, void* out, float* lse, int64_t B, int64_t H,
+                              int64_t Nq, int64_t Nk, int64_t dh, float scale, const float* key_bias, dl_stream_t stream) {
+  DL_CHECK_ARG(q && k && v && out && lse && B > 0 && H > 0, "dl_attn_fwd_ex: null operand");
+  DL_CHECK_ARG(dh == DH, "dl_attn_fwd_ex: head_dim %lld unsupported (64 only)", (long long)dh);
+  DL_CHECK_ARG(Nq % ACH == 0 && Nk % ACH == 0 && Nq > 0 && Nk > 0 && Nq <= 2048 && Nk <= 2048,
+               "dl_attn_fwd_ex: Nq=%lld Nk=%lld must be multiples of 256 up to 2048 (pad and mask)", (long long)Nq, (long long)Nk);
+  const int ldt = 2 * ACH * ROWB + ACH * (int)sizeof(float);
+  (void)hipFuncSetAttribute((const void*)attn_fwd_tiled_k, hipFuncAttributeMaxDynamicSharedMemorySize, ldt);
+  hipLaunchKernelGGL(attn_fwd_tiled_k, (int)(B * H * (Nq / ACH)), 512, ldt, (hipStream_t)stream, (const bf16_t*)q,
+                     (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, lse, (int)H, (int)Nq, (int)Nk, scale, key_bias);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
 extern "C" int dl_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int64_t B, int64_t H,
                            int64_t N, int64_t dh, float scale, dl_stream_t stream) {
   DL_CHECK_ARG(q && k && v && out && lse && B > 0 && H > 0, "dl_attn_fwd: null operand");
   DL_CHECK_ARG(dh == DH, "dl_attn_fwd: head_dim %lld unsupported (64 only)", (long long)dh);
   DL_CHECK_ARG(N % 64 == 0 && N >= 64 && (N <= 256 || (N % ACH == 0 && N <= 2048)),
                "dl_attn_fwd: N=%lld must be a multiple of 64 up to 256, or a multiple of 256 up to 2048", (long long)N);
-  if (N > 256) {  // (the resident-tile kernel runs N/32 waves per workgroup: 8 at most)
-    const int ldt = 2 * ACH * ROWB;
-    (void)hipFuncSetAttribute((const void*)attn_fwd_tiled_k, hipFuncAttributeMaxDynamicSharedMemorySize, ldt);
-    hipLaunchKernelGGL(attn_fwd_tiled_k, (int)(B * H * (N / ACH)), 512, ldt, (hipStream_t)stream, (const bf16_t*)q,
-                       (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, lse, (int)H, (int)N, scale);
-    DL_LAUNCH_CHECK();
-    return DL_OK;
-  }
+  if (N > 256)  // (the resident-tile kernel runs N/32 waves per workgroup: 8 at most)
+    return dl_attn_fwd_ex(q, k, v, out, lse, B, H, N, N, dh, scale, nullptr, stream);
   const int lds = (int)(2 * N * ROWB);
   (void)hipFuncSetAttribute((const void*)attn_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(attn_fwd_k, (int)(B * H), (int)(N / 32) * 64, lds, (hipStream_t)stream, (const bf16_t*)q,
@@ -459,21 +484,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_tiled_k(const bf16_t* __restr
                                                            const bf16_t* __restrict__ v, const bf16_t* __restrict__ out,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                            bf16_t* __restrict__ dq, bf16_t* __restrict__ dk,
-                                                           bf16_t* __restrict__ dv, int H, int N, float scale) {
+                                                           bf16_t* __restrict__ dv, int H, int Nq, int Nk, float scale,
+                                                           const float* __restrict__ key_bias) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ta = smem;
   char* tb = ta + ACH * ROWB;
   float* lse2 = (float*)(tb + ACH * ROWB);
-  float* delta = lse2 + N;
+  float* delta = lse2 + Nq;
+  float* bs = delta + Nq;  // key bias of the resident K chunk (phase A), times log2(e)
   const int lane = threadIdx.x & 63, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
-  const int nch = N / ACH;
-  const int bh = blockIdx.x / nch, cc = blockIdx.x - bh * nch, b = bh / H, h = bh - b * H;
-  const int64_t hoff = (int64_t)bh * N * DH;
+  const int nchq = Nq / ACH, nchk = Nk / ACH, nmax = nchq > nchk ? nchq : nchk;
+  const int bh = blockIdx.x / nmax, cc = blockIdx.x - bh * nmax, b = bh / H, h = bh - b * H;
+  const int64_t hoffq = (int64_t)bh * Nq * DH, hoffk = (int64_t)bh * Nk * DH;
   const int64_t tok_pitch = (int64_t)H * DH;
-  const bf16_t* og = out + (int64_t)b * N * tok_pitch + h * DH;
-  const bf16_t* dog = dout + (int64_t)b * N * tok_pitch + h * DH;
-  for (int row = threadIdx.x >> 1; row < N; row += blockDim.x >> 1) {
+  const bf16_t* og = out + (int64_t)b * Nq * tok_pitch + h * DH;
+  const bf16_t* dog = dout + (int64_t)b * Nq * tok_pitch + h * DH;
+  for (int row = threadIdx.x >> 1; row < Nq; row += blockDim.x >> 1) {
     const int half = threadIdx.x & 1;
     const bf16_t* po = og + (int64_t)row * tok_pitch + half * 32;
     const bf16_t* pd = dog + (int64_t)row * tok_pitch + half * 32;
@@ -489,13 +516,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_tiled_k(const bf16_t* __restr
     acc += __shfl_xor(acc, 1, 64);
     if (half == 0) {
       delta[row] = acc;
-      lse2[row] = lse[(int64_t)bh * N + row] * LOG2E;
+      lse2[row] = lse[(int64_t)bh * Nq + row] * LOG2E;
     }
   }
   const float c = scale * LOG2E;
 
   // ---- phase A: dQ of queries cc*256 + own..
-  {
+  if (cc < nchq) {
     bf16x8_t qf[2][4], dof[2][4];
     float my_lse[2], my_delta[2];
     f32x16_t dqa[2][2];
@@ -504,16 +531,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_tiled_k(const bf16_t* __restr
       const int own = cc * ACH + (wave * 2 + ob) * 32;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        qf[ob][ks] = frag_rows_g(q + hoff, DH, own + (lane & 31), ks, hi);
+        qf[ob][ks] = frag_rows_g(q + hoffq, DH, own + (lane & 31), ks, hi);
         dof[ob][ks] = frag_rows_g(dog, tok_pitch, own + (lane & 31), ks, hi);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) dqa[ob][0][r] = dqa[ob][1][r] = 0.f;
     }
-    for (int kc = 0; kc < nch; ++kc) {
+    for (int kc = 0; kc < nchk; ++kc) {
       __syncthreads();
-      tile_dma(k + hoff + (int64_t)kc * ACH * DH, DH, ta, ACH, wave, nwaves, lane);
-      tile_dma(v + hoff + (int64_t)kc * ACH * DH, DH, tb, ACH, wave, nwaves, lane);
+      tile_dma(k + hoffk + (int64_t)kc * ACH * DH, DH, ta, ACH, wave, nwaves, lane);
+      tile_dma(v + hoffk + (int64_t)kc * ACH * DH, DH, tb, ACH, wave, nwaves, lane);
+      for (int i = threadIdx.x; i < ACH; i += blockDim.x)
+        bs[i] = key_bias ? key_bias[(int64_t)b * Nk + kc * ACH + i] * LOG2E : 0.f;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (kc == 0) {  // lse2 / delta are complete after the first barrier pair
@@ -537,9 +566,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_tiled_k(const bf16_t* __restr
           }
           float ds[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float p = exp2f(st[r] * c - my_lse[ob]);
-            ds[r] = p * (dpt[r] - my_delta[ob]);
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4_t b4 = *(const f32x4_t*)(bs + kb + g4 * 8 + hi * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = g4 * 4 + e;
+              const float p = exp2f(st[r] * c + b4[e] - my_lse[ob]);
+              ds[r] = p * (dpt[r] - my_delta[ob]);
+            }
           }
 #pragma unroll
           for (int kg2 = 0; kg2 < 2; ++kg2) {
@@ -552,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_tiled_k(const bf16_t* __restr
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob) {
       const int own = cc * ACH + (wave * 2 + ob) * 32;
-      bf16_t* dqp = dq + hoff + (int64_t)(own + (lane & 31)) * DH;
+      bf16_t* dqp = dq + hoffq + (int64_t)(own + (lane & 31)) * DH;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -566,20 +600,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_tiled_k(const bf16_t* __restr
   }
 
   // ---- phase B: dK, dV of keys cc*256 + own.., one own block at a time (accumulators: 64 regs each)
-  for (int ob = 0; ob < 2; ++ob) {
+  for (int ob = 0; ob < 2 && cc < nchk; ++ob) {
     const int own = cc * ACH + (wave * 2 + ob) * 32;
+    const float kbias = key_bias ? key_bias[(int64_t)b * Nk + own + (lane & 31)] * LOG2E : 0.f;
     bf16x8_t kf[4], vf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      kf[ks] = frag_rows_g(k + hoff, DH, own + (lane & 31), ks, hi);
-      vf[ks] = frag_rows_g(v + hoff, DH, own + (lane & 31), ks, hi);
+      kf[ks] = frag_rows_g(k + hoffk, DH, own + (lane & 31), ks, hi);
+      vf[ks] = frag_rows_g(v + hoffk, DH, own + (lane & 31), ks, hi);
     }
     f32x16_t dka[2], dva[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dka[0][r] = dka[1][r] = dva[0][r] = dva[1][r] = 0.f;
-    for (int qc = 0; qc < nch; ++qc) {
+    for (int qc = 0; qc < nchq; ++qc) {
       __syncthreads();
-      tile_dma(q + hoff + (int64_t)qc * ACH * DH, DH, ta, ACH, wave, nwaves, lane);
+      tile_dma(q + hoffq + (int64_t)qc * ACH * DH, DH, ta, ACH, wave, nwaves, lane);
       tile_dma(dog + (int64_t)qc * ACH * tok_pitch, tok_pitch, tb, ACH, wave, nwaves, lane);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -600,7 +635,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_tiled_k(const bf16_t* __restr
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = g4 * 4 + e;
-            p[r] = exp2f(s2[r] * c - l4[e]);
+            p[r] = exp2f(s2[r] * c + kbias - l4[e]);
             ds[r] = p[r] * (dp[r] - d4[e]);
           }
         }
@@ -616,8 +651,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_tiled_k(const bf16_t* __restr
         }
       }
     }
-    bf16_t* dkp = dk + hoff + (int64_t)(own + (lane & 31)) * DH;
-    bf16_t* dvp = dv + hoff + (int64_t)(own + (lane & 31)) * DH;
+    bf16_t* dkp = dk + hoffk + (int64_t)(own + (lane & 31)) * DH;
+    bf16_t* dvp = dv + hoffk + (int64_t)(own + (lane & 31)) * DH;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -633,6 +668,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_tiled_k(const bf16_t* __restr
   }
 }
 
+extern "C" int dl_attn_bwd_ex(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                              const float* lse, void* dq, void* dk, void* dv, int64_t B, int64_t H, int64_t Nq, int64_t Nk,
+                              int64_t dh, float scale, const float* key_bias, dl_stream_t stream) {
+  DL_CHECK_ARG(q && k && v && out && dout && lse && dq && dk && dv && B > 0 && H > 0, "dl_attn_bwd_ex: null operand");
+  DL_CHECK_ARG(dh == DH, "dl_attn_bwd_ex: head_dim %lld unsupported (64 only)", (long long)dh);
+  DL_CHECK_ARG(Nq % ACH == 0 && Nk % ACH == 0 && Nq > 0 && Nk > 0 && Nq <= 2048 && Nk <= 2048,
+               "dl_attn_bwd_ex: Nq=%lld Nk=%lld must be multiples of 256 up to 2048", (long long)Nq, (long long)Nk);
+  const int ldt = (int)(2 * ACH * ROWB + (2 * Nq + ACH) * sizeof(float));
+  const int64_t nmax = (Nq > Nk ? Nq : Nk) / ACH;
+  (void)hipFuncSetAttribute((const void*)attn_bwd_tiled_k, hipFuncAttributeMaxDynamicSharedMemorySize, ldt);
+  hipLaunchKernelGGL(attn_bwd_tiled_k, (int)(B * H * nmax), 256, ldt, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k,
+                     (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv,
+                     (int)H, (int)Nq, (int)Nk, scale, key_bias);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
 extern "C" int dl_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                            const float* lse, void* dq, void* dk, void* dv, int64_t B, int64_t H, int64_t N,
                            int64_t dh, float scale, dl_stream_t stream) {
@@ -640,15 +691,7 @@ extern "C" int dl_attn_bwd(const void* q, const void* k, const void* v, const vo
   DL_CHECK_ARG(dh == DH, "dl_attn_bwd: head_dim %lld unsupported (64 only)", (long long)dh);
   DL_CHECK_ARG(N % 64 == 0 && N >= 64 && (N <= 256 || (N % ACH == 0 && N <= 2048)),
                "dl_attn_bwd: N=%lld must be a multiple of 64 up to 256, or a multiple of 256 up to 2048", (long long)N);
-  if (N > 256) {
-    const int ldt = (int)(2 * ACH * ROWB + 2 * N * sizeof(float));
-    (void)hipFuncSetAttribute((const void*)attn_bwd_tiled_k, hipFuncAttributeMaxDynamicSharedMemorySize, ldt);
-    hipLaunchKernelGGL(attn_bwd_tiled_k, (int)(B * H * (N / ACH)), 256, ldt, (hipStream_t)stream, (const bf16_t*)q,
-                       (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dq,
-                       (bf16_t*)dk, (bf16_t*)dv, (int)H, (int)N, scale);
-    DL_LAUNCH_CHECK();
-    return DL_OK;
-  }
+  if (N > 256) return dl_attn_bwd_ex(q, k, v, out, dout, lse, dq, dk, dv, B, H, N, N, dh, scale, nullptr, stream);
   const int lds = (int)(2 * N * ROWB + 2 * N * sizeof(float));
   (void)hipFuncSetAttribute((const void*)attn_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(attn_bwd_k, (int)(B * H), (int)(N / 64) * 64, lds, (hipStream_t)stream, (const bf16_t*)q,

@@ -209,6 +209,16 @@ def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, N, dh, scale):
           float(scale), _s())
 
 
+def attn_fwd_ex(q, k, v, out, lse, B, H, Nq, Nk, dh, scale, key_bias=None):
+    """Nq queries against Nk keys (multiples of 256), optional additive key bias f32 [B, Nk] (0 / -inf)"""
+    _call("dl_attn_fwd_ex", _p(q), _p(k), _p(v), _p(out), _p(lse), B, H, Nq, Nk, dh, float(scale), _p(key_bias), _s())
+
+
+def attn_bwd_ex(q, k, v, out, dout, lse, dq, dk, dv, B, H, Nq, Nk, dh, scale, key_bias=None):
+    _call("dl_attn_bwd_ex", _p(q), _p(k), _p(v), _p(out), _p(dout), _p(lse), _p(dq), _p(dk), _p(dv), B, H, Nq, Nk, dh,
+          float(scale), _p(key_bias), _s())
+
+
 def swiglu_fwd(u, h):
     _call("dl_swiglu_fwd", _p(u), _p(h), u.shape[0], h.shape[1], _s())
 

@@ -180,6 +180,14 @@ DL_API int dl_attn_fwd(const void* q, const void* k, const void* v, void* out, f
 DL_API int dl_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                        const float* lse, void* dq, void* dk, void* dv, int64_t B, int64_t H, int64_t N,
                        int64_t dh, float scale, dl_stream_t stream);
+/* general form (joint text-image attention mmdit.py:172-190 with its key-padding mask, cross-attention of a resampler):
+ * q [B,H,Nq,64] against k, v [B,H,Nk,64]; Nq, Nk multiples of 256 up to 2048 (pad); key_bias f32 [B, Nk] is ADDED to the
+ * scaled scores (0 = attend, -inf = masked / padded key) or NULL; out [B, Nq, H*64], lse [B,H,Nq]. */
+DL_API int dl_attn_fwd_ex(const void* q, const void* k, const void* v, void* out, float* lse, int64_t B, int64_t H,
+                          int64_t Nq, int64_t Nk, int64_t dh, float scale, const float* key_bias, dl_stream_t stream);
+DL_API int dl_attn_bwd_ex(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                          const float* lse, void* dq, void* dk, void* dv, int64_t B, int64_t H, int64_t Nq, int64_t Nk,
+                          int64_t dh, float scale, const float* key_bias, dl_stream_t stream);
 /* PackedSwiGLU nn.py:484-486: h = silu(u[:, :F]) * u[:, F:] ; u bf16 [M, 2F] */
 DL_API int dl_swiglu_fwd(const void* u, void* h, int64_t M, int64_t F, dl_stream_t stream);
 DL_API int dl_swiglu_bwd(const void* dh, const void* u, void* du, int64_t M, int64_t F, dl_stream_t stream);

@@ -256,6 +256,35 @@ def test_attention_fwd_bwd(ops, B, H, N):
     assert rel(dk.float(), k.grad) < 8e-3
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,valid", [(2, 2, 256, 512, (320, 512)), (2, 3, 512, 512, (300, 77)), (1, 1, 256, 256, (200,))])
+def test_attention_cross_lengths_and_key_mask(ops, B, H, Nq, Nk, valid):
+    """general form: Nq queries against Nk keys with a key-padding mask given as an additive bias (0 / -inf): cross-attention
+    of a resampler (320 valid keys padded to 512) and joint text-image attention with padded text tokens"""
+    dh, scale = 64, 64**-0.5
+    q = bf(synth.normal("cx.q", (B, H, Nq, dh))).requires_grad_(True)
+    k = bf(synth.normal("cx.k", (B, H, Nk, dh))).requires_grad_(True)
+    v = bf(synth.normal("cx.v", (B, H, Nk, dh))).requires_grad_(True)
+    keep = torch.zeros(B, Nk, dtype=torch.bool)
+    for i in range(B):
+        keep[i, : valid[i % len(valid)]] = True
+    bias = torch.zeros(B, Nk).masked_fill(~keep, float("-inf"))
+    att = torch.softmax(q @ k.transpose(-1, -2) * scale + bias[:, None, None, :], dim=-1) @ v
+    o_tok = att.transpose(1, 2).reshape(B, Nq, H * dh)
+    do = bf(synth.normal("cx.do", (B, Nq, H * dh)))
+    o_tok.backward(do)
+    out = torch.empty(B, Nq, H * dh, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(B, H, Nq, device=DEV)
+    qd, kd, vd, bd = dev_bf(q.detach()), dev_bf(k.detach()), dev_bf(v.detach()), bias.to(DEV)
+    ops.attn_fwd_ex(qd, kd, vd, out, lse, B, H, Nq, Nk, dh, scale, bd)
+    assert rel(out.float(), o_tok) < 5e-3
+    dq = torch.empty(B, H, Nq, dh, device=DEV, dtype=torch.bfloat16)
+    dk, dv = (torch.empty(B, H, Nk, dh, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    ops.attn_bwd_ex(qd, kd, vd, out, dev_bf(do), lse, dq, dk, dv, B, H, Nq, Nk, dh, scale, bd)
+    assert rel(dq.float(), q.grad) < 8e-3 and rel(dk.float(), k.grad) < 8e-3 and rel(dv.float(), v.grad) < 8e-3
+    masked = (~keep)[:, None, :, None].expand(B, H, Nk, dh)
+    assert float(dk.float().cpu()[masked].abs().max()) == 0.0 and float(dv.float().cpu()[masked].abs().max()) == 0.0
+
+
 def test_attention_peaked_rows(ops):
     """online-softmax rescale branch: one key dominates per query at a late key tile (guide rule 26)."""
     B, H, N, dh = 1, 1, 256, 64
