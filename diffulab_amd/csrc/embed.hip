@@ -152,6 +152,85 @@ extern "C" int dl_silu_bwd(const float* dy, const void* pre, void* dx, int64_t n
   return DL_OK;
 }
 
+__global__ void gelu_bwd_k(const float* __restrict__ dy, const bf16_t* __restrict__ pre, bf16_t* __restrict__ dx,
+                           int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dx[i] = f2bf(dy[i] * dgelu_f(bf2f(pre[i])));
+}
+extern "C" int dl_gelu_bwd(const float* dy, const void* pre, void* dx, int64_t n, dl_stream_t stream) {
+  DL_CHECK_ARG(dy && pre && dx && n > 0, "dl_gelu_bwd: bad args");
+  int64_t g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(gelu_bwd_k, (int)g, 256, 0, (hipStream_t)stream, dy, (const bf16_t*)pre, (bf16_t*)dx, n);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ---------------------------------------------------------------- head split / merge with optional rotary embedding
+// one thread per (token row, head, 8-channel chunk): 16-byte moves; the rotary pairs (2i, 2i+1) of a chunk stay in the thread
+__global__ void heads_split_rope_k(const bf16_t* __restrict__ src, int64_t ld, bf16_t* __restrict__ dst, int B, int H, int n_src,
+                                   int n_dst, int n_off, const float* __restrict__ cs, const float* __restrict__ sn, int rot,
+                                   int backward, int accumulate) {
+  const int64_t total = (int64_t)B * n_src * H * 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i & 7);
+    const int h = (int)((i >> 3) % H);
+    const int64_t row = i / ((int64_t)8 * H);  // b * n_src + n
+    const int n = (int)(row % n_src), b = (int)(row / n_src);
+    bf16_t* ps = (bf16_t*)src + row * ld + h * 64 + c8 * 8;
+    bf16_t* pd = dst + (((int64_t)b * H + h) * n_dst + n_off + n) * 64 + c8 * 8;
+    float v[8];
+    unpack8(*(const u32x4_t*)(backward ? pd : ps), v);
+    const int d0 = c8 * 8;
+    if (cs && d0 < rot) {
+      const f32x4_t cc = *(const f32x4_t*)(cs + (int64_t)n * (rot >> 1) + (d0 >> 1));
+      const f32x4_t ss = *(const f32x4_t*)(sn + (int64_t)n * (rot >> 1) + (d0 >> 1));
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float a = v[2 * p], bq = v[2 * p + 1];
+        const float s = backward ? -ss[p] : ss[p];  // the transpose of a rotation is the rotation by -theta
+        v[2 * p] = a * cc[p] - bq * s;
+        v[2 * p + 1] = a * s + bq * cc[p];
+      }
+    }
+    if (backward) {
+      if (accumulate) {
+        float o[8];
+        unpack8(*(const u32x4_t*)ps, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += o[e];
+      }
+      *(u32x4_t*)ps = pack8(v);
+    } else {
+      *(u32x4_t*)pd = pack8(v);
+    }
+  }
+}
+static int heads_launch(const void* src, int64_t ld, void* dst, int64_t B, int64_t H, int64_t n_src, int64_t n_dst, int64_t n_off,
+                        const float* cs, const float* sn, int64_t rot, int backward, int accumulate, dl_stream_t stream) {
+  int64_t g = (B * n_src * H * 8 + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(heads_split_rope_k, (int)g, 256, 0, (hipStream_t)stream, (const bf16_t*)src, ld, (bf16_t*)dst, (int)B, (int)H,
+                     (int)n_src, (int)n_dst, (int)n_off, cs, sn, (int)rot, backward, accumulate);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_heads_split_rope(const void* src, int64_t ld, void* dst, int64_t B, int64_t H, int64_t n_src, int64_t n_dst,
+                                   int64_t n_off, const float* cs, const float* sn, int64_t rot, dl_stream_t stream) {
+  DL_CHECK_ARG(src && dst && B > 0 && H > 0 && n_src > 0 && n_off >= 0 && n_off + n_src <= n_dst && ld % 8 == 0 && ld >= H * 64 &&
+                   rot % 8 == 0 && rot <= 64 && ((cs == nullptr) == (sn == nullptr)),
+               "dl_heads_split_rope: bad args");
+  return heads_launch(src, ld, dst, B, H, n_src, n_dst, n_off, cs, sn, rot, 0, 0, stream);
+}
+extern "C" int dl_heads_merge_rope_bwd(const void* dst_grad, void* src_grad, int64_t ld, int64_t B, int64_t H, int64_t n_src,
+                                       int64_t n_dst, int64_t n_off, const float* cs, const float* sn, int64_t rot,
+                                       int accumulate, dl_stream_t stream) {
+  DL_CHECK_ARG(dst_grad && src_grad && B > 0 && H > 0 && n_src > 0 && n_off >= 0 && n_off + n_src <= n_dst && ld % 8 == 0 &&
+                   ld >= H * 64 && rot % 8 == 0 && rot <= 64 && ((cs == nullptr) == (sn == nullptr)),
+               "dl_heads_merge_rope_bwd: bad args");
+  return heads_launch(src_grad, ld, (void*)dst_grad, B, H, n_src, n_dst, n_off, cs, sn, rot, 1, accumulate, stream);
+}
+
 // ---------------------------------------------------------------- column sums: out[c] += sum_r x[r, c]
 // block = 256 threads = 64 columns x 4 row-lanes; grid.x over column blocks, grid.y over row slabs
 template <typename T>

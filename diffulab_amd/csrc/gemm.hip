@@ -236,6 +236,9 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restr
     if (ep.act == DL_ACT_SILU) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+    } else if (ep.act == DL_ACT_GELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
     }
     if (ep.resid) {
       const bf16_t* rp = ep.resid + (int64_t)m * ep.ldr + n;
@@ -560,6 +563,9 @@ __device__ __forceinline__ void nt_epilogue_regs(f32x16_t (&acc)[JN][2], int m_b
           if (ep.act == DL_ACT_SILU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+          } else if (ep.act == DL_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
           }
           if (ep.resid) {
             float rr[8];

@@ -14,7 +14,7 @@ from torch import Tensor
 from ._lib import lib
 
 BF16, F32 = 0, 1
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 LOSS_FLOW, LOSS_EPS = 0, 1
 MEAN_TYPES = {"epsilon": 0, "xstart": 1, "xprev": 2}
 PATCH_CPP, PATCH_PPC = 0, 1
@@ -253,6 +253,20 @@ def cond_combine_bwd(dact, emb, idx, demb, demb16, dtable):
 
 def silu_bwd(dy, pre, dx):
     _call("dl_silu_bwd", _p(dy), _p(pre), _p(dx), dy.numel(), _s())
+
+
+def gelu_bwd(dy, pre, dx):
+    _call("dl_gelu_bwd", _p(dy), _p(pre), _p(dx), dy.numel(), _s())
+
+
+def heads_split_rope(src, dst, B, H, n_src, n_off, cos=None, sin=None, rot=0):
+    """src [B*n_src, ld] -> dst [B, H, n_dst, 64] rows n_off.. (+ RoPE on the first `rot` channels when cos/sin are given)"""
+    _call("dl_heads_split_rope", _p(src), src.stride(0), _p(dst), B, H, n_src, dst.shape[2], n_off, _p(cos), _p(sin), rot, _s())
+
+
+def heads_merge_rope_bwd(dst_grad, src_grad, B, H, n_src, n_off, cos=None, sin=None, rot=0, accumulate=False):
+    _call("dl_heads_merge_rope_bwd", _p(dst_grad), _p(src_grad), src_grad.stride(0), B, H, n_src, dst_grad.shape[2], n_off,
+          _p(cos), _p(sin), rot, int(accumulate), _s())
 
 
 def colsum(x, out, R=None, C=None):

@@ -1,9 +1,9 @@
 """Representation-alignment (REPA) loss on the HIP path -- drop-in for ``diffulab.training.losses.repa.RepaLoss`` with
-precomputed target features (``load_dino=False``; the DINOv2 / DINOv3 encoders and the Perceiver resampler need pretrained
-weights / are outside the hot path).
+precomputed target features (``load_dino=False``; the DINOv2 / DINOv3 encoders need pretrained weights and are outside the hot
+path).  ``use_resampler=True`` inserts the HIP-path Perceiver resampler between the MLP and the cosine.
 
 Same constructor kwargs, ``set_model`` / forward-hook mechanics and arithmetic as training/losses/repa.py:96-198:
-features of ``denoiser.layers[alignment_layer - 1]`` -> 3-layer SiLU MLP -> ``coeff * (1 - mean(cosine_similarity(., dst_features)))``.
+features of ``denoiser.layers[alignment_layer - 1]`` -> 3-layer SiLU MLP [-> resampler] -> ``coeff * (1 - mean(cosine_similarity(., dst_features)))``.
 The MLP runs on the bf16 MFMA GEMMs (bias + SiLU fused in the epilogue, pre-activations kept for the backward), the cosine
 rows and their gradient are one HIP kernel each; the feature gradient flows back into the DiT engine's residual stream.
 """
@@ -18,6 +18,7 @@ from torch import Tensor
 from torch.utils.hooks import RemovableHandle
 
 from ... import ops
+from ...networks.repa import PerceiverResampler
 from .common import LossFunction
 
 
@@ -25,11 +26,12 @@ def _rup(v: int, m: int) -> int:
     return (v + m - 1) // m * m
 
 
-class _RepaHead(torch.autograd.Function):
-    """proj MLP + cosine rows in one autograd node: explicit forward / backward launch sequences over the C ABI"""
+class _ProjMLP(torch.autograd.Function):
+    """proj MLP (repa.py:96-102) as one autograd node: explicit forward / backward launch sequences over the C ABI.
+    Returns the projected features bf16 [B, N, E]."""
 
     @staticmethod
-    def forward(ctx, feat: Tensor, dst: Tensor, coeff: float, w1, b1, w2, b2, w3, b3) -> Tensor:
+    def forward(ctx, feat: Tensor, w1, b1, w2, b2, w3, b3) -> Tensor:
         B, N, D = feat.shape
         M = B * N
         dev = feat.device
@@ -48,34 +50,32 @@ class _RepaHead(torch.autograd.Function):
             shadows.append((f, t))
         pre1, h1 = torch.empty(M, Hd, device=dev, dtype=bf), torch.empty(M, Hd, device=dev, dtype=bf)
         pre2, h2 = torch.empty(M, Hd, device=dev, dtype=bf), torch.empty(M, Hd, device=dev, dtype=bf)
-        proj = torch.zeros(M, _rup(E, 64), device=dev, dtype=bf)  # K-padded for the dgrad GEMM
+        proj = torch.empty(M, E, device=dev, dtype=bf)
         ops.gemm_nt(x, shadows[0][0], h1, bias=b1.detach(), act=ops.ACT_SILU, pre_out=pre1)
         ops.gemm_nt(h1, shadows[1][0], h2, bias=b2.detach(), act=ops.ACT_SILU, pre_out=pre2)
         ops.gemm_nt(h2, shadows[2][0], proj, bias=b3.detach(), M=M, N=E, K=Hd)
-        d = dst.reshape(M, E).to(device=dev, dtype=torch.float32).contiguous()
-        cosv, pn2, dn2 = (torch.empty(M, device=dev) for _ in range(3))
-        ops.cosine_rows_fwd(proj[:, :E], d, cosv, pn2, dn2)
-        s = torch.zeros(1, device=dev)
-        ops.colsum(cosv.view(M, 1), s, M, 1)
-        ctx.save_for_backward(x, pre1, h1, pre2, h2, proj, d, cosv, pn2, dn2)
-        ctx.shadows, ctx.coeff, ctx.dims, ctx.feat_shape = shadows, coeff, (M, D, Hd, E), feat.shape
-        return coeff * (1.0 - s[0] / M)
+        ctx.save_for_backward(x, pre1, h1, pre2, h2)
+        ctx.shadows, ctx.dims, ctx.feat_shape = shadows, (M, D, Hd, E), feat.shape
+        return proj.view(B, N, E)
 
     @staticmethod
-    def backward(ctx, gout: Tensor):
-        x, pre1, h1, pre2, h2, proj, d, cosv, pn2, dn2 = ctx.saved_tensors
+    def backward(ctx, dout: Tensor):
+        x, pre1, h1, pre2, h2 = ctx.saved_tensors
         (f1, t1), (f2, t2), (f3, t3) = ctx.shadows
         M, D, Hd, E = ctx.dims
         dev, bf = x.device, torch.bfloat16
-        g = gout.detach().reshape(1).float().contiguous()
-        dproj = torch.zeros_like(proj)
-        ops.cosine_rows_bwd(proj[:, :E], d, cosv, pn2, dn2, -ctx.coeff / M, g, dproj[:, :E])
+        E64 = _rup(E, 64)
+        dproj = dout.reshape(M, E)
+        if E64 != E or dproj.dtype != bf or not dproj.is_contiguous():  # K-padded for the dgrad GEMM
+            pad = torch.zeros(M, E64, device=dev, dtype=bf)
+            pad[:, :E] = dproj
+            dproj = pad
         E8 = _rup(E, 8)
         dw3, db3 = torch.zeros(E8, Hd, device=dev), torch.zeros(E, device=dev)
         ops.gemm_tn(dproj, h2, dw3, M=E8, N=Hd)
         ops.colsum(dproj, db3, M, E)
         dh2 = torch.empty(M, Hd, device=dev)
-        ops.gemm_nt(dproj, t3, dh2, M=M, N=Hd, K=_rup(E, 64))
+        ops.gemm_nt(dproj, t3, dh2, M=M, N=Hd, K=E64)
         dpre2 = torch.empty(M, Hd, device=dev, dtype=bf)
         ops.silu_bwd(dh2, pre2, dpre2)
         dw2, db2 = torch.zeros(Hd, Hd, device=dev), torch.zeros(Hd, device=dev)
@@ -90,7 +90,37 @@ class _RepaHead(torch.autograd.Function):
         ops.colsum(dpre1, db1, M, Hd)
         dfeat = torch.empty(M, D, device=dev, dtype=bf)
         ops.gemm_nt(dpre1, t1, dfeat)
-        return dfeat.view(ctx.feat_shape), None, None, dw1, db1, dw2, db2, dw3[:E], db3
+        return dfeat.view(ctx.feat_shape), dw1, db1, dw2, db2, dw3[:E], db3
+
+
+class _CosineLoss(torch.autograd.Function):
+    """coeff * (1 - mean(cosine_similarity(p, dst, dim=-1))) (repa.py:184-186): one HIP kernel per direction"""
+
+    @staticmethod
+    def forward(ctx, p: Tensor, dst: Tensor, coeff: float) -> Tensor:
+        E = p.shape[-1]
+        M = p.numel() // E
+        dev = p.device
+        p2 = p.reshape(M, E)
+        if p2.dtype != torch.bfloat16 or not p2.is_contiguous():
+            p2 = p2.to(torch.bfloat16).contiguous()
+        d = dst.reshape(M, E).to(device=dev, dtype=torch.float32).contiguous()
+        cosv, pn2, dn2 = (torch.empty(M, device=dev) for _ in range(3))
+        ops.cosine_rows_fwd(p2, d, cosv, pn2, dn2)
+        s = torch.zeros(1, device=dev)
+        ops.colsum(cosv.view(M, 1), s, M, 1)
+        ctx.save_for_backward(p2, d, cosv, pn2, dn2)
+        ctx.coeff, ctx.p_shape = coeff, p.shape
+        return coeff * (1.0 - s[0] / M)
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        p2, d, cosv, pn2, dn2 = ctx.saved_tensors
+        M, E = p2.shape
+        g = gout.detach().reshape(1).float().contiguous()
+        dp = torch.empty_like(p2)
+        ops.cosine_rows_bwd(p2, d, cosv, pn2, dn2, -ctx.coeff / M, g, dp)
+        return dp.view(ctx.p_shape), None, None
 
 
 class RepaLoss(LossFunction):
@@ -114,12 +144,13 @@ class RepaLoss(LossFunction):
         if load_dino:
             raise NotImplementedError("diffulab_amd.RepaLoss: pass load_dino=False and precomputed dst_features (the "
                                       f"{repa_encoder} encoder needs pretrained weights that are not available offline)")
-        if use_resampler:
-            raise NotImplementedError("diffulab_amd.RepaLoss: the Perceiver resampler (perceiver_resampler.py:172-252) is not built")
         self.repa_encoder = None
         self.proj = nn.Sequential(nn.Linear(denoiser_dimension, hidden_dim), nn.SiLU(), nn.Linear(hidden_dim, hidden_dim),
                                   nn.SiLU(), nn.Linear(hidden_dim, embedding_dim))
-        self.resampler = None
+        self.resampler: PerceiverResampler | None = None
+        if use_resampler:
+            assert resampler_params is not None, "Resampler parameters must be provided when using the perceiver resampler."
+            self.resampler = PerceiverResampler(**resampler_params)
         self.alignment_layer = alignment_layer
         self._handles: dict[int, RemovableHandle] = {}
         self._captured_features: dict[int, Tensor] = {}
@@ -164,5 +195,7 @@ class RepaLoss(LossFunction):
         if isinstance(src, tuple):
             src = src[0]
         p = self.proj
-        return _RepaHead.apply(src, dst_features, float(self.coeff), p[0].weight, p[0].bias, p[2].weight, p[2].bias,
-                               p[4].weight, p[4].bias)
+        projected = _ProjMLP.apply(src, p[0].weight, p[0].bias, p[2].weight, p[2].bias, p[4].weight, p[4].bias)
+        if self.resampler is not None:
+            projected = self.resampler(projected)
+        return _CosineLoss.apply(projected, dst_features, float(self.coeff))

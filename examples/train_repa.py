@@ -27,7 +27,8 @@ def train(config_name: str, overrides: list[str]) -> None:
     repa_loss = RepaLoss(denoiser_dimension=cfg.model.inner_dim,  # (the reference reads cfg.model.input_dim, which its yaml lacks)
                          alignment_layer=rp.get("alignment_layer", 8), hidden_dim=rp.get("hidden_dim", 1024),
                          embedding_dim=rp.get("embedding_dim", 1024), load_dino=False,
-                         use_resampler=cfg.perceiver_resampler.get("use_resampler", False), coeff=rp.get("coeff", 0.5))
+                         use_resampler=cfg.perceiver_resampler.get("use_resampler", False),
+                         resampler_params=dict(cfg.perceiver_resampler.get("parameters", {})), coeff=rp.get("coeff", 0.5))
     dl_cfg = cfg.get("dataloader", {})
     mk = lambda ds, shuffle: DataLoader(dataset=ds, batch_size=dl_cfg.get("batch_size", 32), shuffle=shuffle,  # noqa: E731
                                         num_workers=dl_cfg.get("num_workers", 0), pin_memory=dl_cfg.get("pin_memory", False),
@@ -36,7 +37,8 @@ def train(config_name: str, overrides: list[str]) -> None:
     diffuser = Diffuser(denoiser=denoiser, model_type=cfg.diffuser.model_type, n_steps=cfg.diffuser.n_steps,
                         sampling_method=cfg.diffuser.sampling_method, extra_args=dict(cfg.diffuser.get("extra_args", {})),
                         extra_losses=[repa_loss])
-    optimizer = instantiate(cfg.optimizer, params=list(denoiser.parameters()) + list(repa_loss.proj.parameters()))
+    optimizer = instantiate(cfg.optimizer, params=list(denoiser.parameters()) + list(repa_loss.proj.parameters())
+                            + list(repa_loss.resampler.parameters() if repa_loss.resampler else []))
     trainer = BaseTrainer(
         n_epoch=cfg.trainer.n_epoch, gradient_accumulation_step=cfg.trainer.gradient_accumulation_step,
         precision_type=cfg.trainer.precision_type, project_name=cfg.trainer.project_name, use_ema=cfg.trainer.use_ema,

@@ -31,7 +31,7 @@ typedef void* dl_stream_t;
 
 enum { DL_OK = 0, DL_ERR_INVALID = -1, DL_ERR_LAUNCH = -2, DL_ERR_UNSUPPORTED = -3 };
 enum { DL_BF16 = 0, DL_F32 = 1 };
-enum { DL_ACT_NONE = 0, DL_ACT_SILU = 1 };
+enum { DL_ACT_NONE = 0, DL_ACT_SILU = 1, DL_ACT_GELU = 2 };  /* GELU: exact erf form (nn.GELU default) */
 enum { DL_LOSS_FLOW = 0, DL_LOSS_EPS = 1 };                       /* target = a - b | target = a */
 enum { DL_MEAN_EPSILON = 0, DL_MEAN_XSTART = 1, DL_MEAN_XPREV = 2 };
 enum { DL_PATCH_CPP = 0, DL_PATCH_PPC = 1 };                      /* feature order (c p1 p2) | (p1 p2 c) */
@@ -212,6 +212,17 @@ DL_API int dl_cond_combine_bwd(const float* dact, const float* emb, const int64_
                                void* demb_bf16, float* dtable, int64_t B, int64_t E, dl_stream_t stream);
 /* dx = dy * silu'(pre) ; pre bf16 (saved pre-activation), dy f32, dx bf16 */
 DL_API int dl_silu_bwd(const float* dy, const void* pre, void* dx, int64_t n, dl_stream_t stream);
+/* dx = dy * gelu'(pre)  (exact erf GELU; FeedForward of the Perceiver resampler, perceiver_resampler.py:77-80) */
+DL_API int dl_gelu_bwd(const float* dy, const void* pre, void* dx, int64_t n, dl_stream_t stream);
+/* 'b n (h d) -> b h n d' into a longer sequence, with optional rotary embedding (interleaved pairs, nn.py:345-353) on the first
+ * `rot` channels of every head: dst[b, h, n_off + n, :] = rope(src[b*n_src + n, h*64 : h*64+64]); src bf16 rows with stride ld,
+ * dst bf16 [B, H, n_dst, 64]; cos/sin f32 [n_src, rot/2] or NULL (plain head split).  The backward is the same call pattern
+ * in the other direction: src[b*n_src + n, h*64+d] = rope^T(dst[b, h, n_off + n, d]) (accumulate != 0: += into src). */
+DL_API int dl_heads_split_rope(const void* src, int64_t ld, void* dst, int64_t B, int64_t H, int64_t n_src, int64_t n_dst,
+                               int64_t n_off, const float* cos, const float* sin, int64_t rot, dl_stream_t stream);
+DL_API int dl_heads_merge_rope_bwd(const void* dst_grad, void* src_grad, int64_t ld, int64_t B, int64_t H, int64_t n_src,
+                                   int64_t n_dst, int64_t n_off, const float* cos, const float* sin, int64_t rot,
+                                   int accumulate, dl_stream_t stream);
 /* out[c] += sum_r x[r,c]  (bias gradients); x bf16 or f32 per dtype */
 DL_API int dl_colsum(const void* x, int dtype, int64_t ld, float* out, int64_t R, int64_t C,
                      dl_stream_t stream);

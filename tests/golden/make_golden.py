@@ -496,9 +496,44 @@ def gen_repa() -> None:
     save("repa", **o)
 
 
+# ------------------------------------------------------------------ (x) Perceiver resampler of the REPA config
+def gen_resampler() -> None:
+    """the reference PerceiverResampler (networks/repa/perceiver_resampler.py) on seeded inputs: output, input gradient and
+    every parameter gradient (dim 128, depth 2, 2 heads x 64, 256 latents, 64 input tokens = an 8x8 grid)"""
+    import importlib
+
+    root = os.path.join(REF, "diffulab")
+    if "diffulab.networks.repa" not in sys.modules:
+        rp = types.ModuleType("diffulab.networks.repa")
+        rp.__path__ = [f"{root}/networks/repa"]  # type: ignore[attr-defined]
+        sys.modules["diffulab.networks.repa"] = rp
+    sys.modules.pop("diffulab.networks.repa.perceiver_resampler", None)  # (gen_repa registers a stub of this name)
+    PR = importlib.import_module("diffulab.networks.repa.perceiver_resampler").PerceiverResampler
+    from oracle import repa as orepa
+
+    kw = dict(dim=128, depth=2, head_dim=64, num_heads=2, ff_mult=4, num_latents=256)
+    m = PR(**kw)
+    shapes = orepa.resampler_param_shapes(**kw)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == shapes
+    m.load_state_dict(synth.generic_params(shapes, seed=51))
+    x = synth.normal("rs.x", (3, 64, 128)).requires_grad_(True)
+    # As shipped, forward(x) with cos_sin=None raises IndexError: it builds [S, d/2] tables from un-batched position ids and
+    # _apply_rotary (utils/nn.py:342) indexes them as [B, S, d/2].  The module's own cos_sin argument with the same helper on
+    # batched ids ([1, S, 2]) is the evident intent and is what the fixture pins.
+    from diffulab.networks.utils.nn import get_cos_sin_ndim_grid
+
+    ids = torch.stack(torch.meshgrid(torch.arange(8), torch.arange(8), indexing="ij"), dim=-1).view(1, -1, 2)
+    y = m(x, cos_sin=get_cos_sin_ndim_grid(ids, base=m.rope_base, axes_dim=m.rope_axes_dim))
+    (y * synth.normal("rs.dy", tuple(y.shape))).sum().backward()
+    o = {"y": y, "dx": x.grad}
+    for n, p in m.named_parameters():
+        o["g_" + n] = p.grad
+    save("resampler", **o)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve", "repa"]
-    fns = {"repa": gen_repa, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
+    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve", "repa", "resampler"]
+    fns = {"repa": gen_repa, "resampler": gen_resampler, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
            "s2": gen_s2_model, "samplers": gen_samplers, "curve": gen_loss_curve, "unet": gen_unet}
     for w in which:
         print("==", w)

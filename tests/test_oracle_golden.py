@@ -381,3 +381,18 @@ def test_repa_loss_hooked_into_small_dit(golden):
         assert rel(v.grad, g["g_" + n]) < 1e-5, n
     for n, v in P.items():
         assert rel(v.grad, g["gd_" + n]) < 2e-5, n
+
+
+def test_perceiver_resampler(golden):
+    """(x) the REPA config's Perceiver resampler: output, input gradient and parameter gradients vs the reference module"""
+    from oracle import repa as orepa
+
+    g = golden("resampler")
+    kw = dict(dim=128, depth=2, head_dim=64, num_heads=2, ff_mult=4, num_latents=256)
+    P = {k: v.requires_grad_(True) for k, v in synth.generic_params(orepa.resampler_param_shapes(**kw), seed=51).items()}
+    x = synth.normal("rs.x", (3, 64, 128)).requires_grad_(True)
+    y = orepa.perceiver_resampler(P, x, depth=2, head_dim=64, num_heads=2)
+    (y * synth.normal("rs.dy", tuple(y.shape))).sum().backward()
+    assert rel(y, g["y"]) < 2e-6 and rel(x.grad, g["dx"]) < 1e-5
+    for n, v in P.items():
+        assert rel(v.grad, g["g_" + n]) < 2e-5, n
