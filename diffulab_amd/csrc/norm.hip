@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(const bf16_t* __restri
                                                           const float* __restrict__ sn, bf16_t* __restrict__ qo,
                                                           bf16_t* __restrict__ ko, bf16_t* __restrict__ vo,
                                                           float* __restrict__ rrms, int64_t M, int N, int H, int dh,
-                                                          int rot, float eps) {
+                                                          int rot, float eps, const int* __restrict__ pos) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D = H * dh, D8 = D >> 3;
   const float invD = 1.0f / (float)D;
@@ -417,6 +417,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(const bf16_t* __restri
     const float rq = rsqrtf(wave_sum(s1) * invD + eps), rk = rsqrtf(wave_sum(s2) * invD + eps);
     const int64_t b = row / N;
     const int n = (int)(row - b * N);
+    const int nt = pos ? pos[row] : n;  // table row: the token's position on the grid (SPRINT keeps a subset of the tokens)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = lane + 64 * j;
@@ -428,8 +429,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(const bf16_t* __restri
         k[j][e] = k[j][e] * rk * wk[j][e];
       }
       if (d0 < rot) {  // rot is a multiple of 8: a chunk is either fully rotary or fully pass-through
-        const f32x4_t cc = *(const f32x4_t*)(cs + (int64_t)n * (rot >> 1) + (d0 >> 1));
-        const f32x4_t ss = *(const f32x4_t*)(sn + (int64_t)n * (rot >> 1) + (d0 >> 1));
+        const f32x4_t cc = *(const f32x4_t*)(cs + (int64_t)nt * (rot >> 1) + (d0 >> 1));
+        const f32x4_t ss = *(const f32x4_t*)(sn + (int64_t)nt * (rot >> 1) + (d0 >> 1));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float qa = q[j][2 * i], qb = q[j][2 * i + 1], ka = k[j][2 * i], kb = k[j][2 * i + 1];
@@ -451,9 +452,17 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(const bf16_t* __restri
   }
 }
 
+extern "C" int dl_qk_norm_rope_fwd_ex(const void* qkv, const float* scale_q, const float* scale_k, const float* cos,
+                                      const float* sin, void* q, void* k, void* v, float* rrms, int64_t B, int64_t N,
+                                      int64_t H, int64_t dh, int64_t rot, float eps, const int32_t* pos, dl_stream_t stream);
 extern "C" int dl_qk_norm_rope_fwd(const void* qkv, const float* scale_q, const float* scale_k, const float* cos,
                                    const float* sin, void* q, void* k, void* v, float* rrms, int64_t B, int64_t N,
                                    int64_t H, int64_t dh, int64_t rot, float eps, dl_stream_t stream) {
+  return dl_qk_norm_rope_fwd_ex(qkv, scale_q, scale_k, cos, sin, q, k, v, rrms, B, N, H, dh, rot, eps, nullptr, stream);
+}
+extern "C" int dl_qk_norm_rope_fwd_ex(const void* qkv, const float* scale_q, const float* scale_k, const float* cos,
+                                      const float* sin, void* q, void* k, void* v, float* rrms, int64_t B, int64_t N,
+                                      int64_t H, int64_t dh, int64_t rot, float eps, const int32_t* pos, dl_stream_t stream) {
   DL_CHECK_ARG(qkv && scale_q && scale_k && cos && sin && q && k && v && rrms && B > 0 && N > 0,
                "dl_qk_norm_rope_fwd: null operand");
   const int64_t D = H * dh;
@@ -465,7 +474,7 @@ extern "C" int dl_qk_norm_rope_fwd(const void* qkv, const float* scale_q, const 
   const int nj = cdiv(D, 512);
 #define LAUNCH(NJ)                                                                                                  \
   hipLaunchKernelGGL(qk_norm_rope_fwd_k<NJ>, grid, 256, 0, (hipStream_t)stream, (const bf16_t*)qkv, scale_q, scale_k, \
-                     cos, sin, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, rrms, M, (int)N, (int)H, (int)dh, (int)rot, eps)
+                     cos, sin, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, rrms, M, (int)N, (int)H, (int)dh, (int)rot, eps, pos)
   if (nj == 1) LAUNCH(1);
   else LAUNCH(2);
 #undef LAUNCH
@@ -482,7 +491,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(const bf16_t* __restri
                                                           const float* __restrict__ cs, const float* __restrict__ sn,
                                                           const float* __restrict__ rrms, bf16_t* __restrict__ dqkv,
                                                           float* __restrict__ dscale, int64_t M, int N, int H, int dh,
-                                                          int rot) {
+                                                          int rot, const int* __restrict__ pos) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = (float*)smem;  // [4 waves][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -498,6 +507,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(const bf16_t* __restri
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
     const int64_t b = row / N;
     const int n = (int)(row - b * N);
+    const int nt = pos ? pos[row] : n;
     const bf16_t* p = qkv + row * 3 * D;
     float xq[NJ][8], xk[NJ][8], gq[NJ][8], gk[NJ][8], gv[NJ][8];
     load_row<NJ>(p, D8, lane, xq);
@@ -518,8 +528,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(const bf16_t* __restri
       unpack8(*(const u32x4_t*)(dk + o), gk[j]);
       unpack8(*(const u32x4_t*)(dv + o), gv[j]);
       if (d0 < rot) {  // transpose of the rotation
-        const f32x4_t cc = *(const f32x4_t*)(cs + (int64_t)n * (rot >> 1) + (d0 >> 1));
-        const f32x4_t ss = *(const f32x4_t*)(sn + (int64_t)n * (rot >> 1) + (d0 >> 1));
+        const f32x4_t cc = *(const f32x4_t*)(cs + (int64_t)nt * (rot >> 1) + (d0 >> 1));
+        const f32x4_t ss = *(const f32x4_t*)(sn + (int64_t)nt * (rot >> 1) + (d0 >> 1));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float qa = gq[j][2 * i], qb = gq[j][2 * i + 1], ka = gk[j][2 * i], kb = gk[j][2 * i + 1];
@@ -570,10 +580,20 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(const bf16_t* __restri
   }
 }
 
+extern "C" int dl_qk_norm_rope_bwd_ex(const void* dq, const void* dk, const void* dv, const void* qkv,
+                                   const float* scale_q, const float* scale_k, const float* cos, const float* sin,
+                                   const float* rrms, void* dqkv, float* dscale, int64_t B, int64_t N, int64_t H,
+                                   int64_t dh, int64_t rot, const int32_t* pos, dl_stream_t stream);
 extern "C" int dl_qk_norm_rope_bwd(const void* dq, const void* dk, const void* dv, const void* qkv,
                                    const float* scale_q, const float* scale_k, const float* cos, const float* sin,
                                    const float* rrms, void* dqkv, float* dscale, int64_t B, int64_t N, int64_t H,
                                    int64_t dh, int64_t rot, dl_stream_t stream) {
+  return dl_qk_norm_rope_bwd_ex(dq, dk, dv, qkv, scale_q, scale_k, cos, sin, rrms, dqkv, dscale, B, N, H, dh, rot, nullptr, stream);
+}
+extern "C" int dl_qk_norm_rope_bwd_ex(const void* dq, const void* dk, const void* dv, const void* qkv,
+                                   const float* scale_q, const float* scale_k, const float* cos, const float* sin,
+                                   const float* rrms, void* dqkv, float* dscale, int64_t B, int64_t N, int64_t H,
+                                   int64_t dh, int64_t rot, const int32_t* pos, dl_stream_t stream) {
   DL_CHECK_ARG(dq && dk && dv && qkv && scale_q && scale_k && cos && sin && rrms && dqkv && dscale && B > 0 && N > 0,
                "dl_qk_norm_rope_bwd: null operand");
   const int64_t D = H * dh;
@@ -587,7 +607,7 @@ extern "C" int dl_qk_norm_rope_bwd(const void* dq, const void* dk, const void* d
 #define LAUNCH(NJ)                                                                                                   \
   hipLaunchKernelGGL(qk_norm_rope_bwd_k<NJ>, grid, 256, lds, (hipStream_t)stream, (const bf16_t*)dq, (const bf16_t*)dk, \
                      (const bf16_t*)dv, (const bf16_t*)qkv, scale_q, scale_k, cos, sin, rrms, (bf16_t*)dqkv, dscale, M, \
-                     (int)N, (int)H, (int)dh, (int)rot)
+                     (int)N, (int)H, (int)dh, (int)rot, pos)
   if (nj == 1) LAUNCH(1);
   else LAUNCH(2);
 #undef LAUNCH

@@ -190,14 +190,37 @@ def gate_bwd(dout, t, gate, rows_per_mod, dt, dgate):
           D, _s())
 
 
-def qk_norm_rope_fwd(qkv, scale_q, scale_k, cos, sin, q, k, v, rrms, B, N, H, dh, rot, eps=1e-6):
-    _call("dl_qk_norm_rope_fwd", _p(qkv), _p(scale_q), _p(scale_k), _p(cos), _p(sin), _p(q), _p(k), _p(v), _p(rrms), B, N,
-          H, dh, rot, float(eps), _s())
+def qk_norm_rope_fwd(qkv, scale_q, scale_k, cos, sin, q, k, v, rrms, B, N, H, dh, rot, eps=1e-6, pos=None):
+    """pos: int32 [B*N] table row of every token (None: its index in the sequence)"""
+    _call("dl_qk_norm_rope_fwd_ex", _p(qkv), _p(scale_q), _p(scale_k), _p(cos), _p(sin), _p(q), _p(k), _p(v), _p(rrms), B, N,
+          H, dh, rot, float(eps), _p(pos), _s())
 
 
-def qk_norm_rope_bwd(dq, dk, dv, qkv, scale_q, scale_k, cos, sin, rrms, dqkv, dscale, B, N, H, dh, rot):
-    _call("dl_qk_norm_rope_bwd", _p(dq), _p(dk), _p(dv), _p(qkv), _p(scale_q), _p(scale_k), _p(cos), _p(sin), _p(rrms),
-          _p(dqkv), _p(dscale), B, N, H, dh, rot, _s())
+def qk_norm_rope_bwd(dq, dk, dv, qkv, scale_q, scale_k, cos, sin, rrms, dqkv, dscale, B, N, H, dh, rot, pos=None):
+    _call("dl_qk_norm_rope_bwd_ex", _p(dq), _p(dk), _p(dv), _p(qkv), _p(scale_q), _p(scale_k), _p(cos), _p(sin), _p(rrms),
+          _p(dqkv), _p(dscale), B, N, H, dh, rot, _p(pos), _s())
+
+
+# ------------------------------------------------------------------ SPRINT token routing
+def gather_tokens(src, idx, dst, B, N, k, D, keep=None):
+    _call("dl_gather_tokens", _p(src), src.stride(0), _p(idx), _p(keep), _p(dst), dst.stride(0), B, N, k, D, _s())
+
+
+def scatter_tokens_add(src, idx, dst, B, N, k, D):
+    _call("dl_scatter_tokens_add", _p(src), src.stride(0), _p(idx), _p(dst), dst.stride(0), B, N, k, D, _s())
+
+
+def restore_tokens(xd, inv, mask, out, B, N, k, D):
+    _call("dl_restore_tokens", _p(xd), xd.stride(0), _p(inv), _p(mask), _p(out), out.stride(0), B, N, k, D, _s())
+
+
+def masked_colsum(x, sel, out, R, C):
+    _call("dl_masked_colsum", _p(x), x.stride(0), _p(sel), _p(out), R, C, _s())
+
+
+def gated_residual_fwd(x, t, gate, rows_per_mod, out):
+    M, D = x.shape
+    _call("dl_gated_residual_fwd", _p(x), _p(t), _p(gate), gate.stride(0), rows_per_mod, _p(out), out.stride(0), M, D, _s())
 
 
 def attn_fwd(q, k, v, out, lse, B, H, N, dh, scale):

@@ -171,6 +171,16 @@ DL_API int dl_qk_norm_rope_bwd(const void* dq, const void* dk, const void* dv, c
                                const float* scale_q, const float* scale_k, const float* cos, const float* sin,
                                const float* rrms, void* dqkv, float* dscale, int64_t B, int64_t N, int64_t H,
                                int64_t dh, int64_t rot, dl_stream_t stream);
+/* same with an optional position index: pos int32 [B*N] gives the cos/sin table row of every token (NULL: row = n).  SPRINT
+ * runs its deep blocks on a per-sample subset of the image tokens whose RoPE rows are gathered with the kept indices
+ * (sprint.py:348-353); the index replaces the gathered [B, k, rot/2] tables. */
+DL_API int dl_qk_norm_rope_fwd_ex(const void* qkv, const float* scale_q, const float* scale_k, const float* cos,
+                                  const float* sin, void* q, void* k, void* v, float* rrms, int64_t B, int64_t N,
+                                  int64_t H, int64_t dh, int64_t rot, float eps, const int32_t* pos, dl_stream_t stream);
+DL_API int dl_qk_norm_rope_bwd_ex(const void* dq, const void* dk, const void* dv, const void* qkv,
+                                  const float* scale_q, const float* scale_k, const float* cos, const float* sin,
+                                  const float* rrms, void* dqkv, float* dscale, int64_t B, int64_t N, int64_t H,
+                                  int64_t dh, int64_t rot, const int32_t* pos, dl_stream_t stream);
 /* F.scaled_dot_product_attention mmdit.py:92-100, no mask: out = softmax(q k^T * scale) v, written as
  * 'b h n d -> b n (h d)'.  lse f32 [B,H,N] = natural-log-sum-exp of the scaled scores (for the backward).
  * dh must be 64; N a multiple of 64 up to 256 (K and V of one head stay resident in LDS), or a multiple of 256 up to 2048
@@ -238,6 +248,27 @@ DL_API int dl_cosine_rows_fwd(const void* p, int64_t ldp, const float* d, int64_
 DL_API int dl_cosine_rows_bwd(const void* p, int64_t ldp, const float* d, int64_t ldd, const float* cosv, const float* pn2,
                               const float* dn2, float gscale, const float* gscale_dev, void* dp, int64_t lddp, int64_t M,
                               int64_t E, float eps, dl_stream_t stream);
+
+/* ------------------------------------------------------------------ SPRINT token routing (sprint.py:317-387) */
+/* drop_tokens' torch.gather (sprint.py:347): dst[b, j, :] = src[b, idx[b, j], :]; src rows [B*N] with stride ld_src, dst rows
+ * [B*k] with stride ld_dst, idx int32 [B, k].  keep int32 [B] or NULL: samples with keep[b] == 0 produce zero rows (the
+ * backward of restore_tokens for samples whose deep path was dropped). */
+DL_API int dl_gather_tokens(const void* src, int64_t ld_src, const int32_t* idx, const int32_t* keep, void* dst,
+                            int64_t ld_dst, int64_t B, int64_t N, int64_t k, int64_t D, dl_stream_t stream);
+/* adjoint of the gather: dst[b, idx[b, j], :] += src[b, j, :] (indices of one sample are distinct) */
+DL_API int dl_scatter_tokens_add(const void* src, int64_t ld_src, const int32_t* idx, void* dst, int64_t ld_dst, int64_t B,
+                                 int64_t N, int64_t k, int64_t D, dl_stream_t stream);
+/* restore_tokens (sprint.py:355-387): out[b, n, :] = inv[b, n] >= 0 ? xd[b, inv[b, n], :] : mask_token; inv int32 [B, N] is the
+ * inverse of the kept indices (-1 = dropped token, or every token of a sample whose deep path is dropped); mask f32 [D]. */
+DL_API int dl_restore_tokens(const void* xd, int64_t ld_xd, const int32_t* inv, const float* mask, void* out, int64_t ld_out,
+                             int64_t B, int64_t N, int64_t k, int64_t D, dl_stream_t stream);
+/* gradient of the mask token: out[c] += sum over rows with sel[row] < 0 of x[row, c] (x bf16, out f32) */
+DL_API int dl_masked_colsum(const void* x, int64_t ld, const int32_t* sel, float* out, int64_t R, int64_t C,
+                            dl_stream_t stream);
+/* x + gate * t materialised (mmdit.py:302,308 at a stage boundary, where no LayerNorm follows to absorb it); gate rows as in
+ * dl_ln_modulate_fwd */
+DL_API int dl_gated_residual_fwd(const void* x, const void* t, const void* gate, int64_t ld_gate, int64_t rows_per_mod,
+                                 void* out, int64_t ld_out, int64_t M, int64_t D, dl_stream_t stream);
 
 /* ------------------------------------------------------------------ optimizer side */
 /* torch.optim.AdamW single-tensor math (configs/optimizer/adamw.yaml) over a flat f32 buffer:

@@ -90,14 +90,14 @@ def rope_tables(grid_h: int, grid_w: int, axes_dim: list[int], base: float) -> t
 def apply_rope(x: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
     """nn.py:345-353: rotate interleaved pairs (x[2j], x[2j+1]) of the first 2*P channels.
 
-    x: [B, N, H, dh]; cos/sin: [N, P].
+    x: [B, N, H, dh]; cos/sin: [N, P], or [B, N, P] per-sample tables (SPRINT's gathered rows, sprint.py:348-353).
     """
     rot = 2 * cos.shape[1]
     xr, xp = x[..., :rot], x[..., rot:]
     a = xr[..., 0::2]
     b = xr[..., 1::2]
-    c = cos[None, :, None, :].to(x.dtype)
-    s = sin[None, :, None, :].to(x.dtype)
+    c = (cos[None] if cos.dim() == 2 else cos)[:, :, None, :].to(x.dtype)
+    s = (sin[None] if sin.dim() == 2 else sin)[:, :, None, :].to(x.dtype)
     ra = a * c - b * s
     rb = a * s + b * c
     out = torch.stack((ra, rb), dim=-1).flatten(-2)

@@ -2,6 +2,7 @@
     python scripts/train_step_bench.py cifar --batch 32     # configs/train_cifar10_flow_matching.yaml (dit.yaml dims, RGB 32x32)
     python scripts/train_step_bench.py s2 --batch 256       # the headline DiT-S/2 workload (same step as bench.py)
     python scripts/train_step_bench.py repa --batch 128     # DiT-B/REPA dims (768/12 heads/12 blocks, 32x8x8 latents) + REPA loss
+    python scripts/train_step_bench.py repa_rs --batch 128  # same + the Perceiver resampler (configs/train_imagenet_flow_matching_repa.yaml)
 """
 import argparse
 import json
@@ -25,6 +26,8 @@ CFG = {
     "repa": (dict(input_channels=32, output_channels=32, inner_dim=768, embedding_dim=256, num_heads=12, mlp_ratio=4, patch_size=1,
                   depth=12, n_classes=1000, classifier_free=True), (32, 8, 8)),
 }
+CFG["repa_rs"] = CFG["repa"]
+RS = dict(depth=3, dim=1024, head_dim=64, num_heads=8, ff_mult=4, num_latents=256)
 
 
 def main() -> None:
@@ -39,16 +42,18 @@ def main() -> None:
     torch.manual_seed(0)
     m = MMDiT(simple_dit=True, **kw).to(dev)
     extra, params = [], list(m.parameters())
-    if a.config == "repa":
-        rl = RepaLoss(alignment_layer=8, denoiser_dimension=768, hidden_dim=1024, load_dino=False, embedding_dim=1024, coeff=0.5).to(dev)
+    if a.config.startswith("repa"):
+        rs = a.config == "repa_rs"
+        rl = RepaLoss(alignment_layer=8, denoiser_dimension=768, hidden_dim=1024, load_dino=False, embedding_dim=1024, coeff=0.5,
+                      use_resampler=rs, resampler_params=RS if rs else None).to(dev)
         rl.set_model(m)
-        extra, params = [rl], params + list(rl.proj.parameters())
+        extra, params = [rl], params + list(rl.parameters())
     d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=50, extra_args={"logits_normal": True},
                  extra_losses=extra)
     opt = FusedAdamW(params, lr=1e-4, weight_decay=0.01)
     x0 = torch.randn(a.batch, *shape, device=dev)
     y = torch.randint(0, kw["n_classes"], (a.batch,), device=dev)
-    dst = torch.randn(a.batch, 64, 1024, device=dev) if a.config == "repa" else None
+    dst = torch.randn(a.batch, 256 if a.config == "repa_rs" else 64, 1024, device=dev) if a.config.startswith("repa") else None
     p = 0.1 if kw["classifier_free"] else 0.0
 
     def step():

@@ -531,9 +531,87 @@ def gen_resampler() -> None:
     save("resampler", **o)
 
 
+# ------------------------------------------------------------------ (xi) SprintDiT, simple_dit (configs/model/sprint.yaml)
+SPRINT_SMALL = dict(input_channels=4, output_channels=4, inner_dim=128, embedding_dim=64, num_heads=2, mlp_ratio=4, patch_size=2,
+                    encoder_depth=1, deep_layers_depth=2, decoder_depth=1, n_classes=10, classifier_free=True, drop_rate=0.75)
+
+
+class _RandRecorder:
+    """records every torch.rand draw of a forward (label drop nn.py:149, token scores sprint.py:343, path drop sprint.py:384)
+    so that the oracle / the HIP path can be fed the same decisions"""
+
+    def __enter__(self):
+        self.draws, self._orig = [], torch.rand
+
+        def rec(*a, **k):
+            out = self._orig(*a, **k)
+            self.draws.append(out.clone())
+            return out
+
+        torch.rand = rec
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand = self._orig
+
+
+def gen_sprint() -> None:
+    import importlib
+
+    from oracle import sprint as osprint
+
+    SprintDiT = importlib.import_module("diffulab.networks.denoisers.sprint").SprintDiT
+    cfg = osprint.SprintConfig(**SPRINT_SMALL)
+    m = SprintDiT(simple_dit=True, **SPRINT_SMALL)
+    shapes = osprint.param_shapes(cfg)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == shapes, set(m.state_dict()) ^ set(shapes)
+    P = synth.dit_params({k: v for k, v in shapes.items() if k != "mask_token"}, seed=61)
+    P["mask_token"] = synth.normal("sp.mask", shapes["mask_token"]) * 0.5
+    m.load_state_dict(P)
+    B, H = 4, 32
+    x = synth.normal("sp.x", (B, 4, H, H))
+    t = synth.uniform("sp.t", (B,), lo=0.05, hi=0.95)
+    y = synth.integers("sp.y", (B,), 10)
+    dy = synth.normal("sp.dy", (B, 4, H, H))
+    o = {}
+    # (a) training step, p = 0: token drop only
+    m.train()
+    torch.manual_seed(3)
+    with _RandRecorder() as r:
+        pred = m(x=x, timesteps=t, y=y, p=0.0)["x"]
+    assert len(r.draws) == 1 and r.draws[0].shape == (B, 256)
+    o["a_scores"], o["a_pred"] = r.draws[0], pred
+    (pred * dy).sum().backward()
+    for n, p in m.named_parameters():
+        o["a_g_" + n] = p.grad.clone()
+    m.zero_grad()
+    # (b) training step, p = 0.5: label drop + token drop + per-sample path drop (seed chosen so both outcomes occur)
+    torch.manual_seed(4)
+    with _RandRecorder() as r:
+        pred = m(x=x, timesteps=t, y=y, p=0.5)["x"]
+    assert [tuple(d.shape) for d in r.draws] == [(B,), (B, 256), (B,)]
+    assert 0 < int((r.draws[2] < 0.5).sum()) < B, r.draws[2]
+    o["b_label_u"], o["b_scores"], o["b_path_u"], o["b_pred"] = r.draws[0], r.draws[1], r.draws[2], pred
+    (pred * dy).sum().backward()
+    for n in ("mask_token", "fuse.weight", "layers.0.attention.qkv.weight", "deep_layers.1.mlp_input.2.weight",
+              "decoder_layers.0.modulation.lin.weight", "label_embed.embedding.weight"):
+        o["b_g_" + n] = dict(m.named_parameters())[n].grad.clone()
+    m.zero_grad()
+    # (c) / (d) eval: no token drop; p = 1 skips the deep layers (the unconditional branch of classifier-free sampling)
+    m.eval()
+    with torch.no_grad():
+        o["c_pred"] = m(x=x, timesteps=t, y=y, p=0.0)["x"]
+        o["d_pred"] = m(x=x, timesteps=t, y=y, p=1.0)["x"]
+    # (e) 4-step Euler sampling with guidance through the Diffuser
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=4)
+    out = d.generate({"x": synth.normal("sp.init", (B, 4, H, H)), "y": y}, use_tqdm=False, guidance_scale=2.0)
+    o["e_loop_x"] = out["x"]
+    save("sprint", **o)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve", "repa", "resampler"]
-    fns = {"repa": gen_repa, "resampler": gen_resampler, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
+    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve", "repa", "resampler", "sprint"]
+    fns = {"repa": gen_repa, "resampler": gen_resampler, "sprint": gen_sprint, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
            "s2": gen_s2_model, "samplers": gen_samplers, "curve": gen_loss_curve, "unet": gen_unet}
     for w in which:
         print("==", w)

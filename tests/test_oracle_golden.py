@@ -396,3 +396,51 @@ def test_perceiver_resampler(golden):
     assert rel(y, g["y"]) < 2e-6 and rel(x.grad, g["dx"]) < 1e-5
     for n, v in P.items():
         assert rel(v.grad, g["g_" + n]) < 2e-5, n
+
+
+def test_sprint_dit(golden):
+    """(xi) SprintDiT(simple_dit=True): training forward/backward with the recorded token-drop scores, label / path drops,
+    eval forward with and without the deep path, and a guided 4-step Euler sampling loop"""
+    from oracle import sprint as osprint
+
+    g = {k: torch.as_tensor(v) for k, v in golden("sprint").items()}
+    kw = dict(input_channels=4, output_channels=4, inner_dim=128, embedding_dim=64, num_heads=2, mlp_ratio=4, patch_size=2,
+              encoder_depth=1, deep_layers_depth=2, decoder_depth=1, n_classes=10, classifier_free=True, drop_rate=0.75)
+    cfg = osprint.SprintConfig(**kw)
+    shapes = osprint.param_shapes(cfg)
+    P = synth.dit_params({k: v for k, v in shapes.items() if k != "mask_token"}, seed=61)
+    P["mask_token"] = synth.normal("sp.mask", shapes["mask_token"]) * 0.5
+    P = {k: v.requires_grad_(True) for k, v in P.items()}
+    B, H = 4, 32
+    x, t, y = synth.normal("sp.x", (B, 4, H, H)), synth.uniform("sp.t", (B,), lo=0.05, hi=0.95), synth.integers("sp.y", (B,), 10)
+    dy = synth.normal("sp.dy", (B, 4, H, H))
+    k = osprint.n_kept(256, 0.75)
+    assert k == 64
+    # (a)
+    pred = osprint.sprint_forward(P, x, t, y, cfg, kept=osprint.kept_indices(g["a_scores"], k))
+    assert rel(pred, g["a_pred"]) < 2e-6
+    (pred * dy).sum().backward()
+    for n, v in P.items():
+        assert rel(v.grad, g["a_g_" + n]) < 2e-5, n
+        v.grad = None
+    # (b)
+    y_eff = torch.where(g["b_label_u"] < 0.5, torch.full_like(y, 10), y)
+    pred = osprint.sprint_forward(P, x, t, y_eff, cfg, kept=osprint.kept_indices(g["b_scores"], k), path_drop=g["b_path_u"] < 0.5)
+    assert rel(pred, g["b_pred"]) < 2e-6
+    (pred * dy).sum().backward()
+    for n in ("mask_token", "fuse.weight", "layers.0.attention.qkv.weight", "deep_layers.1.mlp_input.2.weight",
+              "decoder_layers.0.modulation.lin.weight", "label_embed.embedding.weight"):
+        assert rel(P[n].grad, g["b_g_" + n]) < 2e-5, n
+    # (c), (d)
+    with torch.no_grad():
+        assert rel(osprint.sprint_forward(P, x, t, y, cfg), g["c_pred"]) < 2e-6
+        assert rel(osprint.sprint_forward(P, x, t, torch.full_like(y, 10), cfg, skip_deep=True), g["d_pred"]) < 2e-6
+        # (e) flow.py:410-524 + euler.py:22-41: v = v_uncond + s (v_cond - v_uncond), x -= v dt
+        xs = synth.normal("sp.init", (B, 4, H, H))
+        ts = [1.0, 0.75, 0.5, 0.25, 0.0]
+        for a, b in zip(ts[:-1], ts[1:]):
+            tt = torch.full((B,), a)
+            vc = osprint.sprint_forward(P, xs, tt, y, cfg)
+            vu = osprint.sprint_forward(P, xs, tt, torch.full_like(y, 10), cfg, skip_deep=True)
+            xs = xs - (vu + 2.0 * (vc - vu)) * (a - b)
+        assert rel(xs, g["e_loop_x"]) < 1e-5
