@@ -96,10 +96,14 @@ class ParamLayout:
     """name -> (offset, shape) inside the flat f32 arena.  Order: adaLN weights of all blocks + last layer
     (one [L*6D+2D, E] matrix), their biases, then everything else; every entry starts on a 256-byte boundary."""
 
-    def __init__(self, d: DiTDims) -> None:
+    def __init__(self, d: DiTDims, prefixes: list[str] | None = None, extra: tuple[tuple[str, tuple[int, ...]], ...] = ()) -> None:
+        """prefixes: state_dict prefix of every adaLN-zero block in execution order (default ``layers.{i}.``);
+        extra: further non-block parameters (SPRINT's mask token and fuse linear), placed with the stem / head entries"""
         D, E, p = d.inner_dim, d.embedding_dim, d.patch_size
         self.entries: dict[str, tuple[int, tuple[int, ...]]] = {}
         self.size = 0
+        self.prefixes = prefixes = list(prefixes) if prefixes is not None else [f"layers.{i}." for i in range(d.depth)]
+        nb = len(prefixes)
 
         def add(name: str, shape: tuple[int, ...], align: int = 64) -> None:
             self.size = _rup(self.size, align)
@@ -107,13 +111,13 @@ class ParamLayout:
             self.size += math.prod(shape)
 
         # -- contiguous adaLN matrix / bias (rows are multiples of 64*... so no padding is inserted between them)
-        for i in range(d.depth):
-            add(f"layers.{i}.modulation.lin.weight", (6 * D, E), align=1 if i else 64)
+        for i, pre in enumerate(prefixes):
+            add(pre + "modulation.lin.weight", (6 * D, E), align=1 if i else 64)
         add("last_layer.adaLN_modulation.1.weight", (2 * D, E), align=1)
-        for i in range(d.depth):
-            add(f"layers.{i}.modulation.lin.bias", (6 * D,), align=1 if i else 64)
+        for i, pre in enumerate(prefixes):
+            add(pre + "modulation.lin.bias", (6 * D,), align=1 if i else 64)
         add("last_layer.adaLN_modulation.1.bias", (2 * D,), align=1)
-        self.mod_rows = d.depth * 6 * D + 2 * D
+        self.mod_rows = nb * 6 * D + 2 * D
         if d.n_classes is not None:
             add("label_embed.embedding.weight", (d.n_classes + (1 if d.classifier_free else 0), E))
         add("time_embed.0.weight", (E, d.frequency_embedding))
@@ -123,8 +127,9 @@ class ParamLayout:
         add("conv_proj.weight", (D, d.input_channels, p, p))
         add("last_layer.linear.weight", (p * p * d.output_channels, D))
         add("last_layer.linear.bias", (p * p * d.output_channels,))
-        for i in range(d.depth):
-            pre = f"layers.{i}."
+        for name, shape in extra:
+            add(name, shape)
+        for pre in prefixes:
             add(pre + "norm_1.weight", (D,))
             add(pre + "norm_1.bias", (D,), align=1)  # [w; b] adjacent: one reduce writes both gradients
             add(pre + "norm_2.weight", (D,))
@@ -147,7 +152,8 @@ class DiTEngine:
         dims.validate()
         self.d = dims
         self.dev = torch.device(device)
-        self.layout = ParamLayout(dims)
+        self.layout = self._make_layout(dims)
+        self.prefixes = self.layout.prefixes
         self.params: Tensor | None = None
         self.grads: Tensor | None = None
         self._shadow_key: tuple | None = None
@@ -160,8 +166,11 @@ class DiTEngine:
         self.reducer = None  # optional training.dp.GradReducer: gets ready(lo, hi) as gradient ranges complete
         self._build_shadows()
         ent = self.layout.entries
-        starts = [ent[f"layers.{i}.norm_1.weight"][0] for i in range(dims.depth)] + [self.layout.size]
-        self.layer_ranges = [(starts[i], starts[i + 1]) for i in range(dims.depth)]
+        starts = [ent[pre + "norm_1.weight"][0] for pre in self.prefixes] + [self.layout.size]
+        self.layer_ranges = [(starts[i], starts[i + 1]) for i in range(len(self.prefixes))]
+
+    def _make_layout(self, dims: DiTDims) -> ParamLayout:
+        return ParamLayout(dims)
 
     # ------------------------------------------------------------------ parameters
     def bind(self, params: Tensor, grads: Tensor | None) -> None:
@@ -192,19 +201,22 @@ class DiTEngine:
                 self.sh[t] = torch.zeros(C, _rup(R, 64), device=dev, dtype=torch.bfloat16)
             self._casts.append((name, (R, C), f, t))
 
-        self.mod_name = "layers.0.modulation.lin.weight"  # start of the stacked [mod_rows, E] matrix
+        self.mod_name = self.prefixes[0] + "modulation.lin.weight"  # start of the stacked [mod_rows, E] matrix
         reg("@mod", self.layout.mod_rows, E)
         reg("time_embed.0.weight", E, d.frequency_embedding, dgrad=False)
         reg("time_embed.2.weight", E, E)
         reg("conv_proj.weight", D, d.input_channels * d.patch_size**2, dgrad=False)
         reg("last_layer.linear.weight", d.patch_size**2 * d.output_channels, D)
-        for i in range(d.depth):
-            pre = f"layers.{i}."
+        self._extra_shadows(reg)
+        for pre in self.prefixes:
             reg(pre + "attention.qkv.weight", 3 * D, D)
             reg(pre + "attention.proj_out.weight", D, D)
             reg(pre + "mlp_input.0.weight", 2 * d.mlp_ratio * D, D)
             self.sh[pre + "mlp_input.0.weight|g"] = torch.zeros(2 * d.mlp_ratio * D, D, device=dev, dtype=torch.bfloat16)
             reg(pre + "mlp_input.2.weight", D, d.mlp_ratio * D)
+
+    def _extra_shadows(self, reg) -> None:  # hook: shadows of further linears (subclasses)
+        pass
 
     def _src(self, name: str, shape: tuple[int, int]) -> Tensor:
         if name == "@mod":
@@ -317,6 +329,24 @@ class DiTEngine:
             c, s = rope_grid_tables(gh, gw, d.rope_axes_dim, d.rope_base)
             self._rope[(gh, gw)] = (c.to(dev), s.to(dev))
 
+    def _stem_fwd(self, x: Tensor, t: Tensor, y_eff: Tensor | None, x0: Tensor | None = None) -> Tensor:
+        """patch embedding into ``x0`` (default ws["x"][0]) and the conditioning path: time MLP (+ label row) -> SiLU -> the
+        stacked adaLN GEMM of every block and of the last layer.  Returns the modulation matrix bf16 [Bp, mod_rows]."""
+        d, w, sh = self.d, self.ws, self.sh
+        B, _, _, _, _, _, M, _, _ = self.geo
+        D, E = d.inner_dim, d.embedding_dim
+        ops.patchify(x, w["tokP"], d.patch_size, ops.PATCH_CPP)
+        ops.gemm_nt(w["tokP"], sh["conv_proj.weight|f"], w["x"][0] if x0 is None else x0, M=M, N=D, K=64)
+        ops.timestep_embedding(t, w["temb"][:B])
+        ops.gemm_nt(w["temb"], sh["time_embed.0.weight|f"], w["h1"], bias=self.P("time_embed.0.bias"), act=ops.ACT_SILU,
+                    pre_out=w["pre1"], M=B, N=E, K=d.frequency_embedding)
+        ops.gemm_nt(w["h1"], sh["time_embed.2.weight|f"], w["e"], bias=self.P("time_embed.2.bias"), M=B, N=E, K=E)
+        table = self.P("label_embed.embedding.weight") if d.n_classes is not None else None
+        ops.cond_combine_fwd(w["e"][:B], table, y_eff if table is not None else None, w["emb"][:B], w["se"][:B])
+        mod_bias = self.params[self.layout.entries[self.prefixes[0] + "modulation.lin.bias"][0] :][: self.layout.mod_rows]
+        ops.gemm_nt(w["se"], sh["@mod|f"], w["mod"], bias=mod_bias, M=B, N=self.layout.mod_rows, K=E)
+        return w["mod"]
+
     # ------------------------------------------------------------------ forward
     def forward(self, x: Tensor, t: Tensor, y_eff: Tensor | None, train: bool = True, refresh: bool = True) -> Tensor:
         """x f32 [B,C,H,W]; t f32 [B] (flow: in [0,1]; ddpm: indices as floats, both fed unscaled like the
@@ -336,19 +366,8 @@ class DiTEngine:
         self._train = train
         self._yeff = y_eff
 
-        # stem + conditioning
-        ops.patchify(x, w["tokP"], d.patch_size, ops.PATCH_CPP)
+        mod = self._stem_fwd(x, t, y_eff)
         xs = w["x"]
-        ops.gemm_nt(w["tokP"], sh["conv_proj.weight|f"], xs[0], M=M, N=D, K=64)
-        ops.timestep_embedding(t, w["temb"][:B])
-        ops.gemm_nt(w["temb"], sh["time_embed.0.weight|f"], w["h1"], bias=self.P("time_embed.0.bias"), act=ops.ACT_SILU,
-                    pre_out=w["pre1"], M=B, N=E, K=d.frequency_embedding)
-        ops.gemm_nt(w["h1"], sh["time_embed.2.weight|f"], w["e"], bias=self.P("time_embed.2.bias"), M=B, N=E, K=E)
-        table = self.P("label_embed.embedding.weight") if d.n_classes is not None else None
-        ops.cond_combine_fwd(w["e"][:B], table, y_eff if table is not None else None, w["emb"][:B], w["se"][:B])
-        mod_bias = self.params[self.layout.entries["layers.0.modulation.lin.bias"][0] :][: self.layout.mod_rows]
-        ops.gemm_nt(w["se"], sh["@mod|f"], w["mod"], bias=mod_bias, M=B, N=self.layout.mod_rows, K=E)
-        mod = w["mod"]
 
         # The gated residual of every sub-layer (x += gate * f(...)) is applied by the NEXT LayerNorm-modulate kernel, which
         # has to read the residual stream anyway: the projection / MLP-down GEMMs stay plain stores (fast 256x384 tiles)
@@ -504,6 +523,15 @@ class DiTEngine:
                 self.reducer.ready(*self.layer_ranges[i], extra_events=(side.record_event(),))
         main.wait_stream(side)
 
+        self._cond_bwd(dx)
+
+    def _cond_bwd(self, dx: Tensor) -> None:
+        """backward of _stem_fwd: dx = gradient of the patch-embedded tokens; the modulation gradient was accumulated in
+        ws["dmod32"] by the block kernels"""
+        d, w, sh = self.d, self.ws, self.sh
+        B, _, _, _, _, _, M, _, _ = self.geo
+        D, E = d.inner_dim, d.embedding_dim
+        dmod = w["dmod32"]
         # stem: conv_proj weight gradient (no gradient flows to the input latents)
         Fi = d.input_channels * d.patch_size**2
         gc = self.G("conv_proj.weight").view(D, Fi)
@@ -517,7 +545,7 @@ class DiTEngine:
         # conditioning path: every adaLN linear at once, then the time MLP and the label table
         R = self.layout.mod_rows
         g_modw = self.grads[self.layout.entries[self.mod_name][0] :][: R * E].view(R, E)
-        g_modb = self.grads[self.layout.entries["layers.0.modulation.lin.bias"][0] :][:R]
+        g_modb = self.grads[self.layout.entries[self.prefixes[0] + "modulation.lin.bias"][0] :][:R]
         ops.cast_f32_to_bf16(dmod[:B], w["dmod"][:B])
         dmod = w["dmod"]
         ops.gemm_tn(dmod, w["se"], g_modw)

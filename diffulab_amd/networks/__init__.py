@@ -1,3 +1,3 @@
-from .denoisers import Denoiser, MMDiT, ModelInput, ModelOutput
+from .denoisers import Denoiser, MMDiT, ModelInput, ModelOutput, SprintDiT
 
-__all__ = ["Denoiser", "MMDiT", "ModelInput", "ModelOutput"]
+__all__ = ["Denoiser", "MMDiT", "ModelInput", "ModelOutput", "SprintDiT"]
