@@ -2,6 +2,8 @@
     python scripts/train_step_bench.py cifar --batch 32     # configs/train_cifar10_flow_matching.yaml (dit.yaml dims, RGB 32x32)
     python scripts/train_step_bench.py s2 --batch 256       # the headline DiT-S/2 workload (same step as bench.py)
     python scripts/train_step_bench.py repa --batch 128     # DiT-B/REPA dims (768/12 heads/12 blocks, 32x8x8 latents) + REPA loss
+    python scripts/train_step_bench.py sprint --batch 32    # configs/model/sprint.yaml (512/8, 2+8+2 blocks, 75 % of the tokens skip the deep blocks)
+    python scripts/train_step_bench.py dit12 --batch 32     # the same 12 blocks without token dropping (what SPRINT is compared with)
     python scripts/train_step_bench.py repa_rs --batch 128  # same + the Perceiver resampler (configs/train_imagenet_flow_matching_repa.yaml)
 """
 import argparse
@@ -14,7 +16,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from diffulab_amd import Diffuser, MMDiT  # noqa: E402
+from diffulab_amd import Diffuser, MMDiT, SprintDiT  # noqa: E402
 from diffulab_amd.training import FusedAdamW  # noqa: E402
 from diffulab_amd.training.losses import RepaLoss  # noqa: E402
 
@@ -27,6 +29,10 @@ CFG = {
                   depth=12, n_classes=1000, classifier_free=True), (32, 8, 8)),
 }
 CFG["repa_rs"] = CFG["repa"]
+CFG["dit12"] = (dict(CFG["cifar"][0], depth=12), (3, 32, 32))
+SPRINT = dict(input_channels=3, output_channels=3, inner_dim=512, embedding_dim=512, num_heads=8, mlp_ratio=4, patch_size=2,
+              encoder_depth=2, deep_layers_depth=8, decoder_depth=2, n_classes=10, classifier_free=False, drop_rate=0.75)
+CFG["sprint"] = (SPRINT, (3, 32, 32))
 RS = dict(depth=3, dim=1024, head_dim=64, num_heads=8, ff_mult=4, num_latents=256)
 
 
@@ -40,7 +46,7 @@ def main() -> None:
     dev = "cuda"
     kw, shape = CFG[a.config]
     torch.manual_seed(0)
-    m = MMDiT(simple_dit=True, **kw).to(dev)
+    m = (SprintDiT if a.config == "sprint" else MMDiT)(simple_dit=True, **kw).to(dev)
     extra, params = [], list(m.parameters())
     if a.config.startswith("repa"):
         rs = a.config == "repa_rs"
