@@ -609,9 +609,59 @@ def gen_sprint() -> None:
     save("sprint", **o)
 
 
+# ------------------------------------------------------------------ (xii) MMDiT joint text-image blocks (simple_dit=False)
+JOINT_SMALL = dict(input_channels=4, output_channels=4, inner_dim=128, embedding_dim=64, num_heads=2, mlp_ratio=4, patch_size=2,
+                   depth=2, rope_axes_dim=[16, 24, 24], rope_base=2000, classifier_free=True)
+
+
+def gen_mmdit_joint() -> None:
+    """MMDiT(simple_dit=False) behind the reference PrecomputedEmbedder: 64 text tokens (ragged valid lengths) + 64 image tokens"""
+    import importlib
+    import tempfile
+
+    from oracle import mmdit as ommdit
+
+    PE = importlib.import_module("diffulab.networks.embedders.precomputed").PrecomputedEmbedder
+    Lc, Cd, B, H = 64, 96, 4, 16
+    null = synth.normal("mj.null", (1, Lc, Cd)) * 0.5
+    with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+        torch.save(null, f.name)
+        emb = PE(f.name, null_embedding_seq_len=7)
+    m = MMDiT(simple_dit=False, context_embedder=emb, **JOINT_SMALL)
+    cfg = ommdit.JointConfig(context_dim=Cd, **{k: v for k, v in JOINT_SMALL.items()})
+    shapes = ommdit.param_shapes(cfg)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == shapes, set(m.state_dict()) ^ set(shapes)
+    m.load_state_dict(synth.dit_params(shapes, seed=71))
+    x = synth.normal("mj.x", (B, 4, H, H))
+    t = synth.uniform("mj.t", (B,), lo=0.05, hi=0.95)
+    ctx = synth.normal("mj.ctx", (B, Lc, Cd))
+    keep = torch.arange(Lc)[None, :] < torch.tensor([64, 20, 41, 5])[:, None]
+    dy = synth.normal("mj.dy", (B, 4, H, H))
+    o = {}
+    m.train()
+    pred = m(x=x, timesteps=t, initial_context={"embeddings": ctx, "attn_mask": keep}, p=0.0)["x"]
+    o["a_pred"] = pred
+    (pred * dy).sum().backward()
+    for n, p in m.named_parameters():  # (the context branch of the LAST block feeds nothing: those gradients are None)
+        if p.grad is not None:
+            o["a_g_" + n] = p.grad.clone()
+    m.zero_grad()
+    torch.manual_seed(2)
+    with _RandRecorder() as r:
+        pred = m(x=x, timesteps=t, initial_context={"embeddings": ctx, "attn_mask": keep}, p=0.5)["x"]
+    assert [tuple(d.shape) for d in r.draws] == [(B,)] and 0 < int((r.draws[0] < 0.5).sum()) < B, r.draws
+    o["b_u"], o["b_pred"] = r.draws[0], pred
+    m.eval()
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=4)
+    out = d.generate({"x": synth.normal("mj.init", (B, 4, H, H)), "initial_context": {"embeddings": ctx, "attn_mask": keep}},
+                     use_tqdm=False, guidance_scale=2.0)
+    o["e_loop_x"] = out["x"]
+    save("mmdit_joint", **o)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve", "repa", "resampler", "sprint"]
-    fns = {"repa": gen_repa, "resampler": gen_resampler, "sprint": gen_sprint, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
+    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve", "repa", "resampler", "sprint", "mmdit_joint"]
+    fns = {"repa": gen_repa, "resampler": gen_resampler, "sprint": gen_sprint, "mmdit_joint": gen_mmdit_joint, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
            "s2": gen_s2_model, "samplers": gen_samplers, "curve": gen_loss_curve, "unet": gen_unet}
     for w in which:
         print("==", w)
