@@ -393,7 +393,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(const bf16_t* __restri
                                                           const float* __restrict__ sn, bf16_t* __restrict__ qo,
                                                           bf16_t* __restrict__ ko, bf16_t* __restrict__ vo,
                                                           float* __restrict__ rrms, int64_t M, int N, int H, int dh,
-                                                          int rot, float eps, const int* __restrict__ pos) {
+                                                          int rot, float eps, const int* __restrict__ pos, int n_dst,
+                                                          int n_off) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D = H * dh, D8 = D >> 3;
   const float invD = 1.0f / (float)D;
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(const bf16_t* __restri
           k[j][2 * i + 1] = ka * ss[i] + kb * cc[i];
         }
       }
-      const int64_t o = (((int64_t)b * H + h) * N + n) * dh + d0;
+      const int64_t o = (((int64_t)b * H + h) * n_dst + n_off + n) * dh + d0;
       *(u32x4_t*)(qo + o) = pack8(q[j]);
       *(u32x4_t*)(ko + o) = pack8(k[j]);
       *(u32x4_t*)(vo + o) = pack8(v[j]);
@@ -454,17 +455,21 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(const bf16_t* __restri
 
 extern "C" int dl_qk_norm_rope_fwd_ex(const void* qkv, const float* scale_q, const float* scale_k, const float* cos,
                                       const float* sin, void* q, void* k, void* v, float* rrms, int64_t B, int64_t N,
-                                      int64_t H, int64_t dh, int64_t rot, float eps, const int32_t* pos, dl_stream_t stream);
+                                      int64_t H, int64_t dh, int64_t rot, float eps, const int32_t* pos, int64_t n_dst,
+                                      int64_t n_off, dl_stream_t stream);
 extern "C" int dl_qk_norm_rope_fwd(const void* qkv, const float* scale_q, const float* scale_k, const float* cos,
                                    const float* sin, void* q, void* k, void* v, float* rrms, int64_t B, int64_t N,
                                    int64_t H, int64_t dh, int64_t rot, float eps, dl_stream_t stream) {
-  return dl_qk_norm_rope_fwd_ex(qkv, scale_q, scale_k, cos, sin, q, k, v, rrms, B, N, H, dh, rot, eps, nullptr, stream);
+  return dl_qk_norm_rope_fwd_ex(qkv, scale_q, scale_k, cos, sin, q, k, v, rrms, B, N, H, dh, rot, eps, nullptr, N, 0, stream);
 }
 extern "C" int dl_qk_norm_rope_fwd_ex(const void* qkv, const float* scale_q, const float* scale_k, const float* cos,
                                       const float* sin, void* q, void* k, void* v, float* rrms, int64_t B, int64_t N,
-                                      int64_t H, int64_t dh, int64_t rot, float eps, const int32_t* pos, dl_stream_t stream) {
+                                      int64_t H, int64_t dh, int64_t rot, float eps, const int32_t* pos, int64_t n_dst,
+                                      int64_t n_off, dl_stream_t stream) {
   DL_CHECK_ARG(qkv && scale_q && scale_k && cos && sin && q && k && v && rrms && B > 0 && N > 0,
                "dl_qk_norm_rope_fwd: null operand");
+  DL_CHECK_ARG(n_off >= 0 && n_off + N <= n_dst, "dl_qk_norm_rope_fwd: row window [%lld, %lld) outside n_dst=%lld",
+               (long long)n_off, (long long)(n_off + N), (long long)n_dst);
   const int64_t D = H * dh;
   DL_CHECK_ARG(dh % 8 == 0 && rot % 8 == 0 && rot <= dh && D <= 512 * MAXJ, "dl_qk_norm_rope_fwd: dh=%lld rot=%lld",
                (long long)dh, (long long)rot);
@@ -474,7 +479,8 @@ extern "C" int dl_qk_norm_rope_fwd_ex(const void* qkv, const float* scale_q, con
   const int nj = cdiv(D, 512);
 #define LAUNCH(NJ)                                                                                                  \
   hipLaunchKernelGGL(qk_norm_rope_fwd_k<NJ>, grid, 256, 0, (hipStream_t)stream, (const bf16_t*)qkv, scale_q, scale_k, \
-                     cos, sin, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, rrms, M, (int)N, (int)H, (int)dh, (int)rot, eps, pos)
+                     cos, sin, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, rrms, M, (int)N, (int)H, (int)dh, (int)rot, eps, pos,      \
+                     (int)n_dst, (int)n_off)
   if (nj == 1) LAUNCH(1);
   else LAUNCH(2);
 #undef LAUNCH
@@ -491,7 +497,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(const bf16_t* __restri
                                                           const float* __restrict__ cs, const float* __restrict__ sn,
                                                           const float* __restrict__ rrms, bf16_t* __restrict__ dqkv,
                                                           float* __restrict__ dscale, int64_t M, int N, int H, int dh,
-                                                          int rot, const int* __restrict__ pos) {
+                                                          int rot, const int* __restrict__ pos, int n_dst, int n_off) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = (float*)smem;  // [4 waves][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(const bf16_t* __restri
         continue;
       }
       const int col = c * 8, h = col / dh, d0 = col - h * dh;
-      const int64_t o = (((int64_t)b * H + h) * N + n) * dh + d0;
+      const int64_t o = (((int64_t)b * H + h) * n_dst + n_off + n) * dh + d0;
       unpack8(*(const u32x4_t*)(dq + o), gq[j]);
       unpack8(*(const u32x4_t*)(dk + o), gk[j]);
       unpack8(*(const u32x4_t*)(dv + o), gv[j]);
@@ -583,21 +589,22 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(const bf16_t* __restri
 extern "C" int dl_qk_norm_rope_bwd_ex(const void* dq, const void* dk, const void* dv, const void* qkv,
                                    const float* scale_q, const float* scale_k, const float* cos, const float* sin,
                                    const float* rrms, void* dqkv, float* dscale, int64_t B, int64_t N, int64_t H,
-                                   int64_t dh, int64_t rot, const int32_t* pos, dl_stream_t stream);
+                                   int64_t dh, int64_t rot, const int32_t* pos, int64_t n_dst, int64_t n_off, dl_stream_t stream);
 extern "C" int dl_qk_norm_rope_bwd(const void* dq, const void* dk, const void* dv, const void* qkv,
                                    const float* scale_q, const float* scale_k, const float* cos, const float* sin,
                                    const float* rrms, void* dqkv, float* dscale, int64_t B, int64_t N, int64_t H,
                                    int64_t dh, int64_t rot, dl_stream_t stream) {
-  return dl_qk_norm_rope_bwd_ex(dq, dk, dv, qkv, scale_q, scale_k, cos, sin, rrms, dqkv, dscale, B, N, H, dh, rot, nullptr, stream);
+  return dl_qk_norm_rope_bwd_ex(dq, dk, dv, qkv, scale_q, scale_k, cos, sin, rrms, dqkv, dscale, B, N, H, dh, rot, nullptr, N, 0, stream);
 }
 extern "C" int dl_qk_norm_rope_bwd_ex(const void* dq, const void* dk, const void* dv, const void* qkv,
                                    const float* scale_q, const float* scale_k, const float* cos, const float* sin,
                                    const float* rrms, void* dqkv, float* dscale, int64_t B, int64_t N, int64_t H,
-                                   int64_t dh, int64_t rot, const int32_t* pos, dl_stream_t stream) {
+                                   int64_t dh, int64_t rot, const int32_t* pos, int64_t n_dst, int64_t n_off, dl_stream_t stream) {
   DL_CHECK_ARG(dq && dk && dv && qkv && scale_q && scale_k && cos && sin && rrms && dqkv && dscale && B > 0 && N > 0,
                "dl_qk_norm_rope_bwd: null operand");
   const int64_t D = H * dh;
-  DL_CHECK_ARG(dh % 8 == 0 && rot % 8 == 0 && rot <= dh && D <= 512 * MAXJ, "dl_qk_norm_rope_bwd: bad dims");
+  DL_CHECK_ARG(dh % 8 == 0 && rot % 8 == 0 && rot <= dh && D <= 512 * MAXJ && n_off >= 0 && n_off + N <= n_dst,
+               "dl_qk_norm_rope_bwd: bad dims");
   const int64_t M = B * N;
   int grid = cdiv(M, 4 * 16);  // >= 16 rows per wave so the atomics are amortised
   if (grid > 1024) grid = 1024;
@@ -607,7 +614,7 @@ extern "C" int dl_qk_norm_rope_bwd_ex(const void* dq, const void* dk, const void
 #define LAUNCH(NJ)                                                                                                   \
   hipLaunchKernelGGL(qk_norm_rope_bwd_k<NJ>, grid, 256, lds, (hipStream_t)stream, (const bf16_t*)dq, (const bf16_t*)dk, \
                      (const bf16_t*)dv, (const bf16_t*)qkv, scale_q, scale_k, cos, sin, rrms, (bf16_t*)dqkv, dscale, M, \
-                     (int)N, (int)H, (int)dh, (int)rot, pos)
+                     (int)N, (int)H, (int)dh, (int)rot, pos, (int)n_dst, (int)n_off)
   if (nj == 1) LAUNCH(1);
   else LAUNCH(2);
 #undef LAUNCH

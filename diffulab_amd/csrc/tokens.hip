@@ -87,6 +87,16 @@ __global__ void gated_residual_k(const bf16_t* __restrict__ x, const bf16_t* __r
   }
 }
 
+__global__ void copy_rows3d_k(const bf16_t* __restrict__ src, int64_t sbs, int64_t srs, bf16_t* __restrict__ dst, int64_t dbs,
+                              int64_t drs, int rows, int C8, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8);
+    const int64_t br = i / C8;
+    const int64_t b = br / rows, r = br - b * rows;
+    *(u32x4_t*)(dst + b * dbs + r * drs + c * 8) = *(const u32x4_t*)(src + b * sbs + r * srs + c * 8);
+  }
+}
+
 static inline int row_grid(int64_t total) {
   int64_t g = (total + 255) / 256;
   return (int)(g > 8192 ? 8192 : g);
@@ -145,6 +155,17 @@ extern "C" int dl_gated_residual_fwd(const void* x, const void* t, const void* g
   const int64_t total = M * (D / 8);
   hipLaunchKernelGGL(gated_residual_k, row_grid(total), 256, 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)t,
                      (const bf16_t*)gate, ld_gate, rows_per_mod, (bf16_t*)out, ld_out, (int)(D / 8), total);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_copy_rows3d(const void* src, int64_t src_bs, int64_t src_rs, void* dst, int64_t dst_bs, int64_t dst_rs,
+                              int64_t B, int64_t rows, int64_t cols, dl_stream_t stream) {
+  DL_CHECK_ARG(src && dst && B > 0 && rows > 0 && cols > 0 && cols % 8 == 0 && src_bs % 8 == 0 && src_rs % 8 == 0 &&
+                   dst_bs % 8 == 0 && dst_rs % 8 == 0 && src_rs >= cols && dst_rs >= cols && ALIGNED16(src) && ALIGNED16(dst),
+               "dl_copy_rows3d: bad args");
+  const int64_t total = B * rows * (cols / 8);
+  hipLaunchKernelGGL(copy_rows3d_k, row_grid(total), 256, 0, (hipStream_t)stream, (const bf16_t*)src, src_bs, src_rs,
+                     (bf16_t*)dst, dst_bs, dst_rs, (int)rows, (int)(cols / 8), total);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

@@ -118,6 +118,8 @@ class ParamLayout:
             add(pre + "modulation.lin.bias", (6 * D,), align=1 if i else 64)
         add("last_layer.adaLN_modulation.1.bias", (2 * D,), align=1)
         self.mod_rows = nb * 6 * D + 2 * D
+        self.mod_w0, self.mod_b0 = prefixes[0] + "modulation.lin.weight", prefixes[0] + "modulation.lin.bias"
+        self.block_first = [pre + "norm_1.weight" for pre in prefixes]
         if d.n_classes is not None:
             add("label_embed.embedding.weight", (d.n_classes + (1 if d.classifier_free else 0), E))
         add("time_embed.0.weight", (E, d.frequency_embedding))
@@ -166,7 +168,7 @@ class DiTEngine:
         self.reducer = None  # optional training.dp.GradReducer: gets ready(lo, hi) as gradient ranges complete
         self._build_shadows()
         ent = self.layout.entries
-        starts = [ent[pre + "norm_1.weight"][0] for pre in self.prefixes] + [self.layout.size]
+        starts = [ent[n][0] for n in self.layout.block_first] + [self.layout.size]
         self.layer_ranges = [(starts[i], starts[i + 1]) for i in range(len(self.prefixes))]
 
     def _make_layout(self, dims: DiTDims) -> ParamLayout:
@@ -201,7 +203,7 @@ class DiTEngine:
                 self.sh[t] = torch.zeros(C, _rup(R, 64), device=dev, dtype=torch.bfloat16)
             self._casts.append((name, (R, C), f, t))
 
-        self.mod_name = self.prefixes[0] + "modulation.lin.weight"  # start of the stacked [mod_rows, E] matrix
+        self.mod_name = self.layout.mod_w0  # start of the stacked [mod_rows, E] matrix
         reg("@mod", self.layout.mod_rows, E)
         reg("time_embed.0.weight", E, d.frequency_embedding, dgrad=False)
         reg("time_embed.2.weight", E, E)
@@ -209,11 +211,16 @@ class DiTEngine:
         reg("last_layer.linear.weight", d.patch_size**2 * d.output_channels, D)
         self._extra_shadows(reg)
         for pre in self.prefixes:
-            reg(pre + "attention.qkv.weight", 3 * D, D)
-            reg(pre + "attention.proj_out.weight", D, D)
-            reg(pre + "mlp_input.0.weight", 2 * d.mlp_ratio * D, D)
-            self.sh[pre + "mlp_input.0.weight|g"] = torch.zeros(2 * d.mlp_ratio * D, D, device=dev, dtype=torch.bfloat16)
-            reg(pre + "mlp_input.2.weight", D, d.mlp_ratio * D)
+            self._block_shadows(reg, pre)
+
+    def _block_shadows(self, reg, pre: str) -> None:
+        d, dev = self.d, self.dev
+        D = d.inner_dim
+        reg(pre + "attention.qkv.weight", 3 * D, D)
+        reg(pre + "attention.proj_out.weight", D, D)
+        reg(pre + "mlp_input.0.weight", 2 * d.mlp_ratio * D, D)
+        self.sh[pre + "mlp_input.0.weight|g"] = torch.zeros(2 * d.mlp_ratio * D, D, device=dev, dtype=torch.bfloat16)
+        reg(pre + "mlp_input.2.weight", D, d.mlp_ratio * D)
 
     def _extra_shadows(self, reg) -> None:  # hook: shadows of further linears (subclasses)
         pass
@@ -343,7 +350,7 @@ class DiTEngine:
         ops.gemm_nt(w["h1"], sh["time_embed.2.weight|f"], w["e"], bias=self.P("time_embed.2.bias"), M=B, N=E, K=E)
         table = self.P("label_embed.embedding.weight") if d.n_classes is not None else None
         ops.cond_combine_fwd(w["e"][:B], table, y_eff if table is not None else None, w["emb"][:B], w["se"][:B])
-        mod_bias = self.params[self.layout.entries[self.prefixes[0] + "modulation.lin.bias"][0] :][: self.layout.mod_rows]
+        mod_bias = self.params[self.layout.entries[self.layout.mod_b0][0] :][: self.layout.mod_rows]
         ops.gemm_nt(w["se"], sh["@mod|f"], w["mod"], bias=mod_bias, M=B, N=self.layout.mod_rows, K=E)
         return w["mod"]
 
@@ -545,7 +552,7 @@ class DiTEngine:
         # conditioning path: every adaLN linear at once, then the time MLP and the label table
         R = self.layout.mod_rows
         g_modw = self.grads[self.layout.entries[self.mod_name][0] :][: R * E].view(R, E)
-        g_modb = self.grads[self.layout.entries[self.prefixes[0] + "modulation.lin.bias"][0] :][:R]
+        g_modb = self.grads[self.layout.entries[self.layout.mod_b0][0] :][:R]
         ops.cast_f32_to_bf16(dmod[:B], w["dmod"][:B])
         dmod = w["dmod"]
         ops.gemm_tn(dmod, w["se"], g_modw)

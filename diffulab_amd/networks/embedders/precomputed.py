@@ -1,0 +1,41 @@
+"""``PrecomputedEmbedder`` -- drop-in for ``diffulab.networks.embedders.precomputed.PrecomputedEmbedder``
+(embedders/precomputed.py:8-43): the text embeddings arrive precomputed with the batch; classifier-free dropping replaces a
+sample's embeddings and mask by a stored null embedding.  Host-side torch ops on a [B] draw and a select of small tensors; the
+denoiser's HIP engine consumes the result."""
+
+from __future__ import annotations
+
+from pathlib import Path
+
+import torch
+from torch import Tensor
+
+from .common import ContextEmbedder, ContextEmbedderOutput
+
+
+class PrecomputedEmbedder(ContextEmbedder):
+    def __init__(self, path_null_embedding: Path | str | Tensor, null_embedding_seq_len: int) -> None:
+        """path_null_embedding: file written by ``torch.save`` (as in the reference); a tensor is accepted too"""
+        super().__init__()
+        null = path_null_embedding if isinstance(path_null_embedding, Tensor) else torch.load(path_null_embedding)
+        self.null_embedding = null.squeeze()
+        L = self.null_embedding.shape[0]
+        self.null_embedding_mask = torch.arange(L) < null_embedding_seq_len
+        self._output_size = (self.null_embedding.shape[-1],)
+        self._n_output = 1
+
+    def _draw_drop(self, batch_size: int, p: float, device: torch.device) -> Tensor:
+        return torch.rand(batch_size, device=device) < p  # precomputed.py:27
+
+    def drop_conditions(self, context: ContextEmbedderOutput, p: float) -> ContextEmbedderOutput:
+        emb = context["embeddings"]
+        B, device, dtype = emb.shape[0], emb.device, emb.dtype
+        drop = self._draw_drop(B, p, device)
+        null_emb = self.null_embedding.to(device=device, dtype=dtype)
+        null_mask = self.null_embedding_mask.to(device=device)
+        embeddings = torch.where(drop[:, None, None], null_emb.unsqueeze(0).expand(B, -1, -1), emb)
+        attn_mask = torch.where(drop[:, None], null_mask.unsqueeze(0).expand(B, -1), context["attn_mask"])
+        return {"embeddings": embeddings, "attn_mask": attn_mask}
+
+    def forward(self, context: ContextEmbedderOutput, p: float = 0) -> ContextEmbedderOutput:
+        return self.drop_conditions(context, p)

@@ -190,15 +190,21 @@ def gate_bwd(dout, t, gate, rows_per_mod, dt, dgate):
           D, _s())
 
 
-def qk_norm_rope_fwd(qkv, scale_q, scale_k, cos, sin, q, k, v, rrms, B, N, H, dh, rot, eps=1e-6, pos=None):
-    """pos: int32 [B*N] table row of every token (None: its index in the sequence)"""
+def qk_norm_rope_fwd(qkv, scale_q, scale_k, cos, sin, q, k, v, rrms, B, N, H, dh, rot, eps=1e-6, pos=None, n_off=0):
+    """pos: int32 [B*N] table row of every token (None: its index in the sequence); q / k / v are [B, H, n_dst, dh] and the N
+    tokens are written to rows [n_off, n_off + N)"""
     _call("dl_qk_norm_rope_fwd_ex", _p(qkv), _p(scale_q), _p(scale_k), _p(cos), _p(sin), _p(q), _p(k), _p(v), _p(rrms), B, N,
-          H, dh, rot, float(eps), _p(pos), _s())
+          H, dh, rot, float(eps), _p(pos), q.shape[2], n_off, _s())
 
 
-def qk_norm_rope_bwd(dq, dk, dv, qkv, scale_q, scale_k, cos, sin, rrms, dqkv, dscale, B, N, H, dh, rot, pos=None):
+def qk_norm_rope_bwd(dq, dk, dv, qkv, scale_q, scale_k, cos, sin, rrms, dqkv, dscale, B, N, H, dh, rot, pos=None, n_off=0):
     _call("dl_qk_norm_rope_bwd_ex", _p(dq), _p(dk), _p(dv), _p(qkv), _p(scale_q), _p(scale_k), _p(cos), _p(sin), _p(rrms),
-          _p(dqkv), _p(dscale), B, N, H, dh, rot, _p(pos), _s())
+          _p(dqkv), _p(dscale), B, N, H, dh, rot, _p(pos), dq.shape[2], n_off, _s())
+
+
+def copy_rows3d(src, src_bs, src_rs, dst, dst_bs, dst_rs, B, rows, cols):
+    """dst[b, r, :cols] = src[b, r, :cols] with explicit batch / row strides (elements); src / dst may be offset views"""
+    _call("dl_copy_rows3d", _p(src), src_bs, src_rs, _p(dst), dst_bs, dst_rs, B, rows, cols, _s())
 
 
 # ------------------------------------------------------------------ SPRINT token routing

@@ -171,16 +171,20 @@ DL_API int dl_qk_norm_rope_bwd(const void* dq, const void* dk, const void* dv, c
                                const float* scale_q, const float* scale_k, const float* cos, const float* sin,
                                const float* rrms, void* dqkv, float* dscale, int64_t B, int64_t N, int64_t H,
                                int64_t dh, int64_t rot, dl_stream_t stream);
-/* same with an optional position index: pos int32 [B*N] gives the cos/sin table row of every token (NULL: row = n).  SPRINT
+/* same with (a) an optional position index: pos int32 [B*N] gives the cos/sin table row of every token (NULL: row = n) -- SPRINT
  * runs its deep blocks on a per-sample subset of the image tokens whose RoPE rows are gathered with the kept indices
- * (sprint.py:348-353); the index replaces the gathered [B, k, rot/2] tables. */
+ * (sprint.py:348-353); the index replaces the gathered [B, k, rot/2] tables -- and (b) a row window: q, k, v are
+ * [B, H, n_dst, dh] and the N tokens go to rows [n_off, n_off + N) -- the joint text-image attention concatenates the context
+ * and image tokens along the sequence (mmdit.py:181-185); each stream writes its window of the joint buffers. */
 DL_API int dl_qk_norm_rope_fwd_ex(const void* qkv, const float* scale_q, const float* scale_k, const float* cos,
                                   const float* sin, void* q, void* k, void* v, float* rrms, int64_t B, int64_t N,
-                                  int64_t H, int64_t dh, int64_t rot, float eps, const int32_t* pos, dl_stream_t stream);
+                                  int64_t H, int64_t dh, int64_t rot, float eps, const int32_t* pos, int64_t n_dst,
+                                  int64_t n_off, dl_stream_t stream);
 DL_API int dl_qk_norm_rope_bwd_ex(const void* dq, const void* dk, const void* dv, const void* qkv,
                                   const float* scale_q, const float* scale_k, const float* cos, const float* sin,
                                   const float* rrms, void* dqkv, float* dscale, int64_t B, int64_t N, int64_t H,
-                                  int64_t dh, int64_t rot, const int32_t* pos, dl_stream_t stream);
+                                  int64_t dh, int64_t rot, const int32_t* pos, int64_t n_dst, int64_t n_off,
+                                  dl_stream_t stream);
 /* F.scaled_dot_product_attention mmdit.py:92-100, no mask: out = softmax(q k^T * scale) v, written as
  * 'b h n d -> b n (h d)'.  lse f32 [B,H,N] = natural-log-sum-exp of the scaled scores (for the backward).
  * dh must be 64; N a multiple of 64 up to 256 (K and V of one head stay resident in LDS), or a multiple of 256 up to 2048
@@ -265,6 +269,10 @@ DL_API int dl_restore_tokens(const void* xd, int64_t ld_xd, const int32_t* inv, 
 /* gradient of the mask token: out[c] += sum over rows with sel[row] < 0 of x[row, c] (x bf16, out f32) */
 DL_API int dl_masked_colsum(const void* x, int64_t ld, const int32_t* sel, float* out, int64_t R, int64_t C,
                             dl_stream_t stream);
+/* strided row-block copy: dst[b, r, 0:cols] = src[b, r, 0:cols] for b < B, r < rows, with independent batch / row strides
+ * (elements) on both sides -- slices the [context ; image] halves out of / into the joint attention buffers (mmdit.py:207-208) */
+DL_API int dl_copy_rows3d(const void* src, int64_t src_bs, int64_t src_rs, void* dst, int64_t dst_bs, int64_t dst_rs, int64_t B,
+                          int64_t rows, int64_t cols, dl_stream_t stream);
 /* x + gate * t materialised (mmdit.py:302,308 at a stage boundary, where no LayerNorm follows to absorb it); gate rows as in
  * dl_ln_modulate_fwd */
 DL_API int dl_gated_residual_fwd(const void* x, const void* t, const void* gate, int64_t ld_gate, int64_t rows_per_mod,

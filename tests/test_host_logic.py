@@ -102,8 +102,20 @@ def test_module_contract_and_layout():
     m2 = copy.deepcopy(m)
     assert m2._engine is None and torch.equal(m2.conv_proj.weight, m.conv_proj.weight)
     # unsupported reference modes fail loudly, never silently fall back
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError):  # the reference's own assertion (mmdit.py:642): joint blocks need a context embedder
         MMDiT(simple_dit=False)
+    from diffulab_amd.networks.embedders import PrecomputedEmbedder
+
+    emb = PrecomputedEmbedder(torch.zeros(1, 16, 96), null_embedding_seq_len=3)
+    assert emb.n_output == 1 and emb.output_size == (96,) and int(emb.null_embedding_mask.sum()) == 3
+    jkw = dict(simple_dit=False, context_embedder=emb, input_channels=4, inner_dim=128, embedding_dim=64, num_heads=2, patch_size=2,
+               depth=2, rope_axes_dim=[16, 24, 24])
+    mj = MMDiT(**jkw)
+    assert mj.context_embed.weight.shape == (128, 96) and hasattr(mj.layers[0], "modulation_context")
+    with pytest.raises(NotImplementedError):  # single-stream blocks and the default odd 3-axis split (64 // 3 = 21) are not built
+        MMDiT(**{**jkw, "n_single_stream_blocks": 1})
+    with pytest.raises(NotImplementedError):
+        MMDiT(**{**jkw, "rope_axes_dim": None})
     with pytest.raises(NotImplementedError):
         DiTDims(inner_dim=384, num_heads=4).validate()
     with pytest.raises(RuntimeError):
