@@ -154,6 +154,8 @@ class DiTEngine:
         dims.validate()
         self.d = dims
         self.dev = torch.device(device)
+        self._ki = _rup(dims.input_channels * dims.patch_size**2, 64)   # K of the patch-embedding GEMM (zero-padded)
+        self._ko = _rup(dims.output_channels * dims.patch_size**2, 64)  # K of the last linear's data gradient
         self.layout = self._make_layout(dims)
         self.prefixes = self.layout.prefixes
         self.params: Tensor | None = None
@@ -284,7 +286,7 @@ class DiTEngine:
                 return torch.zeros(*shape, device=dev, dtype=dtype)
 
         w: dict[str, object] = {}
-        w["tokP"] = z(M, 64)                      # patchified input, K padded to 64
+        w["tokP"] = z(M, self._ki)                      # patchified input, K padded to 64
         w["temb"] = z(Bp, d.frequency_embedding)
         w["pre1"] = z(Bp, E)
         w["h1"] = z(Bp, E)
@@ -309,7 +311,7 @@ class DiTEngine:
         w["otok"] = z(M, _rup(Fo, 8), dtype=f32)
         w["pred"] = z(B, d.output_channels, H, W, dtype=f32)
         if train:
-            w["dO"] = z(M, 64)
+            w["dO"] = z(M, self._ko)
             w["dxa"], w["dxb"] = z(M, D), z(M, D)
             w["dxm"], w["da"] = z(M, D), z(M, D)
             w["dh"] = z(M, d.mlp_ratio * D)
@@ -326,7 +328,7 @@ class DiTEngine:
             w["dh1"] = z(Bp, E, dtype=f32)
             w["dpre1"] = z(Bp, E)
             w["scr_last"] = z(_rup(Fo, 8), D, dtype=f32)
-            w["scr_conv"] = z(D, 64, dtype=f32)
+            w["scr_conv"] = z(D, self._ki, dtype=f32)
         self.ws, self._ws_key = w, key
         self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)
         if len(self._ws_cache) >= 8:  # bound the cache: drop the oldest shape (its graphs are dropped by the module too)
@@ -343,7 +345,7 @@ class DiTEngine:
         B, _, _, _, _, _, M, _, _ = self.geo
         D, E = d.inner_dim, d.embedding_dim
         ops.patchify(x, w["tokP"], d.patch_size, ops.PATCH_CPP)
-        ops.gemm_nt(w["tokP"], sh["conv_proj.weight|f"], w["x"][0] if x0 is None else x0, M=M, N=D, K=64)
+        ops.gemm_nt(w["tokP"], sh["conv_proj.weight|f"], w["x"][0] if x0 is None else x0, M=M, N=D, K=self._ki)
         ops.timestep_embedding(t, w["temb"][:B])
         ops.gemm_nt(w["temb"], sh["time_embed.0.weight|f"], w["h1"], bias=self.P("time_embed.0.bias"), act=ops.ACT_SILU,
                     pre_out=w["pre1"], M=B, N=E, K=d.frequency_embedding)
@@ -449,7 +451,7 @@ class DiTEngine:
             ops.gemm_tn(w["dO"], w["xf"], w["scr_last"], M=Fo8, N=D)
             ops.reduce_rows_f32(w["scr_last"], gl, 1, Fo * D)
         ops.colsum(w["dO"], self.G("last_layer.linear.bias"), M, Fo)
-        ops.gemm_nt(w["dO"], sh["last_layer.linear.weight|t"], w["dxm"], M=M, N=D, K=64)
+        ops.gemm_nt(w["dO"], sh["last_layer.linear.weight|t"], w["dxm"], M=M, N=D, K=self._ko)
         mo = L * 6 * D
         dx, dx_alt = w["dxa"], w["dxb"]
         # every LayerNorm-modulate backward also runs the backward of the gated residual that follows it in the chain

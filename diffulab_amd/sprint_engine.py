@@ -87,7 +87,7 @@ class SprintEngine(DiTEngine):
             with torch.inference_mode(False):
                 return torch.zeros(*shape, device=dev, dtype=dtype)
 
-        w: dict[str, object] = {"tokP": z(M, 64), "temb": z(Bp, d.frequency_embedding), "pre1": z(Bp, E), "h1": z(Bp, E),
+        w: dict[str, object] = {"tokP": z(M, self._ki), "temb": z(Bp, d.frequency_embedding), "pre1": z(Bp, E), "h1": z(Bp, E),
                                 "e": z(Bp, E, dtype=f32), "emb": z(Bp, E, dtype=f32), "se": z(Bp, E),
                                 "mod": z(Bp, self.layout.mod_rows)}
         ne, nd = d.encoder_depth, d.deep_layers_depth
@@ -114,7 +114,7 @@ class SprintEngine(DiTEngine):
         w["otok"] = z(M, _rup(Fo, 8), dtype=f32)
         w["pred"] = z(B, d.output_channels, H, W, dtype=f32)
         if train:
-            w["dO"] = z(M, 64)
+            w["dO"] = z(M, self._ko)
             for nt in {N, k}:  # chain scratch per token count
                 mt = B * nt
                 w[f"s{nt}"] = {"dxa": z(mt, D), "dxb": z(mt, D), "dxm": z(mt, D), "da": z(mt, D), "dh": z(mt, F),
@@ -124,7 +124,7 @@ class SprintEngine(DiTEngine):
             w["dmod32"] = z(Bp, self.layout.mod_rows, dtype=f32)
             w["dse"], w["demb"], w["demb16"] = z(Bp, E, dtype=f32), z(Bp, E, dtype=f32), z(Bp, E)
             w["dh1"], w["dpre1"] = z(Bp, E, dtype=f32), z(Bp, E)
-            w["scr_last"], w["scr_conv"] = z(_rup(Fo, 8), D, dtype=f32), z(D, 64, dtype=f32)
+            w["scr_last"], w["scr_conv"] = z(_rup(Fo, 8), D, dtype=f32), z(D, self._ki, dtype=f32)
         self.ws, self._ws_key = w, key
         self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)
         if len(self._ws_cache) >= 8:
@@ -309,7 +309,7 @@ class SprintEngine(DiTEngine):
             ops.gemm_tn(w["dO"], w["xf"], w["scr_last"], M=Fo8, N=D)
             ops.reduce_rows_f32(w["scr_last"], gl, 1, Fo * D)
         ops.colsum(w["dO"], self.G("last_layer.linear.bias"), M, Fo)
-        ops.gemm_nt(w["dO"], sh["last_layer.linear.weight|t"], sN["dxm"], M=M, N=D, K=64)
+        ops.gemm_nt(w["dO"], sh["last_layer.linear.weight|t"], sN["dxm"], M=M, N=D, K=self._ko)
         mo = L * 6 * D
         ops.ln_modulate_bwd(sN["dxm"], w["xdec"], None, None, mod[:, mo : mo + D], N, w["meanf"], w["rstdf"], None, sN["dxa"],
                             dmod[:, mo : mo + D], dmod[:, mo + D : mo + 2 * D], None)

@@ -4,6 +4,8 @@
     python scripts/train_step_bench.py repa --batch 128     # DiT-B/REPA dims (768/12 heads/12 blocks, 32x8x8 latents) + REPA loss
     python scripts/train_step_bench.py sprint --batch 32    # configs/model/sprint.yaml (512/8, 2+8+2 blocks, 75 % of the tokens skip the deep blocks)
     python scripts/train_step_bench.py dit12 --batch 32     # the same 12 blocks without token dropping (what SPRINT is compared with)
+    python scripts/train_step_bench.py joint --batch 16     # joint text-image MMDiT: 768/12 heads, 12 MMDiTBlocks, 128x32x32 latents at patch 1
+                                                            # (1024 image tokens) + 128 text tokens of width 1024, ragged key mask
     python scripts/train_step_bench.py repa_rs --batch 128  # same + the Perceiver resampler (configs/train_imagenet_flow_matching_repa.yaml)
 """
 import argparse
@@ -33,6 +35,9 @@ CFG["dit12"] = (dict(CFG["cifar"][0], depth=12), (3, 32, 32))
 SPRINT = dict(input_channels=3, output_channels=3, inner_dim=512, embedding_dim=512, num_heads=8, mlp_ratio=4, patch_size=2,
               encoder_depth=2, deep_layers_depth=8, decoder_depth=2, n_classes=10, classifier_free=False, drop_rate=0.75)
 CFG["sprint"] = (SPRINT, (3, 32, 32))
+JOINT = dict(input_channels=128, output_channels=128, inner_dim=768, embedding_dim=768, num_heads=12, mlp_ratio=4, patch_size=1,
+             depth=12, classifier_free=True, rope_base=2000, rope_axes_dim=[16, 24, 24])
+CFG["joint"] = (JOINT, (128, 32, 32))
 RS = dict(depth=3, dim=1024, head_dim=64, num_heads=8, ff_mult=4, num_latents=256)
 
 
@@ -46,7 +51,16 @@ def main() -> None:
     dev = "cuda"
     kw, shape = CFG[a.config]
     torch.manual_seed(0)
-    m = (SprintDiT if a.config == "sprint" else MMDiT)(simple_dit=True, **kw).to(dev)
+    ctx = None
+    if a.config == "joint":
+        from diffulab_amd.networks.embedders import PrecomputedEmbedder
+
+        Lc, Cd = 128, 1024
+        m = MMDiT(simple_dit=False, context_embedder=PrecomputedEmbedder(torch.randn(1, Lc, Cd), 7), **kw).to(dev)
+        keep = torch.arange(Lc, device=dev)[None, :] < torch.randint(8, Lc + 1, (a.batch, 1), device=dev)
+        ctx = {"embeddings": torch.randn(a.batch, Lc, Cd, device=dev, dtype=torch.bfloat16), "attn_mask": keep}
+    else:
+        m = (SprintDiT if a.config == "sprint" else MMDiT)(simple_dit=True, **kw).to(dev)
     extra, params = [], list(m.parameters())
     if a.config.startswith("repa"):
         rs = a.config == "repa_rs"
@@ -58,14 +72,15 @@ def main() -> None:
                  extra_losses=extra)
     opt = FusedAdamW(params, lr=1e-4, weight_decay=0.01)
     x0 = torch.randn(a.batch, *shape, device=dev)
-    y = torch.randint(0, kw["n_classes"], (a.batch,), device=dev)
+    y = torch.randint(0, kw["n_classes"], (a.batch,), device=dev) if kw.get("n_classes") else None
     dst = torch.randn(a.batch, 256 if a.config == "repa_rs" else 64, 1024, device=dev) if a.config.startswith("repa") else None
     p = 0.1 if kw["classifier_free"] else 0.0
 
     def step():
         opt.zero_grad()
         t = d.draw_timesteps(a.batch).to(dev, non_blocking=True)
-        losses = d.compute_loss({"x": x0, "y": y, "p": p}, timesteps=t, extra_args={"dst_features": dst} if dst is not None else {})
+        inputs = {"x": x0, "initial_context": ctx, "p": p} if ctx is not None else {"x": x0, "y": y, "p": p}
+        losses = d.compute_loss(inputs, timesteps=t, extra_args={"dst_features": dst} if dst is not None else {})
         sum(losses.values()).backward()
         opt.step()
 

@@ -659,9 +659,79 @@ def gen_mmdit_joint() -> None:
     save("mmdit_joint", **o)
 
 
+# ------------------------------------------------------------------ (xiii) SprintDiT joint form with single-stream deep blocks
+SPRINT_JOINT = dict(input_channels=4, output_channels=4, inner_dim=128, embedding_dim=64, num_heads=2, mlp_ratio=4, patch_size=1,
+                    encoder_depth=1, deep_layers_depth=3, n_single_stream_blocks=2, decoder_depth=2, rope_axes_dim=[16, 24, 24],
+                    rope_base=2000, classifier_free=True, drop_rate=0.75)
+
+
+def gen_sprint_joint() -> None:
+    """SprintDiT(simple_dit=False): joint encoder block, deep stage = one joint + two single-stream blocks on 64 of 256 image
+    tokens, fuse / fuse_context, two joint decoder blocks; 64 text tokens with a ragged mask (the shape of
+    configs/train_imagenet_repa_txt_to_img_sprint.yaml at small width)"""
+    import importlib
+    import tempfile
+
+    from oracle import sprint as osprint
+
+    PE = importlib.import_module("diffulab.networks.embedders.precomputed").PrecomputedEmbedder
+    SprintDiT = importlib.import_module("diffulab.networks.denoisers.sprint").SprintDiT
+    Lc, Cd, B, H = 64, 96, 4, 16
+    null = synth.normal("sj.null", (1, Lc, Cd)) * 0.5
+    with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+        torch.save(null, f.name)
+        emb = PE(f.name, null_embedding_seq_len=7)
+    m = SprintDiT(simple_dit=False, context_embedder=emb, **SPRINT_JOINT)
+    cfg = osprint.SprintJointConfig(context_dim=Cd, **SPRINT_JOINT)
+    shapes = osprint.joint_param_shapes(cfg)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == shapes, set(m.state_dict()) ^ set(shapes)
+    P = synth.dit_params({k: v for k, v in shapes.items() if k != "mask_token"}, seed=81)
+    P["mask_token"] = synth.normal("sj.mask", shapes["mask_token"]) * 0.5
+    m.load_state_dict(P)
+    x = synth.normal("sj.x", (B, 4, H, H))
+    t = synth.uniform("sj.t", (B,), lo=0.05, hi=0.95)
+    ctx = synth.normal("sj.ctx", (B, Lc, Cd))
+    keep = torch.arange(Lc)[None, :] < torch.tensor([64, 20, 41, 5])[:, None]
+    dy = synth.normal("sj.dy", (B, 4, H, H))
+    ic = {"embeddings": ctx, "attn_mask": keep}
+    o = {}
+    m.train()
+    torch.manual_seed(5)
+    with _RandRecorder() as r:
+        pred = m(x=x, timesteps=t, initial_context=ic, p=0.0)["x"]
+    assert [tuple(d.shape) for d in r.draws] == [(B,), (B, 256)], [tuple(d.shape) for d in r.draws]  # embedder draw (p = 0), scores
+    o["a_scores"], o["a_pred"] = r.draws[1], pred
+    (pred * dy).sum().backward()
+    big = ("fuse.weight", "fuse_context.weight", "context_embed.weight", "conv_proj.weight", "layers.0.attention.qkv_context.weight",
+           "layers.0.mlp_input.2.weight", "deep_layers.0.attention.input_proj_out.weight", "deep_layers.0.mlp_context.0.weight",
+           "deep_layers.1.attention.qkv.weight", "deep_layers.1.mlp.0.weight", "deep_layers.2.attention.proj_out.weight",
+           "deep_layers.2.mlp.2.weight", "deep_layers.2.modulation.1.weight", "decoder_layers.0.mlp_context.2.weight",
+           "decoder_layers.1.attention.qkv_input.weight", "decoder_layers.1.modulation_context.lin.weight")
+    for n, p in m.named_parameters():  # every vector / small tensor and one matrix of each kind (the oracle carries the rest)
+        if p.grad is not None and (p.numel() <= 16384 or n in big):
+            o["a_g_" + n] = p.grad.clone()
+    o["a_none"] = np.array(sorted(n for n, p in m.named_parameters() if p.grad is None))
+    m.zero_grad()
+    for seed in range(6, 64):  # first seed whose draws drop some (not all) contexts and some (not all) deep paths
+        torch.manual_seed(seed)
+        with _RandRecorder() as r, torch.no_grad():
+            pred = m(x=x, timesteps=t, initial_context=ic, p=0.5)["x"]
+        assert [tuple(d.shape) for d in r.draws] == [(B,), (B, 256), (B,)]
+        if 0 < int((r.draws[0] < 0.5).sum()) < B and 0 < int((r.draws[2] < 0.5).sum()) < B:
+            break
+    else:
+        raise AssertionError("no seed with mixed drops")
+    o["b_ctx_u"], o["b_scores"], o["b_path_u"], o["b_pred"] = r.draws[0], r.draws[1], r.draws[2], pred
+    m.eval()
+    with torch.no_grad():
+        o["c_pred"] = m(x=x, timesteps=t, initial_context=ic, p=0.0)["x"]
+        o["d_pred"] = m(x=x, timesteps=t, initial_context=ic, p=1.0)["x"]
+    save("sprint_joint", **o)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve", "repa", "resampler", "sprint", "mmdit_joint"]
-    fns = {"repa": gen_repa, "resampler": gen_resampler, "sprint": gen_sprint, "mmdit_joint": gen_mmdit_joint, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
+    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve", "repa", "resampler", "sprint", "mmdit_joint", "sprint_joint"]
+    fns = {"repa": gen_repa, "resampler": gen_resampler, "sprint": gen_sprint, "mmdit_joint": gen_mmdit_joint, "sprint_joint": gen_sprint_joint, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
            "s2": gen_s2_model, "samplers": gen_samplers, "curve": gen_loss_curve, "unet": gen_unet}
     for w in which:
         print("==", w)

@@ -482,3 +482,46 @@ def test_mmdit_joint_blocks(golden):
             vc, vu = ommdit.mmdit_forward(P, xs, tt, ctx, keep, cfg), ommdit.mmdit_forward(P, xs, tt, cu, ku, cfg)
             xs = xs - (vu + 2.0 * (vc - vu)) * (a - b)
         assert rel(xs, g["e_loop_x"]) < 1e-5
+
+
+def test_sprint_dit_joint_form(golden):
+    """(xiii) SprintDiT(simple_dit=False): joint encoder / decoder blocks, single-stream deep blocks on the kept tokens,
+    fuse + fuse_context; recorded token scores, context drop and path drop; eval with and without the deep path"""
+    from oracle import mmdit as ommdit
+    from oracle import sprint as osprint
+
+    raw = golden("sprint_joint")
+    no_grad = set(str(n) for n in raw["a_none"])
+    g = {k: torch.as_tensor(v) for k, v in raw.items() if k != "a_none"}
+    kw = dict(input_channels=4, output_channels=4, inner_dim=128, embedding_dim=64, num_heads=2, mlp_ratio=4, patch_size=1,
+              encoder_depth=1, deep_layers_depth=3, n_single_stream_blocks=2, decoder_depth=2, rope_axes_dim=[16, 24, 24],
+              rope_base=2000, classifier_free=True, drop_rate=0.75)
+    cfg = osprint.SprintJointConfig(context_dim=96, **kw)
+    shapes = osprint.joint_param_shapes(cfg)
+    P = synth.dit_params({k: v for k, v in shapes.items() if k != "mask_token"}, seed=81)
+    P["mask_token"] = synth.normal("sj.mask", shapes["mask_token"]) * 0.5
+    P = {k: v.requires_grad_(True) for k, v in P.items()}
+    Lc, Cd, B, H = 64, 96, 4, 16
+    null, null_keep = (synth.normal("sj.null", (1, Lc, Cd)) * 0.5)[0], torch.arange(Lc) < 7
+    x, t = synth.normal("sj.x", (B, 4, H, H)), synth.uniform("sj.t", (B,), lo=0.05, hi=0.95)
+    ctx = synth.normal("sj.ctx", (B, Lc, Cd))
+    keep = torch.arange(Lc)[None, :] < torch.tensor([64, 20, 41, 5])[:, None]
+    dy = synth.normal("sj.dy", (B, 4, H, H))
+    pred = osprint.sprint_mmdit_forward(P, x, t, ctx, keep, cfg, kept=osprint.kept_indices(g["a_scores"], 64))
+    assert rel(pred, g["a_pred"]) < 2e-6
+    (pred * dy).sum().backward()
+    checked = 0
+    for n, v in P.items():
+        if "a_g_" + n in g:
+            assert rel(v.grad, g["a_g_" + n]) < 2e-5, n
+            checked += 1
+        assert (v.grad is None) == (n in no_grad), n  # context branch of the last decoder block feeds nothing
+    assert checked > 80 and all(n.startswith("decoder_layers.1.") and "context" in n for n in no_grad)
+    with torch.no_grad():
+        c2, k2 = ommdit.drop_context(ctx, keep, null, null_keep, g["b_ctx_u"] < 0.5)
+        pred = osprint.sprint_mmdit_forward(P, x, t, c2, k2, cfg, kept=osprint.kept_indices(g["b_scores"], 64),
+                                            path_drop=g["b_path_u"] < 0.5)
+        assert rel(pred, g["b_pred"]) < 2e-6
+        assert rel(osprint.sprint_mmdit_forward(P, x, t, ctx, keep, cfg), g["c_pred"]) < 2e-6
+        cu, ku = ommdit.drop_context(ctx, keep, null, null_keep, torch.ones(B, dtype=torch.bool))
+        assert rel(osprint.sprint_mmdit_forward(P, x, t, cu, ku, cfg, skip_deep=True), g["d_pred"]) < 2e-6
