@@ -48,6 +48,7 @@ class Route:
     keep: Tensor | None
     k: int
     skip_deep: bool = False
+    pos_lat: Tensor | None = None  # joint form: RoPE table row of every [text ; kept image] token, int32 [B * (Lc + k)]
 
 
 class SprintEngine(DiTEngine):

@@ -209,3 +209,109 @@ def test_sprint_flow_loss_step_with_adamw_learns():
         losses.append(loss.item())
     assert all(v == v for v in losses) and sum(losses[-5:]) < sum(losses[:5])
     assert float(m.mask_token.grad.abs().max()) > 0
+
+
+# ------------------------------------------------------------------ joint text-image form (simple_dit=False)
+JKW = dict(input_channels=4, output_channels=4, inner_dim=128, embedding_dim=64, num_heads=2, mlp_ratio=4, patch_size=1,
+           encoder_depth=1, deep_layers_depth=3, n_single_stream_blocks=2, decoder_depth=2, rope_axes_dim=[16, 24, 24], rope_base=2000,
+           classifier_free=True, drop_rate=0.75)
+
+
+def _joint_model(**over):
+    from diffulab_amd import SprintDiT
+    from diffulab_amd.networks.embedders import PrecomputedEmbedder
+
+    kw = {**JKW, **over}
+    null = synth.normal("sj.null", (1, 64, 96)) * 0.5
+    m = SprintDiT(simple_dit=False, context_embedder=PrecomputedEmbedder(null, null_embedding_seq_len=7), **kw)
+    cfg = osprint.SprintJointConfig(context_dim=96, **kw)
+    shapes = osprint.joint_param_shapes(cfg)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == shapes
+    P = synth.dit_params({k: v for k, v in shapes.items() if k != "mask_token"}, seed=81)
+    P["mask_token"] = synth.normal("sj.mask", shapes["mask_token"]) * 0.5
+    m.load_state_dict(P)
+    return m.to(DEV), P, cfg
+
+
+def _joint_inputs():
+    B, H, Lc = 4, 16, 64
+    keep = torch.arange(Lc)[None, :] < torch.tensor([64, 20, 41, 5])[:, None]
+    return (synth.normal("sj.x", (B, 4, H, H)), synth.uniform("sj.t", (B,), lo=0.05, hi=0.95), synth.normal("sj.ctx", (B, Lc, 96)), keep,
+            synth.normal("sj.dy", (B, 4, H, H)))
+
+
+def _check_grads(m, ref: dict, none: set):
+    bad = []
+    for n, p in m.named_parameters():
+        if n in none:  # no gradient in the reference: exact zeros here
+            assert float(p.grad.abs().max()) == 0.0, n
+            continue
+        if n not in ref:
+            continue
+        e = rel(p.grad, ref[n])
+        if e > (8e-2 if p.dim() == 1 or n == "mask_token" else 4e-2):
+            bad.append((n, e))
+    assert not bad, bad
+
+
+def test_sprint_joint_training_step_against_reference_fixture_and_oracle(golden):
+    """joint encoder block -> 64 of 256 image tokens through one joint + two single-stream deep blocks -> fuse / fuse_context ->
+    two joint decoder blocks: prediction vs the reference; gradients vs the reference (stored subset) and vs the oracle (all)"""
+    raw = golden("sprint_joint")
+    none = set(str(n) for n in raw["a_none"])
+    g = {k: torch.as_tensor(v) for k, v in raw.items() if k != "a_none"}
+    m, P, cfg = _joint_model()
+    x, t, ctx, keep, dy = _joint_inputs()
+    m.train()
+    _inject(m, scores=g["a_scores"])
+    ic = {"embeddings": ctx.to(DEV), "attn_mask": keep.to(DEV)}
+    pred = m(x=x.to(DEV), timesteps=t.to(DEV), initial_context=ic, p=0.0)["x"]
+    assert rel(pred, g["a_pred"]) < 1.5e-2
+    (pred * dy.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    _check_grads(m, {n: g["a_g_" + n] for n, _ in m.named_parameters() if "a_g_" + n in g}, none)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    po = osprint.sprint_mmdit_forward(Pr, x, t, ctx, keep, cfg, kept=osprint.kept_indices(g["a_scores"], 64))
+    (po * dy).sum().backward()
+    _check_grads(m, {n: v.grad for n, v in Pr.items()}, none)
+
+
+def test_sprint_joint_drops_and_eval_against_reference_fixture(golden):
+    from oracle import mmdit as ommdit  # noqa: F401
+
+    raw = golden("sprint_joint")
+    g = {k: torch.as_tensor(v) for k, v in raw.items() if k != "a_none"}
+    m, _, _ = _joint_model()
+    x, t, ctx, keep, _ = _joint_inputs()
+    ic = {"embeddings": ctx.to(DEV), "attn_mask": keep.to(DEV)}
+    m.train()
+    _inject(m, scores=g["b_scores"], path_u=g["b_path_u"])
+    m.context_embedder._draw_drop = lambda batch_size, p, device: g["b_ctx_u"].to(device) < p
+    with torch.no_grad():
+        assert rel(m(x=x.to(DEV), timesteps=t.to(DEV), initial_context=ic, p=0.5)["x"], g["b_pred"]) < 1.5e-2
+    del m.context_embedder._draw_drop
+    m.eval()
+    with torch.no_grad():
+        assert rel(m(x=x.to(DEV), timesteps=t.to(DEV), initial_context=ic, p=0.0)["x"], g["c_pred"]) < 1.5e-2
+        assert rel(m(x=x.to(DEV), timesteps=t.to(DEV), initial_context=ic, p=1.0)["x"], g["d_pred"]) < 1.5e-2
+
+
+@pytest.mark.parametrize("ns", [0, 3])
+def test_sprint_joint_other_deep_stage_mixes_against_oracle(ns):
+    """deep stage of joint blocks only (n_single_stream_blocks = 0) and of single-stream blocks only (the txt-to-img config)"""
+    m, P, cfg = _joint_model(n_single_stream_blocks=ns)
+    x, t, ctx, keep, dy = _joint_inputs()
+    scores = synth.uniform("sj.sc", (4, 256))
+    path_u = torch.tensor([0.9, 0.1, 0.8, 0.7])
+    m.train()
+    _inject(m, scores=scores, path_u=path_u)
+    m.context_embedder._draw_drop = lambda batch_size, p, device: torch.zeros(batch_size, dtype=torch.bool, device=device)
+    pred = m(x=x.to(DEV), timesteps=t.to(DEV), initial_context={"embeddings": ctx.to(DEV), "attn_mask": keep.to(DEV)}, p=0.5)["x"]
+    (pred * dy.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    po = osprint.sprint_mmdit_forward(Pr, x, t, ctx, keep, cfg, kept=osprint.kept_indices(scores, 64), path_drop=path_u < 0.5)
+    assert rel(pred, po) < 1.5e-2
+    (po * dy).sum().backward()
+    none = {n for n, v in Pr.items() if v.grad is None}
+    _check_grads(m, {n: v.grad for n, v in Pr.items()}, none)
