@@ -6,6 +6,8 @@
     python scripts/train_step_bench.py dit12 --batch 32     # the same 12 blocks without token dropping (what SPRINT is compared with)
     python scripts/train_step_bench.py joint --batch 16     # joint text-image MMDiT: 768/12 heads, 12 MMDiTBlocks, 128x32x32 latents at patch 1
                                                             # (1024 image tokens) + 128 text tokens of width 1024, ragged key mask
+    python scripts/train_step_bench.py sprint_joint --batch 16  # configs/train_imagenet_repa_txt_to_img_sprint.yaml: 768/12, 2 joint encoder +
+                                                            # 8 single-stream deep (256 of 1024 image tokens) + 2 joint decoder blocks
     python scripts/train_step_bench.py repa_rs --batch 128  # same + the Perceiver resampler (configs/train_imagenet_flow_matching_repa.yaml)
 """
 import argparse
@@ -38,6 +40,10 @@ CFG["sprint"] = (SPRINT, (3, 32, 32))
 JOINT = dict(input_channels=128, output_channels=128, inner_dim=768, embedding_dim=768, num_heads=12, mlp_ratio=4, patch_size=1,
              depth=12, classifier_free=True, rope_base=2000, rope_axes_dim=[16, 24, 24])
 CFG["joint"] = (JOINT, (128, 32, 32))
+SPRINT_JOINT = dict(input_channels=128, output_channels=128, inner_dim=768, embedding_dim=768, num_heads=12, mlp_ratio=4, patch_size=1,
+                    encoder_depth=2, deep_layers_depth=8, n_single_stream_blocks=8, decoder_depth=2, classifier_free=True,
+                    rope_base=2000, rope_axes_dim=[16, 24, 24])
+CFG["sprint_joint"] = (SPRINT_JOINT, (128, 32, 32))
 RS = dict(depth=3, dim=1024, head_dim=64, num_heads=8, ff_mult=4, num_latents=256)
 
 
@@ -52,11 +58,12 @@ def main() -> None:
     kw, shape = CFG[a.config]
     torch.manual_seed(0)
     ctx = None
-    if a.config == "joint":
+    if a.config in ("joint", "sprint_joint"):
         from diffulab_amd.networks.embedders import PrecomputedEmbedder
 
         Lc, Cd = 128, 1024
-        m = MMDiT(simple_dit=False, context_embedder=PrecomputedEmbedder(torch.randn(1, Lc, Cd), 7), **kw).to(dev)
+        cls = MMDiT if a.config == "joint" else SprintDiT
+        m = cls(simple_dit=False, context_embedder=PrecomputedEmbedder(torch.randn(1, Lc, Cd), 7), **kw).to(dev)
         keep = torch.arange(Lc, device=dev)[None, :] < torch.randint(8, Lc + 1, (a.batch, 1), device=dev)
         ctx = {"embeddings": torch.randn(a.batch, Lc, Cd, device=dev, dtype=torch.bfloat16), "attn_mask": keep}
     else:
