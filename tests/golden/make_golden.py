@@ -729,9 +729,44 @@ def gen_sprint_joint() -> None:
     save("sprint_joint", **o)
 
 
+# ------------------------------------------------------------------ (xiv) DDT, simple_ddt (configs/model/ddt.yaml)
+DDT_SMALL = dict(input_channels=4, output_channels=4, inner_dim=128, num_heads=2, mlp_ratio=4, patch_size=2, encoder_depth=2,
+                 decoder_depth=2, n_classes=10, classifier_free=True)
+
+
+def gen_ddt() -> None:
+    import importlib
+
+    from oracle import ddt as oddt
+
+    DDT = importlib.import_module("diffulab.networks.denoisers.ddt").DDT
+    cfg = oddt.DDTConfig(**DDT_SMALL)
+    m = DDT(simple_ddt=True, **DDT_SMALL)
+    shapes = oddt.param_shapes(cfg)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == shapes, set(m.state_dict()) ^ set(shapes)
+    m.load_state_dict(synth.dit_params(shapes, seed=91))
+    B, H = 4, 16
+    x = synth.normal("dd.x", (B, 4, H, H))
+    t = synth.uniform("dd.t", (B,), lo=0.05, hi=0.95)
+    y = synth.integers("dd.y", (B,), 10)
+    dy = synth.normal("dd.dy", (B, 4, H, H))
+    o = {}
+    m.train()
+    pred = m(x=x, timesteps=t, y=y, p=0.0)["x"]
+    o["pred"] = pred
+    (pred * dy).sum().backward()
+    for n, p in m.named_parameters():
+        o["g_" + n] = p.grad.clone()
+    m.eval()
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=4)
+    out = d.generate({"x": synth.normal("dd.init", (B, 4, H, H)), "y": y}, use_tqdm=False, guidance_scale=2.0)
+    o["loop_x"] = out["x"]
+    save("ddt", **o)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve", "repa", "resampler", "sprint", "mmdit_joint", "sprint_joint"]
-    fns = {"repa": gen_repa, "resampler": gen_resampler, "sprint": gen_sprint, "mmdit_joint": gen_mmdit_joint, "sprint_joint": gen_sprint_joint, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
+    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve", "repa", "resampler", "sprint", "mmdit_joint", "sprint_joint", "ddt"]
+    fns = {"repa": gen_repa, "resampler": gen_resampler, "sprint": gen_sprint, "mmdit_joint": gen_mmdit_joint, "sprint_joint": gen_sprint_joint, "ddt": gen_ddt, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
            "s2": gen_s2_model, "samplers": gen_samplers, "curve": gen_loss_curve, "unet": gen_unet}
     for w in which:
         print("==", w)

@@ -525,3 +525,31 @@ def test_sprint_dit_joint_form(golden):
         assert rel(osprint.sprint_mmdit_forward(P, x, t, ctx, keep, cfg), g["c_pred"]) < 2e-6
         cu, ku = ommdit.drop_context(ctx, keep, null, null_keep, torch.ones(B, dtype=torch.bool))
         assert rel(osprint.sprint_mmdit_forward(P, x, t, cu, ku, cfg, skip_deep=True), g["d_pred"]) < 2e-6
+
+
+def test_ddt_simple(golden):
+    """(xiv) DDT(simple_ddt=True): DiT encoder, decoder DiT blocks with per-token adaLN conditioning silu(enc + t_emb), guided
+    sampling loop"""
+    from oracle import ddt as oddt
+
+    g = {k: torch.as_tensor(v) for k, v in golden("ddt").items()}
+    kw = dict(input_channels=4, output_channels=4, inner_dim=128, num_heads=2, mlp_ratio=4, patch_size=2, encoder_depth=2,
+              decoder_depth=2, n_classes=10, classifier_free=True)
+    cfg = oddt.DDTConfig(**kw)
+    P = {k: v.requires_grad_(True) for k, v in synth.dit_params(oddt.param_shapes(cfg), seed=91).items()}
+    B, H = 4, 16
+    x, t, y = synth.normal("dd.x", (B, 4, H, H)), synth.uniform("dd.t", (B,), lo=0.05, hi=0.95), synth.integers("dd.y", (B,), 10)
+    dy = synth.normal("dd.dy", (B, 4, H, H))
+    pred = oddt.ddt_forward(P, x, t, y, cfg)
+    assert rel(pred, g["pred"]) < 2e-6
+    (pred * dy).sum().backward()
+    for n, v in P.items():
+        assert rel(v.grad, g["g_" + n]) < 2e-5, n
+    with torch.no_grad():
+        xs = synth.normal("dd.init", (B, 4, H, H))
+        ts = [1.0, 0.75, 0.5, 0.25, 0.0]
+        for a, b in zip(ts[:-1], ts[1:]):
+            tt = torch.full((B,), a)
+            vc, vu = oddt.ddt_forward(P, xs, tt, y, cfg), oddt.ddt_forward(P, xs, tt, torch.full_like(y, 10), cfg)
+            xs = xs - (vu + 2.0 * (vc - vu)) * (a - b)
+        assert rel(xs, g["loop_x"]) < 1e-5
