@@ -6,6 +6,6 @@ Same plugin API as the reference (`Diffuser` / `Denoiser` / `Sampler`), hand-wri
 
 from . import ops  # noqa: F401
 from .diffuse import Diffuser, Flow, GaussianDiffusion  # noqa: F401
-from .networks.denoisers import Denoiser, MMDiT, SprintDiT, UNetModel  # noqa: F401
+from .networks.denoisers import DDT, Denoiser, MMDiT, SprintDiT, UNetModel  # noqa: F401
 
-__all__ = ["Diffuser", "Flow", "GaussianDiffusion", "Denoiser", "MMDiT", "SprintDiT", "UNetModel", "ops"]
+__all__ = ["Diffuser", "Flow", "GaussianDiffusion", "DDT", "Denoiser", "MMDiT", "SprintDiT", "UNetModel", "ops"]

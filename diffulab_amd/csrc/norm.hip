@@ -318,6 +318,139 @@ extern "C" int dl_ln_modulate_bwd(const void* dout, const void* x, const float* 
   return DL_OK;
 }
 
+// ======================================================================== LayerNorm + modulate, backward, PER-TOKEN modulation
+// DDT's decoder conditions every token on its own vector (ddt.py:423-424 -> Modulation on [B, S, D]): scale / shift / gate have
+// one row per token, so their gradients are per-row outputs (written as bf16 straight into the modulation-gradient matrix, no
+// accumulation) and only the affine gradients need a column reduction: registers -> LDS -> one of n_part f32 partial slabs.
+template <int NJ>
+__global__ __launch_bounds__(256) void ln_mod_bwd_tok_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        const bf16_t* __restrict__ scale, int64_t ld_mod,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
+                                                        bf16_t* __restrict__ dscale, bf16_t* __restrict__ dshift, int64_t ld_dmod,
+                                                        float* __restrict__ dwb, int n_part, const bf16_t* __restrict__ gt,
+                                                        const bf16_t* __restrict__ ggate, int64_t ld_gate,
+                                                        bf16_t* __restrict__ gdt, bf16_t* __restrict__ dgate, int rows_per_wg,
+                                                        int64_t M, int D) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = (float*)smem;  // [2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D8 = D >> 3;
+  const float invD = 1.0f / (float)D;
+  for (int i = threadIdx.x; i < 2 * D; i += 256) red[i] = 0.f;
+  float wv[NJ][8], bv[NJ][8], a_dw[NJ][8], a_db[NJ][8];
+  load_row_f32<NJ>(w, D8, lane, wv, 1.0f);
+  load_row_f32<NJ>(b, D8, lane, bv, 0.0f);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a_dw[j][e] = a_db[j][e] = 0.f;
+  const int64_t row_begin = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t row_end = row_begin + rows_per_wg < M ? row_begin + rows_per_wg : M;
+  for (int64_t row = row_begin + wave; row < row_end; row += 4) {
+    float dv[NJ][8], xv[NJ][8], rv[NJ][8], sc[NJ][8], ov[NJ][8];
+    load_row<NJ>(dout + row * D, D8, lane, dv);
+    load_row<NJ>(x + row * D, D8, lane, xv);
+    load_row<NJ>(scale + row * ld_mod, D8, lane, sc);
+    if (dres) load_row<NJ>(dres + row * D, D8, lane, rv);
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const bool on = (lane + 64 * j) < D8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = on ? (xv[j][e] - mu) * rs : 0.f;
+        const float d = on ? dv[j][e] : 0.f;
+        ov[j][e] = d * (xh * wv[j][e] + bv[j][e]);  // dscale of this token
+        const float dy = d * (1.0f + sc[j][e]);
+        a_dw[j][e] += dy * xh;
+        a_db[j][e] += dy;
+        const float dxh = dy * wv[j][e];
+        s1 += dxh;
+        s2 += dxh * xh;
+        xv[j][e] = xh;
+        dv[j][e] = dxh;
+        if (!dres) rv[j][e] = 0.f;
+      }
+    }
+    store_row<NJ>(dscale + row * ld_dmod, D8, lane, ov);
+    {  // dshift of this token = dout (re-read: the registers now hold dxh)
+      float sv[NJ][8];
+      load_row<NJ>(dout + row * D, D8, lane, sv);
+      store_row<NJ>(dshift + row * ld_dmod, D8, lane, sv);
+    }
+    const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rv[j][e] += rs * (dv[j][e] - c1 - xv[j][e] * c2);
+    store_row<NJ>(dx + row * D, D8, lane, rv);
+    if (gt) {  // fused backward of the gated residual that follows in the chain, per-token gate
+      float tv[NJ][8], gv[NJ][8];
+      load_row<NJ>(gt + row * D, D8, lane, tv);
+      load_row<NJ>(ggate + row * ld_gate, D8, lane, gv);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dxr = bf2f(f2bf(rv[j][e]));
+          tv[j][e] = dxr * tv[j][e];   // dgate of this token
+          rv[j][e] = dxr * gv[j][e];   // dt
+        }
+      store_row<NJ>(dgate + row * ld_dmod, D8, lane, tv);
+      store_row<NJ>(gdt + row * D, D8, lane, rv);
+    }
+  }
+  if (!dwb) return;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = lane + 64 * j;
+    if (c < D8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        atomicAdd(red + c * 8 + e, a_dw[j][e]);
+        atomicAdd(red + D + c * 8 + e, a_db[j][e]);
+      }
+    }
+  }
+  __syncthreads();
+  float* dst = dwb + (size_t)(blockIdx.x % n_part) * 2 * D;
+  for (int i = threadIdx.x; i < 2 * D; i += 256) unsafeAtomicAdd(dst + i, red[i]);
+}
+
+extern "C" int dl_ln_modulate_bwd_tok(const void* dout, const void* x, const float* w, const float* b, const void* scale,
+                                      int64_t ld_mod, const float* mean, const float* rstd, const void* dres, void* dx,
+                                      void* dscale, void* dshift, int64_t ld_dmod, float* dwb_partial, int64_t n_part,
+                                      const void* gate_t, const void* gate, int64_t ld_gate, void* dt, void* dgate, int64_t M,
+                                      int64_t D, dl_stream_t stream) {
+  DL_CHECK_ARG(dout && x && scale && mean && rstd && dx && dscale && dshift && M > 0, "dl_ln_modulate_bwd_tok: null operand");
+  DL_CHECK_ARG((w == nullptr) == (b == nullptr) && (w == nullptr) == (dwb_partial == nullptr) && (!dwb_partial || n_part > 0),
+               "dl_ln_modulate_bwd_tok: w, b and dwb_partial must all be given or all NULL");
+  DL_CHECK_ARG(D % 8 == 0 && D <= 512 * MAXJ && ld_mod % 8 == 0 && ld_dmod % 8 == 0, "dl_ln_modulate_bwd_tok: D=%lld", (long long)D);
+  DL_CHECK_ARG((((uintptr_t)dout | (uintptr_t)x | (uintptr_t)scale | (uintptr_t)dx | (uintptr_t)dres | (uintptr_t)dscale |
+                 (uintptr_t)dshift) & 15) == 0, "dl_ln_modulate_bwd_tok: 16-byte alignment");
+  DL_CHECK_ARG(!gate_t || (gate && dt && dgate && ld_gate % 8 == 0 &&
+                           (((uintptr_t)gate_t | (uintptr_t)gate | (uintptr_t)dt | (uintptr_t)dgate) & 15) == 0),
+               "dl_ln_modulate_bwd_tok: the fused gate backward needs gate_t, gate, dt and dgate (16-byte aligned)");
+  const int rows_per_wg = 64;
+  const int grid = cdiv(M, rows_per_wg);
+  const size_t lds = (size_t)2 * D * sizeof(float);
+  const int nj = cdiv(D, 512);
+#define LAUNCH(NJ)                                                                                                              \
+  hipLaunchKernelGGL(ln_mod_bwd_tok_k<NJ>, grid, 256, lds, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)x, w, b,        \
+                     (const bf16_t*)scale, ld_mod, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, (bf16_t*)dscale, (bf16_t*)dshift,  \
+                     ld_dmod, dwb_partial, (int)n_part, (const bf16_t*)gate_t, (const bf16_t*)gate, ld_gate, (bf16_t*)dt,            \
+                     (bf16_t*)dgate, rows_per_wg, M, (int)D)
+  if (nj == 1) LAUNCH(1);
+  else LAUNCH(2);
+#undef LAUNCH
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
 // ======================================================================== gated residual, backward
 template <int NJ>
 __global__ __launch_bounds__(512) void gate_bwd_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ t,

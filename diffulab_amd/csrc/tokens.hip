@@ -97,6 +97,44 @@ __global__ void copy_rows3d_k(const bf16_t* __restrict__ src, int64_t sbs, int64
   }
 }
 
+// DDT decoder conditioning (ddt.py:423-424 + the SiLU inside Modulation nn.py:530): z = silu(enc + temb[b]); out = silu(z)
+__global__ void ddt_cond_fwd_k(const bf16_t* __restrict__ enc, int64_t ld, const float* __restrict__ temb, int64_t ld_t, int N,
+                               bf16_t* __restrict__ out, int D8, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D8);
+    const int64_t row = i / D8;
+    float v[8];
+    unpack8(*(const u32x4_t*)(enc + row * ld + c * 8), v);
+    const float* tp = temb + (row / N) * ld_t + c * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = silu_f(silu_f(v[e] + tp[e]));
+    *(u32x4_t*)(out + row * (int64_t)D8 * 8 + c * 8) = pack8(v);
+  }
+}
+// denc = dsz * silu'(z) * silu'(u), u = enc + temb[b], z = silu(u); dtemb[b, :] += sum_n denc   (one workgroup per (sample, slab))
+__global__ __launch_bounds__(256) void ddt_cond_bwd_k(const bf16_t* __restrict__ dsz, const bf16_t* __restrict__ enc, int64_t ld,
+                                                      const float* __restrict__ temb, int64_t ld_t, int N, bf16_t* __restrict__ denc,
+                                                      float* __restrict__ dtemb, int D, int rows_per_wg) {
+  const int b = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, N);
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    const float tb = temb[(int64_t)b * ld_t + c];
+    float acc = 0.f;
+    for (int n = r0; n < r1; ++n) {
+      const int64_t row = (int64_t)b * N + n;
+      const float u = bf2f(enc[row * ld + c]) + tb;
+      const float su = 1.f / (1.f + __expf(-u));
+      const float z = u * su;
+      const float dz_du = su * (1.f + u * (1.f - su));
+      const float sz = 1.f / (1.f + __expf(-z));
+      const float d = bf2f(dsz[row * (int64_t)D + c]) * (sz * (1.f + z * (1.f - sz))) * dz_du;
+      denc[row * (int64_t)D + c] = f2bf(d);
+      acc += d;
+    }
+    unsafeAtomicAdd(dtemb + (int64_t)b * ld_t + c, acc);
+  }
+}
+
 static inline int row_grid(int64_t total) {
   int64_t g = (total + 255) / 256;
   return (int)(g > 8192 ? 8192 : g);
@@ -166,6 +204,26 @@ extern "C" int dl_copy_rows3d(const void* src, int64_t src_bs, int64_t src_rs, v
   const int64_t total = B * rows * (cols / 8);
   hipLaunchKernelGGL(copy_rows3d_k, row_grid(total), 256, 0, (hipStream_t)stream, (const bf16_t*)src, src_bs, src_rs,
                      (bf16_t*)dst, dst_bs, dst_rs, (int)rows, (int)(cols / 8), total);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_ddt_cond_fwd(const void* enc, int64_t ld, const float* temb, int64_t ld_t, int64_t B, int64_t N, int64_t D,
+                               void* out, dl_stream_t stream) {
+  DL_CHECK_ARG(enc && temb && out && B > 0 && N > 0 && D > 0 && D % 8 == 0 && ld % 8 == 0 && ld >= D && ld_t >= D && ld_t % 4 == 0 &&
+                   ALIGNED16(enc) && ALIGNED16(out) && ALIGNED16(temb),
+               "dl_ddt_cond_fwd: bad args");
+  const int64_t total = B * N * (D / 8);
+  hipLaunchKernelGGL(ddt_cond_fwd_k, row_grid(total), 256, 0, (hipStream_t)stream, (const bf16_t*)enc, ld, temb, ld_t, (int)N,
+                     (bf16_t*)out, (int)(D / 8), total);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_ddt_cond_bwd(const void* dsz, const void* enc, int64_t ld, const float* temb, int64_t ld_t, int64_t B, int64_t N,
+                               int64_t D, void* denc, float* dtemb, dl_stream_t stream) {
+  DL_CHECK_ARG(dsz && enc && temb && denc && dtemb && B > 0 && N > 0 && D > 0 && ld >= D && ld_t >= D, "dl_ddt_cond_bwd: bad args");
+  const int rows_per_wg = 16;
+  hipLaunchKernelGGL(ddt_cond_bwd_k, dim3(cdiv(N, rows_per_wg), (unsigned)B), 256, 0, (hipStream_t)stream, (const bf16_t*)dsz,
+                     (const bf16_t*)enc, ld, temb, ld_t, (int)N, (bf16_t*)denc, dtemb, (int)D, rows_per_wg);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

@@ -150,6 +150,8 @@ class ParamLayout:
 
 
 class DiTEngine:
+    _conv_name = "conv_proj.weight"  # patch-embedding convolution of the (encoder) token stream
+
     def __init__(self, dims: DiTDims, device: torch.device | str = "cuda") -> None:
         dims.validate()
         self.d = dims
@@ -209,7 +211,7 @@ class DiTEngine:
         reg("@mod", self.layout.mod_rows, E)
         reg("time_embed.0.weight", E, d.frequency_embedding, dgrad=False)
         reg("time_embed.2.weight", E, E)
-        reg("conv_proj.weight", D, d.input_channels * d.patch_size**2, dgrad=False)
+        reg(self._conv_name, D, d.input_channels * d.patch_size**2, dgrad=False)
         reg("last_layer.linear.weight", d.patch_size**2 * d.output_channels, D)
         self._extra_shadows(reg)
         for pre in self.prefixes:
@@ -345,7 +347,7 @@ class DiTEngine:
         B, _, _, _, _, _, M, _, _ = self.geo
         D, E = d.inner_dim, d.embedding_dim
         ops.patchify(x, w["tokP"], d.patch_size, ops.PATCH_CPP)
-        ops.gemm_nt(w["tokP"], sh["conv_proj.weight|f"], w["x"][0] if x0 is None else x0, M=M, N=D, K=self._ki)
+        ops.gemm_nt(w["tokP"], sh[self._conv_name + "|f"], w["x"][0] if x0 is None else x0, M=M, N=D, K=self._ki)
         ops.timestep_embedding(t, w["temb"][:B])
         ops.gemm_nt(w["temb"], sh["time_embed.0.weight|f"], w["h1"], bias=self.P("time_embed.0.bias"), act=ops.ACT_SILU,
                     pre_out=w["pre1"], M=B, N=E, K=d.frequency_embedding)
@@ -534,16 +536,16 @@ class DiTEngine:
 
         self._cond_bwd(dx)
 
-    def _cond_bwd(self, dx: Tensor) -> None:
+    def _cond_bwd(self, dx: Tensor, extra_demb: Tensor | None = None) -> None:
         """backward of _stem_fwd: dx = gradient of the patch-embedded tokens; the modulation gradient was accumulated in
-        ws["dmod32"] by the block kernels"""
+        ws["dmod32"] by the block kernels.  extra_demb: f32 [>= B, E] further gradient of the time embedding (DDT's decoder)"""
         d, w, sh = self.d, self.ws, self.sh
         B, _, _, _, _, _, M, _, _ = self.geo
         D, E = d.inner_dim, d.embedding_dim
         dmod = w["dmod32"]
         # stem: conv_proj weight gradient (no gradient flows to the input latents)
         Fi = d.input_channels * d.patch_size**2
-        gc = self.G("conv_proj.weight").view(D, Fi)
+        gc = self.G(self._conv_name).view(D, Fi)
         if Fi % 8 == 0:
             ops.gemm_tn(dx, w["tokP"], gc, M=D, N=Fi)
         else:
@@ -563,6 +565,9 @@ class DiTEngine:
         table = d.n_classes is not None
         ops.cond_combine_bwd(w["dse"][:B], w["emb"][:B], self._yeff if table else None, w["demb"][:B], w["demb16"][:B],
                              self.G("label_embed.embedding.weight") if table else None)
+        if extra_demb is not None:
+            w["demb"][:B].add_(extra_demb[:B])
+            ops.cast_f32_to_bf16(w["demb"][:B], w["demb16"][:B])
         ops.colsum(w["demb"], self.G("time_embed.2.bias"), B, E)
         ops.gemm_tn(w["demb16"], w["h1"], self.G("time_embed.2.weight"))
         ops.gemm_nt(w["demb16"], sh["time_embed.2.weight|t"], w["dh1"], M=B, N=E, K=E)

@@ -1,4 +1,4 @@
-from .denoisers import Denoiser, MMDiT, ModelInput, ModelOutput, SprintDiT
+from .denoisers import DDT, Denoiser, MMDiT, ModelInput, ModelOutput, SprintDiT
 from .embedders import ContextEmbedder, PrecomputedEmbedder
 
-__all__ = ["Denoiser", "MMDiT", "ModelInput", "ModelOutput", "SprintDiT", "ContextEmbedder", "PrecomputedEmbedder"]
+__all__ = ["DDT", "Denoiser", "MMDiT", "ModelInput", "ModelOutput", "SprintDiT", "ContextEmbedder", "PrecomputedEmbedder"]

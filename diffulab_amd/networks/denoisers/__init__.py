@@ -1,6 +1,7 @@
 from .common import Denoiser, ModelInput, ModelOutput
+from .ddt import DDT
 from .mmdit import MMDiT
 from .sprint import SprintDiT
 from .unet import UNetModel
 
-__all__ = ["Denoiser", "MMDiT", "ModelInput", "ModelOutput", "SprintDiT", "UNetModel"]
+__all__ = ["DDT", "Denoiser", "MMDiT", "ModelInput", "ModelOutput", "SprintDiT", "UNetModel"]

@@ -184,6 +184,24 @@ def ln_modulate_bwd(dout, x, w, b, scale, rows_per_mod, mean, rstd, dres, dx, ds
           gate.stride(0) if gate is not None else 0, _p(dt), _p(dgate), M, D, _s())
 
 
+def ln_modulate_bwd_tok(dout, x, w, b, scale, mean, rstd, dres, dx, dscale, dshift, dwb_partial, gate_t=None, gate=None, dt=None,
+                        dgate=None):
+    """per-token modulation: scale / gate rows per token; dscale / dshift / dgate bf16 row windows written per token"""
+    M, D = x.shape
+    assert dscale.dtype == torch.bfloat16 and dshift.stride(0) == dscale.stride(0)
+    _call("dl_ln_modulate_bwd_tok", _p(dout), _p(x), _p(w), _p(b), _p(scale), scale.stride(0), _p(mean), _p(rstd), _p(dres), _p(dx),
+          _p(dscale), _p(dshift), dscale.stride(0), _p(dwb_partial), dwb_partial.shape[0] if dwb_partial is not None else 0,
+          _p(gate_t), _p(gate), gate.stride(0) if gate is not None else 0, _p(dt), _p(dgate), M, D, _s())
+
+
+def ddt_cond_fwd(enc, temb, B, N, out):
+    _call("dl_ddt_cond_fwd", _p(enc), enc.stride(0), _p(temb), temb.stride(0), B, N, out.shape[1], _p(out), _s())
+
+
+def ddt_cond_bwd(dsz, enc, temb, B, N, denc, dtemb):
+    _call("dl_ddt_cond_bwd", _p(dsz), _p(enc), enc.stride(0), _p(temb), temb.stride(0), B, N, dsz.shape[1], _p(denc), _p(dtemb), _s())
+
+
 def gate_bwd(dout, t, gate, rows_per_mod, dt, dgate):
     M, D = dout.shape
     _call("dl_gate_bwd", _p(dout), _p(t), _p(gate), gate.stride(0), rows_per_mod, _p(dt), _p(dgate), dgate.stride(0), M,

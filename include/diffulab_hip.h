@@ -156,6 +156,22 @@ DL_API int dl_ln_modulate_bwd(const void* dout, const void* x, const float* w, c
                               const void* dres, void* dx, float* dscale, float* dshift, int64_t ld_dmod,
                               float* dwb_partial, const void* gate_t, const void* gate, int64_t ld_gate, void* dt,
                               float* dgate, int64_t M, int64_t D, dl_stream_t stream);
+/* dl_ln_modulate_bwd for PER-TOKEN modulation (DDT decoder, ddt.py:423-424,455-457: Modulation on [B, S, D]): scale / gate have
+ * one row per token (row stride ld_mod / ld_gate); dscale / dshift / dgate are bf16 rows WRITTEN per token (row stride ld_dmod:
+ * windows of the [tokens, mod_rows] modulation-gradient matrix); dwb_partial f32 [n_part, 2, D] accumulates the affine
+ * gradients (NULL with w == NULL), folded by dl_reduce_rows_f32. */
+DL_API int dl_ln_modulate_bwd_tok(const void* dout, const void* x, const float* w, const float* b, const void* scale,
+                                  int64_t ld_mod, const float* mean, const float* rstd, const void* dres, void* dx, void* dscale,
+                                  void* dshift, int64_t ld_dmod, float* dwb_partial, int64_t n_part, const void* gate_t,
+                                  const void* gate, int64_t ld_gate, void* dt, void* dgate, int64_t M, int64_t D,
+                                  dl_stream_t stream);
+/* DDT decoder conditioning (ddt.py:423-424 followed by the SiLU of Modulation / adaLN_modulation, nn.py:530, mmdit.py:543):
+ * out[m, :] = silu(silu(enc[m, :] + temb[m / N, :])) (bf16 rows, the operand of the stacked per-token adaLN GEMM); backward:
+ * denc = dout * d(silu o silu), dtemb[b, :] += sum over the N tokens of sample b (f32, atomically accumulated) */
+DL_API int dl_ddt_cond_fwd(const void* enc, int64_t ld, const float* temb, int64_t ld_t, int64_t B, int64_t N, int64_t D, void* out,
+                           dl_stream_t stream);
+DL_API int dl_ddt_cond_bwd(const void* dsz, const void* enc, int64_t ld, const float* temb, int64_t ld_t, int64_t B, int64_t N,
+                           int64_t D, void* denc, float* dtemb, dl_stream_t stream);
 /* x_new = x + gate * t backward (mmdit.py:296-307): dt = gate * dout (bf16) ; dgate[g,:] = sum_{m in g} dout * t (f32,
  * written, row stride ld_dmod) */
 DL_API int dl_gate_bwd(const void* dout, const void* t, const void* gate, int64_t ld_mod, int64_t rows_per_mod,
