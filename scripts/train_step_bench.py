@@ -3,6 +3,7 @@
     python scripts/train_step_bench.py s2 --batch 256       # the headline DiT-S/2 workload (same step as bench.py)
     python scripts/train_step_bench.py repa --batch 128     # DiT-B/REPA dims (768/12 heads/12 blocks, 32x8x8 latents) + REPA loss
     python scripts/train_step_bench.py sprint --batch 32    # configs/model/sprint.yaml (512/8, 2+8+2 blocks, 75 % of the tokens skip the deep blocks)
+    python scripts/train_step_bench.py ddt --batch 256      # configs/model/ddt.yaml (512/8, 8 encoder + 4 per-token-conditioned decoder blocks)
     python scripts/train_step_bench.py dit12 --batch 32     # the same 12 blocks without token dropping (what SPRINT is compared with)
     python scripts/train_step_bench.py joint --batch 16     # joint text-image MMDiT: 768/12 heads, 12 MMDiTBlocks, 128x32x32 latents at patch 1
                                                             # (1024 image tokens) + 128 text tokens of width 1024, ragged key mask
@@ -20,7 +21,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from diffulab_amd import Diffuser, MMDiT, SprintDiT  # noqa: E402
+from diffulab_amd import DDT, Diffuser, MMDiT, SprintDiT  # noqa: E402
 from diffulab_amd.training import FusedAdamW  # noqa: E402
 from diffulab_amd.training.losses import RepaLoss  # noqa: E402
 
@@ -37,6 +38,8 @@ CFG["dit12"] = (dict(CFG["cifar"][0], depth=12), (3, 32, 32))
 SPRINT = dict(input_channels=3, output_channels=3, inner_dim=512, embedding_dim=512, num_heads=8, mlp_ratio=4, patch_size=2,
               encoder_depth=2, deep_layers_depth=8, decoder_depth=2, n_classes=10, classifier_free=False, drop_rate=0.75)
 CFG["sprint"] = (SPRINT, (3, 32, 32))
+CFG["ddt"] = (dict(input_channels=3, output_channels=3, inner_dim=512, num_heads=8, mlp_ratio=4, patch_size=2, encoder_depth=8,
+                   decoder_depth=4, n_classes=10, classifier_free=False), (3, 32, 32))
 JOINT = dict(input_channels=128, output_channels=128, inner_dim=768, embedding_dim=768, num_heads=12, mlp_ratio=4, patch_size=1,
              depth=12, classifier_free=True, rope_base=2000, rope_axes_dim=[16, 24, 24])
 CFG["joint"] = (JOINT, (128, 32, 32))
@@ -66,6 +69,8 @@ def main() -> None:
         m = cls(simple_dit=False, context_embedder=PrecomputedEmbedder(torch.randn(1, Lc, Cd), 7), **kw).to(dev)
         keep = torch.arange(Lc, device=dev)[None, :] < torch.randint(8, Lc + 1, (a.batch, 1), device=dev)
         ctx = {"embeddings": torch.randn(a.batch, Lc, Cd, device=dev, dtype=torch.bfloat16), "attn_mask": keep}
+    elif a.config == "ddt":
+        m = DDT(simple_ddt=True, **kw).to(dev)
     else:
         m = (SprintDiT if a.config == "sprint" else MMDiT)(simple_dit=True, **kw).to(dev)
     extra, params = [], list(m.parameters())
