@@ -327,19 +327,47 @@ class UNetEngine:
         ops.gemm_nt(cols, self.sh[name + "|f"], out, bias=bias, resid=resid, M=M, N=co, K=ldk)
         return out
 
+    def _off_chain(self, fn, *tensors: Tensor) -> None:
+        """run `fn` (launches whose results nothing downstream in the backward reads: bias / weight gradients) on the side HIP
+        stream, after everything issued so far on the main stream; `tensors` are the main-stream buffers it reads (kept from being
+        recycled by the allocator until the side stream is past them).  DL_UNET_SIDE=0 keeps everything on one stream."""
+        if not self._use_side:
+            fn()
+            return
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        ev = main.record_event()
+        for t in tensors:
+            t.record_stream(side)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            fn()
+
+    def _side_stream(self) -> "torch.cuda.Stream":
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
+
+    @property
+    def _use_side(self) -> bool:
+        return os.environ.get("DL_UNET_SIDE", "1") != "0"
+
     def _conv3_bwd(self, dy: Tensor, x: Tensor, B: int, H: int, W: int, ci: int, name: str, co: int,
                    need_dx: bool = True) -> Tensor | None:
         M = B * H * W
         Mp, ldk, co8 = _rup(M, 64), _rup(9 * ci, 64), _rup(co, 8)
-        ops.colsum(dy, self.Gr(name[:-6] + "bias"), M, co)
         dyp = self._padded(dy, Mp, co8)
-        g = self._scr("wg", ldk * co8, torch.float32).view(ldk, co8)  # transposed: 9*Ci rows fit the 384-row wgrad tiles
-        g.zero_()
-        if not ops.conv3x3_wgrad_tn(x, B, H, W, ci, dyp, co8, g, self._zero):
-            cols = self._scr("cols", Mp * ldk).view(Mp, ldk)
-            ops.im2col3x3(x, cols, B, H, W, ci)
-            ops.gemm_tn(cols, dyp, g, M=ldk, N=co8)
-        ops.conv3x3_wgrad_fold(g, self.Gr(name))
+
+        def wgrad() -> None:  # bias + weight gradient: off the dependency chain of the backward
+            ops.colsum(dy, self.Gr(name[:-6] + "bias"), M, co)
+            g = self._new(ldk, co8, dtype=torch.float32, zero=True)  # transposed: 9*Ci rows fit the 384-row wgrad tiles
+            if not ops.conv3x3_wgrad_tn(x, B, H, W, ci, dyp, co8, g, self._zero):
+                cols = self._new(Mp, ldk)
+                ops.im2col3x3(x, cols, B, H, W, ci)
+                ops.gemm_tn(cols, dyp, g, M=ldk, N=co8)
+            ops.conv3x3_wgrad_fold(g, self.Gr(name))
+
+        self._off_chain(wgrad, dy, dyp, x)
         if not need_dx:
             return None
         dx = self._new(M, ci)
@@ -362,9 +390,13 @@ class UNetEngine:
     def _lin_bwd(self, dy: Tensor, x: Tensor, name: str, co: int, ci: int, need_dx: bool = True) -> Tensor | None:
         M = dy.shape[0]
         Mp = _rup(M, 64)
-        ops.colsum(dy, self.Gr(name[:-6] + "bias"), M, co)
         dyp, xp = self._padded(dy, Mp, dy.shape[1]), self._padded(x, Mp, x.shape[1])
-        ops.gemm_tn(dyp, xp, self.Gr(name).view(co, ci), M=co, N=ci)
+
+        def wgrad() -> None:
+            ops.colsum(dy, self.Gr(name[:-6] + "bias"), M, co)
+            ops.gemm_tn(dyp, xp, self.Gr(name).view(co, ci), M=co, N=ci)
+
+        self._off_chain(wgrad, dy, dyp, xp)
         if not need_dx:
             return None
         K = _rup(co, 64)
@@ -607,6 +639,8 @@ class UNetEngine:
         ops.silu_bwd(dh1, s["pre1"][:B], dpre1[:B])
         ops.gemm_tn(dpre1, s["temb"], self.Gr("time_embed.0.weight"), M=te, N=mc)
         ops.colsum(dpre1, self.Gr("time_embed.0.bias"), B, te)
+        if self._use_side:
+            torch.cuda.current_stream().wait_stream(self._side_stream())
         if self.reducer is not None:
             self.reducer.ready(0, self.layout.size)
             self.reducer.finish()
