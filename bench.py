@@ -270,6 +270,7 @@ def main() -> None:
         }
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()  # rank 0 was still replaying / printing: tear the communicator down together
         dist.destroy_process_group()
 
 
