@@ -55,3 +55,48 @@ def ddt_forward(P: dict[str, Tensor], x: Tensor, t: Tensor, y_eff: Tensor | None
     for i in range(cfg.decoder_depth):
         dec = odit.dit_block(P, f"decoder_layers.{i}.", dec, z, cos, sin, cfg)
     return odit.unpatchify(odit.last_layer(P, dec, z, cfg), gh, gw, cfg)
+
+
+# ------------------------------------------------------------------------------------------------ joint-encoder form
+from . import mmdit as ommdit  # noqa: E402
+
+
+@dataclass
+class DDTJointConfig(ommdit.JointConfig):
+    encoder_depth: int = 8
+    decoder_depth: int = 4
+
+    def __post_init__(self) -> None:
+        self.embedding_dim = self.inner_dim
+        super().__post_init__()
+
+
+def joint_param_shapes(cfg: DDTJointConfig) -> dict[str, tuple[int, ...]]:
+    """state_dict layout of DDT(simple_ddt=False) with a one-output context embedder and n_single_stream_blocks = 0"""
+    kw = {k: getattr(cfg, k) for k in ommdit.JointConfig.__dataclass_fields__}
+    enc = ommdit.param_shapes(ommdit.JointConfig(**{**kw, "depth": cfg.encoder_depth}))
+    dit = odit.param_shapes(odit.DiTConfig(**{**{k: getattr(cfg, k) for k in odit.DiTConfig.__dataclass_fields__}, "depth": 1,
+                                               "n_classes": None}))
+    s = {k: v for k, v in enc.items() if k != "conv_proj.weight"}
+    s["conv_proj_encoder.weight"] = s["conv_proj_decoder.weight"] = enc["conv_proj.weight"]
+    for i in range(cfg.decoder_depth):
+        s.update({f"decoder_layers.{i}." + k[len("layers.0."):]: v for k, v in dit.items() if k.startswith("layers.0.")})
+    return s
+
+
+def ddt_joint_forward(P: dict[str, Tensor], x: Tensor, t: Tensor, ctx: Tensor, keep: Tensor | None, cfg: DDTJointConfig) -> Tensor:
+    """ddt.py:274-344 (encode_mmddt) + :404-464 (decode) with the context already through the embedder"""
+    enc_in, gh, gw = odit.patchify({"conv_proj.weight": P["conv_proj_encoder.weight"]}, x, cfg)
+    dec, _, _ = odit.patchify({"conv_proj.weight": P["conv_proj_decoder.weight"]}, x, cfg)
+    emb = odit.cond_embedding(P, t, None, cfg)
+    c = ctx @ P["context_embed.weight"].t()
+    Lc = c.shape[1]
+    cos, sin = ommdit.rope_tables_joint(Lc, gh, gw, cfg.rope_axes_dim, cfg.rope_base)
+    h = enc_in
+    for i in range(cfg.encoder_depth):
+        h, c = ommdit.joint_block(P, f"layers.{i}.", h, c, emb, cos, sin, keep, cfg)
+    z = odit.silu(h + emb[:, None, :])
+    ci, si = cos[Lc:], sin[Lc:]  # decoder position ids (0, h, w) = the image rows of the joint table
+    for i in range(cfg.decoder_depth):
+        dec = odit.dit_block(P, f"decoder_layers.{i}.", dec, z, ci, si, cfg)
+    return odit.unpatchify(odit.last_layer(P, dec, z, cfg), gh, gw, cfg)

@@ -764,9 +764,59 @@ def gen_ddt() -> None:
     save("ddt", **o)
 
 
+# ------------------------------------------------------------------ (xv) DDT with the joint text-image encoder
+DDT_JOINT = dict(input_channels=4, output_channels=4, inner_dim=128, num_heads=2, mlp_ratio=4, patch_size=2, encoder_depth=2,
+                 decoder_depth=2, rope_axes_dim=[16, 24, 24], rope_base=1000, classifier_free=True)
+
+
+def gen_ddt_joint() -> None:
+    """DDT(simple_ddt=False) behind the reference PrecomputedEmbedder (configs/train_imagenet_repa_txt_to_img.yaml at small width)"""
+    import importlib
+    import tempfile
+
+    from oracle import ddt as oddt
+
+    PE = importlib.import_module("diffulab.networks.embedders.precomputed").PrecomputedEmbedder
+    DDT = importlib.import_module("diffulab.networks.denoisers.ddt").DDT
+    Lc, Cd, B, H = 64, 96, 4, 16
+    null = synth.normal("dj.null", (1, Lc, Cd)) * 0.5
+    with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+        torch.save(null, f.name)
+        emb = PE(f.name, null_embedding_seq_len=7)
+    m = DDT(simple_ddt=False, context_embedder=emb, **DDT_JOINT)
+    cfg = oddt.DDTJointConfig(context_dim=Cd, **DDT_JOINT)
+    shapes = oddt.joint_param_shapes(cfg)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == shapes, set(m.state_dict()) ^ set(shapes)
+    m.load_state_dict(synth.dit_params(shapes, seed=101))
+    x = synth.normal("dj.x", (B, 4, H, H))
+    t = synth.uniform("dj.t", (B,), lo=0.05, hi=0.95)
+    ctx = synth.normal("dj.ctx", (B, Lc, Cd))
+    keep = torch.arange(Lc)[None, :] < torch.tensor([64, 20, 41, 5])[:, None]
+    dy = synth.normal("dj.dy", (B, 4, H, H))
+    ic = {"embeddings": ctx, "attn_mask": keep}
+    o = {}
+    m.train()
+    pred = m(x=x, timesteps=t, initial_context=ic, p=0.0)["x"]
+    o["pred"] = pred
+    (pred * dy).sum().backward()
+    big = ("context_embed.weight", "conv_proj_decoder.weight", "layers.0.attention.qkv_context.weight", "layers.1.mlp_input.0.weight",
+           "decoder_layers.0.modulation.lin.weight", "decoder_layers.1.attention.qkv.weight", "decoder_layers.1.mlp_input.2.weight",
+           "last_layer.adaLN_modulation.1.weight")
+    for n, p in m.named_parameters():
+        if p.grad is not None and (p.numel() <= 16384 or n in big):
+            o["g_" + n] = p.grad.clone()
+    o["none"] = np.array(sorted(n for n, p in m.named_parameters() if p.grad is None))
+    torch.manual_seed(2)
+    with _RandRecorder() as r, torch.no_grad():
+        o["b_pred"] = m(x=x, timesteps=t, initial_context=ic, p=0.5)["x"]
+    assert 0 < int((r.draws[0] < 0.5).sum()) < B
+    o["b_u"] = r.draws[0]
+    save("ddt_joint", **o)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve", "repa", "resampler", "sprint", "mmdit_joint", "sprint_joint", "ddt"]
-    fns = {"repa": gen_repa, "resampler": gen_resampler, "sprint": gen_sprint, "mmdit_joint": gen_mmdit_joint, "sprint_joint": gen_sprint_joint, "ddt": gen_ddt, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
+    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve", "repa", "resampler", "sprint", "mmdit_joint", "sprint_joint", "ddt", "ddt_joint"]
+    fns = {"repa": gen_repa, "resampler": gen_resampler, "sprint": gen_sprint, "mmdit_joint": gen_mmdit_joint, "sprint_joint": gen_sprint_joint, "ddt": gen_ddt, "ddt_joint": gen_ddt_joint, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
            "s2": gen_s2_model, "samplers": gen_samplers, "curve": gen_loss_curve, "unet": gen_unet}
     for w in which:
         print("==", w)

@@ -553,3 +553,36 @@ def test_ddt_simple(golden):
             vc, vu = oddt.ddt_forward(P, xs, tt, y, cfg), oddt.ddt_forward(P, xs, tt, torch.full_like(y, 10), cfg)
             xs = xs - (vu + 2.0 * (vc - vu)) * (a - b)
         assert rel(xs, g["loop_x"]) < 1e-5
+
+
+def test_ddt_joint_encoder(golden):
+    """(xv) DDT(simple_ddt=False): joint text-image encoder blocks, per-token-conditioned decoder on the 3-axis image RoPE rows"""
+    from oracle import ddt as oddt
+    from oracle import mmdit as ommdit
+
+    raw = golden("ddt_joint")
+    none = set(str(n) for n in raw["none"])
+    g = {k: torch.as_tensor(v) for k, v in raw.items() if k != "none"}
+    kw = dict(input_channels=4, output_channels=4, inner_dim=128, num_heads=2, mlp_ratio=4, patch_size=2, encoder_depth=2,
+              decoder_depth=2, rope_axes_dim=[16, 24, 24], rope_base=1000, classifier_free=True)
+    cfg = oddt.DDTJointConfig(context_dim=96, **kw)
+    P = {k: v.requires_grad_(True) for k, v in synth.dit_params(oddt.joint_param_shapes(cfg), seed=101).items()}
+    Lc, Cd, B, H = 64, 96, 4, 16
+    null, null_keep = (synth.normal("dj.null", (1, Lc, Cd)) * 0.5)[0], torch.arange(Lc) < 7
+    x, t = synth.normal("dj.x", (B, 4, H, H)), synth.uniform("dj.t", (B,), lo=0.05, hi=0.95)
+    ctx = synth.normal("dj.ctx", (B, Lc, Cd))
+    keep = torch.arange(Lc)[None, :] < torch.tensor([64, 20, 41, 5])[:, None]
+    dy = synth.normal("dj.dy", (B, 4, H, H))
+    pred = oddt.ddt_joint_forward(P, x, t, ctx, keep, cfg)
+    assert rel(pred, g["pred"]) < 2e-6
+    (pred * dy).sum().backward()
+    checked = 0
+    for n, v in P.items():
+        if "g_" + n in g:
+            assert rel(v.grad, g["g_" + n]) < 2e-5, n
+            checked += 1
+        assert (v.grad is None) == (n in none), n
+    assert checked > 50
+    with torch.no_grad():
+        c2, k2 = ommdit.drop_context(ctx, keep, null, null_keep, g["b_u"] < 0.5)
+        assert rel(oddt.ddt_joint_forward(P, x, t, c2, k2, cfg), g["b_pred"]) < 2e-6
