@@ -9,6 +9,7 @@
                                                             # (1024 image tokens) + 128 text tokens of width 1024, ragged key mask
     python scripts/train_step_bench.py sprint_joint --batch 16  # configs/train_imagenet_repa_txt_to_img_sprint.yaml: 768/12, 2 joint encoder +
                                                             # 8 single-stream deep (256 of 1024 image tokens) + 2 joint decoder blocks
+    python scripts/train_step_bench.py ddt_joint --batch 16    # configs/train_imagenet_repa_txt_to_img.yaml: 640/10 heads, 8 joint encoder + 4 decoder blocks
     python scripts/train_step_bench.py repa_rs --batch 128  # same + the Perceiver resampler (configs/train_imagenet_flow_matching_repa.yaml)
 """
 import argparse
@@ -47,6 +48,8 @@ SPRINT_JOINT = dict(input_channels=128, output_channels=128, inner_dim=768, embe
                     encoder_depth=2, deep_layers_depth=8, n_single_stream_blocks=8, decoder_depth=2, classifier_free=True,
                     rope_base=2000, rope_axes_dim=[16, 24, 24])
 CFG["sprint_joint"] = (SPRINT_JOINT, (128, 32, 32))
+CFG["ddt_joint"] = (dict(input_channels=128, output_channels=128, inner_dim=640, num_heads=10, mlp_ratio=4, patch_size=1, encoder_depth=8,
+                         decoder_depth=4, classifier_free=True, rope_base=1000, rope_axes_dim=[20, 22, 22]), (128, 32, 32))
 RS = dict(depth=3, dim=1024, head_dim=64, num_heads=8, ff_mult=4, num_latents=256)
 
 
@@ -61,12 +64,15 @@ def main() -> None:
     kw, shape = CFG[a.config]
     torch.manual_seed(0)
     ctx = None
-    if a.config in ("joint", "sprint_joint"):
+    if a.config in ("joint", "sprint_joint", "ddt_joint"):
         from diffulab_amd.networks.embedders import PrecomputedEmbedder
 
         Lc, Cd = 128, 1024
-        cls = MMDiT if a.config == "joint" else SprintDiT
-        m = cls(simple_dit=False, context_embedder=PrecomputedEmbedder(torch.randn(1, Lc, Cd), 7), **kw).to(dev)
+        emb = PrecomputedEmbedder(torch.randn(1, Lc, Cd), 7)
+        if a.config == "ddt_joint":
+            m = DDT(simple_ddt=False, context_embedder=emb, **kw).to(dev)
+        else:
+            m = (MMDiT if a.config == "joint" else SprintDiT)(simple_dit=False, context_embedder=emb, **kw).to(dev)
         keep = torch.arange(Lc, device=dev)[None, :] < torch.randint(8, Lc + 1, (a.batch, 1), device=dev)
         ctx = {"embeddings": torch.randn(a.batch, Lc, Cd, device=dev, dtype=torch.bfloat16), "attn_mask": keep}
     elif a.config == "ddt":
