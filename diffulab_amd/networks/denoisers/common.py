@@ -176,17 +176,32 @@ class FlatArenaDenoiser(Denoiser):
             return (pred, *(eng.feature(k).clone() for k in taps))
         return self._infer(eng, x, t, y_eff)
 
+    # hooks of the hipGraph replay for denoisers whose launch sequence reads further per-call state held on the engine
+    def _graph_key(self, eng) -> tuple | None:
+        """hashable part of the capture key beyond the input shapes; None: this call cannot be replayed (run it eagerly)"""
+        return ()
+
+    def _graph_inputs(self, eng) -> tuple:
+        """further per-call input tensors the launch sequence reads through the engine (entries may be None)"""
+        return ()
+
+    def _graph_set_inputs(self, eng, tensors: tuple) -> None:
+        """point the engine at `tensors` (the static copies a captured graph reads)"""
+
     def _infer(self, eng, x: Tensor, t: Tensor, y_eff: Tensor | None) -> Tensor:
         """inference forward: the engine's launch sequence is static per input shape, so it is captured once into a hipGraph
         and replayed (sampler loops at small batch are launch-bound: ~110 launches per DiT-S forward).  DL_HIPGRAPH=0
         disables the capture."""
-        if os.environ.get("DL_HIPGRAPH", "1") == "0":
+        extra = self._graph_key(eng)
+        if os.environ.get("DL_HIPGRAPH", "1") == "0" or extra is None:
             return eng.forward(x, t, y_eff, train=False).clone()
         graphs = self.__dict__.get("_graphs")
         if graphs is None:
             graphs = {}
             object.__setattr__(self, "_graphs", graphs)
-        key = (id(eng), tuple(x.shape), y_eff is not None)
+        ins = self._graph_inputs(eng)
+        key = (id(eng), tuple(x.shape), y_eff is not None, extra,
+               tuple(None if i is None else (tuple(i.shape), i.dtype) for i in ins))
         ent = graphs.get(key)
         if ent is None:
             out = eng.forward(x, t, y_eff, train=False).clone()  # eager: allocates workspaces / tables, refreshes the shadows
@@ -195,23 +210,29 @@ class FlatArenaDenoiser(Denoiser):
             with torch.inference_mode(False), torch.no_grad():
                 xs, ts = x.detach().clone(), t.detach().clone()
                 ys = y_eff.detach().clone() if y_eff is not None else None
+                statics = tuple(None if i is None else i.detach().clone() for i in ins)
+                self._graph_set_inputs(eng, statics)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 try:
                     with torch.cuda.graph(g):
                         out_s = eng.forward(xs, ts, ys, train=False, refresh=False)
-                    graphs[key] = (g, xs, ts, ys, out_s)
+                    graphs[key] = (g, xs, ts, ys, out_s, statics)
                 except Exception as e:  # capture refused: stay eager for this shape (and say so once)
                     logging.warning("hipGraph capture of the inference forward failed (%s): running eagerly", e)
                     graphs[key] = False
             return out
         if ent is False:
             return eng.forward(x, t, y_eff, train=False).clone()
-        g, xs, ts, ys, out_s = ent
+        g, xs, ts, ys, out_s, statics = ent
         eng.refresh_shadows()
         xs.copy_(x)
         ts.copy_(t)
         if ys is not None:
             ys.copy_(y_eff)
+        for st, cur in zip(statics, ins):
+            if st is not None:
+                st.copy_(cur)
+        self._graph_set_inputs(eng, statics)
         g.replay()
         return out_s.clone()

@@ -119,10 +119,12 @@ class DDT(FlatArenaDenoiser):
     def _make_engine(self, device: torch.device):
         return DDTEngine(self.dims, device) if self.simple_ddt else DDTJointEngine(self.dims, device)
 
-    def _infer(self, eng, x: Tensor, t: Tensor, y_eff: Tensor | None) -> Tensor:
-        if self.simple_ddt:
-            return super()._infer(eng, x, t, y_eff)
-        return eng.forward(x, t, None, train=False).clone()  # eager: the context tensors are inputs of the launch sequence
+    def _graph_inputs(self, eng) -> tuple:  # (the context tensors are per-call inputs of the joint launch sequence)
+        return () if self.simple_ddt else tuple(eng.context)
+
+    def _graph_set_inputs(self, eng, tensors: tuple) -> None:
+        if not self.simple_ddt:
+            eng.context = tuple(tensors)
 
     def forward(
         self,

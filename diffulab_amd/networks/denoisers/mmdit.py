@@ -226,10 +226,13 @@ class MMDiT(FlatArenaDenoiser):
     def _make_engine(self, device: torch.device) -> DiTEngine:
         return DiTEngine(self.dims, device) if self.simple_dit else JointEngine(self.dims, device)
 
-    def _infer(self, eng, x: Tensor, t: Tensor, y_eff: Tensor | None) -> Tensor:
-        if self.simple_dit:
-            return super()._infer(eng, x, t, y_eff)
-        return eng.forward(x, t, None, train=False).clone()  # eager: the context tensors are inputs of the launch sequence
+    # the context tensors are per-call inputs of the joint launch sequence: a captured graph reads static copies of them
+    def _graph_inputs(self, eng) -> tuple:
+        return () if self.simple_dit else tuple(eng.context)
+
+    def _graph_set_inputs(self, eng, tensors: tuple) -> None:
+        if not self.simple_dit:
+            eng.context = tuple(tensors)
 
     def _forward_joint(self, x: Tensor, timesteps: Tensor, initial_context: Any, p: float) -> ModelOutput:
         """mmdit.py:789-851: the embedder (context drop for classifier-free guidance) stays host-side torch"""

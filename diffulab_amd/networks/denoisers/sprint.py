@@ -199,8 +199,18 @@ class SprintDiT(FlatArenaDenoiser):
             self._eval_routes[key] = r
         return r
 
-    def _infer(self, eng, x: Tensor, t: Tensor, y_eff: Tensor | None) -> Tensor:  # eager (the routing is an input of the sequence)
-        return eng.forward(x, t, y_eff, train=False).clone()
+    # hipGraph replay: an eval-mode routing without a random path drop is one of the cached Route objects (persistent tensors),
+    # so it is part of the capture key; a routing drawn for this call (0 < p < 1) runs eagerly
+    def _graph_key(self, eng) -> tuple | None:
+        r = eng.route
+        return (id(r), r.skip_deep) if any(r is c for c in self._eval_routes.values()) else None
+
+    def _graph_inputs(self, eng) -> tuple:
+        return () if self.simple_dit else tuple(eng.context)
+
+    def _graph_set_inputs(self, eng, tensors: tuple) -> None:
+        if not self.simple_dit:
+            eng.context = tuple(tensors)
 
     # ------------------------------------------------------------------ forward (sprint.py:575-624)
     def forward(
