@@ -582,8 +582,12 @@ def gen_sprint() -> None:
     assert len(r.draws) == 1 and r.draws[0].shape == (B, 256)
     o["a_scores"], o["a_pred"] = r.draws[0], pred
     (pred * dy).sum().backward()
-    for n, p in m.named_parameters():
-        o["a_g_" + n] = p.grad.clone()
+    big = ("fuse.weight", "conv_proj.weight", "layers.0.attention.qkv.weight", "layers.0.modulation.lin.weight",
+           "deep_layers.0.mlp_input.0.weight", "deep_layers.1.attention.proj_out.weight", "deep_layers.1.mlp_input.2.weight",
+           "decoder_layers.0.attention.qkv.weight", "decoder_layers.0.mlp_input.2.weight", "last_layer.adaLN_modulation.1.weight")
+    for n, p in m.named_parameters():  # every vector / small tensor and one matrix of each kind (the oracle carries the rest)
+        if p.numel() <= 16384 or n in big:
+            o["a_g_" + n] = p.grad.clone()
     m.zero_grad()
     # (b) training step, p = 0.5: label drop + token drop + per-sample path drop (seed chosen so both outcomes occur)
     torch.manual_seed(4)
@@ -755,8 +759,13 @@ def gen_ddt() -> None:
     pred = m(x=x, timesteps=t, y=y, p=0.0)["x"]
     o["pred"] = pred
     (pred * dy).sum().backward()
-    for n, p in m.named_parameters():
-        o["g_" + n] = p.grad.clone()
+    big = ("conv_proj_encoder.weight", "conv_proj_decoder.weight", "layers.0.attention.qkv.weight", "layers.1.mlp_input.0.weight",
+           "layers.1.modulation.lin.weight", "decoder_layers.0.modulation.lin.weight", "decoder_layers.0.attention.proj_out.weight",
+           "decoder_layers.1.attention.qkv.weight", "decoder_layers.1.mlp_input.2.weight", "last_layer.adaLN_modulation.1.weight",
+           "time_embed.2.weight")
+    for n, p in m.named_parameters():  # every vector / small tensor and one matrix of each kind (the oracle carries the rest)
+        if p.numel() <= 16384 or n in big:
+            o["g_" + n] = p.grad.clone()
     m.eval()
     d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=4)
     out = d.generate({"x": synth.normal("dd.init", (B, 4, H, H)), "y": y}, use_tqdm=False, guidance_scale=2.0)
