@@ -268,6 +268,9 @@ class DDTEngine(SprintEngine, PerTokenDecoder):
             with torch.inference_mode(False):
                 return torch.zeros(*shape, device=dev, dtype=dtype)
 
+        def zr(rows, *rest, dtype=bf):  # row buffer: zero rows pad it to a multiple of 64 for the weight-gradient GEMMs
+            return z(_rup(rows, 64), *rest, dtype=dtype)[:rows]
+
         w: dict[str, object] = {"tokP": z(M, self._ki), "temb": z(Bp, d.frequency_embedding), "pre1": z(Bp, E), "h1": z(Bp, E),
                                 "e": z(Bp, E, dtype=f32), "emb": z(Bp, E, dtype=f32), "se": z(Bp, E),
                                 "mod": z(Bp, self.layout.mod_rows)}
@@ -511,7 +514,7 @@ class DDTJointEngine(SprintJointEngine, PerTokenDecoder):
         N = gh * gw
         Tf = Lc + N
         Tpf = _rup(Tf, 256)
-        if Tpf > 2048 or N % 64 or (N > 256 and N % 256) or (B * Lc) % 64 or Lc < 1:
+        if Tpf > 2048 or N % 64 or (N > 256 and N % 256) or Lc < 1:
             raise NotImplementedError(f"joint DDT HIP path: context + image tokens <= 2048 (got {Lc} + {N}), image tokens a multiple of "
                                       "64 up to 256 or of 256 beyond, batch * context tokens a multiple of 64")
         M, Bp, Fo, F = B * N, _rup(B, 64), p * p * d.output_channels, d.mlp_ratio * D
@@ -522,12 +525,15 @@ class DDTJointEngine(SprintJointEngine, PerTokenDecoder):
             with torch.inference_mode(False):
                 return torch.zeros(*shape, device=dev, dtype=dtype)
 
+        def zr(rows, *rest, dtype=bf):  # row buffer: zero rows pad it to a multiple of 64 for the weight-gradient GEMMs
+            return z(_rup(rows, 64), *rest, dtype=dtype)[:rows]
+
         w: dict[str, object] = {"tokP": z(M, self._ki), "temb": z(Bp, d.frequency_embedding), "pre1": z(Bp, E), "h1": z(Bp, E),
                                 "e": z(Bp, E, dtype=f32), "emb": z(Bp, E, dtype=f32), "se": z(Bp, E),
                                 "mod": z(Bp, self.layout.mod_rows)}
-        w["ctxP"] = z(B * Lc, _rup(d.context_dim, 64))
+        w["ctxP"] = zr(B * Lc, _rup(d.context_dim, 64))
         w["x"] = [z(M, D)]
-        w["c0"] = z(B * Lc, D)
+        w["c0"] = zr(B * Lc, D)
         w["kb_f"] = z(B, Tpf, dtype=f32)
         w["kb_f"][:, Tf:] = float("-inf")
         blk = []
@@ -537,11 +543,11 @@ class DDTJointEngine(SprintJointEngine, PerTokenDecoder):
                                           "k": z(B, Hh, Tpf, 64), "v": z(B, Hh, Tpf, 64)}
                 for st, nt in (("input", N), ("context", Lc)):
                     mt = B * nt
-                    a = {"x0": z(mt, D), "mean1": z(mt, dtype=f32), "rstd1": z(mt, dtype=f32), "xm1": z(mt, D), "qkv": z(mt, 3 * D),
-                         "rrms": z(mt, 2, dtype=f32), "a": z(mt, D), "t1": z(mt, D), "x1": z(mt, D), "mean2": z(mt, dtype=f32),
-                         "rstd2": z(mt, dtype=f32), "xm2": z(mt, D), "u": z(mt, 2 * F), "h": z(mt, F), "t2": z(mt, D)}
+                    a = {"x0": zr(mt, D), "mean1": zr(mt, dtype=f32), "rstd1": zr(mt, dtype=f32), "xm1": zr(mt, D), "qkv": zr(mt, 3 * D),
+                         "rrms": zr(mt, 2, dtype=f32), "a": zr(mt, D), "t1": zr(mt, D), "x1": zr(mt, D), "mean2": zr(mt, dtype=f32),
+                         "rstd2": zr(mt, dtype=f32), "xm2": zr(mt, D), "u": zr(mt, 2 * F), "h": zr(mt, F), "t2": zr(mt, D)}
                     if train:
-                        a["wg"] = {"dt2": z(mt, D), "du": z(mt, 2 * F), "dt1": z(mt, D), "dqkv": z(mt, 3 * D)}
+                        a["wg"] = {"dt2": zr(mt, D), "du": zr(mt, 2 * F), "dt1": zr(mt, D), "dqkv": zr(mt, 3 * D)}
                         a["dwb"] = z(2, B, 2, D, dtype=f32)
                     per[st] = a
             else:
@@ -564,7 +570,7 @@ class DDTJointEngine(SprintJointEngine, PerTokenDecoder):
             w["dO"] = z(M, self._ko)
             w[f"s_x{N}"] = {"dxa": z(M, D), "dxb": z(M, D), "dxm": z(M, D), "dxm2": z(M, D), "da": z(M, D), "dh": z(M, F),
                             "dq": z(B, Hh, N, 64), "dk": z(B, Hh, N, 64), "dv": z(B, Hh, N, 64)}
-            w["s_c"] = {"dxa": z(B * Lc, D), "dxb": z(B * Lc, D), "dxm": z(B * Lc, D), "da": z(B * Lc, D), "dh": z(B * Lc, F)}
+            w["s_c"] = {"dxa": zr(B * Lc, D), "dxb": zr(B * Lc, D), "dxm": zr(B * Lc, D), "da": zr(B * Lc, D), "dh": zr(B * Lc, F)}
             w["dao_f"] = z(B * Tpf, D)
             w["dq_f"], w["dk_f"], w["dv_f"] = (z(B, Hh, Tpf, 64) for _ in range(3))
             w["dtmod"] = z(M, R)

@@ -155,9 +155,9 @@ class JointEngine(DiTEngine):
         N = gh * gw
         T = Lc + N
         Tp = _rup(T, 256)
-        if Tp > 2048 or (B * N) % 64 or (B * Lc) % 64 or Lc < 1:
-            raise NotImplementedError(f"joint MMDiT HIP path: context + image tokens <= 2048 (got {Lc} + {N}), batch * tokens of "
-                                      "each stream a multiple of 64")
+        if Tp > 2048 or (B * N) % 64 or Lc < 1:
+            raise NotImplementedError(f"joint MMDiT HIP path: context + image tokens <= 2048 (got {Lc} + {N}), image tokens a "
+                                      "multiple of 64")
         M, Bp, Fo, F = B * N, _rup(B, 64), p * p * d.output_channels, d.mlp_ratio * D
         bf, f32 = torch.bfloat16, torch.float32
 
@@ -165,12 +165,15 @@ class JointEngine(DiTEngine):
             with torch.inference_mode(False):
                 return torch.zeros(*shape, device=dev, dtype=dtype)
 
+        def zr(rows, *rest, dtype=bf):  # row buffer: zero rows pad it to a multiple of 64 for the weight-gradient GEMMs
+            return z(_rup(rows, 64), *rest, dtype=dtype)[:rows]
+
         w: dict[str, object] = {"tokP": z(M, self._ki), "temb": z(Bp, d.frequency_embedding), "pre1": z(Bp, E), "h1": z(Bp, E),
                                 "e": z(Bp, E, dtype=f32), "emb": z(Bp, E, dtype=f32), "se": z(Bp, E),
                                 "mod": z(Bp, self.layout.mod_rows)}
-        w["ctxP"] = z(B * Lc, _rup(d.context_dim, 64))
+        w["ctxP"] = zr(B * Lc, _rup(d.context_dim, 64))
         w["x"] = [z(M, D)]
-        w["c0"] = z(B * Lc, D)
+        w["c0"] = zr(B * Lc, D)
         w["kbias"] = z(B, Tp, dtype=f32)
         w["kbias"][:, T:] = float("-inf")  # padded key rows
         w["q"], w["k"], w["v"] = (z(B, d.num_heads, Tp, 64) for _ in range(3))
@@ -180,11 +183,11 @@ class JointEngine(DiTEngine):
             per = {"ao": z(B * Tp, D), "lse": z(B, d.num_heads, Tp, dtype=f32)}
             for st in STREAMS:
                 mt = B * ntok[st]
-                a = {"x0": z(mt, D), "mean1": z(mt, dtype=f32), "rstd1": z(mt, dtype=f32), "xm1": z(mt, D), "qkv": z(mt, 3 * D),
-                     "rrms": z(mt, 2, dtype=f32), "a": z(mt, D), "t1": z(mt, D), "x1": z(mt, D), "mean2": z(mt, dtype=f32),
-                     "rstd2": z(mt, dtype=f32), "xm2": z(mt, D), "u": z(mt, 2 * F), "h": z(mt, F), "t2": z(mt, D)}
+                a = {"x0": zr(mt, D), "mean1": zr(mt, dtype=f32), "rstd1": zr(mt, dtype=f32), "xm1": zr(mt, D), "qkv": zr(mt, 3 * D),
+                     "rrms": zr(mt, 2, dtype=f32), "a": zr(mt, D), "t1": zr(mt, D), "x1": zr(mt, D), "mean2": zr(mt, dtype=f32),
+                     "rstd2": zr(mt, dtype=f32), "xm2": zr(mt, D), "u": zr(mt, 2 * F), "h": zr(mt, F), "t2": zr(mt, D)}
                 if train:
-                    a["wg"] = {"dt2": z(mt, D), "du": z(mt, 2 * F), "dt1": z(mt, D), "dqkv": z(mt, 3 * D)}
+                    a["wg"] = {"dt2": zr(mt, D), "du": zr(mt, 2 * F), "dt1": zr(mt, D), "dqkv": zr(mt, 3 * D)}
                     a["dwb"] = z(2, B, 2, D, dtype=f32)
                 per[st] = a
             if train:  # q / k / v of every block are kept for the backward
@@ -199,7 +202,7 @@ class JointEngine(DiTEngine):
             w["dO"] = z(M, self._ko)
             for st in STREAMS:
                 mt = B * ntok[st]
-                w["s_" + st] = {"dxa": z(mt, D), "dxb": z(mt, D), "dxm": z(mt, D), "da": z(mt, D), "dh": z(mt, F)}
+                w["s_" + st] = {"dxa": zr(mt, D), "dxb": zr(mt, D), "dxm": zr(mt, D), "da": zr(mt, D), "dh": zr(mt, F)}
             w["dao"] = z(B * Tp, D)
             w["dq"], w["dk"], w["dv"] = (z(B, d.num_heads, Tp, 64) for _ in range(3))
             w["dmod"] = z(Bp, self.layout.mod_rows)

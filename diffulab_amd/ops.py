@@ -156,10 +156,23 @@ def gemm_nt_dswiglu(dt: Tensor, w2t: Tensor, u: Tensor, du: Tensor) -> bool:
     return True
 
 
+def _padded_rows(t: Tensor) -> Tensor:
+    """a row buffer allocated as the leading slice of a zero-padded parent (rows rounded up to 64): the parent"""
+    base = t._base
+    if base is not None and base.dim() == t.dim() and base.shape[1:] == t.shape[1:] and base.data_ptr() == t.data_ptr() \
+            and base.shape[0] == (t.shape[0] + 63) // 64 * 64 and base.stride() == t.stride():
+        return base
+    return t
+
+
 def gemm_tn(a: Tensor, b: Tensor, out: Tensor, *, M: int | None = None, N: int | None = None, max_wgs: int = 0) -> Tensor:
-    """out[M,N] (f32) += a[R,M]^T @ b[R,N].  max_wgs > 0 caps the persistent workgroups (side-stream wgrads)."""
+    """out[M,N] (f32) += a[R,M]^T @ b[R,N].  max_wgs > 0 caps the persistent workgroups (side-stream wgrads).  R must be a
+    multiple of 64: operands that are leading slices of zero-padded row buffers are widened to their parents."""
     M = a.shape[1] if M is None else M
     N = b.shape[1] if N is None else N
+    if a.shape[0] % 64:
+        a, b = _padded_rows(a), _padded_rows(b)
+        assert a.shape[0] == b.shape[0], "gemm_tn operands with a ragged row count must be zero-padded row buffers"
     _call("dl_gemm_tn_ex", _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, a.shape[0], int(max_wgs), _s())
     return out
 

@@ -173,7 +173,7 @@ class SprintJointEngine(DiTEngine):
         N = gh * gw
         Tf, Td = Lc + N, Lc + k
         Tpf, Tpd = _rup(Tf, 256), _rup(Td, 256)
-        if Tpf > 2048 or (B * N) % 64 or (B * Lc) % 64 or (B * k) % 64 or Lc < 1:
+        if Tpf > 2048 or (B * N) % 64 or Lc < 1:
             raise NotImplementedError(f"joint SprintDiT HIP path: context + image tokens <= 2048 (got {Lc} + {N}), batch * tokens of "
                                       f"each stream a multiple of 64 (kept {k})")
         M, Bp, Fo, F = B * N, _rup(B, 64), p * p * d.output_channels, d.mlp_ratio * D
@@ -184,12 +184,15 @@ class SprintJointEngine(DiTEngine):
             with torch.inference_mode(False):
                 return torch.zeros(*shape, device=dev, dtype=dtype)
 
+        def zr(rows, *rest, dtype=bf):  # row buffer: zero rows pad it to a multiple of 64 for the weight-gradient GEMMs
+            return z(_rup(rows, 64), *rest, dtype=dtype)[:rows]
+
         w: dict[str, object] = {"tokP": z(M, self._ki), "temb": z(Bp, d.frequency_embedding), "pre1": z(Bp, E), "h1": z(Bp, E),
                                 "e": z(Bp, E, dtype=f32), "emb": z(Bp, E, dtype=f32), "se": z(Bp, E),
                                 "mod": z(Bp, self.layout.mod_rows)}
-        w["ctxP"] = z(B * Lc, _rup(d.context_dim, 64))
+        w["ctxP"] = zr(B * Lc, _rup(d.context_dim, 64))
         w["x"] = [z(M, D)]
-        w["c0"] = z(B * Lc, D)
+        w["c0"] = zr(B * Lc, D)
         w["kb_f"], w["kb_d"] = z(B, Tpf, dtype=f32), z(B, Tpd, dtype=f32)
         w["kb_f"][:, Tf:] = float("-inf")
         w["kb_d"][:, Td:] = float("-inf")
@@ -203,40 +206,40 @@ class SprintJointEngine(DiTEngine):
             if kind == "J":
                 for st, nt in (("input", nx), ("context", Lc)):
                     mt = B * nt
-                    a = {"x0": z(mt, D), "mean1": z(mt, dtype=f32), "rstd1": z(mt, dtype=f32), "xm1": z(mt, D), "qkv": z(mt, 3 * D),
-                         "rrms": z(mt, 2, dtype=f32), "a": z(mt, D), "t1": z(mt, D), "x1": z(mt, D), "mean2": z(mt, dtype=f32),
-                         "rstd2": z(mt, dtype=f32), "xm2": z(mt, D), "u": z(mt, 2 * F), "h": z(mt, F), "t2": z(mt, D)}
+                    a = {"x0": zr(mt, D), "mean1": zr(mt, dtype=f32), "rstd1": zr(mt, dtype=f32), "xm1": zr(mt, D), "qkv": zr(mt, 3 * D),
+                         "rrms": zr(mt, 2, dtype=f32), "a": zr(mt, D), "t1": zr(mt, D), "x1": zr(mt, D), "mean2": zr(mt, dtype=f32),
+                         "rstd2": zr(mt, dtype=f32), "xm2": zr(mt, D), "u": zr(mt, 2 * F), "h": zr(mt, F), "t2": zr(mt, D)}
                     if train:
-                        a["wg"] = {"dt2": z(mt, D), "du": z(mt, 2 * F), "dt1": z(mt, D), "dqkv": z(mt, 3 * D)}
+                        a["wg"] = {"dt2": zr(mt, D), "du": zr(mt, 2 * F), "dt1": zr(mt, D), "dqkv": zr(mt, 3 * D)}
                         a["dwb"] = z(2, B, 2, D, dtype=f32)
                     per[st] = a
             else:
                 mt = B * Td
-                per.update({"x0": z(mt, D), "mean": z(mt, dtype=f32), "rstd": z(mt, dtype=f32), "m": z(mt, D), "qkv": z(mt, 3 * D),
-                            "rrms": z(mt, 2, dtype=f32), "a": z(mt, D), "ta": z(mt, D), "u": z(mt, 2 * F), "h": z(mt, F), "t": z(mt, D)})
+                per.update({"x0": zr(mt, D), "mean": zr(mt, dtype=f32), "rstd": zr(mt, dtype=f32), "m": zr(mt, D), "qkv": zr(mt, 3 * D),
+                            "rrms": zr(mt, 2, dtype=f32), "a": zr(mt, D), "ta": zr(mt, D), "u": zr(mt, 2 * F), "h": zr(mt, F), "t": zr(mt, D)})
                 if train:
-                    per["wg"] = {"dt": z(mt, D), "du": z(mt, 2 * F), "dqkv": z(mt, 3 * D)}
+                    per["wg"] = {"dt": zr(mt, D), "du": zr(mt, 2 * F), "dqkv": zr(mt, 3 * D)}
                     per["dwb"] = z(1, B, 2, D, dtype=f32)
             blk.append(per)
         w["blk"] = blk
-        w["cat"], w["ccat"] = z(M, 2 * D), z(B * Lc, 2 * D)   # [restored | encoder image], [deep context | encoder context]
-        w["c_enc"] = z(B * Lc, D)
+        w["cat"], w["ccat"] = z(M, 2 * D), zr(B * Lc, 2 * D)   # [restored | encoder image], [deep context | encoder context]
+        w["c_enc"] = zr(B * Lc, D)
         w["xd0"], w["xd_out"] = z(B * k, D), z(B * k, D)
-        w["xj"], w["cj"] = z(B * k, D), z(B * Lc, D)           # outputs of the deep joint sub-stage
-        w["lat0"], w["lat_out"] = z(B * Td, D), z(B * Td, D)
-        w["xfuse"], w["cfuse"], w["xdec"] = z(M, D), z(B * Lc, D), z(M, D)
+        w["xj"], w["cj"] = z(B * k, D), zr(B * Lc, D)           # outputs of the deep joint sub-stage
+        w["lat0"], w["lat_out"] = zr(B * Td, D), zr(B * Td, D)
+        w["xfuse"], w["cfuse"], w["xdec"] = z(M, D), zr(B * Lc, D), z(M, D)
         w["meanf"], w["rstdf"], w["xf"] = z(M, dtype=f32), z(M, dtype=f32), z(M, D)
         w["otok"] = z(M, _rup(Fo, 8), dtype=f32)
         w["pred"] = z(B, d.output_channels, H, W, dtype=f32)
         if train:
             w["dO"] = z(M, self._ko)
             for name, mt in ((f"x{N}", M), (f"x{k}", B * k), ("c", B * Lc), ("l", B * Td)):
-                w["s_" + name] = {"dxa": z(mt, D), "dxb": z(mt, D), "dxm": z(mt, D), "dxm2": z(mt, D), "da": z(mt, D), "dh": z(mt, F)}
+                w["s_" + name] = {"dxa": zr(mt, D), "dxb": zr(mt, D), "dxm": zr(mt, D), "dxm2": zr(mt, D), "da": zr(mt, D), "dh": zr(mt, F)}
             for tag, Tp in (("f", Tpf), ("d", Tpd)):
                 w["dao_" + tag] = z(B * Tp, D)
                 w["dq_" + tag], w["dk_" + tag], w["dv_" + tag] = (z(B, Hh, Tp, 64) for _ in range(3))
-            w["dleft"], w["dright"], w["dcl"], w["dcr"] = z(M, D), z(M, D), z(B * Lc, D), z(B * Lc, D)
-            w["dxd"], w["dlat"], w["dxj"], w["dcj"] = z(B * k, D), z(B * Td, D), z(B * k, D), z(B * Lc, D)
+            w["dleft"], w["dright"], w["dcl"], w["dcr"] = z(M, D), z(M, D), zr(B * Lc, D), zr(B * Lc, D)
+            w["dxd"], w["dlat"], w["dxj"], w["dcj"] = z(B * k, D), zr(B * Td, D), z(B * k, D), zr(B * Lc, D)
             w["dxdec"] = z(M, D)
             w["dmod"] = z(Bp, self.layout.mod_rows)
             w["dmod32"] = z(Bp, self.layout.mod_rows, dtype=f32)

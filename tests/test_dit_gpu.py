@@ -304,3 +304,25 @@ def test_dit_on_1024_tokens_against_oracle():
     assert abs(loss.item() - ref.item()) / ref.item() < 2e-3
     for name, p in m.named_parameters():
         assert rel(p.grad, Pr[name].grad) < 2.5e-2, name
+
+
+@pytest.mark.parametrize("B,H", [(1, 16), (3, 16), (5, 32), (7, 16)])
+def test_ragged_batch_sizes_against_oracle(B, H):
+    """batch sizes that are not multiples of anything (a last partial batch, single-image sampling): forward and every gradient"""
+    from diffulab_amd import MMDiT
+
+    kw = dict(input_channels=4, output_channels=4, inner_dim=128, embedding_dim=64, num_heads=2, mlp_ratio=4, patch_size=2, depth=2,
+              n_classes=10, classifier_free=True)
+    cfg = odit.DiTConfig(**kw)
+    P = synth.dit_params(odit.param_shapes(cfg), seed=5)
+    m = MMDiT(simple_dit=True, **kw)
+    m.load_state_dict(P)
+    m = m.to(DEV)
+    x, t, y = synth.normal(f"e.x{B}", (B, 4, H, H)), synth.uniform(f"e.t{B}", (B,), lo=0.1, hi=0.9), synth.integers(f"e.y{B}", (B,), 10)
+    pred = m(x=x.to(DEV), timesteps=t.to(DEV), y=y.to(DEV))["x"]
+    pred.square().mean().backward()
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    po = odit.dit_forward(Pr, x, t, y, cfg)
+    po.square().mean().backward()
+    assert rel(pred, po) < 1.5e-2
+    assert max(rel(p.grad, Pr[n].grad) for n, p in m.named_parameters()) < 4e-2

@@ -121,3 +121,34 @@ def test_joint_mmdit_context_drop_and_guided_sampling_against_reference_fixture(
     out = d.generate({"x": synth.normal("mj.init", (B, 4, H, H)).to(DEV),
                       "initial_context": {"embeddings": ctx.to(DEV), "attn_mask": keep.to(DEV)}}, use_tqdm=False, guidance_scale=2.0)
     assert rel(out["x"], g["e_loop_x"]) < 3e-2
+
+
+def test_joint_mmdit_ragged_context_length_against_oracle():
+    """77 text tokens, batch 3 (rows of the context stream are not a multiple of 64: zero-padded row buffers feed the weight-gradient
+    GEMMs), no attention mask: prediction and every gradient against the oracle"""
+    from diffulab_amd import MMDiT
+    from diffulab_amd.networks.embedders import PrecomputedEmbedder
+
+    Lr, Br = 77, 3
+    m = MMDiT(simple_dit=False, context_embedder=PrecomputedEmbedder(torch.zeros(1, Lr, Cd), null_embedding_seq_len=5), **KW)
+    cfg = ommdit.JointConfig(context_dim=Cd, **KW)
+    P = synth.dit_params(ommdit.param_shapes(cfg), seed=73)
+    m.load_state_dict(P)
+    m = m.to(DEV)
+    x, t = synth.normal("mr.x", (Br, 4, H, H)), synth.uniform("mr.t", (Br,), lo=0.05, hi=0.95)
+    ctx, dy = synth.normal("mr.ctx", (Br, Lr, Cd)), synth.normal("mr.dy", (Br, 4, H, H))
+    keep = torch.ones(Br, Lr, dtype=torch.bool)
+    m.train()
+    pred = m(x=x.to(DEV), timesteps=t.to(DEV), initial_context={"embeddings": ctx.to(DEV), "attn_mask": keep.to(DEV)}, p=0.0)["x"]
+    (pred * dy.to(DEV)).sum().backward()
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    po = ommdit.mmdit_forward(Pr, x, t, ctx, keep, cfg)
+    assert rel(pred, po) < 1.5e-2
+    (po * dy).sum().backward()
+    bad = []
+    for n, p in m.named_parameters():
+        if Pr[n].grad is None:
+            assert float(p.grad.abs().max()) == 0.0, n
+        elif rel(p.grad, Pr[n].grad) > (8e-2 if p.dim() == 1 else 4e-2):
+            bad.append((n, rel(p.grad, Pr[n].grad)))
+    assert not bad, bad

@@ -324,3 +324,32 @@ def test_sprint_joint_other_deep_stage_mixes_against_oracle(ns):
     (po * dy).sum().backward()
     none = {n for n, v in Pr.items() if v.grad is None}
     _check_grads(m, {n: v.grad for n, v in Pr.items()}, none)
+
+
+def test_sprint_joint_ragged_context_length_against_oracle():
+    """77 text tokens, batch 3, single-stream deep stage on 77 + 64 = 141 latent rows per sample"""
+    from diffulab_amd import SprintDiT
+    from diffulab_amd.networks.embedders import PrecomputedEmbedder
+
+    Lr, Br = 77, 3
+    m = SprintDiT(simple_dit=False, context_embedder=PrecomputedEmbedder(torch.zeros(1, Lr, 96), null_embedding_seq_len=5), **JKW)
+    cfg = osprint.SprintJointConfig(context_dim=96, **JKW)
+    shapes = osprint.joint_param_shapes(cfg)
+    P = synth.dit_params({k: v for k, v in shapes.items() if k != "mask_token"}, seed=83)
+    P["mask_token"] = synth.normal("sr.mask", shapes["mask_token"]) * 0.5
+    m.load_state_dict(P)
+    m = m.to(DEV)
+    x, t = synth.normal("sr.x", (Br, 4, 16, 16)), synth.uniform("sr.t", (Br,), lo=0.05, hi=0.95)
+    ctx, dy = synth.normal("sr.ctx", (Br, Lr, 96)), synth.normal("sr.dy", (Br, 4, 16, 16))
+    keep = torch.arange(Lr)[None, :] < torch.tensor([77, 9, 40])[:, None]
+    scores = synth.uniform("sr.sc", (Br, 256))
+    m.train()
+    _inject(m, scores=scores)
+    pred = m(x=x.to(DEV), timesteps=t.to(DEV), initial_context={"embeddings": ctx.to(DEV), "attn_mask": keep.to(DEV)}, p=0.0)["x"]
+    (pred * dy.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    po = osprint.sprint_mmdit_forward(Pr, x, t, ctx, keep, cfg, kept=osprint.kept_indices(scores, 64))
+    assert rel(pred, po) < 1.5e-2
+    (po * dy).sum().backward()
+    _check_grads(m, {n: v.grad for n, v in Pr.items()}, {n for n, v in Pr.items() if v.grad is None})
