@@ -6,7 +6,9 @@ import torch
 from diffulab_amd import ops
 
 dev = "cuda"
-B, N, D = 256, 256, 384
+B, N, D = 256, 256, int(sys.argv[1]) if len(sys.argv) > 1 else 384   # python scripts/row_kernel_bench.py [D]
+if D > 384:
+    B = 128
 M = B * N
 bf = torch.bfloat16
 x, t = torch.randn(M, D, device=dev).to(bf), torch.randn(M, D, device=dev).to(bf)
@@ -34,3 +36,15 @@ print(f"ln_mod_fwd plain          : {us:7.1f} us  {2 * M * D * 2 / us / 1e6:5.2f
 us = timeit(lambda: ops.ln_modulate_fwd(x, w, b, mod[:, :D], mod[:, D:2 * D], N, 1e-5, out, mean, rstd, t=t,
                                         gate=mod[:, 2 * D:3 * D], x_out=xo))
 print(f"ln_mod_fwd + gated resid  : {us:7.1f} us  {4 * M * D * 2 / us / 1e6:5.2f} TB/s")
+
+# backward (+ the fused backward of the gated residual that follows): dout, x, dres, t in; dx, dt out; f32 accumulators by atomics
+dout, dres = torch.randn(M, D, device=dev).to(bf), torch.randn(M, D, device=dev).to(bf)
+ops.ln_modulate_fwd(x, w, b, mod[:, :D], mod[:, D:2 * D], N, 1e-5, out, mean, rstd)
+dx, dt = torch.empty_like(x), torch.empty_like(x)
+dmod = torch.zeros(B, 6 * D, device=dev)
+dwb = torch.zeros(B, 2, D, device=dev)
+us = timeit(lambda: ops.ln_modulate_bwd(dout, x, w, b, mod[:, :D], N, mean, rstd, dres, dx, dmod[:, :D], dmod[:, D:2 * D], dwb))
+print(f"ln_mod_bwd plain          : {us:7.1f} us  {4 * M * D * 2 / us / 1e6:5.2f} TB/s")
+us = timeit(lambda: ops.ln_modulate_bwd(dout, x, w, b, mod[:, :D], N, mean, rstd, dres, dx, dmod[:, :D], dmod[:, D:2 * D], dwb,
+                                        gate_t=t, gate=mod[:, 2 * D:3 * D], dt=dt, dgate=dmod[:, 2 * D:3 * D]))
+print(f"ln_mod_bwd + gate bwd     : {us:7.1f} us  {6 * M * D * 2 / us / 1e6:5.2f} TB/s")
