@@ -159,3 +159,62 @@ def test_grad_reducer_on_rccl_single_rank():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+class _RangeRecorder:
+    """stands in for training.dp.GradReducer: records the gradient-arena ranges an engine's backward declares final"""
+
+    def __init__(self):
+        self.ranges, self.finished = [], False
+
+    def ready(self, lo, hi, extra_events=()):
+        assert not self.finished
+        self.ranges.append((lo, hi))
+
+    def finish(self):
+        self.finished = True
+
+
+@pytest.mark.parametrize("family", ["dit", "sprint", "ddt", "joint", "sprint_joint", "ddt_joint", "unet"])
+def test_every_engine_hands_the_whole_gradient_arena_to_the_reducer_in_contiguous_descending_ranges(family):
+    """the data-parallel reducer buckets the ranges of one backward into contiguous all-reduces (dp.py:_flush asserts it): every
+    engine must announce [0, size) exactly once, high addresses first (blocks finish in reverse order), then finish()"""
+    import diffulab_amd as da
+    from diffulab_amd.networks.embedders import PrecomputedEmbedder
+
+    torch.manual_seed(0)
+    emb = PrecomputedEmbedder(torch.zeros(1, 64, 96), 7)
+    small = dict(input_channels=4, output_channels=4, inner_dim=128, num_heads=2, mlp_ratio=4, patch_size=2)
+    jk = dict(rope_axes_dim=[16, 24, 24], classifier_free=True)
+    B, H = 4, 16
+    inputs = {"y": torch.randint(0, 10, (B,), device=DEV)}
+    ctx = {"initial_context": {"embeddings": torch.randn(B, 64, 96, device=DEV), "attn_mask": torch.ones(B, 64, dtype=torch.bool, device=DEV)}}
+    if family == "dit":
+        m = da.MMDiT(simple_dit=True, embedding_dim=64, depth=3, n_classes=10, **small)
+    elif family == "sprint":
+        m, H = da.SprintDiT(simple_dit=True, embedding_dim=64, encoder_depth=1, deep_layers_depth=2, decoder_depth=1, n_classes=10, **small), 32
+    elif family == "ddt":
+        m = da.DDT(simple_ddt=True, encoder_depth=2, decoder_depth=2, n_classes=10, **small)
+    elif family == "joint":
+        m, inputs = da.MMDiT(simple_dit=False, context_embedder=emb, embedding_dim=64, depth=2, **small, **jk), ctx
+    elif family == "sprint_joint":
+        m, inputs, H = da.SprintDiT(simple_dit=False, context_embedder=emb, embedding_dim=64, encoder_depth=1, deep_layers_depth=3,
+                                    n_single_stream_blocks=2, decoder_depth=2, **small, **jk), ctx, 32
+    elif family == "ddt_joint":
+        m, inputs = da.DDT(simple_ddt=False, context_embedder=emb, encoder_depth=2, decoder_depth=2, **small, **jk), ctx
+    else:
+        m = da.UNetModel(image_size=[16, 16], in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1,
+                         attention_resolutions=[2], channel_mult="1, 2", num_heads=2, use_scale_shift_norm=True, resblock_updown=True,
+                         n_classes=10, classifier_free=True)
+        small = dict(input_channels=1)
+    m = m.to(DEV).train()
+    rec = _RangeRecorder()
+    m.engine.reducer = rec
+    x = torch.randn(B, small["input_channels"], H, H, device=DEV)
+    out = m(x=x, timesteps=torch.rand(B, device=DEV), **inputs)["x"]
+    out.square().mean().backward()
+    torch.cuda.synchronize()
+    assert rec.finished and rec.ranges
+    assert rec.ranges[0][1] == m._flat_grad.numel() and rec.ranges[-1][0] == 0
+    for (lo, hi), (lo2, hi2) in zip(rec.ranges, rec.ranges[1:]):
+        assert lo < hi and hi2 == lo, rec.ranges
