@@ -644,16 +644,25 @@ static int dispatch_big(const void* A, int64_t lda, const void* B, int64_t ldb, 
   if (M % TBM) return 1;
   if (variant == 1 && N % 128 == 0 && (M / TBM) * (N / 128) >= 64)
     return launch_big<128, 3>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
-  if (variant == 4 && (epi == 0 || epi == 2) && N % 384 == 0 && (M / TBM) * (N / 384) >= 64)
+  // One persistent workgroup per CU: pick the WIDEST tile that still gives the chip enough tiles (>= 192 of its 256 CUs).
+  // A 256x384 tiling of an [8192, 768] output is 64 tiles -- a quarter of the chip -- and measured 2x slower than the 128x128
+  // kernel (scripts/gemm_mid_bench.py); narrower tiles stage fewer FLOPs per byte but keep every CU busy.
+  const int64_t mt = M / TBM, fill = 192;
+  const bool v4 = variant == 4, v24 = variant == 2 || variant == 4;
+  if (v4 && (epi == 0 || epi == 2) && N % 384 == 0 && mt * (N / 384) >= fill)
     return launch_big<384, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
-  if ((variant == 2 || variant == 4) && N % 192 == 0 && (M / TBM) * (N / 192) >= 64)
-    return launch_big<192, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
-  // power-of-two widths (UNet channel counts 128 / 256 / 512 / 1024): 256x256 tiles, else the 256x128 3-stage ring
-  // (only when the launch fills the chip: the low-resolution UNet levels have few, K-deep tiles and do better on 128x128)
-  if (variant == 4 && epi <= 1 && N % 256 == 0 && (M / TBM) * (N / 256) >= 192)
+  if (v4 && epi <= 1 && N % 256 == 0 && mt * (N / 256) >= fill)
     return launch_big<256, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
-  if (variant == 4 && epi <= 1 && N % 128 == 0 && (M / TBM) * (N / 128) >= 192)
+  if (v24 && N % 192 == 0 && mt * (N / 192) >= fill)
+    return launch_big<192, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
+  if (v4 && epi <= 1 && N % 128 == 0 && mt * (N / 128) >= fill)
     return launch_big<128, 3>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
+  if (epi >= 2) {  // the fused SwiGLU epilogues only exist in the persistent kernels: take the tiling with the most tiles
+    if (v24 && N % 192 == 0 && mt * (N / 192) >= 64)
+      return launch_big<192, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
+    if (v4 && epi == 2 && N % 384 == 0 && mt * (N / 384) >= 64)
+      return launch_big<384, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
+  }
   return 1;
 }
 
