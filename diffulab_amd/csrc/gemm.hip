@@ -892,7 +892,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_tn_k(const bf16_t* __restr
 // Operand images in LDS are the row-major [64 r][384|128] slabs written by the DMA (1 KiB chunks run over
 // row boundaries for the 768-byte A rows: the per-lane source address is derived from the linear image
 // offset); fragments come out through ds_read_b64_tr_b16 with the 32-byte-chunk XOR swizzle of gemm_tn_k.
-// Requires Mo % 384 == 0, No % 128 == 0, R % 64 == 0.
+// Requires No % 128 == 0, R % 64 == 0, Mo % 8 == 0 (a ragged last 384-row m-tile clamps its loads and masks its atomics).
 // =====================================================================================================
 #define WBM 384
 #define WBN 128
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // block -> (A-panel unit = (split, m-tile), n-tile): the tiles_n workgroups that read the same A panel get block
   // ids congruent mod 8, i.e. land on ONE XCD and share the panel in its L2 (one HBM read instead of tiles_n)
-  const int tiles_n = N / WBN, tiles_m = M / WBM;
+  const int tiles_n = N / WBN, tiles_m = (M + WBM - 1) / WBM;  // (the last m-tile may be ragged: M % 8 == 0)
   const int grp = blockIdx.x / (8 * tiles_n), rem = blockIdx.x - grp * 8 * tiles_n;
   const int unit = grp * 8 + (rem & 7), nt = rem >> 3;
   const int split = unit / tiles_m, mt = unit - split * tiles_m;
@@ -931,7 +931,10 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __
     const int o = c * 1024 + lane * 16;
     const int r = o / pitch, s = (o - r * pitch) >> 4;
     const int q = s ^ ((r & 3) << 2);
-    src_off[i] = (int64_t)r * (is_a ? lda : ldb) + q * 8;
+    // ragged last m-tile: lanes whose 8 columns lie beyond M re-read the tile's last valid chunk (their products land in
+    // output rows >= M, which are never stored)
+    const int qv = (!CONV && is_a && m0 + q * 8 >= M) ? (M - m0) / 8 - 1 : q;
+    src_off[i] = (int64_t)r * (is_a ? lda : ldb) + qv * 8;
     lds_off[i] = (is_a ? 0 : WBM * 2 * BK) + c * 1024;
     crow[i] = r;
     cdy[i] = cdx[i] = 0;
@@ -1026,7 +1029,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 96 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        unsafeAtomicAdd(&C[(int64_t)m * ldc + n], acc[i][j][r]);
+        if (m < M) unsafeAtomicAdd(&C[(int64_t)m * ldc + n], acc[i][j][r]);
       }
     }
 }
@@ -1056,10 +1059,11 @@ extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t 
       (void)hipFuncSetAttribute((const void*)gemm_tn_big_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE);
     }
     const int nsteps = (int)(R / BK);
-    if (variant == 1 && M % WBM == 0 && N % WBN == 0 && nsteps >= 64) {
+    const int64_t tiles_m64 = (M + WBM - 1) / WBM;
+    if (variant == 1 && N % WBN == 0 && nsteps >= 64 && 5 * M >= 3 * tiles_m64 * WBM) {  // (ragged last m-tile: >= 60 % useful)
       // one workgroup per CU at most (128 KiB of LDS each): units (= m-tiles x splits) are padded to a multiple of
       // 8 for the XCD mapping, so pick the split count from the padded budget
-      const int tiles_m = (int)(M / WBM), tiles_n = (int)(N / WBN);
+      const int tiles_m = (int)tiles_m64, tiles_n = (int)(N / WBN);
       // max_workgroups > 0: the caller runs this GEMM beside other work (the engines' side-stream wgrads) and wants some
       // CUs left unclaimed by the persistent workgroups, so the latency-bound kernels of the main chain keep full occupancy there
       const int budget = (max_workgroups > 0 && max_workgroups < n_cu) ? max_workgroups : n_cu;

@@ -108,7 +108,8 @@ def test_gemm_nt_epilogues(ops, M):
     assert rel(o32, bf(resid) + bf(a) @ bf(b).t()) < 2e-5
 
 
-@pytest.mark.parametrize("R,M,N", [(1024, 384, 1152), (128, 16, 384), (256, 2304, 64), (4096, 384, 384), (64, 136, 264), (8192, 1152, 384), (16384, 384, 1536)])
+@pytest.mark.parametrize("R,M,N", [(1024, 384, 1152), (128, 16, 384), (256, 2304, 64), (4096, 384, 384), (64, 136, 264), (8192, 1152, 384), (16384, 384, 1536),
+                                   (8192, 512, 512), (4096, 4096, 512), (8192, 1024, 128), (4096, 640, 2560)])  # ragged last 384-row m-tile
 def test_gemm_tn(ops, R, M, N):
     a = synth.normal(f"tn.a{R}{M}", (R, M))
     b = synth.normal(f"tn.b{R}{N}", (R, N))
