@@ -66,15 +66,17 @@ class _Lib:
             )
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
+        self._fns: dict[str, tuple] = {}
         for name, (restype, argtypes, _) in self.protos.items():
             fn = getattr(self.cdll, name)  # AttributeError here == header/library mismatch
             fn.restype = restype
             fn.argtypes = argtypes
+            self._fns[name] = (fn, restype is ctypes.c_int and name not in _VALUE_RETURNING)
 
     def call(self, name: str, *args):
-        fn = getattr(self.cdll, name)
+        fn, status = self._fns[name]  # (one dict lookup per launch: small-batch steps issue ~700 launches)
         rc = fn(*args)
-        if self.protos[name][0] is ctypes.c_int and name not in _VALUE_RETURNING and rc != 0:
+        if status and rc != 0:
             raise RuntimeError(f"{name} failed ({rc}): {self.cdll.dl_last_error().decode()}")
         return rc
 

@@ -183,12 +183,20 @@ class DiTEngine:
         assert params.dtype == torch.float32 and params.numel() == self.layout.size and params.is_cuda
         self.params, self.grads = params, grads
         self._shadow_key = None
+        self._pviews: dict[str, Tensor] = {}
+        self._gviews: dict[str, Tensor] = {}
 
     def P(self, name: str) -> Tensor:
-        return self.layout.view(self.params, name)
+        v = self._pviews.get(name)  # (views of the arena are cached: creating one costs ~3 us and a block uses a dozen)
+        if v is None:
+            v = self._pviews[name] = self.layout.view(self.params, name)
+        return v
 
     def G(self, name: str) -> Tensor:
-        return self.layout.view(self.grads, name)
+        v = self._gviews.get(name)
+        if v is None:
+            v = self._gviews[name] = self.layout.view(self.grads, name)
+        return v
 
     def _build_shadows(self) -> None:
         """bf16 copies consumed by the MFMA GEMMs: W [out, rup64(in)] for forward, W^T [in, rup64(out)] for dgrad."""

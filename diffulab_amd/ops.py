@@ -20,7 +20,13 @@ MEAN_TYPES = {"epsilon": 0, "xstart": 1, "xprev": 2}
 PATCH_CPP, PATCH_PPC = 0, 1
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _s() -> int:
+    """the caller's current HIP stream (raw handle)"""
+    if _raw_stream is not None:  # 0.1 us instead of 2.6 us for constructing a torch Stream object per launch
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -32,8 +38,14 @@ def _p(t: Tensor | None) -> int | None:
     return t.data_ptr()
 
 
+_LIB = None
+
+
 def _call(name: str, *args) -> None:
-    lib().call(name, *args)
+    global _LIB
+    if _LIB is None:
+        _LIB = lib()
+    _LIB.call(name, *args)
 
 
 # ------------------------------------------------------------------ diffusion heads
