@@ -739,7 +739,8 @@ extern "C" int dl_qk_norm_rope_bwd_ex(const void* dq, const void* dk, const void
   DL_CHECK_ARG(dh % 8 == 0 && rot % 8 == 0 && rot <= dh && D <= 512 * MAXJ && n_off >= 0 && n_off + N <= n_dst,
                "dl_qk_norm_rope_bwd: bad dims");
   const int64_t M = B * N;
-  int grid = cdiv(M, 4 * 16);  // >= 16 rows per wave so the atomics are amortised
+  // >= 16 rows per wave so the atomics are amortised; a few thousand rows would leave half the chip idle that way: 4 rows per wave
+  int grid = cdiv(M, M >= 32768 ? 4 * 16 : 4 * 4);
   if (grid > 1024) grid = 1024;
   if (grid < 1) grid = 1;
   const int nj = cdiv(D, 512);
