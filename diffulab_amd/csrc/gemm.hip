@@ -644,19 +644,28 @@ static int dispatch_big(const void* A, int64_t lda, const void* B, int64_t ldb, 
   if (M % TBM) return 1;
   if (variant == 1 && N % 128 == 0 && (M / TBM) * (N / 128) >= 64)
     return launch_big<128, 3>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
-  // One persistent workgroup per CU: pick the WIDEST tile that still gives the chip enough tiles (>= 192 of its 256 CUs).
-  // A 256x384 tiling of an [8192, 768] output is 64 tiles -- a quarter of the chip -- and measured 2x slower than the 128x128
-  // kernel (scripts/gemm_mid_bench.py); narrower tiles stage fewer FLOPs per byte but keep every CU busy.
-  const int64_t mt = M / TBM, fill = 192;
+  // One persistent workgroup per CU, so a launch runs in ceil(tiles / 256) rounds: score every tile width the shape allows by
+  // (fraction of the CU-rounds that do work) x (relative efficiency of the tile: wider tiles stage fewer bytes per FLOP) and take
+  // the best; widths that would leave more than 30 % of the rounds idle are not considered and the shape falls to the 128x128
+  // kernel.  (A 256x384 tiling of an [8192, 768] output is 64 tiles -- a quarter of the chip -- and measured 2x slower than the
+  // 128x128 kernel; [16384, 768] is best at 256x192 = 256 tiles; scripts/gemm_mid_bench.py.)
+  const int64_t mt = M / TBM;
   const bool v4 = variant == 4, v24 = variant == 2 || variant == 4;
-  if (v4 && (epi == 0 || epi == 2) && N % 384 == 0 && mt * (N / 384) >= fill)
-    return launch_big<384, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
-  if (v4 && epi <= 1 && N % 256 == 0 && mt * (N / 256) >= fill)
-    return launch_big<256, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
-  if (v24 && N % 192 == 0 && mt * (N / 192) >= fill)
-    return launch_big<192, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
-  if (v4 && epi <= 1 && N % 128 == 0 && mt * (N / 128) >= fill)
+  auto score = [&](int tn, double eff, bool allowed) -> double {
+    if (!allowed || N % tn) return 0.0;
+    const int64_t tiles = mt * (N / tn), rounds = (tiles + 255) / 256;
+    const double util = (double)tiles / (double)(rounds * 256);
+    return util >= 0.7 ? util * eff : 0.0;
+  };
+  const double s384 = score(384, 1.00, v4 && (epi == 0 || epi == 2)), s256 = score(256, 0.95, v4 && epi <= 1);
+  const double s192 = score(192, 0.90, v24), s128 = score(128, 0.80, v4 && epi <= 1);
+  const double best = fmax(fmax(s384, s256), fmax(s192, s128));
+  if (best > 0.0) {
+    if (best == s384) return launch_big<384, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
+    if (best == s256) return launch_big<256, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
+    if (best == s192) return launch_big<192, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
     return launch_big<128, 3>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
+  }
   if (epi >= 2) {  // the fused SwiGLU epilogues only exist in the persistent kernels: take the tiling with the most tiles
     if (v24 && N % 192 == 0 && mt * (N / 192) >= 64)
       return launch_big<192, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
