@@ -139,8 +139,39 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
 
         return wrapper
 
+    # the HBM-bound row kernels of the same step: algorithmic bytes (every bf16 operand read or written once) / launch time
+    hbm_rec: list[tuple[str, torch.cuda.Event, torch.cuda.Event, float]] = []
+
+    def nbytes(*ts) -> float:
+        return float(sum(t.numel() * t.element_size() for t in ts if t is not None))
+
+    row_bytes = {
+        "swiglu_bwd": lambda dh, u, du: nbytes(dh, u, du),
+        "ln_modulate_fwd": lambda x, w, b, sc, sh, rpm, eps, out, mean, rstd, t=None, gate=None, x_out=None: nbytes(x, out, t, x_out),
+        "ln_modulate_bwd": lambda dout, x, w, b, sc, rpm, mean, rstd, dres, dx, dsc, dsh, dwb, gate_t=None, gate=None, dt=None,
+        dgate=None: nbytes(dout, x, dres, dx, gate_t, dt),
+        "qk_norm_rope_fwd": lambda qkv, sq, sk, cos, sin, q, k, v, *a, **kw: nbytes(qkv, q, k, v),
+        "qk_norm_rope_bwd": lambda dq, dk, dv, qkv, sq, sk, cos, sin, rrms, dqkv, *a, **kw: nbytes(dq, dk, dv, qkv, dqkv),
+    }
+    orig_rows = {n: getattr(ops, n) for n in row_bytes}
+
+    def timed_row(kind: str):
+        fn, fb = orig_rows[kind], row_bytes[kind]
+
+        def wrapper(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **kw)
+            e1.record()
+            hbm_rec.append((kind, e0, e1, fb(*a, **kw)))
+            return r
+
+        return wrapper
+
     for n in orig:
         setattr(ops, n, timed(n))
+    for n in orig_rows:
+        setattr(ops, n, timed_row(n))
     saved_reducer, model.engine.reducer = model.engine.reducer, None
     reps = 2
     try:
@@ -148,7 +179,7 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
             step()
         torch.cuda.synchronize()
     finally:
-        for n, f in orig.items():
+        for n, f in list(orig.items()) + list(orig_rows.items()):
             setattr(ops, n, f)
         model.engine.reducer = saved_reducer
     per: dict[str, list[float]] = {}
@@ -170,13 +201,23 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
         if rows:
             traffic = round(sum(v["launches"] * (v["fetch_MB"] + v["write_MB"]) for v in rows) * 1e6
                             / sum(v["launches"] for v in rows))
+    hb: dict[str, list[float]] = {}
+    for name, e0, e1, nb in hbm_rec:
+        d = hb.setdefault(name, [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += e0.elapsed_time(e1)
+        d[2] += nb
+    hbm_kernels = {k: {"launches_per_step": v[0] // reps, "avg_launch_us": round(v[1] * 1e3 / v[0], 2),
+                       "achieved_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1), "frac_of_8TBps": round(v[2] / (v[1] * 1e-3) / 8e12, 3)}
+                   for k, v in sorted(hb.items())}
     step_ach = images_per_s_per_gpu * train_flops_per_image() / 1e12
     return {"bound": "mfma", "kernel": "gemm_nt_big_k (all variants; NT GEMM of every linear fwd + dgrad)",
             "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
             "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_g_pmc_traffic.txt)",
             "flops_per_launch": round(fl / n_l), "launches_per_step": n_l // reps, "avg_launch_us": round(ms * 1e3 / n_l, 2),
             "ms_per_step": round(ms / reps, 3), "kernels": kernels,
-            "step_achieved": round(step_ach, 1), "step_frac": round(step_ach / PEAK_BF16_TFLOPS, 4)}
+            "step_achieved": round(step_ach, 1), "step_frac": round(step_ach / PEAK_BF16_TFLOPS, 4),
+            "hbm_bound_kernels": hbm_kernels}
 
 
 def main() -> None:
