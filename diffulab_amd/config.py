@@ -54,11 +54,18 @@ def _merge(dst: dict, src: dict) -> dict:
 def load_config(config_dir: str | Path, name: str, overrides: list[str] | None = None) -> Config:
     """compose ``<config_dir>/<name>.yaml``: every ``- group: option`` of its ``defaults`` list loads
     ``<config_dir>/<group>/<option>.yaml`` under key ``group``; ``_self_`` marks where the file's own keys are merged;
-    ``overrides`` are ``a.b.c=value`` strings (values parsed as YAML)."""
+    ``overrides`` are ``a.b.c=value`` strings (values parsed as YAML) or, like Hydra, ``group=option`` to pick another file of a
+    defaults group (``optimizer=sgd``)."""
     config_dir = Path(config_dir)
     raw = yaml.safe_load((config_dir / f"{name}.yaml").read_text()) or {}
     defaults = raw.pop("defaults", [])
     raw.pop("hydra", None)
+    overrides = list(overrides or [])
+    for ov in list(overrides):  # group choice overrides replace the entry of the defaults list
+        key, _, val = ov.partition("=")
+        if "." not in key and (config_dir / key / f"{val}.yaml").exists():
+            defaults = [({key: val} if isinstance(d, dict) and key in d else d) for d in defaults]
+            overrides.remove(ov)
     out: dict[str, Any] = {}
     merged_self = False
     for d in defaults:
@@ -71,7 +78,7 @@ def load_config(config_dir: str | Path, name: str, overrides: list[str] | None =
             _merge(out, {group: node})
     if not merged_self:
         _merge(out, raw)
-    for ov in overrides or []:
+    for ov in overrides:
         key, _, val = ov.partition("=")
         cur = out
         parts = key.split(".")

@@ -24,6 +24,15 @@ def test_config_composition_and_instantiate():
     assert item["model_inputs"]["x"].shape == (1, 32, 32) and item["model_inputs"]["y"].dtype == torch.int64
     c2 = load_config(os.path.join(ROOT, "configs"), "train_cifar10_flow_matching")
     assert c2.diffuser.n_steps == 100 and c2.diffuser.extra_args.logits_normal is True and c2.model.inner_dim == 512
+    # Hydra-style group choice: another file of a defaults group
+    c3 = load_config(os.path.join(ROOT, "configs"), "train_cifar10_flow_matching", ["optimizer=sgd", "model=sprint", "trainer.n_epoch=2"])
+    assert c3.optimizer._target_ == "torch.optim.SGD" and c3.optimizer.nesterov is True and c3.trainer.n_epoch == 2
+    assert c3.model._target_.endswith("SprintDiT") and c3.model.drop_rate == 0.75
+    # every shipped top-level config composes and names an importable denoiser
+    for name in sorted(f[:-5] for f in os.listdir(os.path.join(ROOT, "configs")) if f.endswith(".yaml")):
+        cfg = load_config(os.path.join(ROOT, "configs"), name)
+        assert cfg.model._target_.split(".")[-1] in ("MMDiT", "UNetModel", "SprintDiT", "DDT"), name
+        assert {"trainer", "diffuser", "dataset", "optimizer"} <= set(cfg), name
 
 
 def test_ema_decay_schedule_matches_ema_pytorch_formula():
