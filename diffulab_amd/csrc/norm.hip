@@ -302,7 +302,9 @@ extern "C" int dl_ln_modulate_bwd(const void* dout, const void* x, const float* 
                "dl_ln_modulate_bwd: 16-byte alignment");
   const int nj = cdiv(D, 512);
   const int groups = (int)(M / rows_per_mod);
-  const int split = (rows_per_mod % 64 == 0) ? (int)(rows_per_mod / 64) : 1;
+  // 64 rows per workgroup; 32 when that would leave the launch under one workgroup per CU (a few thousand rows)
+  const int rows_wg = (rows_per_mod % 64 == 0 && rows_per_mod >= 128 && M / 64 < 256) ? 32 : 64;
+  const int split = (rows_per_mod % rows_wg == 0) ? (int)(rows_per_mod / rows_wg) : 1;
   DL_CHECK_ARG(!gate_t || (gate && dt && dgate && ld_gate % 8 == 0 && (((uintptr_t)gate_t | (uintptr_t)gate | (uintptr_t)dt) & 15) == 0),
                "dl_ln_modulate_bwd: the fused gate backward needs gate_t, gate, dt and dgate (16-byte aligned)");
   const size_t lds = (size_t)5 * D * sizeof(float);
