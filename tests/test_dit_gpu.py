@@ -326,3 +326,29 @@ def test_ragged_batch_sizes_against_oracle(B, H):
     po.square().mean().backward()
     assert rel(pred, po) < 1.5e-2
     assert max(rel(p.grad, Pr[n].grad) for n, p in m.named_parameters()) < 4e-2
+
+
+def test_non_square_latents_and_x_context_against_oracle():
+    """16 x 32 latents (8 x 16 token grid: the row / column RoPE axes differ) with an extra conditioning image concatenated along
+    the channels (`x_context`, mmdit.py:918-919): forward and every gradient"""
+    from diffulab_amd import MMDiT
+
+    kw = dict(input_channels=6, output_channels=4, inner_dim=128, embedding_dim=64, num_heads=2, mlp_ratio=4, patch_size=2, depth=2,
+              n_classes=10, classifier_free=True)
+    cfg = odit.DiTConfig(**kw)
+    P = synth.dit_params(odit.param_shapes(cfg), seed=9)
+    m = MMDiT(simple_dit=True, **kw)
+    m.load_state_dict(P)
+    m = m.to(DEV)
+    B, H, W = 4, 16, 32
+    x, xc = synth.normal("ns.x", (B, 4, H, W)), synth.normal("ns.xc", (B, 2, H, W))
+    t, y = synth.uniform("ns.t", (B,), lo=0.1, hi=0.9), synth.integers("ns.y", (B,), 10)
+    dy = synth.normal("ns.dy", (B, 4, H, W))
+    pred = m(x=x.to(DEV), timesteps=t.to(DEV), y=y.to(DEV), x_context=xc.to(DEV))["x"]
+    assert pred.shape == (B, 4, H, W)
+    (pred * dy.to(DEV)).sum().backward()
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    po = odit.dit_forward(Pr, torch.cat((x, xc), dim=1), t, y, cfg)
+    (po * dy).sum().backward()
+    assert rel(pred, po) < 1.5e-2
+    assert max(rel(p.grad, Pr[n].grad) for n, p in m.named_parameters()) < 4e-2
