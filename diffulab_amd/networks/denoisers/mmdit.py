@@ -21,6 +21,7 @@ from torch import Tensor
 
 from ...engine import DiTDims, DiTEngine
 from ...mmdit_engine import JointDims, JointEngine
+from ...sprint_joint_engine import JointStackDims
 from .common import FlatArenaDenoiser, ModelOutput
 
 
@@ -102,6 +103,21 @@ class MMDiTBlock(nn.Module):
         raise RuntimeError("MMDiTBlock parameters are consumed by the fused HIP engine; call the MMDiT module instead")
 
 
+class MMDiTSingleStreamBlock(nn.Module):
+    """parameter container of a single-stream block (reference mmdit.py:442-470); never called on its own"""
+
+    def __init__(self, inner_dim: int, embedding_dim: int, mlp_ratio: int) -> None:
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(inner_dim, mlp_ratio * inner_dim * 2, bias=False), nn.Identity(),
+                                 nn.Linear(mlp_ratio * inner_dim, inner_dim, bias=False))
+        self.attention = _Attention(inner_dim)
+        self.modulation = nn.Sequential(nn.SiLU(), nn.Linear(embedding_dim, 3 * inner_dim))
+        self.norm = nn.LayerNorm(inner_dim)
+
+    def forward(self, *a: Any, **k: Any) -> Tensor:
+        raise RuntimeError("MMDiTSingleStreamBlock parameters are consumed by the fused HIP engine; call the owning denoiser module")
+
+
 class _LabelEmbed(nn.Module):
     def __init__(self, n_classes: int, dim: int, cfg: bool) -> None:
         super().__init__()
@@ -142,11 +158,11 @@ class MMDiT(FlatArenaDenoiser):
         assert not (n_classes is not None and context_embedder is not None), "n_classes and context_embedder cannot both be specified"
         if simple_dit and context_embedder is not None:
             raise NotImplementedError("diffulab_amd.MMDiT: simple_dit=True takes class labels, not a context embedder")
-        if n_single_stream_blocks > 0:
-            if not simple_dit:
-                raise NotImplementedError("diffulab_amd.MMDiT: MMDiTSingleStreamBlock (mmdit.py:442-532) is not built; use "
-                                          "n_single_stream_blocks=0")
+        if n_single_stream_blocks > 0 and simple_dit:
             logging.warning("n_single_stream_blocks is ignored when simple_dit=True. All blocks are single-stream DiT blocks.")
+        if n_single_stream_blocks > depth:
+            raise ValueError("n_single_stream_blocks cannot exceed depth")
+        self.n_single_stream_blocks = 0 if simple_dit else n_single_stream_blocks
         self.simple_dit = simple_dit
         self.patch_size = patch_size
         self.input_channels = input_channels
@@ -196,17 +212,19 @@ class MMDiT(FlatArenaDenoiser):
         if rope_axes_dim is None:
             rope_axes_dim = [int((partial_rotary_factor * heads_dim) // 3)] * 3
         self.rope_axes_dim = list(rope_axes_dim)
-        self.dims = JointDims(input_channels=self.input_channels, output_channels=self.output_channels, inner_dim=inner_dim,
-                              embedding_dim=embedding_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, patch_size=self.patch_size,
-                              depth=depth, rope_base=float(self.rope_base), frequency_embedding=self.frequency_embedding,
-                              n_classes=None, classifier_free=self.classifier_free, rope_axes_dim=self.rope_axes_dim,
-                              context_dim=ce.output_size[0])
+        ns = self.n_single_stream_blocks
+        common = dict(input_channels=self.input_channels, output_channels=self.output_channels, inner_dim=inner_dim,
+                      embedding_dim=embedding_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, patch_size=self.patch_size, depth=depth,
+                      rope_base=float(self.rope_base), frequency_embedding=self.frequency_embedding, n_classes=None,
+                      classifier_free=self.classifier_free, rope_axes_dim=self.rope_axes_dim, context_dim=ce.output_size[0])
+        self.dims = JointStackDims(n_single_stream_blocks=ns, **common) if ns else JointDims(**common)
         self.dims.validate()
         self.last_layer = _LastLayer(embedding_dim, inner_dim, self.patch_size, self.output_channels)
         self.time_embed = nn.Sequential(nn.Linear(self.frequency_embedding, embedding_dim), nn.SiLU(),
                                         nn.Linear(embedding_dim, embedding_dim))
         self.conv_proj = nn.Conv2d(self.input_channels, inner_dim, kernel_size=self.patch_size, stride=self.patch_size, bias=False)
-        self.layers = nn.ModuleList([MMDiTBlock(inner_dim, embedding_dim, mlp_ratio) for _ in range(depth)])
+        self.layers = nn.ModuleList([MMDiTBlock(inner_dim, embedding_dim, mlp_ratio) for _ in range(depth - ns)]
+                                    + [MMDiTSingleStreamBlock(inner_dim, embedding_dim, mlp_ratio) for _ in range(ns)])
         self.apply(self._init_weights)
 
     # reference init: xavier on Linear/Conv2d, zero biases, zero adaLN (mmdit.py:735-745)
@@ -224,7 +242,13 @@ class MMDiT(FlatArenaDenoiser):
                 p.detach().zero_()
 
     def _make_engine(self, device: torch.device) -> DiTEngine:
-        return DiTEngine(self.dims, device) if self.simple_dit else JointEngine(self.dims, device)
+        if self.simple_dit:
+            return DiTEngine(self.dims, device)
+        if self.n_single_stream_blocks:
+            from ...sprint_joint_engine import JointStackEngine
+
+            return JointStackEngine(self.dims, device)
+        return JointEngine(self.dims, device)
 
     # the context tensors are per-call inputs of the joint launch sequence: a captured graph reads static copies of them
     def _graph_inputs(self, eng) -> tuple:

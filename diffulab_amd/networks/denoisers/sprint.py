@@ -22,22 +22,7 @@ from torch import Tensor
 from ...sprint_engine import Route, SprintDims, SprintEngine
 from ...sprint_joint_engine import SprintJointDims, SprintJointEngine
 from .common import FlatArenaDenoiser, ModelOutput
-from .mmdit import DiTBlock, MMDiT, MMDiTBlock, _Attention, _LabelEmbed, _LastLayer
-
-
-class MMDiTSingleStreamBlock(nn.Module):
-    """parameter container of a single-stream block (reference mmdit.py:442-470); never called on its own"""
-
-    def __init__(self, inner_dim: int, embedding_dim: int, mlp_ratio: int) -> None:
-        super().__init__()
-        self.mlp = nn.Sequential(nn.Linear(inner_dim, mlp_ratio * inner_dim * 2, bias=False), nn.Identity(),
-                                 nn.Linear(mlp_ratio * inner_dim, inner_dim, bias=False))
-        self.attention = _Attention(inner_dim)
-        self.modulation = nn.Sequential(nn.SiLU(), nn.Linear(embedding_dim, 3 * inner_dim))
-        self.norm = nn.LayerNorm(inner_dim)
-
-    def forward(self, *a: Any, **k: Any) -> Tensor:
-        raise RuntimeError("MMDiTSingleStreamBlock parameters are consumed by the fused HIP engine; call the SprintDiT module")
+from .mmdit import DiTBlock, MMDiT, MMDiTBlock, MMDiTSingleStreamBlock, _LabelEmbed, _LastLayer
 
 
 class SprintDiT(FlatArenaDenoiser):

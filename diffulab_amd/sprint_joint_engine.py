@@ -51,7 +51,7 @@ class SprintJointDims(JointDims):
 
 
 class SprintJointLayout:
-    def __init__(self, d: SprintJointDims) -> None:
+    def __init__(self, d: "SprintJointDims | JointStackDims", sprint: bool = True) -> None:
         D, E, p = d.inner_dim, d.embedding_dim, d.patch_size
         F = d.mlp_ratio * D
         self.entries: dict[str, tuple[int, tuple[int, ...]]] = {}
@@ -97,9 +97,10 @@ class SprintJointLayout:
         add("context_embed.weight", (D, d.context_dim))
         add("last_layer.linear.weight", (p * p * d.output_channels, D))
         add("last_layer.linear.bias", (p * p * d.output_channels,))
-        add("mask_token", (1, 1, D))
-        add("fuse.weight", (D, 2 * D))
-        add("fuse_context.weight", (D, 2 * D))
+        if sprint:
+            add("mask_token", (1, 1, D))
+            add("fuse.weight", (D, 2 * D))
+            add("fuse_context.weight", (D, 2 * D))
         self.block_first = []
         for pre, kind in kinds:
             if kind == "J":
@@ -631,3 +632,225 @@ class SprintJointEngine(DiTEngine):
         main.wait_stream(side)
         ops.gemm_tn(dc0, w["ctxP"], self.G("context_embed.weight"), M=D, N=Cd)
         self._cond_bwd(dx0)
+
+
+# ================================================================================================ plain MMDiT with single-stream blocks
+@dataclass
+class JointStackDims(JointDims):
+    n_single_stream_blocks: int = 0
+
+    def kinds(self) -> list[tuple[str, str]]:
+        nj = self.depth - self.n_single_stream_blocks
+        return [(f"layers.{i}.", "J" if i < nj else "S") for i in range(self.depth)]
+
+
+class JointStackEngine(SprintJointEngine):
+    """MMDiT(simple_dit=False, n_single_stream_blocks > 0) (mmdit.py:699-731, 789-851): joint blocks, then single-stream blocks on
+    the concatenated [context ; image] latents; the image rows of the result feed the last layer.  Reuses the joint and
+    single-stream stages of SprintJointEngine without the token routing."""
+
+    route = None
+
+    def _make_layout(self, d: JointStackDims) -> SprintJointLayout:  # type: ignore[override]
+        self.kinds = d.kinds()
+        return SprintJointLayout(d, sprint=False)
+
+    def _extra_shadows(self, reg) -> None:
+        reg("context_embed.weight", self.d.inner_dim, self.d.context_dim, dgrad=False)
+
+    def _alloc(self, B: int, H: int, W: int, train: bool, Lc: int = 0, k: int = 0) -> None:  # type: ignore[override]
+        d, dev = self.d, self.dev
+        key = (B, H, W, train, Lc)
+        if key == self._ws_key:
+            return
+        if key in self._ws_cache:
+            self.ws, self.geo = self._ws_cache[key]
+            self._ws_key = key
+            return
+        D, E, p = d.inner_dim, d.embedding_dim, d.patch_size
+        gh, gw = H // p, W // p
+        N = gh * gw
+        T = Lc + N
+        Tp = _rup(T, 256)
+        if Tp > 2048 or (B * N) % 64 or Lc < 1:
+            raise NotImplementedError(f"joint MMDiT HIP path: context + image tokens <= 2048 (got {Lc} + {N}), image tokens a "
+                                      "multiple of 64")
+        M, Bp, Fo, F = B * N, _rup(B, 64), p * p * d.output_channels, d.mlp_ratio * D
+        bf, f32 = torch.bfloat16, torch.float32
+        Hh = d.num_heads
+
+        def z(*shape, dtype=bf):
+            with torch.inference_mode(False):
+                return torch.zeros(*shape, device=dev, dtype=dtype)
+
+        def zr(rows, *rest, dtype=bf):
+            return z(_rup(rows, 64), *rest, dtype=dtype)[:rows]
+
+        w: dict[str, object] = {"tokP": z(M, self._ki), "temb": z(Bp, d.frequency_embedding), "pre1": z(Bp, E), "h1": z(Bp, E),
+                                "e": z(Bp, E, dtype=f32), "emb": z(Bp, E, dtype=f32), "se": z(Bp, E),
+                                "mod": z(Bp, self.layout.mod_rows)}
+        w["ctxP"] = zr(B * Lc, _rup(d.context_dim, 64))
+        w["x"] = [z(M, D)]
+        w["c0"] = zr(B * Lc, D)
+        w["kb_f"] = z(B, Tp, dtype=f32)
+        w["kb_f"][:, T:] = float("-inf")
+        blk = []
+        for _, kind in self.kinds:
+            per: dict[str, object] = {"ao": z(B * Tp, D), "lse": z(B, Hh, Tp, dtype=f32), "q": z(B, Hh, Tp, 64), "k": z(B, Hh, Tp, 64),
+                                      "v": z(B, Hh, Tp, 64)}
+            if kind == "J":
+                for st, nt in (("input", N), ("context", Lc)):
+                    mt = B * nt
+                    a = {"x0": zr(mt, D), "mean1": z(mt, dtype=f32), "rstd1": z(mt, dtype=f32), "xm1": zr(mt, D), "qkv": zr(mt, 3 * D),
+                         "rrms": z(mt, 2, dtype=f32), "a": zr(mt, D), "t1": zr(mt, D), "x1": zr(mt, D), "mean2": z(mt, dtype=f32),
+                         "rstd2": z(mt, dtype=f32), "xm2": zr(mt, D), "u": zr(mt, 2 * F), "h": zr(mt, F), "t2": zr(mt, D)}
+                    if train:
+                        a["wg"] = {"dt2": zr(mt, D), "du": zr(mt, 2 * F), "dt1": zr(mt, D), "dqkv": zr(mt, 3 * D)}
+                        a["dwb"] = z(2, B, 2, D, dtype=f32)
+                    per[st] = a
+            else:
+                mt = B * T
+                per.update({"x0": zr(mt, D), "mean": z(mt, dtype=f32), "rstd": z(mt, dtype=f32), "m": zr(mt, D), "qkv": zr(mt, 3 * D),
+                            "rrms": z(mt, 2, dtype=f32), "a": zr(mt, D), "ta": zr(mt, D), "u": zr(mt, 2 * F), "h": zr(mt, F),
+                            "t": zr(mt, D)})
+                if train:
+                    per["wg"] = {"dt": zr(mt, D), "du": zr(mt, 2 * F), "dqkv": zr(mt, 3 * D)}
+                    per["dwb"] = z(1, B, 2, D, dtype=f32)
+            blk.append(per)
+        w["blk"] = blk
+        w["xj"], w["cj"] = z(M, D), zr(B * Lc, D)
+        w["lat0"], w["lat_out"] = zr(B * T, D), zr(B * T, D)
+        w["xl"] = z(M, D)
+        w["meanf"], w["rstdf"], w["xf"] = z(M, dtype=f32), z(M, dtype=f32), z(M, D)
+        w["otok"] = z(M, _rup(Fo, 8), dtype=f32)
+        w["pred"] = z(B, d.output_channels, H, W, dtype=f32)
+        if train:
+            w["dO"] = z(M, self._ko)
+            for name, mt in ((f"x{N}", M), ("c", B * Lc), ("l", B * T)):
+                w["s_" + name] = {"dxa": zr(mt, D), "dxb": zr(mt, D), "dxm": zr(mt, D), "dxm2": zr(mt, D), "da": zr(mt, D),
+                                  "dh": zr(mt, F)}
+            w["dao_f"] = z(B * Tp, D)
+            w["dq_f"], w["dk_f"], w["dv_f"] = (z(B, Hh, Tp, 64) for _ in range(3))
+            for n_ in ("dao", "dq", "dk", "dv"):  # (the single-stream stage addresses its attention scratch as "_d")
+                w[n_ + "_d"] = w[n_ + "_f"]
+            w["dxl"], w["dlat"], w["dxj"], w["dcj"] = z(M, D), zr(B * T, D), z(M, D), zr(B * Lc, D)
+            w["dmod"] = z(Bp, self.layout.mod_rows)
+            w["dmod32"] = z(Bp, self.layout.mod_rows, dtype=f32)
+            w["dse"], w["demb"], w["demb16"] = z(Bp, E, dtype=f32), z(Bp, E, dtype=f32), z(Bp, E)
+            w["dh1"], w["dpre1"] = z(Bp, E, dtype=f32), z(Bp, E)
+            w["scr_last"], w["scr_conv"] = z(_rup(Fo, 8), D, dtype=f32), z(D, self._ki, dtype=f32)
+        self.ws, self._ws_key = w, key
+        self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)
+        if len(self._ws_cache) >= 8:
+            self._ws_cache.pop(next(iter(self._ws_cache)))
+        self._ws_cache[key] = (w, self.geo)
+        if (Lc, gh, gw) not in self._rope:
+            c, s = joint_rope_tables(Lc, gh, gw, d.rope_axes_dim, d.rope_base)
+            self._rope[(Lc, gh, gw)] = (c.to(dev), s.to(dev))
+
+    def forward(self, x: Tensor, t: Tensor, y_eff: Tensor | None = None, train: bool = True, refresh: bool = True) -> Tensor:
+        d = self.d
+        B, C, H, W = x.shape
+        assert C == d.input_channels and x.dtype == torch.float32 and x.is_cuda and self.context is not None
+        ctx, keep = self.context
+        Lc = ctx.shape[1]
+        self._alloc(B, H, W, train, Lc)
+        if refresh:
+            self.refresh_shadows(force=train)
+        w, sh = self.ws, self.sh
+        _, _, _, gh, gw, N, M, Bp, Fo = self.geo
+        D, L, Cd = d.inner_dim, d.depth, d.context_dim
+        nj = L - d.n_single_stream_blocks
+        T = Lc + N
+        self._train, self._yeff, self._Lc = train, None, Lc
+        self._tabs = self._rope[(Lc, gh, gw)]
+        mod = self._stem_fwd(x, t, None)
+        w["ctxP"][:, :Cd].copy_(ctx.reshape(B * Lc, Cd))
+        ops.gemm_nt(w["ctxP"], sh["context_embed.weight|f"], w["c0"], M=B * Lc, N=D, K=w["ctxP"].shape[1])
+        kb = w["kb_f"]
+        if keep is None:
+            kb[:, :Lc].zero_()
+        else:
+            kb[:, :Lc].zero_().masked_fill_(~keep.to(device=kb.device, dtype=torch.bool), float("-inf"))
+        xs, cs = w["x"][0], w["c0"]
+        if nj:
+            self._jstage_fwd(range(0, nj), xs, cs, N, None, kb, w["xj"], w["cj"])
+            xs, cs = w["xj"], w["cj"]
+        lat0 = w["lat0"]
+        ops.copy_rows3d(cs, Lc * D, D, lat0, T * D, D, B, Lc, D)
+        ops.copy_rows3d(xs, N * D, D, lat0[Lc:], T * D, D, B, N, D)
+        self._sstage_fwd(range(nj, L), lat0, T, None, kb, w["lat_out"])
+        ops.copy_rows3d(w["lat_out"][Lc:], T * D, D, w["xl"], N * D, D, B, N, D)
+        mo = self.layout.mod_rows - 2 * D
+        ops.ln_modulate_fwd(w["xl"], None, None, mod[:, mo : mo + D], mod[:, mo + D : mo + 2 * D], N, 1e-6, w["xf"], w["meanf"],
+                            w["rstdf"])
+        ops.gemm_nt(w["xf"], sh["last_layer.linear.weight|f"], w["otok"], bias=self.P("last_layer.linear.bias"), M=M, N=Fo, K=D)
+        ops.unpatchify(w["otok"], w["pred"], d.patch_size)
+        return w["pred"]
+
+    def feature(self, kblk: int) -> Tensor:
+        nj = self.d.depth - self.d.n_single_stream_blocks
+        assert self._train
+        B, N, D = self.geo[0], self.geo[5], self.d.inner_dim
+        if kblk + 1 < nj:
+            return self.ws["blk"][kblk + 1]["input"]["x0"].view(B, N, D)
+        if kblk + 1 == nj:
+            return self.ws["xj"].view(B, N, D)
+        raise NotImplementedError("forward hooks on single-stream blocks (the image rows live inside the concatenated latents)")
+
+    def backward(self, dpred: Tensor, dfeats: dict[int, Tensor] | None = None) -> None:
+        assert self._train and self.grads is not None
+        d, w, sh = self.d, self.ws, self.sh
+        B, H, W, gh, gw, N, M, Bp, Fo = self.geo
+        D, L, Cd, Lc = d.inner_dim, d.depth, d.context_dim, self._Lc
+        nj = L - d.n_single_stream_blocks
+        T = Lc + N
+        dfe = {kb_: g.reshape(-1, D).to(torch.bfloat16).contiguous() for kb_, g in (dfeats or {}).items()}
+        mod, dmod = w["mod"], w["dmod32"]
+        dmod[:B].zero_()
+        Fo8 = _rup(Fo, 8)
+        sN = w[f"s_x{N}"]
+        ops.patchify(dpred, w["dO"], d.patch_size, ops.PATCH_PPC)
+        gl = self.G("last_layer.linear.weight")
+        if Fo == Fo8:
+            ops.gemm_tn(w["dO"], w["xf"], gl, M=Fo, N=D)
+        else:
+            w["scr_last"].zero_()
+            ops.gemm_tn(w["dO"], w["xf"], w["scr_last"], M=Fo8, N=D)
+            ops.reduce_rows_f32(w["scr_last"], gl, 1, Fo * D)
+        ops.colsum(w["dO"], self.G("last_layer.linear.bias"), M, Fo)
+        ops.gemm_nt(w["dO"], sh["last_layer.linear.weight|t"], sN["dxm"], M=M, N=D, K=self._ko)
+        mo = self.layout.mod_rows - 2 * D
+        ops.ln_modulate_bwd(sN["dxm"], w["xl"], None, None, mod[:, mo : mo + D], N, w["meanf"], w["rstdf"], None, w["dxl"],
+                            dmod[:, mo : mo + D], dmod[:, mo + D : mo + 2 * D], None)
+
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        side.wait_stream(main)
+        side_wgs = int(os.environ.get("DL_SIDE_WGS", "192"))
+
+        def wgrad(x_grad: Tensor, x_in: Tensor, gname: str) -> None:
+            ev = main.record_event()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                ops.gemm_tn(x_grad, x_in, self.G(gname), max_wgs=side_wgs)
+
+        def fold_norm(partial: Tensor, gname: str) -> None:
+            ev = main.record_event()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                ops.reduce_rows_f32(partial, self.G(gname), B, 2 * D, clear=True)
+
+        hooks = (wgrad, fold_norm, side)
+        dlat = w["dlat"]
+        dlat.zero_()  # the context rows of the last block's output feed nothing
+        ops.copy_rows3d(w["dxl"], N * D, D, dlat[Lc:], T * D, D, B, N, D)
+        dl = self._sstage_bwd(range(nj, L), dlat, T, None, w["kb_f"], hooks)
+        ops.copy_rows3d(dl[Lc:], T * D, D, w["dxj"], N * D, D, B, N, D)
+        ops.copy_rows3d(dl, T * D, D, w["dcj"], Lc * D, D, B, Lc, D)
+        gx, gc = w["dxj"], w["dcj"]
+        if nj:
+            gx, gc = self._jstage_bwd(range(0, nj), gx, gc, N, None, w["kb_f"], "f", dfe, hooks)
+        main.wait_stream(side)
+        ops.gemm_tn(gc, w["ctxP"], self.G("context_embed.weight"), M=D, N=Cd)
+        self._cond_bwd(gx)

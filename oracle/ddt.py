@@ -74,7 +74,7 @@ class DDTJointConfig(ommdit.JointConfig):
 def joint_param_shapes(cfg: DDTJointConfig) -> dict[str, tuple[int, ...]]:
     """state_dict layout of DDT(simple_ddt=False) with a one-output context embedder and n_single_stream_blocks = 0"""
     kw = {k: getattr(cfg, k) for k in ommdit.JointConfig.__dataclass_fields__}
-    enc = ommdit.param_shapes(ommdit.JointConfig(**{**kw, "depth": cfg.encoder_depth}))
+    enc = ommdit.param_shapes(ommdit.JointConfig(**{**kw, "depth": cfg.encoder_depth, "n_single_stream_blocks": 0}))
     dit = odit.param_shapes(odit.DiTConfig(**{**{k: getattr(cfg, k) for k in odit.DiTConfig.__dataclass_fields__}, "depth": 1,
                                                "n_classes": None}))
     s = {k: v for k, v in enc.items() if k != "conv_proj.weight"}

@@ -17,6 +17,7 @@ from . import dit as odit
 class JointConfig(odit.DiTConfig):
     context_dim: int = 96
     n_classes: int | None = None
+    n_single_stream_blocks: int = 0  # the last blocks of the stack are MMDiTSingleStreamBlocks (mmdit.py:715-728)
 
     def __post_init__(self) -> None:
         if not self.rope_axes_dim:
@@ -36,7 +37,14 @@ def param_shapes(cfg: JointConfig) -> dict[str, tuple[int, ...]]:
     s["time_embed.0.weight"], s["time_embed.0.bias"] = (E, cfg.frequency_embedding), (E,)
     s["time_embed.2.weight"], s["time_embed.2.bias"] = (E, E), (E,)
     s["conv_proj.weight"] = (D, cfg.input_channels, p, p)
-    for i in range(cfg.depth):
+    F = cfg.mlp_ratio * D
+    for i in range(cfg.depth - cfg.n_single_stream_blocks, cfg.depth):
+        pre = f"layers.{i}."
+        s.update({pre + "mlp.0.weight": (2 * F, D), pre + "mlp.2.weight": (D, F), pre + "attention.qkv.weight": (3 * D, D),
+                  pre + "attention.qk_norm.query_norm.scale": (D,), pre + "attention.qk_norm.key_norm.scale": (D,),
+                  pre + "attention.proj_out.weight": (D, D), pre + "modulation.1.weight": (3 * D, E),
+                  pre + "modulation.1.bias": (3 * D,), pre + "norm.weight": (D,), pre + "norm.bias": (D,)})
+    for i in range(cfg.depth - cfg.n_single_stream_blocks):
         pre = f"layers.{i}."
         for st in STREAMS:
             s[pre + f"modulation_{st}.lin.weight"], s[pre + f"modulation_{st}.lin.bias"] = (6 * D, E), (6 * D,)
@@ -125,8 +133,14 @@ def mmdit_forward(P: dict[str, Tensor], x: Tensor, t: Tensor, ctx: Tensor, keep:
     emb = odit.cond_embedding(P, t, None, cfg)
     c = ctx @ P["context_embed.weight"].t()
     cos, sin = rope_tables_joint(c.shape[1], gh, gw, cfg.rope_axes_dim, cfg.rope_base)
+    nj = cfg.depth - cfg.n_single_stream_blocks
     for i in range(cfg.depth):
-        tok, c = joint_block(P, f"layers.{i}.", tok, c, emb, cos, sin, keep, cfg)
+        if i < nj:
+            tok, c = joint_block(P, f"layers.{i}.", tok, c, emb, cos, sin, keep, cfg)
+        else:
+            from .sprint import single_stream_block  # (oracle.sprint imports this module)
+
+            tok, c = single_stream_block(P, f"layers.{i}.", tok, c, emb, cos, sin, keep, cfg)
         if taps is not None:
             taps[f"layer{i}"], taps[f"context{i}"] = tok, c
     return odit.unpatchify(odit.last_layer(P, tok, emb, cfg), gh, gw, cfg)

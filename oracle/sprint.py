@@ -106,7 +106,8 @@ def joint_param_shapes(cfg: SprintJointConfig) -> dict[str, tuple[int, ...]]:
     """state_dict layout of SprintDiT(simple_dit=False) with a one-output context embedder (sprint.py:96-256)"""
     D, E = cfg.inner_dim, cfg.embedding_dim
     F = cfg.mlp_ratio * D
-    base = ommdit.param_shapes(ommdit.JointConfig(**{**{k: getattr(cfg, k) for k in ommdit.JointConfig.__dataclass_fields__}, "depth": 1}))
+    base = ommdit.param_shapes(ommdit.JointConfig(**{**{k: getattr(cfg, k) for k in ommdit.JointConfig.__dataclass_fields__}, "depth": 1,
+                                                     "n_single_stream_blocks": 0}))
     s: dict[str, tuple[int, ...]] = {"mask_token": (1, 1, D)}
     s.update({k: v for k, v in base.items() if not k.startswith("layers.")})
     s["fuse.weight"], s["fuse_context.weight"] = (D, 2 * D), (D, 2 * D)

@@ -823,9 +823,48 @@ def gen_ddt_joint() -> None:
     save("ddt_joint", **o)
 
 
+# ------------------------------------------------------------------ (xvi) MMDiT with single-stream blocks at the end of the stack
+def gen_mmdit_single() -> None:
+    import importlib
+    import tempfile
+
+    from oracle import mmdit as ommdit
+
+    PE = importlib.import_module("diffulab.networks.embedders.precomputed").PrecomputedEmbedder
+    Lc, Cd, B, H = 64, 96, 4, 16
+    null = synth.normal("ms.null", (1, Lc, Cd)) * 0.5
+    with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+        torch.save(null, f.name)
+        emb = PE(f.name, null_embedding_seq_len=7)
+    kw = dict(JOINT_SMALL, depth=3, n_single_stream_blocks=2)
+    m = MMDiT(simple_dit=False, context_embedder=emb, **kw)
+    cfg = ommdit.JointConfig(context_dim=Cd, **kw)
+    shapes = ommdit.param_shapes(cfg)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == shapes, set(m.state_dict()) ^ set(shapes)
+    m.load_state_dict(synth.dit_params(shapes, seed=111))
+    x = synth.normal("ms.x", (B, 4, H, H))
+    t = synth.uniform("ms.t", (B,), lo=0.05, hi=0.95)
+    ctx = synth.normal("ms.ctx", (B, Lc, Cd))
+    keep = torch.arange(Lc)[None, :] < torch.tensor([64, 20, 41, 5])[:, None]
+    dy = synth.normal("ms.dy", (B, 4, H, H))
+    o = {}
+    m.train()
+    pred = m(x=x, timesteps=t, initial_context={"embeddings": ctx, "attn_mask": keep}, p=0.0)["x"]
+    o["pred"] = pred
+    (pred * dy).sum().backward()
+    big = ("context_embed.weight", "layers.0.attention.qkv_context.weight", "layers.0.mlp_input.0.weight",
+           "layers.1.attention.qkv.weight", "layers.1.mlp.2.weight", "layers.1.modulation.1.weight",
+           "layers.2.attention.proj_out.weight", "layers.2.mlp.0.weight")
+    for n, p in m.named_parameters():
+        if p.grad is not None and (p.numel() <= 16384 or n in big):
+            o["g_" + n] = p.grad.clone()
+    o["none"] = np.array(sorted(n for n, p in m.named_parameters() if p.grad is None))
+    save("mmdit_single", **o)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve", "repa", "resampler", "sprint", "mmdit_joint", "sprint_joint", "ddt", "ddt_joint"]
-    fns = {"repa": gen_repa, "resampler": gen_resampler, "sprint": gen_sprint, "mmdit_joint": gen_mmdit_joint, "sprint_joint": gen_sprint_joint, "ddt": gen_ddt, "ddt_joint": gen_ddt_joint, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
+    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve", "repa", "resampler", "sprint", "mmdit_joint", "sprint_joint", "ddt", "ddt_joint", "mmdit_single"]
+    fns = {"repa": gen_repa, "resampler": gen_resampler, "sprint": gen_sprint, "mmdit_joint": gen_mmdit_joint, "sprint_joint": gen_sprint_joint, "ddt": gen_ddt, "ddt_joint": gen_ddt_joint, "mmdit_single": gen_mmdit_single, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
            "s2": gen_s2_model, "samplers": gen_samplers, "curve": gen_loss_curve, "unet": gen_unet}
     for w in which:
         print("==", w)

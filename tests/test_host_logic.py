@@ -112,9 +112,9 @@ def test_module_contract_and_layout():
                depth=2, rope_axes_dim=[16, 24, 24])
     mj = MMDiT(**jkw)
     assert mj.context_embed.weight.shape == (128, 96) and hasattr(mj.layers[0], "modulation_context")
-    with pytest.raises(NotImplementedError):  # single-stream blocks and the default odd 3-axis split (64 // 3 = 21) are not built
-        MMDiT(**{**jkw, "n_single_stream_blocks": 1})
-    with pytest.raises(NotImplementedError):
+    ms = MMDiT(**{**jkw, "n_single_stream_blocks": 1})  # the last block of the stack becomes a single-stream block
+    assert hasattr(ms.layers[0], "modulation_context") and hasattr(ms.layers[1], "mlp") and ms.layers[1].modulation[1].out_features == 384
+    with pytest.raises(NotImplementedError):  # the reference's default 3-axis split (64 // 3 = 21, odd) is not a valid RoPE width
         MMDiT(**{**jkw, "rope_axes_dim": None})
     with pytest.raises(NotImplementedError):
         DiTDims(inner_dim=384, num_heads=4).validate()

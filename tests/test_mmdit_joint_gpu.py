@@ -152,3 +152,46 @@ def test_joint_mmdit_ragged_context_length_against_oracle():
         elif rel(p.grad, Pr[n].grad) > (8e-2 if p.dim() == 1 else 4e-2):
             bad.append((n, rel(p.grad, Pr[n].grad)))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("depth,ns", [(3, 2), (2, 2)])
+def test_mmdit_with_single_stream_blocks(golden, depth, ns):
+    """MMDiT(simple_dit=False, n_single_stream_blocks > 0): joint blocks then single-stream blocks on [context ; image] (also a
+    stack of single-stream blocks only): prediction vs the reference fixture (depth 3), every gradient vs the oracle"""
+    from diffulab_amd import MMDiT
+    from diffulab_amd.networks.embedders import PrecomputedEmbedder
+
+    kw = dict(KW, depth=depth, n_single_stream_blocks=ns)
+    m = MMDiT(simple_dit=False, context_embedder=PrecomputedEmbedder(torch.zeros(1, Lc, Cd), null_embedding_seq_len=7), **kw)
+    cfg = ommdit.JointConfig(context_dim=Cd, **kw)
+    shapes = ommdit.param_shapes(cfg)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == shapes
+    P = synth.dit_params(shapes, seed=111)
+    m.load_state_dict(P)
+    m = m.to(DEV)
+    x, t = synth.normal("ms.x", (B, 4, H, H)), synth.uniform("ms.t", (B,), lo=0.05, hi=0.95)
+    ctx, dy = synth.normal("ms.ctx", (B, Lc, Cd)), synth.normal("ms.dy", (B, 4, H, H))
+    keep = torch.arange(Lc)[None, :] < torch.tensor([64, 20, 41, 5])[:, None]
+    m.train()
+    pred = m(x=x.to(DEV), timesteps=t.to(DEV), initial_context={"embeddings": ctx.to(DEV), "attn_mask": keep.to(DEV)}, p=0.0)["x"]
+    if depth == 3:
+        g = {k: torch.as_tensor(v) for k, v in golden("mmdit_single").items() if k != "none"}
+        assert rel(pred, g["pred"]) < 1.5e-2
+    (pred * dy.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    po = ommdit.mmdit_forward(Pr, x, t, ctx, keep, cfg)
+    assert rel(pred, po) < 1.5e-2
+    (po * dy).sum().backward()
+    bad = []
+    for n, p in m.named_parameters():
+        if Pr[n].grad is None:
+            assert float(p.grad.abs().max()) == 0.0, n
+        elif rel(p.grad, Pr[n].grad) > (8e-2 if p.dim() == 1 else 4e-2):
+            bad.append((n, rel(p.grad, Pr[n].grad)))
+    assert not bad, bad
+    m.eval()
+    with torch.no_grad():  # eager and hipGraph-replayed inference agree
+        a1 = m(x=x.to(DEV), timesteps=t.to(DEV), initial_context={"embeddings": ctx.to(DEV), "attn_mask": keep.to(DEV)}, p=0.0)["x"].clone()
+        a2 = m(x=x.to(DEV), timesteps=t.to(DEV), initial_context={"embeddings": ctx.to(DEV), "attn_mask": keep.to(DEV)}, p=0.0)["x"]
+    assert rel(a1, po) < 1.5e-2 and rel(a2, a1) < 1e-6

@@ -594,3 +594,31 @@ def test_ddt_joint_encoder(golden):
     with torch.no_grad():
         c2, k2 = ommdit.drop_context(ctx, keep, null, null_keep, g["b_u"] < 0.5)
         assert rel(oddt.ddt_joint_forward(P, x, t, c2, k2, cfg), g["b_pred"]) < 2e-6
+
+
+def test_mmdit_with_single_stream_blocks(golden):
+    """(xvi) MMDiT(simple_dit=False, n_single_stream_blocks=2): one joint block, then two single-stream blocks on [context ; image]"""
+    from oracle import mmdit as ommdit
+
+    raw = golden("mmdit_single")
+    none = set(str(n) for n in raw["none"])
+    g = {k: torch.as_tensor(v) for k, v in raw.items() if k != "none"}
+    kw = dict(input_channels=4, output_channels=4, inner_dim=128, embedding_dim=64, num_heads=2, mlp_ratio=4, patch_size=2, depth=3,
+              rope_axes_dim=[16, 24, 24], rope_base=2000, classifier_free=True, n_single_stream_blocks=2)
+    cfg = ommdit.JointConfig(context_dim=96, **kw)
+    P = {k: v.requires_grad_(True) for k, v in synth.dit_params(ommdit.param_shapes(cfg), seed=111).items()}
+    Lc, Cd, B, H = 64, 96, 4, 16
+    x, t = synth.normal("ms.x", (B, 4, H, H)), synth.uniform("ms.t", (B,), lo=0.05, hi=0.95)
+    ctx = synth.normal("ms.ctx", (B, Lc, Cd))
+    keep = torch.arange(Lc)[None, :] < torch.tensor([64, 20, 41, 5])[:, None]
+    dy = synth.normal("ms.dy", (B, 4, H, H))
+    pred = ommdit.mmdit_forward(P, x, t, ctx, keep, cfg)
+    assert rel(pred, g["pred"]) < 2e-6
+    (pred * dy).sum().backward()
+    checked = 0
+    for n, v in P.items():
+        if "g_" + n in g:
+            assert rel(v.grad, g["g_" + n]) < 2e-5, n
+            checked += 1
+        assert (v.grad is None) == (n in none), n
+    assert checked > 30
