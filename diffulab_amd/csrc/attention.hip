@@ -76,6 +76,9 @@ __device__ __forceinline__ bf16x8_t pack_frag(const float* p) {
   for (int i = 0; i < 4; ++i) r.u[i] = pack2bf(p[2 * i], p[2 * i + 1]);
   return r.v;
 }
+// raw v_exp_f32: exp2f() wraps it in a denormal-range rescale (cmp / cndmask / add / ldexp, 6 VALU instructions per element, half of
+// the backward kernel's VALU stream); a probability below 2^-126 flushing to zero is exactly what softmax wants
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
 extern "C" int dl_attn_fwd_ex(const void* q, const void* k, const void* v, void* out, float* lse, int64_t B, int64_t H,
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(512) void attn_fwd_k(const bf16_t* __restrict__ q, 
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
+    const float alpha = fast_exp2(m_run - m_new);
     m_run = m_new;
     float ps = 0.f;
     float p[2][16];
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(512) void attn_fwd_k(const bf16_t* __restrict__ q, 
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        p[t][r] = exp2f(s[t][r] - m_new);
+        p[t][r] = fast_exp2(s[t][r] - m_new);
         ps += p[t][r];
       }
     l_run = l_run * alpha + ps;
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(512) void attn_fwd_tiled_k(const bf16_t* __restrict
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       float m_new = fmaxf(m_run, mx);
       if (m_new == -INFINITY) m_new = 0.f;  // every key so far is masked: keep exp2(-inf - m) = 0 well defined
-      const float alpha = exp2f(m_run - m_new);
+      const float alpha = fast_exp2(m_run - m_new);
       m_run = m_new;
       float ps = 0.f;
       float p[2][16];
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(512) void attn_fwd_tiled_k(const bf16_t* __restrict
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          p[t][r] = exp2f(s[t][r] - m_new);
+          p[t][r] = fast_exp2(s[t][r] - m_new);
           ps += p[t][r];
         }
       l_run = l_run * alpha + ps;
@@ -375,8 +378,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
     f32x16_t dqa[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqa[0][r] = dqa[1][r] = 0.f;
-    for (int kb = 0; kb < N; kb += 32) {
-      f32x16_t st, dpt;
+    // software pipeline over the key blocks: the S / dP MFMAs of block kb + 32 are issued before the exp / dS arithmetic of block kb
+    auto scores = [&](int kb, f32x16_t& st, f32x16_t& dpt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[r] = dpt[r] = 0.f;
 #pragma unroll
@@ -384,10 +387,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
         st = MFMA(frag_rows(ta, kb + (lane & 31), ks, hi), qf[ks], st);
         dpt = MFMA(frag_rows(tb, kb + (lane & 31), ks, hi), dof[ks], dpt);
       }
+    };
+    auto step = [&](int kb, f32x16_t& st, f32x16_t& dpt, f32x16_t& stn, f32x16_t& dptn) {
+      if (kb + 32 < N) scores(kb + 32, stn, dptn);
       float ds[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(st[r] * c - my_lse);
+        const float p = fast_exp2(st[r] * c - my_lse);
         ds[r] = p * (dpt[r] - my_delta);
       }
 #pragma unroll
@@ -396,6 +402,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
         dqa[0] = MFMA(frag_cols(ta, kb + kg2 * 16, 0, lane), df, dqa[0]);
         dqa[1] = MFMA(frag_cols(ta, kb + kg2 * 16, 32, lane), df, dqa[1]);
       }
+    };
+    f32x16_t s0, d0, s1, d1;  // two tile pairs in flight, roles swapped by the 2x unroll (N is a multiple of 64)
+    scores(0, s0, d0);
+    for (int kb = 0; kb < N; kb += 64) {
+      step(kb, s0, d0, s1, d1);
+      step(kb + 32, s1, d1, s0, d0);
     }
     bf16_t* dqp = dq + hoff + (int64_t)(own + (lane & 31)) * DH;
 #pragma unroll
@@ -428,15 +440,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
     f32x16_t dka[2], dva[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dka[0][r] = dka[1][r] = dva[0][r] = dva[1][r] = 0.f;
-    for (int qb = 0; qb < N; qb += 32) {
-      f32x16_t s, dp;
+    // (software pipeline as in phase A, on S only: dK / dV / S / dP accumulators leave no room for a second dP tile)
+    auto scores_t = [&](int qb, f32x16_t& s) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        s = MFMA(frag_rows(ta, qb + (lane & 31), ks, hi), kf[ks], s);
-        dp = MFMA(frag_rows(tb, qb + (lane & 31), ks, hi), vf[ks], dp);
-      }
+      for (int ks = 0; ks < 4; ++ks) s = MFMA(frag_rows(ta, qb + (lane & 31), ks, hi), kf[ks], s);
+    };
+    auto step_t = [&](int qb, f32x16_t& s, f32x16_t& sn) {
+      f32x16_t dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) dp = MFMA(frag_rows(tb, qb + (lane & 31), ks, hi), vf[ks], dp);
+      if (qb + 32 < N) scores_t(qb + 32, sn);
       float p[16], ds[16];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -445,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = g4 * 4 + e;
-          p[r] = exp2f(s[r] * c - l4[e]);
+          p[r] = fast_exp2(s[r] * c - l4[e]);
           ds[r] = p[r] * (dp[r] - d4[e]);
         }
       }
@@ -459,6 +476,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
         dka[0] = MFMA(frag_cols(ta, rbase, 0, lane), df, dka[0]);
         dka[1] = MFMA(frag_cols(ta, rbase, 32, lane), df, dka[1]);
       }
+    };
+    f32x16_t s0, s1;  // (no 2x unroll here: it spills; the 16 register copies per block are cheaper)
+    scores_t(0, s0);
+    for (int qb = 0; qb < N; qb += 32) {
+      step_t(qb, s0, s1);
+      s0 = s1;
     }
     bf16_t* dkp = dk + hoff + (int64_t)(own + (lane & 31)) * DH;
     bf16_t* dvp = dv + hoff + (int64_t)(own + (lane & 31)) * DH;
@@ -571,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_tiled_k(const bf16_t* __restr
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int r = g4 * 4 + e;
-              const float p = exp2f(st[r] * c + b4[e] - my_lse[ob]);
+              const float p = fast_exp2(st[r] * c + b4[e] - my_lse[ob]);
               ds[r] = p * (dpt[r] - my_delta[ob]);
             }
           }
@@ -635,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_tiled_k(const bf16_t* __restr
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = g4 * 4 + e;
-            p[r] = exp2f(s2[r] * c + kbias - l4[e]);
+            p[r] = fast_exp2(s2[r] * c + kbias - l4[e]);
             ds[r] = p[r] * (dp[r] - d4[e]);
           }
         }
