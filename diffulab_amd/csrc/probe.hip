@@ -116,8 +116,49 @@ __global__ __launch_bounds__(512, 2) void copy_probe_k(const bf16_t* __restrict_
   out[blockIdx.x * 512 + threadIdx.x] = (float)(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) + ((float*)smem)[threadIdx.x];
 }
 
+
+// store-pattern probe: 256 persistent workgroups x 8 waves write a [65536, 1152] bf16 matrix in 256 x 384 tiles, every wave a
+// 64 x 192 sub-tile (the qkv GEMM's output), `iters` times.  mode 8: the register epilogue's pattern -- one instruction = 32 rows
+// x 32 contiguous bytes (lane & 31 = row, lane >> 5 = 16-byte half); mode 9: the same bytes with 8 lanes per row -- one
+// instruction = 8 rows x 128 contiguous bytes.
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void store_probe_k(bf16_t* __restrict__ out, int iters) {
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ld = 1152, tiles_n = 3, ntiles = 256 * 3;
+  u32x4_t v = {0x3c003c00u + (unsigned)lane, 0x3c003c01u, 0x3c003c02u, 0x3c003c03u};
+  for (int it = 0; it < iters; ++it)
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const int m0 = (tile / tiles_n) * 256 + wm * 64, n0 = (tile % tiles_n) * 384 + wn * 192;
+      if (MODE == 8) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp)
+              *(u32x4_t*)(out + (int64_t)(m0 + i * 32 + (lane & 31)) * ld + n0 + j * 32 + 16 * gp + 8 * hi) = v;
+      } else {
+        // 192 columns = 384 B = 3 lines of 128 B per row: 8 lanes per line, 8 rows per instruction, 24 instructions per 64 rows
+#pragma unroll
+        for (int rg = 0; rg < 8; ++rg)
+#pragma unroll
+          for (int ln = 0; ln < 3; ++ln)
+            *(u32x4_t*)(out + (int64_t)(m0 + rg * 8 + (lane >> 3)) * ld + n0 + ln * 64 + (lane & 7) * 8) = v;
+      }
+      v[1] += 1;
+    }
+}
+
 extern "C" int dl_probe_mfma(int mode, int iters, const void* src, float* out, dl_stream_t stream) {
-  DL_CHECK_ARG(out && iters > 0 && mode >= 0 && mode <= 7 && (mode < 3 || src), "dl_probe_mfma: bad args");
+  DL_CHECK_ARG(out && iters > 0 && mode >= 0 && mode <= 9 && (mode < 3 || mode > 7 || src), "dl_probe_mfma: bad args");
+  if (mode >= 8) {  // store-pattern probe: out is a bf16 [65536, 1152] buffer
+    if (mode == 8) hipLaunchKernelGGL(store_probe_k<8>, 256, 512, 0, (hipStream_t)stream, (bf16_t*)out, iters);
+    else hipLaunchKernelGGL(store_probe_k<9>, 256, 512, 0, (hipStream_t)stream, (bf16_t*)out, iters);
+    DL_LAUNCH_CHECK();
+    return DL_OK;
+  }
   const int lds = 114688;
 #define GO(MODE)                                                                                               \
   do {                                                                                                         \

@@ -405,7 +405,9 @@ DL_API int dl_copy2d_bf16(const void* src, int64_t lds, void* dst, int64_t ldd, 
 DL_API int dl_probe_tr16(uint16_t* out, dl_stream_t stream);
 /* sustained MFMA 32x32x16 bf16 rate of the GEMM main-loop skeleton on 256 workgroups x 8 waves, `iters` k-steps of
  * 24 MFMAs per wave: mode 0 MFMA only, 1 + LDS fragment reads, 2 + one workgroup barrier per k-step, 3 + the 56 KiB
- * direct-to-LDS DMA per k-step from `src` (>= 256*57344 bytes).  out: f32 [256*512] (sink). */
+ * direct-to-LDS DMA per k-step from `src` (>= 256*57344 bytes).  out: f32 [256*512] (sink).
+ * modes 8 / 9: store-pattern probe -- `out` is a bf16 [65536, 1152] buffer written `iters` times in the GEMM register
+ * epilogue's pattern (32 rows x 32 B per instruction) / with full 128-byte lines per 8 lanes. */
 DL_API int dl_probe_mfma(int mode, int iters, const void* src, float* out, dl_stream_t stream);
 
 #ifdef __cplusplus

@@ -39,7 +39,12 @@ if which in ("nt", "all"):
         else:
             fn = lambda: ops.gemm_nt(a, b, out)
         us = timeit(fn)
-        print(f"nt {name:10s} M={M} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s")
+        err = ""
+        if kw != "gate" and os.environ.get("GEMM_BENCH_CHECK"):
+            ref = a.float() @ b.float().T
+            err = f"  max|err| {(out.float() - ref).abs().max().item():.3e} (ref max {ref.abs().max().item():.1f})"
+            del ref
+        print(f"nt {name:10s} M={M} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s{err}")
 if which in ("tn", "all"):
     for name, Mo, No in [("w_qkv", 1152, 384), ("w_proj", 384, 384), ("w_mlp1", 3072, 384), ("w_mlp2", 384, 1536)]:
         a, b = rnd(M, Mo), rnd(M, No)
