@@ -108,9 +108,11 @@ def main() -> None:
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    t_issue = (time.perf_counter() - t0) / a.steps  # host time to issue a step (the GPU runs behind it): == ms_per_step when launch-bound
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     print(json.dumps({"config": a.config, "batch": a.batch, "ms_per_step": round(dt * 1e3, 3), "images_per_s": round(a.batch / dt, 1),
+                      "host_issue_ms_per_step": round(t_issue * 1e3, 3),
                       "params_M": round(sum(q.numel() for q in m.parameters()) / 1e6, 1)}))
 
 
