@@ -81,8 +81,23 @@ __device__ __forceinline__ bf16x8_t pack_frag(const float* p) {
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
+// where head (b, h) of V (or dV) lives: element offset b * bs + h * hs, rows `pitch` elements apart.  Head-major [B, H, N, 64] is
+// {H*N*64, N*64, 64}; the v third of the token-major qkv rows [B*N, 3D] is {N*3D, 64, 3D} on a pointer advanced by 2D, which lets
+// the N <= 256 kernels read V / write dV in place (no head-split copy of V in the QK-norm kernels).
+struct HeadLayout {
+  int64_t bs, hs;
+  int pitch;
+};
+
 extern "C" int dl_attn_fwd_ex(const void* q, const void* k, const void* v, void* out, float* lse, int64_t B, int64_t H,
                               int64_t Nq, int64_t Nk, int64_t dh, float scale, const float* key_bias, dl_stream_t stream);
+extern "C" int dl_attn_fwd_sv(const void* q, const void* k, const void* v, int64_t v_batch_stride, int64_t v_head_stride,
+                              int64_t v_pitch, void* out, float* lse, int64_t B, int64_t H, int64_t N, int64_t dh, float scale,
+                              dl_stream_t stream);
+extern "C" int dl_attn_bwd_sv(const void* q, const void* k, const void* v, int64_t v_batch_stride, int64_t v_head_stride,
+                              int64_t v_pitch, const void* out, const void* dout, const float* lse, void* dq, void* dk, void* dv,
+                              int64_t dv_batch_stride, int64_t dv_head_stride, int64_t dv_pitch, int64_t B, int64_t H, int64_t N,
+                              int64_t dh, float scale, dl_stream_t stream);
 extern "C" int dl_attn_bwd_ex(const void* q, const void* k, const void* v, const void* out, const void* dout,
                               const float* lse, void* dq, void* dk, void* dv, int64_t B, int64_t H, int64_t Nq, int64_t Nk,
                               int64_t dh, float scale, const float* key_bias, dl_stream_t stream);
@@ -90,7 +105,7 @@ extern "C" int dl_attn_bwd_ex(const void* q, const void* k, const void* v, const
 // ====================================================================================== forward
 __global__ __launch_bounds__(512) void attn_fwd_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                   const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
-                                                  float* __restrict__ lse, int H, int N, float scale) {
+                                                  float* __restrict__ lse, int H, int N, float scale, HeadLayout vl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kt = smem;
   char* vt = smem + N * ROWB;
@@ -99,9 +114,9 @@ __global__ __launch_bounds__(512) void attn_fwd_k(const bf16_t* __restrict__ q, 
   const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
   const bf16_t* qg = q + (int64_t)bh * N * DH;
   const bf16_t* kg = k + (int64_t)bh * N * DH;
-  const bf16_t* vg = v + (int64_t)bh * N * DH;
+  const bf16_t* vg = v + b * vl.bs + h * vl.hs;
   tile_dma(kg, DH, kt, N, wave, nwaves, lane);
-  tile_dma(vg, DH, vt, N, wave, nwaves, lane);
+  tile_dma(vg, vl.pitch, vt, N, wave, nwaves, lane);
 
   const int q0 = wave * 32;
   bf16x8_t qf[4];
@@ -307,10 +322,21 @@ extern "C" int dl_attn_fwd(const void* q, const void* k, const void* v, void* ou
                "dl_attn_fwd: N=%lld must be a multiple of 64 up to 256, or a multiple of 256 up to 2048", (long long)N);
   if (N > 256)  // (the resident-tile kernel runs N/32 waves per workgroup: 8 at most)
     return dl_attn_fwd_ex(q, k, v, out, lse, B, H, N, N, dh, scale, nullptr, stream);
+  return dl_attn_fwd_sv(q, k, v, H * N * DH, N * DH, DH, out, lse, B, H, N, dh, scale, stream);
+}
+extern "C" int dl_attn_fwd_sv(const void* q, const void* k, const void* v, int64_t v_batch_stride, int64_t v_head_stride,
+                              int64_t v_pitch, void* out, float* lse, int64_t B, int64_t H, int64_t N, int64_t dh, float scale,
+                              dl_stream_t stream) {
+  DL_CHECK_ARG(q && k && v && out && lse && B > 0 && H > 0, "dl_attn_fwd_sv: null operand");
+  DL_CHECK_ARG(dh == DH, "dl_attn_fwd_sv: head_dim %lld unsupported (64 only)", (long long)dh);
+  DL_CHECK_ARG(N % 64 == 0 && N >= 64 && N <= 256, "dl_attn_fwd_sv: N=%lld must be a multiple of 64 up to 256", (long long)N);
+  DL_CHECK_ARG(v_pitch >= DH && v_pitch % 8 == 0 && v_head_stride % 8 == 0 && v_batch_stride % 8 == 0 && ((uintptr_t)v & 15) == 0,
+               "dl_attn_fwd_sv: V rows must be 16-byte aligned");
   const int lds = (int)(2 * N * ROWB);
   (void)hipFuncSetAttribute((const void*)attn_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(attn_fwd_k, (int)(B * H), (int)(N / 32) * 64, lds, (hipStream_t)stream, (const bf16_t*)q,
-                     (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, lse, (int)H, (int)N, scale);
+                     (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, lse, (int)H, (int)N, scale,
+                     HeadLayout{v_batch_stride, v_head_stride, (int)v_pitch});
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
@@ -325,7 +351,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
                                                      const bf16_t* __restrict__ v, const bf16_t* __restrict__ out,
                                                      const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                      bf16_t* __restrict__ dq, bf16_t* __restrict__ dk,
-                                                     bf16_t* __restrict__ dv, int H, int N, float scale) {
+                                                     bf16_t* __restrict__ dv, int H, int N, float scale, HeadLayout vl,
+                                                     HeadLayout dvl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ta = smem;             // phase A: K   | phase B: Q
   char* tb = ta + N * ROWB;    // phase A: V   | phase B: dO
@@ -339,7 +366,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
   const bf16_t* og = out + (int64_t)b * N * tok_pitch + h * DH;
   const bf16_t* dog = dout + (int64_t)b * N * tok_pitch + h * DH;
   tile_dma(k + hoff, DH, ta, N, wave, nwaves, lane);
-  tile_dma(v + hoff, DH, tb, N, wave, nwaves, lane);
+  const bf16_t* vg = v + b * vl.bs + h * vl.hs;
+  tile_dma(vg, vl.pitch, tb, N, wave, nwaves, lane);
   // delta and lse2: two threads per row, 32 head-dim columns each
   for (int row = threadIdx.x >> 1; row < N; row += blockDim.x >> 1) {
     const int half = threadIdx.x & 1;
@@ -435,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       kf[ks] = frag_rows_g(k + hoff, DH, own + (lane & 31), ks, hi);
-      vf[ks] = frag_rows_g(v + hoff, DH, own + (lane & 31), ks, hi);
+      vf[ks] = frag_rows_g(vg, vl.pitch, own + (lane & 31), ks, hi);
     }
     f32x16_t dka[2], dva[2];
 #pragma unroll
@@ -484,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
       s0 = s1;
     }
     bf16_t* dkp = dk + hoff + (int64_t)(own + (lane & 31)) * DH;
-    bf16_t* dvp = dv + hoff + (int64_t)(own + (lane & 31)) * DH;
+    bf16_t* dvp = dv + b * dvl.bs + h * dvl.hs + (int64_t)(own + (lane & 31)) * dvl.pitch;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -715,11 +743,26 @@ extern "C" int dl_attn_bwd(const void* q, const void* k, const void* v, const vo
   DL_CHECK_ARG(N % 64 == 0 && N >= 64 && (N <= 256 || (N % ACH == 0 && N <= 2048)),
                "dl_attn_bwd: N=%lld must be a multiple of 64 up to 256, or a multiple of 256 up to 2048", (long long)N);
   if (N > 256) return dl_attn_bwd_ex(q, k, v, out, dout, lse, dq, dk, dv, B, H, N, N, dh, scale, nullptr, stream);
+  return dl_attn_bwd_sv(q, k, v, H * N * DH, N * DH, DH, out, dout, lse, dq, dk, dv, H * N * DH, N * DH, DH, B, H, N, dh, scale,
+                        stream);
+}
+extern "C" int dl_attn_bwd_sv(const void* q, const void* k, const void* v, int64_t v_batch_stride, int64_t v_head_stride,
+                              int64_t v_pitch, const void* out, const void* dout, const float* lse, void* dq, void* dk, void* dv,
+                              int64_t dv_batch_stride, int64_t dv_head_stride, int64_t dv_pitch, int64_t B, int64_t H, int64_t N,
+                              int64_t dh, float scale, dl_stream_t stream) {
+  DL_CHECK_ARG(q && k && v && out && dout && lse && dq && dk && dv && B > 0 && H > 0, "dl_attn_bwd_sv: null operand");
+  DL_CHECK_ARG(dh == DH, "dl_attn_bwd_sv: head_dim %lld unsupported (64 only)", (long long)dh);
+  DL_CHECK_ARG(N % 64 == 0 && N >= 64 && N <= 256, "dl_attn_bwd_sv: N=%lld must be a multiple of 64 up to 256", (long long)N);
+  DL_CHECK_ARG(v_pitch >= DH && v_pitch % 8 == 0 && v_head_stride % 8 == 0 && v_batch_stride % 8 == 0 && ((uintptr_t)v & 15) == 0 &&
+                   dv_pitch >= DH && dv_pitch % 4 == 0 && dv_head_stride % 4 == 0 && dv_batch_stride % 4 == 0 &&
+                   ((uintptr_t)dv & 7) == 0,
+               "dl_attn_bwd_sv: V rows must be 16-byte aligned, dV rows 8-byte aligned");
   const int lds = (int)(2 * N * ROWB + 2 * N * sizeof(float));
   (void)hipFuncSetAttribute((const void*)attn_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(attn_bwd_k, (int)(B * H), (int)(N / 64) * 64, lds, (hipStream_t)stream, (const bf16_t*)q,
                      (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dq,
-                     (bf16_t*)dk, (bf16_t*)dv, (int)H, (int)N, scale);
+                     (bf16_t*)dk, (bf16_t*)dv, (int)H, (int)N, scale, HeadLayout{v_batch_stride, v_head_stride, (int)v_pitch},
+                     HeadLayout{dv_batch_stride, dv_head_stride, (int)dv_pitch});
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(const bf16_t* __restri
     float q[NJ][8], k[NJ][8], v[NJ][8];
     load_row<NJ>(p, D8, lane, q);
     load_row<NJ>(p + D, D8, lane, k);
-    load_row<NJ>(p + 2 * D, D8, lane, v);
+    if (vo) load_row<NJ>(p + 2 * D, D8, lane, v);  // vo == NULL: the attention reads V in place (dl_attn_fwd_sv)
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(const bf16_t* __restri
       const int64_t o = (((int64_t)b * H + h) * n_dst + n_off + n) * dh + d0;
       *(u32x4_t*)(qo + o) = pack8(q[j]);
       *(u32x4_t*)(ko + o) = pack8(k[j]);
-      *(u32x4_t*)(vo + o) = pack8(v[j]);
+      if (vo) *(u32x4_t*)(vo + o) = pack8(v[j]);
     }
     if (lane == 0) {
       rrms[row * 2] = rq;
@@ -601,7 +601,7 @@ extern "C" int dl_qk_norm_rope_fwd_ex(const void* qkv, const float* scale_q, con
                                       const float* sin, void* q, void* k, void* v, float* rrms, int64_t B, int64_t N,
                                       int64_t H, int64_t dh, int64_t rot, float eps, const int32_t* pos, int64_t n_dst,
                                       int64_t n_off, dl_stream_t stream) {
-  DL_CHECK_ARG(qkv && scale_q && scale_k && cos && sin && q && k && v && rrms && B > 0 && N > 0,
+  DL_CHECK_ARG(qkv && scale_q && scale_k && cos && sin && q && k && rrms && B > 0 && N > 0,
                "dl_qk_norm_rope_fwd: null operand");
   DL_CHECK_ARG(n_off >= 0 && n_off + N <= n_dst, "dl_qk_norm_rope_fwd: row window [%lld, %lld) outside n_dst=%lld",
                (long long)n_off, (long long)(n_off + N), (long long)n_dst);
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(const bf16_t* __restri
       const int64_t o = (((int64_t)b * H + h) * n_dst + n_off + n) * dh + d0;
       unpack8(*(const u32x4_t*)(dq + o), gq[j]);
       unpack8(*(const u32x4_t*)(dk + o), gk[j]);
-      unpack8(*(const u32x4_t*)(dv + o), gv[j]);
+      if (dv) unpack8(*(const u32x4_t*)(dv + o), gv[j]);
       if (d0 < rot) {  // transpose of the rotation
         const f32x4_t cc = *(const f32x4_t*)(cs + (int64_t)nt * (rot >> 1) + (d0 >> 1));
         const f32x4_t ss = *(const f32x4_t*)(sn + (int64_t)nt * (rot >> 1) + (d0 >> 1));
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(const bf16_t* __restri
     bf16_t* o = dqkv + row * 3 * D;
     store_row<NJ>(o, D8, lane, gq);
     store_row<NJ>(o + D, D8, lane, gk);
-    store_row<NJ>(o + 2 * D, D8, lane, gv);
+    if (dv) store_row<NJ>(o + 2 * D, D8, lane, gv);  // dv == NULL: dl_attn_bwd_sv already wrote the v third of dqkv
   }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
@@ -735,7 +735,7 @@ extern "C" int dl_qk_norm_rope_bwd_ex(const void* dq, const void* dk, const void
                                    const float* scale_q, const float* scale_k, const float* cos, const float* sin,
                                    const float* rrms, void* dqkv, float* dscale, int64_t B, int64_t N, int64_t H,
                                    int64_t dh, int64_t rot, const int32_t* pos, int64_t n_dst, int64_t n_off, dl_stream_t stream) {
-  DL_CHECK_ARG(dq && dk && dv && qkv && scale_q && scale_k && cos && sin && rrms && dqkv && dscale && B > 0 && N > 0,
+  DL_CHECK_ARG(dq && dk && qkv && scale_q && scale_k && cos && sin && rrms && dqkv && dscale && B > 0 && N > 0,
                "dl_qk_norm_rope_bwd: null operand");
   const int64_t D = H * dh;
   DL_CHECK_ARG(dh % 8 == 0 && rot % 8 == 0 && rot <= dh && D <= 512 * MAXJ && n_off >= 0 && n_off + N <= n_dst,

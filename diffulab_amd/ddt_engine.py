@@ -123,9 +123,13 @@ class PerTokenDecoder:
             a["xin"] = xcur
             ops.gemm_nt(a["xm1"], sh[pre + "attention.qkv.weight|f"], a["qkv"])
             ops.qk_norm_rope_fwd(a["qkv"], self.P(pre + "attention.qk_norm.query_norm.scale"),
-                                 self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["q"], a["k"], a["v"], a["rrms"], B, N, Hh,
+                                 self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["q"], a["k"],
+                                 None if ops.v_in_place(N) else a["v"], a["rrms"], B, N, Hh,
                                  64, rot)
-            ops.attn_fwd(a["q"], a["k"], a["v"], a["a"], a["lse"], B, Hh, N, 64, 64**-0.5)
+            if ops.v_in_place(N):  # V read in place from the qkv rows (engine.py)
+                ops.attn_fwd_qkv(a["q"], a["k"], a["qkv"], a["a"], a["lse"], B, Hh, N, 64, 64**-0.5)
+            else:
+                ops.attn_fwd(a["q"], a["k"], a["v"], a["a"], a["lse"], B, Hh, N, 64, 64**-0.5)
             ops.gemm_nt(a["a"], sh[pre + "attention.proj_out.weight|f"], a["t1"])
             ops.ln_modulate_fwd(xcur, self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"), tm[:, mo + 3 * D : mo + 4 * D],
                                 tm[:, mo + 4 * D : mo + 5 * D], 1, 1e-5, a["xm2"], a["mean2"], a["rstd2"], t=a["t1"],
@@ -187,8 +191,13 @@ class PerTokenDecoder:
             dx, dx_alt = dx_alt, dx
             wgrad(g["dt1"], a["a"], pre + "attention.proj_out.weight")
             ops.gemm_nt(g["dt1"], sh[pre + "attention.proj_out.weight|t"], s["da"])
-            ops.attn_bwd(a["q"], a["k"], a["v"], a["a"], s["da"], a["lse"], s["dq"], s["dk"], s["dv"], B, Hh, N, 64, 64**-0.5)
-            ops.qk_norm_rope_bwd(s["dq"], s["dk"], s["dv"], a["qkv"], self.P(pre + "attention.qk_norm.query_norm.scale"),
+            if ops.v_in_place(N):
+                ops.attn_bwd_qkv(a["q"], a["k"], a["qkv"], a["a"], s["da"], a["lse"], s["dq"], s["dk"], g["dqkv"], B, Hh, N, 64,
+                                 64**-0.5)
+            else:
+                ops.attn_bwd(a["q"], a["k"], a["v"], a["a"], s["da"], a["lse"], s["dq"], s["dk"], s["dv"], B, Hh, N, 64, 64**-0.5)
+            ops.qk_norm_rope_bwd(s["dq"], s["dk"], None if ops.v_in_place(N) else s["dv"], a["qkv"],
+                                 self.P(pre + "attention.qk_norm.query_norm.scale"),
                                  self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], g["dqkv"],
                                  self.G(pre + "attention.qk_norm.query_norm.scale"), B, N, Hh, 64, rot)
             wgrad(g["dqkv"], a["xm1"], pre + "attention.qkv.weight")

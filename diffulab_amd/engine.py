@@ -310,7 +310,8 @@ class DiTEngine:
         for _ in range(nl):
             per.append({
                 "mean1": z(M, dtype=f32), "rstd1": z(M, dtype=f32), "xm1": z(M, D), "qkv": z(M, 3 * D),
-                "q": z(B, d.num_heads, N, 64), "k": z(B, d.num_heads, N, 64), "v": z(B, d.num_heads, N, 64),
+                "q": z(B, d.num_heads, N, 64), "k": z(B, d.num_heads, N, 64),
+                "v": None if ops.v_in_place(N) else z(B, d.num_heads, N, 64),  # (N <= 256: V is read in place from qkv)
                 "rrms": z(M, 2, dtype=f32), "a": z(M, D), "lse": z(B, d.num_heads, N, dtype=f32), "t1": z(M, D),
                 "x1": z(M, D), "mean2": z(M, dtype=f32), "rstd2": z(M, dtype=f32), "xm2": z(M, D),
                 "u": z(M, 2 * d.mlp_ratio * D), "h": z(M, d.mlp_ratio * D), "t2": z(M, D),
@@ -328,7 +329,8 @@ class DiTEngine:
             # per-block inputs of the weight-gradient GEMMs (consumed asynchronously on the side stream)
             w["wg"] = [{"dt2": z(M, D), "du": z(M, 2 * d.mlp_ratio * D), "dt1": z(M, D), "dqkv": z(M, 3 * D)}
                        for _ in range(L)]
-            w["dq"], w["dk"], w["dv"] = (z(B, d.num_heads, N, 64) for _ in range(3))
+            w["dq"], w["dk"] = z(B, d.num_heads, N, 64), z(B, d.num_heads, N, 64)
+            w["dv"] = None if ops.v_in_place(N) else z(B, d.num_heads, N, 64)
             w["dmod"] = z(Bp, self.layout.mod_rows)                  # bf16 operand of the modulation GEMMs' backward
             w["dmod32"] = z(Bp, self.layout.mod_rows, dtype=f32)     # f32 accumulator the block kernels add into
             w["dwb"] = z(2 * L, B, 2, D, dtype=f32)  # per-norm partials: folded on the side stream, cleared while read
@@ -405,10 +407,15 @@ class DiTEngine:
                                     mod[:, mo + D : mo + 2 * D], N, 1e-5, a["xm1"], a["mean1"], a["rstd1"], t=pend[1],
                                     gate=pend[2], x_out=xin)
             ops.gemm_nt(a["xm1"], sh[pre + "attention.qkv.weight|f"], a["qkv"])
+            # up to 256 tokens the attention kernels address V (and dV) inside the token-major qkv (dqkv) rows: no V head split
+            v_in_place = ops.v_in_place(N)
             ops.qk_norm_rope_fwd(a["qkv"], self.P(pre + "attention.qk_norm.query_norm.scale"),
-                                 self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["q"], a["k"], a["v"],
-                                 a["rrms"], B, N, Hh, 64, rot)
-            ops.attn_fwd(a["q"], a["k"], a["v"], a["a"], a["lse"], B, Hh, N, 64, 64**-0.5)
+                                 self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["q"], a["k"],
+                                 None if v_in_place else a["v"], a["rrms"], B, N, Hh, 64, rot)
+            if v_in_place:
+                ops.attn_fwd_qkv(a["q"], a["k"], a["qkv"], a["a"], a["lse"], B, Hh, N, 64, 64**-0.5)
+            else:
+                ops.attn_fwd(a["q"], a["k"], a["v"], a["a"], a["lse"], B, Hh, N, 64, 64**-0.5)
             ops.gemm_nt(a["a"], sh[pre + "attention.proj_out.weight|f"], a["t1"])
             ops.ln_modulate_fwd(xin, self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"),
                                 mod[:, mo + 3 * D : mo + 4 * D], mod[:, mo + 4 * D : mo + 5 * D], N, 1e-5, a["xm2"],
@@ -519,9 +526,15 @@ class DiTEngine:
             # attention branch
             wgrad(g["dt1"], a["a"], pre + "attention.proj_out.weight")
             ops.gemm_nt(g["dt1"], sh[pre + "attention.proj_out.weight|t"], w["da"])
-            ops.attn_bwd(a["q"], a["k"], a["v"], a["a"], w["da"], a["lse"], w["dq"], w["dk"], w["dv"], B, Hh, N, 64,
-                         64**-0.5)
-            ops.qk_norm_rope_bwd(w["dq"], w["dk"], w["dv"], a["qkv"], self.P(pre + "attention.qk_norm.query_norm.scale"),
+            v_in_place = ops.v_in_place(N)
+            if v_in_place:  # dV goes straight into the v third of dqkv
+                ops.attn_bwd_qkv(a["q"], a["k"], a["qkv"], a["a"], w["da"], a["lse"], w["dq"], w["dk"], g["dqkv"], B, Hh, N, 64,
+                                 64**-0.5)
+            else:
+                ops.attn_bwd(a["q"], a["k"], a["v"], a["a"], w["da"], a["lse"], w["dq"], w["dk"], w["dv"], B, Hh, N, 64,
+                             64**-0.5)
+            ops.qk_norm_rope_bwd(w["dq"], w["dk"], None if v_in_place else w["dv"], a["qkv"],
+                                 self.P(pre + "attention.qk_norm.query_norm.scale"),
                                  self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], g["dqkv"],
                                  self.G(pre + "attention.qk_norm.query_norm.scale"), B, N, Hh, 64, rot)
             wgrad(g["dqkv"], a["xm1"], pre + "attention.qkv.weight")

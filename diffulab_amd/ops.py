@@ -8,6 +8,8 @@ There is no fallback path: a missing library or a CPU tensor raises.
 
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import Tensor
 
@@ -279,6 +281,26 @@ def attn_fwd(q, k, v, out, lse, B, H, N, dh, scale):
 def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, N, dh, scale):
     _call("dl_attn_bwd", _p(q), _p(k), _p(v), _p(out), _p(dout), _p(lse), _p(dq), _p(dk), _p(dv), B, H, N, dh,
           float(scale), _s())
+
+
+def v_in_place(N: int) -> bool:
+    """up to 256 tokens the attention kernels address V / dV inside the token-major qkv / dqkv rows (no head-split copy of V);
+    DL_ATTN_V_IN_PLACE=0 restores the head-major V buffers (A/B switch)"""
+    return N <= 256 and os.environ.get("DL_ATTN_V_IN_PLACE", "1") != "0"
+
+
+def attn_fwd_qkv(q, k, qkv, out, lse, B, H, N, dh, scale):
+    """N <= 256: V is read in place from the v third of the token-major qkv rows [B*N, 3*H*dh]"""
+    D = H * dh
+    _call("dl_attn_fwd_sv", _p(q), _p(k), qkv.data_ptr() + 2 * D * 2, N * 3 * D, dh, 3 * D, _p(out), _p(lse), B, H, N, dh,
+          float(scale), _s())
+
+
+def attn_bwd_qkv(q, k, qkv, out, dout, lse, dq, dk, dqkv, B, H, N, dh, scale):
+    """N <= 256: V read from qkv, dV written into the v third of dqkv [B*N, 3*H*dh] (qk_norm_rope_bwd then takes dv=None)"""
+    D = H * dh
+    _call("dl_attn_bwd_sv", _p(q), _p(k), qkv.data_ptr() + 2 * D * 2, N * 3 * D, dh, 3 * D, _p(out), _p(dout), _p(lse), _p(dq),
+          _p(dk), dqkv.data_ptr() + 2 * D * 2, N * 3 * D, dh, 3 * D, B, H, N, dh, float(scale), _s())
 
 
 def attn_fwd_ex(q, k, v, out, lse, B, H, Nq, Nk, dh, scale, key_bias=None):

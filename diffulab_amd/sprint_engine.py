@@ -161,9 +161,13 @@ class SprintEngine(DiTEngine):
             a["xin"] = xcur
             ops.gemm_nt(a["xm1"], sh[pre + "attention.qkv.weight|f"], a["qkv"])
             ops.qk_norm_rope_fwd(a["qkv"], self.P(pre + "attention.qk_norm.query_norm.scale"),
-                                 self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["q"], a["k"], a["v"], a["rrms"], B, nt,
+                                 self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["q"], a["k"],
+                                 None if ops.v_in_place(nt) else a["v"], a["rrms"], B, nt,
                                  Hh, 64, rot, pos=pos)
-            ops.attn_fwd(a["q"], a["k"], a["v"], a["a"], a["lse"], B, Hh, nt, 64, 64**-0.5)
+            if ops.v_in_place(nt):  # V read in place from the qkv rows (engine.py)
+                ops.attn_fwd_qkv(a["q"], a["k"], a["qkv"], a["a"], a["lse"], B, Hh, nt, 64, 64**-0.5)
+            else:
+                ops.attn_fwd(a["q"], a["k"], a["v"], a["a"], a["lse"], B, Hh, nt, 64, 64**-0.5)
             ops.gemm_nt(a["a"], sh[pre + "attention.proj_out.weight|f"], a["t1"])
             ops.ln_modulate_fwd(xcur, self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"), mod[:, mo + 3 * D : mo + 4 * D],
                                 mod[:, mo + 4 * D : mo + 5 * D], nt, 1e-5, a["xm2"], a["mean2"], a["rstd2"], t=a["t1"],
@@ -216,8 +220,13 @@ class SprintEngine(DiTEngine):
             dx = dx_alt
             wgrad(g["dt1"], a["a"], pre + "attention.proj_out.weight")
             ops.gemm_nt(g["dt1"], sh[pre + "attention.proj_out.weight|t"], s["da"])
-            ops.attn_bwd(a["q"], a["k"], a["v"], a["a"], s["da"], a["lse"], s["dq"], s["dk"], s["dv"], B, Hh, nt, 64, 64**-0.5)
-            ops.qk_norm_rope_bwd(s["dq"], s["dk"], s["dv"], a["qkv"], self.P(pre + "attention.qk_norm.query_norm.scale"),
+            if ops.v_in_place(nt):
+                ops.attn_bwd_qkv(a["q"], a["k"], a["qkv"], a["a"], s["da"], a["lse"], s["dq"], s["dk"], g["dqkv"], B, Hh, nt, 64,
+                                 64**-0.5)
+            else:
+                ops.attn_bwd(a["q"], a["k"], a["v"], a["a"], s["da"], a["lse"], s["dq"], s["dk"], s["dv"], B, Hh, nt, 64, 64**-0.5)
+            ops.qk_norm_rope_bwd(s["dq"], s["dk"], None if ops.v_in_place(nt) else s["dv"], a["qkv"],
+                                 self.P(pre + "attention.qk_norm.query_norm.scale"),
                                  self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], g["dqkv"],
                                  self.G(pre + "attention.qk_norm.query_norm.scale"), B, nt, Hh, 64, rot, pos=pos)
             wgrad(g["dqkv"], a["xm1"], pre + "attention.qkv.weight")

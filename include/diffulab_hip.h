@@ -178,7 +178,8 @@ DL_API int dl_gate_bwd(const void* dout, const void* t, const void* gate, int64_
                        void* dt, float* dgate, int64_t ld_dmod, int64_t M, int64_t D, dl_stream_t stream);
 /* QKNorm (nn.py:427-431,473-475: RMS over the FULL inner dim, eps 1e-6) + N-D RoPE on interleaved pairs
  * (nn.py:345-353,377-400) + head split 'b n (h d) -> b h n d' (mmdit.py:85-91).
- * qkv bf16 [B*N, 3D]; cos/sin f32 [N, rot/2]; q,k,v out bf16 [B,H,N,dh]; rrms f32 [B*N, 2] saved. */
+ * qkv bf16 [B*N, 3D]; cos/sin f32 [N, rot/2]; q,k,v out bf16 [B,H,N,dh]; rrms f32 [B*N, 2] saved.
+ * v (forward) / dv (backward) may be NULL: V is then neither copied nor its gradient written (see dl_attn_fwd_sv). */
 DL_API int dl_qk_norm_rope_fwd(const void* qkv, const float* scale_q, const float* scale_k, const float* cos,
                                const float* sin, void* q, void* k, void* v, float* rrms, int64_t B, int64_t N,
                                int64_t H, int64_t dh, int64_t rot, float eps, dl_stream_t stream);
@@ -218,6 +219,17 @@ DL_API int dl_attn_fwd_ex(const void* q, const void* k, const void* v, void* out
 DL_API int dl_attn_bwd_ex(const void* q, const void* k, const void* v, const void* out, const void* dout,
                           const float* lse, void* dq, void* dk, void* dv, int64_t B, int64_t H, int64_t Nq, int64_t Nk,
                           int64_t dh, float scale, const float* key_bias, dl_stream_t stream);
+/* the N <= 256 kernels with V (and dV) addressed in place: head (b, h) of V starts at element b*v_batch_stride +
+ * h*v_head_stride of `v`, its rows are v_pitch elements apart.  With v = qkv + 2*D, strides {N*3D, 64, 3D} the attention
+ * reads the v third of the token-major qkv rows [B*N, 3D] (the reference's `qkv.chunk(3)`, mmdit.py:85-93) and the backward
+ * writes dV straight into the v third of dqkv, so dl_qk_norm_rope_{fwd,bwd} are called with v / dv = NULL and never copy V. */
+DL_API int dl_attn_fwd_sv(const void* q, const void* k, const void* v, int64_t v_batch_stride, int64_t v_head_stride,
+                          int64_t v_pitch, void* out, float* lse, int64_t B, int64_t H, int64_t N, int64_t dh, float scale,
+                          dl_stream_t stream);
+DL_API int dl_attn_bwd_sv(const void* q, const void* k, const void* v, int64_t v_batch_stride, int64_t v_head_stride,
+                          int64_t v_pitch, const void* out, const void* dout, const float* lse, void* dq, void* dk, void* dv,
+                          int64_t dv_batch_stride, int64_t dv_head_stride, int64_t dv_pitch, int64_t B, int64_t H, int64_t N,
+                          int64_t dh, float scale, dl_stream_t stream);
 /* PackedSwiGLU nn.py:484-486: h = silu(u[:, :F]) * u[:, F:] ; u bf16 [M, 2F] */
 DL_API int dl_swiglu_fwd(const void* u, void* h, int64_t M, int64_t F, dl_stream_t stream);
 DL_API int dl_swiglu_bwd(const void* dh, const void* u, void* du, int64_t M, int64_t F, dl_stream_t stream);

@@ -257,6 +257,31 @@ def test_attention_fwd_bwd(ops, B, H, N):
     assert rel(dk.float(), k.grad) < 8e-3
 
 
+@pytest.mark.parametrize("B,H,N", [(2, 6, 256), (3, 2, 64), (2, 3, 192)])
+def test_attention_reads_v_and_writes_dv_inside_the_qkv_rows(ops, B, H, N):
+    """dl_attn_{fwd,bwd}_sv: V addressed in place in the v third of token-major qkv rows [B*N, 3D], dV written into the v third of
+    dqkv (whose q / k thirds must stay untouched) -- bit-identical to the head-major call on the same values."""
+    dh, D = 64, H * 64
+    scale = dh**-0.5
+    q, k = (dev_bf(bf(synth.normal(f"sv.{n}{N}", (B, H, N, dh)))) for n in "qk")
+    qkv = dev_bf(bf(synth.normal(f"sv.qkv{N}", (B * N, 3 * D))))
+    v = qkv.view(B, N, 3, H, dh)[:, :, 2].permute(0, 2, 1, 3).contiguous()  # 'b n (h d) -> b h n d' of the v third
+    do = dev_bf(bf(synth.normal(f"sv.do{N}", (B, N, D))))
+    out0, out1 = (torch.empty(B, N, D, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    lse0, lse1 = (torch.empty(B, H, N, device=DEV) for _ in range(2))
+    ops.attn_fwd(q, k, v, out0, lse0, B, H, N, dh, scale)
+    ops.attn_fwd_qkv(q, k, qkv, out1, lse1, B, H, N, dh, scale)
+    assert torch.equal(out0, out1) and torch.equal(lse0, lse1)
+    dq0, dk0, dv0, dq1, dk1 = (torch.empty(B, H, N, dh, device=DEV, dtype=torch.bfloat16) for _ in range(5))
+    dqkv = torch.full((B * N, 3 * D), 7.0, device=DEV, dtype=torch.bfloat16)
+    ops.attn_bwd(q, k, v, out0, do, lse0, dq0, dk0, dv0, B, H, N, dh, scale)
+    ops.attn_bwd_qkv(q, k, qkv, out1, do, lse1, dq1, dk1, dqkv, B, H, N, dh, scale)
+    assert torch.equal(dq0, dq1) and torch.equal(dk0, dk1)
+    got = dqkv.view(B, N, 3, H, dh)
+    assert torch.equal(got[:, :, 2].permute(0, 2, 1, 3), dv0)
+    assert bool((got[:, :, :2] == 7.0).all())
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,valid", [(2, 2, 256, 512, (320, 512)), (2, 3, 512, 512, (300, 77)), (1, 1, 256, 256, (200,))])
 def test_attention_cross_lengths_and_key_mask(ops, B, H, Nq, Nk, valid):
     """general form: Nq queries against Nk keys with a key-padding mask given as an additive bias (0 / -inf): cross-attention
