@@ -150,8 +150,10 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
         "ln_modulate_fwd": lambda x, w, b, sc, sh, rpm, eps, out, mean, rstd, t=None, gate=None, x_out=None: nbytes(x, out, t, x_out),
         "ln_modulate_bwd": lambda dout, x, w, b, sc, rpm, mean, rstd, dres, dx, dsc, dsh, dwb, gate_t=None, gate=None, dt=None,
         dgate=None: nbytes(dout, x, dres, dx, gate_t, dt),
-        "qk_norm_rope_fwd": lambda qkv, sq, sk, cos, sin, q, k, v, *a, **kw: nbytes(qkv, q, k, v),
-        "qk_norm_rope_bwd": lambda dq, dk, dv, qkv, sq, sk, cos, sin, rrms, dqkv, *a, **kw: nbytes(dq, dk, dv, qkv, dqkv),
+        # (v / dv None: V stays inside the qkv rows and only the q and k thirds of qkv / dqkv are touched)
+        "qk_norm_rope_fwd": lambda qkv, sq, sk, cos, sin, q, k, v, *a, **kw: nbytes(q, k, v) + nbytes(qkv) * (1.0 if v is not None else 2 / 3),
+        "qk_norm_rope_bwd": lambda dq, dk, dv, qkv, sq, sk, cos, sin, rrms, dqkv, *a, **kw: nbytes(dq, dk, dv)
+        + nbytes(qkv, dqkv) * (1.0 if dv is not None else 2 / 3),
     }
     orig_rows = {n: getattr(ops, n) for n in row_bytes}
 
