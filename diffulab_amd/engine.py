@@ -553,6 +553,11 @@ class DiTEngine:
             dx, dx_alt = dx_alt, dx
             if self.reducer is not None:  # this block's gradient range is final once BOTH streams are past this point
                 self.reducer.ready(*self.layer_ranges[i], extra_events=(side.record_event(),))
+        if os.environ.get("DL_TAIL_PROBE") == "1":  # how long the side stream's wgrads run on after the main chain is done
+            e_main, e_side = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e_main.record(main)
+            e_side.record(side)
+            self._tail_probe = (e_main, e_side)
         main.wait_stream(side)
 
         self._cond_bwd(dx)
