@@ -81,6 +81,26 @@ __device__ __forceinline__ bf16x8_t pack_frag(const float* p) {
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
+// store a transposed 64-column accumulator pair (lane & 31 = row, register r <-> column 8*(r>>2) + 4*hi + (r&3) of each 32-wide
+// half) as bf16: one v_permlane32_swap per register pair gives every lane 8 consecutive columns = one 16-byte store, 32 contiguous
+// bytes per row and instruction (the GEMM epilogue's scheme) instead of 8-byte stores
+__device__ __forceinline__ void store_rows64(bf16_t* rowp, const f32x16_t (&a)[2], float mul, int hi) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[dt][8 * gp + e] * mul), __float_as_uint(a[dt][8 * gp + 4 + e] * mul),
+                                                   false, false);
+        v[e] = __uint_as_float(sw[0]);
+        v[4 + e] = __uint_as_float(sw[1]);
+      }
+      *(u32x4_t*)(rowp + dt * 32 + 16 * gp + 8 * hi) = pack8(v);
+    }
+}
+
 // where head (b, h) of V (or dV) lives: element offset b * bs + h * hs, rows `pitch` elements apart.  Head-major [B, H, N, 64] is
 // {H*N*64, N*64, 64}; the v third of the token-major qkv rows [B*N, 3D] is {N*3D, 64, 3D} on a pointer advanced by 2D, which lets
 // the N <= 256 kernels read V / write dV in place (no head-split copy of V in the QK-norm kernels).
@@ -181,16 +201,7 @@ __global__ __launch_bounds__(512) void attn_fwd_k(const bf16_t* __restrict__ q, 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
   const int qrow = q0 + (lane & 31);
-  bf16_t* op = out + ((int64_t)b * N + qrow) * (H * DH) + h * DH;
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      u32x2_t w;
-      w[0] = pack2bf(o[dt][g4 * 4 + 0] * inv, o[dt][g4 * 4 + 1] * inv);
-      w[1] = pack2bf(o[dt][g4 * 4 + 2] * inv, o[dt][g4 * 4 + 3] * inv);
-      *(u32x2_t*)(op + dt * 32 + g4 * 8 + hi * 4) = w;
-    }
+  store_rows64(out + ((int64_t)b * N + qrow) * (H * DH) + h * DH, o, inv, hi);
   if (hi == 0) lse[(int64_t)bh * N + qrow] = (m_run + log2f(l_tot)) * LN2;
 }
 
@@ -286,16 +297,7 @@ __global__ __launch_bounds__(512) void attn_fwd_tiled_k(const bf16_t* __restrict
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
   const int qrow = q0 + (lane & 31);
-  bf16_t* op = out + ((int64_t)b * Nq + qrow) * (H * DH) + h * DH;
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      u32x2_t w;
-      w[0] = pack2bf(o[dt][g4 * 4 + 0] * inv, o[dt][g4 * 4 + 1] * inv);
-      w[1] = pack2bf(o[dt][g4 * 4 + 2] * inv, o[dt][g4 * 4 + 3] * inv);
-      *(u32x2_t*)(op + dt * 32 + g4 * 8 + hi * 4) = w;
-    }
+  store_rows64(out + ((int64_t)b * Nq + qrow) * (H * DH) + h * DH, o, inv, hi);
   if (hi == 0) lse[(int64_t)bh * Nq + qrow] = (m_run + log2f(l_tot)) * LN2;
 }
 
@@ -437,16 +439,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
       step(kb, s0, d0, s1, d1);
       step(kb + 32, s1, d1, s0, d0);
     }
-    bf16_t* dqp = dq + hoff + (int64_t)(own + (lane & 31)) * DH;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        u32x2_t w;
-        w[0] = pack2bf(dqa[dt][g4 * 4 + 0] * scale, dqa[dt][g4 * 4 + 1] * scale);
-        w[1] = pack2bf(dqa[dt][g4 * 4 + 2] * scale, dqa[dt][g4 * 4 + 3] * scale);
-        *(u32x2_t*)(dqp + dt * 32 + g4 * 8 + hi * 4) = w;
-      }
+    store_rows64(dq + hoff + (int64_t)(own + (lane & 31)) * DH, dqa, scale, hi);
   }
 
   // ------------------------------------------------------------------ swap the resident tiles: Q and dO replace K and V
@@ -511,20 +504,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
       step_t(qb, s0, s1);
       s0 = s1;
     }
-    bf16_t* dkp = dk + hoff + (int64_t)(own + (lane & 31)) * DH;
-    bf16_t* dvp = dv + b * dvl.bs + h * dvl.hs + (int64_t)(own + (lane & 31)) * dvl.pitch;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        u32x2_t w;
-        w[0] = pack2bf(dka[dt][g4 * 4 + 0] * scale, dka[dt][g4 * 4 + 1] * scale);
-        w[1] = pack2bf(dka[dt][g4 * 4 + 2] * scale, dka[dt][g4 * 4 + 3] * scale);
-        *(u32x2_t*)(dkp + dt * 32 + g4 * 8 + hi * 4) = w;
-        w[0] = pack2bf(dva[dt][g4 * 4 + 0], dva[dt][g4 * 4 + 1]);
-        w[1] = pack2bf(dva[dt][g4 * 4 + 2], dva[dt][g4 * 4 + 3]);
-        *(u32x2_t*)(dvp + dt * 32 + g4 * 8 + hi * 4) = w;
-      }
+    store_rows64(dk + hoff + (int64_t)(own + (lane & 31)) * DH, dka, scale, hi);
+    store_rows64(dv + b * dvl.bs + h * dvl.hs + (int64_t)(own + (lane & 31)) * dvl.pitch, dva, 1.0f, hi);
   }
 }
 
@@ -637,16 +618,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_tiled_k(const bf16_t* __restr
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob) {
       const int own = cc * ACH + (wave * 2 + ob) * 32;
-      bf16_t* dqp = dq + hoffq + (int64_t)(own + (lane & 31)) * DH;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          u32x2_t w;
-          w[0] = pack2bf(dqa[ob][dt][g4 * 4 + 0] * scale, dqa[ob][dt][g4 * 4 + 1] * scale);
-          w[1] = pack2bf(dqa[ob][dt][g4 * 4 + 2] * scale, dqa[ob][dt][g4 * 4 + 3] * scale);
-          *(u32x2_t*)(dqp + dt * 32 + g4 * 8 + hi * 4) = w;
-        }
+      store_rows64(dq + hoffq + (int64_t)(own + (lane & 31)) * DH, dqa[ob], scale, hi);
     }
   }
 
@@ -702,20 +674,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_tiled_k(const bf16_t* __restr
         }
       }
     }
-    bf16_t* dkp = dk + hoffk + (int64_t)(own + (lane & 31)) * DH;
-    bf16_t* dvp = dv + hoffk + (int64_t)(own + (lane & 31)) * DH;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        u32x2_t w;
-        w[0] = pack2bf(dka[dt][g4 * 4 + 0] * scale, dka[dt][g4 * 4 + 1] * scale);
-        w[1] = pack2bf(dka[dt][g4 * 4 + 2] * scale, dka[dt][g4 * 4 + 3] * scale);
-        *(u32x2_t*)(dkp + dt * 32 + g4 * 8 + hi * 4) = w;
-        w[0] = pack2bf(dva[dt][g4 * 4 + 0], dva[dt][g4 * 4 + 1]);
-        w[1] = pack2bf(dva[dt][g4 * 4 + 2], dva[dt][g4 * 4 + 3]);
-        *(u32x2_t*)(dvp + dt * 32 + g4 * 8 + hi * 4) = w;
-      }
+    store_rows64(dk + hoffk + (int64_t)(own + (lane & 31)) * DH, dka, scale, hi);
+    store_rows64(dv + hoffk + (int64_t)(own + (lane & 31)) * DH, dva, 1.0f, hi);
   }
 }
 
@@ -754,9 +714,9 @@ extern "C" int dl_attn_bwd_sv(const void* q, const void* k, const void* v, int64
   DL_CHECK_ARG(dh == DH, "dl_attn_bwd_sv: head_dim %lld unsupported (64 only)", (long long)dh);
   DL_CHECK_ARG(N % 64 == 0 && N >= 64 && N <= 256, "dl_attn_bwd_sv: N=%lld must be a multiple of 64 up to 256", (long long)N);
   DL_CHECK_ARG(v_pitch >= DH && v_pitch % 8 == 0 && v_head_stride % 8 == 0 && v_batch_stride % 8 == 0 && ((uintptr_t)v & 15) == 0 &&
-                   dv_pitch >= DH && dv_pitch % 4 == 0 && dv_head_stride % 4 == 0 && dv_batch_stride % 4 == 0 &&
-                   ((uintptr_t)dv & 7) == 0,
-               "dl_attn_bwd_sv: V rows must be 16-byte aligned, dV rows 8-byte aligned");
+                   dv_pitch >= DH && dv_pitch % 8 == 0 && dv_head_stride % 8 == 0 && dv_batch_stride % 8 == 0 &&
+                   ((uintptr_t)dv & 15) == 0,
+               "dl_attn_bwd_sv: V and dV rows must be 16-byte aligned");
   const int lds = (int)(2 * N * ROWB + 2 * N * sizeof(float));
   (void)hipFuncSetAttribute((const void*)attn_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(attn_bwd_k, (int)(B * H), (int)(N / 64) * 64, lds, (hipStream_t)stream, (const bf16_t*)q,
