@@ -109,7 +109,7 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
     launch goes to (the wgrad GEMMs run on the engine's side stream).  The dominant kernel is the NT GEMM family
     `gemm_nt_big_k` (every linear's forward and data-gradient: 2/3 of the step's FLOPs, all on the critical path);
     `achieved` = algorithmic FLOPs of its launches (2 M N K each) / their summed launch durations.  `traffic` is the
-    HBM bytes per launch of the same kernels from the committed PMC passes (profiles/r01_g_pmc_traffic.json:
+    HBM bytes per launch of the same kernels from the committed PMC passes (profiles/r01_m_pmc_traffic.json:
     FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, calibrated on adamw_k), null if that file is absent."""
     from diffulab_amd import ops
 
@@ -196,7 +196,7 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
     n_l, ms, fl = sum(v[0] for v in fam), sum(v[1] for v in fam), sum(v[2] for v in fam)
     ach = fl / (ms * 1e-3) / 1e12
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01_m_pmc_traffic.json")
     if os.path.exists(tpath):
         t = json.load(open(tpath))
         rows = [v for k, v in t.items() if k.startswith("gemm_nt_big_k")]
@@ -215,7 +215,7 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
     step_ach = images_per_s_per_gpu * train_flops_per_image() / 1e12
     return {"bound": "mfma", "kernel": "gemm_nt_big_k (all variants; NT GEMM of every linear fwd + dgrad)",
             "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-            "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_g_pmc_traffic.txt)",
+            "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_m_pmc_traffic.txt)",
             "flops_per_launch": round(fl / n_l), "launches_per_step": n_l // reps, "avg_launch_us": round(ms * 1e3 / n_l, 2),
             "ms_per_step": round(ms / reps, 3), "kernels": kernels,
             "step_achieved": round(step_ach, 1), "step_frac": round(step_ach / PEAK_BF16_TFLOPS, 4),
