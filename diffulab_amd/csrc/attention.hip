@@ -370,26 +370,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
   tile_dma(k + hoff, DH, ta, N, wave, nwaves, lane);
   const bf16_t* vg = v + b * vl.bs + h * vl.hs;
   tile_dma(vg, vl.pitch, tb, N, wave, nwaves, lane);
-  // delta and lse2: two threads per row, 32 head-dim columns each
-  for (int row = threadIdx.x >> 1; row < N; row += blockDim.x >> 1) {
-    const int half = threadIdx.x & 1;
-    const bf16_t* po = og + (int64_t)row * tok_pitch + half * 32;
-    const bf16_t* pd = dog + (int64_t)row * tok_pitch + half * 32;
-    float acc = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float a[8], d[8];
-      unpack8(*(const u32x4_t*)(po + i * 8), a);
-      unpack8(*(const u32x4_t*)(pd + i * 8), d);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc += a[e] * d[e];
-    }
-    acc += __shfl_xor(acc, 1, 64);
-    if (half == 0) {
-      delta[row] = acc;
-      lse2[row] = lse[(int64_t)bh * N + row] * LOG2E;
-    }
-  }
+  // (delta = rowsum(dO * O) and lse * log2(e) of a query block are computed by the wave that owns the block in phase A, from the
+  // dO fragments it loads anyway plus the matching O fragments, and left in LDS for phase B: no separate pass over O and dO)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -404,7 +386,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
       qf[ks] = frag_rows_g(q + hoff, DH, own + (lane & 31), ks, hi);
       dof[ks] = frag_rows_g(dog, tok_pitch, own + (lane & 31), ks, hi);
     }
-    const float my_lse = lse2[own + (lane & 31)], my_delta = delta[own + (lane & 31)];
+    float my_delta = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8_t of = frag_rows_g(og, tok_pitch, own + (lane & 31), ks, hi);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) my_delta += (float)of[e] * (float)dof[ks][e];
+    }
+    my_delta += __shfl_xor(my_delta, 32, 64);  // the other 32 head-dim columns of the row live in the other lane half
+    const float my_lse = lse[(int64_t)bh * N + own + (lane & 31)] * LOG2E;
+    if (hi == 0) {
+      delta[own + (lane & 31)] = my_delta;
+      lse2[own + (lane & 31)] = my_lse;
+    }
     f32x16_t dqa[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqa[0][r] = dqa[1][r] = 0.f;

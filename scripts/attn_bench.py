@@ -34,3 +34,11 @@ us = timeit(lambda: ops.attn_fwd(q, k, v, out, lse, B, H, N, dh, scale))
 print(f"attn_fwd N={N}: {us:7.1f} us  {fl / us / 1e6:6.1f} TFLOP/s")
 us = timeit(lambda: ops.attn_bwd(q, k, v, out, do, lse, dq, dk, dv, B, H, N, dh, scale))
 print(f"attn_bwd N={N}: {us:7.1f} us  {3.5 * fl / us / 1e6:6.1f} TFLOP/s (7 matmuls incl. the recomputed S, twice)")
+if N <= 256:  # V / dV in place inside token-major qkv / dqkv rows
+    D = H * dh
+    qkv = torch.randn(B * N, 3 * D, device=dev).to(bf)
+    dqkv = torch.empty_like(qkv)
+    us = timeit(lambda: ops.attn_fwd_qkv(q, k, qkv, out, lse, B, H, N, dh, scale))
+    print(f"attn_fwd_qkv N={N}: {us:7.1f} us")
+    us = timeit(lambda: ops.attn_bwd_qkv(q, k, qkv, out, do, lse, dq, dk, dqkv, B, H, N, dh, scale))
+    print(f"attn_bwd_qkv N={N}: {us:7.1f} us")
