@@ -15,6 +15,12 @@
 
 #include "common.h"
 
+static int g_gemm_probe = 0;
+extern "C" int dl_probe_gemm_set(int flags) {
+  g_gemm_probe = flags;
+  return DL_OK;
+}
+
 #define BM 128
 #define BN 128
 #define BK 64
@@ -316,7 +322,9 @@ template <int JN, int TN_, int EPI>
 __device__ __forceinline__ void nt_epilogue_regs(f32x16_t (&acc)[JN][2], int m_base, int n_base, int lane, void* C,
                                                  int64_t ldc, const NtEpilogue& ep);
 
-template <int TN_, int NST, int EPI>
+// PROBE (tuning builds only, scripts/gemm_probe.py): 1 = no epilogue stores, 2 = no MFMA, 4 = no DMA after the ring fill,
+// 8 = no LDS fragment reads -- each leaves the rest of the kernel in place, so the differences locate the limiter
+template <int TN_, int NST, int EPI, int PROBE = 0>
 __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __restrict__ A, int64_t lda,
                                                                   const bf16_t* __restrict__ Bm, int64_t ldb,
                                                                   void* __restrict__ C, int64_t ldc, int M, int N,
@@ -356,8 +364,10 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
   const bf16_t* s_tb = Bm + (int64_t)((s_tile % tiles_n) * TN_) * ldb;
   auto stage_next = [&]() {
     char* base = smem + (s_it % NST) * STAGE;
+    if (!(PROBE & 4) || s_it < NST - 1) {
 #pragma unroll
-    for (int i = 0; i < CH; ++i) glds16((is_a[i] ? s_ta : s_tb) + src_off[i] + s_kt * BK, base + lds_off[i]);
+      for (int i = 0; i < CH; ++i) glds16((is_a[i] ? s_ta : s_tb) + src_off[i] + s_kt * BK, base + lds_off[i]);
+    }
     ++s_it;
     if (++s_kt == nk) {
       s_kt = 0;
@@ -373,8 +383,8 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
     // groups spread the bursts over the tile period and let one group's stores drain while the others run MFMAs
     // (the column tiles of one A row-panel sit on one XCD in consecutive slots: they keep a common phase so that they still
     // read the panel together out of that XCD's L2)
-    const int phase = ((blockIdx.x >> 3) / tiles_n) & 3;
-    for (int w = 0; w < phase * nk * ep.stagger; ++w) __builtin_amdgcn_s_sleep(16);
+    const int phase = ((blockIdx.x >> 3) / tiles_n) & ((ep.stagger >> 8) ? 1 : 3);
+    for (int w = 0; w < phase * nk * (ep.stagger & 255); ++w) __builtin_amdgcn_s_sleep(16);
   }
   int xrow[2], wrow[JN];
 #pragma unroll
@@ -399,7 +409,10 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
   for (int it = 0; it < total; ++it) {
     // stage `it` must have landed; the NST-2 younger stages (and the previous tile's stores) may stay in flight
     if (it + NST - 2 < total) {
-      if (EPI == 0 && after_epi) wait_vmcnt<(NST - 2) * CH + ESTORES>();
+      // (the epilogue's stores are the youngest entries of the in-order counter: a counted wait lets them drain under this k-step)
+      if (EPI == 0 && after_epi && !(PROBE & 1)) wait_vmcnt<(NST - 2) * CH + ESTORES>();
+      else if (EPI == 2 && after_epi && C) wait_vmcnt<(NST - 2) * CH + 6 * JN>();
+      else if (EPI == 2 && after_epi) wait_vmcnt<(NST - 2) * CH + 2 * JN>();
       else wait_vmcnt<(NST - 2) * CH>();
     } else {
       wait_vmcnt<0>();
@@ -415,14 +428,21 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
       bf16x8_t xf[2], wf[JN];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        xf[i] = *(const bf16x8_t*)(sa + xrow[i] * 128 + ((((kk << 1) | hi) ^ ((xrow[i] >> 1) & 7)) << 4));
+        xf[i] = *(const bf16x8_t*)(((PROBE & 8) ? smem : sa) + xrow[i] * 128 + (((((PROBE & 8) ? 0 : (kk << 1)) | hi) ^ ((xrow[i] >> 1) & 7)) << 4));
 #pragma unroll
       for (int j = 0; j < JN; ++j)
-        wf[j] = *(const bf16x8_t*)(sb + wrow[j] * 128 + ((((kk << 1) | hi) ^ ((wrow[j] >> 1) & 7)) << 4));
+        wf[j] = *(const bf16x8_t*)(((PROBE & 8) ? smem + TBM * 128 : sb) + wrow[j] * 128 + (((((PROBE & 8) ? 0 : (kk << 1)) | hi) ^ ((wrow[j] >> 1) & 7)) << 4));
+      if (PROBE & 2) {
 #pragma unroll
-      for (int j = 0; j < JN; ++j)
+        for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(xf[i]));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+        for (int j = 0; j < JN; ++j) asm volatile("" ::"v"(wf[j]));
+      } else {
+#pragma unroll
+        for (int j = 0; j < JN; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+      }
     }
     if (NST >= 3 && s_it < total) stage_next();
     after_epi = false;
@@ -431,9 +451,22 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
       after_epi = true;
       // ---- epilogue of `tile` straight from registers: acc[j][i][r] = C[m][n] with
       //      m = m0 + wm*64 + i*32 + (lane&31),  n = n0 + wn*TN/2 + j*32 + 8*(r>>2) + 4*hi + (r&3)
-      nt_epilogue_regs<JN, TN_, EPI>(acc, (tile / tiles_n) * TBM + wm * 64, (tile % tiles_n) * TN_ + wn * (TN_ / 2), lane, C,
-                                     ldc, ep);
-      if (EPI) wait_vmcnt<0>();  // unknown number of epilogue memory ops: drain so the counted waits stay exact
+      if (PROBE & 1) {
+#pragma unroll
+        for (int j = 0; j < JN; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              asm volatile("" ::"v"(acc[j][i][r]));
+              acc[j][i][r] = 0.f;
+            }
+          }
+      } else {
+        nt_epilogue_regs<JN, TN_, EPI>(acc, (tile / tiles_n) * TBM + wm * 64, (tile % tiles_n) * TN_ + wn * (TN_ / 2), lane, C,
+                                       ldc, ep);
+      }
+      if (EPI && EPI != 2) wait_vmcnt<0>();  // unknown number of epilogue memory ops: drain so the counted waits stay exact
       tile += G;
     }
   }
@@ -613,16 +646,44 @@ static int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, vo
   const int ntiles = (int)((M / TBM) * (N / TN_));
   int grid = n_cu < ntiles ? n_cu : ntiles;
   grid &= ~7;
-  static int stagger = -1;
+  static int stagger = -1, stagger_min = 6;
   if (stagger < 0) {
-    const char* e = getenv("DL_GEMM_NT_STAGGER");
+    const char* e = getenv("DL_GEMM_NT_STAGGER");  // sleep units per k-step and phase; + 256: two phase groups instead of four
     stagger = e ? atoi(e) : 2;
+    e = getenv("DL_GEMM_NT_STAGGER_MIN");
+    if (e) stagger_min = atoi(e);
   }
   NtEpilogue ep = ep_in;
-  ep.stagger = (ntiles >= 6 * grid) ? stagger : 0;  // pays only when every workgroup walks many tiles (measured: MLP-up)
+  ep.stagger = (ntiles >= stagger_min * grid) ? stagger : 0;  // pays only when every workgroup walks many tiles (measured: MLP-up)
 #define BIG_GO(E)                                                                                                     \
   hipLaunchKernelGGL((gemm_nt_big_k<TN_, NST, E>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)A, lda, (const bf16_t*)B, \
                      ldb, C, ldc, (int)M, (int)N, (int)K, ep)
+  if constexpr (TN_ == 384 && NST == 2) {
+   if (g_gemm_probe && epi == 0) {
+#define PROBE_GO(P)                                                                                                   \
+  hipLaunchKernelGGL((gemm_nt_big_k<384, 2, 0, P>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)A, lda, \
+                     (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep)
+    static bool attr = false;
+    if (!attr) {
+      attr = true;
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 0, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 0, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    }
+    if (g_gemm_probe == 1) PROBE_GO(1);
+    else if (g_gemm_probe == 2) PROBE_GO(2);
+    else if (g_gemm_probe == 4) PROBE_GO(4);
+    else if (g_gemm_probe == 8) PROBE_GO(8);
+    else if (g_gemm_probe == 5) PROBE_GO(5);
+    else PROBE_GO(10);
+#undef PROBE_GO
+    DL_LAUNCH_CHECK();
+    return DL_OK;
+   }
+  }
   if (epi == 0) BIG_GO(0);
   else if (epi == 1) BIG_GO(1);
   else if (epi == 2) BIG_GO(2);
@@ -906,7 +967,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_tn_k(const bf16_t* __restr
 #define WBM 384
 #define WBN 128
 #define W_STAGE ((WBM + WBN) * 2 * BK)  // 65536 B per stage
-template <bool CONV>
+template <bool CONV, int PROBE = 0>
 __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __restrict__ A, int64_t lda,
                                                                   const bf16_t* __restrict__ Bm, int64_t ldb,
                                                                   float* __restrict__ C, int64_t ldc, int M, int N,
@@ -972,6 +1033,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __
       }
       return;
     }
+    if ((PROBE & 4) && st != s_begin) return;
 #pragma unroll
     for (int i = 0; i < 8; ++i) glds16(p + src_off[i], base + lds_off[i]);
   };
@@ -993,16 +1055,42 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // PROBE & 16: L2 prefetch.  A stage's DMA waits for its slowest line, and the lines an operand panel touches for the first time
+  // come from HBM (~2 us under load) with at most one stage (64 KiB) in flight per CU: every thread pulls ONE dword of one
+  // 128-byte line of the stage two k-steps ahead into a dummy LDS strip (no register destination; counted in vmcnt as the
+  // youngest op, so the counted wait below does not wait for it), which brings the line into this XCD's L2 ahead of the DMA
+  auto prefetch = [&](int st) {
+    if (st >= s_end) st = s_end - 1;
+    const int line = threadIdx.x;
+    const bf16_t* p;
+    if (line < 384) {
+      const int row = line / 6;
+      int seg = line - row * 6;
+      if (m0 + seg * 64 >= M) seg = 0;
+      p = A + m0 + ((int64_t)st * BK + row) * lda + seg * 64;
+    } else {
+      const int l2 = line - 384, row = l2 >> 1, seg = l2 & 1;
+      p = Bm + n0 + ((int64_t)st * BK + row) * ldb + seg * 64;
+    }
+    __builtin_amdgcn_global_load_lds((glb_void_t*)p, (lds_void_t*)(smem + 2 * W_STAGE + wave * 256), 4, 0, 0);
+  };
+  if (PROBE & 16) {
+    prefetch(s_begin + 1);
+    prefetch(s_begin + 2);
+  }
   stage(s_begin, 0);
   for (int st = s_begin; st < s_end; ++st) {
     const int it = st - s_begin;
-    wait_vmcnt<0>();
+    if ((PROBE & 16) && st != s_begin) wait_vmcnt<1>();
+    else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (st + 1 < s_end) stage(st + 1, (it + 1) & 1);
-    const char* ta = smem + (it & 1) * W_STAGE;
+    if (PROBE & 16) prefetch(st + 3);
+    const char* ta = smem + ((PROBE & 8) ? 0 : (it & 1)) * W_STAGE;
     const char* tb = ta + WBM * 2 * BK;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk_ = 0; kk_ < 4; ++kk_) {
+      const int kk = (PROBE & 8) ? 0 : kk_;
       bf16x8_t af[3], bfg[2];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -1024,11 +1112,27 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __
         u.h[1] = lds_tr16(tb + tr_off(wn * 64 + j * 32, kk, 1, WBN * 2));
         bfg[j] = u.v;
       }
+      if (PROBE & 2) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i) asm volatile("" ::"v"(af[i]));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfg[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(bfg[j]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfg[j], acc[i][j], 0, 0, 0);
+      }
     }
+  }
+  if (PROBE & 1) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+    return;
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -1084,6 +1188,26 @@ extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t 
       const int sps = (nsteps + splits - 1) / splits;
       splits = (nsteps + sps - 1) / sps;
       const int units = (tiles_m * splits + 7) & ~7;  // surplus units exit at once
+      if (g_gemm_probe) {
+#define TN_PROBE_GO(P)                                                                                                              \
+  do {                                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)gemm_tn_big_k<false, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE + 2048); \
+    hipLaunchKernelGGL((gemm_tn_big_k<false, P>), units * (int)(N / WBN), BIG_THREADS, 2 * W_STAGE + 2048, (hipStream_t)stream,      \
+                       (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)R, sps, ConvGeom{});               \
+  } while (0)
+        if (g_gemm_probe == 1) TN_PROBE_GO(1);
+        else if (g_gemm_probe == 2) TN_PROBE_GO(2);
+        else if (g_gemm_probe == 4) TN_PROBE_GO(4);
+        else if (g_gemm_probe == 8) TN_PROBE_GO(8);
+        else if (g_gemm_probe == 5) TN_PROBE_GO(5);
+        else if (g_gemm_probe == 16) TN_PROBE_GO(16);
+        else if (g_gemm_probe == 17) TN_PROBE_GO(17);
+        else if (g_gemm_probe == 26) TN_PROBE_GO(26);
+        else TN_PROBE_GO(10);
+#undef TN_PROBE_GO
+        DL_LAUNCH_CHECK();
+        return DL_OK;
+      }
       hipLaunchKernelGGL(gemm_tn_big_k<false>, units * (int)(N / WBN), BIG_THREADS, 2 * W_STAGE, (hipStream_t)stream,
                          (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)R, sps, ConvGeom{});
       DL_LAUNCH_CHECK();

@@ -164,6 +164,7 @@ class DiTEngine:
         self.grads: Tensor | None = None
         self._shadow_key: tuple | None = None
         self.manual_version = 0
+        self.param_version = 0  # sum of the parameters' own version counters, set by the owning module before every forward
         self._ws_key: tuple | None = None
         self._ws_cache: dict[tuple, tuple] = {}
         self._cast_table = None
@@ -245,7 +246,9 @@ class DiTEngine:
 
     def refresh_shadows(self, force: bool = False) -> None:
         ver = 0 if self.params.is_inference() else self.params._version
-        key = (self.params.data_ptr(), ver, self.manual_version, _PARAM_EPOCH)
+        # writes THROUGH a parameter (load_state_dict on a flattened model, a stock optimizer, p.copy_) bump that parameter's
+        # version counter, not the arena's: the owning module passes the sum of those counters as param_version
+        key = (self.params.data_ptr(), ver, self.manual_version, _PARAM_EPOCH, self.param_version)
         if not force and key == self._shadow_key:
             return
         if self._cast_table is None or self._cast_table_ptr != self.params.data_ptr():
@@ -490,7 +493,12 @@ class DiTEngine:
 
         side_wgs = int(os.environ.get("DL_SIDE_WGS", "192"))  # of 256 CUs: measured best (256: -1.2 %, 160: -1.5 %)
 
+        serial = os.environ.get("DL_WGRAD_SERIAL") == "1"  # A/B switch: weight gradients inline on the main stream
+
         def wgrad(x_grad: Tensor, x_in: Tensor, gname: str) -> None:
+            if serial:
+                ops.gemm_tn(x_grad, x_in, self.G(gname))
+                return
             ev = main.record_event()
             with torch.cuda.stream(side):
                 side.wait_event(ev)

@@ -52,6 +52,7 @@ class EngineFn(torch.autograd.Function):
         differentiable outputs -- what a forward hook on ``denoiser.layers[i]`` sees in the reference (RePA, repa.py:133-134)"""
         ctx.module, ctx.taps = module, tuple(taps)
         ctx.set_materialize_grads(False)
+        ctx.serial = module._next_serial()
         pred = module._engine.forward(x, t, y_eff, train=True).clone()
         ctx.pred_shape = pred.shape
         if not taps:
@@ -63,6 +64,12 @@ class EngineFn(torch.autograd.Function):
         m = ctx.module
         grads = {k: g for k, g in zip(ctx.taps, dfeats) if g is not None}
         if dpred is not None or grads:
+            if ctx.serial != m.__dict__.get("_fwd_serial"):
+                # the engine keeps ONE set of saved activations (the last train-mode forward): a backward through an older
+                # forward of the same module would silently differentiate the newer one's activations
+                raise RuntimeError(f"{type(m).__name__}: backward through a forward that is no longer the module's latest "
+                                   "train-mode forward (two grad-enabled forwards before one backward are not supported: "
+                                   "call backward after each forward, or concatenate the batches)")
             m._prepare_grads()
             if dpred is None:
                 dpred = torch.zeros(ctx.pred_shape, device=m._engine.dev)
@@ -100,6 +107,22 @@ class FlatArenaDenoiser(Denoiser):
 
     def _named(self) -> dict[str, nn.Parameter]:
         return dict(self.named_parameters())
+
+    def _next_serial(self) -> int:
+        """stamps a train-mode forward (the engine's saved activations belong to the latest one only)"""
+        n = self.__dict__.get("_fwd_serial", 0) + 1
+        object.__setattr__(self, "_fwd_serial", n)
+        return n
+
+    def _param_version(self) -> int:
+        """sum of the parameters' version counters: in-place writes through a parameter (``load_state_dict``, stock
+        optimizers, ``p.copy_``) are invisible to the arena's own counter the bf16 weight shadows used to be keyed on"""
+        plist = self.__dict__.get("_plist")
+        if plist is None or len(plist[1]) != plist[0]:
+            ps = list(self.parameters())
+            plist = (len(ps), ps)
+            object.__setattr__(self, "_plist", plist)
+        return sum(p._version for p in plist[1])
 
     def _is_flat(self) -> bool:
         if self._flat is None or self._engine is None:
@@ -168,10 +191,12 @@ class FlatArenaDenoiser(Denoiser):
     def _run(self, x: Tensor, t: Tensor, y_eff: Tensor | None, taps: tuple = ()):
         """prediction (and, with taps, the tapped block outputs)"""
         eng = self.engine
+        eng.param_version = self._param_version()
         need_grad = torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())
         if need_grad:
             return EngineFn.apply(self, x, t, y_eff, self._anchor, tuple(taps))
         if taps:  # validation with an auxiliary loss on intermediate features: run the keep-everything sequence eagerly
+            self._next_serial()  # (this overwrites the saved activations of an earlier grad-enabled forward)
             pred = eng.forward(x, t, y_eff, train=True).clone()
             return (pred, *(eng.feature(k).clone() for k in taps))
         return self._infer(eng, x, t, y_eff)
@@ -217,14 +242,16 @@ class FlatArenaDenoiser(Denoiser):
                 try:
                     with torch.cuda.graph(g):
                         out_s = eng.forward(xs, ts, ys, train=False, refresh=False)
-                    graphs[key] = (g, xs, ts, ys, out_s, statics)
+                    # the entry holds the workspace it was captured on: the engine's per-shape cache may evict that workspace
+                    # later (train shape, then many inference shapes), and a replay must never touch freed memory
+                    graphs[key] = (g, xs, ts, ys, out_s, statics, getattr(eng, "ws", None))
                 except Exception as e:  # capture refused: stay eager for this shape (and say so once)
                     logging.warning("hipGraph capture of the inference forward failed (%s): running eagerly", e)
                     graphs[key] = False
             return out
         if ent is False:
             return eng.forward(x, t, y_eff, train=False).clone()
-        g, xs, ts, ys, out_s, statics = ent
+        g, xs, ts, ys, out_s, statics, _ws_alive = ent
         eng.refresh_shadows()
         xs.copy_(x)
         ts.copy_(t)

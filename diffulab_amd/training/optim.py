@@ -39,6 +39,17 @@ class FusedAdamW(torch.optim.Optimizer):
                  weight_decay: float = 1e-2) -> None:
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = 1.0  # data parallel: 1/world (gradients are SUM-reduced), folded into the update kernel
+        self._legacy_arena_state: dict | None = None
+
+    @staticmethod
+    def _arena_key(group, rest: list) -> Tensor:
+        skip = {id(p) for p in rest}
+        return next(p for p in group["params"] if id(p) not in skip and p.requires_grad)
+
+    def load_state_dict(self, state_dict) -> None:
+        super().load_state_dict(state_dict)
+        for k in [k for k in self.state if isinstance(k, str) and k.startswith("arena")]:
+            self._legacy_arena_state = self.state.pop(k)
 
     def _flat(self, group) -> tuple[Tensor, Tensor, list] | None:
         """(param arena, grad arena, parameters NOT in it) when (most of) the group lives in one flat arena -- e.g. a denoiser's
@@ -85,10 +96,18 @@ class FusedAdamW(torch.optim.Optimizer):
             rest = group["params"]
             if flat is not None:
                 pb, gb, rest = flat
-                st = self.state.setdefault("arena%d" % pb.data_ptr(), {})
+                # The arena's moments are keyed on the group's first arena parameter: Optimizer.state_dict() maps parameter keys
+                # to stable indices, so a checkpoint resumes in a new process (a key derived from the arena's address would not)
+                st = self.state[self._arena_key(group, rest)]
+                if not st and self._legacy_arena_state is not None and self._legacy_arena_state["m"].numel() == pb.numel():
+                    st.update(self._legacy_arena_state)  # checkpoint written with the address-keyed entry of round 1
+                    self._legacy_arena_state = None
                 if not st:
                     st["step"], st["m"], st["v"] = 0, torch.zeros_like(pb), torch.zeros_like(pb)
-                st["step"] += 1
+                if st["m"].device != pb.device or st["m"].numel() != pb.numel():  # state loaded before the model moved
+                    assert st["m"].numel() == pb.numel(), "optimizer state does not match the parameter arena"
+                    st["m"], st["v"] = st["m"].to(pb.device), st["v"].to(pb.device)
+                st["step"] = int(st["step"]) + 1
                 ops.adamw_step(pb, gb, st["m"], st["v"], group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"],
                                self.grad_scale)
                 bump_param_epoch()  # raw-pointer writes bump no torch version counter: tell the engines
@@ -99,7 +118,9 @@ class FusedAdamW(torch.optim.Optimizer):
                     st = self.state[p]
                     if not st:
                         st["step"], st["m"], st["v"] = 0, torch.zeros_like(p.data), torch.zeros_like(p.data)
-                    st["step"] += 1
+                    if st["m"].device != p.device:
+                        st["m"], st["v"] = st["m"].to(p.device), st["v"].to(p.device)
+                    st["step"] = int(st["step"]) + 1
                     ops.adamw_step(p.data, p.grad, st["m"], st["v"], group["lr"], b1, b2, group["eps"],
                                    group["weight_decay"], st["step"], self.grad_scale)
             bump_param_epoch()

@@ -2,8 +2,10 @@
 
 ``training_step`` keeps the reference's order of operations (base_trainer.py:138-153): zero_grad -> draw timesteps (CPU generator)
 -> compute_loss -> ``.item()`` of every loss into the tracker -> backward -> optimizer.step -> scheduler -> EMA update.
-Differences are confined to what Accelerate did implicitly (see trainers/common.py): loss / gradient_accumulation_step before
-backward, optimizer / scheduler / EMA only on the synchronising micro-step, gradient all-reduce overlapped with backward.
+What Accelerate did implicitly is spelled out (see trainers/common.py): loss / gradient_accumulation_step before backward,
+``zero_grad`` / ``step`` / scheduler gated on the synchronising micro-step (so with k > 1 the default reproduces the reference's
+"(1/k) * gradient of the last micro-batch" update), EMA on every micro-step, gradient all-reduce overlapped
+with backward.
 """
 
 from __future__ import annotations
@@ -36,9 +38,10 @@ class BaseTrainer(Trainer):
         per_batch_scheduler: bool = False,
         ema_denoiser: EMA | None = None,
     ) -> None:
-        first_micro = self._micro % self.gradient_accumulation_step == 0
         self.begin_micro_step()
-        if first_micro:  # accelerate turns optimizer.zero_grad() into a no-op on non-synchronising micro-steps
+        # AcceleratedOptimizer.zero_grad() only acts while gradient_state.sync_gradients is set, and accumulate() sets that flag
+        # for the micro-step being entered: the reference therefore clears the window's gradients right before the LAST backward
+        if self.sync_gradients if self.reference_accumulation else self.window_start:
             optimizer.zero_grad()
         batch = self.shard_batch(batch)
         model_inputs = self.move_dict_to_device(dict(batch["model_inputs"]))
@@ -93,9 +96,9 @@ class BaseTrainer(Trainer):
             p_classifier_free_guidance = 0
         if denoiser_ckpt:
             diffuser.denoiser.load_state_dict(torch.load(denoiser_ckpt))
-        if optimizer_ckpt:
-            optimizer.load_state_dict(torch.load(optimizer_ckpt, weights_only=False))
         self.prepare(diffuser, optimizer)
+        if optimizer_ckpt:  # after prepare(): the state follows the parameters' device (and the arena exists)
+            optimizer.load_state_dict(torch.load(optimizer_ckpt, weights_only=False))
         if self.use_ema:
             ema_denoiser = EMA(diffuser.denoiser, beta=self.ema_rate, update_after_step=self.ema_update_after_step,
                                update_every=self.ema_update_every).to(self.device)
@@ -106,6 +109,7 @@ class BaseTrainer(Trainer):
         for loss in diffuser.extra_losses:  # accelerator.prepare(loss) in the reference: device placement, then the hooks
             loss.to(self.device)
             loss.set_model(diffuser.denoiser)
+        self.broadcast_extra_losses(diffuser)
         if getattr(diffuser.denoiser, "context_embedder", None) is not None and not train_embedder:
             for param in diffuser.denoiser.context_embedder.parameters():
                 param.requires_grad = False
@@ -115,7 +119,7 @@ class BaseTrainer(Trainer):
         logging.info("Begin training")
         for epoch in range(epoch_start, self.n_epoch):
             diffuser.train()
-            for batch in train_dataloader:
+            for batch in self.iterate(train_dataloader):
                 self.training_step(diffuser=diffuser, optimizer=optimizer, batch=batch, tracker=tracker,
                                    p_classifier_free_guidance=p_classifier_free_guidance, scheduler=scheduler,
                                    per_batch_scheduler=per_batch_scheduler, ema_denoiser=ema_denoiser)

@@ -7,8 +7,15 @@ Mirrors ``training/trainers/common.py:25-271`` of the reference (same constructo
   * the DDP wrap of ``accelerator.prepare`` becomes ``training.dp.GradReducer`` on the flat gradient arena (bucketed in-place
     all-reduce on a side stream, 1/world folded into the fused AdamW), parameters broadcast from rank 0 at start;
   * ``split_batches=True`` semantics (common.py:104): the DataLoader batch is the GLOBAL batch, each rank takes its contiguous slice;
-  * ``accelerator.accumulate`` semantics: the loss is divided by ``gradient_accumulation_step``, gradients are reduced and the
-    optimizer / scheduler / EMA advance only on the last micro-step;
+  * ``accelerator.accumulate`` semantics, INCLUDING the reference's ordering quirk: ``training_step`` opens
+    with ``optimizer.zero_grad()`` (base_trainer.py:138), which Accelerate gates on ``sync_gradients`` of the CURRENT micro-step, so
+    on the synchronising micro-step the gradients of the k-1 earlier micro-batches are zeroed before its backward and the update
+    applies (1/k) * grad(last micro-batch).  That is the default here (``reference_accumulation = True``; pinned by
+    ``tests/golden/accum_k2.npz``, produced with accelerate itself).  ``DIFFULAB_TRUE_ACCUMULATION=1`` (or
+    ``trainer.reference_accumulation = False``) switches to textbook accumulation: zero at the window's first micro-step, update
+    with the mean gradient of the k micro-batches.  In both modes the loss is divided by k, only the synchronising micro-step
+    reduces across ranks / steps the optimizer and the scheduler, and the last batch of a dataloader pass always synchronises
+    (Accelerate's ``sync_with_dataloader``);
   * mixed precision: the HIP path always computes in bf16 MFMA with f32 accumulation and f32 master weights, so
     ``precision_type`` in {"no", "bf16"} is accepted for config compatibility and changes nothing; "fp16" is refused;
   * ``compile`` / ``dynamo_plugin_kwargs`` are accepted and ignored (no tracing compiler: the launch sequences are static);
@@ -82,7 +89,10 @@ class Trainer(ABC):
             self.save_path.mkdir(parents=True, exist_ok=True)
             if run_config is not None:
                 (self.save_path / "run_config.json").write_text(json.dumps(run_config, indent=1, default=str))
-        self._micro = 0
+        self._micro = 0            # micro-steps run so far
+        self._accum_step = 0       # position inside the accumulation window (accelerate's ``Accelerator.step``)
+        self._end_of_dataloader = False
+        self.reference_accumulation = os.environ.get("DIFFULAB_TRUE_ACCUMULATION", "0") != "1"
         self._reducer: GradReducer | None = None
 
     # ------------------------------------------------------------------ accelerate-equivalent plumbing
@@ -97,7 +107,9 @@ class Trainer(ABC):
         for k, v in batch.items():
             if isinstance(v, dict):
                 out[k] = self.shard_batch(v)
-            elif isinstance(v, (Tensor, list)) and len(v) % self.world == 0 and len(v) > 0:
+            elif isinstance(v, (Tensor, list)) and len(v) > 0:
+                if len(v) % self.world:  # (accelerate's split_batches=True refuses such a batch size too)
+                    raise ValueError(f"split_batches: batch entry {k!r} has {len(v)} rows, not divisible by world size {self.world}")
                 n = len(v) // self.world
                 out[k] = v[self.rank * n : (self.rank + 1) * n]
             else:
@@ -119,9 +131,23 @@ class Trainer(ABC):
                 else:
                     raise RuntimeError("data-parallel training needs diffulab_amd.training.FusedAdamW (grad_scale = 1/world)")
 
+    def broadcast_extra_losses(self, diffuser: "Diffuser") -> None:
+        """accelerator.prepare(loss) DDP-wraps the auxiliary loss heads (REPA projector / resampler): every rank starts from
+        rank 0's values.  Call after the heads were moved to the device."""
+        if self.world == 1:
+            return
+        for loss in diffuser.extra_losses:
+            for t in list(loss.parameters()) + list(loss.buffers()):
+                dist.broadcast(t.data, src=0)
+
     @property
     def sync_gradients(self) -> bool:
-        return (self._micro + 1) % self.gradient_accumulation_step == 0
+        """accelerate ``_do_sync``: every k-th micro-step of the window, and always on the last batch of a dataloader pass"""
+        return self._end_of_dataloader or (self._accum_step + 1) % self.gradient_accumulation_step == 0
+
+    @property
+    def window_start(self) -> bool:
+        return self._accum_step % self.gradient_accumulation_step == 0
 
     def begin_micro_step(self) -> None:
         if self._reducer is not None:
@@ -129,6 +155,18 @@ class Trainer(ABC):
 
     def end_micro_step(self) -> None:
         self._micro += 1
+        self._accum_step = 0 if self._end_of_dataloader else self._accum_step + 1
+
+    def iterate(self, dataloader: Iterable[BatchData]):
+        """yields the batches of one pass and flags the last one (``GradientState.end_of_dataloader``), which forces a sync"""
+        it = iter(dataloader)
+        batch = next(it, None)
+        while batch is not None:
+            nxt = next(it, None)
+            self._end_of_dataloader = nxt is None
+            yield batch
+            batch = nxt
+        self._end_of_dataloader = False
 
     def reduce_extra_grads(self, diffuser: "Diffuser") -> None:
         """data parallel: parameters of auxiliary loss heads (REPA projector) live outside the denoiser's gradient arena, so

@@ -210,6 +210,7 @@ class UNetEngine:
         self.grads: Tensor | None = None
         self._shadow_key: tuple | None = None
         self.manual_version = 0
+        self.param_version = 0  # see DiTEngine.refresh_shadows
         self.reducer = None  # optional training.dp.GradReducer
         self._scratch: dict[str, Tensor] = {}
         self._saved: dict | None = None
@@ -271,7 +272,7 @@ class UNetEngine:
 
     def refresh_shadows(self, force: bool = False) -> None:
         ver = 0 if self.params.is_inference() else self.params._version
-        key = (self.params.data_ptr(), ver, self.manual_version, _eng._PARAM_EPOCH)
+        key = (self.params.data_ptr(), ver, self.manual_version, _eng._PARAM_EPOCH, self.param_version)
         if not force and key == self._shadow_key:
             return
         for name, (R, C), fwd, dgrad in self._lin:

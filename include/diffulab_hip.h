@@ -420,6 +420,10 @@ DL_API int dl_probe_tr16(uint16_t* out, dl_stream_t stream);
  * direct-to-LDS DMA per k-step from `src` (>= 256*57344 bytes).  out: f32 [256*512] (sink).
  * modes 8 / 9: store-pattern probe -- `out` is a bf16 [65536, 1152] buffer written `iters` times in the GEMM register
  * epilogue's pattern (32 rows x 32 B per instruction) / with full 128-byte lines per 8 lanes. */
+/* tuning builds: bit flags that strip one component from the persistent GEMM kernels (256x384 NT tiles / 384x128 TN tiles):
+ * 1 = no epilogue stores / atomics, 2 = no MFMA, 4 = no operand DMA after the first stage, 8 = no LDS fragment reads
+ * (5 and 10 combine them); 0 restores the product kernels.  scripts/gemm_probe.py */
+DL_API int dl_probe_gemm_set(int flags);
 DL_API int dl_probe_mfma(int mode, int iters, const void* src, float* out, dl_stream_t stream);
 
 #ifdef __cplusplus

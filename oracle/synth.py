@@ -68,3 +68,30 @@ def generic_params(shapes: dict[str, tuple[int, ...]], seed: int = 0) -> dict[st
         else:
             out[name] = normal(name, shp, seed, int(np.prod(shp[1:])) ** -0.5)
     return out
+
+
+def write_fake_mnist(root: str, n_train: int = 12, n_test: int = 5, seed: int = 11) -> None:
+    """seeded digits in the REAL idx on-disk format (big-endian magic / counts, uint8 payload): inputs of the dataset-reader tests"""
+    import os
+
+    rng = np.random.default_rng(seed)
+    for stem, n in (("train", n_train), ("t10k", n_test)):
+        img = rng.integers(0, 256, size=(n, 28, 28), dtype=np.uint8)
+        lab = rng.integers(0, 10, size=(n,), dtype=np.uint8)
+        with open(os.path.join(root, f"{stem}-images-idx3-ubyte"), "wb") as f:
+            f.write(np.array([2051, n, 28, 28], dtype=">u4").tobytes() + img.tobytes())
+        with open(os.path.join(root, f"{stem}-labels-idx1-ubyte"), "wb") as f:
+            f.write(np.array([2049, n], dtype=">u4").tobytes() + lab.tobytes())
+
+
+def write_fake_cifar10(root: str, batches: dict[str, int], seed: int = 12) -> None:
+    """seeded images in the REAL python-pickle batch format of CIFAR-10 (dict with "data" uint8 [N, 3072] and "labels")"""
+    import os
+    import pickle
+
+    rng = np.random.default_rng(seed)
+    for name, n in batches.items():
+        d = {"data": rng.integers(0, 256, size=(n, 3072), dtype=np.uint8), "labels": [int(v) for v in rng.integers(0, 10, size=n)],
+             "batch_label": name, "filenames": [f"{i}.png" for i in range(n)]}
+        with open(os.path.join(root, name), "wb") as f:
+            pickle.dump(d, f, protocol=2)

@@ -45,6 +45,13 @@ if which in ("nt", "all"):
             err = f"  max|err| {(out.float() - ref).abs().max().item():.3e} (ref max {ref.abs().max().item():.1f})"
             del ref
         print(f"nt {name:10s} M={M} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s{err}")
+if which in ("nt", "all", "swiglu"):
+    a, wp = rnd(M, 384), rnd(3072, 384)
+    u, h = torch.empty(M, 3072, device=dev, dtype=torch.bfloat16), torch.empty(M, 1536, device=dev, dtype=torch.bfloat16)
+    us = timeit(lambda: ops.gemm_nt_swiglu(a, wp, u, h))
+    print(f"nt mlp1+swiglu (U and H stored)      : {us:8.1f} us  {2.0*M*3072*384/us/1e6:7.1f} TF/s")
+    us = timeit(lambda: ops.gemm_nt_swiglu(a, wp, None, h))
+    print(f"nt mlp1+swiglu (H only, inference)   : {us:8.1f} us  {2.0*M*3072*384/us/1e6:7.1f} TF/s")
 if which in ("tn", "all"):
     for name, Mo, No in [("w_qkv", 1152, 384), ("w_proj", 384, 384), ("w_mlp1", 3072, 384), ("w_mlp2", 384, 1536)]:
         a, b = rnd(M, Mo), rnd(M, No)

@@ -862,9 +862,33 @@ def gen_mmdit_single() -> None:
     save("mmdit_single", **o)
 
 
+def gen_datasets() -> None:
+    """the reference's MNIST idx / CIFAR-10 pickle readers (datasets/mnist.py, datasets/cifar10.py) on small synthetic files written
+    by oracle.synth.write_fake_mnist / write_fake_cifar10 (seeded bytes in the real on-disk formats): items 0, 3 and the last"""
+    import importlib
+    import tempfile
+
+    dn = types.ModuleType("diffulab.datasets")
+    dn.__path__ = [os.path.join(REF, "diffulab", "datasets")]
+    sys.modules["diffulab.datasets"] = dn
+    mn = importlib.import_module("diffulab.datasets.mnist")
+    cf = importlib.import_module("diffulab.datasets.cifar10")
+    o = {}
+    with tempfile.TemporaryDirectory() as td:
+        synth.write_fake_mnist(td, n_train=12, n_test=5, seed=11)
+        synth.write_fake_cifar10(td, batches={"data_batch_1": 6, "data_batch_2": 4}, seed=12)
+        for tag, ds in (("mnist_train", mn.MNISTDataset(td, train=True)), ("mnist_test", mn.MNISTDataset(td, train=False)),
+                        ("cifar", cf.CIFAR10Dataset(td, batches_to_load=["data_batch_1", "data_batch_2"]))):
+            o[f"{tag}_len"] = len(ds)
+            for i in (0, 3, len(ds) - 1):
+                it = ds[i]["model_inputs"]
+                o[f"{tag}_x{i}"], o[f"{tag}_y{i}"] = it["x"], it["y"]
+    save("datasets", **o)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve", "repa", "resampler", "sprint", "mmdit_joint", "sprint_joint", "ddt", "ddt_joint", "mmdit_single"]
-    fns = {"repa": gen_repa, "resampler": gen_resampler, "sprint": gen_sprint, "mmdit_joint": gen_mmdit_joint, "sprint_joint": gen_sprint_joint, "ddt": gen_ddt, "ddt_joint": gen_ddt_joint, "mmdit_single": gen_mmdit_single, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
+    which = sys.argv[1:] or ["datasets", "schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve", "repa", "resampler", "sprint", "mmdit_joint", "sprint_joint", "ddt", "ddt_joint", "mmdit_single"]
+    fns = {"datasets": gen_datasets, "repa": gen_repa, "resampler": gen_resampler, "sprint": gen_sprint, "mmdit_joint": gen_mmdit_joint, "sprint_joint": gen_sprint_joint, "ddt": gen_ddt, "ddt_joint": gen_ddt_joint, "mmdit_single": gen_mmdit_single, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
            "s2": gen_s2_model, "samplers": gen_samplers, "curve": gen_loss_curve, "unet": gen_unet}
     for w in which:
         print("==", w)

@@ -62,9 +62,99 @@ def test_shard_batch_and_accumulation_boundaries(tmp_path):
         flags.append(t.sync_gradients)
         t.end_micro_step()
     assert flags == [False, False, True, False, False, True]
+    flags = []
+    for _ in t.iterate(range(5)):  # the last batch of a dataloader pass always synchronises and restarts the window
+        flags.append(t.sync_gradients)
+        t.end_micro_step()
+    assert flags == [False, False, True, False, True] and t._accum_step == 0
     t.world, t.rank = 4, 2
     b = {"model_inputs": {"x": torch.arange(8)[:, None], "y": torch.arange(8), "p": 0.1}, "extra": {"captions": list("abcdefgh")}}
     s = t.shard_batch(b)
     assert s["model_inputs"]["x"].flatten().tolist() == [4, 5] and s["model_inputs"]["y"].tolist() == [4, 5]
     assert s["model_inputs"]["p"] == 0.1 and s["extra"]["captions"] == ["e", "f"]
     assert (tmp_path / "p").is_dir()
+    import pytest
+    with pytest.raises(ValueError):  # split_batches=True refuses a batch the ranks cannot share evenly
+        t.shard_batch({"model_inputs": {"x": torch.arange(6)}})
+
+
+class _FakeDiffuser:
+    """just enough of ``Diffuser`` for ``BaseTrainer.train`` on CPU: a torch module as denoiser and an MSE ``compute_loss``"""
+
+    model_type = "rectified_flow"
+    extra_losses: list = []
+
+    def __init__(self, model, on_loss):
+        self.denoiser, self.on_loss = model, on_loss
+        self.denoiser.classifier_free = False
+
+    def train(self):
+        self.denoiser.train()
+
+    def eval(self):
+        self.denoiser.eval()
+
+    def draw_timesteps(self, n):
+        return torch.zeros(n)
+
+    def compute_loss(self, model_inputs, timesteps, extra_args):
+        self.on_loss()
+        return {"loss": torch.nn.functional.mse_loss(self.denoiser(model_inputs["x"]), extra_args["target"])}
+
+
+def _replay_accum_fixture(tmp_path, true_accumulation: bool):
+    import numpy as np
+
+    from diffulab_amd.training import BaseTrainer
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "accum_k2.npz"))
+    model = torch.nn.Linear(g["xs"].shape[2], g["ys"].shape[2])
+    with torch.no_grad():
+        model.weight.copy_(torch.from_numpy(g["w0"]))
+        model.bias.copy_(torch.from_numpy(g["b0"]))
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0 / (1.0 + 0.5 * s))
+    seen_w, seen_lr = [], []
+    # compute_loss of micro-step i observes the parameters left by micro-step i-1
+    d = _FakeDiffuser(model, lambda: (seen_w.append(model.weight.detach().clone().numpy()), seen_lr.append(opt.param_groups[0]["lr"])))
+    loader = [{"model_inputs": {"x": torch.from_numpy(g["xs"][i])}, "extra": {"target": torch.from_numpy(g["ys"][i])}}
+              for i in range(g["xs"].shape[0])]
+    t = BaseTrainer(n_epoch=int(g["n_epoch"]), gradient_accumulation_step=int(g["k"]), save_path=tmp_path, project_name="acc")
+    t.reference_accumulation = not true_accumulation
+    t.device = torch.device("cpu")
+    t.train(d, opt, loader, scheduler=sched, per_batch_scheduler=True)
+    seen_w.append(model.weight.detach().clone().numpy())
+    seen_lr.append(opt.param_groups[0]["lr"])
+    return g, np.stack(seen_w[1:]), np.array(seen_lr[1:])
+
+
+def test_gradient_accumulation_reproduces_accelerate_fixture(tmp_path):
+    """the default reproduces what the reference does under Accelerate with k = 2 (zero_grad is gated on the
+    CURRENT micro-step's sync flag, so the update uses (1/k) * grad(last micro-batch); the last batch of a pass always syncs):
+    parameters and learning rate after every one of the 10 micro-steps against tests/golden/accum_k2.npz (made with accelerate)"""
+    import numpy as np
+
+    g, w, lr = _replay_accum_fixture(tmp_path, true_accumulation=False)
+    assert w.shape == g["traj_w"].shape
+    np.testing.assert_allclose(w, g["traj_w"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(lr, g["traj_lr"], rtol=1e-12)
+
+
+def test_true_accumulation_switch_differs_from_the_reference(tmp_path):
+    """the documented switch gives textbook accumulation, which is NOT the reference trajectory"""
+    import numpy as np
+
+    g, w, lr = _replay_accum_fixture(tmp_path, true_accumulation=True)
+    np.testing.assert_allclose(lr, g["traj_lr"], rtol=1e-12)  # same synchronisation points
+    assert np.abs(w - g["traj_w"]).max() > 1e-4
+    # first window: mean gradient of micro-batches 0 and 1
+    import torch as th
+    m = th.nn.Linear(g["xs"].shape[2], g["ys"].shape[2])
+    with th.no_grad():
+        m.weight.copy_(th.from_numpy(g["w0"]))
+        m.bias.copy_(th.from_numpy(g["b0"]))
+    o = th.optim.AdamW(m.parameters(), lr=1e-2, weight_decay=0.01)
+    (0.5 * (th.nn.functional.mse_loss(m(th.from_numpy(g["xs"][0])), th.from_numpy(g["ys"][0]))
+            + th.nn.functional.mse_loss(m(th.from_numpy(g["xs"][1])), th.from_numpy(g["ys"][1])))).backward()
+    o.step()
+    np.testing.assert_allclose(w[1], m.weight.detach().numpy(), atol=2e-7)
