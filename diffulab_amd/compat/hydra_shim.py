@@ -53,8 +53,7 @@ def main(version_base: Any = None, config_path: str | None = None, config_name: 
         def run(cfg: Any = None) -> Any:
             if cfg is not None:
                 return fn(cfg)
-            here = os.path.dirname(os.path.abspath(sys.modules[fn.__module__].__file__ if fn.__module__ in sys.modules and
-                                                   getattr(sys.modules[fn.__module__], "__file__", None) else sys.argv[0]))
+            here = os.path.dirname(os.path.abspath(fn.__code__.co_filename))  # config_path is relative to the script
             name, overrides, args = config_name, [], sys.argv[1:]
             i = 0
             while i < len(args):

@@ -1,4 +1,6 @@
-from .denoisers import DDT, Denoiser, MMDiT, ModelInput, ModelOutput, SprintDiT
+from .denoisers import DDT, Denoiser, MMDiT, ModelInput, ModelOutput, SprintDiT, UNetModel
 from .embedders import ContextEmbedder, PrecomputedEmbedder
+from .repa import PerceiverResampler
 
-__all__ = ["DDT", "Denoiser", "MMDiT", "ModelInput", "ModelOutput", "SprintDiT", "ContextEmbedder", "PrecomputedEmbedder"]
+__all__ = ["DDT", "Denoiser", "MMDiT", "ModelInput", "ModelOutput", "SprintDiT", "UNetModel", "ContextEmbedder", "PrecomputedEmbedder",
+           "PerceiverResampler"]

@@ -1,33 +1,45 @@
-"""Counterpart of the reference's examples/train_diffusion.py on the MI355X build: same flow (datasets -> DataLoader ->
-denoiser -> Diffuser -> optimizer -> BaseTrainer.train), YAML configs of the same shape under ../configs.
+"""Training entry point in the shape of the reference's examples/train_diffusion.py (same imports, same Hydra composition, same
+objects in the same order: datasets -> DataLoader -> denoiser -> Diffuser -> optimizer -> BaseTrainer.train).
 
-    python examples/train_diffusion.py train_mnist_ddpm trainer.n_epoch=1 dataloader.batch_size=64
-    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_diffusion.py train_dit_s2_flow_matching
+    python examples/train_diffusion.py --config-name train_mnist_ddpm dataset=mnist_synthetic trainer.n_epoch=1
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_diffusion.py \\
+        --config-name train_dit_s2_flow_matching
+
+The reference's OWN script runs unmodified through ``python -m diffulab.run <script> [overrides]``.
+hydra-core / omegaconf are used when installed; this image has neither, so the stand-ins of diffulab_amd.compat.hydra_shim are
+registered under those names (no network to install them).
 """
 
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import hydra
+except ImportError:
+    from diffulab_amd.compat import hydra_shim
+
+    hydra_shim.install()
+    import hydra
 import torch
+from hydra.utils import instantiate
+from omegaconf import DictConfig, OmegaConf
 from torch.utils.data import DataLoader
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-
-from diffulab_amd.config import instantiate, load_config  # noqa: E402
-from diffulab_amd.diffuse import Diffuser  # noqa: E402
-from diffulab_amd.training import BaseTrainer  # noqa: E402
+from diffulab.diffuse import Diffuser
+from diffulab.training import BaseTrainer
 
 
-def train(config_name: str, overrides: list[str]) -> None:
-    cfg = load_config(os.path.join(ROOT, "configs"), config_name, overrides)
+@hydra.main(version_base=None, config_path="../configs", config_name="train_mnist_flow_matching")
+def train(cfg: DictConfig):
+    print(OmegaConf.to_yaml(cfg))
     train_dataset = instantiate(cfg.dataset.train)
     val_dataset = instantiate(cfg.dataset.val)
     dl_cfg = cfg.get("dataloader", {})
-    mk = lambda ds, shuffle: DataLoader(dataset=ds, batch_size=dl_cfg.get("batch_size", 32), shuffle=shuffle,  # noqa: E731
-                                        num_workers=dl_cfg.get("num_workers", 0), pin_memory=dl_cfg.get("pin_memory", False),
-                                        drop_last=True)
-    train_loader, val_loader = mk(train_dataset, dl_cfg.get("shuffle", True)), mk(val_dataset, False)
+    loader = lambda ds, shuffle: DataLoader(dataset=ds, batch_size=dl_cfg.get("batch_size", 32), shuffle=shuffle,  # noqa: E731
+                                            num_workers=dl_cfg.get("num_workers", 0), pin_memory=dl_cfg.get("pin_memory", False),
+                                            drop_last=dl_cfg.get("drop_last", False))
+    train_loader, val_loader = loader(train_dataset, dl_cfg.get("shuffle", True)), loader(val_dataset, False)
 
     denoiser = instantiate(cfg.model)
     print(f"Number of trainable parameters: {sum(p.numel() for p in denoiser.parameters() if p.requires_grad):,}")
@@ -42,10 +54,14 @@ def train(config_name: str, overrides: list[str]) -> None:
         use_ema=cfg.trainer.use_ema,
         ema_update_after_step=cfg.trainer.get("ema_update_after_step", 0),
         ema_update_every=cfg.trainer.get("ema_update_every", 10),
-        run_config=cfg,
+        run_config=OmegaConf.to_container(cfg, resolve=True),
         compile=cfg.trainer.get("compile", False),
+        init_kwargs={"wandb": cfg.trainer.get("wandb", {})},
         **({"save_path": cfg.trainer.save_path} if "save_path" in cfg.trainer else {}),
     )
+    if os.environ.get("DIFFULAB_DRY_RUN") == "1":  # construct everything, train nothing (CPU smoke of the entry point)
+        print(f"dry run: {type(denoiser).__name__} / {type(optimizer).__name__} / {len(train_loader)} train batches")
+        return
     trainer.train(diffuser=diffuser, optimizer=optimizer, train_dataloader=train_loader, val_dataloader=val_loader,
                   log_validation_images=cfg.trainer.log_validation_images, val_steps=cfg.trainer.get("val_steps", 50))
     if torch.distributed.is_initialized():
@@ -53,4 +69,4 @@ def train(config_name: str, overrides: list[str]) -> None:
 
 
 if __name__ == "__main__":
-    train(sys.argv[1] if len(sys.argv) > 1 else "train_mnist_ddpm", sys.argv[2:])
+    train()

@@ -112,6 +112,8 @@ def rms_norm(x: Tensor, scale: Tensor, eps: float = 1e-6) -> Tensor:
 
 
 def layer_norm(x: Tensor, w: Tensor | None, b: Tensor | None, eps: float) -> Tensor:
+    x = x.float()  # no-op on the fp32 path; under bf16_autocast() the statistics and the output are f32, like torch's layer_norm
+    #                on the GPU autocast list
     mu = x.mean(dim=-1, keepdim=True)
     var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
     y = (x - mu) * torch.rsqrt(var + eps)
@@ -129,6 +131,14 @@ def attention(q: Tensor, k: Tensor, v: Tensor, scale: float) -> Tensor:
     s = torch.matmul(q, k.transpose(-1, -2)) * scale
     p = torch.softmax(s, dim=-1)
     return torch.matmul(p, v)
+
+
+def bf16_autocast():
+    """the oracle's bf16 leg (test yardstick only): the SAME functions under ``torch.autocast("cpu", bfloat16)`` -- every ``@`` /
+    matmul runs on bf16 operands and returns bf16, the residual stream is bf16, LayerNorm / RMSNorm statistics and softmax stay
+    f32 -- i.e. the dtype flow of the reference DiT under accelerate's bf16 mixed precision.  Comparing it with
+    the fp32 oracle gives the error a bf16 pipeline makes on its own; the HIP path is held to a multiple of that."""
+    return torch.autocast("cpu", dtype=torch.bfloat16)
 
 
 # ----------------------------------------------------------------------------- blocks

@@ -78,7 +78,7 @@ def test_small_model_against_reference_fixture(golden):
     assert rel(inputs["x"], od.flow_add_noise(x0, t, noise)) < 1e-6  # model_inputs["x"] is overwritten with z_t
     loss = losses["loss"]
     loss.backward()
-    assert abs(loss.item() - float(g["loss"])) / float(g["loss"]) < 2e-3
+    assert abs(loss.item() - float(g["loss"])) / float(g["loss"]) < 1e-3
     with torch.no_grad():
         pred = m(x=inputs["x"], timesteps=t.to(DEV), y=y.to(DEV))["x"]
     assert rel(pred, g["pred"]) < 1e-2
@@ -114,7 +114,7 @@ def test_ddpm_head_and_label_drop_against_oracle():
     T = od.GaussianTables(1000)
     ref = od.mse_loss(odit.dit_forward(Pr, od.ddpm_add_noise(T, x0, ti, noise), ti, y, cfg), noise)
     ref.backward()
-    assert abs(loss.item() - ref.item()) / ref.item() < 2e-3
+    assert abs(loss.item() - ref.item()) / ref.item() < 1e-3
     for name, p in m.named_parameters():
         assert rel(p.grad, Pr[name].grad) < 2.5e-2, name
     # p = 1 drops every label (Appendix C.12): equals the oracle fed the null class
@@ -174,7 +174,7 @@ def test_dit_s2_against_reference_fixture(golden):
     inputs = {"x": x0.to(DEV), "y": y.to(DEV), "p": 0.0}
     loss = d.compute_loss(inputs, timesteps=t, noise=noise.to(DEV))["loss"]
     loss.backward()
-    assert abs(loss.item() - float(g["loss"])) / float(g["loss"]) < 2e-3
+    assert abs(loss.item() - float(g["loss"])) / float(g["loss"]) < 1e-3
     with torch.no_grad():
         pred = m(x=inputs["x"], timesteps=t.to(DEV), y=y.to(DEV))["x"]
     assert rel(pred, g["pred"]) < 2e-2
@@ -252,7 +252,7 @@ def test_cifar_dit_dims_against_oracle():
     loss.backward()
     ref = od.flow_loss(odit.dit_forward(Pr, od.flow_add_noise(x0, t, noise), t, y, cfg), x0, noise)
     ref.backward()
-    assert abs(loss.item() - ref.item()) / ref.item() < 2e-3
+    assert abs(loss.item() - ref.item()) / ref.item() < 1e-3
     for name, p in m.named_parameters():
         assert rel(p.grad, Pr[name].grad) < 2.5e-2, name
 
@@ -301,7 +301,7 @@ def test_dit_on_1024_tokens_against_oracle():
     loss.backward()
     ref = od.flow_loss(odit.dit_forward(Pr, od.flow_add_noise(x0, t, noise), t, y, cfg), x0, noise)
     ref.backward()
-    assert abs(loss.item() - ref.item()) / ref.item() < 2e-3
+    assert abs(loss.item() - ref.item()) / ref.item() < 1e-3
     for name, p in m.named_parameters():
         assert rel(p.grad, Pr[name].grad) < 2.5e-2, name
 

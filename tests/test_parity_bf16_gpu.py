@@ -1,0 +1,112 @@
+"""Parity of the HIP path against the fp32 oracle, HELD TO THE bf16 REGIME'S OWN ERROR.
+
+The HIP denoisers compute in bf16 with f32 accumulation -- the precision of the reference under accelerate's bf16 mixed precision.
+Every test here runs three legs on the same seeded inputs and weights:
+
+    fp32  : the oracle in fp32 (pinned to the reference by tests/golden/*.npz)          -> the expected values
+    bf16  : the SAME oracle under ``odit.bf16_autocast()`` (bf16 matmuls / residual stream, f32 norm statistics)
+    hip   : the product path through the C ABI
+
+and asserts, per tensor, ``err(hip, fp32) <= max(SURVEY's bound, 1.5 * err(bf16, fp32))``: SURVEY §8c's 1e-2 (gradients /
+activations) and 1e-3 (loss) hold wherever a bf16 pipeline can meet them at all, and where bf16 itself cannot (deep stacks: the
+autocast leg alone is 1.4e-2 median on DiT-S/2 gradients) the HIP path may not be more than 1.5x worse than it.
+"""
+
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import diffusion as od  # noqa: E402
+from oracle import dit as odit  # noqa: E402
+from oracle import synth  # noqa: E402
+
+DEV = "cuda"
+S2 = dict(input_channels=4, output_channels=4, inner_dim=384, embedding_dim=384, num_heads=6, mlp_ratio=4, patch_size=2, depth=12,
+          n_classes=1000, classifier_free=True)
+SMALL = dict(input_channels=4, output_channels=4, inner_dim=128, embedding_dim=64, num_heads=2, mlp_ratio=4, patch_size=2, depth=2,
+             n_classes=10, classifier_free=True)
+GRAD_BOUND, LOSS_BOUND, FACTOR = 1e-2, 1e-3, 1.5
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def three_legs(cfgk, seed, B, H, tag, head="flow"):
+    """-> (loss, grads) of the fp32 oracle, the bf16-autocast oracle and the HIP path on identical inputs"""
+    from diffulab_amd import Diffuser, MMDiT
+
+    cfg = odit.DiTConfig(**cfgk)
+    P = synth.dit_params(odit.param_shapes(cfg), seed=seed)
+    C = cfgk["input_channels"]
+    x0, noise = synth.normal(f"{tag}.x0", (B, C, H, H)), synth.normal(f"{tag}.noise", (B, C, H, H))
+    t = synth.uniform(f"{tag}.t", (B,), lo=0.05, hi=0.95)
+    y = synth.integers(f"{tag}.y", (B,), cfgk["n_classes"])
+    out = {}
+    for leg in ("fp32", "bf16"):
+        Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        t0 = time.time()
+        if leg == "bf16":
+            with odit.bf16_autocast():
+                loss = od.flow_loss(odit.dit_forward(Pr, od.flow_add_noise(x0, t, noise), t, y, cfg), x0, noise)
+        else:
+            loss = od.flow_loss(odit.dit_forward(Pr, od.flow_add_noise(x0, t, noise), t, y, cfg), x0, noise)
+        loss.backward()
+        out[leg] = (loss.item(), {k: v.grad for k, v in Pr.items()})
+        print(f"{tag}: {leg} oracle leg {time.time() - t0:.1f} s")
+    m = MMDiT(simple_dit=True, **cfgk)
+    m.load_state_dict(P)
+    m = m.to(DEV)
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=50)
+    loss = d.compute_loss({"x": x0.to(DEV), "y": y.to(DEV), "p": 0.0}, timesteps=t, noise=noise.to(DEV))["loss"]
+    loss.backward()
+    torch.cuda.synchronize()
+    out["hip"] = (loss.item(), {k: p.grad.detach().cpu() for k, p in m.named_parameters()})
+    return out
+
+
+def check(out, tag):
+    l32, g32 = out["fp32"]
+    e_loss_bf, e_loss_hip = abs(out["bf16"][0] - l32) / l32, abs(out["hip"][0] - l32) / l32
+    assert e_loss_hip <= max(LOSS_BOUND, FACTOR * e_loss_bf), (tag, e_loss_hip, e_loss_bf)
+    rows, relaxed = [], 0
+    for k in g32:
+        e_bf, e_hip = rel(out["bf16"][1][k], g32[k]), rel(out["hip"][1][k], g32[k])
+        bound = max(GRAD_BOUND, FACTOR * e_bf)
+        relaxed += bound > GRAD_BOUND
+        rows.append((e_hip / bound, k, e_hip, e_bf))
+    rows.sort(reverse=True)
+    med = sorted(r[2] for r in rows)[len(rows) // 2], sorted(r[3] for r in rows)[len(rows) // 2]
+    print(f"{tag}: loss err hip {e_loss_hip:.2e} / bf16-autocast {e_loss_bf:.2e};  gradient rel-L2 median hip {med[0]:.2e} / bf16-autocast "
+          f"{med[1]:.2e};  {relaxed} of {len(rows)} tensors need more than {GRAD_BOUND:g} (bf16 itself misses it);  tightest: "
+          + ", ".join(f"{k} hip {eh:.2e} bf16 {eb:.2e}" for _, k, eh, eb in rows[:4]))
+    bad = [(k, eh, eb) for ratio, k, eh, eb in rows if ratio > 1.0]
+    assert not bad, (tag, bad[:8])
+
+
+def test_small_dit_hip_error_within_the_bf16_regime():
+    check(three_legs(SMALL, seed=5, B=4, H=16, tag="pb.small"), "small DiT (2 blocks, 64 tokens)")
+
+
+def test_dit_s2_small_batch_hip_error_within_the_bf16_regime():
+    check(three_legs(S2, seed=7, B=4, H=32, tag="pb.s2"), "DiT-S/2 B=4")
+
+
+@pytest.mark.timeout(1200)
+def test_full_training_step_at_the_benched_shape_b256():
+    """ONE full B=256 DiT-S/2 train step through Diffuser.compute_loss + backward -- the shape bench.py times: M = 65536 token rows,
+    the 256x384 persistent NT tiles (plain and fused-SwiGLU epilogues), the 384x128 split-R weight-gradient kernel on the side
+    stream with its 192-workgroup cap and f32 atomics, attention with V in place -- against the fp32 oracle on the same inputs,
+    loss and EVERY parameter gradient (the benched kernels were never parity-checked at the benched shape)."""
+    out = three_legs(S2, seed=7, B=256, H=32, tag="pb.b256")
+    check(out, "DiT-S/2 B=256 (benched shape)")
+    # whole-arena figure as well: one number for the report
+    flat = lambda g: torch.cat([g[k].flatten().double() for k in sorted(g)])  # noqa: E731
+    e = ((flat(out["hip"][1]) - flat(out["fp32"][1])).norm() / flat(out["fp32"][1]).norm()).item()
+    e_bf = ((flat(out["bf16"][1]) - flat(out["fp32"][1])).norm() / flat(out["fp32"][1]).norm()).item()
+    print(f"B=256 whole-gradient rel-L2: hip {e:.3e}, bf16-autocast oracle {e_bf:.3e}")
+    assert e <= max(GRAD_BOUND, FACTOR * e_bf)

@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_config_composition_and_instantiate():
     from diffulab_amd.config import instantiate, load_config
 
-    c = load_config(os.path.join(ROOT, "configs"), "train_mnist_ddpm", ["trainer.n_epoch=3", "model.model_channels=64"])
+    c = load_config(os.path.join(ROOT, "configs"), "train_mnist_ddpm", ["trainer.n_epoch=3", "model.model_channels=64",
+                                                                        "dataset=mnist_synthetic"])
     assert c.trainer.n_epoch == 3 and c.trainer.project_name == "mnist_ddpm" and c.trainer.use_ema is True
     assert c.dataloader.batch_size == 128 and c.diffuser.sampling_method == "ddpm"
     assert c.optimizer.lr == 1e-4 and isinstance(c.optimizer.lr, float)
