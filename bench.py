@@ -11,12 +11,15 @@ DiT forward -> backward -> [N>1: RCCL gradient all-reduce overlapped with backwa
 per-GPU batch is fixed (256), `value` is the whole-job images/s.  Nothing under /root/reference is read.
 
 Extra objects on the JSON line:
-  roofline     -- dominant kernel (gemm_nt_big_k, the bf16 MFMA NT GEMM behind every linear's forward and data-gradient):
-                  algorithmic FLOPs of its launches / their HIP-event durations, measured on a profiled replay of the
-                  same step (per-variant and gemm_tn numbers under `kernels`); `traffic` from the committed PMC passes;
-                  plus the whole-step figure (47.2 GFLOP/img x img/s) as `step_achieved`.
-  cpu_baseline -- the CPU oracle (a port of the reference path, oracle/) timed on this host's cores on a bounded
-                  sample (B=8, 1 warm-up + the timed steps that fit in ~25 s), rank 0 at N=1 only.
+  roofline     -- the DOMINANT kernel of the step = the kernel name with the largest summed launch time in a profiled replay of
+                  the same step (HIP events around every GEMM / attention / row-kernel launch, recorded on the stream the launch
+                  goes to) -- the kernel `rocprofv3 --kernel-trace --stats` ranks first (profiles/r02_*_kernel_stats.txt):
+                  algorithmic FLOPs of its launches / their durations; every other instrumented kernel under `kernels` /
+                  `hbm_bound_kernels`; `traffic` from the newest committed PMC pass; the whole-step figure (47.2 GFLOP/img x
+                  img/s) as `step_achieved`.
+  cpu_baseline -- the CPU oracle (a port of the reference path, oracle/) timed on this host's cores by the protocol of
+                  BASELINE.md section 3 / SURVEY 8(d): B=32, 1 warm-up + 3 timed steps, thread count printed; rank 0 at N=1 only.
+  dp           -- N>1: rccl_ranks and the exposed (non-overlapped) part of the gradient all-reduce per step.
 """
 
 from __future__ import annotations
@@ -58,9 +61,9 @@ def _host_threads() -> int:
     return max(1, min(n, 32))
 
 
-def cpu_baseline(batch: int = 8, budget_s: float = 25.0) -> dict:
-    """CPU oracle (port of the reference path) on a bounded sample: B=8 DiT-S/2 flow train steps, one warm-up
-    then as many timed steps as fit in ~budget_s (at least one)."""
+def cpu_baseline(batch: int = 32, n_timed: int = 3, budget_s: float = 150.0) -> dict:
+    """CPU oracle (port of the reference path) by the protocol of BASELINE.md section 3 / SURVEY 8(d): DiT-S/2 flow train steps at
+    B=32, one warm-up then 3 timed steps (cut short only if a pathological host exceeds budget_s)."""
     from oracle import diffusion as od
     from oracle import dit as odit
     from oracle import synth
@@ -84,7 +87,7 @@ def cpu_baseline(batch: int = 8, budget_s: float = 25.0) -> dict:
         opt.step()
         times.append(time.perf_counter() - t0)
         s += 1
-        if s >= 2 and (time.perf_counter() - start > budget_s or s >= 6):
+        if s >= 2 and (time.perf_counter() - start > budget_s or s >= 1 + n_timed):
             break
         if s == 1 and times[0] > budget_s:  # pathological host: keep the single (cold) measurement
             break
@@ -92,6 +95,14 @@ def cpu_baseline(batch: int = 8, budget_s: float = 25.0) -> dict:
     dt = sum(timed) / len(timed)
     return {"value": round(batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle fp32 DiT-S/2 flow train step, B={batch}, {len(times) - len(timed)} warm-up + {len(timed)} timed steps"}
+
+
+def _tn_variant(R: int, M: int, N: int) -> str:
+    """which kernel dl_gemm_tn dispatches to (csrc/gemm.hip dl_gemm_tn_ex, default variant)"""
+    tiles_m = -(-M // 384)
+    if N % 128 == 0 and R // 64 >= 64 and 5 * M >= 3 * tiles_m * 384:
+        return "gemm_tn_big_k"
+    return "gemm_tn_k"
 
 
 def _nt_variant(M: int, N: int, K: int, plain: bool) -> str:
@@ -114,7 +125,7 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
     from diffulab_amd import ops
 
     rec: list[tuple[str, torch.cuda.Event, torch.cuda.Event, float]] = []
-    orig = {n: getattr(ops, n) for n in ("gemm_nt", "gemm_nt_swiglu", "gemm_tn")}
+    orig = {n: getattr(ops, n) for n in ("gemm_nt", "gemm_nt_swiglu", "gemm_tn", "attn_fwd_qkv", "attn_bwd_qkv", "attn_fwd", "attn_bwd")}
 
     def timed(kind: str):
         fn = orig[kind]
@@ -127,9 +138,12 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
                 name, fl = _nt_variant(M, N, K, plain), 2.0 * M * N * K
             elif kind == "gemm_nt_swiglu":
                 name, fl = "gemm_nt_big_k<384,2,2>", 2.0 * a.shape[0] * b.shape[0] * a.shape[1]
+            elif kind.startswith("attn_"):  # (q, k, ..., B, H, N, dh, scale): 4 N^2 dh per head forward, 10 N^2 dh backward
+                Bq, Hq, Nq, dq = a.shape
+                name, fl = ("attn_bwd_k" if "bwd" in kind else "attn_fwd_k"), (10.0 if "bwd" in kind else 4.0) * Bq * Hq * Nq * Nq * dq
             else:
                 M, N = kw.get("M") or a.shape[1], kw.get("N") or b.shape[1]
-                name, fl = "gemm_tn", 2.0 * a.shape[0] * M * N
+                name, fl = _tn_variant(a.shape[0], M, N), 2.0 * a.shape[0] * M * N
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()  # current stream == the stream the launch goes to
             r = fn(a, b, *rest, **kw)
@@ -192,30 +206,34 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
         d[2] += fl
     kernels = {k: {"launches_per_step": v[0] // reps, "avg_launch_us": round(v[1] * 1e3 / v[0], 2),
                    "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in sorted(per.items())}
-    fam = [v for k, v in per.items() if k.startswith("gemm_nt_big_k")]
-    n_l, ms, fl = sum(v[0] for v in fam), sum(v[1] for v in fam), sum(v[2] for v in fam)
-    ach = fl / (ms * 1e-3) / 1e12
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_m_pmc_traffic.json")
-    if os.path.exists(tpath):
-        t = json.load(open(tpath))
-        rows = [v for k, v in t.items() if k.startswith("gemm_nt_big_k")]
-        if rows:
-            traffic = round(sum(v["launches"] * (v["fetch_MB"] + v["write_MB"]) for v in rows) * 1e6
-                            / sum(v["launches"] for v in rows))
     hb: dict[str, list[float]] = {}
     for name, e0, e1, nb in hbm_rec:
         d = hb.setdefault(name, [0, 0.0, 0.0])
         d[0] += 1
         d[1] += e0.elapsed_time(e1)
         d[2] += nb
+    # dominant kernel = largest summed launch time over every instrumented kernel name (the MFMA kernels lead this workload;
+    # the HBM-bound row kernels are reported beside it)
+    dom = max(per, key=lambda k: per[k][1])
+    n_l, ms, fl = per[dom]
+    ach = fl / (ms * 1e-3) / 1e12
+    traffic, tsrc = None, None
+    tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+    if tfiles:
+        tsrc = tfiles[-1]
+        t = json.load(open(os.path.join(ROOT, "profiles", tsrc)))
+        key = dom.replace(",", ", ")  # rocprof prints template arguments with a space
+        rows = [v for k, v in t.items() if k.startswith(key)]
+        if rows:
+            traffic = round(sum(v["launches"] * (v["fetch_MB"] + v["write_MB"]) for v in rows) * 1e6
+                            / sum(v["launches"] for v in rows))
     hbm_kernels = {k: {"launches_per_step": v[0] // reps, "avg_launch_us": round(v[1] * 1e3 / v[0], 2),
                        "achieved_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1), "frac_of_8TBps": round(v[2] / (v[1] * 1e-3) / 8e12, 3)}
                    for k, v in sorted(hb.items())}
     step_ach = images_per_s_per_gpu * train_flops_per_image() / 1e12
-    return {"bound": "mfma", "kernel": "gemm_nt_big_k (all variants; NT GEMM of every linear fwd + dgrad)",
+    return {"bound": "mfma", "kernel": dom + " (largest summed launch time of the step; rocprof ranks it first)",
             "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-            "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_m_pmc_traffic.txt)",
+            "traffic": traffic, "traffic_unit": f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{tsrc})",
             "flops_per_launch": round(fl / n_l), "launches_per_step": n_l // reps, "avg_launch_us": round(ms * 1e3 / n_l, 2),
             "ms_per_step": round(ms / reps, 3), "kernels": kernels,
             "step_achieved": round(step_ach, 1), "step_frac": round(step_ach / PEAK_BF16_TFLOPS, 4),
@@ -230,6 +248,8 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--trainer-mode", action="store_true", help="secondary number: the step as BaseTrainer.training_step runs it "
+                    "with the shipped defaults (per-loss .item() read-back every step, fused EMA update every step)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -270,6 +290,19 @@ def main() -> None:
         sum(losses.values()).backward()
         opt.step()
 
+    ema = None
+    if args.trainer_mode:
+        from diffulab_amd.training import EMA
+
+        ema = EMA(model, beta=0.999, update_after_step=0, update_every=10)
+        base_step = step
+
+        def step() -> None:  # noqa: F811
+            base_step()
+            float(loss_host)  # (the value of the PREVIOUS copy would do for logging; .item() semantics = wait for this one)
+            torch.cuda.current_stream().synchronize()
+            ema.update()
+
     def sync() -> None:
         if world > 1:
             dist.barrier()
@@ -291,6 +324,16 @@ def main() -> None:
     value = world * B * args.steps / dt
     final_loss = float(loss_host)
 
+    dp = None
+    if world > 1:  # a few extra steps with the reducer's wait instrumented: how much of the all-reduce is NOT hidden under backward
+        reducer.measure = True
+        for _ in range(3):
+            step()
+        tail = reducer.exposed_ms()
+        reducer.measure = False
+        dp = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "grad_bytes_per_step": model._flat_grad.numel() * 4,
+              "exposed_allreduce_ms_per_step": None if tail is None else round(tail, 3)}
+
     roof = None
     if rank == 0 and not args.no_roofline:
         roof = roofline_replay(step, model, value / world)
@@ -311,6 +354,10 @@ def main() -> None:
                        "parallelism": f"dp{world}", "flops_per_image": train_flops_per_image(), "final_loss": final_loss},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if dp is not None:
+            out["dp"] = dp
+        if args.trainer_mode:
+            out["config"]["trainer_mode"] = "per-step loss read-back + EMA(update_every=10), as BaseTrainer.training_step with use_ema"
         print(json.dumps(out))
     if world > 1:
         dist.barrier()  # rank 0 was still replaying / printing: tear the communicator down together

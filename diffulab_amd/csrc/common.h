@@ -61,15 +61,41 @@ __device__ __forceinline__ u32x4_t pack8(const float (&f)[8]) {
   return p;
 }
 
+// Wavefront reductions without the LDS: `__shfl_xor` lowers to ds_bpermute_b32 on gfx950, i.e. six dependent round trips through
+// the LDS pipeline per reduction -- slow on its own and, next to a GEMM workgroup that keeps the CU's LDS port busy (the side-stream
+// weight-gradient GEMMs), the reason the LayerNorm kernels ran 2-3x slower inside the training step than alone.  DPP row operations
+// stay in the VALU: two quad permutes, row_half_mirror and row_mirror leave every lane with the sum of its 16-lane row; the four
+// row sums are read through v_readlane (SGPRs) and combined, so the result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);  // row_half_mirror
+  v += dpp_f<0x140>(v);  // row_mirror
+  const int i = __float_as_int(v);
+  return (__int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48)));
+}
+// v + (the value 32 lanes away) / max of the two, for every lane: one v_permlane32_swap instead of a ds_bpermute round trip
+__device__ __forceinline__ float xor32_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  const int i = __float_as_int(v);
+  return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 0)), __int_as_float(__builtin_amdgcn_readlane(i, 16))),
+               fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 32)), __int_as_float(__builtin_amdgcn_readlane(i, 48))));
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // d/dx [x * sigmoid(x)]

@@ -1134,6 +1134,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __
         for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
     return;
   }
+  if (PROBE & 32) C += (int64_t)(__builtin_amdgcn_s_getreg(6164) & 7) * M * ldc;  // HW_REG_XCC_ID[3:0]: one slab per XCD
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -1147,6 +1148,177 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __
     }
 }
 
+
+// =====================================================================================================
+// gemm_tn_wide_k: the wgrads of the two MLP linears (2/3 of the wgrad FLOPs).  The component probe (scripts/gemm_probe.py)
+// shows the 384x128 kernel above waiting for its operand DMA: 64 KiB per k-step and CU at ~8 TB/s chip-wide is 204 us of a
+// 242 us launch, while its MFMA + LDS-read part alone takes 107 us.  A 256x384 (or 384x256) tile stages 80 KiB per
+// 12.6 MFLOP instead of 64 KiB per 6.3 MFLOP (-37 % DMA bytes) and reads 14 transposed fragments per 12 MFMAs instead of 10 per 6.
+//   A384 = false: C tile 256 (m) x 384 (n), 8 waves as 2 x 4, each 128 x 96 = 4 x 3 MFMA tiles  (MLP-up:   [3072, 384])
+//   A384 = true : C tile 384 (m) x 256 (n), 8 waves as 4 x 2, each  96 x 128 = 3 x 4 MFMA tiles (MLP-down: [384, 1536])
+// Twice the tile per workgroup means twice the split-R partial sums, and the f32 atomics of the small kernel already cost 20-33 us
+// per launch: every address is hit by all splits from all 8 XCDs, whose L2s pass the line around.  Here a workgroup adds its
+// partial tile into the slab of ITS XCD (HW_REG_XCC_ID), so a line is only ever touched through one L2, and a small second kernel
+// sums the 8 slabs into C and clears them (the caller provides the zeroed [8, M, N] f32 workspace once).
+// Requires M % TM == 0, N % TN == 0, R % 64 == 0.
+// =====================================================================================================
+template <bool A384>
+__global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_wide_k(const bf16_t* __restrict__ A, int64_t lda,
+                                                                   const bf16_t* __restrict__ Bm, int64_t ldb,
+                                                                   float* __restrict__ slabs, int M, int N, int R,
+                                                                   int steps_per_split, int nsplit_pad) {
+  constexpr int TM = A384 ? 384 : 256, TN_ = A384 ? 256 : 384;
+  constexpr int MI = A384 ? 3 : 4, NI = A384 ? 4 : 3;          // 32x32 MFMA tiles per wave
+  constexpr int A_BYTES = BK * TM * 2, STG = BK * (TM + TN_) * 2;  // 80 KiB per stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // block -> (split, tile): the tiles of one split read the same operand rows; give them block ids congruent mod 8 (one XCD / L2)
+  const int ntile = (M / TM) * (N / TN_);
+  const int tile = (blockIdx.x >> 3) % ntile;
+  const int split = (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / ntile);
+  const int tiles_n = N / TN_;
+  const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN_;
+  const int nsteps_total = R / BK;
+  const int s_begin = split * steps_per_split;
+  int s_end = s_begin + steps_per_split;
+  s_end = s_end < nsteps_total ? s_end : nsteps_total;
+  if (s_begin >= s_end) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = A384 ? (wave >> 1) : (wave >> 2), wn = A384 ? (wave & 1) : (wave & 3);
+
+  // ---- DMA: per stage the 256-column operand is 32 chunks of 1 KiB (2 rows each), the 384-column operand 48 chunks (3 chunks
+  //      = 4 rows); every wave copies 4 + 6 of them.  32-bit element offsets relative to the stage's first row.
+  const bf16_t* p256 = A384 ? Bm + n0 : A + m0;
+  const bf16_t* p384 = A384 ? A + m0 : Bm + n0;
+  const int ld256 = (int)(A384 ? ldb : lda), ld384 = (int)(A384 ? lda : ldb);
+  int off256[2], off384[3];
+  {
+    const int h = lane >> 5, sl = lane & 31;
+#pragma unroll
+    for (int par = 0; par < 2; ++par) off256[par] = h * ld256 + ((sl ^ ((2 * par + h) << 2)) << 3);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int o = j * 1024 + lane * 16, r = o / 768, sj = (o - r * 768) >> 4;
+      off384[j] = r * ld384 + ((sj ^ ((r & 3) << 2)) << 3);
+    }
+  }
+  constexpr int BASE256 = A384 ? A_BYTES : 0, BASE384 = A384 ? 0 : A_BYTES;
+  auto stage = [&](int st, int buf) {
+    char* base = smem + buf * STG;
+    const bf16_t* q256 = p256 + (int64_t)st * BK * ld256;
+    const bf16_t* q384 = p384 + (int64_t)st * BK * ld384;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = wave * 4 + j;  // rows 2c, 2c+1
+      glds16(q256 + off256[j & 1] + 2 * c * ld256, base + BASE256 + c * 1024);
+    }
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int g = wave * 2 + gg;  // rows 4g .. 4g+3
+        glds16(q384 + off384[j] + 4 * g * ld384, base + BASE384 + (3 * g + j) * 1024);
+      }
+  };
+
+  const int li = lane & 15, g4 = lane >> 4;
+  auto tr_off = [&](int cb, int kk, int half, int pitch) -> int {
+    const int r = kk * 16 + (g4 >> 1) * 8 + half * 4 + (li >> 2);
+    const int col = cb + (g4 & 1) * 16 + (li & 3) * 4;
+    const int slot = (col >> 3) ^ ((r & 3) << 2);
+    return r * pitch + slot * 16 + (col & 7) * 2;
+  };
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  stage(s_begin, 0);
+  for (int st = s_begin; st < s_end; ++st) {
+    const int it = st - s_begin;
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (st + 1 < s_end) stage(st + 1, (it + 1) & 1);
+    const char* ta = smem + (it & 1) * STG;
+    const char* tb = ta + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8_t af[MI], bfg[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        union {
+          s16x4_t h[2];
+          bf16x8_t v;
+        } u;
+        u.h[0] = lds_tr16(ta + tr_off(wm * (MI * 32) + i * 32, kk, 0, TM * 2));
+        u.h[1] = lds_tr16(ta + tr_off(wm * (MI * 32) + i * 32, kk, 1, TM * 2));
+        af[i] = u.v;
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        union {
+          s16x4_t h[2];
+          bf16x8_t v;
+        } u;
+        u.h[0] = lds_tr16(tb + tr_off(wn * (NI * 32) + j * 32, kk, 0, TN_ * 2));
+        u.h[1] = lds_tr16(tb + tr_off(wn * (NI * 32) + j * 32, kk, 1, TN_ * 2));
+        bfg[j] = u.v;
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfg[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  if (nsplit_pad < 0) {  // tuning probe: no epilogue
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+    return;
+  }
+  float* Cx = slabs + (int64_t)(__builtin_amdgcn_s_getreg(6164) & 7) * M * N;  // HW_REG_XCC_ID[3:0]
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wn * (NI * 32) + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        unsafeAtomicAdd(&Cx[(int64_t)m * N + n], acc[i][j][r]);
+      }
+    }
+}
+
+// C[m, n] += sum over the 8 per-XCD slabs; the slabs are cleared for the next launch (16-byte lanes)
+__global__ void tn_slab_fold_k(float* __restrict__ slabs, float* __restrict__ C, int64_t ldc, int64_t M, int N) {
+  const int N4 = N >> 2;
+  const int64_t total = M * N4, stride = (int64_t)gridDim.x * blockDim.x, slab = M * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t m = i / N4;
+    const int n = (int)(i - m * N4) * 4;
+    f32x4_t s = *(const f32x4_t*)(C + m * ldc + n);
+    const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      float* p = slabs + x * slab + m * N + n;
+      s += *(const f32x4_t*)p;
+      *(f32x4_t*)p = z;
+    }
+    *(f32x4_t*)(C + m * ldc + n) = s;
+  }
+}
+
+extern "C" int dl_gemm_tn_ws(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                             int64_t N, int64_t R, int max_workgroups, float* workspace, int64_t workspace_elems,
+                             dl_stream_t stream);
 extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                              int64_t N, int64_t R, int max_workgroups, dl_stream_t stream);
 extern "C" int dl_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
@@ -1203,6 +1375,7 @@ extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t 
         else if (g_gemm_probe == 16) TN_PROBE_GO(16);
         else if (g_gemm_probe == 17) TN_PROBE_GO(17);
         else if (g_gemm_probe == 26) TN_PROBE_GO(26);
+        else if (g_gemm_probe == 32) TN_PROBE_GO(32);
         else TN_PROBE_GO(10);
 #undef TN_PROBE_GO
         DL_LAUNCH_CHECK();
@@ -1223,6 +1396,51 @@ extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t 
   splits = (nsteps + sps - 1) / sps;
   hipLaunchKernelGGL(gemm_tn_k<false>, ntile * splits, NT_THREADS, 65536, (hipStream_t)stream, (const bf16_t*)A, lda,
                      (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)R, sps, ConvGeom{});
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+/* dl_gemm_tn_ex with a caller-owned f32 workspace of >= 8*M*N elements (ZERO on first use; left zero on return): shapes with
+ * M % 256 == 0 && N == 384-multiple, or M % 384 == 0 && N % 256 == 0, and a long reduction run the wide-tile kernel with per-XCD
+ * partial slabs; every other shape (or workspace == NULL / too small) is dl_gemm_tn_ex. */
+extern "C" int dl_gemm_tn_ws(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                             int64_t N, int64_t R, int max_workgroups, float* workspace, int64_t workspace_elems,
+                             dl_stream_t stream) {
+  static int wide = -1, n_cu = 0;
+  if (wide < 0) {
+    const char* e = getenv("DL_GEMM_TN_WIDE");
+    wide = e ? atoi(e) : 0;  // measured slower than the 384x128 kernel: opt-in
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+    (void)hipFuncSetAttribute((const void*)gemm_tn_wide_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BK * 640 * 2);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_wide_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BK * 640 * 2);
+  }
+  const bool up = (M % 256 == 0 && N % 384 == 0 && M >= 4 * N), down = (M % 384 == 0 && N % 256 == 0 && N >= 2 * M);
+  const int nsteps = (int)(R / BK);
+  if (!wide || !workspace || workspace_elems < 8 * M * N || !(up || down) || R % BK || nsteps < 128 || ldc % 4 || N % 4 ||
+      ((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)workspace) & 15 || lda % 8 || ldb % 8)
+    return dl_gemm_tn_ex(A, lda, B, ldb, C, ldc, M, N, R, max_workgroups, stream);
+  const int ntile = up ? (int)((M / 256) * (N / 384)) : (int)((M / 384) * (N / 256));
+  const int budget = (max_workgroups > 0 && max_workgroups < n_cu) ? max_workgroups : n_cu;
+  int splits = budget / ntile;
+  if (splits < 1) splits = 1;
+  if (splits > nsteps / 8) splits = nsteps / 8;
+  const int sps = (nsteps + splits - 1) / splits;
+  splits = (nsteps + sps - 1) / sps;
+  const int splits_pad = (splits + 7) & ~7;  // surplus splits exit at once
+  const int flag = (g_gemm_probe & 1) ? -1 : splits_pad;
+  if (up)
+    hipLaunchKernelGGL(gemm_tn_wide_k<false>, splits_pad * ntile, BIG_THREADS, 2 * BK * 640 * 2, (hipStream_t)stream, (const bf16_t*)A,
+                       lda, (const bf16_t*)B, ldb, workspace, (int)M, (int)N, (int)R, sps, flag);
+  else
+    hipLaunchKernelGGL(gemm_tn_wide_k<true>, splits_pad * ntile, BIG_THREADS, 2 * BK * 640 * 2, (hipStream_t)stream, (const bf16_t*)A,
+                       lda, (const bf16_t*)B, ldb, workspace, (int)M, (int)N, (int)R, sps, flag);
+  int64_t g = (M * (N / 4) + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (!(g_gemm_probe & 2))
+  hipLaunchKernelGGL(tn_slab_fold_k, (int)g, 256, 0, (hipStream_t)stream, workspace, C, ldc, M, (int)N);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

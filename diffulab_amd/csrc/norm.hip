@@ -3,6 +3,8 @@
 // One 64-lane wave owns one token row; every lane moves 16-byte (8 x bf16) chunks; row statistics are
 // wavefront shuffles (no LDS); per-sample column reductions (adaLN gradients) are register accumulators
 // reduced across the workgroup's waves through LDS once per workgroup.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define MAXJ 2  // chunks of 8 per lane -> D <= 1024 (NJ=4 spills; wider rows need an LDS-staged variant)
@@ -138,8 +140,14 @@ extern "C" int dl_ln_modulate_fwd(const void* x, const float* w, const float* b,
 // GEMM workgroup that owns most of the CU -- the side-stream wgrad overlap); (2) a tiny kernel folds the partials.
 #define LNB_WAVES 8
 #define LNB1_WAVES 4
-template <int NJ>
-__global__ __launch_bounds__(256) void ln_mod_bwd_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
+// Column sums: only three are independent.  With d = dout, xh = (x - mu) rstd, y = xh w + b, dy = d (1 + scale):
+//   dscale = sum d y = w S2 + b S1,  dshift = S1,  dw = (1 + scale) S2,  db = (1 + scale) S1,  dgate = S3
+//   S1 = sum_rows d,  S2 = sum_rows d xh,  S3 = sum_rows dx_new t
+// so the row loop carries 3 accumulators and ONE constant vector g = (1 + scale) w instead of 5 + 3: 179 -> ~110 VGPRs.  That
+// matters beside the side-stream weight-gradient GEMM (152 VGPRs x 2 waves per SIMD): two of these waves fit into the 208
+// registers it leaves per SIMD instead of one.  PF: software prefetch of the next row (worth it only at one wave per SIMD).
+template <int NJ, bool PF>
+__device__ __forceinline__ void ln_mod_bwd_body(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
                                                     const float* __restrict__ w, const float* __restrict__ b,
                                                     const bf16_t* __restrict__ scale, int64_t ld_mod,
                                                     int64_t rows_per_mod, const float* __restrict__ mean,
@@ -150,29 +158,33 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_k(const bf16_t* __restrict__ d
                                                     int64_t ld_gate, bf16_t* __restrict__ gdt, float* __restrict__ dgate,
                                                     int split, int64_t M, int D) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = (float*)smem;  // [5][D]
+  float* red = (float*)smem;  // [3][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D8 = D >> 3;
   const float invD = 1.0f / (float)D;
   const int64_t g = blockIdx.x / split;
   const int sp = blockIdx.x - (int)g * split;
   const int64_t rows_per_wg = rows_per_mod / split;
-  for (int i = threadIdx.x; i < 5 * D; i += 256) red[i] = 0.f;
-  float wv[NJ][8], bv[NJ][8], sc[NJ][8], gv[NJ][8];
-  load_row_f32<NJ>(w, D8, lane, wv, 1.0f);
-  load_row_f32<NJ>(b, D8, lane, bv, 0.0f);
-  load_row<NJ>(scale + g * ld_mod, D8, lane, sc);
+  for (int i = threadIdx.x; i < 3 * D; i += 256) red[i] = 0.f;
+  float gw[NJ][8], gv[NJ][8];
+  {
+    float wv[NJ][8], sc[NJ][8];
+    load_row_f32<NJ>(w, D8, lane, wv, 1.0f);
+    load_row<NJ>(scale + g * ld_mod, D8, lane, sc);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gw[j][e] = (1.0f + sc[j][e]) * wv[j][e];
+  }
   if (gt) load_row<NJ>(ggate + g * ld_gate, D8, lane, gv);
-  float a_dsc[NJ][8], a_dsh[NJ][8], a_dw[NJ][8], a_db[NJ][8], a_dg[NJ][8];
+  float a_s1[NJ][8], a_s2[NJ][8], a_s3[NJ][8];
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) a_dsc[j][e] = a_dsh[j][e] = a_dw[j][e] = a_db[j][e] = a_dg[j][e] = 0.f;
+    for (int e = 0; e < 8; ++e) a_s1[j][e] = a_s2[j][e] = a_s3[j][e] = 0.f;
 
   const int64_t row_begin = g * rows_per_mod + sp * rows_per_wg;
   const int64_t row_end = row_begin + rows_per_wg < M ? row_begin + rows_per_wg : M;
-  // software prefetch: the packed bf16 rows (dout, x, dres) of the NEXT row are requested before the current row is
-  // processed, so every wave keeps two rows of loads in flight (this kernel often runs at one wave per SIMD next to a GEMM)
   u32x4_t pd[NJ], px[NJ], pr[NJ], pt[NJ];
   float pmu = 0.f, prs = 0.f;
   auto fetch = [&](int64_t row) {
@@ -190,8 +202,9 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_k(const bf16_t* __restrict__ d
     prs = rstd[row];
   };
   int64_t row = row_begin + wave;
-  if (row < row_end) fetch(row);
+  if (PF && row < row_end) fetch(row);
   for (; row < row_end; row += LNB1_WAVES) {
+    if (!PF) fetch(row);
     float dv[NJ][8], xv[NJ][8], rv[NJ][8];
     u32x4_t tq[NJ];  // this row's t (gate fusion), saved before the prefetch of the next row overwrites pt
 #pragma unroll
@@ -210,7 +223,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_k(const bf16_t* __restrict__ d
       if (on && dres) unpack8(pr[j], rv[j]);
     }
     const float mu = pmu, rs = prs;
-    if (row + LNB1_WAVES < row_end) fetch(row + LNB1_WAVES);
+    if (PF && row + LNB1_WAVES < row_end) fetch(row + LNB1_WAVES);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -218,14 +231,10 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_k(const bf16_t* __restrict__ d
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float xh = on ? (xv[j][e] - mu) * rs : 0.f;
-        const float y = xh * wv[j][e] + bv[j][e];
         const float d = dv[j][e];
-        a_dsc[j][e] += d * y;
-        a_dsh[j][e] += d;
-        const float dy = d * (1.0f + sc[j][e]);
-        a_dw[j][e] += dy * xh;
-        a_db[j][e] += dy;
-        const float dxh = dy * wv[j][e];
+        a_s1[j][e] += d;
+        a_s2[j][e] += d * xh;
+        const float dxh = d * gw[j][e];
         s1 += dxh;
         s2 += dxh * xh;
         xv[j][e] = xh;
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_k(const bf16_t* __restrict__ d
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float dxr = bf2f(f2bf(rv[j][e]));
-          a_dg[j][e] += on ? dxr * tv[e] : 0.f;
+          a_s3[j][e] += on ? dxr * tv[e] : 0.f;
           rv[j][e] = dxr * gv[j][e];
         }
       }
@@ -258,9 +267,8 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_k(const bf16_t* __restrict__ d
     }
   }
 
-  // cross-wave reduction of the four column sums: LDS float atomics into ONE [4][D] slab (6 KiB at D = 384), so the
-  // kernel co-resides with a GEMM workgroup that holds 128 KiB of the CU's LDS (the side-stream wgrad overlap)
-  __syncthreads();  // zero-fill below happened before the row loop
+  // cross-wave reduction of the three column sums: LDS float atomics into ONE [3][D] slab
+  __syncthreads();  // zero-fill above happened before the row loop
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int c = lane + 64 * j;
@@ -268,25 +276,43 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_k(const bf16_t* __restrict__ d
       float* base = red + c * 8;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        atomicAdd(base + e, a_dsc[j][e]);
-        atomicAdd(base + D + e, a_dsh[j][e]);
-        atomicAdd(base + 2 * D + e, a_dw[j][e]);
-        atomicAdd(base + 3 * D + e, a_db[j][e]);
-        if (gt) atomicAdd(base + 4 * D + e, a_dg[j][e]);
+        atomicAdd(base + e, a_s1[j][e]);
+        atomicAdd(base + D + e, a_s2[j][e]);
+        if (gt) atomicAdd(base + 2 * D + e, a_s3[j][e]);
       }
     }
   }
   __syncthreads();
   // the `split` workgroups of one sample meet in global f32 accumulators (<= split-way contention per address): the
   // modulation gradients land in the f32 image of dmod, the affine gradients in the per-sample partial [groups, 2, D]
-  for (int i = threadIdx.x; i < (gt ? 5 : 4) * D; i += 256) {
-    const int which = i / D, col = i - which * D;
-    const float v = red[i];
-    if (which == 0) unsafeAtomicAdd(dscale + g * ld_dmod + col, v);
-    else if (which == 1) unsafeAtomicAdd(dshift + g * ld_dmod + col, v);
-    else if (which == 4) unsafeAtomicAdd(dgate + g * ld_dmod + col, v);
-    else if (dwb) unsafeAtomicAdd(dwb + (size_t)g * 2 * D + (which - 2) * D + col, v);
+  for (int col = threadIdx.x; col < D; col += 256) {
+    const float S1 = red[col], S2 = red[D + col];
+    const float wc = w ? w[col] : 1.0f, bc = b ? b[col] : 0.0f, sc1 = 1.0f + bf2f(scale[g * ld_mod + col]);
+    unsafeAtomicAdd(dscale + g * ld_dmod + col, wc * S2 + bc * S1);
+    unsafeAtomicAdd(dshift + g * ld_dmod + col, S1);
+    if (gt) unsafeAtomicAdd(dgate + g * ld_dmod + col, red[2 * D + col]);
+    if (dwb) {
+      unsafeAtomicAdd(dwb + (size_t)g * 2 * D + col, sc1 * S2);
+      unsafeAtomicAdd(dwb + (size_t)g * 2 * D + D + col, sc1 * S1);
+    }
   }
+}
+
+#define LNB_ARGS                                                                                                              \
+  const bf16_t *__restrict__ dout, const bf16_t *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,            \
+      const bf16_t *__restrict__ scale, int64_t ld_mod, int64_t rows_per_mod, const float *__restrict__ mean,                         \
+      const float *__restrict__ rstd, const bf16_t *__restrict__ dres, bf16_t *__restrict__ dx, float *__restrict__ dscale,           \
+      float *__restrict__ dshift, int64_t ld_dmod, float *__restrict__ dwb, const bf16_t *__restrict__ gt,                            \
+      const bf16_t *__restrict__ ggate, int64_t ld_gate, bf16_t *__restrict__ gdt, float *__restrict__ dgate, int split, int64_t M, int D
+#define LNB_PASS dout, x, w, b, scale, ld_mod, rows_per_mod, mean, rstd, dres, dx, dscale, dshift, ld_dmod, dwb, gt, ggate, ld_gate, gdt, dgate, split, M, D
+// D <= 512: capped at 104 VGPRs (two waves per SIMD beside the 152-register weight-gradient GEMM, four alone)
+template <bool PF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void ln_mod_bwd_k(LNB_ARGS) {
+  ln_mod_bwd_body<1, PF>(LNB_PASS);
+}
+template <bool PF>
+__global__ __launch_bounds__(256) void ln_mod_bwd_wide_k(LNB_ARGS) {
+  ln_mod_bwd_body<2, PF>(LNB_PASS);
 }
 
 extern "C" int dl_ln_modulate_bwd(const void* dout, const void* x, const float* w, const float* b, const void* scale,
@@ -307,15 +333,26 @@ extern "C" int dl_ln_modulate_bwd(const void* dout, const void* x, const float* 
   const int split = (rows_per_mod % rows_wg == 0) ? (int)(rows_per_mod / rows_wg) : 1;
   DL_CHECK_ARG(!gate_t || (gate && dt && dgate && ld_gate % 8 == 0 && (((uintptr_t)gate_t | (uintptr_t)gate | (uintptr_t)dt) & 15) == 0),
                "dl_ln_modulate_bwd: the fused gate backward needs gate_t, gate, dt and dgate (16-byte aligned)");
-  const size_t lds = (size_t)5 * D * sizeof(float);
-#define LAUNCH(NJ)                                                                                                       \
-  hipLaunchKernelGGL(ln_mod_bwd_k<NJ>, groups * split, 256, lds, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)x, \
-                     w, b, (const bf16_t*)scale, ld_mod, rows_per_mod, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx,       \
-                     dscale, dshift, ld_dmod, dwb_partial, (const bf16_t*)gate_t, (const bf16_t*)gate, ld_gate,           \
+  const size_t lds = (size_t)3 * D * sizeof(float);
+  static int pf = -1;
+  if (pf < 0) {
+    const char* e = getenv("DL_LN_BWD_PREFETCH");
+    pf = e ? atoi(e) : 0;
+  }
+#define LAUNCH(NJ, PF)                                                                                                        \
+  hipLaunchKernelGGL((KERN_##NJ<PF>), groups * split, 256, lds, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)x, \
+                     w, b, (const bf16_t*)scale, ld_mod, rows_per_mod, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx,          \
+                     dscale, dshift, ld_dmod, dwb_partial, (const bf16_t*)gate_t, (const bf16_t*)gate, ld_gate,              \
                      (bf16_t*)dt, dgate, split, M, (int)D)
-  if (nj == 1) LAUNCH(1);
-  else LAUNCH(2);
+#define KERN_1 ln_mod_bwd_k
+#define KERN_2 ln_mod_bwd_wide_k
+  if (nj == 1 && pf) LAUNCH(1, true);
+  else if (nj == 1) LAUNCH(1, false);
+  else if (pf) LAUNCH(2, true);
+  else LAUNCH(2, false);
 #undef LAUNCH
+#undef KERN_1
+#undef KERN_2
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

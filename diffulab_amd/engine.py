@@ -342,6 +342,9 @@ class DiTEngine:
             w["demb16"] = z(Bp, E)
             w["dh1"] = z(Bp, E, dtype=f32)
             w["dpre1"] = z(Bp, E)
+            # [8 XCDs, M, N] f32 partial slabs of the wide-tile MLP weight-gradient GEMMs (dl_gemm_tn_ws): zero between launches
+            if os.environ.get("DL_GEMM_TN_WIDE") == "1":  # (opt-in experiment: the wide tiles measured slower)
+                w["tn_ws"] = z(8 * 2 * d.mlp_ratio * D * D, dtype=f32)
             w["scr_last"] = z(_rup(Fo, 8), D, dtype=f32)
             w["scr_conv"] = z(D, self._ki, dtype=f32)
         self.ws, self._ws_key = w, key
@@ -495,14 +498,17 @@ class DiTEngine:
 
         serial = os.environ.get("DL_WGRAD_SERIAL") == "1"  # A/B switch: weight gradients inline on the main stream
 
-        def wgrad(x_grad: Tensor, x_in: Tensor, gname: str) -> None:
+        tn_ws = w.get("tn_ws")
+
+        def wgrad(x_grad: Tensor, x_in: Tensor, gname: str, wide: bool = False) -> None:
+            ws = tn_ws if wide else None  # (one workspace: the MLP wgrads run one after the other on the side stream)
             if serial:
-                ops.gemm_tn(x_grad, x_in, self.G(gname))
+                ops.gemm_tn(x_grad, x_in, self.G(gname), ws=ws)
                 return
             ev = main.record_event()
             with torch.cuda.stream(side):
                 side.wait_event(ev)
-                ops.gemm_tn(x_grad, x_in, self.G(gname), max_wgs=side_wgs)
+                ops.gemm_tn(x_grad, x_in, self.G(gname), max_wgs=side_wgs, ws=ws)
 
         def fold_norm(partial: Tensor, gname: str) -> None:  # [B, 2, D] per-sample sums -> [w; b] gradients, off the chain
             ev = main.record_event()
@@ -518,11 +524,11 @@ class DiTEngine:
             pre = f"layers.{i}."
             mo = i * 6 * D
             # MLP branch
-            wgrad(g["dt2"], a["h"], pre + "mlp_input.2.weight")  # dt2 / dgate: produced by the LayerNorm backward before
+            wgrad(g["dt2"], a["h"], pre + "mlp_input.2.weight", wide=True)  # dt2 / dgate: produced by the LayerNorm backward before
             if not (fused_dswiglu and ops.gemm_nt_dswiglu(g["dt2"], sh[pre + "mlp_input.2.weight|t"], a["u"], g["du"])):
                 ops.gemm_nt(g["dt2"], sh[pre + "mlp_input.2.weight|t"], w["dh"])
                 ops.swiglu_bwd(w["dh"], a["u"], g["du"])
-            wgrad(g["du"], a["xm2"], pre + "mlp_input.0.weight")
+            wgrad(g["du"], a["xm2"], pre + "mlp_input.0.weight", wide=True)
             ops.gemm_nt(g["du"], sh[pre + "mlp_input.0.weight|t"], w["dxm"])
             ops.ln_modulate_bwd(w["dxm"], a["x1"], self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"),
                                 mod[:, mo + 3 * D : mo + 4 * D], N, a["mean2"], a["rstd2"], dx, dx_alt,

@@ -179,14 +179,20 @@ def _padded_rows(t: Tensor) -> Tensor:
     return t
 
 
-def gemm_tn(a: Tensor, b: Tensor, out: Tensor, *, M: int | None = None, N: int | None = None, max_wgs: int = 0) -> Tensor:
+def gemm_tn(a: Tensor, b: Tensor, out: Tensor, *, M: int | None = None, N: int | None = None, max_wgs: int = 0,
+            ws: Tensor | None = None) -> Tensor:
     """out[M,N] (f32) += a[R,M]^T @ b[R,N].  max_wgs > 0 caps the persistent workgroups (side-stream wgrads).  R must be a
-    multiple of 64: operands that are leading slices of zero-padded row buffers are widened to their parents."""
+    multiple of 64: operands that are leading slices of zero-padded row buffers are widened to their parents.
+    ws: zeroed f32 workspace of >= 8*M*N elements (left zero): enables the wide-tile kernel for the MLP weight shapes."""
     M = a.shape[1] if M is None else M
     N = b.shape[1] if N is None else N
     if a.shape[0] % 64:
         a, b = _padded_rows(a), _padded_rows(b)
         assert a.shape[0] == b.shape[0], "gemm_tn operands with a ragged row count must be zero-padded row buffers"
+    if ws is not None:
+        _call("dl_gemm_tn_ws", _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, a.shape[0], int(max_wgs),
+              _p(ws), ws.numel(), _s())
+        return out
     _call("dl_gemm_tn_ex", _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, a.shape[0], int(max_wgs), _s())
     return out
 

@@ -29,6 +29,8 @@ class GradReducer:
         self._pending: list[tuple[int, int]] = []
         self._extra: list = []
         self._works = []
+        self.measure = False  # bench: record how long the compute stream waits in finish() = the exposed part of the reduction
+        self.tail_events: list[tuple] = []
 
     # -- called by the engine's backward, ranges arrive high-to-low as blocks finish
     def ready(self, lo: int, hi: int, extra_events=()) -> None:
@@ -66,11 +68,28 @@ class GradReducer:
             self._pending.clear()
             return
         self._flush()
+        e0 = None
+        if self.measure and self.comm_stream is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self._works:
             w.wait()
         self._works.clear()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.tail_events.append((e0, e1))
+
+    def exposed_ms(self) -> float | None:
+        """mean time the compute stream spent waiting for the collectives in finish() over the measured steps"""
+        if not self.tail_events:
+            return None
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.tail_events) / len(self.tail_events)
+        self.tail_events.clear()
+        return ms
 
     @property
     def grad_scale(self) -> float:

@@ -130,6 +130,13 @@ DL_API int dl_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, fl
  * stream beside the main dependency chain leaves CUs free for that chain's latency-bound kernels */
 DL_API int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                          int64_t N, int64_t R, int max_workgroups, dl_stream_t stream);
+/* same with a caller-owned f32 workspace of >= 8*M*N elements, zero on first use and left zero on return: the wgrads of the MLP
+ * linears (nn.py:478-486 / mmdit.py:260-264: [8D, D] and [D, 4D] weights) run 256x384 / 384x256 tiles whose split-R partial
+ * sums meet in one slab per XCD (atomics stay inside one L2) and are folded into C by a second small kernel; other shapes, or
+ * workspace == NULL, behave exactly like dl_gemm_tn_ex */
+DL_API int dl_gemm_tn_ws(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                         int64_t N, int64_t R, int max_workgroups, float* workspace, int64_t workspace_elems,
+                         dl_stream_t stream);
 
 /* ------------------------------------------------------------------ adaLN / norms */
 /* modulate(LayerNorm(x)) mmdit.py:299,305,547 + nn.py:539:  out = (LN(x) * w + b) * (1 + scale) + shift.

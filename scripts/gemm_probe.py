@@ -32,7 +32,7 @@ def timeit(fn):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-NAMES = {0: "full", 1: "-stores", 2: "-mfma", 4: "-dma", 8: "-ldsread", 5: "-stores-dma", 10: "-mfma-ldsread", 16: "+pf", 17: "+pf-stores", 26: "+pf-mfma-ldsread"}
+NAMES = {0: "full", 1: "-stores", 2: "-mfma", 4: "-dma", 8: "-ldsread", 5: "-stores-dma", 10: "-mfma-ldsread", 16: "+pf", 17: "+pf-stores", 26: "+pf-mfma-ldsread", 32: "xcd-slabs"}
 for name, N, K in [][:0] or [("qkv", 1152, 384), ("d_h", 1536, 384), ("d_xm2", 384, 3072), ("d_xm1", 384, 1152), ("d_a", 384, 384)]:
     a, b = rnd(M, K), rnd(N, K)
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
@@ -42,12 +42,13 @@ for name, N, K in [][:0] or [("qkv", 1152, 384), ("d_h", 1536, 384), ("d_xm2", 3
         row.append(f"{NAMES[fl]} {timeit(lambda: ops.gemm_nt(a, b, out)):7.1f}")
     L.call("dl_probe_gemm_set", 0)
     print(f"nt {name:6s} N={N:5d} K={K:5d} us: " + " | ".join(row), flush=True)
-for name, Mo, No in [("w_qkv", 1152, 384), ("w_proj", 384, 384), ("w_mlp1", 3072, 384), ("w_mlp2", 384, 1536)]:
+for name, Mo, No in [("w_mlp1", 3072, 384), ("w_mlp2", 384, 1536)]:
     a, b = rnd(M, Mo), rnd(M, No)
     c = torch.zeros(Mo, No, device=dev)
+    ws = torch.zeros(8 * Mo * No, device=dev)
     row = []
-    for fl in (0, 1, 10, 16, 17, 26):
+    for fl, nm in ((0, "wide full"), (2, "wide -fold"), (3, "wide -fold-atomics")):
         L.call("dl_probe_gemm_set", fl)
-        row.append(f"{NAMES[fl]} {timeit(lambda: ops.gemm_tn(a, b, c)):7.1f}")
+        row.append(f"{nm} {timeit(lambda: ops.gemm_tn(a, b, c, ws=ws)):7.1f}")
     L.call("dl_probe_gemm_set", 0)
     print(f"tn {name:6s} M={Mo:5d} N={No:5d} us: " + " | ".join(row), flush=True)
