@@ -226,6 +226,17 @@ DL_API int dl_attn_fwd_ex(const void* q, const void* k, const void* v, void* out
 DL_API int dl_attn_bwd_ex(const void* q, const void* k, const void* v, const void* out, const void* dout,
                           const float* lse, void* dq, void* dk, void* dv, int64_t B, int64_t H, int64_t Nq, int64_t Nk,
                           int64_t dh, float scale, const float* key_bias, dl_stream_t stream);
+/* fp8 (OCP e4m3) forward of the general form for the long joint text-image sequences (BASELINE config 5; mmdit.py:172-190) on the
+ * CDNA4 block-scaled matrix instruction v_mfma_scale_f32_32x32x64_f8f6f4 (one MFMA contracts a whole 64-wide head dimension).
+ * dl_attn_fp8_quantize: q [B,H,Nq,64], k, v [B,H,Nk,64] bf16 -> q8, k8 (same row layout, 1 byte per element), v8t [B,H,64,Nk]
+ * (V transposed, the keys of every 64-key block in the order the kernel's P registers hold them) and scales f32 [B,H,3]
+ * (amax / 448 of q, k, v per head).  dl_attn_fwd_fp8: same outputs as dl_attn_fwd_ex (out bf16 [B,Nq,H*64], lse f32 [B,H,Nq]);
+ * Nq, Nk multiples of 256 up to 4096; key_bias as in dl_attn_fwd_ex.  The backward stays dl_attn_bwd_ex on the bf16 tensors. */
+DL_API int dl_attn_fp8_quantize(const void* q, const void* k, const void* v, void* q8, void* k8, void* v8t, float* scales,
+                                int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t dh, dl_stream_t stream);
+DL_API int dl_attn_fwd_fp8(const void* q8, const void* k8, const void* v8t, const float* scales, void* out, float* lse,
+                           int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t dh, float scale, const float* key_bias,
+                           dl_stream_t stream);
 /* the N <= 256 kernels with V (and dV) addressed in place: head (b, h) of V starts at element b*v_batch_stride +
  * h*v_head_stride of `v`, its rows are v_pitch elements apart.  With v = qkv + 2*D, strides {N*3D, 64, 3D} the attention
  * reads the v third of the token-major qkv rows [B*N, 3D] (the reference's `qkv.chunk(3)`, mmdit.py:85-93) and the backward
@@ -422,6 +433,9 @@ DL_API int dl_copy2d_bf16(const void* src, int64_t lds, void* dst, int64_t ldd, 
 /* raw ds_read_b64_tr_b16 lane map: fills out[64*4] with what each lane receives when lane l passes
  * address 8*l over an LDS image holding the uint16 values 0..255 */
 DL_API int dl_probe_tr16(uint16_t* out, dl_stream_t stream);
+/* D f32 [32,32] = A[32,64] . B[32,64]^T for e4m3 bytes, through one v_mfma_scale_f32_32x32x64_f8f6f4 with the operand layout
+ * attention_fp8.hip relies on (lane l: row l & 31, bytes [32 (l >> 5), +32)); pins the instruction's semantics */
+DL_API int dl_probe_mfma_f8(const void* a, const void* b, float* d, dl_stream_t stream);
 /* sustained MFMA 32x32x16 bf16 rate of the GEMM main-loop skeleton on 256 workgroups x 8 waves, `iters` k-steps of
  * 24 MFMAs per wave: mode 0 MFMA only, 1 + LDS fragment reads, 2 + one workgroup barrier per k-step, 3 + the 56 KiB
  * direct-to-LDS DMA per k-step from `src` (>= 256*57344 bytes).  out: f32 [256*512] (sink).

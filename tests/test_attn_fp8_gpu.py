@@ -1,0 +1,122 @@
+"""fp8 (e4m3) MFMA attention forward for the long joint sequences (BASELINE config 5; mmdit.py:172-190): semantics of the CDNA4
+block-scaled matrix instruction, the quantisation pre-pass, and the kernel against an fp64 softmax attention on the same bf16
+inputs.  Tolerance: e4m3 keeps 3 mantissa bits, so per-element products carry ~3 % noise that averages over 64-wide dot products and
+hundreds of keys.  Stated tolerance: 6e-2 relative L2 of the attention output on WHITE-NOISE q, k, v (measured 5.3e-2: the worst
+case -- the output is then an average of ~N independent values and every quantisation error is as large as the signal's own spread),
+1e-1 on peaked attention patterns (scores with 3x the spread: the ~4 % rms error of an e4m3 dot product is multiplied by the score
+scale before the exponential; measured 8.1e-2), lse within 6e-2 / 0.5 absolute; through the joint MMDiT (reference fixture) the prediction moves by less than
+3e-2 and the loss by less than 1e-2 against the bf16 path."""
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def test_mfma_scale_f8_operand_layout_probe():
+    from diffulab_amd._lib import lib
+
+    g = torch.Generator().manual_seed(0)
+    vals = torch.tensor([-4.0, -2.0, -1.5, -1.0, -0.5, 0.0, 0.5, 1.0, 1.5, 2.0, 3.0])
+    a = vals[torch.randint(0, len(vals), (32, 64), generator=g)]
+    b = vals[torch.randint(0, len(vals), (32, 64), generator=g)]
+    a8, b8 = a.to(torch.float8_e4m3fn).to(DEV), b.to(torch.float8_e4m3fn).to(DEV)
+    d = torch.empty(32, 32, device=DEV)
+    lib().call("dl_probe_mfma_f8", a8.data_ptr(), b8.data_ptr(), d.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(d.cpu(), a @ b.T)  # exact: every product and partial sum is representable
+
+
+def _inputs(B, H, Nq, Nk, seed):
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda n: (torch.randn(B, H, n, 64, generator=g)).to(torch.bfloat16).to(DEV)  # noqa: E731
+    return mk(Nq), mk(Nk), mk(Nk)
+
+
+def test_quantize_layouts_and_scales():
+    from diffulab_amd import ops
+
+    B, H, N = 2, 3, 256
+    q, k, v = _inputs(B, H, N, N, 1)
+    v = v * 3.0
+    q8, k8 = (torch.empty(B, H, N, 64, device=DEV, dtype=torch.uint8) for _ in range(2))
+    v8t = torch.empty(B, H, 64, N, device=DEV, dtype=torch.uint8)
+    sc = torch.empty(B, H, 3, device=DEV)
+    ops.attn_fp8_quantize(q, k, v, q8, k8, v8t, sc, B, H, N, N)
+    torch.cuda.synchronize()
+    for i, t in enumerate((q, k, v)):
+        amax = t.float().abs().amax(dim=(2, 3))
+        assert torch.allclose(sc[:, :, i], amax / 448.0, rtol=1e-6)
+    deq = lambda t8, s: t8.view(torch.float8_e4m3fn).float() * s[:, :, None, None]  # noqa: E731
+    assert rel(deq(q8, sc[:, :, 0]), q.float()) < 4e-2 and rel(deq(k8, sc[:, :, 1]), k.float()) < 4e-2
+    # v8t[b, h, c, blk*64 + p] = V[blk*64 + key(p), c]:  p = 32 hi + 16 t + r  <->  key = 32 t + (r & 3) + 8 (r >> 2) + 4 hi
+    p = torch.arange(64)
+    hi, t, r = p // 32, (p // 16) % 2, p % 16
+    key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi
+    perm = (torch.arange(N // 64)[:, None] * 64 + key[None, :]).flatten().to(DEV)
+    want = v.float().transpose(2, 3)[:, :, :, perm]
+    assert rel(deq(v8t, sc[:, :, 2]), want) < 4e-2
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 256, 512, False, 1.0), (2, 12, 1280, 1280, True, 1.0), (1, 2, 512, 256, True, 1.0),
+                                   (2, 4, 512, 512, True, 3.0)])
+def test_fp8_attention_forward_against_fp64_softmax(shape):
+    from diffulab_amd import ops
+
+    B, H, Nq, Nk, masked, sharp = shape
+    q, k, v = _inputs(B, H, Nq, Nk, 7)
+    q = (q.float() * sharp).to(torch.bfloat16)  # sharp > 1: peaked attention (a few keys carry each query)
+    bias = None
+    if masked:  # key-padding mask of the joint sequence: a ragged number of valid keys per sample
+        valid = torch.tensor([Nk - 37 * (i + 1) for i in range(B)])
+        bias = torch.where(torch.arange(Nk)[None, :] < valid[:, None], 0.0, float("-inf")).to(DEV)
+    scale = 64**-0.5
+    s = torch.einsum("bhqd,bhkd->bhqk", q.double(), k.double()) * scale
+    if bias is not None:
+        s = s + bias[:, None, None, :].double()
+    ref = torch.einsum("bhqk,bhkd->bhqd", torch.softmax(s, -1), v.double()).transpose(1, 2).reshape(B, Nq, H * 64)
+    ref_lse = torch.logsumexp(s, -1)
+    q8, k8 = torch.empty(B, H, Nq, 64, device=DEV, dtype=torch.uint8), torch.empty(B, H, Nk, 64, device=DEV, dtype=torch.uint8)
+    v8t, sc = torch.empty(B, H, 64, Nk, device=DEV, dtype=torch.uint8), torch.empty(B, H, 3, device=DEV)
+    out, lse = torch.empty(B, Nq, H * 64, device=DEV, dtype=torch.bfloat16), torch.empty(B, H, Nq, device=DEV)
+    ops.attn_fp8_quantize(q, k, v, q8, k8, v8t, sc, B, H, Nq, Nk)
+    ops.attn_fwd_fp8(q8, k8, v8t, sc, out, lse, B, H, Nq, Nk, 64, scale, bias)
+    out16, lse16 = torch.empty_like(out), torch.empty_like(lse)
+    ops.attn_fwd_ex(q, k, v, out16, lse16, B, H, Nq, Nk, 64, scale, bias)
+    torch.cuda.synchronize()
+    e8, e16 = rel(out.float(), ref), rel(out16.float(), ref)
+    print(f"fp8 attention {shape}: rel-L2 {e8:.3e} (bf16 kernel {e16:.3e}); max |lse - ref| {float((lse.double() - ref_lse).abs().max()):.3e}")
+    assert e8 < (6e-2 if sharp == 1.0 else 1e-1)
+    assert float((lse.double() - ref_lse).abs().max()) < (6e-2 if sharp == 1.0 else 0.5)
+    assert bool(torch.isfinite(out.float()).all())
+
+
+def test_joint_mmdit_with_fp8_attention_stays_close_to_the_bf16_path(monkeypatch, golden):
+    """the joint text-image MMDiT (reference fixture mmdit_joint: ragged key-padding mask) with DIFFULAB_FP8_ATTENTION=1: forward in
+    fp8, backward in bf16 with the fp8 forward's lse.  Against the REFERENCE's prediction and gradients at the fp8 tolerances."""
+    import test_mmdit_joint_gpu as tj
+
+    g = {k: torch.as_tensor(v) for k, v in golden("mmdit_joint").items()}
+    x, t, ctx, keep, dy = tj._inputs()
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DIFFULAB_FP8_ATTENTION", mode)
+        m = tj._model()
+        m.train()
+        pred = m(x=x.to(DEV), timesteps=t.to(DEV), initial_context={"embeddings": ctx.to(DEV), "attn_mask": keep.to(DEV)}, p=0.0)["x"]
+        (pred * dy.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        res[mode] = (pred.detach().float().cpu(), {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()})
+    e_pred8, e_pred16 = rel(res["1"][0], g["a_pred"]), rel(res["0"][0], g["a_pred"])
+    errs = sorted(rel(res["1"][1][n], g["a_g_" + n]) for n in res["1"][1] if "a_g_" + n in g)
+    print(f"joint MMDiT prediction vs reference: fp8 attention {e_pred8:.3e}, bf16 {e_pred16:.3e}; gradient rel-L2 with fp8 attention: "
+          f"median {errs[len(errs) // 2]:.3e}, max {errs[-1]:.3e}")
+    assert e_pred8 < 3e-2 and errs[len(errs) // 2] < 6e-2 and errs[-1] < 0.2
+    assert not torch.equal(res["0"][0], res["1"][0])  # the switch really changed the attention kernel
