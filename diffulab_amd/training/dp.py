@@ -12,16 +12,27 @@ micro-step reduces (`no_sync` otherwise).
 
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 from torch import Tensor
 
 
 class GradReducer:
-    def __init__(self, flat_grad: Tensor, bucket_bytes: int = 48 << 20, group=None) -> None:
+    def __init__(self, flat_grad: Tensor, bucket_bytes: int = 48 << 20, group=None, backend: str | None = None, comm=None) -> None:
+        """backend "torch" (default): torch.distributed collectives (backend nccl = RCCL);  "abi" (or DIFFULAB_DP_BACKEND=abi):
+        the same exchange through libdiffulab_comm.so (include/diffulab_comm.h: dl_reduce_scatter_allgather_async on the
+        library's own communicator and comm stream), for hosts that drive the C ABI without torch.distributed"""
         self.flat = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.backend = backend or os.environ.get("DIFFULAB_DP_BACKEND", "torch")
+        self.comm = comm
+        if self.backend == "abi" and self.comm is None and flat_grad.is_cuda and (self.world > 1 or comm is not None):
+            from .._comm import Communicator
+
+            self.comm = Communicator(dist.get_rank(group), self.world, flat_grad.device.index)
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.enabled = self.world > 1
         self.sync = True  # False inside a gradient-accumulation micro-step (no_sync)
@@ -50,6 +61,12 @@ class GradReducer:
         assert sum(h - l for l, h in self._pending) == hi - lo, "gradient ranges of one bucket must be contiguous"
         self._pending.clear()
         chunk = self.flat[lo:hi]
+        if self.comm is not None:  # C-ABI path: the library owns the comm stream and the ordering events
+            for e in self._extra:
+                self.comm.after_event(e.cuda_event)
+            self._extra.clear()
+            self.comm.all_reduce_async(chunk.data_ptr(), chunk.numel(), torch.cuda.current_stream().cuda_stream)
+            return
         if self.comm_stream is not None:
             ev = torch.cuda.Event()
             ev.record()  # everything that produced this range is on the compute stream before this point
@@ -68,6 +85,9 @@ class GradReducer:
             self._pending.clear()
             return
         self._flush()
+        if self.comm is not None:
+            self.comm.wait(torch.cuda.current_stream().cuda_stream)
+            return
         e0 = None
         if self.measure and self.comm_stream is not None:
             e0 = torch.cuda.Event(enable_timing=True)

@@ -48,3 +48,17 @@ def test_no_product_module_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
+
+
+def test_comm_library_exports_every_symbol_of_its_header():
+    """include/diffulab_comm.h (dl_comm_*, dl_reduce_scatter_allgather_async): the RCCL communicator library loads and exports
+    every declared entry point (no collective is issued here)"""
+    from diffulab_amd import _comm
+
+    text = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "diffulab_comm.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(dl_[a-z0-9_]+)\s*\(", text))
+    assert {"dl_comm_init", "dl_comm_destroy", "dl_reduce_scatter_allgather_async", "dl_comm_wait", "dl_comm_unique_id"} <= declared
+    cdll = ctypes.CDLL(_comm.LIB_PATH)
+    for name in declared:
+        assert hasattr(cdll, name), name
+    assert _comm.lib().dl_comm_rank(None) == -1

@@ -206,6 +206,38 @@ def test_grad_reducer_on_rccl_single_rank():
             dist.destroy_process_group()
 
 
+def test_grad_reducer_through_the_comm_c_abi_single_rank():
+    """the same backward with the exchange going through libdiffulab_comm.so (dl_comm_init / dl_reduce_scatter_allgather_async /
+    dl_comm_after_event / dl_comm_wait on the library's own RCCL communicator and stream; 1 rank: the sum leaves the data as it is):
+    gradients equal the plain run and the compute stream really waited for the collectives"""
+    from diffulab_amd import Diffuser
+    from diffulab_amd._comm import Communicator
+    from diffulab_amd.training.dp import GradReducer
+
+    B = 8
+    x0 = synth.normal("ca.x0", (B, 4, 16, 16)).to(DEV)
+    noise = synth.normal("ca.noise", (B, 4, 16, 16)).to(DEV)
+    y = synth.integers("ca.y", (B,), 10).to(DEV)
+    t = synth.uniform("ca.t", (B,), lo=0.05, hi=0.95)
+    ma, mb = small_dit(), small_dit()
+    comm = Communicator(rank=0, world=1, device=0)
+    try:
+        mb.engine  # flatten
+        comm.broadcast_async(mb._flat.data_ptr(), mb._flat.numel(), 0, torch.cuda.current_stream().cuda_stream)
+        comm.wait(torch.cuda.current_stream().cuda_stream)
+        red = GradReducer(mb._flat_grad, bucket_bytes=1 << 18, backend="abi", comm=comm)
+        red.enabled = True  # world == 1 would switch it off
+        mb.engine.reducer = red
+        for m in (ma, mb):
+            d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=4)
+            d.compute_loss({"x": x0.clone(), "y": y, "p": 0.0}, timesteps=t, noise=noise)["loss"].backward()
+        torch.cuda.synchronize()
+        assert not red._pending and rel(mb._flat_grad, ma._flat_grad) < 1e-4 and torch.equal(mb._flat, ma._flat)
+    finally:
+        mb.engine.reducer = None
+        comm.close()
+
+
 class _RangeRecorder:
     """stands in for training.dp.GradReducer: records the gradient-arena ranges an engine's backward declares final"""
 
