@@ -52,6 +52,14 @@ if which in ("nt", "all", "swiglu"):
     print(f"nt mlp1+swiglu (U and H stored)      : {us:8.1f} us  {2.0*M*3072*384/us/1e6:7.1f} TF/s")
     us = timeit(lambda: ops.gemm_nt_swiglu(a, wp, None, h))
     print(f"nt mlp1+swiglu (H only, inference)   : {us:8.1f} us  {2.0*M*3072*384/us/1e6:7.1f} TF/s")
+if which in ("nt", "all", "swiglu"):
+    dt2, w2t = rnd(M, 384), rnd(1536, 384)
+    uu, du = rnd(M, 3072), torch.empty(M, 3072, device=dev, dtype=torch.bfloat16)
+    dh = torch.empty(M, 1536, device=dev, dtype=torch.bfloat16)
+    us_f = timeit(lambda: ops.gemm_nt_dswiglu(dt2, w2t, uu, du))
+    us_g = timeit(lambda: ops.gemm_nt(dt2, w2t, dh))
+    us_s = timeit(lambda: ops.swiglu_bwd(dh, uu, du))
+    print(f"nt d_h + swiglu_bwd fused epilogue   : {us_f:8.1f} us   (separate: gemm {us_g:.1f} + swiglu_bwd {us_s:.1f} = {us_g + us_s:.1f} us)")
 if which in ("tn", "all"):
     for name, Mo, No in [("w_qkv", 1152, 384), ("w_proj", 384, 384), ("w_mlp1", 3072, 384), ("w_mlp2", 384, 1536)]:
         a, b = rnd(M, Mo), rnd(M, No)

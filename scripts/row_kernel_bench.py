@@ -48,3 +48,16 @@ print(f"ln_mod_bwd plain          : {us:7.1f} us  {4 * M * D * 2 / us / 1e6:5.2f
 us = timeit(lambda: ops.ln_modulate_bwd(dout, x, w, b, mod[:, :D], N, mean, rstd, dres, dx, dmod[:, :D], dmod[:, D:2 * D], dwb,
                                         gate_t=t, gate=mod[:, 2 * D:3 * D], dt=dt, dgate=dmod[:, 2 * D:3 * D]))
 print(f"ln_mod_bwd + gate bwd     : {us:7.1f} us  {6 * M * D * 2 / us / 1e6:5.2f} TB/s")
+
+# QK-RMSNorm + RoPE + head split, forward and backward (V in place: only the q and k thirds move)
+H, dh = D // 64, 64
+qkv = torch.randn(M, 3 * D, device=dev).to(bf)
+sq, sk = torch.ones(D, device=dev), torch.ones(D, device=dev)
+cs, sn = torch.rand(N, dh // 2, device=dev), torch.rand(N, dh // 2, device=dev)
+q, k = torch.empty(B, H, N, dh, device=dev, dtype=bf), torch.empty(B, H, N, dh, device=dev, dtype=bf)
+rr = torch.empty(M, 2, device=dev)
+us = timeit(lambda: ops.qk_norm_rope_fwd(qkv, sq, sk, cs, sn, q, k, None, rr, B, N, H, dh, dh))
+print(f"qk_norm_rope_fwd (V in place): {us:7.1f} us  {4 * M * D * 2 / us / 1e6:5.2f} TB/s")
+dq, dk, dqkv, dsc = torch.randn_like(q), torch.randn_like(k), torch.empty_like(qkv), torch.zeros(2, D, device=dev)
+us = timeit(lambda: ops.qk_norm_rope_bwd(dq, dk, None, qkv, sq, sk, cs, sn, rr, dqkv, dsc, B, N, H, dh, dh))
+print(f"qk_norm_rope_bwd (V in place): {us:7.1f} us  {6 * M * D * 2 / us / 1e6:5.2f} TB/s")
