@@ -427,6 +427,32 @@ extern "C" int dl_adamw_step(float* p, const float* g, float* m, float* v, int64
   return DL_OK;
 }
 
+// same update with the scalars read from device memory (hyper = {lr, beta1, beta2, eps, weight_decay, lr / bias_corr1,
+// 1 / sqrt(bias_corr2), grad_scale}): the launch carries no per-step value, so a captured hipGraph of the training step can be
+// replayed while the host refreshes the 32 bytes before each replay (training/graph_step.py)
+__global__ void adamw_dev_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            int64_t n, const float* __restrict__ hyper) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], inv_bc1_lr = hyper[5],
+              inv_sqrt_bc2 = hyper[6], gs = hyper[7];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gr = g[i] * gs;
+    float pj = p[i] * (1.0f - lr * wd);
+    const float mj = b1 * m[i] + (1.0f - b1) * gr;
+    const float vj = b2 * v[i] + (1.0f - b2) * gr * gr;
+    pj -= inv_bc1_lr * (mj / (sqrtf(vj) * inv_sqrt_bc2 + eps));
+    p[i] = pj;
+    m[i] = mj;
+    v[i] = vj;
+  }
+}
+extern "C" int dl_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, dl_stream_t stream) {
+  DL_CHECK_ARG(p && g && m && v && hyper && n > 0, "dl_adamw_step_dev: bad args");
+  hipLaunchKernelGGL(adamw_dev_k, ew_grid(n), 256, 0, (hipStream_t)stream, p, g, m, v, n, hyper);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
 __global__ void ema_k(float* __restrict__ ema, const float* __restrict__ p, float w, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {

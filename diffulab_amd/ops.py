@@ -433,6 +433,11 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
           float(wd), float(1.0 - beta1**step), float(1.0 - beta2**step), float(grad_scale), _s())
 
 
+def adamw_step_dev(p, g, m, v, hyper):
+    """AdamW with the scalars read from the device buffer `hyper` f32 [8] (graph-replayable launch)"""
+    _call("dl_adamw_step_dev", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _s())
+
+
 def cast_weight(src, dst, dst_t):
     R, C = src.shape
     _call("dl_cast_weight", _p(src), R, C, _p(dst), dst.stride(0) if dst is not None else 0, _p(dst_t),

@@ -40,6 +40,32 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = 1.0  # data parallel: 1/world (gradients are SUM-reduced), folded into the update kernel
         self._legacy_arena_state: dict | None = None
+        self._graph_hyper: list[tuple[Tensor, Tensor]] | None = None  # per group: (device f32[8], pinned host mirror)
+
+    # ---- hipGraph support (training/graph_step.py): inside a captured step the update kernels read their scalars from a device
+    #      buffer; the host advances the step count and refreshes that buffer BEFORE each replay
+    def begin_graph_mode(self) -> None:
+        dev = next(p for g in self.param_groups for p in g["params"]).device
+        self._graph_hyper = [(torch.zeros(8, device=dev), torch.zeros(8).pin_memory()) for _ in self.param_groups]
+        self._graph_step = max([int(st["step"]) for st in self.state.values() if "step" in st] or [0])
+
+    def end_graph_mode(self) -> None:
+        self._graph_hyper = None
+
+    def advance(self) -> None:
+        """one optimizer step is about to be replayed: bump the step count everywhere and upload the hyper-parameters"""
+        assert self._graph_hyper is not None
+        self._graph_step += 1
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] = self._graph_step
+        for group, (dev, host) in zip(self.param_groups, self._graph_hyper):
+            b1, b2 = group["betas"]
+            bc1, bc2 = 1.0 - b1**self._graph_step, 1.0 - b2**self._graph_step
+            host.copy_(torch.tensor([group["lr"], b1, b2, group["eps"], group["weight_decay"], group["lr"] / bc1, bc2**-0.5,
+                                     self.grad_scale], dtype=torch.float32))
+            dev.copy_(host, non_blocking=True)
+        bump_param_epoch()
 
     @staticmethod
     def _arena_key(group, rest: list) -> Tensor:
@@ -90,8 +116,21 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
+            if self._graph_hyper is not None:  # captured step: scalars come from the device buffer, state must already exist
+                hyper = self._graph_hyper[gi][0]
+                flat = self._flat(group)
+                rest = group["params"]
+                if flat is not None:
+                    pb, gb, rest = flat
+                    st = self.state[self._arena_key(group, rest)]
+                    ops.adamw_step_dev(pb, gb, st["m"], st["v"], hyper)
+                for p in rest:
+                    if p.grad is not None:
+                        st = self.state[p]
+                        ops.adamw_step_dev(p.data, p.grad, st["m"], st["v"], hyper)
+                continue
             flat = self._flat(group)
             rest = group["params"]
             if flat is not None:

@@ -330,6 +330,10 @@ DL_API int dl_gated_residual_fwd(const void* x, const void* t, const void* gate,
 DL_API int dl_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                          float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
                          float grad_scale, dl_stream_t stream);
+/* the same update with its eight scalars in device memory: hyper = {lr, beta1, beta2, eps, weight_decay, lr / bias_corr1,
+ * 1 / sqrt(bias_corr2), grad_scale}.  No per-step value travels in the launch, so a captured hipGraph of the whole training step
+ * (base_trainer.py:138-151: zero_grad -> loss -> backward -> optimizer.step) replays with the host refreshing 32 bytes */
+DL_API int dl_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, dl_stream_t stream);
 /* bf16 shadow of an f32 [R,C] weight: dst [R, ld_dst] (cols >= C zeroed up to ld_dst) and/or the transpose
  * dstT [C, ld_t] (cols >= R zeroed up to ld_t).  Either destination may be NULL. */
 DL_API int dl_cast_weight(const float* src, int64_t R, int64_t C, void* dst, int64_t ld_dst, void* dstT,

@@ -59,6 +59,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--graph", action="store_true", help="the whole step as one hipGraph (training/graph_step.py)")
     a = ap.parse_args()
     dev = "cuda"
     kw, shape = CFG[a.config]
@@ -102,6 +103,16 @@ def main() -> None:
         sum(losses.values()).backward()
         opt.step()
 
+    if a.graph:
+        from diffulab_amd.training.graph_step import GraphedTrainStep
+
+        gs = GraphedTrainStep(d, opt, warmup=3)
+
+        def step():  # noqa: F811
+            t = d.draw_timesteps(a.batch).to(dev, non_blocking=True)
+            inputs = {"x": x0, "initial_context": ctx, "p": p} if ctx is not None else {"x": x0, "y": y, "p": p}
+            gs(inputs, t, {"dst_features": dst} if dst is not None else {})
+
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
@@ -111,7 +122,7 @@ def main() -> None:
     t_issue = (time.perf_counter() - t0) / a.steps  # host time to issue a step (the GPU runs behind it): == ms_per_step when launch-bound
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-    print(json.dumps({"config": a.config, "batch": a.batch, "ms_per_step": round(dt * 1e3, 3), "images_per_s": round(a.batch / dt, 1),
+    print(json.dumps({"config": a.config, "batch": a.batch, "graph": bool(a.graph and any(v not in (None, False) for v in gs._graphs.values())) if a.graph else False, "ms_per_step": round(dt * 1e3, 3), "images_per_s": round(a.batch / dt, 1),
                       "host_issue_ms_per_step": round(t_issue * 1e3, 3),
                       "params_M": round(sum(q.numel() for q in m.parameters()) / 1e6, 1)}))
 
