@@ -184,6 +184,7 @@ class DiTEngine:
         assert params.dtype == torch.float32 and params.numel() == self.layout.size and params.is_cuda
         self.params, self.grads = params, grads
         self._shadow_key = None
+        self._blk_cache: dict[tuple, object] = {}
         self._pviews: dict[str, Tensor] = {}
         self._gviews: dict[str, Tensor] = {}
 
@@ -374,6 +375,73 @@ class DiTEngine:
         ops.gemm_nt(w["se"], sh["@mod|f"], w["mod"], bias=mod_bias, M=B, N=self.layout.mod_rows, K=E)
         return w["mod"]
 
+    # ------------------------------------------------------------------ native block driver (csrc/block.hip)
+    def _native_blocks(self) -> bool:
+        """one C call per block and direction (dl_dit_block_fwd / _bwd) instead of ~25 launches from Python; DL_NATIVE_BLOCK=0 is the
+        A/B switch back to the Python-issued sequence (identical kernels, identical order)"""
+        return type(self) is DiTEngine and os.environ.get("DL_NATIVE_BLOCK", "1") != "0"
+
+    def _block_args(self, i: int, train: bool):
+        """the dl_dit_block_t of block i on the current workspace (cached: every pointer is fixed once arena and workspace exist)"""
+        key = (self._ws_key, i)
+        blk = self._blk_cache.get(key)
+        if blk is not None:
+            return blk
+        from ._block import DitBlock
+
+        d, w, sh = self.d, self.ws, self.sh
+        B, _, _, gh, gw, N, M, Bp, Fo = self.geo
+        D, L, F = d.inner_dim, d.depth, d.mlp_ratio * d.inner_dim
+        pre, mo = f"layers.{i}.", i * 6 * D
+        mod, xs = w["mod"], w["x"]
+        a = w["layers"][i if train else 0]
+        xin = xs[i] if train else xs[i & 1]
+        cos, sin = self._rope[(gh, gw)]
+        mrow = lambda off: mod.data_ptr() + 2 * off  # noqa: E731  (row view mod[:, off:]: bf16)
+        blk = DitBlock()
+        blk.B, blk.N, blk.D, blk.H, blk.F = B, N, D, d.num_heads, F
+        blk.ld_mod = mod.stride(0)
+        blk.ldw_d, blk.ldw_f = sh[pre + "attention.qkv.weight|f"].stride(0), sh[pre + "mlp_input.2.weight|f"].stride(0)
+        blk.ldwt_d, blk.ldwt_f2 = sh[pre + "attention.proj_out.weight|t"].stride(0), sh[pre + "mlp_input.0.weight|t"].stride(0)
+        blk.ldwt_3d = sh[pre + "attention.qkv.weight|t"].stride(0)
+        blk.rot, blk.eps = sum(d.rope_axes_dim), 1e-5
+        prev = None
+        if i > 0:
+            ap = w["layers"][(i - 1) if train else 0]
+            prev = (ap["x1"], ap["t2"], mrow((i - 1) * 6 * D + 5 * D))
+        blk.set(x_in=xin, pend_x=prev[0] if prev else None, pend_t=prev[1] if prev else None, pend_gate=prev[2] if prev else None,
+                scale1=mrow(mo), shift1=mrow(mo + D), gate1=mrow(mo + 2 * D), scale2=mrow(mo + 3 * D), shift2=mrow(mo + 4 * D),
+                gate2=mrow(mo + 5 * D),
+                ln1_w=self.P(pre + "norm_1.weight"), ln1_b=self.P(pre + "norm_1.bias"), ln2_w=self.P(pre + "norm_2.weight"),
+                ln2_b=self.P(pre + "norm_2.bias"), qn_scale=self.P(pre + "attention.qk_norm.query_norm.scale"),
+                kn_scale=self.P(pre + "attention.qk_norm.key_norm.scale"),
+                w_qkv=sh[pre + "attention.qkv.weight|f"], w_proj=sh[pre + "attention.proj_out.weight|f"],
+                w_up=sh[pre + "mlp_input.0.weight|f"], w_up_perm=sh[pre + "mlp_input.0.weight|g"], w_down=sh[pre + "mlp_input.2.weight|f"],
+                wt_qkv=sh[pre + "attention.qkv.weight|t"], wt_proj=sh[pre + "attention.proj_out.weight|t"],
+                wt_up=sh[pre + "mlp_input.0.weight|t"], wt_down=sh[pre + "mlp_input.2.weight|t"], rope_cos=cos, rope_sin=sin,
+                xm1=a["xm1"], mean1=a["mean1"], rstd1=a["rstd1"], qkv=a["qkv"], q=a["q"], k=a["k"], v=a["v"], rrms=a["rrms"], a=a["a"],
+                lse=a["lse"], t1=a["t1"], x1=a["x1"], xm2=a["xm2"], mean2=a["mean2"], rstd2=a["rstd2"], u=a["u"], h=a["h"], t2=a["t2"])
+        if train and self.grads is not None:
+            g, dmod = w["wg"][i], w["dmod32"]
+            blk.ld_dmod = dmod.stride(0)
+            drow = lambda off: dmod.data_ptr() + 4 * off  # noqa: E731
+            pg = None
+            if i > 0:
+                mp = (i - 1) * 6 * D
+                pg = (w["layers"][i - 1]["t2"], mrow(mp + 5 * D), w["wg"][i - 1]["dt2"], drow(mp + 5 * D))
+            blk.set(dt2=g["dt2"], dx_in=w["dxa"], dx_mid=w["dxb"], dx_out=w["dxa"], dh=w["dh"], du=g["du"], dxm=w["dxm"], dt1=g["dt1"],
+                    da=w["da"], dq=w["dq"], dk=w["dk"], dv=w["dv"], dqkv=g["dqkv"], dfeat=None,
+                    dscale1=drow(mo), dshift1=drow(mo + D), dgate1=drow(mo + 2 * D), dscale2=drow(mo + 3 * D), dshift2=drow(mo + 4 * D),
+                    dwb1=w["dwb"][2 * i], dwb2=w["dwb"][2 * i + 1],
+                    prev_t2=pg[0] if pg else None, prev_gate2=pg[1] if pg else None, prev_dt2=pg[2] if pg else None,
+                    prev_dgate2=pg[3] if pg else None,
+                    g_qkv=self.G(pre + "attention.qkv.weight"), g_proj=self.G(pre + "attention.proj_out.weight"),
+                    g_up=self.G(pre + "mlp_input.0.weight"), g_down=self.G(pre + "mlp_input.2.weight"),
+                    g_ln1=self.G(pre + "norm_1.weight"), g_ln2=self.G(pre + "norm_2.weight"),
+                    g_qk_scale=self.G(pre + "attention.qk_norm.query_norm.scale"))
+        self._blk_cache[key] = blk
+        return blk
+
     # ------------------------------------------------------------------ forward
     def forward(self, x: Tensor, t: Tensor, y_eff: Tensor | None, train: bool = True, refresh: bool = True) -> Tensor:
         """x f32 [B,C,H,W]; t f32 [B] (flow: in [0,1]; ddpm: indices as floats, both fed unscaled like the
@@ -400,7 +468,13 @@ class DiTEngine:
         # has to read the residual stream anyway: the projection / MLP-down GEMMs stay plain stores (fast 256x384 tiles)
         # and write t1 / t2, which the backward needs for the gate gradients.
         pend = None  # (x_base, t, gate) of the sub-layer whose residual add is still pending
+        native = self._native_blocks()
         for i in range(L):
+            if native:
+                ops.dit_block_fwd(self._block_args(i, train), train)
+                a = w["layers"][i if train else 0]
+                pend = (a["x1"], a["t2"], mod[:, i * 6 * D + 5 * D : i * 6 * D + 6 * D])
+                continue
             a = w["layers"][i if train else 0]
             xin = xs[i] if train else xs[i & 1]
             pre = f"layers.{i}."
@@ -518,7 +592,15 @@ class DiTEngine:
 
         # fused MLP-down dgrad + SwiGLU backward (dH never written): 32 % less HBM traffic than the GEMM + elementwise pair
         fused_dswiglu = os.environ.get("DL_FUSED_DSWIGLU", "0") == "1"
+        native = self._native_blocks() and not fused_dswiglu and not serial and dx is w["dxa"]
         for i in reversed(range(L)):
+            if native:
+                blk = self._block_args(i, True)
+                blk.set(dfeat=dfeats.get(i - 1))
+                ops.dit_block_bwd(blk, main.cuda_stream, side.cuda_stream, side_wgs)
+                if self.reducer is not None:
+                    self.reducer.ready(*self.layer_ranges[i], extra_events=(side.record_event(),))
+                continue
             a = w["layers"][i]
             g = w["wg"][i]
             pre = f"layers.{i}."

@@ -305,6 +305,19 @@ def attn_fwd_fp8(q8, k8, v8t, scales, out, lse, B, H, Nq, Nk, dh, scale, key_bia
     _call("dl_attn_fwd_fp8", _p(q8), _p(k8), _p(v8t), _p(scales), _p(out), _p(lse), B, H, Nq, Nk, dh, float(scale), _p(key_bias), _s())
 
 
+def dit_block_fwd(blk, train: bool) -> None:
+    """one adaLN-zero DiT block forward issued by the library (blk: diffulab_amd._block.DitBlock)"""
+    import ctypes
+
+    _call("dl_dit_block_fwd", ctypes.addressof(blk), int(train), _s())
+
+
+def dit_block_bwd(blk, main_stream: int, side_stream: int, side_wgs: int) -> None:
+    import ctypes
+
+    _call("dl_dit_block_bwd", ctypes.addressof(blk), main_stream, side_stream, int(side_wgs))
+
+
 def attn_fwd_qkv(q, k, qkv, out, lse, B, H, N, dh, scale):
     """N <= 256: V is read in place from the v third of the token-major qkv rows [B*N, 3*H*dh]"""
     D = H * dh

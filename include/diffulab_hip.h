@@ -433,6 +433,52 @@ DL_API int dl_add_bf16(const void* a, const void* b, void* out, int64_t n, dl_st
 DL_API int dl_copy2d_bf16(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols,
                           dl_stream_t stream);
 
+/* ------------------------------------------------------------------ fused block driver */
+/* One adaLN-zero DiT block (DiTBlock._forward mmdit.py:288-309, DiTAttention mmdit.py:75-104, MLP mmdit.py:260-264) as ONE call
+ * per direction: the library issues the block's launch sequence itself (csrc/block.hip) -- the SURVEY section 8b "fused driver".
+ * Every pointer is a caller-owned device buffer (bf16 unless noted); M = B*N token rows, dh = D/H = 64, F = mlp_ratio*D.
+ * Index of p[]: */
+enum {
+  /* forward inputs / saved activations */
+  DL_BLK_X_IN = 0,    /* [M,D] residual stream entering the block (written when PEND_X is given) */
+  DL_BLK_PEND_X,      /* [M,D] or NULL: x before the previous block's MLP residual; then x_in = pend_x + pend_gate * pend_t */
+  DL_BLK_PEND_T,      /* [M,D] previous block's t2 */
+  DL_BLK_PEND_GATE,   /* [Bp, ld_mod] row view: previous block's gate2 */
+  DL_BLK_SCALE1, DL_BLK_SHIFT1, DL_BLK_GATE1, DL_BLK_SCALE2, DL_BLK_SHIFT2, DL_BLK_GATE2, /* row views of the modulation matrix */
+  DL_BLK_LN1_W, DL_BLK_LN1_B, DL_BLK_LN2_W, DL_BLK_LN2_B, DL_BLK_QN_SCALE, DL_BLK_KN_SCALE,  /* f32 parameters */
+  DL_BLK_W_QKV, DL_BLK_W_PROJ, DL_BLK_W_UP, DL_BLK_W_UP_PERM, DL_BLK_W_DOWN,          /* bf16 shadows [out, in] */
+  DL_BLK_WT_QKV, DL_BLK_WT_PROJ, DL_BLK_WT_UP, DL_BLK_WT_DOWN,                        /* transposed shadows [in, out] */
+  DL_BLK_ROPE_COS, DL_BLK_ROPE_SIN,                                                   /* f32 [N, rot/2] */
+  DL_BLK_XM1, DL_BLK_MEAN1, DL_BLK_RSTD1, DL_BLK_QKV, DL_BLK_Q, DL_BLK_K, DL_BLK_V /* NULL: V in place (N <= 256) */, DL_BLK_RRMS,
+  DL_BLK_A, DL_BLK_LSE, DL_BLK_T1, DL_BLK_X1, DL_BLK_XM2, DL_BLK_MEAN2, DL_BLK_RSTD2, DL_BLK_U, DL_BLK_H, DL_BLK_T2,
+  /* backward */
+  DL_BLK_DT2,         /* [M,D] gradient of t2 (produced by the LayerNorm backward of the block above / the head) */
+  DL_BLK_DX_IN,       /* [M,D] residual-stream gradient entering from above */
+  DL_BLK_DX_MID,      /* [M,D] scratch: residual-stream gradient between the two branches */
+  DL_BLK_DX_OUT,      /* [M,D] residual-stream gradient leaving the block (may alias DX_IN) */
+  DL_BLK_DH, DL_BLK_DU, DL_BLK_DXM, DL_BLK_DT1, DL_BLK_DA, DL_BLK_DQ, DL_BLK_DK, DL_BLK_DV, DL_BLK_DQKV, DL_BLK_DFEAT /* or NULL */,
+  DL_BLK_DSCALE1, DL_BLK_DSHIFT1, DL_BLK_DGATE1, DL_BLK_DSCALE2, DL_BLK_DSHIFT2,      /* f32 row views of the modulation gradient */
+  DL_BLK_DWB1, DL_BLK_DWB2,                                                           /* f32 [B,2,D] per-sample LayerNorm-affine sums */
+  DL_BLK_PREV_T2, DL_BLK_PREV_GATE2, DL_BLK_PREV_DT2, DL_BLK_PREV_DGATE2,             /* previous block's MLP residual, or NULL x4 */
+  DL_BLK_G_QKV, DL_BLK_G_PROJ, DL_BLK_G_UP, DL_BLK_G_DOWN, DL_BLK_G_LN1, DL_BLK_G_LN2, DL_BLK_G_QK_SCALE,  /* f32 gradients (+=) */
+  DL_BLK_NPTR
+};
+typedef struct dl_dit_block_t {
+  void* p[80];                   /* indexed by DL_BLK_* */
+  int64_t B, N, D, H, F;
+  int64_t ld_mod, ld_dmod;       /* row strides (elements) of the bf16 modulation matrix and of its f32 gradient */
+  int64_t ldw_d, ldw_f;          /* row strides of the forward shadows with in = D / in = F */
+  int64_t ldwt_d, ldwt_f2, ldwt_3d; /* row strides of the transposed shadows with out = D / 2F / 3D */
+  int64_t rot;                   /* rotary width per head */
+  float eps;                     /* LayerNorm epsilon (1e-5 in the blocks) */
+} dl_dit_block_t;
+/* forward of one block; train != 0 keeps the MLP pre-activations U for the backward.  The MLP branch's gated residual
+ * (x1 + gate2 * t2) is NOT applied: it is the next block's (or the final LayerNorm's) pending triple. */
+DL_API int dl_dit_block_fwd(const dl_dit_block_t* blk, int train, dl_stream_t stream);
+/* backward of one block on `main`; the weight-gradient GEMMs and LayerNorm-affine folds are issued on `side` behind events
+ * (join `side` before the gradients are consumed); side_workgroups caps the persistent wgrad workgroups (0 = one per CU) */
+DL_API int dl_dit_block_bwd(const dl_dit_block_t* blk, dl_stream_t main_stream, dl_stream_t side_stream, int side_workgroups);
+
 /* ------------------------------------------------------------------ debugging probes (tests only) */
 /* raw ds_read_b64_tr_b16 lane map: fills out[64*4] with what each lane receives when lane l passes
  * address 8*l over an LDS image holding the uint16 values 0..255 */
