@@ -189,6 +189,10 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
     for n in orig_rows:
         setattr(ops, n, timed_row(n))
     saved_reducer, model.engine.reducer = model.engine.reducer, None
+    # the timed region issues each block through the native driver (dl_dit_block_fwd / _bwd); the replay issues the SAME launches in
+    # the same order and on the same streams from Python so that every one can be bracketed with events here
+    saved_native = os.environ.get("DL_NATIVE_BLOCK")
+    os.environ["DL_NATIVE_BLOCK"] = "0"
     reps = 2
     try:
         for _ in range(reps):
@@ -198,6 +202,10 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
         for n, f in list(orig.items()) + list(orig_rows.items()):
             setattr(ops, n, f)
         model.engine.reducer = saved_reducer
+        if saved_native is None:
+            del os.environ["DL_NATIVE_BLOCK"]
+        else:
+            os.environ["DL_NATIVE_BLOCK"] = saved_native
     per: dict[str, list[float]] = {}
     for name, e0, e1, fl in rec:
         d = per.setdefault(name, [0, 0.0, 0.0])

@@ -464,6 +464,99 @@ extern "C" int dl_expand2x2(const void* x, void* out, int64_t B, int64_t Hi, int
   return DL_OK;
 }
 
+// ---------------------------------------------------------------- stride-2 pick / zero-stuff (Downsample's 3x3 stride-2 conv, nn.py:79)
+// A stride-2 pad-1 3x3 convolution is the stride-1 one sampled at the even positions: forward = conv3x3 at full resolution + pick,
+// backward = zero-stuff dY to full resolution + the stride-1 data / weight gradients.  8 channels (16 B) per thread.
+__global__ void pick2x2_k(const bf16_t* __restrict__ x, bf16_t* __restrict__ o, int B, int Ho, int Wo, int C8) {
+  const int64_t n = (int64_t)B * Ho * Wo * C8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8);
+    const int64_t r = i / C8;
+    const int xo = (int)(r % Wo), yo = (int)((r / Wo) % Ho), b = (int)(r / ((int64_t)Wo * Ho));
+    ((u32x4_t*)o)[i] = ((const u32x4_t*)x)[(((int64_t)b * 2 * Ho + 2 * yo) * 2 * Wo + 2 * xo) * C8 + c];
+  }
+}
+__global__ void stuff2x2_k(const bf16_t* __restrict__ dy, bf16_t* __restrict__ o, int B, int Hi, int Wi, int C8) {
+  const int64_t n = (int64_t)B * 4 * Hi * Wi * C8;
+  const int W = 2 * Wi, H = 2 * Hi;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8);
+    const int64_t r = i / C8;
+    const int xx = (int)(r % W), yy = (int)((r / W) % H), b = (int)(r / ((int64_t)W * H));
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (!((xx | yy) & 1)) v = ((const u32x4_t*)dy)[(((int64_t)b * Hi + yy / 2) * Wi + xx / 2) * C8 + c];
+    ((u32x4_t*)o)[i] = v;
+  }
+}
+extern "C" int dl_pick2x2(const void* x, void* out, int64_t B, int64_t Ho, int64_t Wo, int64_t C, dl_stream_t stream) {
+  DL_CHECK_ARG(x && out && B > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 8 == 0, "dl_pick2x2: bad args (C % 8)");
+  hipLaunchKernelGGL(pick2x2_k, grid_for(B * Ho * Wo * C / 8), 256, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, (int)B,
+                     (int)Ho, (int)Wo, (int)(C / 8));
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_stuff2x2(const void* dy, void* out, int64_t B, int64_t Hi, int64_t Wi, int64_t C, dl_stream_t stream) {
+  DL_CHECK_ARG(dy && out && B > 0 && Hi > 0 && Wi > 0 && C > 0 && C % 8 == 0, "dl_stuff2x2: bad args (C % 8)");
+  hipLaunchKernelGGL(stuff2x2_k, grid_for(B * 4 * Hi * Wi * C / 8), 256, 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)out,
+                     (int)B, (int)Hi, (int)Wi, (int)(C / 8));
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ---------------------------------------------------------------- additive conditioning (ResBlock, use_scale_shift_norm=False)
+// forward  out[b, p, c] = bf16(x[b, p, c] + e[b, c])          (unet.py:236 `h + emb_out`, both bf16 under autocast)
+// backward de[b, c]     = bf16(sum_p dy[b, p, c])             one workgroup per (sample, 64-channel slab): 32 pixel lanes x 8 chunks
+__global__ void rowbias_add_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ e, int64_t lde, bf16_t* __restrict__ o, int B,
+                              int HW, int C8) {
+  const int64_t n = (int64_t)B * HW * C8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8);
+    const int b = (int)(i / ((int64_t)C8 * HW));
+    float v[8], a[8];
+    unpack8(((const u32x4_t*)x)[i], v);
+    unpack8(*(const u32x4_t*)(e + (int64_t)b * lde + c * 8), a);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] += a[k];
+    ((u32x4_t*)o)[i] = pack8(v);
+  }
+}
+__global__ __launch_bounds__(256) void rowbias_bwd_k(const bf16_t* __restrict__ dy, bf16_t* __restrict__ de, int64_t lde, int HW, int C) {
+  __shared__ float red[32][65];
+  const int b = blockIdx.y, c0 = blockIdx.x * 64;
+  const int chunk = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool live = c0 + chunk * 8 < C;
+  if (live)
+    for (int p = lane; p < HW; p += 32) {
+      float v[8];
+      unpack8(*(const u32x4_t*)(dy + ((int64_t)b * HW + p) * C + c0 + chunk * 8), v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += v[k];
+    }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[lane][chunk * 8 + k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < 64 && c0 + threadIdx.x < C) {
+    float s = 0.f;
+    for (int l = 0; l < 32; ++l) s += red[l][threadIdx.x];
+    de[(int64_t)b * lde + c0 + threadIdx.x] = f2bf(s);
+  }
+}
+extern "C" int dl_rowbias_add(const void* x, const void* e, int64_t lde, void* out, int64_t B, int64_t HW, int64_t C, dl_stream_t stream) {
+  DL_CHECK_ARG(x && e && out && B > 0 && HW > 0 && C > 0 && C % 8 == 0 && lde % 8 == 0, "dl_rowbias_add: bad args (C, lde % 8)");
+  hipLaunchKernelGGL(rowbias_add_k, grid_for(B * HW * C / 8), 256, 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)e, lde,
+                     (bf16_t*)out, (int)B, (int)HW, (int)(C / 8));
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_rowbias_bwd(const void* dy, void* de, int64_t lde, int64_t B, int64_t HW, int64_t C, dl_stream_t stream) {
+  DL_CHECK_ARG(dy && de && B > 0 && B < 65536 && HW > 0 && C > 0 && C % 8 == 0, "dl_rowbias_bwd: bad args (C % 8)");
+  hipLaunchKernelGGL(rowbias_bwd_k, dim3((unsigned)((C + 63) / 64), (unsigned)B), 256, 0, (hipStream_t)stream, (const bf16_t*)dy,
+                     (bf16_t*)de, lde, (int)HW, (int)C);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
 // ---------------------------------------------------------------- small attention (n <= 64 tokens), one workgroup per (b, head)
 // q,k,v,out: token rows [B*n, ld] with head h at columns [h*dh, (h+1)*dh); probs f32 [B,H,n,n] saved for the backward
 #define AS_MAXN 64

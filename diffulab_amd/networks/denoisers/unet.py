@@ -8,9 +8,10 @@ configs/train_mnist_ddpm.yaml) and ``denoiser.pt`` checkpoints carry over.  The 
 parameters (views into one flat HBM arena); the arithmetic is the hand-written HIP path driven by
 ``diffulab_amd.unet_engine.UNetEngine``.  No PyTorch/CPU fallback exists.
 
-Covered: what ``configs/model/unet.yaml`` builds (``resblock_updown=True``, ``use_scale_shift_norm=True``, labels or
-unconditional).  Conv up/down-sampling, additive (non-FiLM) conditioning and the cross-attention Transformer blocks of a
-context embedder raise ``NotImplementedError``.
+Covered: FiLM (``use_scale_shift_norm=True``, what ``configs/model/unet.yaml`` builds) and additive conditioning, ResBlock
+resampling (``resblock_updown=True``) and the plain ``Downsample`` / ``Upsample`` modules with or without their 3x3 conv
+(``conv_resample``), labels or unconditional -- the constructor defaults included.  The cross-attention Transformer blocks of a
+context embedder and dropout > 0 raise ``NotImplementedError``.
 """
 
 from __future__ import annotations
@@ -27,15 +28,28 @@ from .mmdit import _LabelEmbed
 
 
 class _ResBlock(nn.Module):  # parameter holder for unet.py:80-237
-    def __init__(self, cin: int, cout: int, emb: int) -> None:
+    def __init__(self, cin: int, cout: int, emb: int, film: bool) -> None:
         super().__init__()
         self.in_layers = nn.Sequential(nn.GroupNorm(32, cin), nn.SiLU(), nn.Conv2d(cin, cout, 3, padding=1))
-        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb, 2 * cout))
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb, 2 * cout if film else cout))
         conv = nn.Conv2d(cout, cout, 3, padding=1)
         for p in conv.parameters():  # zero_module (unet.py:172)
             p.detach().zero_()
         self.out_layers = nn.Sequential(nn.GroupNorm(32, cout), nn.SiLU(), nn.Dropout(0.0), conv)
         self.skip_connection = nn.Identity() if cin == cout else nn.Conv2d(cin, cout, 1)
+
+
+class _Downsample(nn.Module):  # parameter holder for nn.py:59-88
+    def __init__(self, c: int, use_conv: bool) -> None:
+        super().__init__()
+        self.op = nn.Conv2d(c, c, 3, stride=2, padding=1) if use_conv else nn.AvgPool2d(kernel_size=2, stride=2)
+
+
+class _Upsample(nn.Module):  # parameter holder for nn.py:28-56
+    def __init__(self, c: int, use_conv: bool) -> None:
+        super().__init__()
+        if use_conv:
+            self.conv = nn.Conv2d(c, c, 3, padding=1)
 
 
 class _AttentionBlock(nn.Module):  # parameter holder for unet.py:240-322
@@ -95,7 +109,7 @@ class UNetModel(FlatArenaDenoiser):
                              out_channels=out_channels, num_res_blocks=num_res_blocks,
                              attention_resolutions=tuple(self.attention_resolutions), channel_mult=tuple(self.channel_mult),
                              num_heads=num_heads, use_scale_shift_norm=use_scale_shift_norm, resblock_updown=resblock_updown,
-                             n_classes=n_classes, classifier_free=classifier_free)
+                             conv_resample=conv_resample, n_classes=n_classes, classifier_free=classifier_free)
         self.dims.validate()
 
         te = self.time_embed_dim
@@ -109,7 +123,11 @@ class UNetModel(FlatArenaDenoiser):
                 if b.kind == "conv":
                     mods.append(nn.Conv2d(b.cin, b.cout, 3, padding=1))
                 elif b.kind == "res":
-                    mods.append(_ResBlock(b.cin, b.cout, te))
+                    mods.append(_ResBlock(b.cin, b.cout, te, use_scale_shift_norm))
+                elif b.kind == "down":
+                    mods.append(_Downsample(b.cin, conv_resample))
+                elif b.kind == "up":
+                    mods.append(_Upsample(b.cin, conv_resample))
                 else:
                     mods.append(_AttentionBlock(b.cin))
             return nn.Sequential(*mods)

@@ -576,6 +576,22 @@ def expand2x2(x, out, B, Hi, Wi, C, scale):
     _call("dl_expand2x2", _p(x), _p(out), B, Hi, Wi, C, float(scale), _s())
 
 
+def pick2x2(x, out, B, Ho, Wo, C):
+    _call("dl_pick2x2", _p(x), _p(out), B, Ho, Wo, C, _s())
+
+
+def stuff2x2(dy, out, B, Hi, Wi, C):
+    _call("dl_stuff2x2", _p(dy), _p(out), B, Hi, Wi, C, _s())
+
+
+def rowbias_add(x, e, out, B, HW, C):
+    _call("dl_rowbias_add", _p(x), _p(e), e.stride(0), _p(out), B, HW, C, _s())
+
+
+def rowbias_bwd(dy, de, B, HW, C):
+    _call("dl_rowbias_bwd", _p(dy), _p(de), de.stride(0), B, HW, C, _s())
+
+
 def attn_small_fwd(q, k, v, out, probs, B, n, H, dh):
     _call("dl_attn_small_fwd", _p(q), _p(k), _p(v), q.stride(0), k.stride(0), _p(out), out.stride(0), _p(probs), B, n, H, dh,
           float(dh) ** -0.5, _s())

@@ -39,14 +39,11 @@ class UNetDims:
     num_heads: int = 1
     use_scale_shift_norm: bool = False
     resblock_updown: bool = False
+    conv_resample: bool = True  # read only when resblock_updown is False (unet.py:646,735)
     n_classes: int | None = None
     classifier_free: bool = False
 
     def validate(self) -> None:
-        if not self.resblock_updown:
-            raise NotImplementedError("HIP UNet covers resblock_updown=True (configs/model/unet.yaml); conv resampling is not built")
-        if not self.use_scale_shift_norm:
-            raise NotImplementedError("HIP UNet covers use_scale_shift_norm=True (configs/model/unet.yaml)")
         mc = self.model_channels
         if mc % 32:
             raise NotImplementedError("model_channels must be a multiple of 32 (GroupNorm32)")
@@ -67,13 +64,13 @@ class UNetDims:
 
 @dataclass
 class _Blk:
-    kind: str  # "conv" | "res" | "attn"
+    kind: str  # "conv" | "res" | "attn" | "down" | "up" (the last two: Downsample / Upsample modules, nn.py:28-88)
     prefix: str
     cin: int = 0
     cout: int = 0
     up: bool = False
     down: bool = False
-    emb_off: int = 0  # column offset of this ResBlock's [scale | shift] inside the stacked FiLM projection
+    emb_off: int = 0  # column offset of this ResBlock's [scale | shift] (or additive term) inside the stacked emb projection
 
 
 @dataclass
@@ -88,7 +85,7 @@ class _Plan:
 
 
 def build_plan(d: UNetDims) -> _Plan:
-    """module wiring of unet.py:593-745 for resblock_updown=True without a context embedder"""
+    """module wiring of unet.py:593-745 without a context embedder"""
     mc = d.model_channels
     plan = _Plan()
     ch = int(d.channel_mult[0] * mc)
@@ -105,7 +102,8 @@ def build_plan(d: UNetDims) -> _Plan:
             chans.append(ch)
         if level != len(d.channel_mult) - 1:
             i = len(plan.input_blocks)
-            plan.input_blocks.append([_Blk("res", f"input_blocks.{i}.0.", ch, ch, down=True)])
+            plan.input_blocks.append([_Blk("res", f"input_blocks.{i}.0.", ch, ch, down=True) if d.resblock_updown
+                                      else _Blk("down", f"input_blocks.{i}.0.", ch, ch)])
             chans.append(ch)
             ds *= 2
     plan.middle = [_Blk("res", "middle_block.0.", ch, ch), _Blk("attn", "middle_block.1.", ch, ch),
@@ -119,7 +117,8 @@ def build_plan(d: UNetDims) -> _Plan:
             if ds in d.attention_resolutions:
                 layers.append(_Blk("attn", f"output_blocks.{i}.{len(layers)}.", ch, ch))
             if level and k == d.num_res_blocks:
-                layers.append(_Blk("res", f"output_blocks.{i}.{len(layers)}.", ch, ch, up=True))
+                layers.append(_Blk("res", f"output_blocks.{i}.{len(layers)}.", ch, ch, up=True) if d.resblock_updown
+                              else _Blk("up", f"output_blocks.{i}.{len(layers)}.", ch, ch))
                 ds //= 2
             plan.output_blocks.append(layers)
     plan.final_ch = ch
@@ -127,8 +126,18 @@ def build_plan(d: UNetDims) -> _Plan:
     for b in plan.all_blocks():
         if b.kind == "res":
             b.emb_off = off
-            off += 2 * b.cout
+            off += emb_width(d, b)
     return plan
+
+
+def emb_width(d: UNetDims, b: _Blk) -> int:
+    """rows of emb_layers.1 (unet.py:161-166): [scale | shift] under FiLM, one additive term otherwise"""
+    return 2 * b.cout if d.use_scale_shift_norm else b.cout
+
+
+def resample_conv(b: _Blk) -> str:
+    """parameter prefix of the 3x3 conv inside a Downsample (`op`, nn.py:79) / Upsample (`conv`, nn.py:47) module"""
+    return b.prefix + ("op." if b.kind == "down" else "conv.")
 
 
 class UNetLayout:
@@ -147,10 +156,10 @@ class UNetLayout:
 
         res = [b for b in plan.all_blocks() if b.kind == "res"]
         for i, b in enumerate(res):
-            add(b.prefix + "emb_layers.1.weight", (2 * b.cout, te), align=1 if i else 64)
+            add(b.prefix + "emb_layers.1.weight", (emb_width(d, b), te), align=1 if i else 64)
         for i, b in enumerate(res):
-            add(b.prefix + "emb_layers.1.bias", (2 * b.cout,), align=1 if i else 64)
-        self.emb_rows = sum(2 * b.cout for b in res)
+            add(b.prefix + "emb_layers.1.bias", (emb_width(d, b),), align=1 if i else 64)
+        self.emb_rows = sum(emb_width(d, b) for b in res)
         self.emb_w0, self.emb_b0 = res[0].prefix + "emb_layers.1.weight", res[0].prefix + "emb_layers.1.bias"
         add("time_embed.0.weight", (te, d.model_channels))
         add("time_embed.0.bias", (te,))
@@ -175,6 +184,10 @@ class UNetLayout:
                 if b.cin != b.cout:
                     add(p + "skip_connection.weight", (b.cout, b.cin, 1, 1))
                     add(p + "skip_connection.bias", (b.cout,))
+            elif b.kind in ("down", "up"):
+                if d.conv_resample:
+                    add(resample_conv(b) + "weight", (b.cout, b.cin, 3, 3))
+                    add(resample_conv(b) + "bias", (b.cout,))
             else:
                 c = b.cin
                 for n in ("norm_x", "norm_context"):
@@ -263,6 +276,9 @@ class UNetEngine:
                 conv(p + "out_layers.3.weight", b.cout, b.cout)
                 if b.cin != b.cout:
                     lin(p + "skip_connection.weight", b.cout, b.cin)
+            elif b.kind in ("down", "up"):
+                if d.conv_resample:
+                    conv(resample_conv(b) + "weight", b.cout, b.cin)
             else:
                 c = b.cin
                 lin(p + "to_q.weight", c, c)
@@ -450,7 +466,12 @@ class UNetEngine:
                 ops.reduce2x2(x, x2, B, H2, W2, b.cin, 0.25)
             h = hp
         h2 = self._conv3(h, B, H2, W2, b.cin, p + "in_layers.2.weight", b.cout)
-        film = (eo[:, b.emb_off : b.emb_off + b.cout], eo[:, b.emb_off + b.cout : b.emb_off + 2 * b.cout])
+        if self.d.use_scale_shift_norm:
+            film = (eo[:, b.emb_off : b.emb_off + b.cout], eo[:, b.emb_off + b.cout : b.emb_off + 2 * b.cout])
+        else:  # h + emb_out in front of the plain GroupNorm -> SiLU (unet.py:235-237)
+            film, pre = None, h2
+            h2 = self._new(B * H2 * W2, b.cout)
+            ops.rowbias_add(pre, eo[:, b.emb_off : b.emb_off + b.cout], h2, B, H2 * W2, b.cout)
         h3, st2 = self._gn(h2, B, H2 * W2, b.cout, p + "out_layers.0.", film=film)
         skip = x2 if b.cin == b.cout else self._lin_fwd(x2, p + "skip_connection.weight", b.cout, b.cin)
         out = self._conv3(h3, B, H2, W2, b.cout, p + "out_layers.3.weight", b.cout, resid=skip)  # x + h fused (unet.py:237)
@@ -464,9 +485,13 @@ class UNetEngine:
         dh3 = self._conv3_bwd(dout, h3, B, H2, W2, b.cout, p + "out_layers.3.weight", b.cout)
         dx2 = dout if b.cin == b.cout else self._lin_bwd(dout, x2, p + "skip_connection.weight", b.cout, b.cin)
         o = b.emb_off
-        film = (eo[:, o : o + b.cout], eo[:, o + b.cout : o + 2 * b.cout])
-        dfilm = (deo[:, o : o + b.cout], deo[:, o + b.cout : o + 2 * b.cout])
-        dh2 = self._gn_bwd(dh3, h2, st2, B, H2 * W2, b.cout, p + "out_layers.0.", film=film, dfilm=dfilm)
+        if self.d.use_scale_shift_norm:
+            film = (eo[:, o : o + b.cout], eo[:, o + b.cout : o + 2 * b.cout])
+            dfilm = (deo[:, o : o + b.cout], deo[:, o + b.cout : o + 2 * b.cout])
+            dh2 = self._gn_bwd(dh3, h2, st2, B, H2 * W2, b.cout, p + "out_layers.0.", film=film, dfilm=dfilm)
+        else:  # h2 is the conv output + emb_out: the GroupNorm gradient is both d(conv output) and, summed over pixels, d(emb_out)
+            dh2 = self._gn_bwd(dh3, h2, st2, B, H2 * W2, b.cout, p + "out_layers.0.")
+            ops.rowbias_bwd(dh2, deo[:, o : o + b.cout], B, H2 * W2, b.cout)
         dh = self._conv3_bwd(dh2, h, B, H2, W2, b.cin, p + "in_layers.2.weight", b.cout)
         if b.up or b.down:
             dhp, dxs = self._new(B * H * W, b.cin), self._new(B * H * W, b.cin)
@@ -478,6 +503,44 @@ class UNetEngine:
                 ops.expand2x2(dx2, dxs, B, H2, W2, b.cin, 0.25)
             dh, dx2 = dhp, dxs
         return self._gn_bwd(dh, x, st1, B, H * W, b.cin, p + "in_layers.0.", dres=dx2)
+
+    def _resample_fwd(self, b: _Blk, x: Tensor, B: int, H: int, W: int, save: list | None):
+        """Downsample / Upsample modules (nn.py:28-88) of resblock_updown=False.  The stride-2 conv is the stride-1 implicit GEMM
+        at the input resolution sampled at the even pixels (dl_pick2x2): 4x the needed MACs on the L-1 downsampling convs of a
+        network, in exchange for one conv kernel family."""
+        c, name = b.cin, resample_conv(b) + "weight"
+        if b.kind == "down":
+            H2, W2 = H // 2, W // 2
+            out = self._new(B * H2 * W2, c)
+            if self.d.conv_resample:
+                ops.pick2x2(self._conv3(x, B, H, W, c, name, c), out, B, H2, W2, c)
+            else:
+                ops.reduce2x2(x, out, B, H2, W2, c, 0.25)
+            xin = x
+        else:
+            H2, W2 = 2 * H, 2 * W
+            xin = self._new(B * H2 * W2, c)
+            ops.expand2x2(x, xin, B, H, W, c, 1.0)
+            out = self._conv3(xin, B, H2, W2, c, name, c) if self.d.conv_resample else xin
+        if save is not None:
+            save.append((xin if self.d.conv_resample else None, H, W))
+        return out, H2, W2
+
+    def _resample_bwd(self, b: _Blk, dout: Tensor, B: int, saved) -> Tensor:
+        c, name = b.cin, resample_conv(b) + "weight"
+        xin, H, W = saved
+        dx = self._new(B * H * W, c)
+        if b.kind == "down":
+            if self.d.conv_resample:
+                dfull = self._new(B * H * W, c)
+                ops.stuff2x2(dout, dfull, B, H // 2, W // 2, c)
+                return self._conv3_bwd(dfull, xin, B, H, W, c, name, c)
+            ops.expand2x2(dout, dx, B, H // 2, W // 2, c, 0.25)
+            return dx
+        if self.d.conv_resample:
+            dout = self._conv3_bwd(dout, xin, B, 2 * H, 2 * W, c, name, c)
+        ops.reduce2x2(dout, dx, B, H, W, c, 1.0)
+        return dx
 
     def _attn_fwd(self, b: _Blk, x: Tensor, B: int, H: int, W: int, save: list | None) -> Tensor:
         p, c, n = b.prefix, b.cin, H * W
@@ -515,6 +578,8 @@ class UNetEngine:
                 h = self._conv3(h, B, H, W, b.cin, b.prefix + "weight", b.cout)
             elif b.kind == "res":
                 h, H, W = self._res_fwd(b, h, B, H, W, eo, save)
+            elif b.kind in ("down", "up"):
+                h, H, W = self._resample_fwd(b, h, B, H, W, save)
             else:
                 h = self._attn_fwd(b, h, B, H, W, save)
         return h, H, W
@@ -525,7 +590,12 @@ class UNetEngine:
             if b.kind == "conv":
                 x, H, W = s
                 return self._conv3_bwd(dh, x, B, H, W, b.cin, b.prefix + "weight", b.cout, need_dx=False)
-            dh = self._res_bwd(b, dh, B, s, eo, deo) if b.kind == "res" else self._attn_bwd(b, dh, B, s)
+            if b.kind == "res":
+                dh = self._res_bwd(b, dh, B, s, eo, deo)
+            elif b.kind in ("down", "up"):
+                dh = self._resample_bwd(b, dh, B, s)
+            else:
+                dh = self._attn_bwd(b, dh, B, s)
         return dh
 
     # ------------------------------------------------------------------ forward (unet.py:832-853)
@@ -559,7 +629,7 @@ class UNetEngine:
         ops.cond_combine_fwd(e, table, y_eff if table is not None else None, emb, se[:B])
         R = self.layout.emb_rows
         off = self.layout.entries[self.layout.emb_b0][0]
-        eo = self._new(B, R)
+        eo = self._new(B, _rup(R, 64))  # (additive conditioning: R is a multiple of 32 only; the row stride stays GEMM-aligned)
         ops.gemm_nt(se, self.sh["@emb|f"], eo, bias=self.params[off : off + R], M=B, N=R, K=_rup(te, 64))
 
         h = self._new(B * H * W, Cin)
@@ -597,7 +667,7 @@ class UNetEngine:
         mc, te = d.model_channels, 4 * d.model_channels
         Bp = _rup(B, 64)
         R = self.layout.emb_rows
-        deo = self._new(Bp, R, zero=True)
+        deo = self._new(Bp, _rup(R, 64), zero=True)
         co8 = _rup(d.out_channels, 8)
         do = self._new(B * H * W, co8, zero=True)
         ops.nchw_to_nhwc(dpred, do, B, d.out_channels, H * W)
@@ -624,7 +694,7 @@ class UNetEngine:
 
         # FiLM projections (one stacked GEMM pair), then the conditioning MLP
         w0, b0 = self.layout.entries[self.layout.emb_w0][0], self.layout.entries[self.layout.emb_b0][0]
-        ops.gemm_tn(deo, s["se"], self.grads[w0 : w0 + R * te].view(R, te))
+        ops.gemm_tn(deo, s["se"], self.grads[w0 : w0 + R * te].view(R, te), M=R)
         ops.colsum(deo, self.grads[b0 : b0 + R], B, R)
         dse = self._new(B, te, dtype=torch.float32)
         ops.gemm_nt(deo, self.sh["@emb|t"], dse, M=B, N=te, K=_rup(R, 64))

@@ -418,6 +418,18 @@ DL_API int dl_reduce2x2(const void* x, void* out, int64_t B, int64_t Ho, int64_t
  * avg_pool2d backward (scale 0.25) */
 DL_API int dl_expand2x2(const void* x, void* out, int64_t B, int64_t Hi, int64_t Wi, int64_t C, float scale,
                         dl_stream_t stream);
+/* out[b, yo, xo, c] = x[b, 2yo, 2xo, c] for x [B, 2Ho, 2Wo, C], C % 8 == 0: with dl_conv3x3_nt at full resolution in front this
+ * is Downsample's 3x3 stride-2 pad-1 convolution (nn.py:79) */
+DL_API int dl_pick2x2(const void* x, void* out, int64_t B, int64_t Ho, int64_t Wo, int64_t C, dl_stream_t stream);
+/* out[b, y, x, c] = dy[b, y/2, x/2, c] where y and x are both even, 0 elsewhere (out [B, 2Hi, 2Wi, C], C % 8 == 0): the
+ * backward of dl_pick2x2; the stride-1 data / weight gradients of the conv follow */
+DL_API int dl_stuff2x2(const void* dy, void* out, int64_t B, int64_t Hi, int64_t Wi, int64_t C, dl_stream_t stream);
+/* additive ResBlock conditioning (use_scale_shift_norm=False, unet.py:235-237 `h = h + emb_out`):
+ * out[b, p, c] = x[b, p, c] + e[b, c] over x bf16 [B, HW, C], e bf16 rows of leading dimension lde (C, lde % 8 == 0) */
+DL_API int dl_rowbias_add(const void* x, const void* e, int64_t lde, void* out, int64_t B, int64_t HW, int64_t C,
+                          dl_stream_t stream);
+/* its backward for e: de[b, c] = sum_p dy[b, p, c] (f32 accumulation, bf16 store into rows of leading dimension lde) */
+DL_API int dl_rowbias_bwd(const void* dy, void* de, int64_t lde, int64_t B, int64_t HW, int64_t C, dl_stream_t stream);
 /* AttentionBlock core (unet.py:311-318: heads split the channel dim as (h d), scale = dh^-0.5): q/k/v/out are token rows
  * with head h at columns [h*dh, (h+1)*dh); n <= 64 tokens, dh % 8 == 0; probs f32 [B, H, n, n] is kept for the backward */
 DL_API int dl_attn_small_fwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldkv, void* out,

@@ -2,11 +2,13 @@
 
 Functional restatement over a ``dict[str, Tensor]`` keyed like the reference ``state_dict``
 (``input_blocks.{i}.{j}...``, ``middle_block.{j}...``, ``output_blocks.{i}.{j}...``, ``out.{0,2}``, ``time_embed.{0,2}``,
-``label_embed.embedding``), self-attention / class-conditional variant only (what ``configs/model/unet.yaml`` builds).
+``label_embed.embedding``), self-attention / class-conditional variants: FiLM or additive conditioning
+(``use_scale_shift_norm``), ResBlock or plain ``Upsample`` / ``Downsample`` resampling (``resblock_updown``), with or without
+the resampling conv (``conv_resample``).  ``configs/model/unet.yaml`` builds the FiLM + ResBlock-resampling one.
 
 Reference sites (``/root/reference/src/diffulab``):
   networks/utils/nn.py:11-25       GroupNorm32 (fp32 statistics, 32 groups, eps 1e-5)
-  networks/utils/nn.py:28-88       Upsample (nearest x2) / Downsample (avg-pool 2) without conv
+  networks/utils/nn.py:28-88       Upsample (nearest x2 [+ 3x3 conv]) / Downsample (3x3 stride-2 conv, or avg-pool 2)
   networks/denoisers/unet.py:215-237   ResBlock._forward (FiLM scale/shift, up/down, zero-init out conv)
   networks/denoisers/unet.py:296-322   AttentionBlock._forward (GN -> 1x1 q / kv -> SDPA -> 1x1 out -> + x)
   networks/denoisers/unet.py:593-745   block wiring ; :832-853 forward
@@ -35,13 +37,14 @@ class UNetConfig:
     num_heads: int = 2
     use_scale_shift_norm: bool = True
     resblock_updown: bool = True
+    conv_resample: bool = True   # only read when resblock_updown is False (unet.py:646,735)
     n_classes: int | None = 10
     classifier_free: bool = False
 
 
 @dataclass
 class Block:
-    kind: str                 # "conv" | "res" | "attn"
+    kind: str                 # "conv" | "res" | "attn" | "down" | "up" (the last two: nn.py Downsample / Upsample)
     prefix: str
     cin: int = 0
     cout: int = 0
@@ -58,8 +61,7 @@ class Plan:
 
 
 def build_plan(cfg: UNetConfig) -> Plan:
-    """unet.py:593-745, resblock_updown=True / no context embedder."""
-    assert cfg.resblock_updown, "only the ResBlock up/down variant is restated (configs/model/unet.yaml)"
+    """unet.py:593-745, no context embedder."""
     mc = cfg.model_channels
     plan = Plan()
     ch = cfg.channel_mult[0] * mc
@@ -77,7 +79,8 @@ def build_plan(cfg: UNetConfig) -> Plan:
             chans.append(ch)
         if level != len(cfg.channel_mult) - 1:
             i = len(plan.input_blocks)
-            plan.input_blocks.append([Block("res", f"input_blocks.{i}.0.", ch, ch, down=True)])
+            plan.input_blocks.append([Block("res", f"input_blocks.{i}.0.", ch, ch, down=True) if cfg.resblock_updown
+                                      else Block("down", f"input_blocks.{i}.0.", ch, ch)])
             chans.append(ch)
             ds *= 2
     plan.middle = [Block("res", "middle_block.0.", ch, ch), Block("attn", "middle_block.1.", ch, ch),
@@ -91,7 +94,8 @@ def build_plan(cfg: UNetConfig) -> Plan:
             if ds in cfg.attention_resolutions:
                 layers.append(Block("attn", f"output_blocks.{i}.{len(layers)}.", ch, ch))
             if level and k == cfg.num_res_blocks:
-                layers.append(Block("res", f"output_blocks.{i}.{len(layers)}.", ch, ch, up=True))
+                layers.append(Block("res", f"output_blocks.{i}.{len(layers)}.", ch, ch, up=True) if cfg.resblock_updown
+                              else Block("up", f"output_blocks.{i}.{len(layers)}.", ch, ch))
                 ds //= 2
             plan.output_blocks.append(layers)
     plan.final_ch = ch
@@ -121,6 +125,10 @@ def param_shapes(cfg: UNetConfig) -> dict[str, tuple[int, ...]]:
             s[p + "out_layers.3.weight"], s[p + "out_layers.3.bias"] = (b.cout, b.cout, 3, 3), (b.cout,)
             if b.cin != b.cout:
                 s[p + "skip_connection.weight"], s[p + "skip_connection.bias"] = (b.cout, b.cin, 1, 1), (b.cout,)
+        elif b.kind in ("down", "up"):
+            if cfg.conv_resample:  # Downsample.op / Upsample.conv (nn.py:47,79)
+                n = "op." if b.kind == "down" else "conv."
+                s[p + n + "weight"], s[p + n + "bias"] = (b.cout, b.cin, 3, 3), (b.cout,)
         else:
             c = b.cin
             for n in ("norm_x", "norm_context"):
@@ -203,6 +211,13 @@ def run_blocks(P, blocks: list[Block], h: Tensor, emb: Tensor, cfg: UNetConfig) 
             h = F.conv2d(h, P[b.prefix + "weight"], P[b.prefix + "bias"], padding=1)
         elif b.kind == "res":
             h = res_block(P, b, h, emb, cfg)
+        elif b.kind == "down":  # nn.py:84-88
+            h = (F.conv2d(h, P[b.prefix + "op.weight"], P[b.prefix + "op.bias"], stride=2, padding=1) if cfg.conv_resample
+                 else F.avg_pool2d(h, 2))
+        elif b.kind == "up":  # nn.py:49-56
+            h = F.interpolate(h, scale_factor=2, mode="nearest")
+            if cfg.conv_resample:
+                h = F.conv2d(h, P[b.prefix + "conv.weight"], P[b.prefix + "conv.bias"], padding=1)
         else:
             h = attention_block(P, b, h, cfg)
     return h

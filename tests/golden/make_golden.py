@@ -374,7 +374,8 @@ def build_unet_ref(cfg, seed: int) -> UNetModel:
                   out_channels=cfg.out_channels, num_res_blocks=cfg.num_res_blocks,
                   attention_resolutions=list(cfg.attention_resolutions), channel_mult=", ".join(map(str, cfg.channel_mult)),
                   num_heads=cfg.num_heads, use_scale_shift_norm=cfg.use_scale_shift_norm,
-                  resblock_updown=cfg.resblock_updown, n_classes=cfg.n_classes, classifier_free=cfg.classifier_free)
+                  resblock_updown=cfg.resblock_updown, conv_resample=cfg.conv_resample, n_classes=cfg.n_classes,
+                  classifier_free=cfg.classifier_free)
     P = synth.generic_params(ounet.param_shapes(cfg), seed=seed)
     sd = m.state_dict()
     assert set(sd) == set(P), (set(sd) ^ set(P))
@@ -434,6 +435,46 @@ def gen_unet() -> None:
                 o["un_g_" + n] = p.grad
     o["un_grad_names"], o["un_grad_norms"] = np.array(names), np.array(norms)
     save("unet", **o)
+
+
+# the UNetModel constructor DEFAULTS (additive conditioning, Downsample / Upsample modules with their 3x3 convs: unet.py:541-545)
+# and the conv-free resampling variant; three levels so that two resampling stages of each kind are crossed
+UNET_VARIANTS = {
+    "dflt": ounet.UNetConfig(image_size=(16, 16), in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1,
+                             attention_resolutions=(4,), channel_mult=(1, 2, 2), num_heads=2, use_scale_shift_norm=False,
+                             resblock_updown=False, conv_resample=True, n_classes=10, classifier_free=True),
+    "pool": ounet.UNetConfig(image_size=(16, 16), in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1,
+                             attention_resolutions=(4,), channel_mult=(1, 2, 2), num_heads=2, use_scale_shift_norm=True,
+                             resblock_updown=False, conv_resample=False, n_classes=None, classifier_free=False),
+}
+
+
+def gen_unet_variants() -> None:
+    o = {}
+    B = 4
+    for tag, cfg in UNET_VARIANTS.items():
+        m = build_unet_ref(cfg, seed=29)
+        x0 = synth.normal(f"uv.{tag}.x0", (B, 1, 16, 16))
+        noise = synth.normal(f"uv.{tag}.noise", (B, 1, 16, 16))
+        yl = synth.integers(f"uv.{tag}.y", (B,), 10) if cfg.n_classes else None
+        ti = torch.tensor([7, 250, 999, 0], dtype=torch.int32)
+        gd = Diffuser(m, sampling_method="ddpm", model_type="gaussian_diffusion", n_steps=1000)
+        xt = gd.diffusion.add_noise(x0, ti, noise)[0]
+        kw = {"y": yl, "p": 0.0} if cfg.n_classes else {}
+        o[f"{tag}_pred"] = m(x=xt, timesteps=ti, **kw)["x"]
+        loss = gd.compute_loss({"x": x0.clone(), **kw}, timesteps=ti, noise=noise)["loss"]
+        loss.backward()
+        o[f"{tag}_loss"] = loss
+        names, norms = [], []
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                names.append(n)
+                norms.append(p.grad.double().norm().item())
+                if p.grad.numel() <= 20000:
+                    o[f"{tag}_g_" + n] = p.grad
+        o[f"{tag}_grad_names"], o[f"{tag}_grad_norms"] = np.array(names), np.array(norms)
+    save("unet_variants", **o)
+
 
 # ------------------------------------------------------------------ (viii) loss curve, DiT-S/2 + AdamW
 def gen_loss_curve() -> None:
@@ -887,9 +928,9 @@ def gen_datasets() -> None:
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["datasets", "schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "curve", "repa", "resampler", "sprint", "mmdit_joint", "sprint_joint", "ddt", "ddt_joint", "mmdit_single"]
+    which = sys.argv[1:] or ["datasets", "schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "unet_variants", "curve", "repa", "resampler", "sprint", "mmdit_joint", "sprint_joint", "ddt", "ddt_joint", "mmdit_single"]
     fns = {"datasets": gen_datasets, "repa": gen_repa, "resampler": gen_resampler, "sprint": gen_sprint, "mmdit_joint": gen_mmdit_joint, "sprint_joint": gen_sprint_joint, "ddt": gen_ddt, "ddt_joint": gen_ddt_joint, "mmdit_single": gen_mmdit_single, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
-           "s2": gen_s2_model, "samplers": gen_samplers, "curve": gen_loss_curve, "unet": gen_unet}
+           "s2": gen_s2_model, "samplers": gen_samplers, "curve": gen_loss_curve, "unet": gen_unet, "unet_variants": gen_unet_variants}
     for w in which:
         print("==", w)
         fns[w]()

@@ -357,6 +357,46 @@ def test_unet_blocks_and_small_model(golden):
             assert rel(P[k[5:]].grad, g[k]) < 2e-5, k
 
 
+UNET_VARIANTS = {  # tests/golden/make_golden.py::UNET_VARIANTS
+    "dflt": dict(image_size=(16, 16), in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1, attention_resolutions=(4,),
+                 channel_mult=(1, 2, 2), num_heads=2, use_scale_shift_norm=False, resblock_updown=False, conv_resample=True,
+                 n_classes=10, classifier_free=True),
+    "pool": dict(image_size=(16, 16), in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1, attention_resolutions=(4,),
+                 channel_mult=(1, 2, 2), num_heads=2, use_scale_shift_norm=True, resblock_updown=False, conv_resample=False,
+                 n_classes=None, classifier_free=False),
+}
+
+
+@pytest.mark.parametrize("tag", ["dflt", "pool"])
+def test_unet_constructor_default_and_pooling_variants(golden, tag):
+    """the UNetModel constructor defaults (additive conditioning, Downsample / Upsample with their 3x3 convs) and the conv-free
+    resampling variant, DDPM loss fwd + bwd, against the reference run (tests/golden/unet_variants.npz)"""
+    from oracle import unet as ounet
+
+    g = golden("unet_variants")
+    cfg = ounet.UNetConfig(**UNET_VARIANTS[tag])
+    P = {k: v.requires_grad_(True) for k, v in synth.generic_params(ounet.param_shapes(cfg), seed=29).items()}
+    B = 4
+    x0, noise = synth.normal(f"uv.{tag}.x0", (B, 1, 16, 16)), synth.normal(f"uv.{tag}.noise", (B, 1, 16, 16))
+    yl = synth.integers(f"uv.{tag}.y", (B,), 10) if cfg.n_classes else None
+    ti = torch.tensor([7, 250, 999, 0], dtype=torch.int32)
+    pred = ounet.unet_forward(P, od.ddpm_add_noise(od.GaussianTables(1000), x0, ti, noise), ti, yl, cfg)
+    assert rel(pred, g[f"{tag}_pred"]) < 5e-6
+    loss = od.mse_loss(pred, noise)
+    loss.backward()
+    assert abs(loss.item() - float(g[f"{tag}_loss"])) / float(g[f"{tag}_loss"]) < 1e-6
+    norms = dict(zip(g[f"{tag}_grad_names"].tolist(), g[f"{tag}_grad_norms"].tolist()))
+    assert set(norms) == set(P)
+    floor = 1e-6 * max(norms.values())
+    for n, ref in norms.items():
+        got = P[n].grad.double().norm().item()
+        assert (ref <= floor and got <= 10 * floor) or abs(got - ref) <= 2e-5 * ref, n
+    pre = f"{tag}_g_"
+    for k in g:
+        if k.startswith(pre) and norms[k[len(pre):]] > floor:
+            assert rel(P[k[len(pre):]].grad, g[k]) < 2e-5, k
+
+
 def test_repa_loss_hooked_into_small_dit(golden):
     """(ix) REPA alignment loss on the output of block 0 of the small DiT next to the flow loss: both losses, the projector
     gradients and every denoiser gradient (the feature gradient re-enters the residual stream) vs the reference"""
