@@ -100,6 +100,8 @@ def cpu_baseline(batch: int = 32, n_timed: int = 3, budget_s: float = 150.0) -> 
 def _tn_variant(R: int, M: int, N: int) -> str:
     """which kernel dl_gemm_tn dispatches to (csrc/gemm.hip dl_gemm_tn_ex, default variant)"""
     tiles_m = -(-M // 384)
+    if os.environ.get("DL_GEMM_TN_VARIANT", "2") == "2" and M % 384 == 0 and N % 192 == 0 and R // 32 >= 64:
+        return "gemm_tn_w4_k"
     if N % 128 == 0 and R // 64 >= 64 and 5 * M >= 3 * tiles_m * 384:
         return "gemm_tn_big_k"
     return "gemm_tn_k"

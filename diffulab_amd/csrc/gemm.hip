@@ -820,8 +820,22 @@ extern "C" int dl_gemm_nt_dswiglu(const void* dT, int64_t ldt, const void* W2t, 
 // TN (wgrad): C[m,n] += sum_r A[r,m] B[r,n].  Operand tiles are [64 r][128 cols] row-major in LDS (DMA'd
 // straight from the row-major activations), MFMA fragments come out of ds_read_b64_tr_b16 transposing reads.
 // =====================================================================================================
+// Inline assembly ON PURPOSE (see gemm_w4.hip): behind a direct-to-LDS DMA the waitcnt pass puts s_waitcnt vmcnt(0) in front of a
+// compiler-visible transposing read (it cannot tell the read from the DMA's LDS target), i.e. the prefetched stage is waited for
+// before the current one is consumed and the DMA never overlaps the MFMAs.  The asm read has no memory operand; its lgkmcnt
+// wait is explicit (tr_landed).
 __device__ __forceinline__ s16x4_t lds_tr16(const char* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+  s16x4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)(lds_void_t*)p));
+  return v;
+}
+template <int NA, int NB>
+__device__ __forceinline__ void tr_landed(bf16x8_t (&a)[NA], bf16x8_t (&b)[NB]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(a[i]));  // no MFMA on these registers can be scheduled above the wait
+#pragma unroll
+  for (int j = 0; j < NB; ++j) asm volatile("" : "+v"(b[j]));
 }
 
 template <bool CONV>
@@ -934,6 +948,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_tn_k(const bf16_t* __restr
         af[i] = ua.v;
         bfg[i] = ub.v;
       }
+      tr_landed(af, bfg);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1112,6 +1127,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __
         u.h[1] = lds_tr16(tb + tr_off(wn * 64 + j * 32, kk, 1, WBN * 2));
         bfg[j] = u.v;
       }
+      tr_landed(af, bfg);
       if (PROBE & 2) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) asm volatile("" ::"v"(af[i]));
@@ -1268,6 +1284,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_wide_k(const bf16_t* _
         u.h[1] = lds_tr16(tb + tr_off(wn * (NI * 32) + j * 32, kk, 1, TN_ * 2));
         bfg[j] = u.v;
       }
+      tr_landed(af, bfg);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1319,6 +1336,8 @@ __global__ void tn_slab_fold_k(float* __restrict__ slabs, float* __restrict__ C,
 extern "C" int dl_gemm_tn_ws(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                              int64_t N, int64_t R, int max_workgroups, float* workspace, int64_t workspace_elems,
                              dl_stream_t stream);
+int launch_tn_w4(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t R,
+                 int max_workgroups, hipStream_t stream);  // gemm_w4.hip
 extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                              int64_t N, int64_t R, int max_workgroups, dl_stream_t stream);
 extern "C" int dl_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
@@ -1335,17 +1354,21 @@ extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t 
   {
     static int variant = -1, n_cu = 0;
     if (variant < 0) {
-      const char* e = getenv("DL_GEMM_TN_VARIANT");
-      variant = e ? atoi(e) : 1;
+      const char* e = getenv("DL_GEMM_TN_VARIANT");  // 0: 128x128 kernel, 1: 384x128 persistent, 2: 384x192 ring kernel (gemm_w4.hip)
+      variant = e ? atoi(e) : 2;
       int dev = 0;
       (void)hipGetDevice(&dev);
       (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
       if (n_cu <= 0) n_cu = 256;
       (void)hipFuncSetAttribute((const void*)gemm_tn_big_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE);
     }
+    if (variant == 2 && !g_gemm_probe) {
+      const int rc = launch_tn_w4(A, lda, B, ldb, C, ldc, M, N, R, max_workgroups, (hipStream_t)stream);
+      if (rc <= 0) return rc;
+    }
     const int nsteps = (int)(R / BK);
     const int64_t tiles_m64 = (M + WBM - 1) / WBM;
-    if (variant == 1 && N % WBN == 0 && nsteps >= 64 && 5 * M >= 3 * tiles_m64 * WBM) {  // (ragged last m-tile: >= 60 % useful)
+    if (variant >= 1 && N % WBN == 0 && nsteps >= 64 && 5 * M >= 3 * tiles_m64 * WBM) {  // (ragged last m-tile: >= 60 % useful)
       // one workgroup per CU at most (128 KiB of LDS each): units (= m-tiles x splits) are padded to a multiple of
       // 8 for the XCD mapping, so pick the split count from the padded budget
       const int tiles_m = (int)tiles_m64, tiles_n = (int)(N / WBN);
@@ -1564,6 +1587,7 @@ __global__ void probe_tr16_k(uint16_t* out) {
   for (int i = lane; i < 256; i += 64) img[i] = (uint16_t)i;
   __syncthreads();
   s16x4_t v = lds_tr16((const char*)img + lane * 8);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
 #pragma unroll
   for (int j = 0; j < 4; ++j) out[lane * 4 + j] = (uint16_t)v[j];
 }

@@ -568,7 +568,7 @@ class DiTEngine:
         side = self._side_stream()
         side.wait_stream(main)
 
-        side_wgs = int(os.environ.get("DL_SIDE_WGS", "192"))  # of 256 CUs: measured best (256: -1.2 %, 160: -1.5 %)
+        side_wgs = int(os.environ.get("DL_SIDE_WGS", "128"))  # of 256 CUs; with the ring wgrad kernel: 96: 24.5, 128: 24.1, 160: 24.4, 192: 24.8, 256: 25.8 ms/step
 
         serial = os.environ.get("DL_WGRAD_SERIAL") == "1"  # A/B switch: weight gradients inline on the main stream
 

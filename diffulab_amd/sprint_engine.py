@@ -327,7 +327,7 @@ class SprintEngine(DiTEngine):
         main = torch.cuda.current_stream()
         side = self._side_stream()
         side.wait_stream(main)
-        side_wgs = int(os.environ.get("DL_SIDE_WGS", "192"))
+        side_wgs = int(os.environ.get("DL_SIDE_WGS", "128"))
 
         def wgrad(x_grad: Tensor, x_in: Tensor, gname: str) -> None:
             ev = main.record_event()

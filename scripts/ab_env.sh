@@ -1,7 +1,6 @@
-run() { echo "== $*"; env "$@" python scripts/gemm_bench.py nt 20 2>&1 | grep -E "d_xm2|d_xm1|d_a |mlp2"; }
-run A=1
-run DL_GEMM_NT_ANT=1
-run A=1
-run DL_GEMM_NT_ANT=1
-for i in 1 2 3; do
-for v in 0 1; do echo "ANT=$v"; DL_GEMM_NT_ANT=$v python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | grep -o "\"ms_per_step\": [0-9.]*"; done; done
+#!/bin/bash
+# scratch A/B: headline step under environment switches
+for v in "DL_SIDE_WGS=64" "DL_SIDE_WGS=96" "DL_SIDE_WGS=128" "DL_SIDE_WGS=160" "DL_SIDE_WGS=128 DL_GEMM_TN_W4_XCD=0" "DL_SIDE_WGS=96 DL_GEMM_TN_W4_XCD=0"; do
+  echo "$v"
+  env DL_GEMM_TN_VARIANT=2 $v python scripts/train_step_bench.py s2 --batch 256 --steps 30 --warmup 8 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
+done

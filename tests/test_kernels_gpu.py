@@ -120,6 +120,21 @@ def test_gemm_tn(ops, R, M, N):
     assert rel(c, ref) < 2e-5
 
 
+@pytest.mark.parametrize("R,M,N,cap", [(8192, 1152, 384, 0), (8192, 384, 384, 128), (8192, 3072, 384, 128), (8192, 384, 1536, 0),
+                                         (2048 + 7 * 64, 768, 192, 64), (4096 + 64, 384, 576, 256)])
+def test_gemm_tn_ring_kernel(ops, R, M, N, cap):
+    """gemm_tn_w4_k (csrc/gemm_w4.hip: 384 x 192 tiles, four-slot operand ring, asm transposing reads) at the four weight-gradient
+    shapes of the headline DiT and at token counts that leave ragged last token ranges, with and without the workgroup cap;
+    leading dimensions wider than the operands (the engine hands it column windows of wider activations)"""
+    a = synth.normal(f"tnr.a{R}{M}", (R, M + 64))
+    b = synth.normal(f"tnr.b{R}{N}", (R, N + 128))
+    init = synth.normal(f"tnr.c{M}{N}", (M, N))
+    c = init.to(DEV).clone()
+    ops.gemm_tn(dev_bf(a)[:, 64:], dev_bf(b)[:, :N], c, max_wgs=cap)
+    ref = init + bf(a)[:, 64:].t() @ bf(b)[:, :N]
+    assert rel(c, ref) < 2e-5
+
+
 # ------------------------------------------------------------------ adaLN
 @pytest.mark.parametrize("D,affine", [(384, True), (768, True), (384, False), (128, True)])
 def test_ln_modulate_fwd_bwd(ops, D, affine):
