@@ -16,6 +16,7 @@
 #include "common.h"
 
 static int g_gemm_probe = 0;
+static int g_nt_pipe = -1;  // DL_GEMM_NT_PIPE (latched by the launcher): fragment software pipeline in gemm_nt_big_k
 extern "C" int dl_probe_gemm_set(int flags) {
   g_gemm_probe = flags;
   return DL_OK;
@@ -52,6 +53,7 @@ struct NtEpilogue {
   // persistent big-tile kernel only: start-up skew (in units of ~0.5 us per k-step of a tile) between groups of workgroups,
   // so that the store bursts of their tile epilogues do not hit HBM in lockstep
   int stagger;
+  int pipe;  // persistent big-tile kernel only: fragment software pipeline in the k-step (A/B switch DL_GEMM_NT_PIPE)
 };
 
 // implicit-GEMM view of a 3x3 / pad 1 convolution over NHWC rows: the A operand "cols[p, (tap, ci)]" is never materialised,
@@ -423,6 +425,33 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
     if (NST < 3 && s_it < total) stage_next();  // into the slot whose stage was consumed in iteration it-1
     const char* sa = smem + (it % NST) * STAGE;
     const char* sb = sa + TBM * 128;
+    if constexpr (PROBE == 64) {
+      // Fragment software pipeline: the weight fragment of MFMA pair (kk, j) is read TWO pairs ahead into a three-entry register
+      // ring and the two activation fragments of sub-step kk+1 during sub-step kk, each pair its own scheduling region -- the
+      // LDS latency of a fragment is covered by the four MFMAs in front of its first use instead of being waited for before
+      // every group of twelve (same 32 fragment registers as the unpipelined loop below).
+      bf16x8_t xq[2][2], wq[3];
+      auto rd_x = [&](int kk, int i) -> bf16x8_t {
+        return *(const bf16x8_t*)(sa + xrow[i] * 128 + ((((kk << 1) | hi) ^ ((xrow[i] >> 1) & 7)) << 4));
+      };
+      auto rd_w = [&](int kk, int j) -> bf16x8_t {
+        return *(const bf16x8_t*)(sb + wrow[j] * 128 + ((((kk << 1) | hi) ^ ((wrow[j] >> 1) & 7)) << 4));
+      };
+      xq[0][0] = rd_x(0, 0);
+      xq[0][1] = rd_x(0, 1);
+      wq[0] = rd_w(0, 0);
+      wq[1] = rd_w(0, 1);
+#pragma unroll
+      for (int s = 0; s < 4 * JN; ++s) {
+        const int kk = s / JN, j = s % JN;
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < 4 * JN) wq[(s + 2) % 3] = rd_w((s + 2) / JN, (s + 2) % JN);
+        if (kk < 3 && j < 2) xq[(kk + 1) & 1][j] = rd_x(kk + 1, j);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s % 3], xq[kk & 1][i], acc[j][i], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       bf16x8_t xf[2], wf[JN];
@@ -443,6 +472,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
 #pragma unroll
           for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
       }
+    }
     }
     if (NST >= 3 && s_it < total) stage_next();
     after_epi = false;
@@ -643,6 +673,10 @@ static int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, vo
     (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   }
+  if (g_nt_pipe < 0) {
+    const char* e = getenv("DL_GEMM_NT_PIPE");
+    g_nt_pipe = e ? atoi(e) : 1;
+  }
   const int ntiles = (int)((M / TBM) * (N / TN_));
   int grid = n_cu < ntiles ? n_cu : ntiles;
   grid &= ~7;
@@ -654,6 +688,7 @@ static int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, vo
     if (e) stagger_min = atoi(e);
   }
   NtEpilogue ep = ep_in;
+  ep.pipe = g_nt_pipe;
   ep.stagger = (ntiles >= stagger_min * grid) ? stagger : 0;  // pays only when every workgroup walks many tiles (measured: MLP-up)
 #define BIG_GO(E)                                                                                                     \
   hipLaunchKernelGGL((gemm_nt_big_k<TN_, NST, E>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)A, lda, (const bf16_t*)B, \
@@ -683,6 +718,28 @@ static int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, vo
     DL_LAUNCH_CHECK();
     return DL_OK;
    }
+  }
+  if constexpr (TN_ == 384 && NST == 2) {
+    if (g_nt_pipe) {
+#define PIPE_GO(E)                                                                                                       \
+  hipLaunchKernelGGL((gemm_nt_big_k<384, 2, E, 64>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)A, lda, (const bf16_t*)B, \
+                     ldb, C, ldc, (int)M, (int)N, (int)K, ep)
+      static bool pattr = false;
+      if (!pattr) {
+        pattr = true;
+        (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 0, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 3, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      }
+      if (epi == 0) PIPE_GO(0);
+      else if (epi == 1) PIPE_GO(1);
+      else if (epi == 2) PIPE_GO(2);
+      else PIPE_GO(3);
+#undef PIPE_GO
+      DL_LAUNCH_CHECK();
+      return DL_OK;
+    }
   }
   if (epi == 0) BIG_GO(0);
   else if (epi == 1) BIG_GO(1);

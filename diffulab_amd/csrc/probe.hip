@@ -151,6 +151,47 @@ __global__ __launch_bounds__(512, 2) void store_probe_k(bf16_t* __restrict__ out
     }
 }
 
+// DMA-pattern probe for the NT GEMM operand stream: 256 persistent workgroups x 8 waves walk the (256-row tile, k-step) space of
+// A[M, K] . B[384, K]^T exactly like gemm_nt_big_k<384,2,*> but only issue the direct-to-LDS loads (no LDS reads, no MFMAs):
+//   KB = 128: 64-deep k-steps, 128-byte row segments, 80 KiB stages, 2 ring slots (1 stage in flight);
+//   KB = 64 : 32-deep k-steps,  64-byte row segments (half a cache line per row and step), 40 KiB stages, 4 slots (3 in flight).
+template <int KB>
+__global__ __launch_bounds__(512, 2) void dma_probe_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bw, int M, int K,
+                                                        float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWS = 640, STAGE = ROWS * KB, NS = 163840 / STAGE, CH = STAGE / 1024 / 8, RPC = 1024 / KB, LPR = KB / 16;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nk = K * 2 / KB, ntiles = M / 256;
+  int it = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int kt = 0; kt < nk; ++kt, ++it) {
+      char* base = smem + (it % NS) * STAGE;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int c = wave * CH + i;
+        const int row = c * RPC + lane / LPR;  // 0..639: rows < 256 belong to the A tile, the rest to the 384 weight rows
+        const bf16_t* src = row < 256 ? A + (int64_t)(tile * 256 + row) * K : Bw + (int64_t)(row - 256) * K;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(src + kt * (KB / 2) + (lane % LPR) * 8), (lds_void_t*)(base + c * 1024), 16, 0, 0);
+      }
+      if (KB == 128) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * CH) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * CH) : "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  out[blockIdx.x * 512 + threadIdx.x] = ((float*)smem)[threadIdx.x];
+}
+extern "C" int dl_probe_dma(int kb, const void* A, const void* Bw, int64_t M, int64_t K, float* out, dl_stream_t stream) {
+  DL_CHECK_ARG(A && Bw && out && M % 256 == 0 && K % 64 == 0 && (kb == 64 || kb == 128), "dl_probe_dma: bad args");
+  (void)hipFuncSetAttribute((const void*)dma_probe_k<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+  (void)hipFuncSetAttribute((const void*)dma_probe_k<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+  if (kb == 128) hipLaunchKernelGGL(dma_probe_k<128>, 256, 512, 163840, (hipStream_t)stream, (const bf16_t*)A, (const bf16_t*)Bw, (int)M, (int)K, out);
+  else hipLaunchKernelGGL(dma_probe_k<64>, 256, 512, 163840, (hipStream_t)stream, (const bf16_t*)A, (const bf16_t*)Bw, (int)M, (int)K, out);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
 extern "C" int dl_probe_mfma(int mode, int iters, const void* src, float* out, dl_stream_t stream) {
   DL_CHECK_ARG(out && iters > 0 && mode >= 0 && mode <= 9 && (mode < 3 || mode > 7 || src), "dl_probe_mfma: bad args");
   if (mode >= 8) {  // store-pattern probe: out is a bf16 [65536, 1152] buffer

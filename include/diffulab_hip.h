@@ -507,6 +507,9 @@ DL_API int dl_probe_mfma_f8(const void* a, const void* b, float* d, dl_stream_t 
  * 1 = no epilogue stores / atomics, 2 = no MFMA, 4 = no operand DMA after the first stage, 8 = no LDS fragment reads
  * (5 and 10 combine them); 0 restores the product kernels.  scripts/gemm_probe.py */
 DL_API int dl_probe_gemm_set(int flags);
+/* tuning probe: the operand DMA stream of the 256 x 384 NT GEMM tile walk alone (kb = 128: 64-deep steps / 2 ring slots,
+ * kb = 64: 32-deep steps with 64-byte row segments / 4 ring slots); out: >= 256*512 floats */
+DL_API int dl_probe_dma(int kb, const void* A, const void* Bw, int64_t M, int64_t K, float* out, dl_stream_t stream);
 DL_API int dl_probe_mfma(int mode, int iters, const void* src, float* out, dl_stream_t stream);
 
 #ifdef __cplusplus
