@@ -1,15 +1,21 @@
-// Four-wave, 512-register GEMM generation (gfx950): ONE wave per SIMD owns a 192 x 96 (or 192 x 128) piece of the output tile.
+// Ring-buffered weight-gradient GEMM (gfx950): 384 x 192 output tiles, operand stages in a four-slot LDS ring.
 //
-// Why: the 8-wave kernels of gemm.hip (two waves per SIMD, 150-256 VGPRs each) walk their k-steps in lockstep and the component
-// probes show their phases adding up instead of overlapping: fragment reads + MFMAs alone take twice the
-// MFMA time, and the weight-gradient kernel (384 x 128 tile, 96 x 64 per wave) reads 160 KiB of LDS fragments and stages 64 KiB of
-// operands per 6.3 MFLOP.  With the whole 512-entry register file behind one wave:
-//   * the wave tile grows to 192 x 96: 144 KiB of fragment reads and 72 KiB of staged operands per 9.4 MFLOP (x0.60 / x0.75 per FLOP);
-//   * both fragment sets of a 16-deep sub-step are double buffered IN REGISTERS, so the transposing LDS reads of sub-step p+1 are
-//     issued between the MFMAs of sub-step p (explicit interleave through sched_group_barrier), not ahead of them;
-//   * operand stages are 32 tokens deep in a FOUR-slot ring: three stages (108 KiB) stay in flight under counted vmcnt waits
-//     instead of one, i.e. the direct-to-LDS DMA has three k-steps to land instead of less than one;
-//   * one barrier per stage, placed after the first MFMAs of the sub-step so the matrix pipe runs through the barrier skew.
+// Why a new kernel: the older weight-gradient kernels of gemm.hip (384 x 128 tile, 96 x 64 per wave, two ring slots) (a) read
+// 160 KiB of LDS fragments and stage 64 KiB of operands per 6.3 MFLOP and (b) never overlapped their operand DMA with their MFMAs
+// at all: behind a direct-to-LDS DMA the compiler's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of every compiler-visible
+// transposing LDS read (it cannot tell the read from the DMA's LDS target), so the stage prefetched for the NEXT k-step was waited
+// for before the current one was consumed.  Here:
+//   * the transposing reads are inline assembly without a memory operand, their lgkmcnt wait is explicit (W4_LANDED);
+//   * the wave tile is 96 x 96 (8 waves, two per SIMD, 212 VGPRs): 268 KiB of fragment reads and 144 KiB of staged operands per
+//     18.9 MFLOP (x0.56 / x0.75 per FLOP of the old kernel);
+//   * both fragment sets of a 16-deep sub-step are double buffered IN REGISTERS and the reads of sub-step p+1 are dealt out over
+//     the MFMA rows of sub-step p (one scheduling region per row);
+//   * operand stages are 32 tokens deep in a FOUR-slot ring: three stages (108 KiB) stay in flight under counted vmcnt waits;
+//   * one barrier per stage, placed after the first MFMA row of the sub-step so the matrix pipe runs through the barrier skew;
+//   * all tiles of one token range sit on ONE XCD: every operand byte crosses into exactly one L2.
+// WAVES = 4 (one wave per SIMD, 192 x 96 per wave, 288 accumulator registers) is kept for the record: the compiler holds MFMA
+// accumulators in the 256 AGPRs only and shuttles the remaining 32 through v_accvgpr moves every iteration (275 us vs 176 us on the
+// MLP-up weight gradient); DL_GEMM_TN_W4_WAVES=4 selects it.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -44,7 +50,8 @@ __device__ __forceinline__ void wait_vmcnt_w4() {
 
 // =====================================================================================================
 // gemm_tn_w4_k: C[Mo, No] (f32) += A[R, Mo]^T . B[R, No], reduction over tokens split over workgroups, f32 atomics.
-// Tile 384 (m) x BNW (n), BNW = 192 | 256; 4 waves as 2 (m) x 2 (n), each 192 x BNW/2 = 6 x (BNW/64) MFMA 32x32x16 tiles.
+// Tile 384 (m) x BNW (n), BNW = 192 (256 compiles for WAVES = 8 only on paper: 278 registers); WAVES/2 (m) x 2 (n) waves, each
+// 768/WAVES x BNW/2 = (24/WAVES) x (BNW/64) MFMA 32x32x16 tiles.
 // LDS images are the row-major [32 r][384 | BNW] slabs written by the DMA; fragments come out of ds_read_b64_tr_b16.  16-byte slot
 // swizzle per image row so that the 4 rows of one transposing read fall into 4 distinct 64-byte bank groups:
 //   768- and 512-byte rows (multiples of the 256-byte bank period): slot ^= (r & 3) << 2
