@@ -1,10 +1,7 @@
 #!/bin/bash
-export TMPDIR=/tmp
-OUT=$(pwd)/gpurun_out/joint_prof
-mkdir -p $OUT
-R=$(pwd)
-cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 $R/scripts/train_step_bench.py joint --batch 16 --steps 8 --warmup 4 > $OUT/kt.log 2>&1
-cd $R
-find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} python3 scripts/kernel_stats_summary.py {} 12 "joint B=16, 12 steps in trace" | head -30
-find $OUT -name "*kernel_trace.csv" -delete
+for v in "" "--hi-prio" "" "--hi-prio"; do
+  echo "flags: $v"
+  python scripts/train_step_bench.py s2 --batch 256 --steps 30 --warmup 8 $v 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
+done
+python -c "
+import torch; print(torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream,'priority_range') else 'n/a')"

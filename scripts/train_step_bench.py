@@ -60,6 +60,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--graph", action="store_true", help="the whole step as one hipGraph (training/graph_step.py)")
+    ap.add_argument("--hi-prio", action="store_true", help="run the step on a high-priority HIP stream (the engines' side stream keeps the default priority)")
     a = ap.parse_args()
     dev = "cuda"
     kw, shape = CFG[a.config]
@@ -113,6 +114,8 @@ def main() -> None:
             inputs = {"x": x0, "initial_context": ctx, "p": p} if ctx is not None else {"x": x0, "y": y, "p": p}
             gs(inputs, t, {"dst_features": dst} if dst is not None else {})
 
+    if a.hi_prio:
+        torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
