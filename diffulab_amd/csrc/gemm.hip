@@ -719,27 +719,25 @@ static int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, vo
     return DL_OK;
    }
   }
-  if constexpr (TN_ == 384 && NST == 2) {
-    if (g_nt_pipe) {
-#define PIPE_GO(E)                                                                                                       \
-  hipLaunchKernelGGL((gemm_nt_big_k<384, 2, E, 64>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)A, lda, (const bf16_t*)B, \
+  if (g_nt_pipe) {
+#define PIPE_GO(E)                                                                                                        \
+  hipLaunchKernelGGL((gemm_nt_big_k<TN_, NST, E, 64>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)A, lda, (const bf16_t*)B, \
                      ldb, C, ldc, (int)M, (int)N, (int)K, ep)
-      static bool pattr = false;
-      if (!pattr) {
-        pattr = true;
-        (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 0, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 3, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      }
-      if (epi == 0) PIPE_GO(0);
-      else if (epi == 1) PIPE_GO(1);
-      else if (epi == 2) PIPE_GO(2);
-      else PIPE_GO(3);
-#undef PIPE_GO
-      DL_LAUNCH_CHECK();
-      return DL_OK;
+    static bool pattr = false;
+    if (!pattr) {
+      pattr = true;
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 0, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 3, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     }
+    if (epi == 0) PIPE_GO(0);
+    else if (epi == 1) PIPE_GO(1);
+    else if (epi == 2) PIPE_GO(2);
+    else PIPE_GO(3);
+#undef PIPE_GO
+    DL_LAUNCH_CHECK();
+    return DL_OK;
   }
   if (epi == 0) BIG_GO(0);
   else if (epi == 1) BIG_GO(1);
