@@ -209,7 +209,7 @@ __global__ __launch_bounds__(512) void attn_fwd_k(const bf16_t* __restrict__ q, 
 // Same wave-level algorithm, but a workgroup owns a 256-row query chunk of one head and streams K / V through LDS in
 // 256-key chunks (online softmax across chunks); grid = B * H * N/256.
 #define ACH 256
-__global__ __launch_bounds__(512) void attn_fwd_tiled_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void attn_fwd_tiled_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                         const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
                                                         float* __restrict__ lse, int H, int Nq, int Nk, float scale,
                                                         const float* __restrict__ key_bias) {
