@@ -720,3 +720,241 @@ extern "C" int dl_attn_bwd_sv(const void* q, const void* k, const void* v, int64
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
+
+// ====================================================================================== small attention (UNet AttentionBlock)
+// n <= 64 tokens, head_dim a multiple of 64 up to 512 (unet.py:296-322: 8x8 and 4x4 feature maps, 256..512-wide heads): one
+// workgroup (4 waves) per (batch, head), every matmul on MFMA 32x32x16 in the transposed orientation of the kernels above.
+//   forward : S^T = K Q^T from global fragments (contraction over head_dim) -> LDS f32 -> row softmax (probabilities saved for the
+//             backward, as before) -> O^T = V^T P^T with V staged in LDS as head_dim/64 swizzled [64][64] tiles
+//   backward: dP^T = V dO^T from global fragments; dS = P o (dP - rowsum(P o dP)) * scale in LDS; then dV^T = dO^T P, dQ^T = K^T dS^T,
+//             dK^T = Q^T dS with dO / K / Q staged one after the other in the same LDS tiles
+// Rows >= n of a staged operand re-read row n-1 (finite) and meet probabilities that are exactly 0.
+#define ASM_PITCH 68  // floats per row of the LDS score matrices (16-byte aligned rows, bank skew)
+__device__ __forceinline__ void tile_dma_clamp(const bf16_t* __restrict__ g, int64_t pitch, char* tile, int nvalid, int wave,
+                                               int nwaves, int lane) {
+  for (int c = wave; c < 8; c += nwaves) {  // 64 rows
+    int r = c * 8 + (lane >> 3);
+    const int q = (lane & 7) ^ swz8(r);
+    r = r < nvalid ? r : nvalid - 1;
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(g + (int64_t)r * pitch + q * 8), (lds_void_t*)(tile + c * 1024), 16, 0, 0);
+  }
+}
+// B-operand fragment from a ROW of an LDS score matrix: lane & 31 = row, k-slot j of half hi <-> column cbase + (j&3) + 8(j>>2) + 4hi
+__device__ __forceinline__ bf16x8_t score_frag_row(const float* S, int row, int cbase, int hi) {
+  const float* p = S + row * ASM_PITCH + cbase + hi * 4;
+  const f32x4_t a = *(const f32x4_t*)p, b = *(const f32x4_t*)(p + 8);
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return pack_frag(v);
+}
+// ... from a COLUMN: lane & 31 = column, k-slot j of half hi <-> row rbase + (j&3) + 8(j>>2) + 4hi
+__device__ __forceinline__ bf16x8_t score_frag_col(const float* S, int col, int rbase, int hi) {
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = S[(rbase + (j & 3) + 8 * (j >> 2) + 4 * hi) * ASM_PITCH + col];
+  return pack_frag(v);
+}
+// transposed 32 x 32 accumulator (lane & 31 = token row, register r <-> column 8(r>>2) + 4hi + (r&3)) -> bf16, 8 bytes per store
+__device__ __forceinline__ void store_tile32(bf16_t* rowp, const f32x16_t& a, int hi) {
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    uint2 w;
+    w.x = pack2bf(a[g4 * 4 + 0], a[g4 * 4 + 1]);
+    w.y = pack2bf(a[g4 * 4 + 2], a[g4 * 4 + 3]);
+    *(uint2*)(rowp + g4 * 8 + hi * 4) = w;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_small_mfma_fwd_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                             const bf16_t* __restrict__ v, int64_t ldq, int64_t ldkv,
+                                                             bf16_t* __restrict__ out, int64_t ldo, float* __restrict__ probs,
+                                                             int n, int H, int dh, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* P = (float*)smem;
+  char* vt = smem + 64 * ASM_PITCH * 4;
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const bf16_t* qb = q + (int64_t)b * n * ldq + h * dh;
+  const bf16_t* kb = k + (int64_t)b * n * ldkv + h * dh;
+  const bf16_t* vb = v + (int64_t)b * n * ldkv + h * dh;
+  const int ncb = dh >> 6;
+  for (int cb = 0; cb < ncb; ++cb) tile_dma_clamp(vb + cb * 64, ldkv, vt + cb * 8192, n, wave, 4, lane);
+  {  // S^T tile (ti, tj) of this wave: lane & 31 = query, register r <-> key tj*32 + 8(r>>2) + 4hi + (r&3)
+    const int ti = wave >> 1, tj = wave & 1;
+    const int qi = ti * 32 + (lane & 31), kj = tj * 32 + (lane & 31);
+    const bf16_t* qrow = qb + (int64_t)(qi < n ? qi : n - 1) * ldq + hi * 8;
+    const bf16_t* krow = kb + (int64_t)(kj < n ? kj : n - 1) * ldkv + hi * 8;
+    f32x16_t st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    for (int ks = 0; ks < (dh >> 4); ++ks)
+      st = MFMA(*(const bf16x8_t*)(krow + ks * 16), *(const bf16x8_t*)(qrow + ks * 16), st);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      f32x4_t w = {st[g4 * 4] * scale, st[g4 * 4 + 1] * scale, st[g4 * 4 + 2] * scale, st[g4 * 4 + 3] * scale};
+      *(f32x4_t*)(P + qi * ASM_PITCH + tj * 32 + g4 * 8 + hi * 4) = w;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x < 64) {  // row softmax; rows / columns beyond n become exact zeros
+    const int i = threadIdx.x;
+    float* pr = P + i * ASM_PITCH;
+    if (i < n) {
+      float m = -INFINITY;
+      for (int j = 0; j < n; ++j) m = fmaxf(m, pr[j]);
+      float l = 0.f;
+      for (int j = 0; j < n; ++j) {
+        const float e = __expf(pr[j] - m);
+        pr[j] = e;
+        l += e;
+      }
+      const float inv = 1.0f / l;
+      float* gp = probs + (((int64_t)b * H + h) * n + i) * n;
+      for (int j = 0; j < n; ++j) {
+        pr[j] *= inv;
+        gp[j] = pr[j];
+      }
+      for (int j = n; j < 64; ++j) pr[j] = 0.f;
+    } else {
+      for (int j = 0; j < 64; ++j) pr[j] = 0.f;
+    }
+  }
+  __syncthreads();
+  const int ntile = 2 * (dh >> 5);  // O^T tiles: (token half, 32-column block)
+  for (int t = wave; t < ntile; t += 4) {
+    const int th = t & 1, c32 = t >> 1;
+    const int i = th * 32 + (lane & 31);
+    f32x16_t o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg)
+      o = MFMA(frag_cols(vt + (c32 >> 1) * 8192, kg * 16, (c32 & 1) * 32, lane), score_frag_row(P, i, kg * 16, hi), o);
+    if (i < n) store_tile32(out + ((int64_t)b * n + i) * ldo + h * dh + c32 * 32, o, hi);
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_small_mfma_bwd_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                             const bf16_t* __restrict__ v, int64_t ldq, int64_t ldkv,
+                                                             const bf16_t* __restrict__ dout, int64_t ldo,
+                                                             const float* __restrict__ probs, bf16_t* __restrict__ dq,
+                                                             bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int n, int H, int dh,
+                                                             float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* P = (float*)smem;
+  float* dS = P + 64 * ASM_PITCH;
+  char* tt = smem + 2 * 64 * ASM_PITCH * 4;
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const bf16_t* qb = q + (int64_t)b * n * ldq + h * dh;
+  const bf16_t* kb = k + (int64_t)b * n * ldkv + h * dh;
+  const bf16_t* vb = v + (int64_t)b * n * ldkv + h * dh;
+  const bf16_t* dob = dout + (int64_t)b * n * ldo + h * dh;
+  const int ncb = dh >> 6, ntile = 2 * (dh >> 5);
+  for (int cb = 0; cb < ncb; ++cb) tile_dma_clamp(dob + cb * 64, ldo, tt + cb * 8192, n, wave, 4, lane);
+  const float* gp = probs + ((int64_t)b * H + h) * n * n;
+  for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+    const int i = idx >> 6, j = idx & 63;
+    P[i * ASM_PITCH + j] = (i < n && j < n) ? gp[i * n + j] : 0.f;
+  }
+  {  // dP^T tile of this wave = V dO^T: lane & 31 = query, registers <-> keys
+    const int ti = wave >> 1, tj = wave & 1;
+    const int qi = ti * 32 + (lane & 31), kj = tj * 32 + (lane & 31);
+    const bf16_t* drow = dob + (int64_t)(qi < n ? qi : n - 1) * ldo + hi * 8;
+    const bf16_t* vrow = vb + (int64_t)(kj < n ? kj : n - 1) * ldkv + hi * 8;
+    f32x16_t dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+    for (int ks = 0; ks < (dh >> 4); ++ks)
+      dp = MFMA(*(const bf16x8_t*)(vrow + ks * 16), *(const bf16x8_t*)(drow + ks * 16), dp);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      f32x4_t w = {dp[g4 * 4], dp[g4 * 4 + 1], dp[g4 * 4 + 2], dp[g4 * 4 + 3]};
+      *(f32x4_t*)(dS + qi * ASM_PITCH + tj * 32 + g4 * 8 + hi * 4) = w;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x < 64) {  // dS = P o (dP - rowsum(P o dP)) * scale; P is zero outside [n, n], hence so is dS
+    const int i = threadIdx.x;
+    float dot = 0.f;
+    for (int j = 0; j < 64; ++j) dot += P[i * ASM_PITCH + j] * dS[i * ASM_PITCH + j];
+    for (int j = 0; j < 64; ++j) dS[i * ASM_PITCH + j] = P[i * ASM_PITCH + j] * (dS[i * ASM_PITCH + j] - dot) * scale;
+  }
+  __syncthreads();
+  // dV^T = dO^T P: contraction over queries, lane & 31 = key
+  for (int t = wave; t < ntile; t += 4) {
+    const int th = t & 1, c32 = t >> 1;
+    const int j = th * 32 + (lane & 31);
+    f32x16_t a;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg)
+      a = MFMA(frag_cols(tt + (c32 >> 1) * 8192, kg * 16, (c32 & 1) * 32, lane), score_frag_col(P, j, kg * 16, hi), a);
+    if (j < n) store_tile32(dv + ((int64_t)b * n + j) * ldkv + h * dh + c32 * 32, a, hi);
+  }
+  __syncthreads();
+  for (int cb = 0; cb < ncb; ++cb) tile_dma_clamp(kb + cb * 64, ldkv, tt + cb * 8192, n, wave, 4, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // dQ^T = K^T dS^T: contraction over keys, lane & 31 = query
+  for (int t = wave; t < ntile; t += 4) {
+    const int th = t & 1, c32 = t >> 1;
+    const int i = th * 32 + (lane & 31);
+    f32x16_t a;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg)
+      a = MFMA(frag_cols(tt + (c32 >> 1) * 8192, kg * 16, (c32 & 1) * 32, lane), score_frag_row(dS, i, kg * 16, hi), a);
+    if (i < n) store_tile32(dq + ((int64_t)b * n + i) * ldq + h * dh + c32 * 32, a, hi);
+  }
+  __syncthreads();
+  for (int cb = 0; cb < ncb; ++cb) tile_dma_clamp(qb + cb * 64, ldq, tt + cb * 8192, n, wave, 4, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // dK^T = Q^T dS: contraction over queries, lane & 31 = key
+  for (int t = wave; t < ntile; t += 4) {
+    const int th = t & 1, c32 = t >> 1;
+    const int j = th * 32 + (lane & 31);
+    f32x16_t a;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg)
+      a = MFMA(frag_cols(tt + (c32 >> 1) * 8192, kg * 16, (c32 & 1) * 32, lane), score_frag_col(dS, j, kg * 16, hi), a);
+    if (j < n) store_tile32(dk + ((int64_t)b * n + j) * ldkv + h * dh + c32 * 32, a, hi);
+  }
+}
+
+// launchers for dl_attn_small_{fwd,bwd} (csrc/unet.hip); false: the shape is not theirs (head_dim % 64, > 512)
+bool launch_attn_small_mfma_fwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldkv, void* out, int64_t ldo,
+                                float* probs, int64_t B, int64_t n, int64_t H, int64_t dh, float scale, hipStream_t stream) {
+  if (dh % 64 || dh > 512 || n > 64 || ldq % 8 || ldkv % 8 || ldo % 4) return false;
+  const int lds = 64 * ASM_PITCH * 4 + (int)dh * 128;
+  static bool attr = false;
+  if (!attr) {
+    attr = true;
+    (void)hipFuncSetAttribute((const void*)attn_small_mfma_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * ASM_PITCH * 4 + 512 * 128);
+  }
+  hipLaunchKernelGGL(attn_small_mfma_fwd_k, (int)(B * H), 256, lds, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq,
+                     ldkv, (bf16_t*)out, ldo, probs, (int)n, (int)H, (int)dh, scale);
+  return true;
+}
+bool launch_attn_small_mfma_bwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldkv, const void* dout,
+                                int64_t ldo, const float* probs, void* dq, void* dk, void* dv, int64_t B, int64_t n, int64_t H,
+                                int64_t dh, float scale, hipStream_t stream) {
+  if (dh % 64 || dh > 512 || n > 64 || ldq % 8 || ldkv % 8 || ldo % 8) return false;
+  const int lds = 2 * 64 * ASM_PITCH * 4 + (int)dh * 128;
+  static bool attr = false;
+  if (!attr) {
+    attr = true;
+    (void)hipFuncSetAttribute((const void*)attn_small_mfma_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * ASM_PITCH * 4 + 512 * 128);
+  }
+  hipLaunchKernelGGL(attn_small_mfma_bwd_k, (int)(B * H), 256, lds, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq,
+                     ldkv, (const bf16_t*)dout, ldo, probs, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, (int)n, (int)H, (int)dh, scale);
+  return true;
+}

@@ -668,10 +668,28 @@ __global__ __launch_bounds__(256) void attn_small_bwd_k(const bf16_t* __restrict
     *(u32x4_t*)(dv + o * ldkv + h * dh + dc) = pack8(gv);
   }
 }
+// MFMA form for head_dim % 64 == 0 up to 512 (csrc/attention.hip); DL_ATTN_SMALL_MFMA=0 keeps the f32 VALU kernels below
+bool launch_attn_small_mfma_fwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldkv, void* out, int64_t ldo,
+                                float* probs, int64_t B, int64_t n, int64_t H, int64_t dh, float scale, hipStream_t stream);
+bool launch_attn_small_mfma_bwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldkv, const void* dout,
+                                int64_t ldo, const float* probs, void* dq, void* dk, void* dv, int64_t B, int64_t n, int64_t H,
+                                int64_t dh, float scale, hipStream_t stream);
+static bool attn_small_use_mfma() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("DL_ATTN_SMALL_MFMA");
+    on = e ? atoi(e) : 1;
+  }
+  return on != 0;
+}
 extern "C" int dl_attn_small_fwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldkv, void* out, int64_t ldo,
                                  float* probs, int64_t B, int64_t n, int64_t H, int64_t dh, float scale, dl_stream_t stream) {
   DL_CHECK_ARG(q && k && v && out && probs && B > 0 && n > 0 && n <= AS_MAXN && dh % 8 == 0, "dl_attn_small_fwd: n=%lld dh=%lld",
                (long long)n, (long long)dh);
+  if (attn_small_use_mfma() && launch_attn_small_mfma_fwd(q, k, v, ldq, ldkv, out, ldo, probs, B, n, H, dh, scale, (hipStream_t)stream)) {
+    DL_LAUNCH_CHECK();
+    return DL_OK;
+  }
   hipLaunchKernelGGL(attn_small_fwd_k, (int)(B * H), 256, 0, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k,
                      (const bf16_t*)v, ldq, ldkv, (bf16_t*)out, ldo, probs, (int)n, (int)H, (int)dh, scale);
   DL_LAUNCH_CHECK();
@@ -682,6 +700,11 @@ extern "C" int dl_attn_small_bwd(const void* q, const void* k, const void* v, in
                                  int64_t dh, float scale, dl_stream_t stream) {
   DL_CHECK_ARG(q && k && v && dout && probs && dq && dk && dv && B > 0 && n > 0 && n <= AS_MAXN && dh % 8 == 0,
                "dl_attn_small_bwd: bad args");
+  if (attn_small_use_mfma() &&
+      launch_attn_small_mfma_bwd(q, k, v, ldq, ldkv, dout, ldo, probs, dq, dk, dv, B, n, H, dh, scale, (hipStream_t)stream)) {
+    DL_LAUNCH_CHECK();
+    return DL_OK;
+  }
   hipLaunchKernelGGL(attn_small_bwd_k, (int)(B * H), 256, 0, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k,
                      (const bf16_t*)v, ldq, ldkv, (const bf16_t*)dout, ldo, probs, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, (int)n,
                      (int)H, (int)dh, scale);
