@@ -97,10 +97,14 @@ __device__ __forceinline__ float wave_max(float v) {
   return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 0)), __int_as_float(__builtin_amdgcn_readlane(i, 16))),
                fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 32)), __int_as_float(__builtin_amdgcn_readlane(i, 48))));
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// sigmoid through v_rcp_f32 (1 ulp): the IEEE division sequence (v_div_scale / v_div_fmas / v_div_fixup, ~10 VALU instructions)
+// was most of the arithmetic of the GroupNorm / SwiGLU kernels and of the fused-SwiGLU GEMM epilogue; the result is rounded to
+// bf16 right after
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 // d/dx [x * sigmoid(x)]
 __device__ __forceinline__ float dsilu_f(float x) {
-  float s = 1.0f / (1.0f + __expf(-x));
+  const float s = sigmoid_f(x);
   return s * (1.0f + x * (1.0f - s));
 }
 

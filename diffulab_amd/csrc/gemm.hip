@@ -1604,6 +1604,11 @@ extern "C" int dl_conv3x3_wgrad_tn(const void* x, int64_t ldx, int64_t Bn, int64
       (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
       if (n_cu <= 0) n_cu = 256;
       (void)hipFuncSetAttribute((const void*)gemm_tn_big_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE);
+      // the UNet engine runs these on its side stream beside the GroupNorm / convolution chain: like the DiT weight gradients
+      // they leave part of the chip to it (DL_CONV_WGRAD_WGS, default 192 of 256 workgroups; 0 = no cap: 35.4 ms, 192: 34.9, 128: 36.5, 64: 40.4)
+      const char* e = getenv("DL_CONV_WGRAD_WGS");
+      const int cap = e ? atoi(e) : 192;
+      if (cap > 0 && cap < n_cu) n_cu = cap;
     }
     if (M % WBM == 0 && N % WBN == 0 && nsteps >= 64) {  // same unit / split budget as dl_gemm_tn
       const int tiles_m = (int)(M / WBM), tiles_n = (int)(N / WBN);

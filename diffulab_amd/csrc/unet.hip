@@ -114,13 +114,16 @@ extern "C" int dl_gn_stats(const void* x, float* stats, int64_t B, int64_t HW, i
 // out = act( (xhat*w+b) * (1+scale) + shift ), elementwise over [B*HW, C], 8 channels per thread
 __global__ void gn_apply_fwd_k(const bf16_t* __restrict__ x, const float* __restrict__ st, const float* __restrict__ w,
                                const float* __restrict__ bb, const bf16_t* __restrict__ fs, const bf16_t* __restrict__ fh,
-                               int64_t ldf, int silu, bf16_t* __restrict__ out, int64_t n8, int HW, int C, int G) {
-  const int cg = C / G, C8 = C >> 3;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % C8) * 8;
-    const int b = (int)(i / ((int64_t)HW * C8));
+                               int64_t ldf, int silu, bf16_t* __restrict__ out, int HW, int C, int G) {
+  // grid: x walks the HW*C/8 16-byte chunks of ONE sample (blockIdx.y): every index fits 32 bits, and the per-element group
+  // lookup is one division per chunk (64-bit % and / per chunk plus a division per element made these kernels VALU-bound)
+  const unsigned cg = C / G, C8 = C >> 3, per = (unsigned)HW * C8;
+  const int b = blockIdx.y;
+  const int64_t base = (int64_t)b * per;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < per; i += gridDim.x * blockDim.x) {
+    const unsigned c0 = (i % C8) * 8;
     float v[8], wv[8], bv[8];
-    unpack8(*(const u32x4_t*)(x + i * 8), v);
+    unpack8(*(const u32x4_t*)(x + (base + i) * 8), v);
     *(f32x4_t*)&wv[0] = *(const f32x4_t*)(w + c0);
     *(f32x4_t*)&wv[4] = *(const f32x4_t*)(w + c0 + 4);
     *(f32x4_t*)&bv[0] = *(const f32x4_t*)(bb + c0);
@@ -130,15 +133,32 @@ __global__ void gn_apply_fwd_k(const bf16_t* __restrict__ x, const float* __rest
       unpack8(*(const u32x4_t*)(fs + (int64_t)b * ldf + c0), sc);
       unpack8(*(const u32x4_t*)(fh + (int64_t)b * ldf + c0), sh);
     }
+    unsigned g = c0 / cg, rem = c0 - g * cg;
+    const float* sg = st + ((int64_t)b * G + g) * 2;
+    float mu = sg[0], r = sg[1];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float* sg = st + ((int64_t)b * G + (c0 + e) / cg) * 2;
-      float y = (v[e] - sg[0]) * sg[1] * wv[e] + bv[e];
+      if (rem == cg) {  // next group
+        rem = 0;
+        sg += 2;
+        mu = sg[0];
+        r = sg[1];
+      }
+      ++rem;
+      float y = (v[e] - mu) * r * wv[e] + bv[e];
       if (fs) y = y * (1.0f + sc[e]) + sh[e];
       v[e] = silu ? silu_f(y) : y;
     }
-    *(u32x4_t*)(out + i * 8) = pack8(v);
+    *(u32x4_t*)(out + (base + i) * 8) = pack8(v);
   }
+}
+// x-extent of the per-sample grids above: enough workgroups of 256 to cover a sample once, capped so that B * gx stays moderate
+static inline dim3 gn_grid(int64_t B, int64_t per) {
+  int64_t gx = (per + 255) / 256;
+  const int64_t cap = B >= 4096 ? 1 : 4096 / B;
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  return dim3((unsigned)gx, (unsigned)B);
 }
 extern "C" int dl_gn_apply_fwd(const void* x, const float* stats, const float* w, const float* b, const void* film_scale,
                                const void* film_shift, int64_t ld_film, int act_silu, void* out, int64_t B, int64_t HW,
@@ -148,29 +168,30 @@ extern "C" int dl_gn_apply_fwd(const void* x, const float* stats, const float* w
   DL_CHECK_ARG((((uintptr_t)x | (uintptr_t)out | (uintptr_t)w | (uintptr_t)b | (uintptr_t)film_scale | (uintptr_t)film_shift) & 15) == 0 &&
                    ld_film % 8 == 0,
                "dl_gn_apply_fwd: 16-byte alignment");
-  const int64_t n8 = B * HW * C / 8;
-  hipLaunchKernelGGL(gn_apply_fwd_k, grid_for(n8), 256, 0, (hipStream_t)stream, (const bf16_t*)x, stats, w, b,
-                     (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, (bf16_t*)out, n8, (int)HW, (int)C,
+  DL_CHECK_ARG(B < 65536 && HW * C / 8 < (1ll << 31), "dl_gn_apply_fwd: B < 65536, HW*C/8 < 2^31");
+  hipLaunchKernelGGL(gn_apply_fwd_k, gn_grid(B, HW * C / 8), 256, 0, (hipStream_t)stream, (const bf16_t*)x, stats, w, b,
+                     (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, (bf16_t*)out, (int)HW, (int)C,
                      (int)G);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
 
 // backward pass 1: per (b, c) sums over pixels:  S[b][0][c] = sum dh*y, [1] = sum dh, [2] = sum dy*xhat, [3] = sum dy
-// (dh = dout * act'(h), dy = dh * (1+scale)).  One workgroup per (b, 64-channel slab): 8 chunks x 32 pixel lanes, LDS float
-// atomics fold the pixel lanes; dw / db meet in global f32 atomics (B contributions per channel), FiLM gradients are written.
+// (dh = dout * act'(h), dy = dh * (1+scale)).  One workgroup per (b, 64-channel slab, pixel range): 8 chunks x 32 pixel lanes,
+// two pixels per lane and iteration in flight; the pixel ranges (gridDim.y of them, so that small batches still fill the chip)
+// write PARTIAL sums Sp[range][b][4][C], which gn_group_sums_k adds up (dw / db included: one global atomic per sample and channel).
 __global__ __launch_bounds__(256) void gn_bwd_reduce_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
                                                        const float* __restrict__ st, const float* __restrict__ w,
                                                        const float* __restrict__ bb, const bf16_t* __restrict__ fs,
                                                        const bf16_t* __restrict__ fh, int64_t ldf, int silu,
-                                                       float* __restrict__ S, float* __restrict__ dw, float* __restrict__ db,
-                                                       bf16_t* __restrict__ dfs, bf16_t* __restrict__ dfh, int64_t lddf, int HW,
-                                                       int C, int G) {
+                                                       float* __restrict__ Sp, int B, int HW, int C, int G) {
   __shared__ float red[4][64];
   const int slabs = (C + 63) / 64;
   const int b = blockIdx.x / slabs, cbase = (blockIdx.x % slabs) * 64;
   const int chunk = threadIdx.x & 7, pl = threadIdx.x >> 3;  // 8 chunks x 32 pixel lanes
   const int c0_raw = cbase + chunk * 8;
+  const int ppr = (HW + gridDim.y - 1) / gridDim.y;  // pixels per range
+  const int p_lo = blockIdx.y * ppr, p_hi = (p_lo + ppr < HW) ? p_lo + ppr : HW;
   (&red[0][0])[threadIdx.x] = 0.f;
   __syncthreads();
   {
@@ -191,11 +212,10 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_k(const bf16_t* __restrict_
       sh[e] = fs ? bf2f(fh[(int64_t)b * ldf + c0 + e]) : 0.f;
       a0[e] = a1[e] = a2[e] = a3[e] = 0.f;
     }
-    for (int p = pl; p < HW; p += 32) {
-      const int64_t i = ((int64_t)b * HW + p) * C + c0;
+    auto accum = [&](const u32x4_t& xr, const u32x4_t& dr) {
       float xv[8], dv[8];
-      unpack8(*(const u32x4_t*)(x + i), xv);
-      unpack8(*(const u32x4_t*)(dout + i), dv);
+      unpack8(xr, xv);
+      unpack8(dr, dv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float xh = (xv[e] - mu[e]) * rs[e];
@@ -208,6 +228,18 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_k(const bf16_t* __restrict_
         a2[e] += dy * xh;
         a3[e] += dy;
       }
+    };
+    int p = p_lo + pl;
+    for (; p + 32 < p_hi; p += 64) {  // two pixels of this lane in flight
+      const int64_t i0 = ((int64_t)b * HW + p) * C + c0, i1 = i0 + (int64_t)32 * C;
+      const u32x4_t x0 = *(const u32x4_t*)(x + i0), d0 = *(const u32x4_t*)(dout + i0);
+      const u32x4_t x1 = *(const u32x4_t*)(x + i1), d1 = *(const u32x4_t*)(dout + i1);
+      accum(x0, d0);
+      accum(x1, d1);
+    }
+    if (p < p_hi) {
+      const int64_t i0 = ((int64_t)b * HW + p) * C + c0;
+      accum(*(const u32x4_t*)(x + i0), *(const u32x4_t*)(dout + i0));
     }
     // fold the 8 pixel lanes of this wave (lane bits 3..5) with shuffles, then one LDS atomic per (wave, value)
 #pragma unroll
@@ -233,43 +265,61 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_k(const bf16_t* __restrict_
   __syncthreads();
   if (threadIdx.x < 64 && cbase + (int)threadIdx.x < C) {
     const int c = cbase + threadIdx.x;
+    float* S = Sp + (int64_t)blockIdx.y * B * 4 * C;
 #pragma unroll
     for (int k = 0; k < 4; ++k) S[((int64_t)b * 4 + k) * C + c] = red[k][threadIdx.x];
-    if (dfs) {
-      dfs[(int64_t)b * lddf + c] = f2bf(red[0][threadIdx.x]);
-      dfh[(int64_t)b * lddf + c] = f2bf(red[1][threadIdx.x]);
-    }
-    unsafeAtomicAdd(&dw[c], red[2][threadIdx.x]);
-    unsafeAtomicAdd(&db[c], red[3][threadIdx.x]);
   }
 }
-// per (b, g): A = sum_{c in g} w[c] S[3][c], Bv = sum_{c in g} w[c] S[2][c]
-__global__ void gn_group_sums_k(const float* __restrict__ S, const float* __restrict__ w, float* __restrict__ AB, int C, int G) {
+// per sample: add the pixel-range partials; FiLM gradients dfs = S[0], dfh = S[1] (bf16); per group g:
+// A = sum_{c in g} w[c] S[3][c], Bv = sum_{c in g} w[c] S[2][c]
+__global__ __launch_bounds__(256) void gn_group_sums_k(const float* __restrict__ Sp, int nsplit, int B, const float* __restrict__ w,
+                                                       float* __restrict__ AB, float* __restrict__ dw, float* __restrict__ db,
+                                                       bf16_t* __restrict__ dfs, bf16_t* __restrict__ dfh, int64_t lddf, int C,
+                                                       int G) {
+  __shared__ float ab[GN_MAXG][2];
   const int cg = C / G;
-  const int b = blockIdx.x, g = threadIdx.x;
-  if (g >= G) return;
-  float A = 0.f, Bv = 0.f;
-  for (int c = g * cg; c < (g + 1) * cg; ++c) {
-    A += w[c] * S[((int64_t)b * 4 + 3) * C + c];
-    Bv += w[c] * S[((int64_t)b * 4 + 2) * C + c];
+  const int b = blockIdx.x;
+  if (threadIdx.x < 2 * GN_MAXG) (&ab[0][0])[threadIdx.x] = 0.f;
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < nsplit; ++r) {
+      const float* S = Sp + ((int64_t)r * B + b) * 4 * C;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s[k] += S[(int64_t)k * C + c];
+    }
+    if (dfs) {
+      dfs[(int64_t)b * lddf + c] = f2bf(s[0]);
+      dfh[(int64_t)b * lddf + c] = f2bf(s[1]);
+    }
+    unsafeAtomicAdd(&dw[c], s[2]);
+    unsafeAtomicAdd(&db[c], s[3]);
+    atomicAdd(&ab[c / cg][0], w[c] * s[3]);
+    atomicAdd(&ab[c / cg][1], w[c] * s[2]);
   }
-  AB[((int64_t)b * G + g) * 2] = A;
-  AB[((int64_t)b * G + g) * 2 + 1] = Bv;
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    AB[((int64_t)b * G + threadIdx.x) * 2] = ab[threadIdx.x][0];
+    AB[((int64_t)b * G + threadIdx.x) * 2 + 1] = ab[threadIdx.x][1];
+  }
 }
 // backward pass 2: dx = r * (dy*w - A/n - xhat*Bv/n) (+ dres), 8 channels per thread
 __global__ void gn_bwd_apply_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x, const float* __restrict__ st,
                                const float* __restrict__ w, const float* __restrict__ bb, const bf16_t* __restrict__ fs,
                                const bf16_t* __restrict__ fh, int64_t ldf, int silu, const float* __restrict__ AB,
-                               const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, int64_t n8, int HW, int C, int G) {
-  const int cg = C / G, C8 = C >> 3;
+                               const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, int HW, int C, int G) {
+  // (grid and index arithmetic as in gn_apply_fwd_k: one sample per blockIdx.y, 32-bit indices, one group lookup per run)
+  const unsigned cg = C / G, C8 = C >> 3, per = (unsigned)HW * C8;
   const float inv_n = 1.0f / (float)(HW * cg);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % C8) * 8;
-    const int b = (int)(i / ((int64_t)HW * C8));
+  const int b = blockIdx.y;
+  const int64_t base = (int64_t)b * per;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < per; i += gridDim.x * blockDim.x) {
+    const unsigned c0 = (i % C8) * 8;
+    const int64_t o = (base + i) * 8;
     float xv[8], dv[8], rv[8], sc[8], sh[8];
-    unpack8(*(const u32x4_t*)(x + i * 8), xv);
-    unpack8(*(const u32x4_t*)(dout + i * 8), dv);
-    if (dres) unpack8(*(const u32x4_t*)(dres + i * 8), rv);
+    unpack8(*(const u32x4_t*)(x + o), xv);
+    unpack8(*(const u32x4_t*)(dout + o), dv);
+    if (dres) unpack8(*(const u32x4_t*)(dres + o), rv);
     if (fs) {
       unpack8(*(const u32x4_t*)(fs + (int64_t)b * ldf + c0), sc);
       unpack8(*(const u32x4_t*)(fh + (int64_t)b * ldf + c0), sh);
@@ -279,51 +329,63 @@ __global__ void gn_bwd_apply_k(const bf16_t* __restrict__ dout, const bf16_t* __
     *(f32x4_t*)&wv[4] = *(const f32x4_t*)(w + c0 + 4);
     *(f32x4_t*)&bv[0] = *(const f32x4_t*)(bb + c0);
     *(f32x4_t*)&bv[4] = *(const f32x4_t*)(bb + c0 + 4);
-    int g_prev = -1;
-    float mu = 0.f, r = 0.f, A = 0.f, Bv = 0.f;
+    unsigned g = c0 / cg, rem = c0 - g * cg;
+    const float* sg = st + ((int64_t)b * G + g) * 2;
+    const float* ag = AB + ((int64_t)b * G + g) * 2;
+    float mu = sg[0], r = sg[1], A = ag[0] * inv_n, Bv = ag[1] * inv_n;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int g = (c0 + e) / cg;
-      if (g != g_prev) {  // one f32x2 pair of loads per group run (a single run when C/G >= 8)
-        const float* sg = st + ((int64_t)b * G + g) * 2;
-        const float* ag = AB + ((int64_t)b * G + g) * 2;
+      if (rem == cg) {  // next group
+        rem = 0;
+        sg += 2;
+        ag += 2;
         mu = sg[0];
         r = sg[1];
         A = ag[0] * inv_n;
         Bv = ag[1] * inv_n;
-        g_prev = g;
       }
+      ++rem;
       const float xh = (xv[e] - mu) * r;
       const float s1 = fs ? 1.0f + sc[e] : 1.0f;
       const float h = (xh * wv[e] + bv[e]) * s1 + (fs ? sh[e] : 0.f);
       const float dy = dv[e] * (silu ? dsilu_f(h) : 1.0f) * s1;
       xv[e] = r * (dy * wv[e] - A - xh * Bv) + (dres ? rv[e] : 0.f);
     }
-    *(u32x4_t*)(dx + i * 8) = pack8(xv);
+    *(u32x4_t*)(dx + o) = pack8(xv);
   }
 }
-/* scratch: f32 [B*4*C + B*G*2] */
+// pixel ranges of gn_bwd_reduce_k: enough workgroups to fill the chip at small batch x channel counts, at least 64 pixels each
+static inline int gn_bwd_ranges(int64_t B, int64_t HW, int64_t C) {
+  const int64_t slabs = (C + 63) / 64;
+  int64_t ns = 1024 / (B * slabs);
+  if (ns > HW / 64) ns = HW / 64;
+  if (ns > DL_GN_BWD_MAX_RANGES) ns = DL_GN_BWD_MAX_RANGES;
+  return ns < 1 ? 1 : (int)ns;
+}
+/* scratch: f32 [DL_GN_BWD_MAX_RANGES * B*4*C + B*G*2] */
 extern "C" int dl_gn_bwd(const void* dout, const void* x, const float* stats, const float* w, const float* b,
                          const void* film_scale, const void* film_shift, int64_t ld_film, int act_silu, const void* dres,
                          void* dx, float* dw, float* db, void* dfilm_scale, void* dfilm_shift, int64_t ld_dfilm, float* scratch, int64_t B,
                          int64_t HW, int64_t C, int64_t G, dl_stream_t stream) {
-  DL_CHECK_ARG(dout && x && stats && w && b && dx && dw && db && scratch && B > 0 && C % G == 0 && C % 8 == 0 && G <= 256,
+  DL_CHECK_ARG(dout && x && stats && w && b && dx && dw && db && scratch && B > 0 && C % G == 0 && C % 8 == 0 && G <= GN_MAXG,
                "dl_gn_bwd: bad args");
   DL_CHECK_ARG((film_scale == nullptr) == (dfilm_scale == nullptr), "dl_gn_bwd: film grads iff film inputs");
   DL_CHECK_ARG((((uintptr_t)dout | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dres | (uintptr_t)film_scale | (uintptr_t)film_shift) & 15) == 0 &&
                    ld_film % 8 == 0,
                "dl_gn_bwd: 16-byte alignment");
-  float* S = scratch;
-  float* AB = scratch + B * 4 * C;
+  DL_CHECK_ARG(B < 65536 && HW * C / 8 < (1ll << 31), "dl_gn_bwd: B < 65536, HW*C/8 < 2^31");
+  const int ns = gn_bwd_ranges(B, HW, C);
+  float* Sp = scratch;
+  float* AB = scratch + (int64_t)DL_GN_BWD_MAX_RANGES * B * 4 * C;
   const int slabs = (int)((C + 63) / 64);
-  hipLaunchKernelGGL(gn_bwd_reduce_k, (int)B * slabs, 256, 0, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)x, stats, w,
-                     b, (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, S, dw, db, (bf16_t*)dfilm_scale,
-                     (bf16_t*)dfilm_shift, ld_dfilm, (int)HW, (int)C, (int)G);
-  hipLaunchKernelGGL(gn_group_sums_k, (int)B, 256, 0, (hipStream_t)stream, S, w, AB, (int)C, (int)G);
-  const int64_t n8 = B * HW * C / 8;
-  hipLaunchKernelGGL(gn_bwd_apply_k, grid_for(n8), 256, 0, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)x, stats, w, b,
-                     (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, AB, (const bf16_t*)dres,
-                     (bf16_t*)dx, n8, (int)HW, (int)C, (int)G);
+  hipLaunchKernelGGL(gn_bwd_reduce_k, dim3((unsigned)(B * slabs), (unsigned)ns), 256, 0, (hipStream_t)stream, (const bf16_t*)dout,
+                     (const bf16_t*)x, stats, w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, Sp,
+                     (int)B, (int)HW, (int)C, (int)G);
+  hipLaunchKernelGGL(gn_group_sums_k, (int)B, 256, 0, (hipStream_t)stream, Sp, ns, (int)B, w, AB, dw, db, (bf16_t*)dfilm_scale,
+                     (bf16_t*)dfilm_shift, ld_dfilm, (int)C, (int)G);
+  hipLaunchKernelGGL(gn_bwd_apply_k, gn_grid(B, HW * C / 8), 256, 0, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)x, stats,
+                     w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, AB, (const bf16_t*)dres,
+                     (bf16_t*)dx, (int)HW, (int)C, (int)G);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

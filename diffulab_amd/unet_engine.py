@@ -436,7 +436,7 @@ class UNetEngine:
         dx = self._new(B * HW, C)
         fs, fh = film if film is not None else (None, None)
         dfs, dfh = dfilm if dfilm is not None else (None, None)
-        scr = self._scr("gn", B * 4 * C + B * self.G * 2, torch.float32)
+        scr = self._scr("gn", 8 * B * 4 * C + B * self.G * 2, torch.float32)  # DL_GN_BWD_MAX_RANGES partial-sum slabs
         ops.gn_bwd(dout, x, stats, self.P(wname + "weight"), self.P(wname + "bias"), fs, fh, silu, dres, dx,
                    self.Gr(wname + "weight"), self.Gr(wname + "bias"), dfs, dfh, scr, B, HW, C, self.G)
         return dx

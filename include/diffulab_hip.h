@@ -380,7 +380,9 @@ DL_API int dl_gn_apply_fwd(const void* x, const float* stats, const float* w, co
                            int64_t C, int64_t G, dl_stream_t stream);
 /* backward of dl_gn_stats + dl_gn_apply_fwd: dx bf16 (= gradient through the norm + dres when dres != NULL: the residual /
  * skip fan-in of ResBlock and AttentionBlock), dw/db f32 [C] ACCUMULATED (+=), dfilm_* bf16 [B, ld_dfilm] written
- * (required iff film_* given).  scratch: f32 [B*4*C + B*G*2] */
+ * (required iff film_* given).  scratch: f32 [DL_GN_BWD_MAX_RANGES * B*4*C + B*G*2] (partial sums of the pixel ranges the
+ * reduction is split into, then the per-group sums) */
+#define DL_GN_BWD_MAX_RANGES 8
 DL_API int dl_gn_bwd(const void* dout, const void* x, const float* stats, const float* w, const float* b,
                      const void* film_scale, const void* film_shift, int64_t ld_film, int act_silu, const void* dres,
                      void* dx, float* dw, float* db, void* dfilm_scale, void* dfilm_shift, int64_t ld_dfilm, float* scratch, int64_t B,
