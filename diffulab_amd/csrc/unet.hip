@@ -180,19 +180,24 @@ extern "C" int dl_gn_apply_fwd(const void* x, const float* stats, const float* w
 // (dh = dout * act'(h), dy = dh * (1+scale)).  One workgroup per (b, 64-channel slab, pixel range): 8 chunks x 32 pixel lanes,
 // two pixels per lane and iteration in flight; the pixel ranges (gridDim.y of them, so that small batches still fill the chip)
 // write PARTIAL sums Sp[range][b][4][C], which gn_group_sums_k adds up (dw / db included: one global atomic per sample and channel).
+// NCH = 16-byte channel chunks per workgroup (256 / NCH pixel lanes): 8 for the high-resolution levels (64-channel slabs, 32 pixel
+// lanes), 64 for feature maps of <= 64 pixels (512-channel slabs, 4 pixel lanes: a wave reads 1 KiB of ONE pixel row and a
+// thread's per-channel setup is spread over 4-16 pixels instead of half a pixel)
+template <int NCH>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
                                                        const float* __restrict__ st, const float* __restrict__ w,
                                                        const float* __restrict__ bb, const bf16_t* __restrict__ fs,
                                                        const bf16_t* __restrict__ fh, int64_t ldf, int silu,
                                                        float* __restrict__ Sp, int B, int HW, int C, int G) {
-  __shared__ float red[4][64];
-  const int slabs = (C + 63) / 64;
-  const int b = blockIdx.x / slabs, cbase = (blockIdx.x % slabs) * 64;
-  const int chunk = threadIdx.x & 7, pl = threadIdx.x >> 3;  // 8 chunks x 32 pixel lanes
+  constexpr int SLAB = NCH * 8, PL = 256 / NCH;
+  __shared__ float red[4][SLAB];
+  const int slabs = (C + SLAB - 1) / SLAB;
+  const int b = blockIdx.x / slabs, cbase = (blockIdx.x % slabs) * SLAB;
+  const int chunk = threadIdx.x % NCH, pl = threadIdx.x / NCH;  // NCH chunks x PL pixel lanes
   const int c0_raw = cbase + chunk * 8;
   const int ppr = (HW + gridDim.y - 1) / gridDim.y;  // pixels per range
   const int p_lo = blockIdx.y * ppr, p_hi = (p_lo + ppr < HW) ? p_lo + ppr : HW;
-  (&red[0][0])[threadIdx.x] = 0.f;
+  for (int i = threadIdx.x; i < 4 * SLAB; i += 256) (&red[0][0])[i] = 0.f;
   __syncthreads();
   {
     // (slabs beyond C: chunks with c0 >= C compute on channel 0 of the slab and are dropped at the end, so that every
@@ -230,8 +235,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_k(const bf16_t* __restrict_
       }
     };
     int p = p_lo + pl;
-    for (; p + 32 < p_hi; p += 64) {  // two pixels of this lane in flight
-      const int64_t i0 = ((int64_t)b * HW + p) * C + c0, i1 = i0 + (int64_t)32 * C;
+    for (; p + PL < p_hi; p += 2 * PL) {  // two pixels of this lane in flight
+      const int64_t i0 = ((int64_t)b * HW + p) * C + c0, i1 = i0 + (int64_t)PL * C;
       const u32x4_t x0 = *(const u32x4_t*)(x + i0), d0 = *(const u32x4_t*)(dout + i0);
       const u32x4_t x1 = *(const u32x4_t*)(x + i1), d1 = *(const u32x4_t*)(dout + i1);
       accum(x0, d0);
@@ -241,18 +246,19 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_k(const bf16_t* __restrict_
       const int64_t i0 = ((int64_t)b * HW + p) * C + c0;
       accum(*(const u32x4_t*)(x + i0), *(const u32x4_t*)(dout + i0));
     }
-    // fold the 8 pixel lanes of this wave (lane bits 3..5) with shuffles, then one LDS atomic per (wave, value)
+    // fold the pixel lanes of this wave (lane bits log2(NCH)..5; none when a wave is one pixel row) with shuffles, then one LDS
+    // atomic per (wave, value)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
 #pragma unroll
-      for (int m = 8; m < 64; m <<= 1) {
+      for (int m = NCH; m < 64; m <<= 1) {
         a0[e] += __shfl_xor(a0[e], m);
         a1[e] += __shfl_xor(a1[e], m);
         a2[e] += __shfl_xor(a2[e], m);
         a3[e] += __shfl_xor(a3[e], m);
       }
     }
-    if ((threadIdx.x & 63) < 8 && live) {
+    if ((int)(threadIdx.x & 63) < NCH && live) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         atomicAdd(&red[0][chunk * 8 + e], a0[e]);
@@ -263,11 +269,10 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_k(const bf16_t* __restrict_
     }
   }
   __syncthreads();
-  if (threadIdx.x < 64 && cbase + (int)threadIdx.x < C) {
-    const int c = cbase + threadIdx.x;
-    float* S = Sp + (int64_t)blockIdx.y * B * 4 * C;
+  float* S = Sp + (int64_t)blockIdx.y * B * 4 * C;
+  for (int i = threadIdx.x; i < SLAB && cbase + i < C; i += 256) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) S[((int64_t)b * 4 + k) * C + c] = red[k][threadIdx.x];
+    for (int k = 0; k < 4; ++k) S[((int64_t)b * 4 + k) * C + cbase + i] = red[k][i];
   }
 }
 // per sample: add the pixel-range partials; FiLM gradients dfs = S[0], dfh = S[1] (bf16); per group g:
@@ -276,31 +281,37 @@ __global__ __launch_bounds__(256) void gn_group_sums_k(const float* __restrict__
                                                        float* __restrict__ AB, float* __restrict__ dw, float* __restrict__ db,
                                                        bf16_t* __restrict__ dfs, bf16_t* __restrict__ dfh, int64_t lddf, int C,
                                                        int G) {
-  __shared__ float ab[GN_MAXG][2];
+  // 8 threads per group (one aligned lane octet), each walking every 8th channel of the group; the group sums meet in three
+  // shuffles -- no LDS atomics (64 channels of one group hitting one LDS word made this kernel as slow as the reduction itself)
   const int cg = C / G;
-  const int b = blockIdx.x;
-  if (threadIdx.x < 2 * GN_MAXG) (&ab[0][0])[threadIdx.x] = 0.f;
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < nsplit; ++r) {
-      const float* S = Sp + ((int64_t)r * B + b) * 4 * C;
+  const int b = blockIdx.x, k = threadIdx.x & 7;
+  for (int g = threadIdx.x >> 3; g < G; g += 32) {
+    float A = 0.f, Bv = 0.f;
+    for (int c = g * cg + k; c < (g + 1) * cg; c += 8) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < nsplit; ++r) {
+        const float* S = Sp + ((int64_t)r * B + b) * 4 * C;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) s[k] += S[(int64_t)k * C + c];
+        for (int q = 0; q < 4; ++q) s[q] += S[(int64_t)q * C + c];
+      }
+      if (dfs) {
+        dfs[(int64_t)b * lddf + c] = f2bf(s[0]);
+        dfh[(int64_t)b * lddf + c] = f2bf(s[1]);
+      }
+      unsafeAtomicAdd(&dw[c], s[2]);
+      unsafeAtomicAdd(&db[c], s[3]);
+      A += w[c] * s[3];
+      Bv += w[c] * s[2];
     }
-    if (dfs) {
-      dfs[(int64_t)b * lddf + c] = f2bf(s[0]);
-      dfh[(int64_t)b * lddf + c] = f2bf(s[1]);
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      A += __shfl_xor(A, m);
+      Bv += __shfl_xor(Bv, m);
     }
-    unsafeAtomicAdd(&dw[c], s[2]);
-    unsafeAtomicAdd(&db[c], s[3]);
-    atomicAdd(&ab[c / cg][0], w[c] * s[3]);
-    atomicAdd(&ab[c / cg][1], w[c] * s[2]);
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < G) {
-    AB[((int64_t)b * G + threadIdx.x) * 2] = ab[threadIdx.x][0];
-    AB[((int64_t)b * G + threadIdx.x) * 2 + 1] = ab[threadIdx.x][1];
+    if (k == 0) {
+      AB[((int64_t)b * G + g) * 2] = A;
+      AB[((int64_t)b * G + g) * 2 + 1] = Bv;
+    }
   }
 }
 // backward pass 2: dx = r * (dy*w - A/n - xhat*Bv/n) (+ dres), 8 channels per thread
@@ -356,8 +367,13 @@ __global__ void gn_bwd_apply_k(const bf16_t* __restrict__ dout, const bf16_t* __
 }
 // pixel ranges of gn_bwd_reduce_k: enough workgroups to fill the chip at small batch x channel counts, at least 64 pixels each
 static inline int gn_bwd_ranges(int64_t B, int64_t HW, int64_t C) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("DL_GN_BWD_RANGES");  // tuning switch: force the number of pixel ranges (1 = none)
+    forced = e ? atoi(e) : 0;
+  }
   const int64_t slabs = (C + 63) / 64;
-  int64_t ns = 1024 / (B * slabs);
+  int64_t ns = forced > 0 ? forced : 1024 / (B * slabs);
   if (ns > HW / 64) ns = HW / 64;
   if (ns > DL_GN_BWD_MAX_RANGES) ns = DL_GN_BWD_MAX_RANGES;
   return ns < 1 ? 1 : (int)ns;
@@ -374,13 +390,19 @@ extern "C" int dl_gn_bwd(const void* dout, const void* x, const float* stats, co
                    ld_film % 8 == 0,
                "dl_gn_bwd: 16-byte alignment");
   DL_CHECK_ARG(B < 65536 && HW * C / 8 < (1ll << 31), "dl_gn_bwd: B < 65536, HW*C/8 < 2^31");
-  const int ns = gn_bwd_ranges(B, HW, C);
   float* Sp = scratch;
   float* AB = scratch + (int64_t)DL_GN_BWD_MAX_RANGES * B * 4 * C;
-  const int slabs = (int)((C + 63) / 64);
-  hipLaunchKernelGGL(gn_bwd_reduce_k, dim3((unsigned)(B * slabs), (unsigned)ns), 256, 0, (hipStream_t)stream, (const bf16_t*)dout,
-                     (const bf16_t*)x, stats, w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, Sp,
-                     (int)B, (int)HW, (int)C, (int)G);
+  int ns = 1;
+  if (HW <= 64 && C >= 512) {
+    hipLaunchKernelGGL(gn_bwd_reduce_k<64>, dim3((unsigned)(B * ((C + 511) / 512)), 1u), 256, 0, (hipStream_t)stream,
+                       (const bf16_t*)dout, (const bf16_t*)x, stats, w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift,
+                       ld_film, act_silu, Sp, (int)B, (int)HW, (int)C, (int)G);
+  } else {
+    ns = gn_bwd_ranges(B, HW, C);
+    hipLaunchKernelGGL(gn_bwd_reduce_k<8>, dim3((unsigned)(B * ((C + 63) / 64)), (unsigned)ns), 256, 0, (hipStream_t)stream,
+                       (const bf16_t*)dout, (const bf16_t*)x, stats, w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift,
+                       ld_film, act_silu, Sp, (int)B, (int)HW, (int)C, (int)G);
+  }
   hipLaunchKernelGGL(gn_group_sums_k, (int)B, 256, 0, (hipStream_t)stream, Sp, ns, (int)B, w, AB, dw, db, (bf16_t*)dfilm_scale,
                      (bf16_t*)dfilm_shift, ld_dfilm, (int)C, (int)G);
   hipLaunchKernelGGL(gn_bwd_apply_k, gn_grid(B, HW * C / 8), 256, 0, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)x, stats,
