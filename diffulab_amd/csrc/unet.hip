@@ -183,14 +183,27 @@ extern "C" int dl_gn_apply_fwd(const void* x, const float* stats, const float* w
 // NCH = 16-byte channel chunks per workgroup (256 / NCH pixel lanes): 8 for the high-resolution levels (64-channel slabs, 32 pixel
 // lanes), 64 for feature maps of <= 64 pixels (512-channel slabs, 4 pixel lanes: a wave reads 1 KiB of ONE pixel row and a
 // thread's per-channel setup is spread over 4-16 pixels instead of half a pixel)
-template <int NCH>
+// FUSED (NCH = 64 only, every group of the slab inside it, one pixel range): the workgroup owns whole groups of one sample, so the
+// group sums and the dx pass (gn_group_sums_k + gn_bwd_apply_k) follow in the same launch -- three latency-bound launches of
+// 5-30 us on a few megabytes become one; x / dout are re-read through L2.
+struct GnFused {
+  float* dw;
+  float* db;
+  bf16_t* dfs;
+  bf16_t* dfh;
+  int64_t lddf;
+  const bf16_t* dres;
+  bf16_t* dx;
+};
+template <int NCH, bool FUSED = false>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
                                                        const float* __restrict__ st, const float* __restrict__ w,
                                                        const float* __restrict__ bb, const bf16_t* __restrict__ fs,
                                                        const bf16_t* __restrict__ fh, int64_t ldf, int silu,
-                                                       float* __restrict__ Sp, int B, int HW, int C, int G) {
+                                                       float* __restrict__ Sp, int B, int HW, int C, int G, GnFused fz) {
   constexpr int SLAB = NCH * 8, PL = 256 / NCH;
   __shared__ float red[4][SLAB];
+  __shared__ float ab[FUSED ? 64 : 1][2];
   const int slabs = (C + SLAB - 1) / SLAB;
   const int b = blockIdx.x / slabs, cbase = (blockIdx.x % slabs) * SLAB;
   const int chunk = threadIdx.x % NCH, pl = threadIdx.x / NCH;  // NCH chunks x PL pixel lanes
@@ -269,10 +282,68 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_k(const bf16_t* __restrict_
     }
   }
   __syncthreads();
-  float* S = Sp + (int64_t)blockIdx.y * B * 4 * C;
-  for (int i = threadIdx.x; i < SLAB && cbase + i < C; i += 256) {
+  if constexpr (!FUSED) {
+    float* S = Sp + (int64_t)blockIdx.y * B * 4 * C;
+    for (int i = threadIdx.x; i < SLAB && cbase + i < C; i += 256) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) S[((int64_t)b * 4 + k) * C + cbase + i] = red[k][i];
+      for (int k = 0; k < 4; ++k) S[((int64_t)b * 4 + k) * C + cbase + i] = red[k][i];
+    }
+  } else {
+    const int cg = C / G;
+    const int nch = (C - cbase < SLAB) ? C - cbase : SLAB;  // channels of this slab (a whole number of groups)
+    for (int i = threadIdx.x; i < nch; i += 256) {
+      const int c = cbase + i;
+      if (fz.dfs) {
+        fz.dfs[(int64_t)b * fz.lddf + c] = f2bf(red[0][i]);
+        fz.dfh[(int64_t)b * fz.lddf + c] = f2bf(red[1][i]);
+      }
+      unsafeAtomicAdd(&fz.dw[c], red[2][i]);
+      unsafeAtomicAdd(&fz.db[c], red[3][i]);
+    }
+    const float inv_n = 1.0f / (float)(HW * cg);
+    if ((int)threadIdx.x < nch / cg) {
+      float A = 0.f, Bv = 0.f;
+      for (int j = 0; j < cg; ++j) {
+        const int i = threadIdx.x * cg + j;
+        A += w[cbase + i] * red[3][i];
+        Bv += w[cbase + i] * red[2][i];
+      }
+      ab[threadIdx.x][0] = A * inv_n;
+      ab[threadIdx.x][1] = Bv * inv_n;
+    }
+    __syncthreads();
+    if (c0_raw < C) {
+      const int c0 = c0_raw;
+      float mu[8], rs[8], wv[8], bv[8], sc[8], sh[8], gA[8], gB[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float* sg = st + ((int64_t)b * G + (c0 + e) / cg) * 2;
+        mu[e] = sg[0];
+        rs[e] = sg[1];
+        wv[e] = w[c0 + e];
+        bv[e] = bb[c0 + e];
+        sc[e] = fs ? bf2f(fs[(int64_t)b * ldf + c0 + e]) : 0.f;
+        sh[e] = fs ? bf2f(fh[(int64_t)b * ldf + c0 + e]) : 0.f;
+        gA[e] = ab[(c0 + e - cbase) / cg][0];
+        gB[e] = ab[(c0 + e - cbase) / cg][1];
+      }
+      for (int p = pl; p < HW; p += PL) {
+        const int64_t o = ((int64_t)b * HW + p) * C + c0;
+        float xv[8], dv[8], rv[8];
+        unpack8(*(const u32x4_t*)(x + o), xv);
+        unpack8(*(const u32x4_t*)(dout + o), dv);
+        if (fz.dres) unpack8(*(const u32x4_t*)(fz.dres + o), rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (xv[e] - mu[e]) * rs[e];
+          const float s1 = 1.0f + sc[e];
+          const float h = (xh * wv[e] + bv[e]) * s1 + sh[e];
+          const float dy = dv[e] * (silu ? dsilu_f(h) : 1.0f) * s1;
+          xv[e] = rs[e] * (dy * wv[e] - gA[e] - xh * gB[e]) + (fz.dres ? rv[e] : 0.f);
+        }
+        *(u32x4_t*)(fz.dx + o) = pack8(xv);
+      }
+    }
   }
 }
 // per sample: add the pixel-range partials; FiLM gradients dfs = S[0], dfh = S[1] (bf16); per group g:
@@ -365,6 +436,14 @@ __global__ void gn_bwd_apply_k(const bf16_t* __restrict__ dout, const bf16_t* __
     *(u32x4_t*)(dx + o) = pack8(xv);
   }
 }
+static bool gn_bwd_fused() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("DL_GN_BWD_FUSED");  // A/B switch: 0 = the three-launch form for every shape
+    on = e ? atoi(e) : 1;
+  }
+  return on != 0;
+}
 // pixel ranges of gn_bwd_reduce_k: enough workgroups to fill the chip at small batch x channel counts, at least 64 pixels each
 static inline int gn_bwd_ranges(int64_t B, int64_t HW, int64_t C) {
   static int forced = -1;
@@ -393,15 +472,24 @@ extern "C" int dl_gn_bwd(const void* dout, const void* x, const float* stats, co
   float* Sp = scratch;
   float* AB = scratch + (int64_t)DL_GN_BWD_MAX_RANGES * B * 4 * C;
   int ns = 1;
-  if (HW <= 64 && C >= 512) {
-    hipLaunchKernelGGL(gn_bwd_reduce_k<64>, dim3((unsigned)(B * ((C + 511) / 512)), 1u), 256, 0, (hipStream_t)stream,
+  const GnFused none{};
+  if (HW <= 64 && C >= 512 && 512 % (C / G) == 0 && gn_bwd_fused()) {
+    const GnFused fz{dw, db, (bf16_t*)dfilm_scale, (bf16_t*)dfilm_shift, ld_dfilm, (const bf16_t*)dres, (bf16_t*)dx};
+    hipLaunchKernelGGL((gn_bwd_reduce_k<64, true>), dim3((unsigned)(B * ((C + 511) / 512)), 1u), 256, 0, (hipStream_t)stream,
                        (const bf16_t*)dout, (const bf16_t*)x, stats, w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift,
-                       ld_film, act_silu, Sp, (int)B, (int)HW, (int)C, (int)G);
+                       ld_film, act_silu, Sp, (int)B, (int)HW, (int)C, (int)G, fz);
+    DL_LAUNCH_CHECK();
+    return DL_OK;
+  }
+  if (HW <= 64 && C >= 512) {
+    hipLaunchKernelGGL((gn_bwd_reduce_k<64>), dim3((unsigned)(B * ((C + 511) / 512)), 1u), 256, 0, (hipStream_t)stream,
+                       (const bf16_t*)dout, (const bf16_t*)x, stats, w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift,
+                       ld_film, act_silu, Sp, (int)B, (int)HW, (int)C, (int)G, none);
   } else {
     ns = gn_bwd_ranges(B, HW, C);
-    hipLaunchKernelGGL(gn_bwd_reduce_k<8>, dim3((unsigned)(B * ((C + 63) / 64)), (unsigned)ns), 256, 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((gn_bwd_reduce_k<8>), dim3((unsigned)(B * ((C + 63) / 64)), (unsigned)ns), 256, 0, (hipStream_t)stream,
                        (const bf16_t*)dout, (const bf16_t*)x, stats, w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift,
-                       ld_film, act_silu, Sp, (int)B, (int)HW, (int)C, (int)G);
+                       ld_film, act_silu, Sp, (int)B, (int)HW, (int)C, (int)G, none);
   }
   hipLaunchKernelGGL(gn_group_sums_k, (int)B, 256, 0, (hipStream_t)stream, Sp, ns, (int)B, w, AB, dw, db, (bf16_t*)dfilm_scale,
                      (bf16_t*)dfilm_shift, ld_dfilm, (int)C, (int)G);
