@@ -481,6 +481,29 @@ extern "C" int dl_cast_f32_to_bf16(const float* src, void* dst, int64_t n, dl_st
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
+// strided rows: dst[r, c] = bf16(src[r, c]) for r < rows, c < cols (cols % 4 == 0; both row strides in elements)
+__global__ void cast2d_f2b_k(const float* __restrict__ s, int64_t lds, bf16_t* __restrict__ d, int64_t ldd, int64_t rows, int cols4) {
+  const int64_t n = rows * cols4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols4;
+    const int c = (int)(i - r * cols4) * 4;
+    const f32x4_t v = *(const f32x4_t*)(s + r * lds + c);
+    uint2 o;
+    o.x = pack2bf(v[0], v[1]);
+    o.y = pack2bf(v[2], v[3]);
+    *(uint2*)(d + r * ldd + c) = o;
+  }
+}
+extern "C" int dl_cast2d_f32_to_bf16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int64_t cols,
+                                     dl_stream_t stream) {
+  DL_CHECK_ARG(src && dst && rows > 0 && cols > 0 && cols % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 &&
+                   (((uintptr_t)src & 15) | ((uintptr_t)dst & 7)) == 0,
+               "dl_cast2d_f32_to_bf16: cols, strides %% 4 and 16 / 8-byte alignment");
+  hipLaunchKernelGGL(cast2d_f2b_k, ew_grid(rows * cols / 4), 256, 0, (hipStream_t)stream, src, ld_src, (bf16_t*)dst, ld_dst, rows,
+                     (int)(cols / 4));
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
 extern "C" int dl_cast_bf16_to_f32(const void* src, float* dst, int64_t n, dl_stream_t stream) {
   DL_CHECK_ARG(src && dst && n > 0, "dl_cast_bf16_to_f32: bad args");
   hipLaunchKernelGGL(cast_b2f_k, ew_grid(n), 256, 0, (hipStream_t)stream, (const bf16_t*)src, dst, n);

@@ -590,6 +590,33 @@ class DiTEngine:
                 side.wait_event(ev)
                 ops.reduce_rows_f32(partial, self.G(gname), B, 2 * D, clear=True)
 
+        # Data parallel: the stacked adaLN matrix (L*6D x E, a quarter of the parameters) would only be final in _cond_bwd, i.e. its
+        # 42 MB would be reduced after the backward has ended.  Every block's 6D rows of the modulation gradient are final when that
+        # block's backward is (its MLP gate chunk was written by the block above), so the block's slice of the weight gradient is
+        # computed right there on the side stream and handed to the reducer with the block's own range; the last three blocks ask
+        # for an immediate flush, which leaves a few megabytes for finish().
+        early_mod = self.reducer is not None and type(self) is DiTEngine and os.environ.get("DL_DP_EARLY_MOD", "1") != "0"
+        self._early_mod_done = early_mod
+        w_mod = self.layout.entries[self.mod_name][0]
+        b_mod = self.layout.entries[self.layout.mod_b0][0]
+        E = d.embedding_dim
+
+        def block_done(i: int) -> None:
+            if self.reducer is None:
+                return
+            if early_mod:
+                r0, r1 = i * 6 * D, (i + 1) * 6 * D
+                ev = main.record_event()
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    ops.cast2d_f32_to_bf16(w["dmod32"][:B, r0:r1], w["dmod"][:B, r0:r1])
+                    ops.gemm_tn(w["dmod"][:, r0:r1], w["se"], self.grads[w_mod + r0 * E : w_mod + r1 * E].view(r1 - r0, E))
+                    ops.colsum(w["dmod"][:, r0:r1], self.grads[b_mod + r0 : b_mod + r1], B, r1 - r0)
+            ev_side = side.record_event()
+            self.reducer.ready(*self.layer_ranges[i], extra_events=(ev_side,))
+            if early_mod:
+                self.reducer.ready(w_mod + i * 6 * D * E, w_mod + (i + 1) * 6 * D * E, flush=i < 3)
+
         # fused MLP-down dgrad + SwiGLU backward (dH never written): 32 % less HBM traffic than the GEMM + elementwise pair
         fused_dswiglu = os.environ.get("DL_FUSED_DSWIGLU", "0") == "1"
         native = self._native_blocks() and not fused_dswiglu and not serial and dx is w["dxa"]
@@ -598,8 +625,7 @@ class DiTEngine:
                 blk = self._block_args(i, True)
                 blk.set(dfeat=dfeats.get(i - 1))
                 ops.dit_block_bwd(blk, main.cuda_stream, side.cuda_stream, side_wgs)
-                if self.reducer is not None:
-                    self.reducer.ready(*self.layer_ranges[i], extra_events=(side.record_event(),))
+                block_done(i)
                 continue
             a = w["layers"][i]
             g = w["wg"][i]
@@ -647,8 +673,7 @@ class DiTEngine:
                                 dmod[:, mo + D : mo + 2 * D], w["dwb"][2 * i], **nxt)
             fold_norm(w["dwb"][2 * i], pre + "norm_1.weight")
             dx, dx_alt = dx_alt, dx
-            if self.reducer is not None:  # this block's gradient range is final once BOTH streams are past this point
-                self.reducer.ready(*self.layer_ranges[i], extra_events=(side.record_event(),))
+            block_done(i)  # this block's gradient range is final once BOTH streams are past this point
         if os.environ.get("DL_TAIL_PROBE") == "1":  # how long the side stream's wgrads run on after the main chain is done
             e_main, e_side = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e_main.record(main)
@@ -679,10 +704,17 @@ class DiTEngine:
         R = self.layout.mod_rows
         g_modw = self.grads[self.layout.entries[self.mod_name][0] :][: R * E].view(R, E)
         g_modb = self.grads[self.layout.entries[self.layout.mod_b0][0] :][:R]
-        ops.cast_f32_to_bf16(dmod[:B], w["dmod"][:B])
-        dmod = w["dmod"]
-        ops.gemm_tn(dmod, w["se"], g_modw)
-        ops.colsum(dmod, g_modb, B, R)
+        L6 = len(self.prefixes) * 6 * D if getattr(self, "_early_mod_done", False) else 0
+        if L6:  # the blocks' rows were cast, multiplied and handed to the reducer as the blocks finished (backward: block_done)
+            ops.cast2d_f32_to_bf16(dmod[:B, L6:], w["dmod"][:B, L6:])
+            dmod = w["dmod"]
+            ops.gemm_tn(dmod[:, L6:], w["se"], g_modw[L6:])
+            ops.colsum(dmod[:, L6:], g_modb[L6:], B, R - L6)
+        else:
+            ops.cast_f32_to_bf16(dmod[:B], w["dmod"][:B])
+            dmod = w["dmod"]
+            ops.gemm_tn(dmod, w["se"], g_modw)
+            ops.colsum(dmod, g_modb, B, R)
         ops.gemm_nt(dmod, sh["@mod|t"], w["dse"], M=B, N=E, K=R)
         table = d.n_classes is not None
         ops.cond_combine_bwd(w["dse"][:B], w["emb"][:B], self._yeff if table else None, w["demb"][:B], w["demb16"][:B],
@@ -697,5 +729,10 @@ class DiTEngine:
         ops.gemm_tn(w["dpre1"], w["temb"], self.G("time_embed.0.weight"))
         ops.colsum(w["dpre1"], self.G("time_embed.0.bias"), B, E)
         if self.reducer is not None:
-            self.reducer.ready(0, self.layer_ranges[0][0])
+            if L6:
+                w_mod = self.layout.entries[self.mod_name][0]
+                self.reducer.ready(0, w_mod)
+                self.reducer.ready(w_mod + L6 * E, self.layer_ranges[0][0])
+            else:
+                self.reducer.ready(0, self.layer_ranges[0][0])
             self.reducer.finish()

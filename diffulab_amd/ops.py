@@ -499,6 +499,11 @@ def cast_f32_to_bf16(src, dst):
     _call("dl_cast_f32_to_bf16", _p(src), _p(dst), src.numel(), _s())
 
 
+def cast2d_f32_to_bf16(src, dst):
+    """dst[r, c] = bf16(src[r, c]) over 2-D views whose rows may be windows of wider rows"""
+    _call("dl_cast2d_f32_to_bf16", _p(src), src.stride(0), _p(dst), dst.stride(0), src.shape[0], src.shape[1], _s())
+
+
 def cast_bf16_to_f32(src, dst):
     _call("dl_cast_bf16_to_f32", _p(src), _p(dst), src.numel(), _s())
 

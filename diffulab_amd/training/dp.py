@@ -44,27 +44,41 @@ class GradReducer:
         self.tail_events: list[tuple] = []
 
     # -- called by the engine's backward, ranges arrive high-to-low as blocks finish
-    def ready(self, lo: int, hi: int, extra_events=()) -> None:
-        """[lo, hi) of the arena is final once the current stream AND `extra_events` (side-stream producers) are reached."""
+    def ready(self, lo: int, hi: int, extra_events=(), flush: bool = False) -> None:
+        """[lo, hi) of the arena is final once the current stream AND `extra_events` (side-stream producers) are reached.
+        flush: reduce what is pending now even if the bucket is not full (the engine asks for it on the last blocks of the
+        backward, so that what is left for finish() -- the exposed part of the exchange -- is small)."""
         if not (self.enabled and self.sync):
             return
-        self._pending.append((lo, hi))
+        if hi > lo:
+            self._pending.append((lo, hi))
         self._extra.extend(extra_events)
-        if sum(h - l for l, h in self._pending) >= self.bucket_elems:
+        if flush or sum(h - l for l, h in self._pending) >= self.bucket_elems:
             self._flush()
 
     def _flush(self) -> None:
+        """one all-reduce per contiguous run of the pending ranges (a block's own parameters and its slice of the stacked adaLN
+        matrix sit in different parts of the arena)"""
         if not self._pending:
             return
-        lo = min(l for l, _ in self._pending)
-        hi = max(h for _, h in self._pending)
-        assert sum(h - l for l, h in self._pending) == hi - lo, "gradient ranges of one bucket must be contiguous"
+        runs: list[list[int]] = []
+        for lo, hi in sorted(self._pending):
+            if runs and lo <= runs[-1][1]:
+                assert lo == runs[-1][1], "gradient ranges handed to the reducer must not overlap"
+                runs[-1][1] = hi
+            else:
+                runs.append([lo, hi])
         self._pending.clear()
+        for i, (lo, hi) in enumerate(runs):
+            self._reduce(lo, hi, first=(i == 0))
+
+    def _reduce(self, lo: int, hi: int, first: bool) -> None:
         chunk = self.flat[lo:hi]
         if self.comm is not None:  # C-ABI path: the library owns the comm stream and the ordering events
-            for e in self._extra:
-                self.comm.after_event(e.cuda_event)
-            self._extra.clear()
+            if first:
+                for e in self._extra:
+                    self.comm.after_event(e.cuda_event)
+                self._extra.clear()
             self.comm.all_reduce_async(chunk.data_ptr(), chunk.numel(), torch.cuda.current_stream().cuda_stream)
             return
         if self.comm_stream is not None:
@@ -72,9 +86,10 @@ class GradReducer:
             ev.record()  # everything that produced this range is on the compute stream before this point
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                for e in self._extra:
-                    self.comm_stream.wait_event(e)
-                self._extra.clear()
+                if first:  # (the later runs of this flush follow on the same comm stream)
+                    for e in self._extra:
+                        self.comm_stream.wait_event(e)
+                    self._extra.clear()
                 self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:  # CPU / gloo (tests)
             self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))

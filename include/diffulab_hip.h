@@ -359,6 +359,12 @@ DL_API int dl_cast_weights_batched(const dl_cast_desc_t* desc_dev, int n_desc, i
 /* plain casts */
 DL_API int dl_cast_f32_to_bf16(const float* src, void* dst, int64_t n, dl_stream_t stream);
 DL_API int dl_cast_bf16_to_f32(const void* src, float* dst, int64_t n, dl_stream_t stream);
+/* the same over a column window of wider rows: dst[r, c] = bf16(src[r, c]), r < rows, c < cols (cols and both row strides
+ * multiples of 4 elements).  The data-parallel DiT backward casts each block's [B, 6D] slice of the f32 modulation-gradient
+ * accumulator as soon as that block is done, so that the block's adaLN weight gradient can be reduced early. */
+DL_API int dl_cast2d_f32_to_bf16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int64_t cols,
+                                 dl_stream_t stream);
+
 /* ema = ema + (1 - beta) (p - ema)  == lerp used by ema_pytorch (base_trainer.py:152-153) */
 DL_API int dl_ema_update(float* ema, const float* p, float beta, int64_t n, dl_stream_t stream);
 

@@ -33,6 +33,20 @@ def _worker(rank: int, world: int, port: int, out):
     red.finish()
     expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
     ok &= bool(torch.equal(grads, expect)) and abs(red.grad_scale - 1.0 / world) < 1e-12
+    # a block's own range and its slice of the stacked adaLN matrix sit in different parts of the arena: the pending ranges of one
+    # flush form several contiguous runs, each reduced on its own; flush=True reduces without waiting for a full bucket
+    g3 = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    red3 = GradReducer(g3, bucket_bytes=4 * 10_000)  # never fills: every reduction below is an explicit flush / finish
+    red3.ready(60, 80)        # adaLN rows of the last block
+    red3.ready(800, 1000)     # the last block
+    ok &= len(red3._pending) == 2 and not red3._works
+    red3.ready(40, 60)
+    red3.ready(600, 800, flush=True)
+    ok &= not red3._pending and len(red3._works) == 2  # runs [40, 80) and [600, 1000)
+    red3.ready(0, 40)
+    red3.ready(80, 600)
+    red3.finish()
+    ok &= bool(torch.equal(g3, expect))
     # accumulation micro-step: no communication, gradients untouched
     g2 = torch.ones(n) * (rank + 1)
     red2 = GradReducer(g2)
