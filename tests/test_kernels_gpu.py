@@ -135,6 +135,17 @@ def test_gemm_tn_ring_kernel(ops, R, M, N, cap):
     assert rel(c, ref) < 2e-5
 
 
+def test_cast2d_column_window(ops):
+    """dl_cast2d_f32_to_bf16 on a column window of wider rows (the data-parallel backward casts one block's slice of the f32
+    modulation-gradient accumulator at a time): bit-equal to torch's rounding, nothing written outside the window"""
+    src = torch.randn(37, 512, device=DEV)
+    dst = torch.full((64, 512), 7.0, device=DEV, dtype=torch.bfloat16)
+    ops.cast2d_f32_to_bf16(src[:, 128:320], dst[:37, 128:320])
+    want = torch.full((64, 512), 7.0, device=DEV, dtype=torch.bfloat16)
+    want[:37, 128:320] = src[:, 128:320].to(torch.bfloat16)
+    assert torch.equal(dst, want)
+
+
 # ------------------------------------------------------------------ adaLN
 @pytest.mark.parametrize("D,affine", [(384, True), (768, True), (384, False), (128, True)])
 def test_ln_modulate_fwd_bwd(ops, D, affine):
