@@ -128,7 +128,8 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
 
     rec: list[tuple[str, torch.cuda.Event, torch.cuda.Event, float]] = []
     tn_shapes: dict[tuple[str, int, int, int], int] = {}  # weight-gradient launches of the replay: (kernel, R, M, N) -> count
-    orig = {n: getattr(ops, n) for n in ("gemm_nt", "gemm_nt_swiglu", "gemm_tn", "attn_fwd_qkv", "attn_bwd_qkv", "attn_fwd", "attn_bwd")}
+    orig = {n: getattr(ops, n) for n in ("gemm_nt", "gemm_nt_swiglu", "gemm_tn", "attn_fwd_qkv", "attn_bwd_qkv", "attn_fwd", "attn_bwd",
+                                         "mlp_dswiglu_recompute")}
 
     def timed(kind: str):
         fn = orig[kind]
@@ -141,6 +142,8 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
                 name, fl = _nt_variant(M, N, K, plain), 2.0 * M * N * K
             elif kind == "gemm_nt_swiglu":
                 name, fl = "gemm_nt_big_k<384,2,2>", 2.0 * a.shape[0] * b.shape[0] * a.shape[1]
+            elif kind == "mlp_dswiglu_recompute":  # (x, wp, dt, w2t, du): u tile recomputed (2 M 2F K) + dh tile (2 M F K)
+                name, fl = "mlp_dswiglu_rc_k", 6.0 * a.shape[0] * rest[1].shape[0] * a.shape[1]
             elif kind.startswith("attn_"):  # (q, k, ..., B, H, N, dh, scale): 4 N^2 dh per head forward, 10 N^2 dh backward
                 Bq, Hq, Nq, dq = a.shape
                 name, fl = ("attn_bwd_k" if "bwd" in kind else "attn_fwd_k"), (10.0 if "bwd" in kind else 4.0) * Bq * Hq * Nq * Nq * dq

@@ -51,8 +51,10 @@ extern "C" int dl_dit_block_fwd(const dl_dit_block_t* b, int train, dl_stream_t 
   // LayerNorm 2 (+ the attention branch's gated residual: x1 = x_in + gate1 * t1)
   RUN(dl_ln_modulate_fwd(P(X_IN), (const float*)P(LN2_W), (const float*)P(LN2_B), P(SCALE2), P(SHIFT2), b->ld_mod, N, b->eps, P(XM2),
                          (float*)P(MEAN2), (float*)P(RSTD2), P(T1), P(GATE1), b->ld_mod, P(X1), M, D, stream));
+  // (U == NULL in a training block: the backward recomputes the pre-activations, dl_mlp_dswiglu_recompute)
   int rc = dl_gemm_nt_swiglu(P(XM2), D, P(W_UP_PERM), b->ldw_d, train ? P(U) : nullptr, 2 * F, P(H), F, M, F, D, stream);
   if (rc == DL_ERR_UNSUPPORTED) {  // small / ragged shapes: the unfused pair
+    DL_CHECK_ARG(P(U), "dl_dit_block_fwd: this shape has no fused MLP-up kernel and needs the U buffer");
     RUN(dl_gemm_nt(P(XM2), D, P(W_UP), b->ldw_d, P(U), 2 * F, M, 2 * F, D, nullptr, DL_ACT_NONE, DL_BF16, nullptr, nullptr, 0, nullptr, 0, 1,
                    stream));
     RUN(dl_swiglu_fwd(P(U), P(H), M, F, stream));
@@ -78,8 +80,12 @@ extern "C" int dl_dit_block_bwd(const dl_dit_block_t* b, dl_stream_t main_, dl_s
   };
   // ---- MLP branch (dt2 / its dgate were produced by the LayerNorm backward that ran before this block)
   RUN(wgrad(P(DT2), D, P(H), F, P(G_DOWN), D, F));
-  RUN(dl_gemm_nt(P(DT2), D, P(WT_DOWN), b->ldwt_d, P(DH), F, M, F, D, nullptr, DL_ACT_NONE, DL_BF16, nullptr, nullptr, 0, nullptr, 0, 1, main));
-  RUN(dl_swiglu_bwd(P(DH), P(U), P(DU), M, F, main));
+  if (P(U)) {
+    RUN(dl_gemm_nt(P(DT2), D, P(WT_DOWN), b->ldwt_d, P(DH), F, M, F, D, nullptr, DL_ACT_NONE, DL_BF16, nullptr, nullptr, 0, nullptr, 0, 1, main));
+    RUN(dl_swiglu_bwd(P(DH), P(U), P(DU), M, F, main));
+  } else {  // no saved pre-activations: recomputed per tile next to dH, neither written (csrc/mlp_bwd.hip)
+    RUN(dl_mlp_dswiglu_recompute(P(XM2), D, P(W_UP_PERM), b->ldw_d, P(DT2), D, P(WT_DOWN), b->ldwt_d, P(DU), 2 * F, M, F, D, D, main));
+  }
   RUN(wgrad(P(DU), 2 * F, P(XM2), D, P(G_UP), 2 * F, D));
   RUN(dl_gemm_nt(P(DU), 2 * F, P(WT_UP), b->ldwt_f2, P(DXM), D, M, D, 2 * F, nullptr, DL_ACT_NONE, DL_BF16, nullptr, nullptr, 0, nullptr, 0,
                  1, main));

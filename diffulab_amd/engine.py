@@ -309,6 +309,12 @@ class DiTEngine:
         w["se"] = z(Bp, E)
         w["mod"] = z(Bp, self.layout.mod_rows)
         nl = L if train else 1                    # inference reuses one block's buffers for every layer
+        # MLP backward with recomputed pre-activations (csrc/mlp_bwd.hip): the training forward then stores h only and no
+        # [M, 2F] pre-activation buffer exists (403 MB per block at B = 256); shapes without that kernel keep u
+        F_ = d.mlp_ratio * D
+        rc_u = (train and type(self) is DiTEngine and os.environ.get("DL_MLP_RECOMPUTE", "1") != "0" and M % 256 == 0 and D % 64 == 0
+                and F_ % 384 == 0 and (M // 256) * (F_ // 128) >= 64)
+        w["mlp_recompute"] = rc_u
         w["x"] = [z(M, D) for _ in range((L + 1) if train else 2)]
         per = []
         for _ in range(nl):
@@ -318,7 +324,7 @@ class DiTEngine:
                 "v": None if ops.v_in_place(N) else z(B, d.num_heads, N, 64),  # (N <= 256: V is read in place from qkv)
                 "rrms": z(M, 2, dtype=f32), "a": z(M, D), "lse": z(B, d.num_heads, N, dtype=f32), "t1": z(M, D),
                 "x1": z(M, D), "mean2": z(M, dtype=f32), "rstd2": z(M, dtype=f32), "xm2": z(M, D),
-                "u": z(M, 2 * d.mlp_ratio * D), "h": z(M, d.mlp_ratio * D), "t2": z(M, D),
+                "u": None if rc_u else z(M, 2 * d.mlp_ratio * D), "h": z(M, d.mlp_ratio * D), "t2": z(M, D),
             })
         w["layers"] = per
         w["meanf"], w["rstdf"] = z(M, dtype=f32), z(M, dtype=f32)
@@ -501,6 +507,7 @@ class DiTEngine:
                                 mod[:, mo + 3 * D : mo + 4 * D], mod[:, mo + 4 * D : mo + 5 * D], N, 1e-5, a["xm2"],
                                 a["mean2"], a["rstd2"], t=a["t1"], gate=mod[:, mo + 2 * D : mo + 3 * D], x_out=a["x1"])
             if not ops.gemm_nt_swiglu(a["xm2"], sh[pre + "mlp_input.0.weight|g"], a["u"] if train else None, a["h"]):
+                assert a["u"] is not None, "the recompute mode is only chosen for shapes the fused MLP-up kernel serves"
                 ops.gemm_nt(a["xm2"], sh[pre + "mlp_input.0.weight|f"], a["u"])  # small / ragged shapes: unfused pair
                 ops.swiglu_fwd(a["u"], a["h"])
             ops.gemm_nt(a["h"], sh[pre + "mlp_input.2.weight|f"], a["t2"])
@@ -633,7 +640,10 @@ class DiTEngine:
             mo = i * 6 * D
             # MLP branch
             wgrad(g["dt2"], a["h"], pre + "mlp_input.2.weight", wide=True)  # dt2 / dgate: produced by the LayerNorm backward before
-            if not (fused_dswiglu and ops.gemm_nt_dswiglu(g["dt2"], sh[pre + "mlp_input.2.weight|t"], a["u"], g["du"])):
+            if a["u"] is None:  # no saved pre-activations: the u tile is recomputed next to the dh tile, neither is written
+                assert ops.mlp_dswiglu_recompute(a["xm2"], sh[pre + "mlp_input.0.weight|g"], g["dt2"], sh[pre + "mlp_input.2.weight|t"],
+                                                 g["du"])
+            elif not (fused_dswiglu and ops.gemm_nt_dswiglu(g["dt2"], sh[pre + "mlp_input.2.weight|t"], a["u"], g["du"])):
                 ops.gemm_nt(g["dt2"], sh[pre + "mlp_input.2.weight|t"], w["dh"])
                 ops.swiglu_bwd(w["dh"], a["u"], g["du"])
             wgrad(g["du"], a["xm2"], pre + "mlp_input.0.weight", wide=True)

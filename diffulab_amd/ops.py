@@ -159,6 +159,14 @@ def gemm_nt_swiglu(x: Tensor, w_perm: Tensor, u: Tensor | None, h: Tensor) -> bo
     return True
 
 
+def mlp_dswiglu_recompute(x: Tensor, wp: Tensor, dt: Tensor, w2t: Tensor, du: Tensor) -> bool:
+    """du = SwiGLU backward of dh = dt @ w2t^T with u = x @ wp^T recomputed per tile (nothing saved, nothing written but du);
+    False when the shape has no such kernel (caller: dgrad GEMM + swiglu_bwd on the saved u)"""
+    M, F = x.shape[0], w2t.shape[0]
+    return _maybe("dl_mlp_dswiglu_recompute", _p(x), x.stride(0), _p(wp), wp.stride(0), _p(dt), dt.stride(0), _p(w2t), w2t.stride(0),
+                  _p(du), du.stride(0), M, F, x.shape[1], dt.shape[1], _s())
+
+
 def gemm_nt_dswiglu(dt: Tensor, w2t: Tensor, u: Tensor, du: Tensor) -> bool:
     """fused MLP-down dgrad + SwiGLU backward; False when unsupported for the shape"""
     rc = lib().cdll.dl_gemm_nt_dswiglu(_p(dt), dt.stride(0), _p(w2t), w2t.stride(0), _p(u), u.stride(0), _p(du),

@@ -118,6 +118,15 @@ DL_API int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, vo
  * dl_gemm_nt + dl_swiglu_fwd. */
 DL_API int dl_gemm_nt_swiglu(const void* X, int64_t ldx, const void* Wp, int64_t ldw, void* U, int64_t ldu, void* H,
                              int64_t ldh, int64_t M, int64_t F, int64_t K, dl_stream_t stream);
+/* PackedSwiGLU MLP backward WITHOUT saved pre-activations (nn.py:478-486, mmdit.py:260-264): dU = [dH x3 silu'(x1) | dH silu(x1)]
+ * with u = [x1 | x3] = X Wp^T RECOMPUTED per 256 x 128-unit tile (rounded to bf16 as the forward would have stored it) and
+ * dH = dT W2t^T, neither of them written to memory.  X = the MLP input (modulated LayerNorm output) [M, K1], Wp = the row-permuted
+ * [2F, K1] shadow of dl_cast_weight_swiglu, dT [M, K2] = gradient of the MLP output, W2t [F, K2] = transposed shadow of the
+ * MLP-down weight.  With it the training forward calls dl_gemm_nt_swiglu with U = NULL (h only).  M % 256 == 0, F % 128 == 0,
+ * K1, K2 % 64 == 0, >= 64 tiles -- otherwise DL_ERR_UNSUPPORTED. */
+DL_API int dl_mlp_dswiglu_recompute(const void* X, int64_t ldx, const void* Wp, int64_t ldwp, const void* dT, int64_t ldt,
+                                    const void* W2t, int64_t ldw2, void* dU, int64_t lddu, int64_t M, int64_t F, int64_t K1,
+                                    int64_t K2, dl_stream_t stream);
 /* mlp_input[2] dgrad + PackedSwiGLU backward fused: dH = dT W2 is never written; dU = [dH x3 silu'(x1) | dH silu(x1)].
  * W2t = transposed bf16 shadow [F, K]; U = saved pre-activations [M, 2F].  Same shape rule as above. */
 DL_API int dl_gemm_nt_dswiglu(const void* dT, int64_t ldt, const void* W2t, int64_t ldw, const void* U, int64_t ldu,

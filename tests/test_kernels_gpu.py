@@ -562,6 +562,17 @@ def test_fused_swiglu_gemms(ops):
     ops.gemm_nt(dev_bf(dt), w2t, dh)
     ops.swiglu_bwd(dh, u, du_ref)
     assert rel(du.float(), du_ref.float()) < 6e-3
+    # ... and without any saved u: the backward recomputes the u tile it needs (bit-identical to the stored one: same accumulation
+    # order, same rounding) next to the dh tile, so it must land where the fused epilogue on the stored u lands
+    du_rc = torch.full_like(du, float("nan"))
+    assert ops.mlp_dswiglu_recompute(dev_bf(x), w1p, dev_bf(dt), w2t, du_rc)
+    assert torch.equal(du_rc, du)
+    xw = torch.zeros(M, D + 64, device=DEV, dtype=torch.bfloat16)  # operands that are column windows of wider rows
+    xw[:, 64:] = dev_bf(x)
+    duw = torch.zeros(M, 2 * F + 128, device=DEV, dtype=torch.bfloat16)
+    assert ops.mlp_dswiglu_recompute(xw[:, 64:], w1p, dev_bf(dt), w2t, duw[:, : 2 * F])
+    assert torch.equal(duw[:, : 2 * F], du) and float(duw[:, 2 * F :].abs().sum()) == 0.0
+    assert not ops.mlp_dswiglu_recompute(dev_bf(x)[:512], w1p, dev_bf(dt)[:512], w2t, du_rc[:512])  # too few tiles
     # small shapes have no fused kernel: the wrappers say so instead of computing something else
     xs = torch.zeros(256, D, device=DEV, dtype=torch.bfloat16)
     assert not ops.gemm_nt_swiglu(xs, w1p, u[:256], h[:256])
