@@ -179,8 +179,7 @@ class PerTokenDecoder:
             a, pre, mo = w["blk"][bi], self.prefixes[bi], j * 6 * D
             g = a["wg"]
             wgrad(g["dt2"], a["h"], pre + "mlp_input.2.weight")
-            ops.gemm_nt(g["dt2"], sh[pre + "mlp_input.2.weight|t"], s["dh"])
-            ops.swiglu_bwd(s["dh"], a["u"], g["du"])
+            ops.mlp_swiglu_bwd(g["dt2"], sh[pre + "mlp_input.2.weight|t"], a["xm2"], sh[pre + "mlp_input.0.weight|g"], a["u"], s["dh"], g["du"])
             wgrad(g["du"], a["xm2"], pre + "mlp_input.0.weight")
             ops.gemm_nt(g["du"], sh[pre + "mlp_input.0.weight|t"], s["dxm"])
             ops.ln_modulate_bwd_tok(s["dxm"], a["x1"], self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"),
@@ -288,7 +287,7 @@ class DDTEngine(SprintEngine, PerTokenDecoder):
             a = {"x0": z(M, D), "mean1": z(M, dtype=f32), "rstd1": z(M, dtype=f32), "xm1": z(M, D), "qkv": z(M, 3 * D),
                  "q": z(B, d.num_heads, N, 64), "k": z(B, d.num_heads, N, 64), "v": z(B, d.num_heads, N, 64),
                  "rrms": z(M, 2, dtype=f32), "a": z(M, D), "lse": z(B, d.num_heads, N, dtype=f32), "t1": z(M, D), "x1": z(M, D),
-                 "mean2": z(M, dtype=f32), "rstd2": z(M, dtype=f32), "xm2": z(M, D), "u": z(M, 2 * F), "h": z(M, F), "t2": z(M, D)}
+                 "mean2": z(M, dtype=f32), "rstd2": z(M, dtype=f32), "xm2": z(M, D), "u": ops.mlp_u_buffer(z, M, D, F, train), "h": z(M, F), "t2": z(M, D)}
             if train:
                 a["wg"] = {"dt2": z(M, D), "du": z(M, 2 * F), "dt1": z(M, D), "dqkv": z(M, 3 * D)}
                 a["dwb"] = z(2, B, 2, D, dtype=f32)        # encoder blocks: per-sample partials
@@ -554,7 +553,7 @@ class DDTJointEngine(SprintJointEngine, PerTokenDecoder):
                     mt = B * nt
                     a = {"x0": zr(mt, D), "mean1": zr(mt, dtype=f32), "rstd1": zr(mt, dtype=f32), "xm1": zr(mt, D), "qkv": zr(mt, 3 * D),
                          "rrms": zr(mt, 2, dtype=f32), "a": zr(mt, D), "t1": zr(mt, D), "x1": zr(mt, D), "mean2": zr(mt, dtype=f32),
-                         "rstd2": zr(mt, dtype=f32), "xm2": zr(mt, D), "u": zr(mt, 2 * F), "h": zr(mt, F), "t2": zr(mt, D)}
+                         "rstd2": zr(mt, dtype=f32), "xm2": zr(mt, D), "u": ops.mlp_u_buffer(zr, mt, D, F, train), "h": zr(mt, F), "t2": zr(mt, D)}
                     if train:
                         a["wg"] = {"dt2": zr(mt, D), "du": zr(mt, 2 * F), "dt1": zr(mt, D), "dqkv": zr(mt, 3 * D)}
                         a["dwb"] = z(2, B, 2, D, dtype=f32)
@@ -563,7 +562,7 @@ class DDTJointEngine(SprintJointEngine, PerTokenDecoder):
                 per = {"x0": z(M, D), "mean1": z(M, dtype=f32), "rstd1": z(M, dtype=f32), "xm1": z(M, D), "qkv": z(M, 3 * D),
                        "q": z(B, Hh, N, 64), "k": z(B, Hh, N, 64), "v": z(B, Hh, N, 64), "rrms": z(M, 2, dtype=f32), "a": z(M, D),
                        "lse": z(B, Hh, N, dtype=f32), "t1": z(M, D), "x1": z(M, D), "mean2": z(M, dtype=f32), "rstd2": z(M, dtype=f32),
-                       "xm2": z(M, D), "u": z(M, 2 * F), "h": z(M, F), "t2": z(M, D)}
+                       "xm2": z(M, D), "u": ops.mlp_u_buffer(z, M, D, F, train), "h": z(M, F), "t2": z(M, D)}
                 if train:
                     per["wg"] = {"dt2": z(M, D), "du": z(M, 2 * F), "dt1": z(M, D), "dqkv": z(M, 3 * D)}
                     per["dwbp"] = z(2, N_PART, 2, D, dtype=f32)

@@ -312,8 +312,7 @@ class DiTEngine:
         # MLP backward with recomputed pre-activations (csrc/mlp_bwd.hip): the training forward then stores h only and no
         # [M, 2F] pre-activation buffer exists (403 MB per block at B = 256); shapes without that kernel keep u
         F_ = d.mlp_ratio * D
-        rc_u = (train and type(self) is DiTEngine and os.environ.get("DL_MLP_RECOMPUTE", "1") != "0" and M % 256 == 0 and D % 64 == 0
-                and F_ % 384 == 0 and (M // 256) * (F_ // 128) >= 64)
+        rc_u = train and type(self) is DiTEngine and ops.mlp_recompute_ok(M, D, F_)
         w["mlp_recompute"] = rc_u
         w["x"] = [z(M, D) for _ in range((L + 1) if train else 2)]
         per = []

@@ -185,7 +185,7 @@ class JointEngine(DiTEngine):
                 mt = B * ntok[st]
                 a = {"x0": zr(mt, D), "mean1": zr(mt, dtype=f32), "rstd1": zr(mt, dtype=f32), "xm1": zr(mt, D), "qkv": zr(mt, 3 * D),
                      "rrms": zr(mt, 2, dtype=f32), "a": zr(mt, D), "t1": zr(mt, D), "x1": zr(mt, D), "mean2": zr(mt, dtype=f32),
-                     "rstd2": zr(mt, dtype=f32), "xm2": zr(mt, D), "u": zr(mt, 2 * F), "h": zr(mt, F), "t2": zr(mt, D)}
+                     "rstd2": zr(mt, dtype=f32), "xm2": zr(mt, D), "u": ops.mlp_u_buffer(zr, mt, D, F, train), "h": zr(mt, F), "t2": zr(mt, D)}
                 if train:
                     a["wg"] = {"dt2": zr(mt, D), "du": zr(mt, 2 * F), "dt1": zr(mt, D), "dqkv": zr(mt, 3 * D)}
                     a["dwb"] = z(2, B, 2, D, dtype=f32)
@@ -371,8 +371,7 @@ class JointEngine(DiTEngine):
                 a, mo, s, g = per[st], base + mc, scr[st], per[st]["wg"]
                 # MLP branch (dt2 / dgate were produced by the LayerNorm backward that precedes this block in the chain)
                 wgrad(g["dt2"], a["h"], pre + f"mlp_{st}.2.weight")
-                ops.gemm_nt(g["dt2"], sh[pre + f"mlp_{st}.2.weight|t"], s["dh"])
-                ops.swiglu_bwd(s["dh"], a["u"], g["du"])
+                ops.mlp_swiglu_bwd(g["dt2"], sh[pre + f"mlp_{st}.2.weight|t"], a["xm2"], sh[pre + f"mlp_{st}.0.weight|g"], a["u"], s["dh"], g["du"])
                 wgrad(g["du"], a["xm2"], pre + f"mlp_{st}.0.weight")
                 ops.gemm_nt(g["du"], sh[pre + f"mlp_{st}.0.weight|t"], s["dxm"])
                 nx = other(s, dx[st])

@@ -159,6 +159,32 @@ def gemm_nt_swiglu(x: Tensor, w_perm: Tensor, u: Tensor | None, h: Tensor) -> bo
     return True
 
 
+def mlp_recompute_ok(M: int, D: int, F: int) -> bool:
+    """shapes for which the training step keeps no SwiGLU pre-activations (the backward recomputes them: csrc/mlp_bwd.hip) --
+    the rule implies that the fused MLP-up forward serves the shape too; DL_MLP_RECOMPUTE=0 turns it off"""
+    import os
+
+    # D <= 512: measured -3 % on the DiT-S/2 step (D = 384), neutral at D = 512 (SPRINT, DDT: the u buffers are still saved),
+    # +3..5 % at D = 768 (joint MMDiT: the wider contraction makes the recomputed GEMM cost more than the bytes it saves)
+    return (os.environ.get("DL_MLP_RECOMPUTE", "1") != "0" and M % 256 == 0 and D % 64 == 0 and D <= 512 and F % 384 == 0
+            and (M // 256) * (F // 128) >= 64)
+
+
+def mlp_u_buffer(alloc, M: int, D: int, F: int, train: bool):
+    """the [M, 2F] pre-activation buffer of a block's workspace, or None when the training backward recomputes it"""
+    return None if (train and mlp_recompute_ok(M, D, F)) else alloc(M, 2 * F)
+
+
+def mlp_swiglu_bwd(dt: Tensor, w2t: Tensor, x: Tensor, wp: Tensor, u: Tensor | None, dh: Tensor, du: Tensor) -> None:
+    """du = SwiGLU backward of dh = dt @ w2t^T: from the saved pre-activations u, or (u None) recomputed per tile"""
+    if u is None:
+        if not mlp_dswiglu_recompute(x, wp, dt, w2t, du):
+            raise RuntimeError("no saved SwiGLU pre-activations and no recompute kernel for this shape")
+        return
+    gemm_nt(dt, w2t, dh)
+    swiglu_bwd(dh, u, du)
+
+
 def mlp_dswiglu_recompute(x: Tensor, wp: Tensor, dt: Tensor, w2t: Tensor, du: Tensor) -> bool:
     """du = SwiGLU backward of dh = dt @ w2t^T with u = x @ wp^T recomputed per tile (nothing saved, nothing written but du);
     False when the shape has no such kernel (caller: dgrad GEMM + swiglu_bwd on the saved u)"""

@@ -99,7 +99,7 @@ class SprintEngine(DiTEngine):
             a = {"x0": z(mt, D), "mean1": z(mt, dtype=f32), "rstd1": z(mt, dtype=f32), "xm1": z(mt, D), "qkv": z(mt, 3 * D),
                  "q": z(B, d.num_heads, nt, 64), "k": z(B, d.num_heads, nt, 64), "v": z(B, d.num_heads, nt, 64),
                  "rrms": z(mt, 2, dtype=f32), "a": z(mt, D), "lse": z(B, d.num_heads, nt, dtype=f32), "t1": z(mt, D),
-                 "x1": z(mt, D), "mean2": z(mt, dtype=f32), "rstd2": z(mt, dtype=f32), "xm2": z(mt, D), "u": z(mt, 2 * F),
+                 "x1": z(mt, D), "mean2": z(mt, dtype=f32), "rstd2": z(mt, dtype=f32), "xm2": z(mt, D), "u": ops.mlp_u_buffer(z, mt, D, F, train),
                  "h": z(mt, F), "t2": z(mt, D)}
             if train:
                 a["wg"] = {"dt2": z(mt, D), "du": z(mt, 2 * F), "dt1": z(mt, D), "dqkv": z(mt, 3 * D)}
@@ -207,8 +207,7 @@ class SprintEngine(DiTEngine):
             a, pre, mo = w["blk"][bi], self.prefixes[bi], bi * 6 * D
             g = a["wg"]
             wgrad(g["dt2"], a["h"], pre + "mlp_input.2.weight")
-            ops.gemm_nt(g["dt2"], sh[pre + "mlp_input.2.weight|t"], s["dh"])
-            ops.swiglu_bwd(s["dh"], a["u"], g["du"])
+            ops.mlp_swiglu_bwd(g["dt2"], sh[pre + "mlp_input.2.weight|t"], a["xm2"], sh[pre + "mlp_input.0.weight|g"], a["u"], s["dh"], g["du"])
             wgrad(g["du"], a["xm2"], pre + "mlp_input.0.weight")
             ops.gemm_nt(g["du"], sh[pre + "mlp_input.0.weight|t"], s["dxm"])
             dx_alt = other(dx)

@@ -209,7 +209,7 @@ class SprintJointEngine(DiTEngine):
                     mt = B * nt
                     a = {"x0": zr(mt, D), "mean1": zr(mt, dtype=f32), "rstd1": zr(mt, dtype=f32), "xm1": zr(mt, D), "qkv": zr(mt, 3 * D),
                          "rrms": zr(mt, 2, dtype=f32), "a": zr(mt, D), "t1": zr(mt, D), "x1": zr(mt, D), "mean2": zr(mt, dtype=f32),
-                         "rstd2": zr(mt, dtype=f32), "xm2": zr(mt, D), "u": zr(mt, 2 * F), "h": zr(mt, F), "t2": zr(mt, D)}
+                         "rstd2": zr(mt, dtype=f32), "xm2": zr(mt, D), "u": ops.mlp_u_buffer(zr, mt, D, F, train), "h": zr(mt, F), "t2": zr(mt, D)}
                     if train:
                         a["wg"] = {"dt2": zr(mt, D), "du": zr(mt, 2 * F), "dt1": zr(mt, D), "dqkv": zr(mt, 3 * D)}
                         a["dwb"] = z(2, B, 2, D, dtype=f32)
@@ -217,7 +217,7 @@ class SprintJointEngine(DiTEngine):
             else:
                 mt = B * Td
                 per.update({"x0": zr(mt, D), "mean": zr(mt, dtype=f32), "rstd": zr(mt, dtype=f32), "m": zr(mt, D), "qkv": zr(mt, 3 * D),
-                            "rrms": zr(mt, 2, dtype=f32), "a": zr(mt, D), "ta": zr(mt, D), "u": zr(mt, 2 * F), "h": zr(mt, F), "t": zr(mt, D)})
+                            "rrms": zr(mt, 2, dtype=f32), "a": zr(mt, D), "ta": zr(mt, D), "u": ops.mlp_u_buffer(zr, mt, D, F, train), "h": zr(mt, F), "t": zr(mt, D)})
                 if train:
                     per["wg"] = {"dt": zr(mt, D), "du": zr(mt, 2 * F), "dqkv": zr(mt, 3 * D)}
                     per["dwb"] = z(1, B, 2, D, dtype=f32)
@@ -349,8 +349,7 @@ class SprintJointEngine(DiTEngine):
                     continue
                 a, mo, s, g = per[st], base + mc, scr[st], per[st]["wg"]
                 wgrad(g["dt2"], a["h"], pre + f"mlp_{st}.2.weight")
-                ops.gemm_nt(g["dt2"], sh[pre + f"mlp_{st}.2.weight|t"], s["dh"])
-                ops.swiglu_bwd(s["dh"], a["u"], g["du"])
+                ops.mlp_swiglu_bwd(g["dt2"], sh[pre + f"mlp_{st}.2.weight|t"], a["xm2"], sh[pre + f"mlp_{st}.0.weight|g"], a["u"], s["dh"], g["du"])
                 wgrad(g["du"], a["xm2"], pre + f"mlp_{st}.0.weight")
                 ops.gemm_nt(g["du"], sh[pre + f"mlp_{st}.0.weight|t"], s["dxm"])
                 nx_ = other(s, dx[st])
@@ -449,8 +448,7 @@ class SprintJointEngine(DiTEngine):
             g = a["wg"]
             wgrad(g["dt"], a["h"], pre + "mlp.2.weight")
             wgrad(g["dt"], a["a"], pre + "attention.proj_out.weight")
-            ops.gemm_nt(g["dt"], sh[pre + "mlp.2.weight|t"], s["dh"])
-            ops.swiglu_bwd(s["dh"], a["u"], g["du"])
+            ops.mlp_swiglu_bwd(g["dt"], sh[pre + "mlp.2.weight|t"], a["m"], sh[pre + "mlp.0.weight|g"], a["u"], s["dh"], g["du"])
             wgrad(g["du"], a["m"], pre + "mlp.0.weight")
             ops.gemm_nt(g["du"], sh[pre + "mlp.0.weight|t"], s["dxm"])
             ops.gemm_nt(g["dt"], sh[pre + "attention.proj_out.weight|t"], s["da"])
@@ -703,7 +701,7 @@ class JointStackEngine(SprintJointEngine):
                     mt = B * nt
                     a = {"x0": zr(mt, D), "mean1": z(mt, dtype=f32), "rstd1": z(mt, dtype=f32), "xm1": zr(mt, D), "qkv": zr(mt, 3 * D),
                          "rrms": z(mt, 2, dtype=f32), "a": zr(mt, D), "t1": zr(mt, D), "x1": zr(mt, D), "mean2": z(mt, dtype=f32),
-                         "rstd2": z(mt, dtype=f32), "xm2": zr(mt, D), "u": zr(mt, 2 * F), "h": zr(mt, F), "t2": zr(mt, D)}
+                         "rstd2": z(mt, dtype=f32), "xm2": zr(mt, D), "u": ops.mlp_u_buffer(zr, mt, D, F, train), "h": zr(mt, F), "t2": zr(mt, D)}
                     if train:
                         a["wg"] = {"dt2": zr(mt, D), "du": zr(mt, 2 * F), "dt1": zr(mt, D), "dqkv": zr(mt, 3 * D)}
                         a["dwb"] = z(2, B, 2, D, dtype=f32)
@@ -711,7 +709,7 @@ class JointStackEngine(SprintJointEngine):
             else:
                 mt = B * T
                 per.update({"x0": zr(mt, D), "mean": z(mt, dtype=f32), "rstd": z(mt, dtype=f32), "m": zr(mt, D), "qkv": zr(mt, 3 * D),
-                            "rrms": z(mt, 2, dtype=f32), "a": zr(mt, D), "ta": zr(mt, D), "u": zr(mt, 2 * F), "h": zr(mt, F),
+                            "rrms": z(mt, 2, dtype=f32), "a": zr(mt, D), "ta": zr(mt, D), "u": ops.mlp_u_buffer(zr, mt, D, F, train), "h": zr(mt, F),
                             "t": zr(mt, D)})
                 if train:
                     per["wg"] = {"dt": zr(mt, D), "du": zr(mt, 2 * F), "dqkv": zr(mt, 3 * D)}
