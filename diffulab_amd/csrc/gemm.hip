@@ -773,8 +773,8 @@ static int dispatch_big(const void* A, int64_t lda, const void* B, int64_t ldb, 
     const double util = (double)tiles / (double)(rounds * 256);
     return util >= 0.7 ? util * eff : 0.0;
   };
-  const double s384 = score(384, 1.00, v4 && (epi == 0 || epi == 2)), s256 = score(256, 0.95, v4 && epi <= 1);
-  const double s192 = score(192, 0.90, v24), s128 = score(128, 0.80, v4 && epi <= 1);
+  const double s384 = score(384, 1.00, v4 && (epi == 0 || epi == 2)), s256 = score(256, 0.95, v4 && epi <= 2);
+  const double s192 = score(192, 0.90, v24), s128 = score(128, 0.80, v4 && epi <= 2);
   const double best = fmax(fmax(s384, s256), fmax(s192, s128));
   if (best > 0.0) {
     if (best == s384) return launch_big<384, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
@@ -787,6 +787,8 @@ static int dispatch_big(const void* A, int64_t lda, const void* B, int64_t ldb, 
       return launch_big<192, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
     if (v4 && epi == 2 && N % 384 == 0 && mt * (N / 384) >= 64)
       return launch_big<384, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
+    if (v4 && epi == 2 && N % 128 == 0 && mt * (N / 128) >= 64)  // (2F = 4096: the 512-wide configurations)
+      return launch_big<128, 3>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
   }
   return 1;
 }

@@ -164,10 +164,10 @@ def mlp_recompute_ok(M: int, D: int, F: int) -> bool:
     the rule implies that the fused MLP-up forward serves the shape too; DL_MLP_RECOMPUTE=0 turns it off"""
     import os
 
-    # F % 384: the fused MLP-up forward needs 2F % 192 and the recompute kernel F % 128.  D <= 512: measured -3 % on the DiT-S/2 step
-    # (D = 384, F = 1536); at D = 768, F = 3072 it is neutral (DiT-B + REPA, B = 128) to +3..5 % (joint MMDiT: the wider contraction
-    # makes the recomputed GEMM cost more than the bytes it saves).  The 512-wide configurations (F = 2048) have no fused forward.
-    return (os.environ.get("DL_MLP_RECOMPUTE", "1") != "0" and M % 256 == 0 and D % 64 == 0 and D <= 512 and F % 384 == 0
+    # F % 128: the recompute kernel's unit tile (the fused MLP-up forward takes any 2F % 128 with >= 64 tiles).  D <= 512: measured
+    # -3 % on the DiT-S/2 step (D = 384, F = 1536); at D = 768, F = 3072 it is neutral (DiT-B + REPA, B = 128) to +3..5 % (joint MMDiT:
+    # the wider contraction makes the recomputed GEMM cost more than the bytes it saves).
+    return (os.environ.get("DL_MLP_RECOMPUTE", "1") != "0" and M % 256 == 0 and D % 64 == 0 and D <= 512 and F % 128 == 0
             and (M // 256) * (F // 128) >= 64)
 
 

@@ -114,7 +114,7 @@ DL_API int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, vo
  * layout [x1 | x3] (kept for the backward; U == NULL skips it: inference / sampler loops) and H[M,F] = silu(x1) * x3, in
  * ONE pass over the accumulators.
  * Wp = row-permuted bf16 shadow of the [2F, K] weight made by dl_cast_weight_swiglu.  Only shapes served by the
- * big-tile kernels (M % 256 == 0, 2F % 192 == 0, >= 64 tiles) -- otherwise DL_ERR_UNSUPPORTED and the caller runs
+ * big-tile kernels (M % 256 == 0, 2F % 128 == 0, >= 64 tiles) -- otherwise DL_ERR_UNSUPPORTED and the caller runs
  * dl_gemm_nt + dl_swiglu_fwd. */
 DL_API int dl_gemm_nt_swiglu(const void* X, int64_t ldx, const void* Wp, int64_t ldw, void* U, int64_t ldu, void* H,
                              int64_t ldh, int64_t M, int64_t F, int64_t K, dl_stream_t stream);

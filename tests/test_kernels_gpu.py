@@ -573,6 +573,23 @@ def test_fused_swiglu_gemms(ops):
     assert ops.mlp_dswiglu_recompute(xw[:, 64:], w1p, dev_bf(dt), w2t, duw[:, : 2 * F])
     assert torch.equal(duw[:, : 2 * F], du) and float(duw[:, 2 * F :].abs().sum()) == 0.0
     assert not ops.mlp_dswiglu_recompute(dev_bf(x)[:512], w1p, dev_bf(dt)[:512], w2t, du_rc[:512])  # too few tiles
+    # 2F = 4096 (the 512-wide configurations: 256- / 128-wide tiles) through the same three entry points
+    D2, F2, M2 = 512, 2048, 8192
+    x2, dt2 = synth.normal("fs.x2", (M2, D2)), synth.normal("fs.dt2", (M2, D2))
+    w12 = synth.normal("fs.w12", (2 * F2, D2), std=D2**-0.5)
+    w22t = dev_bf(synth.normal("fs.w22", (F2, D2), std=F2**-0.5))
+    w12p = torch.empty(2 * F2, D2, device=DEV, dtype=torch.bfloat16)
+    ops.cast_weight_swiglu(w12.to(DEV), w12p)
+    u2, h2 = torch.empty(M2, 2 * F2, device=DEV, dtype=torch.bfloat16), torch.empty(M2, F2, device=DEV, dtype=torch.bfloat16)
+    assert ops.gemm_nt_swiglu(dev_bf(x2), w12p, u2, h2)
+    u2_ref = torch.empty_like(u2)
+    ops.gemm_nt(dev_bf(x2), dev_bf(w12), u2_ref)
+    assert torch.equal(u2, u2_ref)
+    dh2, du2_ref, du2 = torch.empty(M2, F2, device=DEV, dtype=torch.bfloat16), torch.empty_like(u2), torch.empty_like(u2)
+    ops.gemm_nt(dev_bf(dt2), w22t, dh2)
+    ops.swiglu_bwd(dh2, u2, du2_ref)
+    assert ops.mlp_dswiglu_recompute(dev_bf(x2), w12p, dev_bf(dt2), w22t, du2)
+    assert rel(du2.float(), du2_ref.float()) < 6e-3
     # small shapes have no fused kernel: the wrappers say so instead of computing something else
     xs = torch.zeros(256, D, device=DEV, dtype=torch.bfloat16)
     assert not ops.gemm_nt_swiglu(xs, w1p, u[:256], h[:256])
