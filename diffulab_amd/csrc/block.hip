@@ -34,6 +34,32 @@ extern "C" int dl_dit_block_fwd(const dl_dit_block_t* b, int train, dl_stream_t 
   const int64_t B = b->B, N = b->N, D = b->D, H = b->H, F = b->F, M = B * N, dh = D / H;
   DL_CHECK_ARG(B > 0 && N > 0 && D > 0 && H > 0 && F > 0 && dh == 64, "dl_dit_block_fwd: bad dims (head_dim must be 64)");
   const float sm = 0.125f;  // 64^-0.5
+  if (b->row_gemms & 1) {
+    // Row-complete GEMMs (csrc/gemm_ln.hip): every LayerNorm-modulate is the epilogue of the GEMM in front of it.  XM1 / MEAN1 /
+    // RSTD1 were written by the previous block's MLP-down GEMM (or the patch embedding); the projection carries LN2, the MLP-down
+    // GEMM the gated residual of the MLP branch and the LayerNorm that follows the block.
+    DL_CHECK_ARG(P(V) == nullptr && P(NEXT_X) && P(NEXT_XM) && P(NEXT_SCALE) && P(NEXT_SHIFT) && P(NEXT_MEAN) && P(NEXT_RSTD),
+                 "dl_dit_block_fwd: row_gemms needs V in place and the DL_BLK_NEXT_* slots");
+    if (b->row_gemms & 2) {
+      RUN(dl_gemm_nt_qk_norm_rope(P(XM1), D, P(W_QKV), b->ldw_d, B, N, H, dh, b->rot, 1e-6f, (const float*)P(QN_SCALE),
+                                  (const float*)P(KN_SCALE), (const float*)P(ROPE_COS), (const float*)P(ROPE_SIN), P(QKV), P(Q), P(K),
+                                  (float*)P(RRMS), N, 0, stream));
+    } else {
+      RUN(dl_gemm_nt(P(XM1), D, P(W_QKV), b->ldw_d, P(QKV), 3 * D, M, 3 * D, D, nullptr, DL_ACT_NONE, DL_BF16, nullptr, nullptr, 0, nullptr,
+                     0, 1, stream));
+      RUN(dl_qk_norm_rope_fwd(P(QKV), (const float*)P(QN_SCALE), (const float*)P(KN_SCALE), (const float*)P(ROPE_COS),
+                              (const float*)P(ROPE_SIN), P(Q), P(K), nullptr, (float*)P(RRMS), B, N, H, dh, b->rot, 1e-6f, stream));
+    }
+    RUN(dl_attn_fwd_sv(P(Q), P(K), (const char*)P(QKV) + 2 * D * 2, N * 3 * D, dh, 3 * D, P(A), (float*)P(LSE), B, H, N, dh, sm, stream));
+    RUN(dl_ln_modulate_gemm_fwd(P(A), D, P(W_PROJ), b->ldw_d, M, D, P(X_IN), P(GATE1), b->ld_mod, (const float*)P(LN2_W),
+                                (const float*)P(LN2_B), P(SCALE2), P(SHIFT2), b->ld_mod, N, b->eps, P(T1), P(X1), P(XM2), (float*)P(MEAN2),
+                                (float*)P(RSTD2), D, stream));
+    RUN(dl_gemm_nt_swiglu(P(XM2), D, P(W_UP_PERM), b->ldw_d, train ? P(U) : nullptr, 2 * F, P(H), F, M, F, D, stream));
+    RUN(dl_ln_modulate_gemm_fwd(P(H), F, P(W_DOWN), b->ldw_f, M, F, P(X1), P(GATE2), b->ld_mod, (const float*)P(NEXT_LN_W),
+                                (const float*)P(NEXT_LN_B), P(NEXT_SCALE), P(NEXT_SHIFT), b->ld_mod, N, b->next_eps, P(T2), P(NEXT_X),
+                                P(NEXT_XM), (float*)P(NEXT_MEAN), (float*)P(NEXT_RSTD), D, stream));
+    return DL_OK;
+  }
   // LayerNorm 1 (+ the pending gated residual of the previous block's MLP branch: x_in <- pend_x + pend_gate * pend_t)
   RUN(dl_ln_modulate_fwd(P(PEND_X) ? P(PEND_X) : P(X_IN), (const float*)P(LN1_W), (const float*)P(LN1_B), P(SCALE1), P(SHIFT1),
                          b->ld_mod, N, b->eps, P(XM1), (float*)P(MEAN1), (float*)P(RSTD1), P(PEND_X) ? P(PEND_T) : nullptr,
@@ -87,12 +113,20 @@ extern "C" int dl_dit_block_bwd(const dl_dit_block_t* b, dl_stream_t main_, dl_s
     RUN(dl_mlp_dswiglu_recompute(P(XM2), D, P(W_UP_PERM), b->ldw_d, P(DT2), D, P(WT_DOWN), b->ldwt_d, P(DU), 2 * F, M, F, D, D, main));
   }
   RUN(wgrad(P(DU), 2 * F, P(XM2), D, P(G_UP), 2 * F, D));
-  RUN(dl_gemm_nt(P(DU), 2 * F, P(WT_UP), b->ldwt_f2, P(DXM), D, M, D, 2 * F, nullptr, DL_ACT_NONE, DL_BF16, nullptr, nullptr, 0, nullptr, 0,
-                 1, main));
-  RUN(dl_ln_modulate_bwd(P(DXM), P(X1), (const float*)P(LN2_W), (const float*)P(LN2_B), P(SCALE2), b->ld_mod, N, (const float*)P(MEAN2),
-                         (const float*)P(RSTD2), P(DX_IN), P(DX_MID), (float*)P(DSCALE2), (float*)P(DSHIFT2), b->ld_dmod,
-                         (float*)P(DWB2), P(T1), P(GATE1), b->ld_mod, P(DT1), (float*)P(DGATE1), M, D, main));
-  RUN(fold(P(DWB2), P(G_LN2)));
+  const bool rows = (b->row_gemms & 1) != 0, fold_here = (b->row_gemms & 4) == 0;
+  if (rows) {  // LayerNorm-2 backward (+ the attention branch's gate backward) in the epilogue of the MLP-up data-gradient GEMM
+    RUN(dl_ln_modulate_gemm_bwd(P(DU), 2 * F, P(WT_UP), b->ldwt_f2, M, 2 * F, P(X1), (const float*)P(LN2_W), (const float*)P(LN2_B),
+                                P(SCALE2), b->ld_mod, N, (const float*)P(MEAN2), (const float*)P(RSTD2), P(DX_IN), P(DX_MID),
+                                (float*)P(DSCALE2), (float*)P(DSHIFT2), b->ld_dmod, (float*)P(DWB2), P(T1), P(GATE1), b->ld_mod, P(DT1),
+                                (float*)P(DGATE1), D, main));
+  } else {
+    RUN(dl_gemm_nt(P(DU), 2 * F, P(WT_UP), b->ldwt_f2, P(DXM), D, M, D, 2 * F, nullptr, DL_ACT_NONE, DL_BF16, nullptr, nullptr, 0, nullptr,
+                   0, 1, main));
+    RUN(dl_ln_modulate_bwd(P(DXM), P(X1), (const float*)P(LN2_W), (const float*)P(LN2_B), P(SCALE2), b->ld_mod, N,
+                           (const float*)P(MEAN2), (const float*)P(RSTD2), P(DX_IN), P(DX_MID), (float*)P(DSCALE2), (float*)P(DSHIFT2),
+                           b->ld_dmod, (float*)P(DWB2), P(T1), P(GATE1), b->ld_mod, P(DT1), (float*)P(DGATE1), M, D, main));
+  }
+  if (fold_here) RUN(fold(P(DWB2), P(G_LN2)));
   // ---- attention branch
   RUN(wgrad(P(DT1), D, P(A), D, P(G_PROJ), D, D));
   RUN(dl_gemm_nt(P(DT1), D, P(WT_PROJ), b->ldwt_d, P(DA), D, M, D, D, nullptr, DL_ACT_NONE, DL_BF16, nullptr, nullptr, 0, nullptr, 0, 1, main));
@@ -106,13 +140,22 @@ extern "C" int dl_dit_block_bwd(const dl_dit_block_t* b, dl_stream_t main_, dl_s
                           (const float*)P(ROPE_COS), (const float*)P(ROPE_SIN), (const float*)P(RRMS), P(DQKV), (float*)P(G_QK_SCALE), B, N,
                           H, dh, b->rot, main));
   RUN(wgrad(P(DQKV), 3 * D, P(XM1), D, P(G_QKV), 3 * D, D));
-  RUN(dl_gemm_nt(P(DQKV), 3 * D, P(WT_QKV), b->ldwt_3d, P(DXM), D, M, D, 3 * D, nullptr, DL_ACT_NONE, DL_BF16, nullptr, nullptr, 0, nullptr,
-                 0, 1, main));
+  if (!rows)
+    RUN(dl_gemm_nt(P(DQKV), 3 * D, P(WT_QKV), b->ldwt_3d, P(DXM), D, M, D, 3 * D, nullptr, DL_ACT_NONE, DL_BF16, nullptr, nullptr, 0,
+                   nullptr, 0, 1, main));
   if (P(DFEAT)) RUN(dl_add_bf16(P(DX_MID), P(DFEAT), P(DX_MID), M * D, main));  // auxiliary-loss gradient on this block's input
   // LayerNorm 1 backward + the gated residual of the PREVIOUS block's MLP branch (absent for the first block)
-  RUN(dl_ln_modulate_bwd(P(DXM), P(X_IN), (const float*)P(LN1_W), (const float*)P(LN1_B), P(SCALE1), b->ld_mod, N, (const float*)P(MEAN1),
-                         (const float*)P(RSTD1), P(DX_MID), P(DX_OUT), (float*)P(DSCALE1), (float*)P(DSHIFT1), b->ld_dmod,
-                         (float*)P(DWB1), P(PREV_T2), P(PREV_GATE2), b->ld_mod, P(PREV_DT2), (float*)P(PREV_DGATE2), M, D, main));
-  RUN(fold(P(DWB1), P(G_LN1)));
+  if (rows) {
+    RUN(dl_ln_modulate_gemm_bwd(P(DQKV), 3 * D, P(WT_QKV), b->ldwt_3d, M, 3 * D, P(X_IN), (const float*)P(LN1_W), (const float*)P(LN1_B),
+                                P(SCALE1), b->ld_mod, N, (const float*)P(MEAN1), (const float*)P(RSTD1), P(DX_MID), P(DX_OUT),
+                                (float*)P(DSCALE1), (float*)P(DSHIFT1), b->ld_dmod, (float*)P(DWB1), P(PREV_T2), P(PREV_GATE2), b->ld_mod,
+                                P(PREV_DT2), (float*)P(PREV_DGATE2), D, main));
+  } else {
+    RUN(dl_ln_modulate_bwd(P(DXM), P(X_IN), (const float*)P(LN1_W), (const float*)P(LN1_B), P(SCALE1), b->ld_mod, N,
+                           (const float*)P(MEAN1), (const float*)P(RSTD1), P(DX_MID), P(DX_OUT), (float*)P(DSCALE1), (float*)P(DSHIFT1),
+                           b->ld_dmod, (float*)P(DWB1), P(PREV_T2), P(PREV_GATE2), b->ld_mod, P(PREV_DT2), (float*)P(PREV_DGATE2), M, D,
+                           main));
+  }
+  if (fold_here) RUN(fold(P(DWB1), P(G_LN1)));
   return DL_OK;
 }

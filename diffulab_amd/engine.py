@@ -36,6 +36,12 @@ def bump_param_epoch() -> None:
     _PARAM_EPOCH += 1
 
 
+def _must(ok: bool) -> None:
+    """an entry point that may answer DL_ERR_UNSUPPORTED was chosen for a shape it must serve (no assert: -O would drop the call)"""
+    if not ok:
+        raise RuntimeError("a HIP kernel declined a shape the engine had selected it for")
+
+
 def _rup(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -362,14 +368,16 @@ class DiTEngine:
             c, s = rope_grid_tables(gh, gw, d.rope_axes_dim, d.rope_base)
             self._rope[(gh, gw)] = (c.to(dev), s.to(dev))
 
-    def _stem_fwd(self, x: Tensor, t: Tensor, y_eff: Tensor | None, x0: Tensor | None = None) -> Tensor:
+    def _stem_fwd(self, x: Tensor, t: Tensor, y_eff: Tensor | None, x0: Tensor | None = None, patch_gemm: bool = True) -> Tensor:
         """patch embedding into ``x0`` (default ws["x"][0]) and the conditioning path: time MLP (+ label row) -> SiLU -> the
-        stacked adaLN GEMM of every block and of the last layer.  Returns the modulation matrix bf16 [Bp, mod_rows]."""
+        stacked adaLN GEMM of every block and of the last layer.  Returns the modulation matrix bf16 [Bp, mod_rows].
+        patch_gemm=False leaves the patch-embedding GEMM to the caller (row-complete path: it needs the modulation rows)."""
         d, w, sh = self.d, self.ws, self.sh
         B, _, _, _, _, _, M, _, _ = self.geo
         D, E = d.inner_dim, d.embedding_dim
         ops.patchify(x, w["tokP"], d.patch_size, ops.PATCH_CPP)
-        ops.gemm_nt(w["tokP"], sh[self._conv_name + "|f"], w["x"][0] if x0 is None else x0, M=M, N=D, K=self._ki)
+        if patch_gemm:
+            ops.gemm_nt(w["tokP"], sh[self._conv_name + "|f"], w["x"][0] if x0 is None else x0, M=M, N=D, K=self._ki)
         ops.timestep_embedding(t, w["temb"][:B])
         ops.gemm_nt(w["temb"], sh["time_embed.0.weight|f"], w["h1"], bias=self.P("time_embed.0.bias"), act=ops.ACT_SILU,
                     pre_out=w["pre1"], M=B, N=E, K=d.frequency_embedding)
@@ -388,7 +396,7 @@ class DiTEngine:
 
     def _block_args(self, i: int, train: bool):
         """the dl_dit_block_t of block i on the current workspace (cached: every pointer is fixed once arena and workspace exist)"""
-        key = (self._ws_key, i)
+        key = (self._ws_key, i, self.reducer is None)
         blk = self._blk_cache.get(key)
         if blk is not None:
             return blk
@@ -426,6 +434,22 @@ class DiTEngine:
                 wt_up=sh[pre + "mlp_input.0.weight|t"], wt_down=sh[pre + "mlp_input.2.weight|t"], rope_cos=cos, rope_sin=sin,
                 xm1=a["xm1"], mean1=a["mean1"], rstd1=a["rstd1"], qkv=a["qkv"], q=a["q"], k=a["k"], v=a["v"], rrms=a["rrms"], a=a["a"],
                 lse=a["lse"], t1=a["t1"], x1=a["x1"], xm2=a["xm2"], mean2=a["mean2"], rstd2=a["rstd2"], u=a["u"], h=a["h"], t2=a["t2"])
+        rows = self._row_gemms(M, N)
+        blk.row_gemms = 0
+        if rows:
+            if i + 1 < L:
+                nx, mn, nxt = w["layers"][(i + 1) if train else 0], (i + 1) * 6 * D, f"layers.{i + 1}."
+                lnw, lnb, blk.next_eps = self.P(nxt + "norm_1.weight"), self.P(nxt + "norm_1.bias"), 1e-5
+                xm_n, mu_n, rs_n = nx["xm1"], nx["mean1"], nx["rstd1"]
+            else:
+                mn, lnw, lnb, blk.next_eps = L * 6 * D, None, None, 1e-6
+                xm_n, mu_n, rs_n = w["xf"], w["meanf"], w["rstdf"]
+            blk.set(next_ln_w=lnw, next_ln_b=lnb, next_scale=mrow(mn), next_shift=mrow(mn + D),
+                    next_x=xs[i + 1] if train else xs[(i + 1) & 1], next_xm=xm_n, next_mean=mu_n, next_rstd=rs_n)
+            # bit 1: QK-norm + RoPE in the qkv epilogue (measured slightly slower inside the step: opt-in); bit 2: the LayerNorm-affine
+            # partials of all blocks are folded by ONE launch at the end of the backward (not with a gradient reducer attached: it
+            # wants every block's range final as soon as the block is done)
+            blk.row_gemms = 1 | (2 if os.environ.get("DL_ROW_GEMM_QK", "0") == "1" else 0) | (4 if self.reducer is None else 0)
         if train and self.grads is not None:
             g, dmod = w["wg"][i], w["dmod32"]
             blk.ld_dmod = dmod.stride(0)
@@ -466,8 +490,23 @@ class DiTEngine:
         self._train = train
         self._yeff = y_eff
 
-        mod = self._stem_fwd(x, t, y_eff)
+        fused = self._row_gemms(M, N)
+        mod = self._stem_fwd(x, t, y_eff, patch_gemm=not fused)
         xs = w["x"]
+        if fused:
+            if self._native_blocks():
+                a0 = w["layers"][0]
+                _must(ops.ln_modulate_gemm_fwd(w["tokP"], sh[self._conv_name + "|f"], None, None, self.P("layers.0.norm_1.weight"),
+                                               self.P("layers.0.norm_1.bias"), mod[:, 0:D], mod[:, D : 2 * D], N, 1e-5, None, xs[0],
+                                               a0["xm1"], a0["mean1"], a0["rstd1"], K=self._ki))
+                for i in range(L):
+                    ops.dit_block_fwd(self._block_args(i, train), train)
+            else:
+                self._forward_row_gemms(mod, train)
+            ops.gemm_nt(w["xf"], sh["last_layer.linear.weight|f"], w["otok"], bias=self.P("last_layer.linear.bias"), M=M,
+                        N=Fo, K=D)
+            ops.unpatchify(w["otok"], w["pred"], d.patch_size)
+            return w["pred"]
 
         # The gated residual of every sub-layer (x += gate * f(...)) is applied by the NEXT LayerNorm-modulate kernel, which
         # has to read the residual stream anyway: the projection / MLP-down GEMMs stay plain stores (fast 256x384 tiles)
@@ -521,6 +560,57 @@ class DiTEngine:
         ops.unpatchify(w["otok"], w["pred"], d.patch_size)
         return w["pred"]
 
+    def _row_gemms(self, M: int, N: int) -> bool:
+        """the row-complete GEMM path (csrc/gemm_ln.hip): LayerNorm-modulate forward / backward and QK-norm + RoPE run as epilogues
+        of the GEMMs that feed them.  D == 384 with 256 tokens per sample (one 256 x 384 tile = one sample's whole rows)"""
+        return type(self) is DiTEngine and ops.v_in_place(N) and ops.row_gemm_ok(M, self.d.inner_dim, N)
+
+    def _forward_row_gemms(self, mod: Tensor, train: bool) -> None:
+        """block chain of forward() with every LayerNorm-modulate in the epilogue of the GEMM in front of it: the patch embedding
+        carries LN1 of block 0, the projection carries LN2 of its block, the MLP-down GEMM carries LN1 of the NEXT block (or the
+        final LayerNorm); the qkv GEMM carries QK-norm + RoPE + the head split"""
+        d, w, sh = self.d, self.ws, self.sh
+        B, _, _, gh, gw, N, M, _, _ = self.geo
+        D, L, Hh = d.inner_dim, d.depth, d.num_heads
+        cos, sin = self._rope[(gh, gw)]
+        rot = sum(d.rope_axes_dim)
+        xs = w["x"]
+        lay = lambda i: w["layers"][i if train else 0]  # noqa: E731
+        xbuf = lambda i: xs[i] if train else xs[i & 1]  # noqa: E731
+        fused_qk = os.environ.get("DL_ROW_GEMM_QK", "0") == "1"
+        a0 = lay(0)
+        _must(ops.ln_modulate_gemm_fwd(w["tokP"], sh[self._conv_name + "|f"], None, None, self.P("layers.0.norm_1.weight"),
+                                        self.P("layers.0.norm_1.bias"), mod[:, 0:D], mod[:, D : 2 * D], N, 1e-5, None, xbuf(0),
+                                        a0["xm1"], a0["mean1"], a0["rstd1"], K=self._ki))
+        for i in range(L):
+            a, xin, pre, mo = lay(i), xbuf(i), f"layers.{i}.", i * 6 * D
+            if fused_qk:
+                _must(ops.gemm_nt_qk_norm_rope(a["xm1"], sh[pre + "attention.qkv.weight|f"],
+                                                self.P(pre + "attention.qk_norm.query_norm.scale"),
+                                                self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["qkv"], a["q"], a["k"],
+                                                a["rrms"], B, N, Hh, 64, rot))
+            else:
+                ops.gemm_nt(a["xm1"], sh[pre + "attention.qkv.weight|f"], a["qkv"])
+                ops.qk_norm_rope_fwd(a["qkv"], self.P(pre + "attention.qk_norm.query_norm.scale"),
+                                     self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["q"], a["k"], None, a["rrms"], B, N,
+                                     Hh, 64, rot)
+            ops.attn_fwd_qkv(a["q"], a["k"], a["qkv"], a["a"], a["lse"], B, Hh, N, 64, 64**-0.5)
+            _must(ops.ln_modulate_gemm_fwd(a["a"], sh[pre + "attention.proj_out.weight|f"], xin, mod[:, mo + 2 * D : mo + 3 * D],
+                                            self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"), mod[:, mo + 3 * D : mo + 4 * D],
+                                            mod[:, mo + 4 * D : mo + 5 * D], N, 1e-5, a["t1"], a["x1"], a["xm2"], a["mean2"], a["rstd2"]))
+            if not ops.gemm_nt_swiglu(a["xm2"], sh[pre + "mlp_input.0.weight|g"], a["u"] if train else None, a["h"]):
+                raise RuntimeError("the row-complete path needs the fused MLP-up kernel")
+            if i + 1 < L:
+                nx, mn, nxt = lay(i + 1), (i + 1) * 6 * D, f"layers.{i + 1}."
+                lnw, lnb, eps = self.P(nxt + "norm_1.weight"), self.P(nxt + "norm_1.bias"), 1e-5
+                xm_n, mu_n, rs_n = nx["xm1"], nx["mean1"], nx["rstd1"]
+            else:
+                mn, lnw, lnb, eps = L * 6 * D, None, None, 1e-6
+                xm_n, mu_n, rs_n = w["xf"], w["meanf"], w["rstdf"]
+            _must(ops.ln_modulate_gemm_fwd(a["h"], sh[pre + "mlp_input.2.weight|f"], a["x1"], mod[:, mo + 5 * D : mo + 6 * D], lnw, lnb,
+                                            mod[:, mn : mn + D], mod[:, mn + D : mn + 2 * D], N, eps, a["t2"], xbuf(i + 1), xm_n, mu_n,
+                                            rs_n))
+
     # ------------------------------------------------------------------ backward
     def feature(self, k: int) -> Tensor:
         """output of block k of the last train-mode forward: the residual stream after the block, bf16 [B, N, D] (a view of
@@ -554,17 +644,26 @@ class DiTEngine:
             ops.gemm_tn(w["dO"], w["xf"], w["scr_last"], M=Fo8, N=D)
             ops.reduce_rows_f32(w["scr_last"], gl, 1, Fo * D)
         ops.colsum(w["dO"], self.G("last_layer.linear.bias"), M, Fo)
-        ops.gemm_nt(w["dO"], sh["last_layer.linear.weight|t"], w["dxm"], M=M, N=D, K=self._ko)
+        fused = self._row_gemms(M, N)
+        if not fused:
+            ops.gemm_nt(w["dO"], sh["last_layer.linear.weight|t"], w["dxm"], M=M, N=D, K=self._ko)
         mo = L * 6 * D
         dx, dx_alt = w["dxa"], w["dxb"]
         # every LayerNorm-modulate backward also runs the backward of the gated residual that follows it in the chain
         # (x_new = x + gate * t): it has the residual-stream gradient dx in registers, so dt = gate * dx and dgate += dx * t
         # cost one extra row read / write instead of a separate pass over dx
         ml = (L - 1) * 6 * D
-        ops.ln_modulate_bwd(w["dxm"], xs[L], None, None, mod[:, mo : mo + D], N, w["meanf"], w["rstdf"], dfeats.get(L - 1), dx,
-                            dmod[:, mo : mo + D], dmod[:, mo + D : mo + 2 * D], None, gate_t=w["layers"][L - 1]["t2"],
-                            gate=mod[:, ml + 5 * D : ml + 6 * D], dt=w["wg"][L - 1]["dt2"],
-                            dgate=dmod[:, ml + 5 * D : ml + 6 * D])
+        if fused:  # (row-complete GEMMs: the LayerNorm backward is the epilogue of the data-gradient GEMM in front of it)
+            _must(ops.ln_modulate_gemm_bwd(w["dO"], sh["last_layer.linear.weight|t"], xs[L], None, None, mod[:, mo : mo + D], N,
+                                            w["meanf"], w["rstdf"], dfeats.get(L - 1), dx, dmod[:, mo : mo + D],
+                                            dmod[:, mo + D : mo + 2 * D], None, gate_t=w["layers"][L - 1]["t2"],
+                                            gate=mod[:, ml + 5 * D : ml + 6 * D], dt=w["wg"][L - 1]["dt2"],
+                                            dgate=dmod[:, ml + 5 * D : ml + 6 * D], K=self._ko))
+        else:
+            ops.ln_modulate_bwd(w["dxm"], xs[L], None, None, mod[:, mo : mo + D], N, w["meanf"], w["rstdf"], dfeats.get(L - 1), dx,
+                                dmod[:, mo : mo + D], dmod[:, mo + D : mo + 2 * D], None, gate_t=w["layers"][L - 1]["t2"],
+                                gate=mod[:, ml + 5 * D : ml + 6 * D], dt=w["wg"][L - 1]["dt2"],
+                                dgate=dmod[:, ml + 5 * D : ml + 6 * D])
 
         # The four weight-gradient GEMMs of a block are off the dependency chain (nothing downstream reads them), so they
         # run on a SIDE HIP stream: they overlap the HBM-bound kernels of the main chain (gate/SwiGLU/adaLN/QK-norm
@@ -591,6 +690,8 @@ class DiTEngine:
                 ops.gemm_tn(x_grad, x_in, self.G(gname), max_wgs=side_wgs, ws=ws)
 
         def fold_norm(partial: Tensor, gname: str) -> None:  # [B, 2, D] per-sample sums -> [w; b] gradients, off the chain
+            if defer_fold:
+                return
             ev = main.record_event()
             with torch.cuda.stream(side):
                 side.wait_event(ev)
@@ -626,6 +727,7 @@ class DiTEngine:
         # fused MLP-down dgrad + SwiGLU backward (dH never written): 32 % less HBM traffic than the GEMM + elementwise pair
         fused_dswiglu = os.environ.get("DL_FUSED_DSWIGLU", "0") == "1"
         native = self._native_blocks() and not fused_dswiglu and not serial and dx is w["dxa"]
+        defer_fold = fused and self.reducer is None  # LayerNorm-affine partials of every block: one batched fold after the loop
         for i in reversed(range(L)):
             if native:
                 blk = self._block_args(i, True)
@@ -640,18 +742,25 @@ class DiTEngine:
             # MLP branch
             wgrad(g["dt2"], a["h"], pre + "mlp_input.2.weight", wide=True)  # dt2 / dgate: produced by the LayerNorm backward before
             if a["u"] is None:  # no saved pre-activations: the u tile is recomputed next to the dh tile, neither is written
-                assert ops.mlp_dswiglu_recompute(a["xm2"], sh[pre + "mlp_input.0.weight|g"], g["dt2"], sh[pre + "mlp_input.2.weight|t"],
-                                                 g["du"])
+                _must(ops.mlp_dswiglu_recompute(a["xm2"], sh[pre + "mlp_input.0.weight|g"], g["dt2"], sh[pre + "mlp_input.2.weight|t"],
+                                                 g["du"]))
             elif not (fused_dswiglu and ops.gemm_nt_dswiglu(g["dt2"], sh[pre + "mlp_input.2.weight|t"], a["u"], g["du"])):
                 ops.gemm_nt(g["dt2"], sh[pre + "mlp_input.2.weight|t"], w["dh"])
                 ops.swiglu_bwd(w["dh"], a["u"], g["du"])
             wgrad(g["du"], a["xm2"], pre + "mlp_input.0.weight", wide=True)
-            ops.gemm_nt(g["du"], sh[pre + "mlp_input.0.weight|t"], w["dxm"])
-            ops.ln_modulate_bwd(w["dxm"], a["x1"], self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"),
-                                mod[:, mo + 3 * D : mo + 4 * D], N, a["mean2"], a["rstd2"], dx, dx_alt,
-                                dmod[:, mo + 3 * D : mo + 4 * D], dmod[:, mo + 4 * D : mo + 5 * D], w["dwb"][2 * i + 1],
-                                gate_t=a["t1"], gate=mod[:, mo + 2 * D : mo + 3 * D], dt=g["dt1"],
-                                dgate=dmod[:, mo + 2 * D : mo + 3 * D])
+            if fused:
+                _must(ops.ln_modulate_gemm_bwd(g["du"], sh[pre + "mlp_input.0.weight|t"], a["x1"], self.P(pre + "norm_2.weight"),
+                                                self.P(pre + "norm_2.bias"), mod[:, mo + 3 * D : mo + 4 * D], N, a["mean2"], a["rstd2"],
+                                                dx, dx_alt, dmod[:, mo + 3 * D : mo + 4 * D], dmod[:, mo + 4 * D : mo + 5 * D],
+                                                w["dwb"][2 * i + 1], gate_t=a["t1"], gate=mod[:, mo + 2 * D : mo + 3 * D], dt=g["dt1"],
+                                                dgate=dmod[:, mo + 2 * D : mo + 3 * D]))
+            else:
+                ops.gemm_nt(g["du"], sh[pre + "mlp_input.0.weight|t"], w["dxm"])
+                ops.ln_modulate_bwd(w["dxm"], a["x1"], self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"),
+                                    mod[:, mo + 3 * D : mo + 4 * D], N, a["mean2"], a["rstd2"], dx, dx_alt,
+                                    dmod[:, mo + 3 * D : mo + 4 * D], dmod[:, mo + 4 * D : mo + 5 * D], w["dwb"][2 * i + 1],
+                                    gate_t=a["t1"], gate=mod[:, mo + 2 * D : mo + 3 * D], dt=g["dt1"],
+                                    dgate=dmod[:, mo + 2 * D : mo + 3 * D])
             fold_norm(w["dwb"][2 * i + 1], pre + "norm_2.weight")
             dx, dx_alt = dx_alt, dx
             # attention branch
@@ -669,7 +778,8 @@ class DiTEngine:
                                  self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], g["dqkv"],
                                  self.G(pre + "attention.qk_norm.query_norm.scale"), B, N, Hh, 64, rot)
             wgrad(g["dqkv"], a["xm1"], pre + "attention.qkv.weight")
-            ops.gemm_nt(g["dqkv"], sh[pre + "attention.qkv.weight|t"], w["dxm"])
+            if not fused:
+                ops.gemm_nt(g["dqkv"], sh[pre + "attention.qkv.weight|t"], w["dxm"])
             if i - 1 in dfeats:  # auxiliary-loss gradient on the output of block i-1 (= this block's input)
                 ops.add_bf16(dx, dfeats[i - 1], dx)
             nxt = {}
@@ -677,9 +787,14 @@ class DiTEngine:
                 mp = (i - 1) * 6 * D
                 nxt = dict(gate_t=w["layers"][i - 1]["t2"], gate=mod[:, mp + 5 * D : mp + 6 * D], dt=w["wg"][i - 1]["dt2"],
                            dgate=dmod[:, mp + 5 * D : mp + 6 * D])
-            ops.ln_modulate_bwd(w["dxm"], xs[i], self.P(pre + "norm_1.weight"), self.P(pre + "norm_1.bias"),
-                                mod[:, mo : mo + D], N, a["mean1"], a["rstd1"], dx, dx_alt, dmod[:, mo : mo + D],
-                                dmod[:, mo + D : mo + 2 * D], w["dwb"][2 * i], **nxt)
+            if fused:
+                _must(ops.ln_modulate_gemm_bwd(g["dqkv"], sh[pre + "attention.qkv.weight|t"], xs[i], self.P(pre + "norm_1.weight"),
+                                                self.P(pre + "norm_1.bias"), mod[:, mo : mo + D], N, a["mean1"], a["rstd1"], dx, dx_alt,
+                                                dmod[:, mo : mo + D], dmod[:, mo + D : mo + 2 * D], w["dwb"][2 * i], **nxt))
+            else:
+                ops.ln_modulate_bwd(w["dxm"], xs[i], self.P(pre + "norm_1.weight"), self.P(pre + "norm_1.bias"),
+                                    mod[:, mo : mo + D], N, a["mean1"], a["rstd1"], dx, dx_alt, dmod[:, mo : mo + D],
+                                    dmod[:, mo + D : mo + 2 * D], w["dwb"][2 * i], **nxt)
             fold_norm(w["dwb"][2 * i], pre + "norm_1.weight")
             dx, dx_alt = dx_alt, dx
             block_done(i)  # this block's gradient range is final once BOTH streams are past this point
@@ -689,6 +804,11 @@ class DiTEngine:
             e_side.record(side)
             self._tail_probe = (e_main, e_side)
         main.wait_stream(side)
+        if defer_fold:  # dwb [2L, B, 2, D]: rows 2i -> norm_1 of block i, 2i + 1 -> norm_2; [w; b] of a norm are adjacent in the arena
+            ent = self.layout.entries
+            stride = ent[self.prefixes[1] + "norm_1.weight"][0] - ent[self.prefixes[0] + "norm_1.weight"][0] if L > 1 else 0
+            for j, nm in enumerate(("norm_1.weight", "norm_2.weight")):
+                ops.reduce_rows_batched_f32(w["dwb"][j], 2 * B * 2 * D, self.G(self.prefixes[0] + nm), stride, L, B, 2 * D)
 
         self._cond_bwd(dx)
 

@@ -252,6 +252,39 @@ def ln_modulate_bwd(dout, x, w, b, scale, rows_per_mod, mean, rstd, dres, dx, ds
           gate.stride(0) if gate is not None else 0, _p(dt), _p(dgate), M, D, _s())
 
 
+def row_gemm_ok(M: int, D: int, rows_per_mod: int) -> bool:
+    """shapes served by the row-complete GEMMs (csrc/gemm_ln.hip): a 256 x 384 tile is a whole sample's whole rows.
+    DL_ROW_GEMM=0 restores the GEMM + row-kernel launch pairs (A/B switch)"""
+    return os.environ.get("DL_ROW_GEMM", "1") != "0" and D == 384 and rows_per_mod == 256 and M % 256 == 0 and M // 256 >= 8
+
+
+def ln_modulate_gemm_fwd(a, w_sh, resid, gate, ln_w, ln_b, scale, shift, rows_per_mod, eps, t_out, x_out, xm_out, mean, rstd,
+                         K=None) -> bool:
+    """t = a @ w_sh^T; x' = resid + gate * t; xm = modulate(LN(x')) in one launch; False when the shape has no such kernel"""
+    M, D = xm_out.shape
+    return _maybe("dl_ln_modulate_gemm_fwd", _p(a), a.stride(0), _p(w_sh), w_sh.stride(0), M, a.shape[1] if K is None else K, _p(resid),
+                  _p(gate), gate.stride(0) if gate is not None else 0, _p(ln_w), _p(ln_b), _p(scale), _p(shift), scale.stride(0),
+                  rows_per_mod, float(eps), _p(t_out), _p(x_out), _p(xm_out), _p(mean), _p(rstd), D, _s())
+
+
+def ln_modulate_gemm_bwd(a, wt_sh, x, ln_w, ln_b, scale, rows_per_mod, mean, rstd, dres, dx, dscale, dshift, dwb_partial,
+                         gate_t=None, gate=None, dt=None, dgate=None, K=None) -> bool:
+    """dout = a @ wt_sh^T (never written) -> LayerNorm-modulate backward; dscale / dshift / dgate / dwb_partial are WRITTEN"""
+    M, D = x.shape
+    assert dscale.dtype == torch.float32 and dshift.dtype == torch.float32 and dshift.stride(0) == dscale.stride(0)
+    assert dgate is None or (dgate.dtype == torch.float32 and dgate.stride(0) == dscale.stride(0))
+    return _maybe("dl_ln_modulate_gemm_bwd", _p(a), a.stride(0), _p(wt_sh), wt_sh.stride(0), M, a.shape[1] if K is None else K, _p(x),
+                  _p(ln_w), _p(ln_b), _p(scale), scale.stride(0), rows_per_mod, _p(mean), _p(rstd), _p(dres), _p(dx), _p(dscale),
+                  _p(dshift), dscale.stride(0), _p(dwb_partial), _p(gate_t), _p(gate), gate.stride(0) if gate is not None else 0,
+                  _p(dt), _p(dgate), D, _s())
+
+
+def gemm_nt_qk_norm_rope(a, w_qkv, scale_q, scale_k, cos, sin, qkv, q, k, rrms, B, N, H, dh, rot, eps=1e-6, n_off=0) -> bool:
+    """qkv = a @ w_qkv^T plus RMSNorm + RoPE + head split of its q / k thirds in one launch"""
+    return _maybe("dl_gemm_nt_qk_norm_rope", _p(a), a.stride(0), _p(w_qkv), w_qkv.stride(0), B, N, H, dh, rot, float(eps),
+                  _p(scale_q), _p(scale_k), _p(cos), _p(sin), _p(qkv), _p(q), _p(k), _p(rrms), q.shape[2], n_off, _s())
+
+
 def ln_modulate_bwd_tok(dout, x, w, b, scale, mean, rstd, dres, dx, dscale, dshift, dwb_partial, gate_t=None, gate=None, dt=None,
                         dgate=None):
     """per-token modulation: scale / gate rows per token; dscale / dshift / dgate bf16 row windows written per token"""
@@ -462,6 +495,11 @@ def colsum(x, out, R=None, C=None):
 
 def reduce_rows_f32(partial, out, G, n, clear=False):
     _call("dl_reduce_rows_f32", _p(partial), _p(out), G, n, int(clear), _s())
+
+
+def reduce_rows_batched_f32(partial, partial_stride, out, out_stride, K, G, n):
+    """K folds in one launch: out[k * out_stride + j] += sum_g partial[k * partial_stride + g * n + j] (deterministic)"""
+    _call("dl_reduce_rows_batched_f32", _p(partial), partial_stride, _p(out), out_stride, K, G, n, _s())
 
 
 def cosine_rows_fwd(p, d, cosv, pn2, dn2, eps=1e-8):

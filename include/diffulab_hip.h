@@ -181,6 +181,36 @@ DL_API int dl_ln_modulate_bwd_tok(const void* dout, const void* x, const float* 
                                   void* dshift, int64_t ld_dmod, float* dwb_partial, int64_t n_part, const void* gate_t,
                                   const void* gate, int64_t ld_gate, void* dt, void* dgate, int64_t M, int64_t D,
                                   dl_stream_t stream);
+/* ---- row-complete GEMMs (csrc/gemm_ln.hip): the LayerNorm-modulate / QK-norm row kernels as EPILOGUES of the GEMM that produces
+ * their input.  On persistent 256 x 384 tiles a tile holds whole rows (D == 384) and one whole modulation group (rows_per_mod ==
+ * 256), so row statistics and per-sample column sums complete on chip.  Every per-row output is bit-identical to the unfused launch
+ * pair; the per-sample sums are plain stores in a fixed summation order (no atomics).  DL_ERR_UNSUPPORTED for any other shape
+ * (the caller then issues dl_gemm_nt + the row kernel).
+ *
+ * dl_ln_modulate_gemm_fwd (mmdit.py:296-308 + nn.py:539; DiTBlock._forward's `x = x + gate * f(modulate(norm(x)))` chain):
+ *   t = A[M,K] . W[D,K]^T (bf16) ; x' = resid + gate[m / rows_per_mod] * t (resid NULL: x' = t; gate NULL: x' = resid + t) ;
+ *   xm = (LN(x') * ln_w + ln_b) * (1 + scale) + shift.  Writes t_out (may be NULL), x_out (x'), xm_out, mean, rstd.
+ *   = dl_gemm_nt followed by dl_ln_modulate_fwd(t, gate, x_out). */
+DL_API int dl_ln_modulate_gemm_fwd(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int64_t K, const void* resid,
+                                   const void* gate, int64_t ld_gate, const float* ln_w, const float* ln_b, const void* scale,
+                                   const void* shift, int64_t ld_mod, int64_t rows_per_mod, float eps, void* t_out, void* x_out,
+                                   void* xm_out, float* mean, float* rstd, int64_t D, dl_stream_t stream);
+/* dl_ln_modulate_gemm_bwd: dout = A[M,K] . Wt[D,K]^T (the data gradient of the linear that consumed the modulated rows, never
+ * written) followed by exactly dl_ln_modulate_bwd(dout, x, ...) -- except that dscale / dshift / dgate / dwb_partial are WRITTEN
+ * (=), not accumulated: one tile is one sample, so each of their elements has a single producer. */
+DL_API int dl_ln_modulate_gemm_bwd(const void* A, int64_t lda, const void* Wt, int64_t ldw, int64_t M, int64_t K, const void* x,
+                                   const float* ln_w, const float* ln_b, const void* scale, int64_t ld_mod, int64_t rows_per_mod,
+                                   const float* mean, const float* rstd, const void* dres, void* dx, float* dscale, float* dshift,
+                                   int64_t ld_dmod, float* dwb_partial, const void* gate_t, const void* gate, int64_t ld_gate,
+                                   void* dt, float* dgate, int64_t D, dl_stream_t stream);
+/* dl_gemm_nt_qk_norm_rope (DiTAttention.forward mmdit.py:81-91): qkv[M, 3D] = A[M, D] . Wqkv[3D, D]^T stored as bf16 rows, and in
+ * the same launch the q and k thirds go through RMSNorm over the full D-wide row (nn.py:430), RoPE on the first `rot` channels of
+ * every head (nn.py:345-352) and the head split: q, k [B, H, n_dst, dh] rows [n_off, n_off + N), rrms f32 [M, 2].
+ * = dl_gemm_nt followed by dl_qk_norm_rope_fwd_ex(v = NULL). */
+DL_API int dl_gemm_nt_qk_norm_rope(const void* A, int64_t lda, const void* Wqkv, int64_t ldw, int64_t B, int64_t N, int64_t H,
+                                   int64_t dh, int64_t rot, float eps, const float* scale_q, const float* scale_k, const float* cos,
+                                   const float* sin, void* qkv, void* q, void* k, float* rrms, int64_t n_dst, int64_t n_off,
+                                   dl_stream_t stream);
 /* DDT decoder conditioning (ddt.py:423-424 followed by the SiLU of Modulation / adaLN_modulation, nn.py:530, mmdit.py:543):
  * out[m, :] = silu(silu(enc[m, :] + temb[m / N, :])) (bf16 rows, the operand of the stacked per-token adaLN GEMM); backward:
  * denc = dout * d(silu o silu), dtemb[b, :] += sum over the N tokens of sample b (f32, atomically accumulated) */
@@ -298,6 +328,10 @@ DL_API int dl_colsum(const void* x, int dtype, int64_t ld, float* out, int64_t R
 /* out[j] += sum_g partial[g, j]   (second stage of the LayerNorm affine gradients); clear_partial != 0 zeroes `partial`
  * as it is read, so accumulate-into partial buffers need no memset */
 DL_API int dl_reduce_rows_f32(float* partial, float* out, int64_t G, int64_t n, int clear_partial, dl_stream_t stream);
+/* K such folds in one launch, deterministic (one writer per element, fixed order):
+ * out[k * out_stride + j] += sum_{g < G} partial[k * partial_stride + g * n + j]  for k < K, j < n (strides in elements) */
+DL_API int dl_reduce_rows_batched_f32(const float* partial, int64_t partial_stride, float* out, int64_t out_stride, int64_t K,
+                                      int64_t G, int64_t n, dl_stream_t stream);
 
 /* RePA alignment loss (training/losses/repa.py:196-198): row-wise F.cosine_similarity(p, d, dim=-1, eps) between the projected
  * denoiser features p (bf16 [M, E]) and the target encoder features d (f32 [M, E]); |p|^2 and |d|^2 are kept for the backward.
@@ -490,16 +524,27 @@ enum {
   DL_BLK_DWB1, DL_BLK_DWB2,                                                           /* f32 [B,2,D] per-sample LayerNorm-affine sums */
   DL_BLK_PREV_T2, DL_BLK_PREV_GATE2, DL_BLK_PREV_DT2, DL_BLK_PREV_DGATE2,             /* previous block's MLP residual, or NULL x4 */
   DL_BLK_G_QKV, DL_BLK_G_PROJ, DL_BLK_G_UP, DL_BLK_G_DOWN, DL_BLK_G_LN1, DL_BLK_G_LN2, DL_BLK_G_QK_SCALE,  /* f32 gradients (+=) */
+  /* row_gemms mode: the LayerNorm that FOLLOWS this block (LN1 of the next block, or the final LayerNorm) runs in the epilogue of
+   * this block's MLP-down GEMM: its affine parameters (NULL x2: none), modulation rows and outputs */
+  DL_BLK_NEXT_LN_W, DL_BLK_NEXT_LN_B, DL_BLK_NEXT_SCALE, DL_BLK_NEXT_SHIFT,
+  DL_BLK_NEXT_X,      /* [M,D] residual stream leaving the block (x1 + gate2 * t2) */
+  DL_BLK_NEXT_XM, DL_BLK_NEXT_MEAN, DL_BLK_NEXT_RSTD,
   DL_BLK_NPTR
 };
 typedef struct dl_dit_block_t {
-  void* p[80];                   /* indexed by DL_BLK_* */
+  void* p[96];                   /* indexed by DL_BLK_* */
   int64_t B, N, D, H, F;
   int64_t ld_mod, ld_dmod;       /* row strides (elements) of the bf16 modulation matrix and of its f32 gradient */
   int64_t ldw_d, ldw_f;          /* row strides of the forward shadows with in = D / in = F */
   int64_t ldwt_d, ldwt_f2, ldwt_3d; /* row strides of the transposed shadows with out = D / 2F / 3D */
   int64_t rot;                   /* rotary width per head */
   float eps;                     /* LayerNorm epsilon (1e-5 in the blocks) */
+  float next_eps;                /* epsilon of the LayerNorm behind DL_BLK_NEXT_* */
+  int32_t row_gemms;             /* bit 0: LayerNorm-modulate forward / backward as GEMM epilogues (dl_ln_modulate_gemm_*; needs D == 384,
+                                  * N == 256): LN1 is NOT run by dl_dit_block_fwd (XM1 / MEAN1 / RSTD1 come from the previous block's
+                                  * MLP-down epilogue or the patch embedding) and the MLP branch's gated residual IS applied (NEXT_X);
+                                  * bit 1: QK-norm + RoPE in the qkv GEMM's epilogue; bit 2: dl_dit_block_bwd leaves the LayerNorm-affine
+                                  * partials DWB1 / DWB2 unfolded (the caller folds all blocks at once: dl_reduce_rows_batched_f32) */
 } dl_dit_block_t;
 /* forward of one block; train != 0 keeps the MLP pre-activations U for the backward.  The MLP branch's gated residual
  * (x1 + gate2 * t2) is NOT applied: it is the next block's (or the final LayerNorm's) pending triple. */
