@@ -46,7 +46,10 @@ class OmegaConf:
 
 def main(version_base: Any = None, config_path: str | None = None, config_name: str | None = None) -> Callable:
     """``@hydra.main``: compose ``<dir of the decorated function's file>/<config_path>/<config_name>.yaml`` with the command-line
-    overrides and call the function with the config (``--config-name X`` / ``-cn X`` select another top-level file)"""
+    overrides and call the function with the config.  Hydra's own flags are honoured: ``--config-name / -cn X`` selects another
+    top-level file, ``--config-path / -cp P`` replaces the decorator's config_path (absolute, or relative to the script like the
+    decorator's), ``--config-dir / -cd D`` adds a directory to the search path of the config groups (absolute or relative to the
+    working directory); each also as ``--flag=value``."""
 
     def deco(fn: Callable) -> Callable:
         @functools.wraps(fn)
@@ -54,21 +57,30 @@ def main(version_base: Any = None, config_path: str | None = None, config_name: 
             if cfg is not None:
                 return fn(cfg)
             here = os.path.dirname(os.path.abspath(fn.__code__.co_filename))  # config_path is relative to the script
-            name, overrides, args = config_name, [], sys.argv[1:]
+            name, path, extra, overrides, args = config_name, config_path, [], [], sys.argv[1:]
+            flags = {"--config-name": "name", "-cn": "name", "--config-path": "path", "-cp": "path", "--config-dir": "dir", "-cd": "dir"}
             i = 0
             while i < len(args):
                 a = args[i]
-                if a in ("--config-name", "-cn") and i + 1 < len(args):
-                    name, i = args[i + 1], i + 2
-                    continue
-                if a.startswith("--config-name="):
-                    name = a.split("=", 1)[1]
-                elif "=" in a and not a.startswith("-"):
+                flag, eq, val = a.partition("=")
+                if flag in flags:
+                    if not eq:
+                        if i + 1 >= len(args):
+                            raise ValueError(f"hydra.main: {a} needs a value")
+                        val, i = args[i + 1], i + 1
+                    kind = flags[flag]
+                    if kind == "name":
+                        name = val[:-5] if val.endswith(".yaml") else val
+                    elif kind == "path":
+                        path = val
+                    else:
+                        extra.append(os.path.abspath(val))
+                elif a.startswith("~") or ("=" in a and not a.startswith("-")):
                     overrides.append(a)
                 i += 1
             if name is None:
                 raise ValueError("hydra.main: no config_name given")
-            return fn(load_config(os.path.normpath(os.path.join(here, config_path or ".")), name, overrides))
+            return fn(load_config(os.path.normpath(os.path.join(here, path or ".")), name, overrides, extra_dirs=extra))
 
         return run
 

@@ -51,21 +51,64 @@ def _merge(dst: dict, src: dict) -> dict:
     return dst
 
 
-def load_config(config_dir: str | Path, name: str, overrides: list[str] | None = None) -> Config:
-    """compose ``<config_dir>/<name>.yaml``: every ``- group: option`` of its ``defaults`` list loads
-    ``<config_dir>/<group>/<option>.yaml`` under key ``group``; ``_self_`` marks where the file's own keys are merged;
-    ``overrides`` are ``a.b.c=value`` strings (values parsed as YAML) or, like Hydra, ``group=option`` to pick another file of a
-    defaults group (``optimizer=sgd``)."""
+class ConfigCompositionError(ValueError):
+    """what Hydra raises as MissingConfigException / ConfigCompositionException: an override names a config-group option that
+    does not exist, or sets a key that is not in the composed config without the ``+`` prefix"""
+
+
+def _find_option(search: list[Path], group: str, option: str) -> Path | None:
+    for d in search:
+        f = d / group / f"{option}.yaml"
+        if f.exists():
+            return f
+    return None
+
+
+def load_config(config_dir: str | Path, name: str, overrides: list[str] | None = None,
+                extra_dirs: list[str | Path] | None = None) -> Config:
+    """compose ``<config_dir>/<name>.yaml``: every ``- group: option`` of its ``defaults`` list loads ``<group>/<option>.yaml`` (looked
+    up in ``config_dir``, then in ``extra_dirs`` = Hydra's ``--config-dir``) under key ``group``; ``_self_`` marks where the file's own
+    keys are merged.  ``overrides`` follow Hydra's grammar:
+      ``group=option``   pick another file of a config group -- an option that no search directory holds RAISES (Hydra:
+                         "Could not find 'group/option'"), it never degrades into a string value;
+      ``a.b.c=value``    set an EXISTING key (value parsed as YAML); a key that is not in the config raises (Hydra's struct mode);
+      ``+a.b.c=value``   add a new key; ``++a.b.c=value`` add or override; ``~a.b.c`` delete a key; ``+group=option`` append a group."""
     config_dir = Path(config_dir)
-    raw = yaml.safe_load((config_dir / f"{name}.yaml").read_text()) or {}
-    defaults = raw.pop("defaults", [])
+    search = [config_dir] + [Path(d) for d in (extra_dirs or [])]
+    top = next((d / f"{name}.yaml" for d in search if (d / f"{name}.yaml").exists()), None)
+    if top is None:
+        raise ConfigCompositionError(f"Cannot find primary config '{name}' in {[str(d) for d in search]}")
+    raw = yaml.safe_load(top.read_text()) or {}
+    defaults = list(raw.pop("defaults", []))
     raw.pop("hydra", None)
-    overrides = list(overrides or [])
-    for ov in list(overrides):  # group choice overrides replace the entry of the defaults list
-        key, _, val = ov.partition("=")
-        if "." not in key and (config_dir / key / f"{val}.yaml").exists():
-            defaults = [({key: val} if isinstance(d, dict) and key in d else d) for d in defaults]
-            overrides.remove(ov)
+    groups_in_defaults = {next(iter(d)) for d in defaults if isinstance(d, dict)}
+
+    def is_group(key: str) -> bool:
+        return "." not in key and (key in groups_in_defaults or any((d / key).is_dir() for d in search))
+
+    value_overrides: list[tuple[str, str, str]] = []  # (prefix, dotted key, raw value)
+    for ov in overrides or []:
+        m = re.match(r"^(\+\+|\+|~)?([^=]+?)(?:=(.*))?$", ov, flags=re.S)
+        if m is None:
+            raise ConfigCompositionError(f"Error parsing override '{ov}'")
+        prefix, key, val = m.group(1) or "", m.group(2), m.group(3)
+        if prefix != "~" and val is None:
+            raise ConfigCompositionError(f"Error parsing override '{ov}': missing '='")
+        if prefix in ("", "+") and is_group(key) and not isinstance(yaml.safe_load(val), (dict, list)):
+            if _find_option(search, key, val) is None:
+                have = sorted({f.stem for d in search if (d / key).is_dir() for f in (d / key).glob("*.yaml")})
+                raise ConfigCompositionError(f"Could not find '{key}/{val}'\n\nAvailable options in '{key}':\n\t" + "\n\t".join(have))
+            if key in groups_in_defaults:
+                defaults = [({key: val} if isinstance(d, dict) and key in d else d) for d in defaults]
+            elif prefix == "+":
+                defaults.append({key: val})
+                groups_in_defaults.add(key)
+            else:
+                raise ConfigCompositionError(f"Could not override '{key}'.\nDid you mean to override {key} in the defaults list? "
+                                             f"No match in the defaults list.  To append to your default list use +{key}={val}")
+            continue
+        value_overrides.append((prefix, key, val if val is not None else ""))
+
     out: dict[str, Any] = {}
     merged_self = False
     for d in defaults:
@@ -74,17 +117,37 @@ def load_config(config_dir: str | Path, name: str, overrides: list[str] | None =
             merged_self = True
         else:
             (group, option), = d.items()
-            node = yaml.safe_load((config_dir / group / f"{option}.yaml").read_text()) or {}
-            _merge(out, {group: node})
+            if option is None:
+                continue
+            f = _find_option(search, group, option)
+            if f is None:
+                raise ConfigCompositionError(f"In '{name}': Could not find '{group}/{option}'")
+            _merge(out, {group: yaml.safe_load(f.read_text()) or {}})
     if not merged_self:
         _merge(out, raw)
-    for ov in overrides:
-        key, _, val = ov.partition("=")
+    for prefix, key, val in value_overrides:
         cur = out
         parts = key.split(".")
-        for p in parts[:-1]:
-            cur = cur.setdefault(p, {})
-        cur[parts[-1]] = yaml.safe_load(val)
+        for i, p in enumerate(parts[:-1]):
+            if not isinstance(cur.get(p), dict):
+                if prefix in ("+", "++"):
+                    cur[p] = {}
+                else:
+                    raise ConfigCompositionError(f"Could not override '{key}'.\nTo append to your config use +{key}={val}\n"
+                                                 f"Key '{p}' is not in struct\n    full_key: {'.'.join(parts[: i + 1])}")
+            cur = cur[p]
+        leaf = parts[-1]
+        if prefix == "~":
+            if leaf not in cur:
+                raise ConfigCompositionError(f"Could not delete from config. '{key}' does not exist.")
+            del cur[leaf]
+        elif prefix == "" and leaf not in cur:
+            raise ConfigCompositionError(f"Could not override '{key}'.\nTo append to your config use +{key}={val}\n"
+                                         f"Key '{leaf}' is not in struct\n    full_key: {key}")
+        elif prefix == "+" and leaf in cur:
+            raise ConfigCompositionError(f"Could not append to config. An item is already at '{key}'.")
+        else:
+            cur[leaf] = yaml.safe_load(val)
     return _wrap(out)
 
 
