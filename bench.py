@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: train images/sec/node, DiT-S/2 rectified-flow training on 256x256-image latents (4x32x32).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py                                  # = --gpus 1 --steps 100 --warmup 20; ~1 min with the CPU leg
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -19,7 +19,10 @@ Extra objects on the JSON line:
                   img/s) as `step_achieved`.
   cpu_baseline -- the CPU oracle (a port of the reference path, oracle/) timed on this host's cores by the protocol of
                   BASELINE.md section 3 / SURVEY 8(d): B=32, 1 warm-up + 3 timed steps, thread count printed; rank 0 at N=1 only.
-  dp           -- N>1: rccl_ranks and the exposed (non-overlapped) part of the gradient all-reduce per step.
+  dp           -- N>1: rccl_ranks and the exposed (non-overlapped) part of the gradient all-reduce per step (`--dp-backend gloo`
+                  is the dry mode of this branch for boxes with fewer GPUs than ranks; a GPU test runs it on 2 ranks).
+  config.loss_curve_rel_err -- 20 AdamW steps of DiT-S/2 against the reference's own fp32 loss curve (committed fixture): the
+                  largest / mean per-step relative error of the bf16 HIP path (N=1, outside the timed region).
 """
 
 from __future__ import annotations
@@ -97,10 +100,44 @@ def cpu_baseline(batch: int = 32, n_timed: int = 3, budget_s: float = 150.0) -> 
             "sample": f"oracle fp32 DiT-S/2 flow train step, B={batch}, {len(times) - len(timed)} warm-up + {len(timed)} timed steps"}
 
 
+def loss_curve_rel_err(dev) -> dict:
+    """SURVEY 8(c)(viii) / north_star "loss curve matching CPU reference": 20 AdamW steps of DiT-S/2 (B=4, fixed synthetic data)
+    on the HIP path against the curve the REFERENCE itself produced in fp32 (tests/golden/loss_curve.npz, written by
+    tests/golden/make_golden.py from /root/reference); returns the largest and the mean per-step relative error.  The oracle
+    package only supplies the seeded input generator here (checker use, outside the timed region)."""
+    import numpy as np
+
+    from diffulab_amd import Diffuser, MMDiT
+    from diffulab_amd.training import FusedAdamW
+    from oracle import dit as odit
+    from oracle import synth
+
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "loss_curve.npz"))["losses"]
+    m = MMDiT(**S2)
+    m.load_state_dict(synth.dit_params(odit.param_shapes(odit.DiTConfig()), seed=7))
+    m = m.to(dev)
+    opt = FusedAdamW(m.parameters(), lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8)
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=50)
+    B = 4
+    x0, y = synth.normal("curve.x0", (B, 4, 32, 32)).to(dev), synth.integers("curve.y", (B,), 1000).to(dev)
+    got = []
+    for s in range(len(ref)):
+        noise = synth.normal(f"curve.noise{s}", (B, 4, 32, 32)).to(dev)
+        t = synth.uniform(f"curve.t{s}", (B,), lo=0.02, hi=0.98)
+        opt.zero_grad()
+        loss = d.compute_loss({"x": x0, "y": y, "p": 0.0}, timesteps=t, noise=noise)["loss"]
+        loss.backward()
+        opt.step()
+        got.append(loss.item())
+    err = np.abs(np.array(got) - ref) / ref
+    return {"steps": len(ref), "max": float(f"{err.max():.3e}"), "mean": float(f"{err.mean():.3e}"),
+            "against": "the reference's fp32 curve (tests/golden/loss_curve.npz); compute dtype here: bf16"}
+
+
 def _tn_variant(R: int, M: int, N: int) -> str:
     """which kernel dl_gemm_tn dispatches to (csrc/gemm.hip dl_gemm_tn_ex, default variant)"""
     tiles_m = -(-M // 384)
-    if os.environ.get("DL_GEMM_TN_VARIANT", "2") == "2" and M % 384 == 0 and N % 192 == 0 and R // 32 >= 64:
+    if M % 384 == 0 and N % 192 == 0 and R // 32 >= 64:
         return "gemm_tn_w4_k"
     if N % 128 == 0 and R // 64 >= 64 and 5 * M >= 3 * tiles_m * 384:
         return "gemm_tn_big_k"
@@ -129,7 +166,8 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
     rec: list[tuple[str, torch.cuda.Event, torch.cuda.Event, float]] = []
     tn_shapes: dict[tuple[str, int, int, int], int] = {}  # weight-gradient launches of the replay: (kernel, R, M, N) -> count
     orig = {n: getattr(ops, n) for n in ("gemm_nt", "gemm_nt_swiglu", "gemm_tn", "attn_fwd_qkv", "attn_bwd_qkv", "attn_fwd", "attn_bwd",
-                                         "mlp_dswiglu_recompute")}
+                                         "mlp_dswiglu_recompute", "ln_modulate_gemm_fwd", "ln_modulate_gemm_bwd",
+                                         "gemm_nt_qk_norm_rope", "gemm_tn_group")}
 
     def timed(kind: str):
         fn = orig[kind]
@@ -142,6 +180,15 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
                 name, fl = _nt_variant(M, N, K, plain), 2.0 * M * N * K
             elif kind == "gemm_nt_swiglu":
                 name, fl = "gemm_nt_big_k<384,2,2>", 2.0 * a.shape[0] * b.shape[0] * a.shape[1]
+            elif kind in ("ln_modulate_gemm_fwd", "ln_modulate_gemm_bwd"):  # (a [M, K], w [384, K], ...): row-complete 256x384 tiles
+                K = kw.get("K") or a.shape[1]
+                name, fl = "gemm_nt_rows_k<%d>" % (0 if kind.endswith("fwd") else 1), 2.0 * a.shape[0] * 384 * K
+            elif kind == "gemm_nt_qk_norm_rope":
+                name, fl = "gemm_nt_rows_k<2>", 2.0 * a.shape[0] * b.shape[0] * a.shape[1]
+            elif kind == "gemm_tn_group":  # (probs = [(dy, x, g), ...], slab): one launch + the fold
+                name, fl = "gemm_tn_group_k", sum(2.0 * dy.shape[0] * g.shape[0] * g.shape[1] for dy, _, g in a)
+                tn_shapes[(name, a[0][0].shape[0], tuple((g.shape[0], g.shape[1]) for _, _, g in a), 0)] = \
+                    tn_shapes.get((name, a[0][0].shape[0], tuple((g.shape[0], g.shape[1]) for _, _, g in a), 0), 0) + 1
             elif kind == "mlp_dswiglu_recompute":  # (x, wp, dt, w2t, du): u tile recomputed (2 M 2F K) + dh tile (2 M F K)
                 name, fl = "mlp_dswiglu_rc_k", 6.0 * a.shape[0] * rest[1].shape[0] * a.shape[1]
             elif kind.startswith("attn_"):  # (q, k, ..., B, H, N, dh, scale): 4 N^2 dh per head forward, 10 N^2 dh backward
@@ -249,7 +296,30 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
     # critical path: the step time is the main chain's).  `achieved` above is that in-step figure; the same launches alone on the
     # whole chip (same shapes and counts, uncapped, nothing else resident) are reported next to it.
     alone = None
-    if dom.startswith("gemm_tn") and tn_shapes:
+    if dom == "gemm_tn_group_k" and tn_shapes:
+        t_ms, t_fl = 0.0, 0.0
+        for (name, R, shapes, _), cnt in tn_shapes.items():
+            if name != dom:
+                continue
+            probs = [(torch.randn(R, M, device="cuda").to(torch.bfloat16), torch.randn(R, N, device="cuda").to(torch.bfloat16),
+                      torch.zeros(M, N, device="cuda")) for M, N in shapes]
+            slab = torch.empty(8 * sum(M * N for M, N in shapes), device="cuda")
+            for _ in range(3):
+                ops.gemm_tn_group(probs, slab)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                ops.gemm_tn_group(probs, slab)
+            e1.record()
+            torch.cuda.synchronize()
+            t_ms += e0.elapsed_time(e1) / 10 * cnt
+            t_fl += sum(2.0 * R * M * N for M, N in shapes) * cnt
+        if t_ms > 0:
+            alone = {"achieved": round(t_fl / (t_ms * 1e-3) / 1e12, 1), "frac": round(t_fl / (t_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                     "avg_launch_us": round(t_ms * 1e3 / sum(c for (n, *_), c in tn_shapes.items() if n == dom), 2),
+                     "note": "same launches (+ fold) alone on the whole chip, random operands"}
+    elif dom.startswith("gemm_tn") and tn_shapes:
         t_ms, t_fl = 0.0, 0.0
         for (name, R, M, N), cnt in tn_shapes.items():
             if name != dom:
@@ -285,11 +355,15 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)   # 100 timed steps after 20 warm-up steps (2.2 s + 0.4 s)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dp-backend", choices=("nccl", "gloo"), default="nccl", help="nccl (= RCCL, one rank per GPU) is the product "
+                    "path; gloo is the DRY MODE of the data-parallel branch for boxes with fewer GPUs than ranks: the ranks share the "
+                    "visible GPUs and exchange through gloo, so the reducer, the overlap instrumentation and the `dp` object run "
+                    "(tests/test_trainer_gpu.py); its throughput number means nothing")
     ap.add_argument("--trainer-mode", action="store_true", help="secondary number: the step as BaseTrainer.training_step runs it "
                     "with the shipped defaults (per-loss .item() read-back every step, fused EMA update every step)")
     args = ap.parse_args()
@@ -298,10 +372,15 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if args.dp_backend == "gloo":
+        local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dp_backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from diffulab_amd import Diffuser, MMDiT, ops
     from diffulab_amd.training import FusedAdamW
@@ -380,9 +459,10 @@ def main() -> None:
     if rank == 0 and not args.no_roofline:
         roof = roofline_replay(step, model, value / world)
 
-    cpu = None
+    cpu, curve = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
+        curve = loss_curve_rel_err(dev)
 
     if rank == 0:
         out = {
@@ -393,11 +473,14 @@ def main() -> None:
             "config": {"workload": "DiT-S/2 (MMDiT simple_dit 384/6 heads/12 blocks, patch 2, 39.9M params) rectified-flow "
                                    "train step on 4x32x32 latents (256 tokens), AdamW, label-drop 0.1",
                        "global_batch": world * B, "per_gpu_batch": B, "tokens_per_image": 256,
-                       "parallelism": f"dp{world}", "flops_per_image": train_flops_per_image(), "final_loss": final_loss},
+                       "parallelism": f"dp{world}", "flops_per_image": train_flops_per_image(), "final_loss": final_loss,
+                       "loss_curve_rel_err": curve},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if dp is not None:
             out["dp"] = dp
+            if args.dp_backend == "gloo":
+                out["data"] = "synthetic (DRY MODE of the dp branch: ranks share GPUs, gloo exchange -- not a throughput measurement)"
         if args.trainer_mode:
             out["config"]["trainer_mode"] = "per-step loss read-back + EMA(update_every=10), as BaseTrainer.training_step with use_ema"
         print(json.dumps(out))

@@ -47,27 +47,6 @@ __device__ __forceinline__ float fast_exp2f8(float x) {
   return r;
 }
 
-// ------------------------------------------------------------------------------------------------ layout probe (tests)
-// D[32,32] = A[32,64] . B[32,64]^T with the operand layout this file relies on: lane l holds row (l & 31), bytes
-// [32 (l >> 5), +32) of the row; D in the 32x32 accumulator layout (row (r&3) + 8 (r>>2) + 4 (l>>5), column l & 31).
-__global__ void probe_mfma_f8_k(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, float* __restrict__ d) {
-  const int lane = threadIdx.x, hi = lane >> 5;
-  const v8i_t av = *(const v8i_t*)(a + (lane & 31) * 64 + hi * 32);
-  const v8i_t bv = *(const v8i_t*)(b + (lane & 31) * 64 + hi * 32);
-  f32x16_t acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  acc = mfma_f8(av, bv, acc);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) d[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + (lane & 31)] = acc[r];
-}
-extern "C" int dl_probe_mfma_f8(const void* a, const void* b, float* d, dl_stream_t stream) {
-  DL_CHECK_ARG(a && b && d, "dl_probe_mfma_f8: null");
-  hipLaunchKernelGGL(probe_mfma_f8_k, 1, 64, 0, (hipStream_t)stream, (const uint8_t*)a, (const uint8_t*)b, d);
-  DL_LAUNCH_CHECK();
-  return DL_OK;
-}
-
 // ------------------------------------------------------------------------------------------------ quantisation
 // amax of q, k, v per (b, h): one workgroup per head and tensor
 __global__ __launch_bounds__(256) void f8_amax_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,

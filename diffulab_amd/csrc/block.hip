@@ -96,7 +96,17 @@ extern "C" int dl_dit_block_bwd(const dl_dit_block_t* b, dl_stream_t main_, dl_s
   hipStream_t main = (hipStream_t)main_, side = (hipStream_t)side_;
   const int64_t B = b->B, N = b->N, D = b->D, H = b->H, F = b->F, M = B * N, dh = D / H;
   const float sm = 0.125f;
+  // With a slab the four weight gradients of the block are ONE atomics-free launch (dl_gemm_tn_group) behind the last of their
+  // operands (dqkv); without one (or for shapes the 384 x 192 tile does not divide) they are four dl_gemm_tn_ex launches, each
+  // issued as soon as its operands exist.
+  dl_wgrad_t wg[4];
+  int nwg = 0;
+  bool grouped = P(TN_SLAB) != nullptr && D % 384 == 0 && F % 192 == 0 && M % 32 == 0 && M >= 2048;
   auto wgrad = [&](const void* dy, int64_t ldy, const void* x, int64_t ldx, void* g, int64_t Mo, int64_t No) -> int {
+    if (grouped) {
+      wg[nwg++] = dl_wgrad_t{dy, ldy, x, ldx, (float*)g, Mo, No};
+      return DL_OK;
+    }
     if (fork_to_side(main, side)) return DL_ERR_LAUNCH;
     return dl_gemm_tn_ex(dy, ldy, x, ldx, (float*)g, No, Mo, No, M, side_wgs, side);
   };
@@ -140,6 +150,10 @@ extern "C" int dl_dit_block_bwd(const dl_dit_block_t* b, dl_stream_t main_, dl_s
                           (const float*)P(ROPE_COS), (const float*)P(ROPE_SIN), (const float*)P(RRMS), P(DQKV), (float*)P(G_QK_SCALE), B, N,
                           H, dh, b->rot, main));
   RUN(wgrad(P(DQKV), 3 * D, P(XM1), D, P(G_QKV), 3 * D, D));
+  if (grouped) {
+    if (fork_to_side(main, side)) return DL_ERR_LAUNCH;
+    RUN(dl_gemm_tn_group(wg, nwg, M, (float*)P(TN_SLAB), b->tn_slab_floats, side_wgs, side));
+  }
   if (!rows)
     RUN(dl_gemm_nt(P(DQKV), 3 * D, P(WT_QKV), b->ldwt_3d, P(DXM), D, M, D, 3 * D, nullptr, DL_ACT_NONE, DL_BF16, nullptr, nullptr, 0,
                    nullptr, 0, 1, main));

@@ -52,18 +52,32 @@ DL_COMM_API int dl_comm_unique_id(char out[128]) {
   return 0;
 }
 
-DL_COMM_API int dl_comm_init(dl_comm_t** out, const char id[128], int rank, int world, int device) {
-  if (!out || !id || world < 1 || rank < 0 || rank >= world) return fail("dl_comm_init: bad arguments");
-  HIPC(hipSetDevice(device));
-  dl_comm_t* c = new dl_comm_t();
-  c->rank = rank;
-  c->world = world;
+static void comm_release(dl_comm_t* c) {  // every handle that was created so far (zero-initialised struct: nullptr = not yet)
+  if (c->comm) (void)ncclCommDestroy(c->comm);
+  if (c->ready) (void)hipEventDestroy(c->ready);
+  if (c->done) (void)hipEventDestroy(c->done);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+static int comm_setup(dl_comm_t* c, const char id[128], int rank, int world) {
   ncclUniqueId uid;
   memcpy(&uid, id, 128);
   NCCLC(ncclCommInitRank(&c->comm, world, uid, rank));
   HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPC(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
   HIPC(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+  return 0;
+}
+DL_COMM_API int dl_comm_init(dl_comm_t** out, const char id[128], int rank, int world, int device) {
+  if (!out || !id || world < 1 || rank < 0 || rank >= world) return fail("dl_comm_init: bad arguments");
+  HIPC(hipSetDevice(device));
+  dl_comm_t* c = new dl_comm_t();
+  c->rank = rank;
+  c->world = world;
+  if (comm_setup(c, id, rank, world) != 0) {  // (the error text is already set)
+    comm_release(c);
+    return -1;
+  }
   *out = c;
   return 0;
 }

@@ -15,13 +15,6 @@
 
 #include "common.h"
 
-static int g_gemm_probe = 0;
-static int g_nt_pipe = -1;  // DL_GEMM_NT_PIPE (latched by the launcher): fragment software pipeline in gemm_nt_big_k
-extern "C" int dl_probe_gemm_set(int flags) {
-  g_gemm_probe = flags;
-  return DL_OK;
-}
-
 #define BM 128
 #define BN 128
 #define BK 64
@@ -46,14 +39,13 @@ struct NtEpilogue {
   const bf16_t* gate;
   int64_t ldg;
   int64_t rows_per_gate;
-  // fused SwiGLU (EPI 2: forward, EPI 3: backward): `aux` is h (fwd, written) / u (bwd, read), F = hidden width
+  // fused SwiGLU forward (EPI 2): `aux` is h (written), F = hidden width
   bf16_t* aux;
   int64_t ld_aux;
   int F;
   // persistent big-tile kernel only: start-up skew (in units of ~0.5 us per k-step of a tile) between groups of workgroups,
   // so that the store bursts of their tile epilogues do not hit HBM in lockstep
   int stagger;
-  int pipe;  // persistent big-tile kernel only: fragment software pipeline in the k-step (A/B switch DL_GEMM_NT_PIPE)
 };
 
 // implicit-GEMM view of a 3x3 / pad 1 convolution over NHWC rows: the A operand "cols[p, (tap, ci)]" is never materialised,
@@ -324,9 +316,7 @@ template <int JN, int TN_, int EPI>
 __device__ __forceinline__ void nt_epilogue_regs(f32x16_t (&acc)[JN][2], int m_base, int n_base, int lane, void* C,
                                                  int64_t ldc, const NtEpilogue& ep);
 
-// PROBE (tuning builds only, scripts/gemm_probe.py): 1 = no epilogue stores, 2 = no MFMA, 4 = no DMA after the ring fill,
-// 8 = no LDS fragment reads -- each leaves the rest of the kernel in place, so the differences locate the limiter
-template <int TN_, int NST, int EPI, int PROBE = 0>
+template <int TN_, int NST, int EPI>
 __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __restrict__ A, int64_t lda,
                                                                   const bf16_t* __restrict__ Bm, int64_t ldb,
                                                                   void* __restrict__ C, int64_t ldc, int M, int N,
@@ -366,10 +356,8 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
   const bf16_t* s_tb = Bm + (int64_t)((s_tile % tiles_n) * TN_) * ldb;
   auto stage_next = [&]() {
     char* base = smem + (s_it % NST) * STAGE;
-    if (!(PROBE & 4) || s_it < NST - 1) {
 #pragma unroll
-      for (int i = 0; i < CH; ++i) glds16((is_a[i] ? s_ta : s_tb) + src_off[i] + s_kt * BK, base + lds_off[i]);
-    }
+    for (int i = 0; i < CH; ++i) glds16((is_a[i] ? s_ta : s_tb) + src_off[i] + s_kt * BK, base + lds_off[i]);
     ++s_it;
     if (++s_kt == nk) {
       s_kt = 0;
@@ -412,7 +400,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
     // stage `it` must have landed; the NST-2 younger stages (and the previous tile's stores) may stay in flight
     if (it + NST - 2 < total) {
       // (the epilogue's stores are the youngest entries of the in-order counter: a counted wait lets them drain under this k-step)
-      if (EPI == 0 && after_epi && !(PROBE & 1)) wait_vmcnt<(NST - 2) * CH + ESTORES>();
+      if (EPI == 0 && after_epi) wait_vmcnt<(NST - 2) * CH + ESTORES>();
       else if (EPI == 2 && after_epi && C) wait_vmcnt<(NST - 2) * CH + 6 * JN>();
       else if (EPI == 2 && after_epi) wait_vmcnt<(NST - 2) * CH + 2 * JN>();
       else wait_vmcnt<(NST - 2) * CH>();
@@ -425,11 +413,11 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
     if (NST < 3 && s_it < total) stage_next();  // into the slot whose stage was consumed in iteration it-1
     const char* sa = smem + (it % NST) * STAGE;
     const char* sb = sa + TBM * 128;
-    if constexpr (PROBE == 64) {
+    {
       // Fragment software pipeline: the weight fragment of MFMA pair (kk, j) is read TWO pairs ahead into a three-entry register
       // ring and the two activation fragments of sub-step kk+1 during sub-step kk, each pair its own scheduling region -- the
       // LDS latency of a fragment is covered by the four MFMAs in front of its first use instead of being waited for before
-      // every group of twelve (same 32 fragment registers as the unpipelined loop below).
+      // every group of twelve (32 fragment registers).
       bf16x8_t xq[2][2], wq[3];
       auto rd_x = [&](int kk, int i) -> bf16x8_t {
         return *(const bf16x8_t*)(sa + xrow[i] * 128 + ((((kk << 1) | hi) ^ ((xrow[i] >> 1) & 7)) << 4));
@@ -451,28 +439,6 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
         for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s % 3], xq[kk & 1][i], acc[j][i], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-    } else {
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      bf16x8_t xf[2], wf[JN];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        xf[i] = *(const bf16x8_t*)(((PROBE & 8) ? smem : sa) + xrow[i] * 128 + (((((PROBE & 8) ? 0 : (kk << 1)) | hi) ^ ((xrow[i] >> 1) & 7)) << 4));
-#pragma unroll
-      for (int j = 0; j < JN; ++j)
-        wf[j] = *(const bf16x8_t*)(((PROBE & 8) ? smem + TBM * 128 : sb) + wrow[j] * 128 + (((((PROBE & 8) ? 0 : (kk << 1)) | hi) ^ ((wrow[j] >> 1) & 7)) << 4));
-      if (PROBE & 2) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(xf[i]));
-#pragma unroll
-        for (int j = 0; j < JN; ++j) asm volatile("" ::"v"(wf[j]));
-      } else {
-#pragma unroll
-        for (int j = 0; j < JN; ++j)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
-      }
-    }
     }
     if (NST >= 3 && s_it < total) stage_next();
     after_epi = false;
@@ -481,21 +447,8 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
       after_epi = true;
       // ---- epilogue of `tile` straight from registers: acc[j][i][r] = C[m][n] with
       //      m = m0 + wm*64 + i*32 + (lane&31),  n = n0 + wn*TN/2 + j*32 + 8*(r>>2) + 4*hi + (r&3)
-      if (PROBE & 1) {
-#pragma unroll
-        for (int j = 0; j < JN; ++j)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              asm volatile("" ::"v"(acc[j][i][r]));
-              acc[j][i][r] = 0.f;
-            }
-          }
-      } else {
-        nt_epilogue_regs<JN, TN_, EPI>(acc, (tile / tiles_n) * TBM + wm * 64, (tile % tiles_n) * TN_ + wn * (TN_ / 2), lane, C,
-                                       ldc, ep);
-      }
+      nt_epilogue_regs<JN, TN_, EPI>(acc, (tile / tiles_n) * TBM + wm * 64, (tile % tiles_n) * TN_ + wn * (TN_ / 2), lane, C, ldc,
+                                     ep);
       if (EPI && EPI != 2) wait_vmcnt<0>();  // unknown number of epilogue memory ops: drain so the counted waits stay exact
       tile += G;
     }
@@ -541,47 +494,6 @@ __device__ __forceinline__ void nt_epilogue_regs(f32x16_t (&acc)[JN][2], int m_b
           *(u32x4_t*)((bf16_t*)C + (int64_t)m * ldc + ep.F + u0) = pack8(v3);
         }
         *(u32x4_t*)(ep.aux + (int64_t)m * ep.ld_aux + u0) = pack8(h8);
-      }
-      continue;
-    }
-    if (EPI == 3) {
-      // fused PackedSwiGLU backward: acc = dh tile; du1 = dh * x3 * silu'(x1), du3 = dh * silu(x1) with u = [x1 | x3]
-      // all loads of this row group are issued first (one exposed memory latency per group, not one per chunk)
-      u32x4_t la[JN][2], lb[JN][2];
-#pragma unroll
-      for (int j = 0; j < JN; ++j)
-#pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-          const int c = n_base + j * 32 + 16 * gp + 8 * hi;
-          la[j][gp] = *(const u32x4_t*)(ep.aux + (int64_t)m * ep.ld_aux + c);
-          lb[j][gp] = *(const u32x4_t*)(ep.aux + (int64_t)m * ep.ld_aux + ep.F + c);
-        }
-#pragma unroll
-      for (int j = 0; j < JN; ++j) {
-#pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const unsigned x = __float_as_uint(acc[j][i][8 * gp + e]), y = __float_as_uint(acc[j][i][8 * gp + 4 + e]);
-            auto sw = __builtin_amdgcn_permlane32_swap(x, y, false, false);
-            v[e] = __uint_as_float(sw[0]);
-            v[4 + e] = __uint_as_float(sw[1]);
-            acc[j][i][8 * gp + e] = 0.f;
-            acc[j][i][8 * gp + 4 + e] = 0.f;
-          }
-          const int c = n_base + j * 32 + 16 * gp + 8 * hi;
-          float a[8], b[8], d1[8], d3[8];
-          unpack8(la[j][gp], a);
-          unpack8(lb[j][gp], b);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            d1[e] = v[e] * b[e] * dsilu_f(a[e]);
-            d3[e] = v[e] * silu_f(a[e]);
-          }
-          *(u32x4_t*)((bf16_t*)C + (int64_t)m * ldc + c) = pack8(d1);
-          *(u32x4_t*)((bf16_t*)C + (int64_t)m * ldc + ep.F + c) = pack8(d3);
-        }
       }
       continue;
     }
@@ -671,78 +583,20 @@ static int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, vo
     (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-  }
-  if (g_nt_pipe < 0) {
-    const char* e = getenv("DL_GEMM_NT_PIPE");
-    g_nt_pipe = e ? atoi(e) : 1;
   }
   const int ntiles = (int)((M / TBM) * (N / TN_));
   int grid = n_cu < ntiles ? n_cu : ntiles;
   grid &= ~7;
-  static int stagger = -1, stagger_min = 6;
-  if (stagger < 0) {
-    const char* e = getenv("DL_GEMM_NT_STAGGER");  // sleep units per k-step and phase; + 256: two phase groups instead of four
-    stagger = e ? atoi(e) : 2;
-    e = getenv("DL_GEMM_NT_STAGGER_MIN");
-    if (e) stagger_min = atoi(e);
-  }
   NtEpilogue ep = ep_in;
-  ep.pipe = g_nt_pipe;
-  ep.stagger = (ntiles >= stagger_min * grid) ? stagger : 0;  // pays only when every workgroup walks many tiles (measured: MLP-up)
+  // phase skew of the tile starts (sleep units per k-step and phase group): pays only when every workgroup walks many tiles
+  // (measured: MLP-up)
+  ep.stagger = (ntiles >= 6 * grid) ? 2 : 0;
 #define BIG_GO(E)                                                                                                     \
   hipLaunchKernelGGL((gemm_nt_big_k<TN_, NST, E>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)A, lda, (const bf16_t*)B, \
                      ldb, C, ldc, (int)M, (int)N, (int)K, ep)
-  if constexpr (TN_ == 384 && NST == 2) {
-   if (g_gemm_probe && epi == 0) {
-#define PROBE_GO(P)                                                                                                   \
-  hipLaunchKernelGGL((gemm_nt_big_k<384, 2, 0, P>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)A, lda, \
-                     (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep)
-    static bool attr = false;
-    if (!attr) {
-      attr = true;
-      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 0, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<384, 2, 0, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    }
-    if (g_gemm_probe == 1) PROBE_GO(1);
-    else if (g_gemm_probe == 2) PROBE_GO(2);
-    else if (g_gemm_probe == 4) PROBE_GO(4);
-    else if (g_gemm_probe == 8) PROBE_GO(8);
-    else if (g_gemm_probe == 5) PROBE_GO(5);
-    else PROBE_GO(10);
-#undef PROBE_GO
-    DL_LAUNCH_CHECK();
-    return DL_OK;
-   }
-  }
-  if (g_nt_pipe) {
-#define PIPE_GO(E)                                                                                                        \
-  hipLaunchKernelGGL((gemm_nt_big_k<TN_, NST, E, 64>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)A, lda, (const bf16_t*)B, \
-                     ldb, C, ldc, (int)M, (int)N, (int)K, ep)
-    static bool pattr = false;
-    if (!pattr) {
-      pattr = true;
-      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 0, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 3, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    }
-    if (epi == 0) PIPE_GO(0);
-    else if (epi == 1) PIPE_GO(1);
-    else if (epi == 2) PIPE_GO(2);
-    else PIPE_GO(3);
-#undef PIPE_GO
-    DL_LAUNCH_CHECK();
-    return DL_OK;
-  }
   if (epi == 0) BIG_GO(0);
   else if (epi == 1) BIG_GO(1);
-  else if (epi == 2) BIG_GO(2);
-  else BIG_GO(3);
+  else BIG_GO(2);
 #undef BIG_GO
   DL_LAUNCH_CHECK();
   return DL_OK;
@@ -751,30 +605,21 @@ static int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, vo
 // picks the big-tile variant; returns 1 if no big kernel applies (caller falls back), else the launch status (<= 0)
 static int dispatch_big(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
                         int64_t K, const NtEpilogue& ep, int epi, hipStream_t stream) {
-  static int variant = -1;
-  if (variant < 0) {
-    const char* e = getenv("DL_GEMM_NT_VARIANT");
-    variant = e ? atoi(e) : 4;  // 4 = 256x384 tiles where N % 384 == 0, else 256x192 (best measured); 2 = 256x192 only;
-                                // 1 = 256x128 3-stage ring; 0 = small-tile kernel only
-  }
   if (M % TBM) return 1;
-  if (variant == 1 && N % 128 == 0 && (M / TBM) * (N / 128) >= 64)
-    return launch_big<128, 3>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
   // One persistent workgroup per CU, so a launch runs in ceil(tiles / 256) rounds: score every tile width the shape allows by
   // (fraction of the CU-rounds that do work) x (relative efficiency of the tile: wider tiles stage fewer bytes per FLOP) and take
   // the best; widths that would leave more than 30 % of the rounds idle are not considered and the shape falls to the 128x128
   // kernel.  (A 256x384 tiling of an [8192, 768] output is 64 tiles -- a quarter of the chip -- and measured 2x slower than the
   // 128x128 kernel; [16384, 768] is best at 256x192 = 256 tiles; scripts/gemm_mid_bench.py.)
   const int64_t mt = M / TBM;
-  const bool v4 = variant == 4, v24 = variant == 2 || variant == 4;
   auto score = [&](int tn, double eff, bool allowed) -> double {
     if (!allowed || N % tn) return 0.0;
     const int64_t tiles = mt * (N / tn), rounds = (tiles + 255) / 256;
     const double util = (double)tiles / (double)(rounds * 256);
     return util >= 0.7 ? util * eff : 0.0;
   };
-  const double s384 = score(384, 1.00, v4 && (epi == 0 || epi == 2)), s256 = score(256, 0.95, v4 && epi <= 2);
-  const double s192 = score(192, 0.90, v24), s128 = score(128, 0.80, v4 && epi <= 2);
+  const double s384 = score(384, 1.00, epi == 0 || epi == 2), s256 = score(256, 0.95, true);
+  const double s192 = score(192, 0.90, true), s128 = score(128, 0.80, true);
   const double best = fmax(fmax(s384, s256), fmax(s192, s128));
   if (best > 0.0) {
     if (best == s384) return launch_big<384, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
@@ -782,12 +627,12 @@ static int dispatch_big(const void* A, int64_t lda, const void* B, int64_t ldb, 
     if (best == s192) return launch_big<192, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
     return launch_big<128, 3>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
   }
-  if (epi >= 2) {  // the fused SwiGLU epilogues only exist in the persistent kernels: take the tiling with the most tiles
-    if (v24 && N % 192 == 0 && mt * (N / 192) >= 64)
+  if (epi == 2) {  // the fused SwiGLU epilogue only exists in the persistent kernels: take the tiling with the most tiles
+    if (N % 192 == 0 && mt * (N / 192) >= 64)
       return launch_big<192, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
-    if (v4 && epi == 2 && N % 384 == 0 && mt * (N / 384) >= 64)
+    if (N % 384 == 0 && mt * (N / 384) >= 64)
       return launch_big<384, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
-    if (v4 && epi == 2 && N % 128 == 0 && mt * (N / 128) >= 64)  // (2F = 4096: the 512-wide configurations)
+    if (N % 128 == 0 && mt * (N / 128) >= 64)  // (2F = 4096: the 512-wide configurations)
       return launch_big<128, 3>(A, lda, B, ldb, C, ldc, M, N, K, ep, epi, stream);
   }
   return 1;
@@ -818,12 +663,7 @@ extern "C" int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb
   }
   const int nwg = cdiv(M, BM) * cdiv(N, BN);
   int ksplit = 1;
-  static int splitk_on = -1;
-  if (splitk_on < 0) {
-    const char* e = getenv("DL_GEMM_NT_SPLITK");
-    splitk_on = e ? atoi(e) : 1;
-  }
-  if (splitk_on && out_dtype == DL_F32 && !bias && act == DL_ACT_NONE && !pre_out && !resid && nwg < 64 && K >= 2048) {
+  if (out_dtype == DL_F32 && !bias && act == DL_ACT_NONE && !pre_out && !resid && nwg < 64 && K >= 2048) {
     ksplit = 256 / nwg;
     if (ksplit > K / 512) ksplit = (int)(K / 512);
     if (ksplit > 1) {
@@ -852,22 +692,6 @@ extern "C" int dl_gemm_nt_swiglu(const void* X, int64_t ldx, const void* Wp, int
   const int rc = dispatch_big(X, ldx, Wp, ldw, U, ldu, M, 2 * F, K, ep, 2, (hipStream_t)stream);
   if (rc == 1) {
     dl_set_error("dl_gemm_nt_swiglu: no fused kernel for M=%lld F=%lld", (long long)M, (long long)F);
-    return DL_ERR_UNSUPPORTED;
-  }
-  return rc;
-}
-
-/* fused MLP-down dgrad + PackedSwiGLU backward: dH = dT W2 (never materialised), dU = [dH * x3 * silu'(x1) | dH * silu(x1)].
- * W2t = transposed bf16 shadow [F, K=D]; U = saved pre-activations [M, 2F]. */
-extern "C" int dl_gemm_nt_dswiglu(const void* dT, int64_t ldt, const void* W2t, int64_t ldw, const void* U, int64_t ldu,
-                                  void* dU, int64_t lddu, int64_t M, int64_t F, int64_t K, dl_stream_t stream) {
-  DL_CHECK_ARG(dT && W2t && U && dU && M > 0 && F > 0 && K > 0, "dl_gemm_nt_dswiglu: null/empty operand");
-  DL_CHECK_ARG(K % BK == 0 && F % 8 == 0 && ldt % 8 == 0 && ldw % 8 == 0 && ldu % 8 == 0 && lddu % 8 == 0,
-               "dl_gemm_nt_dswiglu: K %% 64, F/ld %% 8");
-  NtEpilogue ep{nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, 1, (bf16_t*)U, ldu, (int)F};
-  const int rc = dispatch_big(dT, ldt, W2t, ldw, dU, lddu, M, F, K, ep, 3, (hipStream_t)stream);
-  if (rc == 1) {
-    dl_set_error("dl_gemm_nt_dswiglu: no fused kernel for M=%lld F=%lld", (long long)M, (long long)F);
     return DL_ERR_UNSUPPORTED;
   }
   return rc;
@@ -1039,7 +863,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_tn_k(const bf16_t* __restr
 #define WBM 384
 #define WBN 128
 #define W_STAGE ((WBM + WBN) * 2 * BK)  // 65536 B per stage
-template <bool CONV, int PROBE = 0>
+template <bool CONV>
 __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __restrict__ A, int64_t lda,
                                                                   const bf16_t* __restrict__ Bm, int64_t ldb,
                                                                   float* __restrict__ C, int64_t ldc, int M, int N,
@@ -1105,7 +929,6 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __
       }
       return;
     }
-    if ((PROBE & 4) && st != s_begin) return;
 #pragma unroll
     for (int i = 0; i < 8; ++i) glds16(p + src_off[i], base + lds_off[i]);
   };
@@ -1127,42 +950,16 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // PROBE & 16: L2 prefetch.  A stage's DMA waits for its slowest line, and the lines an operand panel touches for the first time
-  // come from HBM (~2 us under load) with at most one stage (64 KiB) in flight per CU: every thread pulls ONE dword of one
-  // 128-byte line of the stage two k-steps ahead into a dummy LDS strip (no register destination; counted in vmcnt as the
-  // youngest op, so the counted wait below does not wait for it), which brings the line into this XCD's L2 ahead of the DMA
-  auto prefetch = [&](int st) {
-    if (st >= s_end) st = s_end - 1;
-    const int line = threadIdx.x;
-    const bf16_t* p;
-    if (line < 384) {
-      const int row = line / 6;
-      int seg = line - row * 6;
-      if (m0 + seg * 64 >= M) seg = 0;
-      p = A + m0 + ((int64_t)st * BK + row) * lda + seg * 64;
-    } else {
-      const int l2 = line - 384, row = l2 >> 1, seg = l2 & 1;
-      p = Bm + n0 + ((int64_t)st * BK + row) * ldb + seg * 64;
-    }
-    __builtin_amdgcn_global_load_lds((glb_void_t*)p, (lds_void_t*)(smem + 2 * W_STAGE + wave * 256), 4, 0, 0);
-  };
-  if (PROBE & 16) {
-    prefetch(s_begin + 1);
-    prefetch(s_begin + 2);
-  }
   stage(s_begin, 0);
   for (int st = s_begin; st < s_end; ++st) {
     const int it = st - s_begin;
-    if ((PROBE & 16) && st != s_begin) wait_vmcnt<1>();
-    else wait_vmcnt<0>();
+    wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (st + 1 < s_end) stage(st + 1, (it + 1) & 1);
-    if (PROBE & 16) prefetch(st + 3);
-    const char* ta = smem + ((PROBE & 8) ? 0 : (it & 1)) * W_STAGE;
+    const char* ta = smem + (it & 1) * W_STAGE;
     const char* tb = ta + WBM * 2 * BK;
 #pragma unroll
-    for (int kk_ = 0; kk_ < 4; ++kk_) {
-      const int kk = (PROBE & 8) ? 0 : kk_;
+    for (int kk = 0; kk < 4; ++kk) {
       bf16x8_t af[3], bfg[2];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -1185,29 +982,12 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __
         bfg[j] = u.v;
       }
       tr_landed(af, bfg);
-      if (PROBE & 2) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) asm volatile("" ::"v"(af[i]));
+      for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(bfg[j]));
-      } else {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfg[j], acc[i][j], 0, 0, 0);
-      }
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfg[j], acc[i][j], 0, 0, 0);
     }
   }
-  if (PROBE & 1) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
-    return;
-  }
-  if (PROBE & 32) C += (int64_t)(__builtin_amdgcn_s_getreg(6164) & 7) * M * ldc;  // HW_REG_XCC_ID[3:0]: one slab per XCD
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -1222,177 +1002,6 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __
 }
 
 
-// =====================================================================================================
-// gemm_tn_wide_k: the wgrads of the two MLP linears (2/3 of the wgrad FLOPs).  The component probe (scripts/gemm_probe.py)
-// shows the 384x128 kernel above waiting for its operand DMA: 64 KiB per k-step and CU at ~8 TB/s chip-wide is 204 us of a
-// 242 us launch, while its MFMA + LDS-read part alone takes 107 us.  A 256x384 (or 384x256) tile stages 80 KiB per
-// 12.6 MFLOP instead of 64 KiB per 6.3 MFLOP (-37 % DMA bytes) and reads 14 transposed fragments per 12 MFMAs instead of 10 per 6.
-//   A384 = false: C tile 256 (m) x 384 (n), 8 waves as 2 x 4, each 128 x 96 = 4 x 3 MFMA tiles  (MLP-up:   [3072, 384])
-//   A384 = true : C tile 384 (m) x 256 (n), 8 waves as 4 x 2, each  96 x 128 = 3 x 4 MFMA tiles (MLP-down: [384, 1536])
-// Twice the tile per workgroup means twice the split-R partial sums, and the f32 atomics of the small kernel already cost 20-33 us
-// per launch: every address is hit by all splits from all 8 XCDs, whose L2s pass the line around.  Here a workgroup adds its
-// partial tile into the slab of ITS XCD (HW_REG_XCC_ID), so a line is only ever touched through one L2, and a small second kernel
-// sums the 8 slabs into C and clears them (the caller provides the zeroed [8, M, N] f32 workspace once).
-// Requires M % TM == 0, N % TN == 0, R % 64 == 0.
-// =====================================================================================================
-template <bool A384>
-__global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_wide_k(const bf16_t* __restrict__ A, int64_t lda,
-                                                                   const bf16_t* __restrict__ Bm, int64_t ldb,
-                                                                   float* __restrict__ slabs, int M, int N, int R,
-                                                                   int steps_per_split, int nsplit_pad) {
-  constexpr int TM = A384 ? 384 : 256, TN_ = A384 ? 256 : 384;
-  constexpr int MI = A384 ? 3 : 4, NI = A384 ? 4 : 3;          // 32x32 MFMA tiles per wave
-  constexpr int A_BYTES = BK * TM * 2, STG = BK * (TM + TN_) * 2;  // 80 KiB per stage
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // block -> (split, tile): the tiles of one split read the same operand rows; give them block ids congruent mod 8 (one XCD / L2)
-  const int ntile = (M / TM) * (N / TN_);
-  const int tile = (blockIdx.x >> 3) % ntile;
-  const int split = (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / ntile);
-  const int tiles_n = N / TN_;
-  const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN_;
-  const int nsteps_total = R / BK;
-  const int s_begin = split * steps_per_split;
-  int s_end = s_begin + steps_per_split;
-  s_end = s_end < nsteps_total ? s_end : nsteps_total;
-  if (s_begin >= s_end) return;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = A384 ? (wave >> 1) : (wave >> 2), wn = A384 ? (wave & 1) : (wave & 3);
-
-  // ---- DMA: per stage the 256-column operand is 32 chunks of 1 KiB (2 rows each), the 384-column operand 48 chunks (3 chunks
-  //      = 4 rows); every wave copies 4 + 6 of them.  32-bit element offsets relative to the stage's first row.
-  const bf16_t* p256 = A384 ? Bm + n0 : A + m0;
-  const bf16_t* p384 = A384 ? A + m0 : Bm + n0;
-  const int ld256 = (int)(A384 ? ldb : lda), ld384 = (int)(A384 ? lda : ldb);
-  int off256[2], off384[3];
-  {
-    const int h = lane >> 5, sl = lane & 31;
-#pragma unroll
-    for (int par = 0; par < 2; ++par) off256[par] = h * ld256 + ((sl ^ ((2 * par + h) << 2)) << 3);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int o = j * 1024 + lane * 16, r = o / 768, sj = (o - r * 768) >> 4;
-      off384[j] = r * ld384 + ((sj ^ ((r & 3) << 2)) << 3);
-    }
-  }
-  constexpr int BASE256 = A384 ? A_BYTES : 0, BASE384 = A384 ? 0 : A_BYTES;
-  auto stage = [&](int st, int buf) {
-    char* base = smem + buf * STG;
-    const bf16_t* q256 = p256 + (int64_t)st * BK * ld256;
-    const bf16_t* q384 = p384 + (int64_t)st * BK * ld384;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = wave * 4 + j;  // rows 2c, 2c+1
-      glds16(q256 + off256[j & 1] + 2 * c * ld256, base + BASE256 + c * 1024);
-    }
-#pragma unroll
-    for (int gg = 0; gg < 2; ++gg)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int g = wave * 2 + gg;  // rows 4g .. 4g+3
-        glds16(q384 + off384[j] + 4 * g * ld384, base + BASE384 + (3 * g + j) * 1024);
-      }
-  };
-
-  const int li = lane & 15, g4 = lane >> 4;
-  auto tr_off = [&](int cb, int kk, int half, int pitch) -> int {
-    const int r = kk * 16 + (g4 >> 1) * 8 + half * 4 + (li >> 2);
-    const int col = cb + (g4 & 1) * 16 + (li & 3) * 4;
-    const int slot = (col >> 3) ^ ((r & 3) << 2);
-    return r * pitch + slot * 16 + (col & 7) * 2;
-  };
-
-  f32x16_t acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  stage(s_begin, 0);
-  for (int st = s_begin; st < s_end; ++st) {
-    const int it = st - s_begin;
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (st + 1 < s_end) stage(st + 1, (it + 1) & 1);
-    const char* ta = smem + (it & 1) * STG;
-    const char* tb = ta + A_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      bf16x8_t af[MI], bfg[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        union {
-          s16x4_t h[2];
-          bf16x8_t v;
-        } u;
-        u.h[0] = lds_tr16(ta + tr_off(wm * (MI * 32) + i * 32, kk, 0, TM * 2));
-        u.h[1] = lds_tr16(ta + tr_off(wm * (MI * 32) + i * 32, kk, 1, TM * 2));
-        af[i] = u.v;
-      }
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        union {
-          s16x4_t h[2];
-          bf16x8_t v;
-        } u;
-        u.h[0] = lds_tr16(tb + tr_off(wn * (NI * 32) + j * 32, kk, 0, TN_ * 2));
-        u.h[1] = lds_tr16(tb + tr_off(wn * (NI * 32) + j * 32, kk, 1, TN_ * 2));
-        bfg[j] = u.v;
-      }
-      tr_landed(af, bfg);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfg[j], acc[i][j], 0, 0, 0);
-    }
-  }
-  if (nsplit_pad < 0) {  // tuning probe: no epilogue
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
-    return;
-  }
-  float* Cx = slabs + (int64_t)(__builtin_amdgcn_s_getreg(6164) & 7) * M * N;  // HW_REG_XCC_ID[3:0]
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = n0 + wn * (NI * 32) + j * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        unsafeAtomicAdd(&Cx[(int64_t)m * N + n], acc[i][j][r]);
-      }
-    }
-}
-
-// C[m, n] += sum over the 8 per-XCD slabs; the slabs are cleared for the next launch (16-byte lanes)
-__global__ void tn_slab_fold_k(float* __restrict__ slabs, float* __restrict__ C, int64_t ldc, int64_t M, int N) {
-  const int N4 = N >> 2;
-  const int64_t total = M * N4, stride = (int64_t)gridDim.x * blockDim.x, slab = M * N;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int64_t m = i / N4;
-    const int n = (int)(i - m * N4) * 4;
-    f32x4_t s = *(const f32x4_t*)(C + m * ldc + n);
-    const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int x = 0; x < 8; ++x) {
-      float* p = slabs + x * slab + m * N + n;
-      s += *(const f32x4_t*)p;
-      *(f32x4_t*)p = z;
-    }
-    *(f32x4_t*)(C + m * ldc + n) = s;
-  }
-}
-
-extern "C" int dl_gemm_tn_ws(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
-                             int64_t N, int64_t R, int max_workgroups, float* workspace, int64_t workspace_elems,
-                             dl_stream_t stream);
 int launch_tn_w4(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t R,
                  int max_workgroups, hipStream_t stream);  // gemm_w4.hip
 extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
@@ -1409,23 +1018,21 @@ extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t 
                "dl_gemm_tn: M,N,lda,ldb must be multiples of 8 (M=%lld N=%lld)", (long long)M, (long long)N);
   DL_CHECK_ARG((((uintptr_t)A | (uintptr_t)B) & 15) == 0, "dl_gemm_tn: 16-byte alignment");
   {
-    static int variant = -1, n_cu = 0;
-    if (variant < 0) {
-      const char* e = getenv("DL_GEMM_TN_VARIANT");  // 0: 128x128 kernel, 1: 384x128 persistent, 2: 384x192 ring kernel (gemm_w4.hip)
-      variant = e ? atoi(e) : 2;
+    static int n_cu = 0;
+    if (n_cu == 0) {
       int dev = 0;
       (void)hipGetDevice(&dev);
       (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
       if (n_cu <= 0) n_cu = 256;
       (void)hipFuncSetAttribute((const void*)gemm_tn_big_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE);
     }
-    if (variant == 2 && !g_gemm_probe) {
+    {  // 384 x 192 ring kernel (gemm_w4.hip) for the shapes its tile divides
       const int rc = launch_tn_w4(A, lda, B, ldb, C, ldc, M, N, R, max_workgroups, (hipStream_t)stream);
       if (rc <= 0) return rc;
     }
     const int nsteps = (int)(R / BK);
     const int64_t tiles_m64 = (M + WBM - 1) / WBM;
-    if (variant >= 1 && N % WBN == 0 && nsteps >= 64 && 5 * M >= 3 * tiles_m64 * WBM) {  // (ragged last m-tile: >= 60 % useful)
+    if (N % WBN == 0 && nsteps >= 64 && 5 * M >= 3 * tiles_m64 * WBM) {  // (ragged last m-tile: >= 60 % useful)
       // one workgroup per CU at most (128 KiB of LDS each): units (= m-tiles x splits) are padded to a multiple of
       // 8 for the XCD mapping, so pick the split count from the padded budget
       const int tiles_m = (int)tiles_m64, tiles_n = (int)(N / WBN);
@@ -1440,27 +1047,6 @@ extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t 
       const int sps = (nsteps + splits - 1) / splits;
       splits = (nsteps + sps - 1) / sps;
       const int units = (tiles_m * splits + 7) & ~7;  // surplus units exit at once
-      if (g_gemm_probe) {
-#define TN_PROBE_GO(P)                                                                                                              \
-  do {                                                                                                                              \
-    (void)hipFuncSetAttribute((const void*)gemm_tn_big_k<false, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE + 2048); \
-    hipLaunchKernelGGL((gemm_tn_big_k<false, P>), units * (int)(N / WBN), BIG_THREADS, 2 * W_STAGE + 2048, (hipStream_t)stream,      \
-                       (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)R, sps, ConvGeom{});               \
-  } while (0)
-        if (g_gemm_probe == 1) TN_PROBE_GO(1);
-        else if (g_gemm_probe == 2) TN_PROBE_GO(2);
-        else if (g_gemm_probe == 4) TN_PROBE_GO(4);
-        else if (g_gemm_probe == 8) TN_PROBE_GO(8);
-        else if (g_gemm_probe == 5) TN_PROBE_GO(5);
-        else if (g_gemm_probe == 16) TN_PROBE_GO(16);
-        else if (g_gemm_probe == 17) TN_PROBE_GO(17);
-        else if (g_gemm_probe == 26) TN_PROBE_GO(26);
-        else if (g_gemm_probe == 32) TN_PROBE_GO(32);
-        else TN_PROBE_GO(10);
-#undef TN_PROBE_GO
-        DL_LAUNCH_CHECK();
-        return DL_OK;
-      }
       hipLaunchKernelGGL(gemm_tn_big_k<false>, units * (int)(N / WBN), BIG_THREADS, 2 * W_STAGE, (hipStream_t)stream,
                          (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)R, sps, ConvGeom{});
       DL_LAUNCH_CHECK();
@@ -1476,51 +1062,6 @@ extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t 
   splits = (nsteps + sps - 1) / sps;
   hipLaunchKernelGGL(gemm_tn_k<false>, ntile * splits, NT_THREADS, 65536, (hipStream_t)stream, (const bf16_t*)A, lda,
                      (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)R, sps, ConvGeom{});
-  DL_LAUNCH_CHECK();
-  return DL_OK;
-}
-
-/* dl_gemm_tn_ex with a caller-owned f32 workspace of >= 8*M*N elements (ZERO on first use; left zero on return): shapes with
- * M % 256 == 0 && N == 384-multiple, or M % 384 == 0 && N % 256 == 0, and a long reduction run the wide-tile kernel with per-XCD
- * partial slabs; every other shape (or workspace == NULL / too small) is dl_gemm_tn_ex. */
-extern "C" int dl_gemm_tn_ws(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
-                             int64_t N, int64_t R, int max_workgroups, float* workspace, int64_t workspace_elems,
-                             dl_stream_t stream) {
-  static int wide = -1, n_cu = 0;
-  if (wide < 0) {
-    const char* e = getenv("DL_GEMM_TN_WIDE");
-    wide = e ? atoi(e) : 0;  // measured slower than the 384x128 kernel: opt-in
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n_cu <= 0) n_cu = 256;
-    (void)hipFuncSetAttribute((const void*)gemm_tn_wide_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BK * 640 * 2);
-    (void)hipFuncSetAttribute((const void*)gemm_tn_wide_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BK * 640 * 2);
-  }
-  const bool up = (M % 256 == 0 && N % 384 == 0 && M >= 4 * N), down = (M % 384 == 0 && N % 256 == 0 && N >= 2 * M);
-  const int nsteps = (int)(R / BK);
-  if (!wide || !workspace || workspace_elems < 8 * M * N || !(up || down) || R % BK || nsteps < 128 || ldc % 4 || N % 4 ||
-      ((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)workspace) & 15 || lda % 8 || ldb % 8)
-    return dl_gemm_tn_ex(A, lda, B, ldb, C, ldc, M, N, R, max_workgroups, stream);
-  const int ntile = up ? (int)((M / 256) * (N / 384)) : (int)((M / 384) * (N / 256));
-  const int budget = (max_workgroups > 0 && max_workgroups < n_cu) ? max_workgroups : n_cu;
-  int splits = budget / ntile;
-  if (splits < 1) splits = 1;
-  if (splits > nsteps / 8) splits = nsteps / 8;
-  const int sps = (nsteps + splits - 1) / splits;
-  splits = (nsteps + sps - 1) / sps;
-  const int splits_pad = (splits + 7) & ~7;  // surplus splits exit at once
-  const int flag = (g_gemm_probe & 1) ? -1 : splits_pad;
-  if (up)
-    hipLaunchKernelGGL(gemm_tn_wide_k<false>, splits_pad * ntile, BIG_THREADS, 2 * BK * 640 * 2, (hipStream_t)stream, (const bf16_t*)A,
-                       lda, (const bf16_t*)B, ldb, workspace, (int)M, (int)N, (int)R, sps, flag);
-  else
-    hipLaunchKernelGGL(gemm_tn_wide_k<true>, splits_pad * ntile, BIG_THREADS, 2 * BK * 640 * 2, (hipStream_t)stream, (const bf16_t*)A,
-                       lda, (const bf16_t*)B, ldb, workspace, (int)M, (int)N, (int)R, sps, flag);
-  int64_t g = (M * (N / 4) + 255) / 256;
-  if (g > 2048) g = 2048;
-  if (!(g_gemm_probe & 2))
-  hipLaunchKernelGGL(tn_slab_fold_k, (int)g, 256, 0, (hipStream_t)stream, workspace, C, ldc, M, (int)N);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
@@ -1589,7 +1130,7 @@ extern "C" int dl_conv3x3_nt(const void* x, int64_t ldx, int64_t Bn, int64_t H, 
  * of 64 and rows >= B*H*W zero; g f32 [9*Ci, ldg] accumulated into (dl_conv3x3_wgrad_fold finishes the job). */
 extern "C" int dl_conv3x3_wgrad_tn(const void* x, int64_t ldx, int64_t Bn, int64_t H, int64_t W, int64_t Ci, const void* dY,
                                    int64_t ldy, int64_t R, int64_t Co, float* g, int64_t ldg, const void* zero,
-                                   dl_stream_t stream) {
+                                   int max_workgroups, dl_stream_t stream) {
   DL_CHECK_ARG(x && dY && g && zero && Bn > 0 && H > 0 && W > 0 && Co > 0, "dl_conv3x3_wgrad_tn: bad args");
   if (Ci % 128 != 0) return DL_ERR_UNSUPPORTED;
   DL_CHECK_ARG(R % BK == 0 && R >= Bn * H * W && Co % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldy >= Co && ldg >= Co,
@@ -1606,15 +1147,11 @@ extern "C" int dl_conv3x3_wgrad_tn(const void* x, int64_t ldx, int64_t Bn, int64
       (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
       if (n_cu <= 0) n_cu = 256;
       (void)hipFuncSetAttribute((const void*)gemm_tn_big_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE);
-      // the UNet engine runs these on its side stream beside the GroupNorm / convolution chain: like the DiT weight gradients
-      // they leave part of the chip to it (DL_CONV_WGRAD_WGS, default 192 of 256 workgroups; 0 = no cap: 35.4 ms, 192: 34.9, 128: 36.5, 64: 40.4)
-      const char* e = getenv("DL_CONV_WGRAD_WGS");
-      const int cap = e ? atoi(e) : 192;
-      if (cap > 0 && cap < n_cu) n_cu = cap;
     }
     if (M % WBM == 0 && N % WBN == 0 && nsteps >= 64) {  // same unit / split budget as dl_gemm_tn
       const int tiles_m = (int)(M / WBM), tiles_n = (int)(N / WBN);
-      int padded_max = (n_cu / tiles_n) & ~7;
+      const int budget = (max_workgroups > 0 && max_workgroups < n_cu) ? max_workgroups : n_cu;
+      int padded_max = (budget / tiles_n) & ~7;
       if (padded_max < 8) padded_max = 8;
       int splits = padded_max / tiles_m;
       if (splits < 1) splits = 1;
@@ -1640,22 +1177,3 @@ extern "C" int dl_conv3x3_wgrad_tn(const void* x, int64_t ldx, int64_t Bn, int64
   return DL_OK;
 }
 
-// =====================================================================================================
-// probe: raw lane map of ds_read_b64_tr_b16 (tests/test_gpu_probe.py pins the semantics gemm_tn / attention rely on)
-// =====================================================================================================
-__global__ void probe_tr16_k(uint16_t* out) {
-  __shared__ __attribute__((aligned(16))) uint16_t img[256];
-  const int lane = threadIdx.x;
-  for (int i = lane; i < 256; i += 64) img[i] = (uint16_t)i;
-  __syncthreads();
-  s16x4_t v = lds_tr16((const char*)img + lane * 8);
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
-#pragma unroll
-  for (int j = 0; j < 4; ++j) out[lane * 4 + j] = (uint16_t)v[j];
-}
-extern "C" int dl_probe_tr16(uint16_t* out, dl_stream_t stream) {
-  DL_CHECK_ARG(out, "dl_probe_tr16: null");
-  hipLaunchKernelGGL(probe_tr16_k, 1, 64, 0, (hipStream_t)stream, out);
-  DL_LAUNCH_CHECK();
-  return DL_OK;
-}

@@ -13,9 +13,17 @@
 //   * operand stages are 32 tokens deep in a FOUR-slot ring: three stages (108 KiB) stay in flight under counted vmcnt waits;
 //   * one barrier per stage, placed after the first MFMA row of the sub-step so the matrix pipe runs through the barrier skew;
 //   * all tiles of one token range sit on ONE XCD: every operand byte crosses into exactly one L2.
-// WAVES = 4 (one wave per SIMD, 192 x 96 per wave, 288 accumulator registers) is kept for the record: the compiler holds MFMA
-// accumulators in the 256 AGPRs only and shuttles the remaining 32 through v_accvgpr moves every iteration (275 us vs 176 us on the
-// MLP-up weight gradient); DL_GEMM_TN_W4_WAVES=4 selects it.
+// Two launch forms share the tile body (w4_tile):
+//   gemm_tn_w4_k        one problem, token ranges meet in C through f32 atomics (dl_gemm_tn / dl_gemm_tn_ex: any caller, any shape
+//                       the tile divides);
+//   gemm_tn_group_k     up to four problems over the SAME token rows in ONE launch (the four weight gradients of a transformer
+//                       block: 32 tiles at D = 384), every (token range, tile) writes its f32 partial tile with plain stores into
+//                       slab[range], and tn_group_fold_k adds the ranges in a fixed order: g += ((p0 + p1) + p2) + ...  No atomics:
+//                       the result is bit-reproducible, the 68 M atomics per block of the one-problem launches (round 2: 50 of the
+//                       176 us of the MLP-up weight gradient, 33 of 58 us of the projection's) become 75 MB of plain stores and a
+//                       fold, and a workgroup runs 256 - 512 stages instead of 25 - 128.  dl_gemm_tn_group.
+// (A 4-wave, one-wave-per-SIMD form with 192 x 96 wave tiles was measured in round 2 -- 275 vs 176 us: the compiler keeps MFMA
+// accumulators in the 256 AGPRs only and shuttles the other 32 through v_accvgpr moves -- and is not kept.)
 #include <stdlib.h>
 
 #include <type_traits>
@@ -49,21 +57,22 @@ __device__ __forceinline__ void wait_vmcnt_w4() {
 #define W4_AM 384   // output rows (A-operand columns) per tile
 
 // =====================================================================================================
-// gemm_tn_w4_k: C[Mo, No] (f32) += A[R, Mo]^T . B[R, No], reduction over tokens split over workgroups, f32 atomics.
-// Tile 384 (m) x BNW (n), BNW = 192 (256 compiles for WAVES = 8 only on paper: 278 registers); WAVES/2 (m) x 2 (n) waves, each
-// 768/WAVES x BNW/2 = (24/WAVES) x (BNW/64) MFMA 32x32x16 tiles.
+// w4_tile: one 384 (m) x BNW (n) output tile of C = A[R, Mo]^T . B[R, No] over the operand stages [s_begin, s_end) (32 tokens each),
+// left in the accumulators.  BNW = 192; 8 waves as 4 (m) x 2 (n), each 96 x 96 = 3 x 3 MFMA 32x32x16 tiles.
 // LDS images are the row-major [32 r][384 | BNW] slabs written by the DMA; fragments come out of ds_read_b64_tr_b16.  16-byte slot
 // swizzle per image row so that the 4 rows of one transposing read fall into 4 distinct 64-byte bank groups:
 //   768- and 512-byte rows (multiples of the 256-byte bank period): slot ^= (r & 3) << 2
 //   384-byte rows (r and r+2 alias):                                slot ^= ((r >> 1) & 1) << 2
-// Requires Mo % 384 == 0, No % BNW == 0, R % 32 == 0.
+// A, Bm point at column 0 of the operands (the tile's column offsets m0 / n0 are applied here).
 // =====================================================================================================
-// PROBE (tuning builds, DL_GEMM_TN_W4_PROBE): 2 = no MFMAs, 4 = no DMA after the ring fill, 8 = no fragment reads
-template <int BNW, int WAVES, int PROBE = 0>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES / 4, WAVES / 4))) void gemm_tn_w4_k(
-    const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Bm, int64_t ldb, float* __restrict__ C, int64_t ldc,
-    int M, int N, int R, int steps_per_split, int spx) {
-  constexpr int WM = WAVES / 2;                      // waves along m (2 along n)
+#define W4_WAVES 8
+#define W4_BNW 192
+#define W4_LDS (W4_NST * W4_BK * (W4_AM + W4_BNW) * 2)
+template <int BNW>
+__device__ __forceinline__ void w4_tile(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Bm, int64_t ldb,
+                                        int m0, int n0, int s_begin, int s_end, char* smem,
+                                        f32x16_t (&acc)[W4_AM / (W4_WAVES / 2) / 32][BNW / 64]) {
+  constexpr int WAVES = W4_WAVES, WM = WAVES / 2;     // waves along m (2 along n)
   constexpr int IM = W4_AM / WM / 32, JN = BNW / 64;  // MFMA tiles per wave
   constexpr int PA = W4_AM * 2, PB = BNW * 2;        // image row pitches (bytes)
   constexpr int A_BYTES = W4_BK * PA;                // 24 KiB
@@ -72,33 +81,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   constexpr int NCH = STAGE / 1024;                  // 36 | 40
   constexpr int CH = (NCH + WAVES - 1) / WAVES;      // chunks per wave and stage (the last waves may own one less)
   constexpr int CHMIN = NCH / WAVES;                 // what the counted waits assume is outstanding per younger stage
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)smem;  // LDS byte address of the ring (asm reads take addresses)
-  // block -> (A-panel unit = (split, m-tile), n-tile): the workgroups that read the same A panel get block ids congruent mod 8,
-  // i.e. they sit on one XCD and share the panel in its L2
-  const int tiles_n = N / BNW, tiles_m = M / W4_AM;
-  int split, mt, nt;
-  if (spx > 0) {
-    // ALL tiles of one token range on ONE XCD (blockIdx & 7), spx ranges per XCD: every operand byte crosses into exactly one L2
-    // and is fetched from HBM once; its other readers (tiles_n sharers of an A panel, tiles_m sharers of a B panel) hit that L2
-    const int local = blockIdx.x >> 3, ntile = tiles_m * tiles_n;
-    const int sl = local / ntile, tile = local - sl * ntile;
-    split = (blockIdx.x & 7) * spx + sl;
-    mt = tile / tiles_n;
-    nt = tile - mt * tiles_n;
-  } else {
-    const int grp = blockIdx.x / (8 * tiles_n), rem = blockIdx.x - grp * 8 * tiles_n;
-    const int unit = grp * 8 + (rem & 7);
-    nt = rem >> 3;
-    split = unit / tiles_m;
-    mt = unit - split * tiles_m;
-  }
-  const int m0 = mt * W4_AM, n0 = nt * BNW;
-  const int nsteps_total = R / W4_BK;
-  const int s_begin = split * steps_per_split;
-  int s_end = s_begin + steps_per_split;
-  s_end = s_end < nsteps_total ? s_end : nsteps_total;
-  if (s_begin >= s_end) return;
   const int n = s_end - s_begin;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -126,7 +109,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     clds[i] = (a ? 0 : A_BYTES) + cc * 1024;
   }
   auto dma_chunk = [&](int st, int i) {  // chunk i of this wave of (relative) stage st
-    if ((PROBE & 4) && st >= W4_NST) return;
     glds16_w4(cptr[i] + (int64_t)st * cstep[i], smem + (st & (W4_NST - 1)) * STAGE + clds[i]);
   };
 
@@ -146,7 +128,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     boff[j] = A_BYTES + rl * PB + (((col >> 3) ^ sw) << 4) + (col & 7) * 2;
   }
 
-  f32x16_t acc[IM][JN];
 #pragma unroll
   for (int i = 0; i < IM; ++i)
 #pragma unroll
@@ -163,8 +144,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
 #define W4_READ1(BUF, F, SBASE, KK)                                                  \
   do {                                                                               \
     Frag u;                                                                          \
-    if (PROBE & 8) {                                                                 \
-    } else if ((F) < IM) {                                                                  \
+    if ((F) < IM) {                                                                  \
       u.h[0] = lds_tr16_w4<((KK) * 16) * PA>((SBASE) + aoff[(F) < IM ? (F) : 0]);      \
       u.h[1] = lds_tr16_w4<((KK) * 16 + 4) * PA>((SBASE) + aoff[(F) < IM ? (F) : 0]);  \
       af[BUF][(F) < IM ? (F) : 0] = u.v;                                             \
@@ -185,11 +165,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
   _Pragma("unroll") for (int f = 0; f < IM + JN; ++f) W4_READ1(BUF, f, SBASE, KK)
 #define W4_MFMA_ROW(BUF, I)                                             \
   _Pragma("unroll") for (int j = 0; j < JN; ++j) {                      \
-    if (PROBE & 2) {                                                    \
-      asm volatile("" ::"v"(af[BUF][I]), "v"(bfr[BUF][j]));             \
-    } else {                                                            \
-      acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[BUF][I], bfr[BUF][j], acc[I][j], 0, 0, 0); \
-    }                                                                   \
+    acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[BUF][I], bfr[BUF][j], acc[I][j], 0, 0, 0); \
   }
 
   // ---- prologue: fill the ring, wait for stage 0, fetch its first fragment set
@@ -229,7 +205,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     // ---- sub-step 1: the last reads of this stage have landed -> the slot can be refilled once every wave is here
     W4_LANDED(1);
     W4_MFMA_ROW(1, 0);  // (the matrix pipe runs through the barrier skew)
-    if (FULL && !(PROBE & 4)) wait_vmcnt_w4<(W4_NST - 2) * CHMIN>();  // stage it+1 landed; it+2, it+3 may stay in flight
+    if (FULL) wait_vmcnt_w4<(W4_NST - 2) * CHMIN>();  // stage it+1 landed; it+2, it+3 may stay in flight
     else wait_vmcnt_w4<0>();
     __builtin_amdgcn_s_barrier();
     const unsigned sn = lds0 + ((it + 1) & (W4_NST - 1)) * STAGE;
@@ -258,45 +234,140 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
 #undef W4_LANDED
 #undef W4_MFMA_ROW
 
-  // ---- f32 atomics: acc[i][j][r] = C[m][n], n = lane & 31 (128 contiguous bytes per half-wave), m from r and the lane half
-#pragma unroll
-  for (int i = 0; i < IM; ++i)
-#pragma unroll
-    for (int j = 0; j < JN; ++j) {
-      const int nn = n0 + wn * (BNW / 2) + j * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (W4_AM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        unsafeAtomicAdd(&C[(int64_t)m * ldc + nn], acc[i][j][r]);
-      }
-    }
 }
 
-// returns 1 when the shape is not this kernel's (the caller keeps its own path), else the launch status
-int launch_tn_w4(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t R,
-                 int max_workgroups, hipStream_t stream) {
-  static int n_cu = 0, waves = 8, xcd_map = 1, min_steps = 32;
+// acc[i][j][r] = C[m][n]: n = lane & 31 (128 contiguous bytes per half-wave), m from r and the lane half
+#define W4_FOR_ACC(STMT)                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 3; ++i) _Pragma("unroll") for (int j = 0; j < 3; ++j) { \
+    const int nn = n0 + wn * (W4_BNW / 2) + j * 32 + (lane & 31);                               \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                            \
+      const int m = m0 + wm * 96 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);           \
+      STMT;                                                                                     \
+    }                                                                                           \
+  }
+
+// =====================================================================================================
+// gemm_tn_w4_k: C[Mo, No] (f32) += A[R, Mo]^T . B[R, No], reduction over tokens split over workgroups, f32 atomics.
+// Requires Mo % 384 == 0, No % 192 == 0, R % 32 == 0.
+// =====================================================================================================
+__global__ __launch_bounds__(W4_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn_w4_k(
+    const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Bm, int64_t ldb, float* __restrict__ C, int64_t ldc,
+    int M, int N, int R, int steps_per_split, int spx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // block -> (A-panel unit = (split, m-tile), n-tile): the workgroups that read the same A panel get block ids congruent mod 8,
+  // i.e. they sit on one XCD and share the panel in its L2
+  const int tiles_n = N / W4_BNW, tiles_m = M / W4_AM;
+  int split, mt, nt;
+  if (spx > 0) {
+    // ALL tiles of one token range on ONE XCD (blockIdx & 7), spx ranges per XCD: every operand byte crosses into exactly one L2
+    // and is fetched from HBM once; its other readers (tiles_n sharers of an A panel, tiles_m sharers of a B panel) hit that L2
+    const int local = blockIdx.x >> 3, ntile = tiles_m * tiles_n;
+    const int sl = local / ntile, tile = local - sl * ntile;
+    split = (blockIdx.x & 7) * spx + sl;
+    mt = tile / tiles_n;
+    nt = tile - mt * tiles_n;
+  } else {
+    const int grp = blockIdx.x / (8 * tiles_n), rem = blockIdx.x - grp * 8 * tiles_n;
+    const int unit = grp * 8 + (rem & 7);
+    nt = rem >> 3;
+    split = unit / tiles_m;
+    mt = unit - split * tiles_m;
+  }
+  const int m0 = mt * W4_AM, n0 = nt * W4_BNW;
+  const int nsteps_total = R / W4_BK;
+  const int s_begin = split * steps_per_split;
+  int s_end = s_begin + steps_per_split;
+  s_end = s_end < nsteps_total ? s_end : nsteps_total;
+  if (s_begin >= s_end) return;
+  f32x16_t acc[3][3];
+  w4_tile<W4_BNW>(A, lda, Bm, ldb, m0, n0, s_begin, s_end, smem, acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+  W4_FOR_ACC(unsafeAtomicAdd(&C[(int64_t)m * ldc + nn], acc[i][j][r]));
+}
+
+// =====================================================================================================
+// gemm_tn_group_k: up to four problems C_p = A_p[R, Mo_p]^T . B_p[R, No_p] over the same R token rows, S token ranges.
+// Workgroup u (XCD-major: the workgroups of one XCD are consecutive u) -> range u / ntile, tile u % ntile, so a token range sits on
+// one XCD (S = 8) or on 8 / S neighbouring ones and every operand byte crosses into as few L2s as the grid allows.  The partial
+// tile goes to slab[range] (slab-relative offset of the problem + m * No + n) with plain stores.
+// =====================================================================================================
+struct W4Prob {
+  const bf16_t* A;
+  const bf16_t* B;
+  int64_t off;  // float offset of the problem's [Mo, No] image inside a slab
+  int lda, ldb, No, tiles_n, tile0;
+};
+struct W4Group {
+  W4Prob p[4];
+  int nprob, ntile, steps_per_split, nsteps;
+  int64_t slab_stride;  // floats between the slabs of two token ranges
+  float* slab;
+};
+__global__ __launch_bounds__(W4_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn_group_k(W4Group g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int u = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = u / g.ntile, tile = u - split * g.ntile;
+  W4Prob pr = g.p[0];
+  if (g.nprob > 1 && tile >= g.p[1].tile0) pr = g.p[1];
+  if (g.nprob > 2 && tile >= g.p[2].tile0) pr = g.p[2];
+  if (g.nprob > 3 && tile >= g.p[3].tile0) pr = g.p[3];
+  const int lt = tile - pr.tile0, mt = lt / pr.tiles_n, nt = lt - mt * pr.tiles_n;
+  const int m0 = mt * W4_AM, n0 = nt * W4_BNW;
+  const int s_begin = split * g.steps_per_split;
+  int s_end = s_begin + g.steps_per_split;
+  s_end = s_end < g.nsteps ? s_end : g.nsteps;  // (the host sizes the grid so that every range owns at least one stage)
+  f32x16_t acc[3][3];
+  w4_tile<W4_BNW>(pr.A, pr.lda, pr.B, pr.ldb, m0, n0, s_begin, s_end, smem, acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+  float* C = g.slab + (int64_t)split * g.slab_stride + pr.off;
+  const int64_t ldc = pr.No;
+  W4_FOR_ACC(C[(int64_t)m * ldc + nn] = acc[i][j][r]);
+}
+
+// g_p[i] += ((slab_0[off_p + i] + slab_1[..]) + ...) + slab_{S-1}[..]: a fixed summation order, one pass
+struct W4Fold {
+  float* dst[4];
+  int64_t off[5];  // off[p] = first float of problem p inside a slab, off[nprob] = floats per slab that are in use
+  int nprob;
+};
+__global__ __launch_bounds__(256) void tn_group_fold_k(const float* __restrict__ slab, int64_t stride, int splits, W4Fold f) {
+  const int64_t n4 = f.off[f.nprob] >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i << 2;
+    int p = 0;
+    if (f.nprob > 1 && e >= f.off[1]) p = 1;
+    if (f.nprob > 2 && e >= f.off[2]) p = 2;
+    if (f.nprob > 3 && e >= f.off[3]) p = 3;
+    float* d = (p == 0 ? f.dst[0] : p == 1 ? f.dst[1] : p == 2 ? f.dst[2] : f.dst[3]) + (e - f.off[p]);
+    f32x4_t s = *(const f32x4_t*)(slab + e);
+    for (int k = 1; k < splits; ++k) s += *(const f32x4_t*)(slab + k * stride + e);
+    *(f32x4_t*)d = *(const f32x4_t*)d + s;
+  }
+}
+
+static int w4_cus() {
+  static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (n_cu <= 0) n_cu = 256;
-    (void)hipFuncSetAttribute((const void*)gemm_tn_w4_k<192, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_NST * W4_BK * (384 + 192) * 2);
-    (void)hipFuncSetAttribute((const void*)gemm_tn_w4_k<192, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_NST * W4_BK * (384 + 192) * 2);
-    const char* e = getenv("DL_GEMM_TN_W4_WAVES");
-    if (e) waves = atoi(e);
-    e = getenv("DL_GEMM_TN_W4_XCD");  // 0: A-panel sharers on one XCD, token ranges spread (the mapping of gemm_tn_big_k)
-    if (e) xcd_map = atoi(e);
-    e = getenv("DL_GEMM_TN_W4_MINSTEPS");
-    if (e) min_steps = atoi(e);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_w4_k, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_group_k, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
   }
-  const int BNW = 192;
-  if (M % W4_AM || N % BNW || R % W4_BK || R / W4_BK < 64) return 1;
+  return n_cu;
+}
+
+// returns 1 when the shape is not this kernel's (the caller keeps its own path), else the launch status
+int launch_tn_w4(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t R,
+                 int max_workgroups, hipStream_t stream) {
+  const int n_cu = w4_cus(), min_steps = 32;
+  if (M % W4_AM || N % W4_BNW || R % W4_BK || R / W4_BK < 64) return 1;
   const int nsteps = (int)(R / W4_BK);
-  const int tiles_m = (int)(M / W4_AM), tiles_n = (int)(N / BNW), ntile = tiles_m * tiles_n;
+  const int tiles_m = (int)(M / W4_AM), tiles_n = (int)(N / W4_BNW), ntile = tiles_m * tiles_n;
   const int budget = (max_workgroups > 0 && max_workgroups < n_cu) ? max_workgroups : n_cu;
   int grid, sps, spx = 0;
-  if (xcd_map && ntile <= budget / 8) {
+  if (ntile <= budget / 8) {
     spx = (budget / 8) / ntile;                       // token ranges per XCD
     while (spx > 1 && nsteps / (8 * spx) < min_steps) --spx;
     sps = (nsteps + 8 * spx - 1) / (8 * spx);
@@ -311,32 +382,64 @@ int launch_tn_w4(const void* A, int64_t lda, const void* B, int64_t ldb, float* 
     splits = (nsteps + sps - 1) / sps;
     grid = ((tiles_m * splits + 7) & ~7) * tiles_n;  // surplus units exit at once
   }
-  static int probe = -1;
-  if (probe < 0) {
-    const char* e = getenv("DL_GEMM_TN_W4_PROBE");
-    probe = e ? atoi(e) : 0;
-    (void)hipFuncSetAttribute((const void*)gemm_tn_w4_k<192, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_NST * W4_BK * (384 + 192) * 2);
-    (void)hipFuncSetAttribute((const void*)gemm_tn_w4_k<192, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_NST * W4_BK * (384 + 192) * 2);
-    (void)hipFuncSetAttribute((const void*)gemm_tn_w4_k<192, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_NST * W4_BK * (384 + 192) * 2);
-    (void)hipFuncSetAttribute((const void*)gemm_tn_w4_k<192, 8, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_NST * W4_BK * (384 + 192) * 2);
-    (void)hipFuncSetAttribute((const void*)gemm_tn_w4_k<192, 8, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_NST * W4_BK * (384 + 192) * 2);
-    (void)hipFuncSetAttribute((const void*)gemm_tn_w4_k<192, 8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_NST * W4_BK * (384 + 192) * 2);
-  }
-#define W4_PROBE_GO(P)                                                                                                       \
-  hipLaunchKernelGGL((gemm_tn_w4_k<192, 8, P>), grid, 512, W4_NST * W4_BK * (384 + 192) * 2, stream, (const bf16_t*)A, lda, \
-                     (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)R, sps, spx)
-  if (probe == 2) W4_PROBE_GO(2);
-  else if (probe == 4) W4_PROBE_GO(4);
-  else if (probe == 8) W4_PROBE_GO(8);
-  else if (probe == 10) W4_PROBE_GO(10);
-  else if (probe == 12) W4_PROBE_GO(12);
-  else if (probe == 6) W4_PROBE_GO(6);
-  else if (waves == 4)
-    hipLaunchKernelGGL((gemm_tn_w4_k<192, 4>), grid, 256, W4_NST * W4_BK * (384 + 192) * 2, stream, (const bf16_t*)A, lda,
-                       (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)R, sps, spx);
-  else
-    hipLaunchKernelGGL((gemm_tn_w4_k<192, 8>), grid, 512, W4_NST * W4_BK * (384 + 192) * 2, stream, (const bf16_t*)A, lda,
-                       (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)R, sps, spx);
+  hipLaunchKernelGGL(gemm_tn_w4_k, grid, W4_WAVES * 64, W4_LDS, stream, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, (int)M,
+                     (int)N, (int)R, sps, spx);
   if (hipGetLastError() != hipSuccess) return DL_ERR_LAUNCH;
+  return DL_OK;
+}
+
+extern "C" int dl_gemm_tn_group(const dl_wgrad_t* probs, int n_probs, int64_t R, float* slab, int64_t slab_floats, int max_workgroups,
+                                dl_stream_t stream) {
+  DL_CHECK_ARG(probs && n_probs >= 1 && n_probs <= 4 && slab && R > 0, "dl_gemm_tn_group: 1..4 problems and a slab");
+  const int n_cu = w4_cus();
+  if (R % W4_BK || R / W4_BK < 64 || R >= (1ll << 31)) return DL_ERR_UNSUPPORTED;
+  W4Group g{};
+  W4Fold f{};
+  int ntile = 0;
+  int64_t total = 0;
+  for (int i = 0; i < n_probs; ++i) {
+    const dl_wgrad_t& q = probs[i];
+    DL_CHECK_ARG(q.dy && q.x && q.g && q.m_out > 0 && q.n_in > 0, "dl_gemm_tn_group: null operand in problem %d", i);
+    if (q.m_out % W4_AM || q.n_in % W4_BNW) return DL_ERR_UNSUPPORTED;
+    DL_CHECK_ARG(q.ld_dy % 8 == 0 && q.ld_x % 8 == 0 && q.ld_dy >= q.m_out && q.ld_x >= q.n_in && q.ld_dy < (1ll << 31) &&
+                     q.ld_x < (1ll << 31),
+                 "dl_gemm_tn_group: leading dimensions of problem %d", i);
+    DL_CHECK_ARG((((uintptr_t)q.dy | (uintptr_t)q.x | (uintptr_t)q.g) & 15) == 0, "dl_gemm_tn_group: 16-byte alignment");
+    W4Prob& p = g.p[i];
+    p.A = (const bf16_t*)q.dy;
+    p.B = (const bf16_t*)q.x;
+    p.lda = (int)q.ld_dy;
+    p.ldb = (int)q.ld_x;
+    p.No = (int)q.n_in;
+    p.tiles_n = (int)(q.n_in / W4_BNW);
+    p.tile0 = ntile;
+    p.off = total;
+    f.dst[i] = q.g;
+    f.off[i] = total;
+    ntile += (int)(q.m_out / W4_AM) * p.tiles_n;
+    total += q.m_out * q.n_in;
+  }
+  f.off[n_probs] = total;
+  f.nprob = g.nprob = n_probs;
+  DL_CHECK_ARG((((uintptr_t)slab) & 15) == 0 && slab_floats >= total, "dl_gemm_tn_group: slab of %lld floats < one partial image (%lld)",
+               (long long)slab_floats, (long long)total);
+  const int nsteps = (int)(R / W4_BK);
+  const int budget = (max_workgroups > 0 && max_workgroups < n_cu) ? max_workgroups : n_cu;
+  int splits = budget / ntile;
+  if (splits < 1) splits = 1;
+  if (splits > nsteps / 32) splits = nsteps / 32;
+  if ((int64_t)splits * total > slab_floats) splits = (int)(slab_floats / total);
+  const int sps = (nsteps + splits - 1) / splits;
+  splits = (nsteps + sps - 1) / sps;  // every range owns at least one stage
+  g.ntile = ntile;
+  g.steps_per_split = sps;
+  g.nsteps = nsteps;
+  g.slab_stride = total;
+  g.slab = slab;
+  hipLaunchKernelGGL(gemm_tn_group_k, splits * ntile, W4_WAVES * 64, W4_LDS, (hipStream_t)stream, g);
+  int64_t fg = ((total >> 2) + 255) / 256;
+  if (fg > 1024) fg = 1024;
+  hipLaunchKernelGGL(tn_group_fold_k, (int)fg, 256, 0, (hipStream_t)stream, slab, total, splits, f);
+  DL_LAUNCH_CHECK();
   return DL_OK;
 }

@@ -1,7 +1,24 @@
 // Microarchitecture probes (tests / tuning only): sustained MFMA rate with and without the LDS fragment traffic and
 // the workgroup barrier of the GEMM main loop.  mode 0: MFMA only; 1: + ds_read_b128 fragments (256x192 tile pattern);
 // 2: + one s_barrier per k-step; 3: + direct-to-LDS DMA of a 56 KiB stage per k-step from `src` (L2-resident).
-#include "common.h"
+//
+// LAB CODE, NOT PART OF THE PRODUCT: this file is the whole of libdiffulab_probe.so (include/diffulab_probe.h); nothing in
+// libdiffulab_hip.so or under diffulab_amd/*.py loads it.  Users: tests/ (the two instruction-semantics probes that pin the operand
+// layouts the product kernels rely on: dl_probe_tr16, dl_probe_mfma_f8) and scripts/*_probe.py (tuning).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../common.h"
+#include "../../../include/diffulab_probe.h"
+
+static thread_local char g_probe_err[256];
+void dl_set_error(const char* fmt, ...) {  // (the product library has its own; symbols are hidden, the two never meet)
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_probe_err, sizeof(g_probe_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* dl_probe_last_error(void) { return g_probe_err; }
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
@@ -223,6 +240,51 @@ extern "C" int dl_probe_mfma(int mode, int iters, const void* src, float* out, d
 #undef GOC
   }
 #undef GO
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// =====================================================================================================
+// raw lane map of ds_read_b64_tr_b16 (pins the semantics the weight-gradient GEMMs and the attention kernels rely on)
+// =====================================================================================================
+__global__ void probe_tr16_k(uint16_t* out) {
+  __shared__ __attribute__((aligned(16))) uint16_t img[256];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 256; i += 64) img[i] = (uint16_t)i;
+  __syncthreads();
+  s16x4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)(lds_void_t*)((const char*)img + lane * 8)));
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[lane * 4 + j] = (uint16_t)v[j];
+}
+extern "C" int dl_probe_tr16(uint16_t* out, dl_stream_t stream) {
+  DL_CHECK_ARG(out, "dl_probe_tr16: null");
+  hipLaunchKernelGGL(probe_tr16_k, 1, 64, 0, (hipStream_t)stream, out);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// =====================================================================================================
+// D[32,32] = A[32,64] . B[32,64]^T through ONE v_mfma_scale_f32_32x32x64_f8f6f4 with the operand layout attention_fp8.hip relies
+// on: lane l holds row (l & 31), bytes [32 (l >> 5), +32) of the row; D in the 32x32 accumulator layout (row (r&3) + 8 (r>>2) +
+// 4 (l>>5), column l & 31).  cbsz = 0 / blgp = 0: both operands OCP e4m3; scale exponents 127 = 2^0 in every byte.
+// =====================================================================================================
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+__global__ void probe_mfma_f8_k(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, float* __restrict__ d) {
+  const int lane = threadIdx.x, hi = lane >> 5;
+  const v8i_t av = *(const v8i_t*)(a + (lane & 31) * 64 + hi * 32);
+  const v8i_t bv = *(const v8i_t*)(b + (lane & 31) * 64 + hi * 32);
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) d[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + (lane & 31)] = acc[r];
+}
+extern "C" int dl_probe_mfma_f8(const void* a, const void* b, float* d, dl_stream_t stream) {
+  DL_CHECK_ARG(a && b && d, "dl_probe_mfma_f8: null");
+  hipLaunchKernelGGL(probe_mfma_f8_k, 1, 64, 0, (hipStream_t)stream, (const uint8_t*)a, (const uint8_t*)b, d);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

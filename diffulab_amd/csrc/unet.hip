@@ -436,23 +436,11 @@ __global__ void gn_bwd_apply_k(const bf16_t* __restrict__ dout, const bf16_t* __
     *(u32x4_t*)(dx + o) = pack8(xv);
   }
 }
-static bool gn_bwd_fused() {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("DL_GN_BWD_FUSED");  // A/B switch: 0 = the three-launch form for every shape
-    on = e ? atoi(e) : 1;
-  }
-  return on != 0;
-}
+static bool gn_bwd_fused() { return true; }  // (the three-launch form stays for the shapes the fused kernel does not take)
 // pixel ranges of gn_bwd_reduce_k: enough workgroups to fill the chip at small batch x channel counts, at least 64 pixels each
 static inline int gn_bwd_ranges(int64_t B, int64_t HW, int64_t C) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("DL_GN_BWD_RANGES");  // tuning switch: force the number of pixel ranges (1 = none)
-    forced = e ? atoi(e) : 0;
-  }
   const int64_t slabs = (C + 63) / 64;
-  int64_t ns = forced > 0 ? forced : 1024 / (B * slabs);
+  int64_t ns = 1024 / (B * slabs);
   if (ns > HW / 64) ns = HW / 64;
   if (ns > DL_GN_BWD_MAX_RANGES) ns = DL_GN_BWD_MAX_RANGES;
   return ns < 1 ? 1 : (int)ns;
@@ -846,14 +834,7 @@ bool launch_attn_small_mfma_fwd(const void* q, const void* k, const void* v, int
 bool launch_attn_small_mfma_bwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldkv, const void* dout,
                                 int64_t ldo, const float* probs, void* dq, void* dk, void* dv, int64_t B, int64_t n, int64_t H,
                                 int64_t dh, float scale, hipStream_t stream);
-static bool attn_small_use_mfma() {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("DL_ATTN_SMALL_MFMA");
-    on = e ? atoi(e) : 1;
-  }
-  return on != 0;
-}
+static bool attn_small_use_mfma() { return true; }  // (head widths the MFMA kernels do not take fall to the f32 VALU kernels)
 extern "C" int dl_attn_small_fwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldkv, void* out, int64_t ldo,
                                  float* probs, int64_t B, int64_t n, int64_t H, int64_t dh, float scale, dl_stream_t stream) {
   DL_CHECK_ARG(q && k && v && out && probs && B > 0 && n > 0 && n <= AS_MAXN && dh % 8 == 0, "dl_attn_small_fwd: n=%lld dh=%lld",

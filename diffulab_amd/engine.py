@@ -354,9 +354,10 @@ class DiTEngine:
             w["demb16"] = z(Bp, E)
             w["dh1"] = z(Bp, E, dtype=f32)
             w["dpre1"] = z(Bp, E)
-            # [8 XCDs, M, N] f32 partial slabs of the wide-tile MLP weight-gradient GEMMs (dl_gemm_tn_ws): zero between launches
-            if os.environ.get("DL_GEMM_TN_WIDE") == "1":  # (opt-in experiment: the wide tiles measured slower)
-                w["tn_ws"] = z(8 * 2 * d.mlp_ratio * D * D, dtype=f32)
+            # partial slabs of the grouped weight-gradient launch (dl_gemm_tn_group: the four linears of a block in one atomics-free
+            # launch): 8 token ranges x (4 + 3 mlp_ratio) D^2 floats; one set, the side stream runs the blocks one after the other
+            if self._grouped_wgrad(M):
+                w["tn_slab"] = torch.empty(8 * (4 + 3 * d.mlp_ratio) * D * D, device=dev, dtype=f32)
             w["scr_last"] = z(_rup(Fo, 8), D, dtype=f32)
             w["scr_conv"] = z(D, self._ki, dtype=f32)
         self.ws, self._ws_key = w, key
@@ -467,7 +468,8 @@ class DiTEngine:
                     g_qkv=self.G(pre + "attention.qkv.weight"), g_proj=self.G(pre + "attention.proj_out.weight"),
                     g_up=self.G(pre + "mlp_input.0.weight"), g_down=self.G(pre + "mlp_input.2.weight"),
                     g_ln1=self.G(pre + "norm_1.weight"), g_ln2=self.G(pre + "norm_2.weight"),
-                    g_qk_scale=self.G(pre + "attention.qk_norm.query_norm.scale"))
+                    g_qk_scale=self.G(pre + "attention.qk_norm.query_norm.scale"), tn_slab=w.get("tn_slab"))
+            blk.tn_slab_floats = w["tn_slab"].numel() if "tn_slab" in w else 0
         self._blk_cache[key] = blk
         return blk
 
@@ -559,6 +561,13 @@ class DiTEngine:
                     N=Fo, K=D)
         ops.unpatchify(w["otok"], w["pred"], d.patch_size)
         return w["pred"]
+
+    def _grouped_wgrad(self, M: int) -> bool:
+        """the four weight gradients of a block as ONE launch without atomics (csrc/gemm_w4.hip, dl_gemm_tn_group): every linear of
+        the block must be a whole number of 384 x 192 tiles.  DL_WGRAD_GROUP=0 is the A/B switch back to four atomic launches."""
+        D, F = self.d.inner_dim, self.d.mlp_ratio * self.d.inner_dim
+        return (type(self) is DiTEngine and D % 384 == 0 and F % 192 == 0 and M % 32 == 0 and M >= 2048
+                and os.environ.get("DL_WGRAD_GROUP", "1") != "0")
 
     def _row_gemms(self, M: int, N: int) -> bool:
         """the row-complete GEMM path (csrc/gemm_ln.hip): LayerNorm-modulate forward / backward and QK-norm + RoPE run as epilogues
@@ -673,21 +682,40 @@ class DiTEngine:
         side = self._side_stream()
         side.wait_stream(main)
 
-        side_wgs = int(os.environ.get("DL_SIDE_WGS", "128"))  # of 256 CUs; with the ring wgrad kernel: 96: 24.5, 128: 24.1, 160: 24.4, 192: 24.8, 256: 25.8 ms/step
+        # workgroup cap of the side-stream weight gradients (of 256 CUs).  Four atomic launches per block: 96: 24.5, 128: 24.1, 160:
+        # 24.4, 192: 24.8, 256: 25.8 ms/step (round 2).  The grouped launch (one per block, no atomics) wants the whole chip: every
+        # kernel of the step is then one workgroup per CU and the two streams simply take turns (64: 23.8, 96: 22.4, 128: 22.3,
+        # 192: 22.1, 256: 21.7 ms/step; the same launches inline on the main stream: 21.9)
+        side_wgs = int(os.environ.get("DL_SIDE_WGS", "256" if w.get("tn_slab") is not None else "128"))
 
         serial = os.environ.get("DL_WGRAD_SERIAL") == "1"  # A/B switch: weight gradients inline on the main stream
 
-        tn_ws = w.get("tn_ws")
+        tn_slab = w.get("tn_slab")
+        pending: list[tuple[Tensor, Tensor, Tensor]] = []  # (dy, x, g) of the current block, launched together once dqkv exists
 
-        def wgrad(x_grad: Tensor, x_in: Tensor, gname: str, wide: bool = False) -> None:
-            ws = tn_ws if wide else None  # (one workspace: the MLP wgrads run one after the other on the side stream)
+        def wgrad(x_grad: Tensor, x_in: Tensor, gname: str) -> None:
+            if tn_slab is not None:
+                pending.append((x_grad, x_in, self.G(gname)))
+                return
             if serial:
-                ops.gemm_tn(x_grad, x_in, self.G(gname), ws=ws)
+                ops.gemm_tn(x_grad, x_in, self.G(gname))
                 return
             ev = main.record_event()
             with torch.cuda.stream(side):
                 side.wait_event(ev)
-                ops.gemm_tn(x_grad, x_in, self.G(gname), max_wgs=side_wgs, ws=ws)
+                ops.gemm_tn(x_grad, x_in, self.G(gname), max_wgs=side_wgs)
+
+        def wgrad_flush() -> None:  # the block's four weight gradients: one atomics-free launch + fold (dl_gemm_tn_group)
+            if not pending:
+                return
+            if serial:
+                _must(ops.gemm_tn_group(pending, tn_slab))
+            else:
+                ev = main.record_event()
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    _must(ops.gemm_tn_group(pending, tn_slab, max_wgs=side_wgs))
+            pending.clear()
 
         def fold_norm(partial: Tensor, gname: str) -> None:  # [B, 2, D] per-sample sums -> [w; b] gradients, off the chain
             if defer_fold:
@@ -724,9 +752,7 @@ class DiTEngine:
             if early_mod:
                 self.reducer.ready(w_mod + i * 6 * D * E, w_mod + (i + 1) * 6 * D * E, flush=i < 3)
 
-        # fused MLP-down dgrad + SwiGLU backward (dH never written): 32 % less HBM traffic than the GEMM + elementwise pair
-        fused_dswiglu = os.environ.get("DL_FUSED_DSWIGLU", "0") == "1"
-        native = self._native_blocks() and not fused_dswiglu and not serial and dx is w["dxa"]
+        native = self._native_blocks() and not serial and dx is w["dxa"]
         defer_fold = fused and self.reducer is None  # LayerNorm-affine partials of every block: one batched fold after the loop
         for i in reversed(range(L)):
             if native:
@@ -740,14 +766,14 @@ class DiTEngine:
             pre = f"layers.{i}."
             mo = i * 6 * D
             # MLP branch
-            wgrad(g["dt2"], a["h"], pre + "mlp_input.2.weight", wide=True)  # dt2 / dgate: produced by the LayerNorm backward before
+            wgrad(g["dt2"], a["h"], pre + "mlp_input.2.weight")  # dt2 / dgate: produced by the LayerNorm backward before
             if a["u"] is None:  # no saved pre-activations: the u tile is recomputed next to the dh tile, neither is written
                 _must(ops.mlp_dswiglu_recompute(a["xm2"], sh[pre + "mlp_input.0.weight|g"], g["dt2"], sh[pre + "mlp_input.2.weight|t"],
                                                  g["du"]))
-            elif not (fused_dswiglu and ops.gemm_nt_dswiglu(g["dt2"], sh[pre + "mlp_input.2.weight|t"], a["u"], g["du"])):
+            else:
                 ops.gemm_nt(g["dt2"], sh[pre + "mlp_input.2.weight|t"], w["dh"])
                 ops.swiglu_bwd(w["dh"], a["u"], g["du"])
-            wgrad(g["du"], a["xm2"], pre + "mlp_input.0.weight", wide=True)
+            wgrad(g["du"], a["xm2"], pre + "mlp_input.0.weight")
             if fused:
                 _must(ops.ln_modulate_gemm_bwd(g["du"], sh[pre + "mlp_input.0.weight|t"], a["x1"], self.P(pre + "norm_2.weight"),
                                                 self.P(pre + "norm_2.bias"), mod[:, mo + 3 * D : mo + 4 * D], N, a["mean2"], a["rstd2"],
@@ -778,6 +804,7 @@ class DiTEngine:
                                  self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], g["dqkv"],
                                  self.G(pre + "attention.qk_norm.query_norm.scale"), B, N, Hh, 64, rot)
             wgrad(g["dqkv"], a["xm1"], pre + "attention.qkv.weight")
+            wgrad_flush()
             if not fused:
                 ops.gemm_nt(g["dqkv"], sh[pre + "attention.qkv.weight|t"], w["dxm"])
             if i - 1 in dfeats:  # auxiliary-loss gradient on the output of block i-1 (= this block's input)

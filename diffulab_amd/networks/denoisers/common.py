@@ -91,7 +91,7 @@ class FlatArenaDenoiser(Denoiser):
         raise NotImplementedError
 
     def __deepcopy__(self, memo):  # EMA wrappers deep-copy the module: copy parameters, not the engine/workspace
-        saved = {k: self.__dict__.get(k) for k in ("_engine", "_flat", "_flat_grad", "_anchor", "_graphs")}
+        saved = {k: self.__dict__.get(k) for k in ("_engine", "_flat", "_flat_grad", "_anchor", "_graphs", "_plist")}
         for k in saved:
             object.__setattr__(self, k, None)
         try:
@@ -116,13 +116,15 @@ class FlatArenaDenoiser(Denoiser):
 
     def _param_version(self) -> int:
         """sum of the parameters' version counters: in-place writes through a parameter (``load_state_dict``, stock
-        optimizers, ``p.copy_``) are invisible to the arena's own counter the bf16 weight shadows used to be keyed on"""
+        optimizers, ``p.copy_``) are invisible to the arena's own counter the bf16 weight shadows used to be keyed on.
+        The parameter list is cached between re-flattenings: a parameter object that is replaced or added (``load_state_dict(
+        assign=True)``, a re-registered ``nn.Parameter``) is no longer a view of the arena, so ``engine`` re-flattens before the next
+        forward (``_is_flat``) and ``flatten_parameters`` drops this cache."""
         plist = self.__dict__.get("_plist")
-        if plist is None or len(plist[1]) != plist[0]:
-            ps = list(self.parameters())
-            plist = (len(ps), ps)
+        if plist is None:
+            plist = list(self.parameters())
             object.__setattr__(self, "_plist", plist)
-        return sum(p._version for p in plist[1])
+        return sum(p._version for p in plist)
 
     def _is_flat(self) -> bool:
         if self._flat is None or self._engine is None:
@@ -161,6 +163,7 @@ class FlatArenaDenoiser(Denoiser):
         object.__setattr__(self, "_flat", flat)
         object.__setattr__(self, "_flat_grad", grad)
         object.__setattr__(self, "_anchor", anchor)
+        object.__setattr__(self, "_plist", None)  # (the parameter objects may be new ones: _param_version rebuilds its list)
         self._engine.bind(flat, grad)
 
     def _prepare_grads(self) -> None:

@@ -194,17 +194,6 @@ def mlp_dswiglu_recompute(x: Tensor, wp: Tensor, dt: Tensor, w2t: Tensor, du: Te
                   _p(du), du.stride(0), M, F, x.shape[1], dt.shape[1], _s())
 
 
-def gemm_nt_dswiglu(dt: Tensor, w2t: Tensor, u: Tensor, du: Tensor) -> bool:
-    """fused MLP-down dgrad + SwiGLU backward; False when unsupported for the shape"""
-    rc = lib().cdll.dl_gemm_nt_dswiglu(_p(dt), dt.stride(0), _p(w2t), w2t.stride(0), _p(u), u.stride(0), _p(du),
-                                       du.stride(0), dt.shape[0], u.shape[1] // 2, dt.shape[1], _s())
-    if rc == -3:
-        return False
-    if rc != 0:
-        raise RuntimeError(f"dl_gemm_nt_dswiglu failed ({rc}): {lib().cdll.dl_last_error().decode()}")
-    return True
-
-
 def _padded_rows(t: Tensor) -> Tensor:
     """a row buffer allocated as the leading slice of a zero-padded parent (rows rounded up to 64): the parent"""
     base = t._base
@@ -214,22 +203,47 @@ def _padded_rows(t: Tensor) -> Tensor:
     return t
 
 
-def gemm_tn(a: Tensor, b: Tensor, out: Tensor, *, M: int | None = None, N: int | None = None, max_wgs: int = 0,
-            ws: Tensor | None = None) -> Tensor:
+def gemm_tn(a: Tensor, b: Tensor, out: Tensor, *, M: int | None = None, N: int | None = None, max_wgs: int = 0) -> Tensor:
     """out[M,N] (f32) += a[R,M]^T @ b[R,N].  max_wgs > 0 caps the persistent workgroups (side-stream wgrads).  R must be a
-    multiple of 64: operands that are leading slices of zero-padded row buffers are widened to their parents.
-    ws: zeroed f32 workspace of >= 8*M*N elements (left zero): enables the wide-tile kernel for the MLP weight shapes."""
+    multiple of 64: operands that are leading slices of zero-padded row buffers are widened to their parents."""
     M = a.shape[1] if M is None else M
     N = b.shape[1] if N is None else N
     if a.shape[0] % 64:
         a, b = _padded_rows(a), _padded_rows(b)
         assert a.shape[0] == b.shape[0], "gemm_tn operands with a ragged row count must be zero-padded row buffers"
-    if ws is not None:
-        _call("dl_gemm_tn_ws", _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, a.shape[0], int(max_wgs),
-              _p(ws), ws.numel(), _s())
-        return out
     _call("dl_gemm_tn_ex", _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, a.shape[0], int(max_wgs), _s())
     return out
+
+
+class _WGrad(__import__("ctypes").Structure):
+    """ctypes mirror of dl_wgrad_t (include/diffulab_hip.h)"""
+    import ctypes as _c
+
+    _fields_ = [("dy", _c.c_void_p), ("ld_dy", _c.c_int64), ("x", _c.c_void_p), ("ld_x", _c.c_int64), ("g", _c.c_void_p),
+                ("m_out", _c.c_int64), ("n_in", _c.c_int64)]
+
+
+def gemm_tn_group(probs: list[tuple[Tensor, Tensor, Tensor]], slab: Tensor, max_wgs: int = 0) -> bool:
+    """g_p[M_p, N_p] (f32, contiguous) += dy_p[R, M_p]^T @ x_p[R, N_p] for up to four (dy, x, g) over the same R rows in ONE launch
+    without atomics (bit-reproducible): partial tiles per token range go to `slab` (f32 scratch, >= sum M_p N_p elements; 8 x that
+    fills the chip) and are folded in a fixed order.  False: the 384 x 192 tile does not divide a shape (nothing was launched)."""
+    import ctypes
+
+    arr = (_WGrad * len(probs))()
+    R = probs[0][0].shape[0]
+    for q, (dy, x, g) in zip(arr, probs):
+        assert dy.shape[0] == R and x.shape[0] == R and g.is_contiguous()
+        q.dy, q.ld_dy, q.x, q.ld_x, q.g, q.m_out, q.n_in = _p(dy), dy.stride(0), _p(x), x.stride(0), _p(g), g.shape[0], g.shape[1]
+    global _LIB
+    if _LIB is None:
+        _LIB = lib()
+    fn = _LIB._fns["dl_gemm_tn_group"][0]
+    rc = fn(ctypes.addressof(arr), len(probs), R, _p(slab), slab.numel(), int(max_wgs), _s())
+    if rc == -3:  # DL_ERR_UNSUPPORTED
+        return False
+    if rc != 0:
+        raise RuntimeError(f"dl_gemm_tn_group failed ({rc}): {_LIB.cdll.dl_last_error().decode()}")
+    return True
 
 
 # ------------------------------------------------------------------ block kernels
@@ -632,10 +646,11 @@ def conv3x3_nt(x, B, H, W, ci, wf, out, co, bias, resid, zero, scratch=None) -> 
                   _p(resid), resid.stride(0) if resid is not None else 0, _p(zero), _p(scratch), _s())
 
 
-def conv3x3_wgrad_tn(x, B, H, W, ci, dy, co, g, zero) -> bool:
-    """implicit-GEMM transposed weight gradient g[(tap, ci), co] +=; False -> use im2col3x3 + gemm_tn"""
+def conv3x3_wgrad_tn(x, B, H, W, ci, dy, co, g, zero, max_wgs: int = 0) -> bool:
+    """implicit-GEMM transposed weight gradient g[(tap, ci), co] +=; max_wgs > 0 caps the persistent workgroups (side-stream
+    launches beside the convolution chain); False -> use im2col3x3 + gemm_tn"""
     return _maybe("dl_conv3x3_wgrad_tn", _p(x), x.stride(0), B, H, W, ci, _p(dy), dy.stride(0), dy.shape[0], co, _p(g),
-                  g.stride(0), _p(zero), _s())
+                  g.stride(0), _p(zero), int(max_wgs), _s())
 
 
 def cast_conv3x3_weight(w, wf, wd):
@@ -709,9 +724,3 @@ def masked_stream(pattern: str, device) -> "torch.cuda.Stream":
     with torch.cuda.device(device):
         lib().call("dl_stream_create_masked", arr, words, ctypes.byref(handle))
     return torch.cuda.ExternalStream(handle.value, device=device)
-
-
-def probe_tr16() -> Tensor:
-    out = torch.zeros(256, dtype=torch.int16, device="cuda")
-    _call("dl_probe_tr16", _p(out), _s())
-    return out

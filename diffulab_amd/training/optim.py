@@ -39,18 +39,27 @@ class FusedAdamW(torch.optim.Optimizer):
                  weight_decay: float = 1e-2) -> None:
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = 1.0  # data parallel: 1/world (gradients are SUM-reduced), folded into the update kernel
-        self._legacy_arena_state: dict | None = None
+        self._legacy_arena_states: list[dict] = []
         self._graph_hyper: list[tuple[Tensor, Tensor]] | None = None  # per group: (device f32[8], pinned host mirror)
+        self._graph_buffers: list[tuple[Tensor, Tensor]] | None = None
 
-    # ---- hipGraph support (training/graph_step.py): inside a captured step the update kernels read their scalars from a device
-    #      buffer; the host advances the step count and refreshes that buffer BEFORE each replay
+    # ---- hipGraph support (dl_adamw_step_dev; the captured-step experiment lives in scripts/lab/graph_step.py): inside a captured
+    #      step the update kernels read their scalars from a device buffer; the host advances the step count and refreshes that
+    #      buffer BEFORE each replay.  The buffers are allocated ONCE: graphs captured earlier hold their addresses, so a second
+    #      begin_graph_mode (another input shape being captured) must not replace them.
     def begin_graph_mode(self) -> None:
-        dev = next(p for g in self.param_groups for p in g["params"]).device
-        self._graph_hyper = [(torch.zeros(8, device=dev), torch.zeros(8).pin_memory()) for _ in self.param_groups]
+        if self._graph_hyper is None:
+            if self._graph_buffers is None:
+                dev = next(p for g in self.param_groups for p in g["params"]).device
+                self._graph_buffers = [(torch.zeros(8, device=dev), torch.zeros(8).pin_memory()) for _ in self.param_groups]
+            self._graph_hyper = self._graph_buffers
         self._graph_step = max([int(st["step"]) for st in self.state.values() if "step" in st] or [0])
 
+    def in_graph_mode(self) -> bool:
+        return self._graph_hyper is not None
+
     def end_graph_mode(self) -> None:
-        self._graph_hyper = None
+        self._graph_hyper = None  # (the buffers stay allocated: a graph that is still alive keeps reading them)
 
     def advance(self) -> None:
         """one optimizer step is about to be replayed: bump the step count everywhere and upload the hyper-parameters"""
@@ -73,9 +82,39 @@ class FusedAdamW(torch.optim.Optimizer):
         return next(p for p in group["params"] if id(p) not in skip and p.requires_grad)
 
     def load_state_dict(self, state_dict) -> None:
+        """accepts three optimizer.pt layouts: this class's own (arena-sized ``m`` / ``v`` / ``step`` under the first arena
+        parameter of a group, per-parameter ``m`` / ``v`` / ``step`` for tensors outside the arena), the reference's
+        ``torch.optim.AdamW`` checkpoint (per-parameter ``exp_avg`` / ``exp_avg_sq`` / ``step``: packed into the arena moments at
+        the first step, see _adopt_reference_state) and the address-keyed ``arena*`` entries round 1 wrote (matched by size)"""
         super().load_state_dict(state_dict)
         for k in [k for k in self.state if isinstance(k, str) and k.startswith("arena")]:
-            self._legacy_arena_state = self.state.pop(k)
+            self._legacy_arena_states.append(self.state.pop(k))
+
+    def _adopt_reference_state(self, pb: Tensor, inside: list, key: Tensor) -> None:
+        """torch.optim.AdamW state (the reference's optimizer.pt, base_trainer.py:246-251) -> arena moments: every arena
+        parameter's exp_avg / exp_avg_sq is copied to its offset, the step count is the parameters' common one"""
+        m, v = torch.zeros_like(pb), torch.zeros_like(pb)
+        steps = set()
+        base = pb.storage_offset()
+        for p in inside:
+            st = self.state.get(p)
+            if not st:
+                continue
+            if "exp_avg" not in st or "exp_avg_sq" not in st:
+                raise RuntimeError(f"optimizer state of an arena parameter has keys {sorted(st)}: expected FusedAdamW's "
+                                   "('m', 'v', 'step') or torch.optim.AdamW's ('exp_avg', 'exp_avg_sq', 'step')")
+            o = p.data.storage_offset() - base
+            m[o : o + p.numel()].copy_(st["exp_avg"].reshape(-1).to(pb.device, torch.float32))
+            v[o : o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1).to(pb.device, torch.float32))
+            steps.add(int(st["step"]))
+            if p is not key:
+                del self.state[p]
+        if len(steps) > 1:
+            raise RuntimeError(f"torch.optim.AdamW checkpoint with different step counts per parameter ({sorted(steps)}): the arena "
+                               "update has one")
+        st = self.state[key]
+        st.clear()
+        st["step"], st["m"], st["v"] = (steps.pop() if steps else 0), m, v
 
     def _flat(self, group) -> tuple[Tensor, Tensor, list] | None:
         """(param arena, grad arena, parameters NOT in it) when (most of) the group lives in one flat arena -- e.g. a denoiser's
@@ -137,10 +176,16 @@ class FusedAdamW(torch.optim.Optimizer):
                 pb, gb, rest = flat
                 # The arena's moments are keyed on the group's first arena parameter: Optimizer.state_dict() maps parameter keys
                 # to stable indices, so a checkpoint resumes in a new process (a key derived from the arena's address would not)
-                st = self.state[self._arena_key(group, rest)]
-                if not st and self._legacy_arena_state is not None and self._legacy_arena_state["m"].numel() == pb.numel():
-                    st.update(self._legacy_arena_state)  # checkpoint written with the address-keyed entry of round 1
-                    self._legacy_arena_state = None
+                key = self._arena_key(group, rest)
+                st = self.state[key]
+                if not st:
+                    for i, old in enumerate(self._legacy_arena_states):  # address-keyed entries of round-1 checkpoints
+                        if old["m"].numel() == pb.numel():
+                            st.update(self._legacy_arena_states.pop(i))
+                            break
+                if st and "m" not in st:  # a torch.optim.AdamW checkpoint (per-parameter exp_avg / exp_avg_sq)
+                    skip = {id(p) for p in rest}
+                    self._adopt_reference_state(pb, [p for p in group["params"] if id(p) not in skip and p.requires_grad], key)
                 if not st:
                     st["step"], st["m"], st["v"] = 0, torch.zeros_like(pb), torch.zeros_like(pb)
                 if st["m"].device != pb.device or st["m"].numel() != pb.numel():  # state loaded before the model moved

@@ -38,9 +38,6 @@ class BaseTrainer(Trainer):
         per_batch_scheduler: bool = False,
         ema_denoiser: EMA | None = None,
     ) -> None:
-        if self._use_graph_step(diffuser, optimizer):
-            return self._graphed_training_step(diffuser, optimizer, batch, tracker, p_classifier_free_guidance, scheduler,
-                                               per_batch_scheduler, ema_denoiser)
         self.begin_micro_step()
         # AcceleratedOptimizer.zero_grad() only acts while gradient_state.sync_gradients is set, and accumulate() sets that flag
         # for the micro-step being entered: the reference therefore clears the window's gradients right before the LAST backward
@@ -63,34 +60,6 @@ class BaseTrainer(Trainer):
                 scheduler.step()
         if ema_denoiser is not None:
             ema_denoiser.update()  # counts micro-steps: update_after_step / update_every were scaled in __init__ (common.py:97-98)
-        self.end_micro_step()
-
-    # ------------------------------------------------------------------ the step as one hipGraph (launch-bound configurations)
-    def _use_graph_step(self, diffuser: "Diffuser", optimizer: Optimizer) -> bool:
-        """DIFFULAB_GRAPH_STEP=1, one process, no accumulation, FusedAdamW, HIP denoiser: training/graph_step.py"""
-        import os
-
-        return (os.environ.get("DIFFULAB_GRAPH_STEP", "0") == "1" and self.world == 1 and self.gradient_accumulation_step == 1
-                and hasattr(optimizer, "begin_graph_mode") and hasattr(diffuser.denoiser, "engine") and self.device.type == "cuda")
-
-    def _graphed_training_step(self, diffuser, optimizer, batch, tracker, p_cfg, scheduler, per_batch_scheduler, ema_denoiser) -> None:
-        from ..graph_step import GraphedTrainStep
-
-        gs = self.__dict__.get("_graph_step_obj")
-        if gs is None or gs.diffuser is not diffuser or gs.optimizer is not optimizer:
-            gs = self.__dict__["_graph_step_obj"] = GraphedTrainStep(diffuser, optimizer)
-        self.begin_micro_step()
-        model_inputs = self.move_dict_to_device(dict(batch["model_inputs"]))
-        timesteps = diffuser.draw_timesteps(model_inputs["x"].shape[0]).to(self.device)
-        model_inputs.update({"p": p_cfg})
-        extra = self.move_dict_to_device(dict(batch.get("extra", {})))
-        losses = gs(model_inputs, timesteps, extra)
-        for key, loss in losses.items():
-            tracker.update(loss.item(), key=f"train/{key}")
-        if scheduler is not None and per_batch_scheduler:
-            scheduler.step()  # (the new learning rate reaches the captured update through FusedAdamW.advance())
-        if ema_denoiser is not None:
-            ema_denoiser.update()
         self.end_micro_step()
 
     @torch.no_grad()
@@ -168,7 +137,7 @@ class BaseTrainer(Trainer):
                     diffuser.denoiser = ema_denoiser.ema_model.eval()
                     for loss in diffuser.extra_losses:
                         loss.set_model(ema_denoiser.ema_model)
-                for val_batch in val_dataloader:
+                for val_batch in self.even_batches(val_dataloader):
                     self.validation_step(diffuser=diffuser, val_batch=val_batch, tracker=tracker)
                 total_loss = 0.0
                 for key, value in tracker.avg.items():

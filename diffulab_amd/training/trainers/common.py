@@ -16,8 +16,11 @@ Mirrors ``training/trainers/common.py:25-271`` of the reference (same constructo
     with the mean gradient of the k micro-batches.  In both modes the loss is divided by k, only the synchronising micro-step
     reduces across ranks / steps the optimizer and the scheduler, and the last batch of a dataloader pass always synchronises
     (Accelerate's ``sync_with_dataloader``);
-  * mixed precision: the HIP path always computes in bf16 MFMA with f32 accumulation and f32 master weights, so
-    ``precision_type`` in {"no", "bf16"} is accepted for config compatibility and changes nothing; "fp16" is refused;
+  * mixed precision: the HIP path computes in bf16 MFMA with f32 accumulation, f32 master weights, f32 norm statistics / softmax
+    / loss head -- the reference's ``precision_type="bf16"`` regime, and the only one there is.  ``precision_type="no"`` (the
+    reference's fp32 default) RAISES instead of silently training in bf16 (the fp32 loss curve differs by up to ~3e-3 per step,
+    tests/test_dit_gpu.py); the default of this class is therefore "bf16", and configs/trainer/default.yaml says so; "fp16" is
+    refused as well;
   * ``compile`` / ``dynamo_plugin_kwargs`` are accepted and ignored (no tracing compiler: the launch sequences are static);
   * wandb (absent, no network) is replaced by a JSON-lines log under ``save_path/metrics.jsonl``.
 """
@@ -50,7 +53,7 @@ class Trainer(ABC):
         self,
         n_epoch: int,
         gradient_accumulation_step: int = 1,
-        precision_type: str = "no",
+        precision_type: str = "bf16",
         save_path: str | Path = Path.home() / "experiments" / f"{datetime.now().strftime('%Y%m%d_%H%M%S')}",
         project_name: str = "my_project",
         run_config: dict[str, Any] | None = None,
@@ -62,8 +65,11 @@ class Trainer(ABC):
         compile: bool = False,
         dynamo_plugin_kwargs: dict[str, Any] = {},
     ) -> None:
-        if precision_type not in ("no", "bf16"):
-            raise NotImplementedError(f"precision_type={precision_type!r}: the HIP path computes in bf16 with f32 accumulation")
+        if precision_type != "bf16":
+            raise NotImplementedError(
+                f"precision_type={precision_type!r}: the HIP path has ONE precision regime -- bf16 MFMA operands with f32 accumulation, "
+                "f32 master weights, f32 norm statistics, softmax and loss (the reference's precision_type='bf16').  An fp32 ('no') or "
+                "fp16 run would not be what was asked for, so it is refused: set trainer.precision_type=bf16.")
         self.n_epoch = n_epoch
         self.use_ema = use_ema
         self.ema_rate = ema_rate
@@ -108,7 +114,7 @@ class Trainer(ABC):
             if isinstance(v, dict):
                 out[k] = self.shard_batch(v)
             elif isinstance(v, (Tensor, list)) and len(v) > 0:
-                if len(v) % self.world:  # (accelerate's split_batches=True refuses such a batch size too)
+                if len(v) % self.world:  # (cannot happen behind iterate() / even_batches(): partial batches are completed there)
                     raise ValueError(f"split_batches: batch entry {k!r} has {len(v)} rows, not divisible by world size {self.world}")
                 n = len(v) // self.world
                 out[k] = v[self.rank * n : (self.rank + 1) * n]
@@ -157,9 +163,56 @@ class Trainer(ABC):
         self._micro += 1
         self._accum_step = 0 if self._end_of_dataloader else self._accum_step + 1
 
+    @staticmethod
+    def _rows(batch: Any) -> int | None:
+        """row count of the first tensor / list entry of a (nested) batch dict"""
+        for v in batch.values():
+            n = Trainer._rows(v) if isinstance(v, dict) else (len(v) if isinstance(v, (Tensor, list)) and len(v) > 0 else None)
+            if n is not None:
+                return n
+        return None
+
+    @staticmethod
+    def _complete(batch: Any, first: Any, missing: int) -> Any:
+        """append `missing` rows taken from the start of `first` (wrapping around it) to every tensor / list entry"""
+        out: dict[str, Any] = {}
+        for k, v in batch.items():
+            if isinstance(v, dict):
+                out[k] = Trainer._complete(v, first[k], missing)
+            elif isinstance(v, Tensor) and len(v) > 0:
+                src = first[k]
+                reps = -(-missing // len(src))
+                out[k] = torch.cat([v, (src.repeat((reps,) + (1,) * (src.dim() - 1)) if reps > 1 else src)[:missing].to(v.device)])
+            elif isinstance(v, list) and len(v) > 0:
+                src = first[k]
+                out[k] = v + (src * (-(-missing // len(src))))[:missing]
+            else:
+                out[k] = v
+        return out
+
+    def even_batches(self, dataloader: Iterable[BatchData]):
+        """Accelerate's even_batches=True under split_batches=True (BatchSamplerShard._iter_with_split): with more than one
+        process a last batch that is smaller than the batch size is completed with samples from the FIRST batch of the pass
+        (wrapping around it if needed), so every rank gets batch_size / world rows and no rank runs out of data mid-epoch.
+        One process: batches pass through untouched (a partial last batch stays partial, as in the reference)."""
+        if self.world == 1:
+            yield from dataloader
+            return
+        first, size = None, getattr(dataloader, "batch_size", None)  # (a torch DataLoader knows it; else: the first batch's rows)
+        for batch in dataloader:
+            if first is None:
+                first, size = batch, size or self._rows(batch)
+                if size is not None and size % self.world:
+                    raise ValueError(f"split_batches=True: the batch size ({size}) must be a round multiple of the number of "
+                                     f"processes ({self.world})")
+            n = self._rows(batch)
+            if size is not None and n is not None and n < size:
+                batch = self._complete(batch, first, size - n)
+            yield batch
+
     def iterate(self, dataloader: Iterable[BatchData]):
         """yields the batches of one pass and flags the last one (``GradientState.end_of_dataloader``), which forces a sync"""
-        it = iter(dataloader)
+        it = iter(self.even_batches(dataloader))
         batch = next(it, None)
         while batch is not None:
             nxt = next(it, None)

@@ -127,10 +127,6 @@ DL_API int dl_gemm_nt_swiglu(const void* X, int64_t ldx, const void* Wp, int64_t
 DL_API int dl_mlp_dswiglu_recompute(const void* X, int64_t ldx, const void* Wp, int64_t ldwp, const void* dT, int64_t ldt,
                                     const void* W2t, int64_t ldw2, void* dU, int64_t lddu, int64_t M, int64_t F, int64_t K1,
                                     int64_t K2, dl_stream_t stream);
-/* mlp_input[2] dgrad + PackedSwiGLU backward fused: dH = dT W2 is never written; dU = [dH x3 silu'(x1) | dH silu(x1)].
- * W2t = transposed bf16 shadow [F, K]; U = saved pre-activations [M, 2F].  Same shape rule as above. */
-DL_API int dl_gemm_nt_dswiglu(const void* dT, int64_t ldt, const void* W2t, int64_t ldw, const void* U, int64_t ldu,
-                              void* dU, int64_t lddu, int64_t M, int64_t F, int64_t K, dl_stream_t stream);
 /* nn.Linear wgrad:  C[m,n] += sum_r A[r,m] * B[r,n]   A:[R,M] lda, B:[R,N] ldb, C f32 [M,N] ldc (atomic
  * accumulate across the split of R; caller zeroes C once per optimizer step).  R multiple of 64. */
 DL_API int dl_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
@@ -139,13 +135,24 @@ DL_API int dl_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, fl
  * stream beside the main dependency chain leaves CUs free for that chain's latency-bound kernels */
 DL_API int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                          int64_t N, int64_t R, int max_workgroups, dl_stream_t stream);
-/* same with a caller-owned f32 workspace of >= 8*M*N elements, zero on first use and left zero on return: the wgrads of the MLP
- * linears (nn.py:478-486 / mmdit.py:260-264: [8D, D] and [D, 4D] weights) run 256x384 / 384x256 tiles whose split-R partial
- * sums meet in one slab per XCD (atomics stay inside one L2) and are folded into C by a second small kernel; other shapes, or
- * workspace == NULL, behave exactly like dl_gemm_tn_ex */
-DL_API int dl_gemm_tn_ws(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
-                         int64_t N, int64_t R, int max_workgroups, float* workspace, int64_t workspace_elems,
-                         dl_stream_t stream);
+/* Up to four nn.Linear weight gradients over the SAME R token rows in ONE launch, WITHOUT atomics (the four linears of a
+ * transformer block: mmdit.py:75-104 qkv / proj_out, mmdit.py:260-264 the two MLP linears):  g_p[m,n] += sum_r dy_p[r,m] x_p[r,n].
+ * Every (token range, 384 x 192 tile) workgroup writes its f32 partial tile into slab[range] with plain stores and a fold kernel adds
+ * the ranges in a fixed order, so two runs give bit-identical gradients.  m_out % 384 == 0, n_in % 192 == 0, R % 32 == 0, R >= 2048
+ * -- otherwise DL_ERR_UNSUPPORTED (the caller keeps dl_gemm_tn_ex per problem).  slab: caller-owned f32 scratch of slab_floats >=
+ * sum_p m_out_p * n_in_p elements (contents irrelevant on entry, undefined on return); the number of token ranges is
+ * min(workgroup budget / tiles, slab_floats / that sum), so 8 x the sum lets one launch fill the chip at D = 384.  max_workgroups
+ * caps the grid like dl_gemm_tn_ex (0 = one workgroup per CU). */
+typedef struct dl_wgrad_t {
+  const void* dy;   /* bf16 [R, m_out], row stride ld_dy: gradient of the linear's output */
+  int64_t ld_dy;
+  const void* x;    /* bf16 [R, n_in], row stride ld_x: the linear's input */
+  int64_t ld_x;
+  float* g;         /* f32 [m_out, n_in] contiguous: the weight gradient, accumulated into (+=) */
+  int64_t m_out, n_in;
+} dl_wgrad_t;
+DL_API int dl_gemm_tn_group(const dl_wgrad_t* probs, int n_probs, int64_t R, float* slab, int64_t slab_floats, int max_workgroups,
+                            dl_stream_t stream);
 
 /* ------------------------------------------------------------------ adaLN / norms */
 /* modulate(LayerNorm(x)) mmdit.py:299,305,547 + nn.py:539:  out = (LN(x) * w + b) * (1 + scale) + shift.
@@ -455,10 +462,10 @@ DL_API int dl_conv3x3_nt(const void* x, int64_t ldx, int64_t B, int64_t H, int64
                          int64_t ldr, const void* zero, float* splitk_scratch, dl_stream_t stream);
 /* implicit-GEMM weight gradient, transposed like dl_conv3x3_wgrad_fold expects:
  * g[(tap, ci), co] += sum_p x[p + shift(tap), ci] dY[p, co]; dY rows [R, ldy], R % 64 == 0, rows >= B*H*W zero; Co % 8 == 0.
- * Returns DL_ERR_UNSUPPORTED when Ci % 128 != 0. */
+ * max_workgroups caps the persistent workgroups like dl_gemm_tn_ex (0 = one per CU).  Returns DL_ERR_UNSUPPORTED when Ci % 128 != 0. */
 DL_API int dl_conv3x3_wgrad_tn(const void* x, int64_t ldx, int64_t B, int64_t H, int64_t W, int64_t Ci, const void* dY,
                                int64_t ldy, int64_t R, int64_t Co, float* g, int64_t ldg, const void* zero,
-                               dl_stream_t stream);
+                               int max_workgroups, dl_stream_t stream);
 /* weight gradient from dl_gemm_tn(cols, dY) lands transposed as g f32 [(tap, ci), ldg >= Co]: dw[Co, Ci, 3, 3] += g^T */
 DL_API int dl_conv3x3_wgrad_fold(const float* g, int64_t ldg, float* dw, int64_t Co, int64_t Ci, dl_stream_t stream);
 /* out[b, yo, xo, c] = scale * sum of the 2x2 window of x [B, 2Ho, 2Wo, C]: avg_pool2d forward (scale 0.25, nn.py:86) and
@@ -529,6 +536,7 @@ enum {
   DL_BLK_NEXT_LN_W, DL_BLK_NEXT_LN_B, DL_BLK_NEXT_SCALE, DL_BLK_NEXT_SHIFT,
   DL_BLK_NEXT_X,      /* [M,D] residual stream leaving the block (x1 + gate2 * t2) */
   DL_BLK_NEXT_XM, DL_BLK_NEXT_MEAN, DL_BLK_NEXT_RSTD,
+  DL_BLK_TN_SLAB,     /* f32 [tn_slab_floats] scratch of dl_gemm_tn_group, or NULL: the four weight gradients as dl_gemm_tn_ex launches */
   DL_BLK_NPTR
 };
 typedef struct dl_dit_block_t {
@@ -545,6 +553,8 @@ typedef struct dl_dit_block_t {
                                   * MLP-down epilogue or the patch embedding) and the MLP branch's gated residual IS applied (NEXT_X);
                                   * bit 1: QK-norm + RoPE in the qkv GEMM's epilogue; bit 2: dl_dit_block_bwd leaves the LayerNorm-affine
                                   * partials DWB1 / DWB2 unfolded (the caller folds all blocks at once: dl_reduce_rows_batched_f32) */
+  int64_t tn_slab_floats;        /* size of DL_BLK_TN_SLAB; with a slab the block's four weight gradients are ONE atomics-free launch
+                                  * (dl_gemm_tn_group) issued on `side` once dqkv exists */
 } dl_dit_block_t;
 /* forward of one block; train != 0 keeps the MLP pre-activations U for the backward.  The MLP branch's gated residual
  * (x1 + gate2 * t2) is NOT applied: it is the next block's (or the final LayerNorm's) pending triple. */
@@ -552,27 +562,6 @@ DL_API int dl_dit_block_fwd(const dl_dit_block_t* blk, int train, dl_stream_t st
 /* backward of one block on `main`; the weight-gradient GEMMs and LayerNorm-affine folds are issued on `side` behind events
  * (join `side` before the gradients are consumed); side_workgroups caps the persistent wgrad workgroups (0 = one per CU) */
 DL_API int dl_dit_block_bwd(const dl_dit_block_t* blk, dl_stream_t main_stream, dl_stream_t side_stream, int side_workgroups);
-
-/* ------------------------------------------------------------------ debugging probes (tests only) */
-/* raw ds_read_b64_tr_b16 lane map: fills out[64*4] with what each lane receives when lane l passes
- * address 8*l over an LDS image holding the uint16 values 0..255 */
-DL_API int dl_probe_tr16(uint16_t* out, dl_stream_t stream);
-/* D f32 [32,32] = A[32,64] . B[32,64]^T for e4m3 bytes, through one v_mfma_scale_f32_32x32x64_f8f6f4 with the operand layout
- * attention_fp8.hip relies on (lane l: row l & 31, bytes [32 (l >> 5), +32)); pins the instruction's semantics */
-DL_API int dl_probe_mfma_f8(const void* a, const void* b, float* d, dl_stream_t stream);
-/* sustained MFMA 32x32x16 bf16 rate of the GEMM main-loop skeleton on 256 workgroups x 8 waves, `iters` k-steps of
- * 24 MFMAs per wave: mode 0 MFMA only, 1 + LDS fragment reads, 2 + one workgroup barrier per k-step, 3 + the 56 KiB
- * direct-to-LDS DMA per k-step from `src` (>= 256*57344 bytes).  out: f32 [256*512] (sink).
- * modes 8 / 9: store-pattern probe -- `out` is a bf16 [65536, 1152] buffer written `iters` times in the GEMM register
- * epilogue's pattern (32 rows x 32 B per instruction) / with full 128-byte lines per 8 lanes. */
-/* tuning builds: bit flags that strip one component from the persistent GEMM kernels (256x384 NT tiles / 384x128 TN tiles):
- * 1 = no epilogue stores / atomics, 2 = no MFMA, 4 = no operand DMA after the first stage, 8 = no LDS fragment reads
- * (5 and 10 combine them); 0 restores the product kernels.  scripts/gemm_probe.py */
-DL_API int dl_probe_gemm_set(int flags);
-/* tuning probe: the operand DMA stream of the 256 x 384 NT GEMM tile walk alone (kb = 128: 64-deep steps / 2 ring slots,
- * kb = 64: 32-deep steps with 64-byte row segments / 4 ring slots); out: >= 256*512 floats */
-DL_API int dl_probe_dma(int kb, const void* A, const void* Bw, int64_t M, int64_t K, float* out, dl_stream_t stream);
-DL_API int dl_probe_mfma(int mode, int iters, const void* src, float* out, dl_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,38 @@
+/* libdiffulab_probe.so -- LAB / TEST instrumentation, NOT part of the product ABI (that is diffulab_hip.h + diffulab_comm.h).
+ *
+ * Built from diffulab_amd/csrc/lab/probe.hip by `make probe` (also part of `make all`, so the GPU tests find it in-tree).  Nothing
+ * under diffulab_amd/ loads this library.  Two kinds of entry points:
+ *   - instruction-semantics probes the GPU TESTS use to pin the operand layouts the product kernels rely on
+ *     (dl_probe_tr16, dl_probe_mfma_f8);
+ *   - tuning probes for scripts/ probe scripts (sustained MFMA rate, operand-DMA stream, store patterns).
+ * Same conventions as diffulab_hip.h: plain pointers, int status (0 = ok), the caller's hipStream_t. */
+#ifndef DIFFULAB_PROBE_H
+#define DIFFULAB_PROBE_H
+#include <stdint.h>
+
+#include "diffulab_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+DL_API const char* dl_probe_last_error(void);
+/* raw ds_read_b64_tr_b16 lane map: fills out[64*4] with what each lane receives when lane l passes address 8*l over an LDS image
+ * holding the uint16 values 0..255 */
+DL_API int dl_probe_tr16(uint16_t* out, dl_stream_t stream);
+/* D f32 [32,32] = A[32,64] . B[32,64]^T for e4m3 bytes, through one v_mfma_scale_f32_32x32x64_f8f6f4 with the operand layout
+ * attention_fp8.hip relies on (lane l: row l & 31, bytes [32 (l >> 5), +32)); pins the instruction's semantics */
+DL_API int dl_probe_mfma_f8(const void* a, const void* b, float* d, dl_stream_t stream);
+/* sustained MFMA 32x32x16 bf16 rate of the GEMM main-loop skeleton on 256 workgroups x 8 waves, `iters` k-steps of 24 MFMAs per
+ * wave: mode 0 MFMA only, 1 + LDS fragment reads, 2 + one workgroup barrier per k-step, 3 + the 56 KiB direct-to-LDS DMA per
+ * k-step from `src` (>= 256*57344 bytes), 4-7 copy-path variants.  out: f32 [256*512] (sink).  modes 8 / 9: store-pattern probe --
+ * `out` is a bf16 [65536, 1152] buffer written `iters` times in the GEMM register epilogue's pattern (32 rows x 32 B per
+ * instruction) / with full 128-byte lines per 8 lanes. */
+DL_API int dl_probe_mfma(int mode, int iters, const void* src, float* out, dl_stream_t stream);
+/* the operand DMA stream of the 256 x 384 NT GEMM tile walk alone (kb = 128: 64-deep steps / 2 ring slots, kb = 64: 32-deep steps
+ * with 64-byte row segments / 4 ring slots); out: >= 256*512 floats */
+DL_API int dl_probe_dma(int kb, const void* A, const void* Bw, int64_t M, int64_t K, float* out, dl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFULAB_PROBE_H */

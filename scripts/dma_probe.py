@@ -3,7 +3,8 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from diffulab_amd._lib import lib
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _probe_lib import lib  # libdiffulab_probe.so (lab code, include/diffulab_probe.h)
 
 L = lib()
 dev = "cuda"

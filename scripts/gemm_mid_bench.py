@@ -1,6 +1,5 @@
-"""plain NT GEMMs at mid-size row counts (M = 8192: CIFAR DiT at batch 32, DiT-B/REPA at batch 128 x 64 tokens) under the three
-dispatch variants: DL_GEMM_NT_VARIANT=4 (256x384 / 256x192 tiles when >= 64 tiles), 2 (256x192 only), 0 (128x128 kernel)
-    for v in 4 2 0; do DL_GEMM_NT_VARIANT=$v python scripts/gemm_mid_bench.py; done"""
+"""plain NT GEMMs at mid-size row counts (M = 8192: CIFAR DiT at batch 32, DiT-B/REPA at batch 128 x 64 tokens) through the tile
+dispatch of dl_gemm_nt (widest persistent tile that still fills >= 70 % of the CU rounds, else the 128x128 kernel)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,10 +19,9 @@ def timeit(fn, iters=30):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-v = os.environ.get("DL_GEMM_NT_VARIANT", "4")
 for M in (8192, 16384):
     for D in (512, 768):
         for name, N, K in (("qkv", 3 * D, D), ("proj", D, D), ("mlp2", D, 4 * D), ("d_h", 4 * D, D), ("d_xm2", D, 8 * D), ("d_xm1", D, 3 * D)):
             a, b, out = rnd(M, K), rnd(N, K), torch.empty(M, N, device=dev, dtype=torch.bfloat16)
             us = timeit(lambda: ops.gemm_nt(a, b, out))
-            print(f"v{v} M={M:6d} D={D} {name:6s} N={N:5d} K={K:5d}: {us:7.1f} us {2.0*M*N*K/us/1e6:7.1f} TF/s", flush=True)
+            print(f"M={M:6d} D={D} {name:6s} N={N:5d} K={K:5d}: {us:7.1f} us {2.0*M*N*K/us/1e6:7.1f} TF/s", flush=True)

@@ -1,4 +1,7 @@
-"""The whole training step as ONE hipGraph (zero_grad -> noise + loss head -> denoiser forward -> backward with its side-stream
+"""LAB CODE (moved out of the package in round 3: measured slower than the eager launches on this ROCm, DESIGN.md section 6 --
+kept for runtimes whose graph launch is cheaper; nothing under diffulab_amd/ imports it).
+
+The whole training step as ONE hipGraph (zero_grad -> noise + loss head -> denoiser forward -> backward with its side-stream
 weight-gradient GEMMs -> fused AdamW), for the launch-bound configurations.
 
 A training step of the joint text-image SPRINT model (BASELINE config 5) is ~1400 kernel launches; at the yaml's batch size the
@@ -67,6 +70,8 @@ class GraphedTrainStep:
         self.optimizer.zero_grad()
         losses = self.diffuser.compute_loss(model_inputs=model_inputs, timesteps=timesteps, extra_args=extra)
         sum(losses.values()).backward()
+        if self.optimizer.in_graph_mode():  # a graph of another shape is alive: the update reads the device scalars, refresh them
+            self.optimizer.advance()
         self.optimizer.step()
         return losses
 
@@ -118,7 +123,8 @@ class GraphedTrainStep:
             import logging
 
             logging.warning("hipGraph capture of the training step failed (%s): running this shape eagerly", e)
-            opt.end_graph_mode()
+            if not any(v not in (None, False) for v in self._graphs.values()):  # other shapes' graphs keep the device scalars
+                opt.end_graph_mode()
             torch.cuda.synchronize()
             self._graphs[key] = False
             return False

@@ -1,7 +1,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from diffulab_amd._lib import lib
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _probe_lib import lib  # libdiffulab_probe.so (lab code, include/diffulab_probe.h)
 L = lib()
 src = (torch.randn(256 * 57344 // 2, device="cuda") * 0.1).to(torch.bfloat16)
 out = torch.zeros(256 * 512, device="cuda")

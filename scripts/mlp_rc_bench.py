@@ -29,9 +29,8 @@ f_u = timeit(lambda: ops.gemm_nt_swiglu(x, w1p, u, h))
 f_h = timeit(lambda: ops.gemm_nt_swiglu(x, w1p, None, h))
 b_g = timeit(lambda: ops.gemm_nt(dt, w2t, dh))
 b_s = timeit(lambda: ops.swiglu_bwd(dh, u, du))
-b_f = timeit(lambda: ops.gemm_nt_dswiglu(dt, w2t, u, du))
 b_r = timeit(lambda: ops.mlp_dswiglu_recompute(x, w1p, dt, w2t, du))
 print(f"forward  : u and h stored {f_u:6.1f} us | h only {f_h:6.1f} us")
-print(f"backward : dgrad GEMM {b_g:6.1f} + swiglu_bwd {b_s:6.1f} = {b_g + b_s:6.1f} us | fused epilogue on stored u {b_f:6.1f} us | "
+print(f"backward : dgrad GEMM {b_g:6.1f} + swiglu_bwd {b_s:6.1f} = {b_g + b_s:6.1f} us | "
       f"recompute {b_r:6.1f} us ({(2.0 * M * F * D + 4.0 * M * F * D) / b_r / 1e6:6.1f} TF/s over both GEMMs)")
 print(f"fwd + bwd: stored {f_u + b_g + b_s:6.1f} us | recompute {f_h + b_r:6.1f} us")

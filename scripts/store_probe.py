@@ -3,7 +3,8 @@ on a [65536, 1152] bf16 output (dl_probe_mfma modes 8 / 9):  python scripts/stor
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from diffulab_amd._lib import lib
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _probe_lib import lib  # libdiffulab_probe.so (lab code, include/diffulab_probe.h)
 L = lib()
 
 out = torch.empty(65536, 1152, device="cuda", dtype=torch.bfloat16)

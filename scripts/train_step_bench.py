@@ -105,7 +105,8 @@ def main() -> None:
         opt.step()
 
     if a.graph:
-        from diffulab_amd.training.graph_step import GraphedTrainStep
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab"))
+        from graph_step import GraphedTrainStep  # scripts/lab (lab code, not part of the package)
 
         gs = GraphedTrainStep(d, opt, warmup=3)
 

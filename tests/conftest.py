@@ -37,3 +37,20 @@ def golden():
         return cache[name]
 
     return load
+
+
+@pytest.fixture(scope="session")
+def probe_lib():
+    """libdiffulab_probe.so (include/diffulab_probe.h): LAB instrumentation, not part of the product ABI -- the GPU tests use its two
+    instruction-semantics probes to pin the operand layouts the product kernels rely on"""
+    import ctypes
+
+    path = os.path.join(ROOT, "diffulab_amd", "libdiffulab_probe.so")
+    if not os.path.exists(path):
+        pytest.fail(f"{path} not found: `make -C diffulab_amd/csrc probe`")
+    lib = ctypes.CDLL(path)
+    for name in ("dl_probe_tr16", "dl_probe_mfma_f8"):
+        getattr(lib, name).restype = ctypes.c_int
+    lib.dl_probe_tr16.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.dl_probe_mfma_f8.argtypes = [ctypes.c_void_p] * 4
+    return lib

@@ -481,7 +481,7 @@ def gen_loss_curve() -> None:
     cfg = S2
     m = build_ref(cfg, seed=7)
     opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8)
-    B, steps = 4, 12
+    B, steps = 4, 20  # 20 steps
     x0 = synth.normal("curve.x0", (B, 4, 32, 32))
     y = synth.integers("curve.y", (B,), 1000)
     losses = []

@@ -20,16 +20,14 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-def test_mfma_scale_f8_operand_layout_probe():
-    from diffulab_amd._lib import lib
-
+def test_mfma_scale_f8_operand_layout_probe(probe_lib):
     g = torch.Generator().manual_seed(0)
     vals = torch.tensor([-4.0, -2.0, -1.5, -1.0, -0.5, 0.0, 0.5, 1.0, 1.5, 2.0, 3.0])
     a = vals[torch.randint(0, len(vals), (32, 64), generator=g)]
     b = vals[torch.randint(0, len(vals), (32, 64), generator=g)]
     a8, b8 = a.to(torch.float8_e4m3fn).to(DEV), b.to(torch.float8_e4m3fn).to(DEV)
     d = torch.empty(32, 32, device=DEV)
-    lib().call("dl_probe_mfma_f8", a8.data_ptr(), b8.data_ptr(), d.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert probe_lib.dl_probe_mfma_f8(a8.data_ptr(), b8.data_ptr(), d.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
     torch.cuda.synchronize()
     assert torch.equal(d.cpu(), a @ b.T)  # exact: every product and partial sum is representable
 

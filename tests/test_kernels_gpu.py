@@ -52,10 +52,12 @@ def dev_bf(x):
 
 
 # ------------------------------------------------------------------ hardware semantics the kernels rely on
-def test_probe_tr16_lane_map(ops):
+def test_probe_tr16_lane_map(probe_lib):
     """ds_read_b64_tr_b16: inside each 16-lane group, lane i receives element (i%4) of the 8 bytes addressed
     by lane 4j + i/4, for j = 0..3 (a 4x16 transpose).  gemm_tn and attention are built on this."""
-    got = ops.probe_tr16().cpu().numpy().astype(np.int64).reshape(64, 4)
+    out = torch.zeros(256, dtype=torch.int16, device=DEV)
+    assert probe_lib.dl_probe_tr16(out.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    got = out.cpu().numpy().astype(np.int64).reshape(64, 4)
     os.makedirs("gpurun_out", exist_ok=True)
     np.savetxt("gpurun_out/probe_tr16.txt", got, fmt="%d")
     exp = np.zeros((64, 4), dtype=np.int64)
@@ -133,6 +135,37 @@ def test_gemm_tn_ring_kernel(ops, R, M, N, cap):
     ops.gemm_tn(dev_bf(a)[:, 64:], dev_bf(b)[:, :N], c, max_wgs=cap)
     ref = init + bf(a)[:, 64:].t() @ bf(b)[:, :N]
     assert rel(c, ref) < 2e-5
+
+
+@pytest.mark.parametrize("R,cap,ranges", [(4096 + 32 * 7, 0, 8), (8192, 128, 8), (2048, 64, 8), (4096, 0, 1), (16384, 0, 3)])
+def test_gemm_tn_group_is_exact_and_bit_reproducible(ops, R, cap, ranges):
+    """dl_gemm_tn_group (csrc/gemm_w4.hip): the four weight gradients of a DiT-S block (qkv, proj_out, MLP up / down: 32 tiles of
+    384 x 192) in ONE launch, partial tiles per token range in a slab, folded in a fixed order.  += semantics, column windows of
+    wider operands, ragged last token range, a slab that only has room for `ranges` partial images, the workgroup cap -- and two
+    runs are bit-identical (the one-problem launches meet in f32 atomics and are not)"""
+    D, F = 384, 1536
+    shapes = [(3 * D, D), (D, D), (2 * F, D), (D, F)]
+    probs, refs = [], []
+    for i, (Mo, No) in enumerate(shapes):
+        a = synth.normal(f"tng.a{i}{R}", (R, Mo + 64))
+        b = synth.normal(f"tng.b{i}{R}", (R, No + 128))
+        init = synth.normal(f"tng.c{i}", (Mo, No))
+        probs.append((dev_bf(a)[:, 64:], dev_bf(b)[:, :No], init))
+        refs.append(init + bf(a)[:, 64:].t() @ bf(b)[:, :No])
+    total = sum(m * n for m, n in shapes)
+    slab = torch.full((ranges * total,), float("nan"), device=DEV)  # contents on entry are irrelevant
+    outs = []
+    for _ in range(2):
+        gs = [init.to(DEV).clone() for _, _, init in probs]
+        assert ops.gemm_tn_group([(a, b, g) for (a, b, _), g in zip(probs, gs)], slab, max_wgs=cap)
+        outs.append(gs)
+    for g0, g1, ref in zip(outs[0], outs[1], refs):
+        assert rel(g0, ref) < 2e-5
+        assert torch.equal(g0, g1)
+    # a shape the tile does not divide: nothing is launched, the caller keeps the per-problem path
+    g = torch.zeros(128, 384, device=DEV)
+    assert not ops.gemm_tn_group([(probs[0][0][:, :128], probs[0][1], g)], slab)
+    assert float(g.abs().max()) == 0.0
 
 
 def test_cast2d_column_window(ops):
@@ -534,7 +567,8 @@ def test_adamw_and_casts(ops):
 
 
 def test_fused_swiglu_gemms(ops):
-    """MLP-up GEMM + SwiGLU forward and MLP-down dgrad + SwiGLU backward fused into the GEMM epilogues == the unfused pair."""
+    """MLP-up GEMM + SwiGLU forward fused into the GEMM epilogue, and the MLP backward that recomputes the pre-activations, == the
+    unfused pairs."""
     M, D, F = 16384, 384, 1536
     x = synth.normal("fs.x", (M, D))
     w1 = synth.normal("fs.w1", (2 * F, D), std=D**-0.5)
@@ -553,25 +587,22 @@ def test_fused_swiglu_gemms(ops):
     assert rel(h.float(), h_ref.float()) < 6e-3  # h is computed from the f32 accumulators here, from bf16 u there
     cpu_u = bf(x) @ bf(w1).t()
     assert rel(h.float(), odit.silu(cpu_u[:, :F]) * cpu_u[:, F:]) < 4e-3
-    # backward
+    # backward: the dgrad GEMM + elementwise pair on the saved u ...
     w2t = dev_bf(w2.t().contiguous())  # [F, D]
-    du = torch.empty(M, 2 * F, device=DEV, dtype=torch.bfloat16)
-    assert ops.gemm_nt_dswiglu(dev_bf(dt), w2t, u, du)
     dh = torch.empty(M, F, device=DEV, dtype=torch.bfloat16)
-    du_ref = torch.empty_like(du)
+    du_ref = torch.empty(M, 2 * F, device=DEV, dtype=torch.bfloat16)
     ops.gemm_nt(dev_bf(dt), w2t, dh)
     ops.swiglu_bwd(dh, u, du_ref)
-    assert rel(du.float(), du_ref.float()) < 6e-3
     # ... and without any saved u: the backward recomputes the u tile it needs (bit-identical to the stored one: same accumulation
-    # order, same rounding) next to the dh tile, so it must land where the fused epilogue on the stored u lands
-    du_rc = torch.full_like(du, float("nan"))
+    # order, same rounding) next to the dh tile (kept in f32 here, rounded to bf16 there)
+    du_rc = torch.full_like(du_ref, float("nan"))
     assert ops.mlp_dswiglu_recompute(dev_bf(x), w1p, dev_bf(dt), w2t, du_rc)
-    assert torch.equal(du_rc, du)
+    assert rel(du_rc.float(), du_ref.float()) < 6e-3
     xw = torch.zeros(M, D + 64, device=DEV, dtype=torch.bfloat16)  # operands that are column windows of wider rows
     xw[:, 64:] = dev_bf(x)
     duw = torch.zeros(M, 2 * F + 128, device=DEV, dtype=torch.bfloat16)
     assert ops.mlp_dswiglu_recompute(xw[:, 64:], w1p, dev_bf(dt), w2t, duw[:, : 2 * F])
-    assert torch.equal(duw[:, : 2 * F], du) and float(duw[:, 2 * F :].abs().sum()) == 0.0
+    assert torch.equal(duw[:, : 2 * F], du_rc) and float(duw[:, 2 * F :].abs().sum()) == 0.0
     assert not ops.mlp_dswiglu_recompute(dev_bf(x)[:512], w1p, dev_bf(dt)[:512], w2t, du_rc[:512])  # too few tiles
     # 2F = 4096 (the 512-wide configurations: 256- / 128-wide tiles) through the same three entry points
     D2, F2, M2 = 512, 2048, 8192

@@ -2,7 +2,9 @@
 accumulation, fused EMA, checkpoints with the reference's file names and state_dict keys."""
 
 import json
+import os
 
+import numpy as np
 import pytest
 import torch
 from torch.utils.data import DataLoader
@@ -341,6 +343,44 @@ def test_optimizer_checkpoint_resumes_step_and_moments(tmp_path):
     del keep
 
 
+def test_reference_adamw_checkpoint_resumes_in_the_fused_optimizer(tmp_path):
+    """the reference saves torch.optim.AdamW's state (per-parameter exp_avg / exp_avg_sq / step, base_trainer.py:246-251).
+    FusedAdamW packs such an optimizer.pt into its arena moments and continues the trajectory: 2 stock-AdamW steps + 1 fused step
+    == 3 stock-AdamW steps (the two optimizers are the same update rule; the stock one runs on the same HIP gradients)."""
+    from diffulab_amd import Diffuser
+    from diffulab_amd.training import FusedAdamW
+
+    x0 = synth.normal("ra.x0", (4, 4, 16, 16)).to(DEV)
+    noise = synth.normal("ra.noise", (4, 4, 16, 16)).to(DEV)
+    y = synth.integers("ra.y", (4,), 10).to(DEV)
+    t = synth.uniform("ra.t", (4,), lo=0.05, hi=0.95)
+
+    def one_step(m, opt):
+        opt.zero_grad()
+        d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=4)
+        d.compute_loss({"x": x0.clone(), "y": y, "p": 0.0}, timesteps=t, noise=noise)["loss"].backward()
+        opt.step()
+
+    kw = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    m = small_dit()
+    stock = torch.optim.AdamW(m.parameters(), foreach=False, **kw)
+    one_step(m, stock)
+    one_step(m, stock)
+    torch.save(stock.state_dict(), tmp_path / "optimizer.pt")
+    sd = {k: v.cpu().clone() for k, v in m.state_dict().items()}
+    one_step(m, stock)  # the continuation
+
+    m2 = small_dit()
+    m2.load_state_dict(sd)
+    opt2 = FusedAdamW(m2.parameters(), **kw)
+    opt2.load_state_dict(torch.load(tmp_path / "optimizer.pt", weights_only=False))
+    one_step(m2, opt2)
+    st = [v for v in opt2.state.values() if "m" in v and v["m"].numel() == m2._flat.numel()]
+    assert len(st) == 1 and st[0]["step"] == 3 and "exp_avg" not in st[0]
+    assert not any("exp_avg" in v for v in opt2.state.values()), "per-parameter entries of the arena parameters are consumed"
+    assert rel(m2._flat, m._flat) < 2e-5
+
+
 def test_weights_written_through_parameters_reach_the_inference_shadows():
     """in-place writes through a parameter (load_state_dict on a flattened model, a stock optimizer) do not bump the
     arena's version counter; eval / no_grad / hipGraph-replay forwards must still see the new weights"""
@@ -461,14 +501,42 @@ def test_two_rank_data_parallel_gradients_equal_the_concatenated_batch(tmp_path)
     assert rel(r0["grad"], m._flat_grad) < 2e-3  # (bf16 kernels on batch 4 vs 8: different tiles / atomics order, same math)
 
 
+@pytest.mark.timeout(900)
+def test_bench_data_parallel_branch_runs_on_two_ranks(tmp_path):
+    """bench.py's N > 1 branch (reducer attached to the engine, weak-scaling accounting, the `dp` object with the
+    exposed all-reduce time) had never executed anywhere.  Its dry mode -- the driver's own launch line with `--dp-backend gloo`, two
+    ranks sharing this box's GPU -- runs the same code path end to end and prints the same JSON line."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29000 + (hash(str(tmp_path)) % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "16",
+           "--dp-backend", "gloo", "--no-roofline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=800, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 3 and line["warmup"] == 2
+    assert line["config"]["global_batch"] == 32 and line["config"]["per_gpu_batch"] == 16 and line["config"]["parallelism"] == "dp2"
+    assert abs(line["value"] - 32 * 1e3 / line["ms_per_step"]) / line["value"] < 1e-2  # whole-job images/s over the max-rank time
+    dp = line["dp"]
+    assert dp["rccl_ranks"] == 2 and dp["backend"] == "gloo" and dp["grad_bytes_per_step"] > 100e6
+    assert isinstance(dp["exposed_allreduce_ms_per_step"], float) and dp["exposed_allreduce_ms_per_step"] >= 0.0
+    assert np.isfinite(line["config"]["final_loss"]) and "DRY MODE" in line["data"]
+
+
 def test_graphed_training_step_follows_the_eager_trajectory():
-    """training/graph_step.py: after three eager steps the whole step (zero_grad -> noise + loss -> forward -> backward with the
+    """scripts/lab/graph_step.py (lab code): after three eager steps the whole step (zero_grad -> noise + loss -> forward -> backward with the
     side-stream wgrads -> FusedAdamW reading its scalars from the device) is captured once and replayed.  Same seeds, same data:
     the parameters after 8 steps agree with 8 eager steps (device RNG draws go through torch's graph-safe generator) and the step
     count / learning-rate changes reach the captured update."""
     from diffulab_amd import Diffuser
     from diffulab_amd.training import FusedAdamW
-    from diffulab_amd.training.graph_step import GraphedTrainStep
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "lab"))
+    from graph_step import GraphedTrainStep  # scripts/lab (lab code, not part of the package)
 
     B = 8
     x0 = synth.normal("gs.x0", (B, 4, 16, 16)).to(DEV)

@@ -3,6 +3,7 @@ ema_pytorch (restated), batch sharding with ``split_batches=True`` semantics, ac
 
 import os
 
+import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -75,8 +76,45 @@ def test_shard_batch_and_accumulation_boundaries(tmp_path):
     assert s["model_inputs"]["p"] == 0.1 and s["extra"]["captions"] == ["e", "f"]
     assert (tmp_path / "p").is_dir()
     import pytest
-    with pytest.raises(ValueError):  # split_batches=True refuses a batch the ranks cannot share evenly
+    with pytest.raises(ValueError):  # a batch the ranks cannot share evenly never reaches shard_batch behind iterate() (below)
         t.shard_batch({"model_inputs": {"x": torch.arange(6)}})
+
+
+@pytest.mark.parametrize("n,batch,world", [(23, 8, 4), (15, 8, 8), (1281167 % (128 * 7) + 128, 128, 8), (5, 8, 2), (16, 8, 4)])
+def test_last_partial_batch_is_completed_like_accelerate_even_batches(tmp_path, n, batch, world):
+    """the reference's loader keeps the last partial batch (drop_last=False) and Accelerate (split_batches=True,
+    even_batches=True) completes it with samples from the first batch instead of failing mid-epoch.  Pinned against accelerate's own
+    BatchSamplerShard: every rank must see exactly the sample indices accelerate would hand it."""
+    accelerate = pytest.importorskip("accelerate")
+    from accelerate.data_loader import BatchSamplerShard
+    from torch.utils.data import BatchSampler, SequentialSampler
+
+    from diffulab_amd.training import BaseTrainer
+
+    class Loader(list):  # (what the trainer sees of a torch DataLoader: iteration and .batch_size)
+        batch_size = batch
+
+    data = torch.arange(n)
+    loader = Loader(({"model_inputs": {"x": data[i : i + batch, None].float(), "y": data[i : i + batch]}, "extra": {"names": [str(int(j)) for j in data[i : i + batch]]}}
+              for i in range(0, n, batch)))
+    for rank in range(world):
+        want = list(BatchSamplerShard(BatchSampler(SequentialSampler(range(n)), batch, drop_last=False), num_processes=world,
+                                      process_index=rank, split_batches=True, even_batches=True))
+        t = BaseTrainer(n_epoch=1, save_path=tmp_path, project_name="p")
+        t.world, t.rank = world, rank
+        got, flags = [], []
+        for b in t.iterate(loader):
+            sh = t.shard_batch(b)
+            assert sh["model_inputs"]["x"].flatten().tolist() == sh["model_inputs"]["y"].tolist() == [int(v) for v in sh["extra"]["names"]]
+            got.append(sh["model_inputs"]["y"].tolist())
+            flags.append(t.sync_gradients)
+            t.end_micro_step()
+        assert got == want, (rank, got, want)
+        assert flags[-1] and len(got) == len(loader)
+    t = BaseTrainer(n_epoch=1, save_path=tmp_path, project_name="p")
+    t.world = 3  # a batch size the processes cannot split evenly is refused on the FIRST batch, as accelerate does at prepare time
+    with pytest.raises(ValueError, match="round multiple"):
+        next(iter(t.iterate(loader)))
 
 
 class _FakeDiffuser:
@@ -159,3 +197,19 @@ def test_true_accumulation_switch_differs_from_the_reference(tmp_path):
             + th.nn.functional.mse_loss(m(th.from_numpy(g["xs"][1])), th.from_numpy(g["ys"][1])))).backward()
     o.step()
     np.testing.assert_allclose(w[1], m.weight.detach().numpy(), atol=2e-7)
+
+
+def test_fp32_precision_is_refused_not_silently_downgraded(tmp_path):
+    """``precision_type="no"`` (the reference's fp32 default) used to be accepted and run in bf16.  The HIP path has
+    one precision regime; asking for another raises at construction, and the shipped trainer config names the regime."""
+    import yaml
+
+    from diffulab_amd.training import BaseTrainer
+
+    for bad in ("no", "fp16", "fp8"):
+        with pytest.raises(NotImplementedError, match="bf16"):
+            BaseTrainer(n_epoch=1, precision_type=bad, save_path=tmp_path, project_name="p")
+    BaseTrainer(n_epoch=1, precision_type="bf16", save_path=tmp_path, project_name="p")
+    BaseTrainer(n_epoch=1, save_path=tmp_path, project_name="p")  # the default is the regime that exists
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert yaml.safe_load(open(os.path.join(root, "configs", "trainer", "default.yaml")))["precision_type"] == "bf16"
