@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
                                                      const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                      bf16_t* __restrict__ dq, bf16_t* __restrict__ dk,
                                                      bf16_t* __restrict__ dv, int H, int N, float scale, HeadLayout vl,
-                                                     HeadLayout dvl) {
+                                                     HeadLayout dvl, HeadLayout dql) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ta = smem;             // phase A: K   | phase B: Q
   char* tb = ta + N * ROWB;    // phase A: V   | phase B: dO
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
       step(kb, s0, d0, s1, d1);
       step(kb + 32, s1, d1, s0, d0);
     }
-    store_rows64(dq + hoff + (int64_t)(own + (lane & 31)) * DH, dqa, scale, hi);
+    store_rows64(dq + b * dql.bs + h * dql.hs + (int64_t)(own + (lane & 31)) * dql.pitch, dqa, scale, hi);
   }
 
   // ------------------------------------------------------------------ swap the resident tiles: Q and dO replace K and V
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
       step_t(qb, s0, s1);
       s0 = s1;
     }
-    store_rows64(dk + hoff + (int64_t)(own + (lane & 31)) * DH, dka, scale, hi);
+    store_rows64(dk + b * dql.bs + h * dql.hs + (int64_t)(own + (lane & 31)) * dql.pitch, dka, scale, hi);
     store_rows64(dv + b * dvl.bs + h * dvl.hs + (int64_t)(own + (lane & 31)) * dvl.pitch, dva, 1.0f, hi);
   }
 }
@@ -700,6 +700,17 @@ extern "C" int dl_attn_bwd(const void* q, const void* k, const void* v, const vo
   return dl_attn_bwd_sv(q, k, v, H * N * DH, N * DH, DH, out, dout, lse, dq, dk, dv, H * N * DH, N * DH, DH, B, H, N, dh, scale,
                         stream);
 }
+static int attn_bwd_launch(const void* q, const void* k, const void* v, HeadLayout vl, const void* out, const void* dout,
+                           const float* lse, void* dq, void* dk, HeadLayout dql, void* dv, HeadLayout dvl, int64_t B, int64_t H,
+                           int64_t N, float scale, dl_stream_t stream) {
+  const int lds = (int)(2 * N * ROWB + 2 * N * sizeof(float));
+  (void)hipFuncSetAttribute((const void*)attn_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(attn_bwd_k, (int)(B * H), (int)(N / 64) * 64, lds, (hipStream_t)stream, (const bf16_t*)q,
+                     (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dq,
+                     (bf16_t*)dk, (bf16_t*)dv, (int)H, (int)N, scale, vl, dvl, dql);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
 extern "C" int dl_attn_bwd_sv(const void* q, const void* k, const void* v, int64_t v_batch_stride, int64_t v_head_stride,
                               int64_t v_pitch, const void* out, const void* dout, const float* lse, void* dq, void* dk, void* dv,
                               int64_t dv_batch_stride, int64_t dv_head_stride, int64_t dv_pitch, int64_t B, int64_t H, int64_t N,
@@ -711,14 +722,20 @@ extern "C" int dl_attn_bwd_sv(const void* q, const void* k, const void* v, int64
                    dv_pitch >= DH && dv_pitch % 8 == 0 && dv_head_stride % 8 == 0 && dv_batch_stride % 8 == 0 &&
                    ((uintptr_t)dv & 15) == 0,
                "dl_attn_bwd_sv: V and dV rows must be 16-byte aligned");
-  const int lds = (int)(2 * N * ROWB + 2 * N * sizeof(float));
-  (void)hipFuncSetAttribute((const void*)attn_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL(attn_bwd_k, (int)(B * H), (int)(N / 64) * 64, lds, (hipStream_t)stream, (const bf16_t*)q,
-                     (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dq,
-                     (bf16_t*)dk, (bf16_t*)dv, (int)H, (int)N, scale, HeadLayout{v_batch_stride, v_head_stride, (int)v_pitch},
-                     HeadLayout{dv_batch_stride, dv_head_stride, (int)dv_pitch});
-  DL_LAUNCH_CHECK();
-  return DL_OK;
+  return attn_bwd_launch(q, k, v, HeadLayout{v_batch_stride, v_head_stride, (int)v_pitch}, out, dout, lse, dq, dk,
+                         HeadLayout{H * N * DH, N * DH, DH}, dv, HeadLayout{dv_batch_stride, dv_head_stride, (int)dv_pitch}, B, H, N,
+                         scale, stream);
+}
+extern "C" int dl_attn_bwd_tok(const void* q, const void* k, const void* qkv, const void* out, const void* dout, const float* lse,
+                               void* dqkv, int64_t B, int64_t H, int64_t N, int64_t dh, float scale, dl_stream_t stream) {
+  DL_CHECK_ARG(q && k && qkv && out && dout && lse && dqkv && B > 0 && H > 0, "dl_attn_bwd_tok: null operand");
+  DL_CHECK_ARG(dh == DH, "dl_attn_bwd_tok: head_dim %lld unsupported (64 only)", (long long)dh);
+  DL_CHECK_ARG(N % 64 == 0 && N >= 64 && N <= 256, "dl_attn_bwd_tok: N=%lld must be a multiple of 64 up to 256", (long long)N);
+  DL_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)dqkv) & 15) == 0, "dl_attn_bwd_tok: qkv / dqkv rows must be 16-byte aligned");
+  const int64_t D = H * DH;
+  const HeadLayout tok{N * 3 * D, DH, (int)(3 * D)};  // head (b, h) of a third starts at b * N * 3D + h * 64, rows 3D apart
+  return attn_bwd_launch(q, k, (const bf16_t*)qkv + 2 * D, tok, out, dout, lse, dqkv, (bf16_t*)dqkv + D, tok, (bf16_t*)dqkv + 2 * D, tok,
+                         B, H, N, scale, stream);
 }
 
 // ====================================================================================== small attention (UNet AttentionBlock)

@@ -141,14 +141,22 @@ extern "C" int dl_dit_block_bwd(const dl_dit_block_t* b, dl_stream_t main_, dl_s
   RUN(wgrad(P(DT1), D, P(A), D, P(G_PROJ), D, D));
   RUN(dl_gemm_nt(P(DT1), D, P(WT_PROJ), b->ldwt_d, P(DA), D, M, D, D, nullptr, DL_ACT_NONE, DL_BF16, nullptr, nullptr, 0, nullptr, 0, 1, main));
   const bool v_in_place = P(V) == nullptr;
-  if (v_in_place)
-    RUN(dl_attn_bwd_sv(P(Q), P(K), (const char*)P(QKV) + 2 * D * 2, N * 3 * D, dh, 3 * D, P(A), P(DA), (const float*)P(LSE), P(DQ), P(DK),
-                       (char*)P(DQKV) + 2 * D * 2, N * 3 * D, dh, 3 * D, B, H, N, dh, sm, main));
-  else
-    RUN(dl_attn_bwd(P(Q), P(K), P(V), P(A), P(DA), (const float*)P(LSE), P(DQ), P(DK), P(DV), B, H, N, dh, sm, main));
-  RUN(dl_qk_norm_rope_bwd(P(DQ), P(DK), v_in_place ? nullptr : P(DV), P(QKV), (const float*)P(QN_SCALE), (const float*)P(KN_SCALE),
-                          (const float*)P(ROPE_COS), (const float*)P(ROPE_SIN), (const float*)P(RRMS), P(DQKV), (float*)P(G_QK_SCALE), B, N,
-                          H, dh, b->rot, main));
+  if (v_in_place && P(QK_PARTIALS) && D <= 512) {
+    // every gradient of the attention leaves token-major inside the dqkv rows; the QK-norm backward transforms them in place
+    RUN(dl_attn_bwd_tok(P(Q), P(K), P(QKV), P(A), P(DA), (const float*)P(LSE), P(DQKV), B, H, N, dh, sm, main));
+    RUN(dl_qk_norm_rope_bwd_inplace(P(QKV), (const float*)P(QN_SCALE), (const float*)P(KN_SCALE), (const float*)P(ROPE_COS),
+                                    (const float*)P(ROPE_SIN), (const float*)P(RRMS), P(DQKV), (float*)P(G_QK_SCALE),
+                                    (float*)P(QK_PARTIALS), B, N, H, dh, b->rot, nullptr, main));
+  } else {
+    if (v_in_place)
+      RUN(dl_attn_bwd_sv(P(Q), P(K), (const char*)P(QKV) + 2 * D * 2, N * 3 * D, dh, 3 * D, P(A), P(DA), (const float*)P(LSE), P(DQ), P(DK),
+                         (char*)P(DQKV) + 2 * D * 2, N * 3 * D, dh, 3 * D, B, H, N, dh, sm, main));
+    else
+      RUN(dl_attn_bwd(P(Q), P(K), P(V), P(A), P(DA), (const float*)P(LSE), P(DQ), P(DK), P(DV), B, H, N, dh, sm, main));
+    RUN(dl_qk_norm_rope_bwd(P(DQ), P(DK), v_in_place ? nullptr : P(DV), P(QKV), (const float*)P(QN_SCALE), (const float*)P(KN_SCALE),
+                            (const float*)P(ROPE_COS), (const float*)P(ROPE_SIN), (const float*)P(RRMS), P(DQKV), (float*)P(G_QK_SCALE), B, N,
+                            H, dh, b->rot, main));
+  }
   RUN(wgrad(P(DQKV), 3 * D, P(XM1), D, P(G_QKV), 3 * D, D));
   if (grouped) {
     if (fork_to_side(main, side)) return DL_ERR_LAUNCH;

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void mlp_dswiglu_rc_k(const bf16_t* 
                                                                     const bf16_t* __restrict__ dT, int64_t ldt,
                                                                     const bf16_t* __restrict__ W2t, int64_t ldw2,
                                                                     bf16_t* __restrict__ dU, int64_t lddu, int M, int F, int K1,
-                                                                    int K2) {
+                                                                    int K2, int csplit) {
   constexpr int RC_STAGE = (RC_TBM + 2 * RC_TU) * 128;  // ring slot: phase 1 stages 256 + 2*TU rows of 64 k, phase 2 256 + TU
   constexpr int CH1 = (RC_TBM + 2 * RC_TU) / 64;  // 1 KiB DMA chunks per wave and phase-1 stage
   constexpr int CH2 = (RC_TBM + RC_TU) / 64;      // ... phase-2 stage
@@ -74,9 +74,18 @@ __global__ __launch_bounds__(RC_THREADS, 2) void mlp_dswiglu_rc_k(const bf16_t* 
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = F / RC_TU, ntiles = (M / RC_TBM) * tiles_n;
   const int nk1 = K1 / 64, nk2 = K2 / 64, nks = nk1 + nk2;
-  const int G = gridDim.x;  // multiple of 8: the 32 workgroups of one XCD own 32 consecutive tiles (n fastest) at every slot
-  const int slot0 = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-  const int cnt = (ntiles - slot0 + G - 1) / G;
+  // Tile ownership by XCD (block b runs on XCD b % 8, each XCD has its own 4 MiB L2): the column tiles are cut into `csplit`
+  // groups and the row panels into 8 / csplit groups; XCD x owns column group x % csplit of panel group x / csplit and walks it
+  // panel-major, so at any time its 32 workgroups read a handful of row panels together (each panel is fetched once and hit
+  // nc - 1 times) and re-read only 1 / csplit of the weights -- with csplit = 1 the 3.5 MB of weights (DiT-S: L2-sized) were evicted
+  // by the streaming panels and the du stores and re-fetched for every slot (PMC: 477 MB fetched per launch for 128 MB of operands)
+  const int G = gridDim.x;  // multiple of 8
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, GL = G >> 3;
+  const int panels = M / RC_TBM, pgroups = 8 / csplit;
+  const int nc = tiles_n / csplit, np_max = (panels + pgroups - 1) / pgroups;  // (the last panel group may be short or empty)
+  const int tm0 = (xcd / csplit) * np_max, tn0 = (xcd % csplit) * nc;
+  const int np = panels - tm0 < np_max ? (panels - tm0 > 0 ? panels - tm0 : 0) : np_max;
+  const int cnt = np * nc > local ? (np * nc - local + GL - 1) / GL : 0;
   const int total = cnt * nks;
 
   // ---- per-lane constant parts of the DMA chunks (element offsets inside the operand tile; the swizzle sits in the source address)
@@ -98,10 +107,11 @@ __global__ __launch_bounds__(RC_THREADS, 2) void mlp_dswiglu_rc_k(const bf16_t* 
     off2[i] = r * (int)(a ? ldt : ldw2) + (((lane & 7) ^ ((r >> 1) & 7)) << 3);
   }
   // DMA cursor: one stage ahead of the compute cursor
-  int c_tile = slot0, c_s = 0, c_g = 0;
+  int c_tile = local, c_s = 0, c_g = 0;  // (XCD-local tile index q: panel tm0 + q / nc, column tile tn0 + q % nc)
   auto issue = [&]() __attribute__((always_inline)) {
     char* base = smem + (c_g & 1) * RC_STAGE;
-    const int tm = c_tile / tiles_n, tn = c_tile - tm * tiles_n;
+    const int pl = c_tile / nc;
+    const int tm = tm0 + pl, tn = tn0 + (c_tile - pl * nc);
     if (c_s < nk1) {
       const bf16_t* pa = X + (int64_t)tm * RC_TBM * ldx + c_s * 64;
       const bf16_t* pb = Wp + (int64_t)tn * (2 * RC_TU) * ldwp + c_s * 64;
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void mlp_dswiglu_rc_k(const bf16_t* 
     ++c_g;
     if (++c_s == nks) {
       c_s = 0;
-      c_tile += G;
+      c_tile += GL;
     }
   };
 
@@ -141,8 +151,8 @@ __global__ __launch_bounds__(RC_THREADS, 2) void mlp_dswiglu_rc_k(const bf16_t* 
   int g = 0;
   bool after_epi = false;
   for (int t = 0; t < cnt; ++t) {
-    const int tile = slot0 + t * G;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int tile = local + t * GL;
+    const int tm = tm0 + tile / nc, tn = tn0 + tile % nc;
     // ------------------------------------------------------------------ phase 1: u tile (x1 | x3 of TU hidden units)
     f32x16_t acc1[JN1][2];
 #pragma unroll
@@ -258,9 +268,17 @@ extern "C" int dl_mlp_dswiglu_recompute(const void* X, int64_t ldx, const void* 
   const int ntiles = (int)((M / RC_TBM) * (F / TU));
   int grid = n_cu < ntiles ? n_cu : ntiles;
   grid &= ~7;
+  // column groups per launch (see the kernel): the widest split that keeps whole column tiles and whole row panels per XCD
+  const int panels = (int)(M / RC_TBM), tiles_n = (int)(F / TU);
+  // column groups per XCD (see the kernel).  Measured at the headline shape (M = 65536, F = 1536): csplit 1 / 2 / 4 = 321 / 326 /
+  // 336 us alone and 21.65 / 21.58 / 21.73 ms per step -- halving or quartering the weights an XCD re-reads (the over-fetch the PMC
+  // pass counts) buys nothing: the kernel waits for the ISSUE of its operand stream, not for L2 misses.  One group.
+  const int csplit = 1;
+  (void)panels;
+  (void)tiles_n;
   hipLaunchKernelGGL(mlp_dswiglu_rc_k<TU>, grid, RC_THREADS, 2 * (RC_TBM + 2 * TU) * 128, (hipStream_t)stream, (const bf16_t*)X, ldx,
                      (const bf16_t*)Wp, ldwp, (const bf16_t*)dT, ldt, (const bf16_t*)W2t, ldw2, (bf16_t*)dU, lddu, (int)M, (int)F, (int)K1,
-                     (int)K2);
+                     (int)K2, csplit);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

@@ -805,6 +805,154 @@ extern "C" int dl_qk_norm_rope_bwd_ex(const void* dq, const void* dk, const void
   return DL_OK;
 }
 
+// ------------------------------------------------------------------------ QK-norm + RoPE backward, token-major and in place
+// The q / k thirds of the dqkv rows arrive holding d(loss)/d(q, k after norm + RoPE) in token-major order (dl_attn_bwd_tok stores
+// them there) and leave holding the gradient of the pre-norm q / k.  One wave per row, lane c owns columns [8c, 8c + 8) of the
+// D-wide q and k rows; every global operand of a row (2 x 2 contiguous D-wide segments, two f32 scalars, the RoPE table entries)
+// is fetched ONE ROW AHEAD of its use -- the head-major kernel above reads H 128-byte segments per row and tensor and waits for
+// each row's loads before it starts (111 us at B = 256, 3.0 TB/s).  Scale-gradient partials: registers -> LDS -> one [2, D] slot per
+// workgroup (plain stores); folded in a fixed order by fold_rows_k (no atomics).
+template <int OCC>
+__device__ __forceinline__ void qk_norm_rope_bwd_inplace_body(
+    const bf16_t* __restrict__ qkv, const float* __restrict__ sq, const float* __restrict__ sk, const float* __restrict__ cs,
+    const float* __restrict__ sn, const float* __restrict__ rrms, bf16_t* dqkv, float* __restrict__ partials, int64_t M, int N,
+    int H, int dh, int rot, const int* __restrict__ pos) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = (float*)smem;  // [4 waves][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D = H * dh, D8 = D >> 3;
+  const bool on = lane < D8;
+  const float invD = 1.0f / (float)D;
+  const int col = lane * 8, hh = on ? col / dh : 0, d0 = col - hh * dh;
+  const bool rope = on && d0 < rot;
+  float wq[8], wk[8], aq[8], ak[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    wq[e] = on ? sq[col + e] : 0.f;
+    wk[e] = on ? sk[col + e] : 0.f;
+    aq[e] = ak[e] = 0.f;
+  }
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  u32x4_t nxq = {0, 0, 0, 0}, nxk = nxq, ngq = nxq, ngk = nxq;
+  f32x4_t ncc = {0.f, 0.f, 0.f, 0.f}, nss = ncc;
+  float nrq = 0.f, nrk = 0.f;
+  auto fetch = [&](int64_t r) {
+    const bf16_t* p = qkv + r * 3 * D + col;
+    const bf16_t* g = dqkv + r * 3 * D + col;
+    if (on) {
+      nxq = *(const u32x4_t*)p;
+      nxk = *(const u32x4_t*)(p + D);
+      ngq = *(const u32x4_t*)g;
+      ngk = *(const u32x4_t*)(g + D);
+    }
+    nrq = rrms[r * 2];
+    nrk = rrms[r * 2 + 1];
+    if (rope) {
+      const int nt = pos ? pos[r] : (int)(r % N);
+      ncc = *(const f32x4_t*)(cs + (int64_t)nt * (rot >> 1) + (d0 >> 1));
+      nss = *(const f32x4_t*)(sn + (int64_t)nt * (rot >> 1) + (d0 >> 1));
+    }
+  };
+  int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row < M) fetch(row);
+  for (; row < M; row += stride) {
+    float xq[8], xk[8], gq[8], gk[8];
+    unpack8(nxq, xq);
+    unpack8(nxk, xk);
+    unpack8(ngq, gq);
+    unpack8(ngk, gk);
+    const f32x4_t cc = ncc, ss = nss;
+    const float rq = nrq, rk = nrk;
+    if (row + stride < M) fetch(row + stride);
+    if (rope) {  // transpose of the rotation
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float qa = gq[2 * i], qb = gq[2 * i + 1], ka = gk[2 * i], kb = gk[2 * i + 1];
+        gq[2 * i] = qa * cc[i] + qb * ss[i];
+        gq[2 * i + 1] = -qa * ss[i] + qb * cc[i];
+        gk[2 * i] = ka * cc[i] + kb * ss[i];
+        gk[2 * i + 1] = -ka * ss[i] + kb * cc[i];
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      aq[e] += gq[e] * xq[e] * rq;  // dscale
+      ak[e] += gk[e] * xk[e] * rk;
+      gq[e] *= wq[e];               // s * dy
+      gk[e] *= wk[e];
+      s1 += gq[e] * xq[e];
+      s2 += gk[e] * xk[e];
+    }
+    const float mq = wave_sum(s1) * invD * rq * rq * rq, mk = wave_sum(s2) * invD * rk * rk * rk;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      gq[e] = rq * gq[e] - xq[e] * mq;
+      gk[e] = rk * gk[e] - xk[e] * mk;
+    }
+    if (on) {
+      bf16_t* o = dqkv + row * 3 * D + col;
+      *(u32x4_t*)o = pack8(gq);
+      *(u32x4_t*)(o + D) = pack8(gk);
+    }
+  }
+  if (on) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(size_t)wave * 2 * D + col + e] = aq[e];
+      red[(size_t)wave * 2 * D + D + col + e] = ak[e];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += 256)
+    partials[(size_t)blockIdx.x * 2 * D + i] = (red[i] + red[2 * D + i]) + (red[4 * D + i] + red[6 * D + i]);
+}
+#define QKI_ARGS                                                                                                                  \
+  const bf16_t *__restrict__ qkv, const float *__restrict__ sq, const float *__restrict__ sk, const float *__restrict__ cs,         \
+      const float *__restrict__ sn, const float *__restrict__ rrms, bf16_t *dqkv, float *__restrict__ partials, int64_t M, int N, \
+      int H, int dh, int rot, const int *__restrict__ pos
+__global__ __launch_bounds__(256) void qk_norm_rope_bwd_inplace_k(QKI_ARGS) {
+  qk_norm_rope_bwd_inplace_body<3>(qkv, sq, sk, cs, sn, rrms, dqkv, partials, M, N, H, dh, rot, pos);
+}
+// (capped at 128 VGPRs for four waves per SIMD it spills 84 bytes per lane inside the row loop: 165 us instead of 110)
+// out[j] += sum_g partial[g * n + j] with ONE writer per element and a fixed order (4 interleaved row lanes, then a fixed tree)
+__global__ __launch_bounds__(256) void fold_rows_k(const float* __restrict__ partial, float* __restrict__ out, int G, int n) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float acc = 0.f;
+  if (c < n)
+    for (int g = rl; g < G; g += 4) acc += partial[(size_t)g * n + c];
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < n) out[c] += (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+extern "C" int dl_qk_norm_rope_bwd_inplace(const void* qkv, const float* scale_q, const float* scale_k, const float* cos,
+                                           const float* sin, const float* rrms, void* dqkv, float* dscale, float* dscale_partials,
+                                           int64_t B, int64_t N, int64_t H, int64_t dh, int64_t rot, const int32_t* pos,
+                                           dl_stream_t stream) {
+  DL_CHECK_ARG(qkv && scale_q && scale_k && cos && sin && rrms && dqkv && dscale && dscale_partials && B > 0 && N > 0,
+               "dl_qk_norm_rope_bwd_inplace: null operand");
+  const int64_t D = H * dh;
+  if (D > 512 || D % 8) {
+    dl_set_error("dl_qk_norm_rope_bwd_inplace: inner width %lld (one wave owns a row of at most 512 columns)", (long long)D);
+    return DL_ERR_UNSUPPORTED;
+  }
+  DL_CHECK_ARG(dh % 8 == 0 && rot % 8 == 0 && rot <= dh, "dl_qk_norm_rope_bwd_inplace: dh=%lld rot=%lld", (long long)dh, (long long)rot);
+  DL_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)dqkv | (uintptr_t)cos | (uintptr_t)sin) & 15) == 0,
+               "dl_qk_norm_rope_bwd_inplace: 16-byte alignment");
+  const int64_t M = B * N;
+  // three workgroups per CU are resident (150 VGPRs): at most 768 workgroups, so that no second, partly filled round follows
+  int grid = cdiv(M, M >= 32768 ? 4 * 16 : 4 * 4);
+  if (grid > 768) grid = 768;
+  const size_t lds = (size_t)4 * 2 * D * sizeof(float);
+  hipLaunchKernelGGL(qk_norm_rope_bwd_inplace_k, grid, 256, lds, (hipStream_t)stream, (const bf16_t*)qkv, scale_q, scale_k, cos, sin,
+                     rrms, (bf16_t*)dqkv, dscale_partials, M, (int)N, (int)H, (int)dh, (int)rot, pos);
+  hipLaunchKernelGGL(fold_rows_k, cdiv(2 * D, 64), 256, 0, (hipStream_t)stream, dscale_partials, dscale, grid, (int)(2 * D));
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
 // ======================================================================== SwiGLU
 __global__ void swiglu_fwd_k(const bf16_t* __restrict__ u, bf16_t* __restrict__ h, int64_t M, int F8) {
   const int64_t total = M * F8, stride = (int64_t)gridDim.x * blockDim.x;

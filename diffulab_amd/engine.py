@@ -344,7 +344,13 @@ class DiTEngine:
             # per-block inputs of the weight-gradient GEMMs (consumed asynchronously on the side stream)
             w["wg"] = [{"dt2": z(M, D), "du": z(M, 2 * d.mlp_ratio * D), "dt1": z(M, D), "dqkv": z(M, 3 * D)}
                        for _ in range(L)]
-            w["dq"], w["dk"] = z(B, d.num_heads, N, 64), z(B, d.num_heads, N, 64)
+            # N <= 256 and D <= 512: dQ / dK / dV leave the attention backward token-major inside the dqkv rows and the QK-norm
+            # backward works in place (its per-workgroup scale-gradient partials land in qk_part): no dq / dk buffers
+            if ops.v_in_place(N) and D <= 512 and type(self) is DiTEngine and os.environ.get("DL_QK_INPLACE", "1") != "0":
+                w["qk_part"] = torch.empty(1024 * 2 * D, device=dev, dtype=f32)
+                w["dq"] = w["dk"] = None
+            else:
+                w["dq"], w["dk"] = z(B, d.num_heads, N, 64), z(B, d.num_heads, N, 64)
             w["dv"] = None if ops.v_in_place(N) else z(B, d.num_heads, N, 64)
             w["dmod"] = z(Bp, self.layout.mod_rows)                  # bf16 operand of the modulation GEMMs' backward
             w["dmod32"] = z(Bp, self.layout.mod_rows, dtype=f32)     # f32 accumulator the block kernels add into
@@ -468,7 +474,8 @@ class DiTEngine:
                     g_qkv=self.G(pre + "attention.qkv.weight"), g_proj=self.G(pre + "attention.proj_out.weight"),
                     g_up=self.G(pre + "mlp_input.0.weight"), g_down=self.G(pre + "mlp_input.2.weight"),
                     g_ln1=self.G(pre + "norm_1.weight"), g_ln2=self.G(pre + "norm_2.weight"),
-                    g_qk_scale=self.G(pre + "attention.qk_norm.query_norm.scale"), tn_slab=w.get("tn_slab"))
+                    g_qk_scale=self.G(pre + "attention.qk_norm.query_norm.scale"), tn_slab=w.get("tn_slab"),
+                    qk_partials=w.get("qk_part"))
             blk.tn_slab_floats = w["tn_slab"].numel() if "tn_slab" in w else 0
         self._blk_cache[key] = blk
         return blk
@@ -793,16 +800,22 @@ class DiTEngine:
             wgrad(g["dt1"], a["a"], pre + "attention.proj_out.weight")
             ops.gemm_nt(g["dt1"], sh[pre + "attention.proj_out.weight|t"], w["da"])
             v_in_place = ops.v_in_place(N)
-            if v_in_place:  # dV goes straight into the v third of dqkv
-                ops.attn_bwd_qkv(a["q"], a["k"], a["qkv"], a["a"], w["da"], a["lse"], w["dq"], w["dk"], g["dqkv"], B, Hh, N, 64,
-                                 64**-0.5)
+            if w.get("qk_part") is not None:  # dQ, dK, dV token-major into dqkv; the QK-norm backward transforms q / k in place
+                ops.attn_bwd_tok(a["q"], a["k"], a["qkv"], a["a"], w["da"], a["lse"], g["dqkv"], B, Hh, N, 64, 64**-0.5)
+                _must(ops.qk_norm_rope_bwd_inplace(a["qkv"], self.P(pre + "attention.qk_norm.query_norm.scale"),
+                                                    self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], g["dqkv"],
+                                                    self.G(pre + "attention.qk_norm.query_norm.scale"), w["qk_part"], B, N, Hh, 64, rot))
             else:
-                ops.attn_bwd(a["q"], a["k"], a["v"], a["a"], w["da"], a["lse"], w["dq"], w["dk"], w["dv"], B, Hh, N, 64,
-                             64**-0.5)
-            ops.qk_norm_rope_bwd(w["dq"], w["dk"], None if v_in_place else w["dv"], a["qkv"],
-                                 self.P(pre + "attention.qk_norm.query_norm.scale"),
-                                 self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], g["dqkv"],
-                                 self.G(pre + "attention.qk_norm.query_norm.scale"), B, N, Hh, 64, rot)
+                if v_in_place:  # dV goes straight into the v third of dqkv
+                    ops.attn_bwd_qkv(a["q"], a["k"], a["qkv"], a["a"], w["da"], a["lse"], w["dq"], w["dk"], g["dqkv"], B, Hh, N, 64,
+                                     64**-0.5)
+                else:
+                    ops.attn_bwd(a["q"], a["k"], a["v"], a["a"], w["da"], a["lse"], w["dq"], w["dk"], w["dv"], B, Hh, N, 64,
+                                 64**-0.5)
+                ops.qk_norm_rope_bwd(w["dq"], w["dk"], None if v_in_place else w["dv"], a["qkv"],
+                                     self.P(pre + "attention.qk_norm.query_norm.scale"),
+                                     self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], g["dqkv"],
+                                     self.G(pre + "attention.qk_norm.query_norm.scale"), B, N, Hh, 64, rot)
             wgrad(g["dqkv"], a["xm1"], pre + "attention.qkv.weight")
             wgrad_flush()
             if not fused:

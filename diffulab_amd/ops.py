@@ -414,6 +414,19 @@ def attn_bwd_qkv(q, k, qkv, out, dout, lse, dq, dk, dqkv, B, H, N, dh, scale):
           _p(dk), dqkv.data_ptr() + 2 * D * 2, N * 3 * D, dh, 3 * D, B, H, N, dh, float(scale), _s())
 
 
+def attn_bwd_tok(q, k, qkv, out, dout, lse, dqkv, B, H, N, dh, scale):
+    """N <= 256: V read from qkv; dQ, dK AND dV written token-major into dqkv [B*N, 3*H*dh] (qk_norm_rope_bwd_inplace follows)"""
+    _call("dl_attn_bwd_tok", _p(q), _p(k), _p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), B, H, N, dh, float(scale), _s())
+
+
+def qk_norm_rope_bwd_inplace(qkv, scale_q, scale_k, cos, sin, rrms, dqkv, dscale, partials, B, N, H, dh, rot, pos=None) -> bool:
+    """the q / k thirds of dqkv: gradient after norm + RoPE (token-major) -> gradient of the pre-norm q / k, in place; dscale f32
+    [2, D] += the scale gradients through `partials` (f32 scratch >= 1024 * 2 * D) in a fixed order.  False: inner width > 512"""
+    assert partials.numel() >= 1024 * 2 * H * dh and partials.dtype == torch.float32
+    return _maybe("dl_qk_norm_rope_bwd_inplace", _p(qkv), _p(scale_q), _p(scale_k), _p(cos), _p(sin), _p(rrms), _p(dqkv), _p(dscale),
+                  _p(partials), B, N, H, dh, rot, _p(pos), _s())
+
+
 def attn_fwd_ex(q, k, v, out, lse, B, H, Nq, Nk, dh, scale, key_bias=None):
     """Nq queries against Nk keys (multiples of 256), optional additive key bias f32 [B, Nk] (0 / -inf)"""
     _call("dl_attn_fwd_ex", _p(q), _p(k), _p(v), _p(out), _p(lse), B, H, Nq, Nk, dh, float(scale), _p(key_bias), _s())

@@ -255,6 +255,15 @@ DL_API int dl_qk_norm_rope_bwd_ex(const void* dq, const void* dk, const void* dv
                                   const float* rrms, void* dqkv, float* dscale, int64_t B, int64_t N, int64_t H,
                                   int64_t dh, int64_t rot, const int32_t* pos, int64_t n_dst, int64_t n_off,
                                   dl_stream_t stream);
+/* backward of dl_qk_norm_rope_fwd IN PLACE on token-major gradient rows (nn.py:427-431, 345-353): on entry the q / k thirds of
+ * dqkv [B*N, 3D] hold d(loss)/d(q after norm + RoPE) and d(loss)/d(k ...) in token-major order (dl_attn_bwd_tok writes them
+ * there); on return they hold the gradient of the pre-norm q / k (the v third is untouched).  The scale gradients are summed
+ * WITHOUT atomics: every workgroup stores its [2, D] partial into dscale_partials (f32 scratch, >= 1024 * 2 * D floats) and one
+ * fold adds them to dscale f32 [2, D] in a fixed order (bit-reproducible).  pos: optional RoPE table row per token (NULL: n). */
+DL_API int dl_qk_norm_rope_bwd_inplace(const void* qkv, const float* scale_q, const float* scale_k, const float* cos,
+                                       const float* sin, const float* rrms, void* dqkv, float* dscale, float* dscale_partials,
+                                       int64_t B, int64_t N, int64_t H, int64_t dh, int64_t rot, const int32_t* pos,
+                                       dl_stream_t stream);
 /* F.scaled_dot_product_attention mmdit.py:92-100, no mask: out = softmax(q k^T * scale) v, written as
  * 'b h n d -> b n (h d)'.  lse f32 [B,H,N] = natural-log-sum-exp of the scaled scores (for the backward).
  * dh must be 64; N a multiple of 64 up to 256 (K and V of one head stay resident in LDS), or a multiple of 256 up to 2048
@@ -294,6 +303,12 @@ DL_API int dl_attn_bwd_sv(const void* q, const void* k, const void* v, int64_t v
                           int64_t v_pitch, const void* out, const void* dout, const float* lse, void* dq, void* dk, void* dv,
                           int64_t dv_batch_stride, int64_t dv_head_stride, int64_t dv_pitch, int64_t B, int64_t H, int64_t N,
                           int64_t dh, float scale, dl_stream_t stream);
+/* dl_attn_bwd_sv whose dQ and dK leave in place as well (N <= 256): V is read from the v third of the token-major qkv rows
+ * [B*N, 3D] and ALL THREE gradients are written into the token-major dqkv rows (dq -> columns [0, D), dk -> [D, 2D), dv ->
+ * [2D, 3D)); dl_qk_norm_rope_bwd_inplace then turns the q / k thirds into the gradient of the pre-norm qkv in place -- no
+ * head-major dq / dk buffers, and the QK-norm backward reads whole 2D-wide rows instead of H 128-byte segments per row. */
+DL_API int dl_attn_bwd_tok(const void* q, const void* k, const void* qkv, const void* out, const void* dout, const float* lse,
+                           void* dqkv, int64_t B, int64_t H, int64_t N, int64_t dh, float scale, dl_stream_t stream);
 /* PackedSwiGLU nn.py:484-486: h = silu(u[:, :F]) * u[:, F:] ; u bf16 [M, 2F] */
 DL_API int dl_swiglu_fwd(const void* u, void* h, int64_t M, int64_t F, dl_stream_t stream);
 DL_API int dl_swiglu_bwd(const void* dh, const void* u, void* du, int64_t M, int64_t F, dl_stream_t stream);
@@ -537,6 +552,8 @@ enum {
   DL_BLK_NEXT_X,      /* [M,D] residual stream leaving the block (x1 + gate2 * t2) */
   DL_BLK_NEXT_XM, DL_BLK_NEXT_MEAN, DL_BLK_NEXT_RSTD,
   DL_BLK_TN_SLAB,     /* f32 [tn_slab_floats] scratch of dl_gemm_tn_group, or NULL: the four weight gradients as dl_gemm_tn_ex launches */
+  DL_BLK_QK_PARTIALS, /* f32 [1024 * 2 * D] scratch of dl_qk_norm_rope_bwd_inplace, or NULL; with it (V in place, D <= 512) dQ / dK /
+                       * dV are written token-major into DQKV (dl_attn_bwd_tok) and DQ / DK are not used */
   DL_BLK_NPTR
 };
 typedef struct dl_dit_block_t {

@@ -95,3 +95,76 @@ def write_fake_cifar10(root: str, batches: dict[str, int], seed: int = 12) -> No
              "batch_label": name, "filenames": [f"{i}.png" for i in range(n)]}
         with open(os.path.join(root, name), "wb") as f:
             pickle.dump(d, f, protocol=2)
+
+
+def write_mds(root: str, columns: dict[str, str], samples: list[dict], shard_samples: int = 0, extra_header: dict | None = None) -> None:
+    """TEST INFRASTRUCTURE: writes `samples` as uncompressed MosaicML MDS shards (index.json + shard.NNNNN.mds) -- an independent
+    restatement of the layout streaming.MDSWriter produces (mosaicml-streaming 0.13.0, the reference's pinned version; the package
+    is absent here), used to test diffulab_amd/datasets/mds.py.  columns: name -> encoding ("int", "str", "bytes",
+    "ndarray[:dtype[:shape]]", numpy scalar names); shard_samples > 0 cuts a new shard every that many samples."""
+    import json
+    import os
+
+    nd_codes = {np.dtype(t): i for i, t in enumerate([np.uint8, np.uint16, np.uint32, np.uint64, np.int8, np.int16, np.int32,
+                                                      np.int64, np.float16, np.float32, np.float64])}
+
+    def enc(encoding: str, v) -> bytes:
+        kind, _, rest = encoding.partition(":")
+        if kind == "int":
+            return np.int64(v).tobytes()
+        if kind == "str":
+            return str(v).encode("utf-8")
+        if kind in ("bytes", "png", "jpeg", "pil", "pkl"):  # (opaque payloads: the tests hand in the already encoded bytes)
+            return bytes(v)
+        if kind == "ndarray":
+            a = np.ascontiguousarray(v)
+            dtype_s, _, shape_s = rest.partition(":")
+            parts = []
+            if dtype_s:
+                assert a.dtype == np.dtype(dtype_s), (a.dtype, dtype_s)
+            else:
+                parts.append(bytes([nd_codes[a.dtype]]))
+            if shape_s:
+                assert a.shape == tuple(int(d) for d in shape_s.split(","))
+            else:
+                big = max(a.shape)
+                st = np.uint8 if big <= 1 << 8 else np.uint16 if big <= 1 << 16 else np.uint32 if big <= 1 << 32 else np.uint64
+                parts += [bytes([nd_codes[np.dtype(st)]]), bytes([a.ndim]), (np.array(a.shape, np.int64) - 1).astype(st).tobytes()]
+            return b"".join(parts) + a.tobytes()
+        return np.dtype(kind).type(v).tobytes()  # numpy scalar encodings
+
+    def fixed_size(encoding: str):
+        kind, _, rest = encoding.partition(":")
+        if kind == "int":
+            return 8
+        if kind == "ndarray":
+            dtype_s, _, shape_s = rest.partition(":")
+            return int(np.dtype(dtype_s).itemsize * np.prod([int(d) for d in shape_s.split(",")])) if dtype_s and shape_s else None
+        return None if kind in ("str", "bytes", "json", "pkl", "pil", "jpeg", "png") else np.dtype(kind).itemsize
+
+    os.makedirs(root, exist_ok=True)
+    names = sorted(columns)  # (MDSWriter sorts the column names)
+    encs, sizes = [columns[n] for n in names], [fixed_size(columns[n]) for n in names]
+    per = shard_samples if shard_samples > 0 else max(1, len(samples))
+    shards = []
+    for si, lo in enumerate(range(0, len(samples), per)):
+        chunk = samples[lo : lo + per]
+        blobs = []
+        for smp in chunk:
+            data = [enc(e, smp[n]) for n, e in zip(names, encs)]
+            head = np.array([len(d) for d, sz in zip(data, sizes) if sz is None], dtype="<u4").tobytes()
+            for d, sz in zip(data, sizes):
+                assert sz is None or len(d) == sz
+            blobs.append(head + b"".join(data))
+        info = {"column_encodings": encs, "column_names": names, "column_sizes": sizes, "compression": None, "format": "mds",
+                "hashes": [], "size_limit": 1 << 26, "version": 2, **(extra_header or {})}
+        config = json.dumps(info, sort_keys=True).encode("utf-8")
+        n = np.uint32(len(chunk))
+        offsets = np.cumsum([0] + [len(b) for b in blobs]).astype("<u4") + np.uint32(4 + 4 * (len(chunk) + 1) + len(config))
+        raw = n.tobytes() + offsets.astype("<u4").tobytes() + config + b"".join(blobs)
+        base = f"shard.{si:05d}.mds"
+        with open(os.path.join(root, base), "wb") as f:
+            f.write(raw)
+        shards.append({**info, "raw_data": {"basename": base, "bytes": len(raw), "hashes": {}}, "samples": len(chunk), "zip_data": None})
+    with open(os.path.join(root, "index.json"), "w") as f:
+        json.dump({"shards": shards, "version": 2}, f, sort_keys=True)

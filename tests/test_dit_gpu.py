@@ -205,8 +205,10 @@ def test_dit_s2_against_reference_fixture(golden):
 
 @pytest.mark.timeout(900)
 def test_loss_curve_against_reference(golden):
-    """12 AdamW steps of DiT-S/2 on fixed synthetic data: the loss curve of the HIP path vs the reference's
-    (north_star: 1e-4 rel is an fp32 target; this bf16 path is held to 5e-3 per step)."""
+    """20 AdamW steps of DiT-S/2 on fixed synthetic data: the loss curve of the HIP path vs the REFERENCE's own
+    fp32 curve.  north_star's 1e-4 is an fp32 target (the reference's own bf16-autocast loss differs from its fp32 loss by 1.5e-4
+    at step 0 already); the bf16 regime -- the only one this path has, see Trainer -- measures max 1.5e-3 / mean 4.2e-4 per step
+    (bench.py reports the same figures as config.loss_curve_rel_err) and is held to 2.5e-3 per step and 8e-4 on average."""
     from diffulab_amd import Diffuser
     from diffulab_amd.training import FusedAdamW
 
@@ -229,8 +231,9 @@ def test_loss_curve_against_reference(golden):
         opt.step()
         got.append(loss.item())
     got, ref = np.array(got), g["losses"]
-    print("loss curve rel err per step:", np.abs(got - ref) / ref)
-    assert np.all(np.abs(got - ref) / ref < 5e-3)
+    err = np.abs(got - ref) / ref
+    print("loss curve rel err per step:", err)
+    assert len(ref) == 20 and err.max() < 2.5e-3 and err.mean() < 8e-4, (err.max(), err.mean())
 
 
 def test_cifar_dit_dims_against_oracle():

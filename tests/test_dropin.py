@@ -196,3 +196,86 @@ def test_latent_reader_item_format_and_prefetcher(tmp_path):
     # the prefetcher yields the loader's batches unchanged, in order (on CPU it is a pass-through)
     got = [b["model_inputs"]["y"].tolist() for b in DevicePrefetcher(DataLoader(ds, batch_size=4), device="cpu")]
     assert got == [lab[0:4].tolist(), lab[4:8].tolist(), lab[8:10].tolist()]
+
+
+def test_mds_shards_are_read_like_the_reference_streaming_dataset(tmp_path):
+    """ImageNetLatentREPA reads the reference's own on-disk format -- uncompressed MosaicML MDS shards with the columns
+    vision_latents / label / dst_features written as "ndarray:<dtype>" / "int" (imagenet.py:18-86, vision_towers/common.py:137-151,
+    repa/common.py:96-111).  (a) a shard assembled BY HAND from the format description pins the byte layout independently of any
+    writer code; (b) multi-shard splits written by the oracle-side writer round-trip through the dataset class, extra columns
+    (an undecodable `image`) are skipped; (c) compressed shards / missing columns fail loudly."""
+    import json
+    import struct
+
+    from oracle import synth
+
+    from diffulab_amd.datasets import ImageNetLatentREPA
+    from diffulab_amd.datasets.mds import MDSDataset
+
+    # ---- (a) hand-assembled: 2 samples, columns (sorted) dst_features "ndarray:float16", label "int", vision_latents "ndarray:float32"
+    lat = [np.arange(6, dtype=np.float32).reshape(1, 2, 3), -np.arange(6, dtype=np.float32).reshape(1, 2, 3)]
+    ft = [np.array([[1.5, -2.0]], dtype=np.float16), np.array([[0.25, 8.0]], dtype=np.float16)]
+    lab = [5, 999]
+
+    def sample(i):
+        f = bytes([0, 2]) + bytes([1 - 1, 2 - 1]) + ft[i].tobytes()             # shape type uint8 (code 0), ndim 2, dims - 1, data
+        v = bytes([0, 3]) + bytes([1 - 1, 2 - 1, 3 - 1]) + lat[i].tobytes()
+        head = struct.pack("<II", len(f), len(v))                                  # sizes of the two variable-size columns
+        return head + f + struct.pack("<q", lab[i]) + v
+    blobs = [sample(0), sample(1)]
+    info = {"column_names": ["dst_features", "label", "vision_latents"], "column_encodings": ["ndarray:float16", "int", "ndarray:float32"],
+            "column_sizes": [None, 8, None], "compression": None, "format": "mds", "hashes": [], "size_limit": 1 << 26, "version": 2}
+    config = json.dumps(info).encode()
+    first = 4 + 4 * 3 + len(config)
+    raw = struct.pack("<I", 2) + struct.pack("<III", first, first + len(blobs[0]), first + len(blobs[0]) + len(blobs[1])) + config + b"".join(blobs)
+    d = tmp_path / "hand" / "train"
+    d.mkdir(parents=True)
+    (d / "shard.00000.mds").write_bytes(raw)
+    (d / "index.json").write_text(json.dumps({"version": 2, "shards": [{**info, "samples": 2, "zip_data": None,
+                                                                         "raw_data": {"basename": "shard.00000.mds", "bytes": len(raw), "hashes": {}}}]}))
+    ds = ImageNetLatentREPA(str(tmp_path / "hand"), local=True, batch_size=2, split="train")
+    with pytest.raises(AssertionError):
+        ds[0]
+    ds.set_latent_scale(2.0)
+    assert len(ds) == 2
+    for i in range(2):
+        it = ds[i]
+        assert torch.equal(it["model_inputs"]["x"], torch.from_numpy(lat[i]) * 2.0) and it["model_inputs"]["x"].dtype == torch.float32
+        assert int(it["model_inputs"]["y"]) == lab[i] and it["model_inputs"]["y"].dtype == torch.long
+        assert torch.equal(it["extra"]["dst_features"], torch.from_numpy(ft[i].astype(np.float32)))
+
+    # ---- (b) writer round trip: 3 shards, a 300-wide axis (uint16 shape type), a column this reader cannot decode but never touches
+    rng = np.random.default_rng(3)
+    smp = [{"vision_latents": rng.standard_normal((4, 8, 8)).astype(np.float32), "label": int(rng.integers(0, 1000)),
+            "dst_features": rng.standard_normal((300, 6)).astype(np.float32), "image": b"\x89PNG not decoded"} for _ in range(7)]
+    synth.write_mds(str(tmp_path / "w" / "val"), {"vision_latents": "ndarray:float32", "label": "int", "dst_features": "ndarray:float32",
+                                                   "image": "png"}, smp, shard_samples=3)
+    ds = ImageNetLatentREPA(str(tmp_path / "w"), split="val")
+    ds.set_latent_scale(1.0)
+    assert len(ds) == 7 and len(ds.mds.shards) == 3
+    for i in (0, 2, 3, 6, -1):
+        it, want = ds[i], smp[i]
+        assert np.array_equal(it["model_inputs"]["x"].numpy(), want["vision_latents"]) and int(it["model_inputs"]["y"]) == want["label"]
+        assert np.array_equal(it["extra"]["dst_features"].numpy(), want["dst_features"])
+    with pytest.raises(IndexError):
+        ds[7]
+    with pytest.raises(NotImplementedError, match="png"):
+        MDSDataset(tmp_path / "w", "val")[0]  # every column requested: the image codec is refused, not guessed
+    # fixed-shape / explicit-dtype / scalar encodings of the format
+    synth.write_mds(str(tmp_path / "fx"), {"a": "ndarray:int16:2,2", "b": "ndarray", "c": "float32", "s": "str"},
+                    [{"a": np.array([[1, -2], [3, 4]], np.int16), "b": np.arange(5, dtype=np.uint64), "c": 0.5, "s": "héllo"}])
+    got = MDSDataset(tmp_path / "fx")[0]
+    assert np.array_equal(got["a"], [[1, -2], [3, 4]]) and got["b"].dtype == np.uint64 and got["b"].tolist() == [0, 1, 2, 3, 4]
+    assert float(got["c"]) == 0.5 and got["s"] == "héllo"
+
+    # ---- (c) loud failures
+    synth.write_mds(str(tmp_path / "z" / "train"), {"vision_latents": "ndarray:float32", "label": "int", "dst_features": "ndarray:float32"},
+                    smp[:2], extra_header={"compression": "zstd"})
+    with pytest.raises(NotImplementedError, match="compressed"):
+        ImageNetLatentREPA(str(tmp_path / "z"), split="train")
+    synth.write_mds(str(tmp_path / "m" / "train"), {"label": "int", "dst_features": "ndarray:float32"}, smp[:2])
+    with pytest.raises(ValueError, match="vision_latents"):
+        ImageNetLatentREPA(str(tmp_path / "m"), split="train")
+    synth.write_mds(str(tmp_path / "n" / "train"), {"label": "int", "vision_latents": "ndarray:float32", "image": "png"}, smp[:2])
+    with pytest.raises(NotImplementedError, match="dst_features"):
+        ImageNetLatentREPA(str(tmp_path / "n"), split="train")

@@ -341,6 +341,51 @@ def test_attention_reads_v_and_writes_dv_inside_the_qkv_rows(ops, B, H, N):
     assert bool((got[:, :, :2] == 7.0).all())
 
 
+@pytest.mark.parametrize("B,H,N,gh,gw", [(2, 6, 256, 16, 16), (3, 2, 64, 8, 8), (2, 8, 128, 8, 16)])
+def test_attention_backward_token_major_and_qk_norm_backward_in_place(ops, B, H, N, gh, gw):
+    """dl_attn_bwd_tok + dl_qk_norm_rope_bwd_inplace (round 3): dQ / dK / dV leave the attention backward token-major inside the dqkv
+    rows and the QK-norm + RoPE backward turns the q / k thirds into the pre-norm gradient in place.  The attention part is
+    BIT-IDENTICAL to dl_attn_bwd_sv (only the addressing differs), the norm part equals dl_qk_norm_rope_bwd up to a bf16 ulp; the
+    scale gradient is summed in a fixed order without atomics: equal to the atomic one to f32 rounding, += semantics, and both
+    outputs are identical from run to run."""
+    dh, D, M = 64, H * 64, B * N
+    scale = dh**-0.5
+    qkv = dev_bf(bf(synth.normal(f"ip.qkv{N}", (M, 3 * D))))
+    sq, sk = (1 + synth.normal("ip.sq", (D,), std=0.1)).to(DEV), (1 + synth.normal("ip.sk", (D,), std=0.1)).to(DEV)
+    cos, sin = (t.to(DEV) for t in odit.rope_tables(gh, gw, [32, 32], 10_000.0))
+    q, k = (torch.empty(B, H, N, dh, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    rrms = torch.empty(M, 2, device=DEV)
+    ops.qk_norm_rope_fwd(qkv, sq, sk, cos, sin, q, k, None, rrms, B, N, H, dh, 64)
+    out, lse = torch.empty(B, N, D, device=DEV, dtype=torch.bfloat16), torch.empty(B, H, N, device=DEV)
+    ops.attn_fwd_qkv(q, k, qkv, out, lse, B, H, N, dh, scale)
+    do = dev_bf(bf(synth.normal(f"ip.do{N}", (B, N, D))))
+    # head-major pair
+    dq, dk = (torch.empty(B, H, N, dh, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    dqkv0 = torch.empty(M, 3 * D, device=DEV, dtype=torch.bfloat16)
+    init = synth.normal("ip.ds0", (2, D)).to(DEV)
+    ds0 = init.clone()
+    ops.attn_bwd_qkv(q, k, qkv, out, do, lse, dq, dk, dqkv0, B, H, N, dh, scale)
+    ops.qk_norm_rope_bwd(dq, dk, None, qkv, sq, sk, cos, sin, rrms, dqkv0, ds0, B, N, H, dh, 64)
+    # token-major, in place (twice: bit-reproducible)
+    part = torch.full((1024 * 2 * D,), float("nan"), device=DEV)
+    res = []
+    for _ in range(2):
+        dqkv1 = torch.full((M, 3 * D), 7.0, device=DEV, dtype=torch.bfloat16)
+        ds1 = init.clone()
+        ops.attn_bwd_tok(q, k, qkv, out, do, lse, dqkv1, B, H, N, dh, scale)
+        got = dqkv1.view(B, N, 3, H, dh)
+        assert torch.equal(got[:, :, 0].permute(0, 2, 1, 3), dq) and torch.equal(got[:, :, 1].permute(0, 2, 1, 3), dk)
+        assert ops.qk_norm_rope_bwd_inplace(qkv, sq, sk, cos, sin, rrms, dqkv1, ds1, part, B, N, H, dh, 64)
+        assert torch.equal(dqkv1[:, 2 * D :], dqkv0[:, 2 * D :])  # dV: the same stores of the same kernel
+        # q / k thirds: the same formulas in two separately compiled kernels (fma contraction differs): a bf16 ulp here and there
+        assert rel(dqkv1[:, : 2 * D].float(), dqkv0[:, : 2 * D].float()) < 1e-3
+        assert float((dqkv1[:, : 2 * D].float() - dqkv0[:, : 2 * D].float()).abs().max()) <= 2.0**-7 * float(dqkv0.float().abs().max())
+        assert rel(ds1 - init, ds0 - init) < 1e-4
+        res.append((dqkv1, ds1))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert not ops.qk_norm_rope_bwd_inplace(qkv, sq, sk, cos, sin, rrms, dqkv1, ds1, torch.empty(1024 * 2 * 1024, device=DEV), B, N, 16, 64, 64)
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,valid", [(2, 2, 256, 512, (320, 512)), (2, 3, 512, 512, (300, 77)), (1, 1, 256, 256, (200,))])
 def test_attention_cross_lengths_and_key_mask(ops, B, H, Nq, Nk, valid):
     """general form: Nq queries against Nk keys with a key-padding mask given as an additive bias (0 / -inf): cross-attention
