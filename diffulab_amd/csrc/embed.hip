@@ -124,7 +124,19 @@ __global__ void cond_combine_bwd_k(const float* __restrict__ dact, const float* 
     const float g = dact[i] * dsilu_f(emb[i]);
     demb[i] = g;
     if (demb16) demb16[i] = f2bf(g);
-    if (dtable && idx) unsafeAtomicAdd(&dtable[idx[b] * E + c], g);
+    if (dtable && idx) {
+      // nn.Embedding backward without atomics: the FIRST sample that carries a label owns that table row and adds the
+      // contributions of every sample with the same label in batch order (one writer per row, a fixed order: bit-reproducible)
+      const int64_t lab = idx[b];
+      bool first = true;
+      for (int b2 = 0; b2 < b; ++b2) first = first && idx[b2] != lab;
+      if (first) {
+        float acc = g;
+        for (int b2 = b + 1; b2 < B; ++b2)
+          if (idx[b2] == lab) acc += dact[(int64_t)b2 * E + c] * dsilu_f(emb[(int64_t)b2 * E + c]);
+        dtable[lab * E + c] += acc;
+      }
+    }
   }
 }
 extern "C" int dl_cond_combine_bwd(const float* dact, const float* emb, const int64_t* idx, float* demb, void* demb_bf16,
@@ -254,6 +266,39 @@ __global__ void colsum_k(const T* __restrict__ x, int64_t ld, float* __restrict_
   red[rl][cl] = acc;
   __syncthreads();
   if (rl == 0 && c < C) unsafeAtomicAdd(&out[c], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+// the same sums with ONE writer per column and a fixed order: every row slab stores its partial row in `part` [slabs, C]
+template <typename T>
+__global__ void colsum_part_k(const T* __restrict__ x, int64_t ld, float* __restrict__ part, int64_t R, int C, int rows_per_slab) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_slab;
+  const int64_t r1 = r0 + rows_per_slab < R ? r0 + rows_per_slab : R;
+  float acc = 0.f;
+  if (c < C)
+    for (int64_t r = r0 + rl; r < r1; r += 4) acc += ldf<T>(x + r * ld + c);
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < C) part[(int64_t)blockIdx.y * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+int launch_fold_partials(const float* part, int64_t stride, int splits, int64_t M, int64_t N, int64_t ldp, float* C, int64_t ldc,
+                         int accumulate, hipStream_t stream);  // gemm.hip
+extern "C" int dl_colsum_det(const void* x, int dtype, int64_t ld, float* out, int64_t R, int64_t C, float* scratch,
+                             int64_t scratch_floats, dl_stream_t stream) {
+  DL_CHECK_ARG(x && out && scratch && R > 0 && C > 0 && ld >= C && scratch_floats >= C, "dl_colsum_det: bad args");
+  int slabs = (int)((R + 255) / 256);
+  if (slabs > 512) slabs = 512;
+  if ((int64_t)slabs * C > scratch_floats) slabs = (int)(scratch_floats / C);
+  const int rps = (int)((R + slabs - 1) / slabs);
+  slabs = (int)((R + rps - 1) / rps);
+  dim3 grid(cdiv(C, 64), slabs);
+  if (dtype == DL_F32)
+    hipLaunchKernelGGL(colsum_part_k<float>, grid, 256, 0, (hipStream_t)stream, (const float*)x, ld, scratch, R, (int)C, rps);
+  else
+    hipLaunchKernelGGL(colsum_part_k<bf16_t>, grid, 256, 0, (hipStream_t)stream, (const bf16_t*)x, ld, scratch, R, (int)C, rps);
+  DL_LAUNCH_CHECK();
+  return launch_fold_partials(scratch, C, slabs, 1, C, C, out, C, 1, (hipStream_t)stream);
 }
 extern "C" int dl_colsum(const void* x, int dtype, int64_t ld, float* out, int64_t R, int64_t C, dl_stream_t stream) {
   DL_CHECK_ARG(x && out && R > 0 && C > 0 && ld >= C, "dl_colsum: bad args");

@@ -46,6 +46,9 @@ struct NtEpilogue {
   // persistent big-tile kernel only: start-up skew (in units of ~0.5 us per k-step of a tile) between groups of workgroups,
   // so that the store bursts of their tile epilogues do not hit HBM in lockstep
   int stagger;
+  // 128x128 kernel with a split contraction (blockIdx.y): > 0 = every split stores its partial tile with plain stores at
+  // C + split * part_stride (floats; the caller folds the images in a fixed order: bit-reproducible); 0 = f32 atomics into C
+  int64_t part_stride;
 };
 
 // implicit-GEMM view of a 3x3 / pad 1 convolution over NHWC rows: the A operand "cols[p, (tap, ci)]" is never materialised,
@@ -262,7 +265,10 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restr
         for (int e = 0; e < 8; ++e) v[e] = rr[e] + v[e];
       }
     }
-    if (ksplit > 1) {
+    if (ksplit > 1 && ep.part_stride > 0) {
+      float* cp = (float*)C + (int64_t)blockIdx.y * ep.part_stride + (int64_t)m * ldc + n;
+      for (int e = 0; e < 8 && n + e < N; ++e) cp[e] = v[e];
+    } else if (ksplit > 1) {
       float* cp = (float*)C + (int64_t)m * ldc + n;
       for (int e = 0; e < 8 && n + e < N; ++e) unsafeAtomicAdd(cp + e, v[e]);
     } else if (ep.out_f32) {
@@ -653,7 +659,7 @@ extern "C" int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb
                "dl_gemm_nt: gate needs resid, rows_per_gate>0, aligned rows");
   DL_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31), "dl_gemm_nt: dims too large");
   NtEpilogue ep{bias, act, out_dtype == DL_F32, (bf16_t*)pre_out, (const bf16_t*)resid, ldr, (const bf16_t*)gate,
-                ldg, rows_per_gate > 0 ? rows_per_gate : 1, nullptr, 0, 0};
+                ldg, rows_per_gate > 0 ? rows_per_gate : 1, nullptr, 0, 0, 0, 0};
   {
     const bool plain = !bias && act == DL_ACT_NONE && out_dtype == DL_BF16 && !pre_out && !resid;
     if (!bias || ((uintptr_t)bias & 15) == 0) {
@@ -723,7 +729,9 @@ template <bool CONV>
 __global__ __launch_bounds__(NT_THREADS, 2) void gemm_tn_k(const bf16_t* __restrict__ A, int64_t lda,
                                                              const bf16_t* __restrict__ Bm, int64_t ldb,
                                                              float* __restrict__ C, int64_t ldc, int M, int N, int R,
-                                                             int steps_per_split, ConvGeom cg) {
+                                                             int steps_per_split, ConvGeom cg, int64_t part_stride) {
+  // part_stride > 0: split s stores its partial [M, N] image with plain stores at C + s * part_stride (the caller folds the images
+  // in a fixed order: bit-reproducible; every split owns at least one step); 0: the splits meet in C through f32 atomics
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = (N + BN - 1) / BN;
   const int tiles_m = (M + BM - 1) / BM;
@@ -845,7 +853,10 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_tn_k(const bf16_t* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < M && n < N) unsafeAtomicAdd(&C[(int64_t)m * ldc + n], acc[i][j][r]);
+        if (m < M && n < N) {
+          if (part_stride > 0) C[(int64_t)split * part_stride + (int64_t)m * ldc + n] = acc[i][j][r];
+          else unsafeAtomicAdd(&C[(int64_t)m * ldc + n], acc[i][j][r]);
+        }
       }
     }
 }
@@ -1061,9 +1072,91 @@ extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t 
   const int sps = (nsteps + splits - 1) / splits;
   splits = (nsteps + sps - 1) / sps;
   hipLaunchKernelGGL(gemm_tn_k<false>, ntile * splits, NT_THREADS, 65536, (hipStream_t)stream, (const bf16_t*)A, lda,
-                     (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)R, sps, ConvGeom{});
+                     (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)R, sps, ConvGeom{}, (int64_t)0);
   DL_LAUNCH_CHECK();
   return DL_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------- deterministic small GEMMs
+// The 128x128 kernels split their contraction over workgroups to fill the chip on skinny problems (the head's [16, 384] weight
+// gradient over 65536 tokens, the conditioning path's [256, 384] product over K = 28416); by default the splits meet in f32 atomics,
+// whose order varies from run to run.  The *_det entry points give every split its own partial image in a caller-owned scratch
+// (plain stores) and fold the images in a fixed order -- two runs are bit-identical.
+__global__ __launch_bounds__(256) void fold_partials_k(const float* __restrict__ part, int64_t stride, int splits, int64_t M, int N,
+                                                       int64_t ldp, float* __restrict__ C, int64_t ldc, int accumulate) {
+  const int64_t total = M * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / N;
+    const int n = (int)(i - m * N);
+    const float* p = part + m * ldp + n;
+    float s = p[0];
+    for (int k = 1; k < splits; ++k) s += p[(int64_t)k * stride];
+    float* c = C + m * ldc + n;
+    *c = accumulate ? *c + s : s;
+  }
+}
+int launch_fold_partials(const float* part, int64_t stride, int splits, int64_t M, int64_t N, int64_t ldp, float* C, int64_t ldc,
+                         int accumulate, hipStream_t stream) {
+  int64_t g = (M * N + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(fold_partials_k, (int)g, 256, 0, stream, part, stride, splits, M, (int)N, ldp, C, ldc, accumulate);
+  return hipGetLastError() == hipSuccess ? DL_OK : DL_ERR_LAUNCH;
+}
+
+extern "C" int dl_gemm_tn_det(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
+                              int64_t R, float* scratch, int64_t scratch_floats, dl_stream_t stream) {
+  DL_CHECK_ARG(A && B && C && scratch && M > 0 && N > 0 && R > 0, "dl_gemm_tn_det: null/empty operand");
+  DL_CHECK_ARG(R % BK == 0, "dl_gemm_tn_det: R=%lld must be a multiple of %d", (long long)R, BK);
+  DL_CHECK_ARG(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N && ldc >= N,
+               "dl_gemm_tn_det: M,N,lda,ldb must be multiples of 8 (M=%lld N=%lld)", (long long)M, (long long)N);
+  DL_CHECK_ARG((((uintptr_t)A | (uintptr_t)B) & 15) == 0, "dl_gemm_tn_det: 16-byte alignment");
+  DL_CHECK_ARG(scratch_floats >= M * N, "dl_gemm_tn_det: scratch of %lld floats < one [M, N] image", (long long)scratch_floats);
+  if (M % 384 == 0 && N % 192 == 0 && R % 32 == 0 && R / 32 >= 64) {  // the 384 x 192 ring kernel's own atomics-free form
+    const dl_wgrad_t one{A, lda, B, ldb, C, M, N};
+    if (ldc == N) return dl_gemm_tn_group(&one, 1, R, scratch, scratch_floats, 0, stream);
+  }
+  const int ntile = cdiv(M, BM) * cdiv(N, BN);
+  const int nsteps = (int)(R / BK);
+  int splits = (1024 + ntile - 1) / ntile;  // aim at >= 4 workgroups per CU
+  if (splits > nsteps) splits = nsteps;
+  if ((int64_t)splits * M * N > scratch_floats) splits = (int)(scratch_floats / (M * N));
+  if (splits < 1) splits = 1;
+  const int sps = (nsteps + splits - 1) / splits;
+  splits = (nsteps + sps - 1) / sps;  // every split owns at least one step
+  hipLaunchKernelGGL(gemm_tn_k<false>, ntile * splits, NT_THREADS, 65536, (hipStream_t)stream, (const bf16_t*)A, lda,
+                     (const bf16_t*)B, ldb, scratch, N, (int)M, (int)N, (int)R, sps, ConvGeom{}, (int64_t)(M * N));
+  DL_LAUNCH_CHECK();
+  return launch_fold_partials(scratch, M * N, splits, M, N, N, C, ldc, 1, (hipStream_t)stream);
+}
+
+extern "C" int dl_gemm_nt_f32_det(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
+                                  int64_t K, float* scratch, int64_t scratch_floats, dl_stream_t stream) {
+  DL_CHECK_ARG(A && B && C && scratch && M > 0 && N > 0 && K > 0, "dl_gemm_nt_f32_det: null/empty operand");
+  DL_CHECK_ARG(K % BK == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && ldc >= N,
+               "dl_gemm_nt_f32_det: K %% 64, leading dims (lda=%lld ldb=%lld ldc=%lld)", (long long)lda, (long long)ldb, (long long)ldc);
+  DL_CHECK_ARG((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && M < (1ll << 31) && N < (1ll << 31), "dl_gemm_nt_f32_det: alignment / dims");
+  const int nwg = cdiv(M, BM) * cdiv(N, BN);
+  int ksplit = 1;
+  if (nwg < 64 && K >= 2048) {
+    ksplit = 256 / nwg;
+    if (ksplit > K / 512) ksplit = (int)(K / 512);
+    if ((int64_t)ksplit * M * N > scratch_floats) ksplit = (int)(scratch_floats / (M * N));
+    if (ksplit < 1) ksplit = 1;
+  }
+  NtEpilogue ep{};
+  ep.out_f32 = 1;
+  ep.rows_per_gate = 1;
+  if (ksplit == 1) {
+    hipLaunchKernelGGL(gemm_nt_k<false>, dim3(nwg, 1), NT_THREADS, NT_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)A, lda,
+                       (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep, 1, ConvGeom{});
+    DL_LAUNCH_CHECK();
+    return DL_OK;
+  }
+  ep.part_stride = M * N;
+  hipLaunchKernelGGL(gemm_nt_k<false>, dim3(nwg, ksplit), NT_THREADS, NT_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)A, lda,
+                     (const bf16_t*)B, ldb, scratch, N, (int)M, (int)N, (int)K, ep, ksplit, ConvGeom{});
+  DL_LAUNCH_CHECK();
+  return launch_fold_partials(scratch, M * N, ksplit, M, N, N, C, ldc, 0, (hipStream_t)stream);
 }
 
 // ----------------------------------------------------------------------------------------------------- implicit-GEMM 3x3 conv
@@ -1172,7 +1265,7 @@ extern "C" int dl_conv3x3_wgrad_tn(const void* x, int64_t ldx, int64_t Bn, int64
   const int sps = (nsteps + splits - 1) / splits;
   splits = (nsteps + sps - 1) / sps;
   hipLaunchKernelGGL(gemm_tn_k<true>, ntile * splits, NT_THREADS, 65536, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                     (const bf16_t*)dY, ldy, g, ldg, (int)M, (int)N, (int)R, sps, cg);
+                     (const bf16_t*)dY, ldy, g, ldg, (int)M, (int)N, (int)R, sps, cg, (int64_t)0);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

@@ -364,6 +364,10 @@ class DiTEngine:
             # launch): 8 token ranges x (4 + 3 mlp_ratio) D^2 floats; one set, the side stream runs the blocks one after the other
             if self._grouped_wgrad(M):
                 w["tn_slab"] = torch.empty(8 * (4 + 3 * d.mlp_ratio) * D * D, device=dev, dtype=f32)
+            # scratch of the bit-reproducible small GEMMs / column sums of the head and the conditioning path (partial images per
+            # split, folded in a fixed order: ops.gemm_tn / gemm_nt / colsum with scratch=): two images of the stacked adaLN
+            # weight gradient is the largest user
+            w["det_scr"] = torch.empty(max(2 * self.layout.mod_rows * E, 1 << 22), device=dev, dtype=f32)
             w["scr_last"] = z(_rup(Fo, 8), D, dtype=f32)
             w["scr_conv"] = z(D, self._ki, dtype=f32)
         self.ws, self._ws_key = w, key
@@ -653,13 +657,14 @@ class DiTEngine:
         # head: last linear + final adaLN
         ops.patchify(dpred, w["dO"], d.patch_size, ops.PATCH_PPC)
         gl = self.G("last_layer.linear.weight")
+        det = w.get("det_scr")
         if Fo == Fo8:
-            ops.gemm_tn(w["dO"], w["xf"], gl, M=Fo, N=D)
+            ops.gemm_tn(w["dO"], w["xf"], gl, M=Fo, N=D, scratch=det)
         else:
             w["scr_last"].zero_()
-            ops.gemm_tn(w["dO"], w["xf"], w["scr_last"], M=Fo8, N=D)
+            ops.gemm_tn(w["dO"], w["xf"], w["scr_last"], M=Fo8, N=D, scratch=det)
             ops.reduce_rows_f32(w["scr_last"], gl, 1, Fo * D)
-        ops.colsum(w["dO"], self.G("last_layer.linear.bias"), M, Fo)
+        ops.colsum(w["dO"], self.G("last_layer.linear.bias"), M, Fo, scratch=det)
         fused = self._row_gemms(M, N)
         if not fused:
             ops.gemm_nt(w["dO"], sh["last_layer.linear.weight|t"], w["dxm"], M=M, N=D, K=self._ko)
@@ -859,14 +864,15 @@ class DiTEngine:
         B, _, _, _, _, _, M, _, _ = self.geo
         D, E = d.inner_dim, d.embedding_dim
         dmod = w["dmod32"]
+        det = w.get("det_scr")  # scratch of the bit-reproducible small GEMMs / column sums (None: the atomic forms)
         # stem: conv_proj weight gradient (no gradient flows to the input latents)
         Fi = d.input_channels * d.patch_size**2
         gc = self.G(self._conv_name).view(D, Fi)
         if Fi % 8 == 0:
-            ops.gemm_tn(dx, w["tokP"], gc, M=D, N=Fi)
+            ops.gemm_tn(dx, w["tokP"], gc, M=D, N=Fi, scratch=det)
         else:
             w["scr_conv"].zero_()
-            ops.gemm_tn(dx, w["tokP"], w["scr_conv"], M=D, N=_rup(Fi, 8))
+            ops.gemm_tn(dx, w["tokP"], w["scr_conv"], M=D, N=_rup(Fi, 8), scratch=det)
             gc.add_(w["scr_conv"][:, :Fi])  # ragged edge (e.g. RGB p=2 -> 12 features): torch slice-add, not on the hot path
 
         # conditioning path: every adaLN linear at once, then the time MLP and the label table
@@ -877,26 +883,26 @@ class DiTEngine:
         if L6:  # the blocks' rows were cast, multiplied and handed to the reducer as the blocks finished (backward: block_done)
             ops.cast2d_f32_to_bf16(dmod[:B, L6:], w["dmod"][:B, L6:])
             dmod = w["dmod"]
-            ops.gemm_tn(dmod[:, L6:], w["se"], g_modw[L6:])
-            ops.colsum(dmod[:, L6:], g_modb[L6:], B, R - L6)
+            ops.gemm_tn(dmod[:, L6:], w["se"], g_modw[L6:], scratch=det)
+            ops.colsum(dmod[:, L6:], g_modb[L6:], B, R - L6, scratch=det)
         else:
             ops.cast_f32_to_bf16(dmod[:B], w["dmod"][:B])
             dmod = w["dmod"]
-            ops.gemm_tn(dmod, w["se"], g_modw)
-            ops.colsum(dmod, g_modb, B, R)
-        ops.gemm_nt(dmod, sh["@mod|t"], w["dse"], M=B, N=E, K=R)
+            ops.gemm_tn(dmod, w["se"], g_modw, scratch=det)
+            ops.colsum(dmod, g_modb, B, R, scratch=det)
+        ops.gemm_nt(dmod, sh["@mod|t"], w["dse"], M=B, N=E, K=R, scratch=det)
         table = d.n_classes is not None
         ops.cond_combine_bwd(w["dse"][:B], w["emb"][:B], self._yeff if table else None, w["demb"][:B], w["demb16"][:B],
                              self.G("label_embed.embedding.weight") if table else None)
         if extra_demb is not None:
             w["demb"][:B].add_(extra_demb[:B])
             ops.cast_f32_to_bf16(w["demb"][:B], w["demb16"][:B])
-        ops.colsum(w["demb"], self.G("time_embed.2.bias"), B, E)
-        ops.gemm_tn(w["demb16"], w["h1"], self.G("time_embed.2.weight"))
+        ops.colsum(w["demb"], self.G("time_embed.2.bias"), B, E, scratch=det)
+        ops.gemm_tn(w["demb16"], w["h1"], self.G("time_embed.2.weight"), scratch=det)
         ops.gemm_nt(w["demb16"], sh["time_embed.2.weight|t"], w["dh1"], M=B, N=E, K=E)
         ops.silu_bwd(w["dh1"][:B], w["pre1"][:B], w["dpre1"][:B])
-        ops.gemm_tn(w["dpre1"], w["temb"], self.G("time_embed.0.weight"))
-        ops.colsum(w["dpre1"], self.G("time_embed.0.bias"), B, E)
+        ops.gemm_tn(w["dpre1"], w["temb"], self.G("time_embed.0.weight"), scratch=det)
+        ops.colsum(w["dpre1"], self.G("time_embed.0.bias"), B, E, scratch=det)
         if self.reducer is not None:
             if L6:
                 w_mod = self.layout.entries[self.mod_name][0]

@@ -136,11 +136,19 @@ def ddim_step(pred, pred_uncond, guidance, xt, noise, t, tables, coefs, mean_typ
 # ------------------------------------------------------------------ GEMMs
 def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias: Tensor | None = None, act: int = ACT_NONE,
             pre_out: Tensor | None = None, resid: Tensor | None = None, gate: Tensor | None = None,
-            rows_per_gate: int = 1, M: int | None = None, N: int | None = None, K: int | None = None) -> Tensor:
-    """out[M,N] = epilogue(a[M,K] @ b[N,K]^T); a/b bf16 2-D (row stride = .stride(0)); out bf16 or f32."""
+            rows_per_gate: int = 1, M: int | None = None, N: int | None = None, K: int | None = None,
+            scratch: Tensor | None = None) -> Tensor:
+    """out[M,N] = epilogue(a[M,K] @ b[N,K]^T); a/b bf16 2-D (row stride = .stride(0)); out bf16 or f32.
+    scratch (f32, plain f32 output only): the bit-reproducible form -- a split contraction keeps its partial images there and
+    folds them in a fixed order instead of meeting in f32 atomics (dl_gemm_nt_f32_det)."""
     M = a.shape[0] if M is None else M
     N = b.shape[0] if N is None else N
     K = a.shape[1] if K is None else K
+    if scratch is not None:
+        assert out.dtype == torch.float32 and bias is None and act == ACT_NONE and pre_out is None and resid is None
+        _call("dl_gemm_nt_f32_det", _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, _p(scratch), scratch.numel(),
+              _s())
+        return out
     _call("dl_gemm_nt", _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, _p(bias), act,
           F32 if out.dtype == torch.float32 else BF16, _p(pre_out), _p(resid), resid.stride(0) if resid is not None else 0,
           _p(gate), gate.stride(0) if gate is not None else 0, rows_per_gate, _s())
@@ -203,14 +211,20 @@ def _padded_rows(t: Tensor) -> Tensor:
     return t
 
 
-def gemm_tn(a: Tensor, b: Tensor, out: Tensor, *, M: int | None = None, N: int | None = None, max_wgs: int = 0) -> Tensor:
+def gemm_tn(a: Tensor, b: Tensor, out: Tensor, *, M: int | None = None, N: int | None = None, max_wgs: int = 0,
+            scratch: Tensor | None = None) -> Tensor:
     """out[M,N] (f32) += a[R,M]^T @ b[R,N].  max_wgs > 0 caps the persistent workgroups (side-stream wgrads).  R must be a
-    multiple of 64: operands that are leading slices of zero-padded row buffers are widened to their parents."""
+    multiple of 64: operands that are leading slices of zero-padded row buffers are widened to their parents.
+    scratch (f32, >= M*N): the bit-reproducible form (dl_gemm_tn_det: partial images per split + fixed-order fold, no atomics)."""
     M = a.shape[1] if M is None else M
     N = b.shape[1] if N is None else N
     if a.shape[0] % 64:
         a, b = _padded_rows(a), _padded_rows(b)
         assert a.shape[0] == b.shape[0], "gemm_tn operands with a ragged row count must be zero-padded row buffers"
+    if scratch is not None:
+        _call("dl_gemm_tn_det", _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, a.shape[0], _p(scratch),
+              scratch.numel(), _s())
+        return out
     _call("dl_gemm_tn_ex", _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, a.shape[0], int(max_wgs), _s())
     return out
 
@@ -514,9 +528,14 @@ def heads_merge_rope_bwd(dst_grad, src_grad, B, H, n_src, n_off, cos=None, sin=N
           _p(cos), _p(sin), rot, int(accumulate), _s())
 
 
-def colsum(x, out, R=None, C=None):
+def colsum(x, out, R=None, C=None, scratch=None):
+    """out[c] += sum_r x[r, c]; scratch (f32): the bit-reproducible form (row-slab partials + fixed-order fold, dl_colsum_det)"""
     R = x.shape[0] if R is None else R
     C = x.shape[1] if C is None else C
+    if scratch is not None:
+        _call("dl_colsum_det", _p(x), F32 if x.dtype == torch.float32 else BF16, x.stride(0), _p(out), R, C, _p(scratch), scratch.numel(),
+              _s())
+        return
     _call("dl_colsum", _p(x), F32 if x.dtype == torch.float32 else BF16, x.stride(0), _p(out), R, C, _s())
 
 

@@ -153,6 +153,19 @@ typedef struct dl_wgrad_t {
 } dl_wgrad_t;
 DL_API int dl_gemm_tn_group(const dl_wgrad_t* probs, int n_probs, int64_t R, float* slab, int64_t slab_floats, int max_workgroups,
                             dl_stream_t stream);
+/* Bit-reproducible forms of the small, skinny GEMMs and column sums whose default kernels split their contraction over
+ * workgroups and meet in f32 atomics (the head's and the patch embedding's weight gradients over all tokens, the conditioning
+ * path's products, bias gradients): every split stores its partial image into the caller-owned f32 `scratch` and one fold adds
+ * the images in a fixed order.  The number of splits is min(what fills the chip, scratch_floats / (M N)), at least 1.
+ *   dl_gemm_tn_det      C[M,N] (f32) += A[R,M]^T B[R,N]          (same operand rules as dl_gemm_tn)
+ *   dl_gemm_nt_f32_det  C[M,N] (f32)  = A[M,K] B[N,K]^T          (the plain f32-output form of dl_gemm_nt)
+ *   dl_colsum_det       out[C] (f32) += sum_r x[r, :]            (dtype DL_BF16 / DL_F32 like dl_colsum) */
+DL_API int dl_gemm_tn_det(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
+                          int64_t R, float* scratch, int64_t scratch_floats, dl_stream_t stream);
+DL_API int dl_gemm_nt_f32_det(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
+                              int64_t K, float* scratch, int64_t scratch_floats, dl_stream_t stream);
+DL_API int dl_colsum_det(const void* x, int dtype, int64_t ld, float* out, int64_t R, int64_t C, float* scratch,
+                         int64_t scratch_floats, dl_stream_t stream);
 
 /* ------------------------------------------------------------------ adaLN / norms */
 /* modulate(LayerNorm(x)) mmdit.py:299,305,547 + nn.py:539:  out = (LN(x) * w + b) * (1 + scale) + shift.

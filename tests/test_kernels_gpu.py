@@ -669,3 +669,60 @@ def test_fused_swiglu_gemms(ops):
     # small shapes have no fused kernel: the wrappers say so instead of computing something else
     xs = torch.zeros(256, D, device=DEV, dtype=torch.bfloat16)
     assert not ops.gemm_nt_swiglu(xs, w1p, u[:256], h[:256])
+
+
+def test_small_gemms_and_column_sums_have_bit_reproducible_forms(ops):
+    """dl_gemm_tn_det / dl_gemm_nt_f32_det / dl_colsum_det (round 3): the skinny problems of the head and the conditioning path
+    split their contraction over workgroups; with a scratch every split keeps its partial image and a fold adds them in a fixed
+    order -- same values as the atomic forms (f32 rounding), += / = semantics kept, and two runs are bit-identical."""
+    scr = torch.full((1 << 22,), float("nan"), device=DEV)
+    for R, M, N in [(65536, 16, 384), (65536, 384, 16), (256, 384, 384), (8192, 1152, 384), (4096, 136, 264)]:  # incl. the group path
+        a, b = synth.normal(f"det.a{R}{M}", (R, M)), synth.normal(f"det.b{R}{N}", (R, N))
+        init = synth.normal(f"det.c{M}{N}", (M, N))
+        ref = init + bf(a).t() @ bf(b)
+        outs = []
+        for _ in range(2):
+            c = init.to(DEV).clone()
+            ops.gemm_tn(dev_bf(a), dev_bf(b), c, scratch=scr)
+            outs.append(c)
+        assert rel(outs[0], ref) < 2e-5 and torch.equal(outs[0], outs[1]), (R, M, N)
+    # a scratch with room for two partial images only: fewer splits, same result
+    a, b = synth.normal("det.a6553616", (65536, 16)), synth.normal("det.b65536384", (65536, 384))
+    c = torch.zeros(16, 384, device=DEV)
+    ops.gemm_tn(dev_bf(a), dev_bf(b), c, scratch=scr[: 2 * 16 * 384])
+    assert rel(c, bf(a).t() @ bf(b)) < 2e-5
+    for M, N, K in [(256, 384, 28416), (64, 136, 4096), (256, 384, 384)]:  # split-K, split-K ragged, no split
+        a, b = synth.normal(f"dnt.a{M}{K}", (M, K)), synth.normal(f"dnt.b{N}{K}", (N, K), std=K**-0.5)
+        outs = []
+        for _ in range(2):
+            c = torch.full((M, N), float("nan"), device=DEV)  # '=' semantics: the previous content is irrelevant
+            ops.gemm_nt(dev_bf(a), dev_bf(b), c, scratch=scr)
+            outs.append(c)
+        assert rel(outs[0], bf(a) @ bf(b).t()) < 2e-5 and torch.equal(outs[0], outs[1]), (M, N, K)
+    for R, C, dt in [(65536, 16, torch.bfloat16), (256, 28416, torch.bfloat16), (300, 384, torch.float32)]:
+        x = synth.normal(f"dcs.{R}{C}", (R, C)).to(dt)
+        init = synth.normal(f"dcs.o{C}", (C,))
+        outs = []
+        for _ in range(2):
+            o = init.to(DEV).clone()
+            ops.colsum(x.to(DEV), o, scratch=scr)
+            outs.append(o)
+        assert rel(outs[0], init + x.float().sum(0)) < 1e-5 and torch.equal(outs[0], outs[1]), (R, C)
+
+
+def test_label_table_gradient_without_atomics(ops):
+    """dl_cond_combine_bwd: nn.Embedding's backward (repeated labels add up) with one writer per table row and a fixed order:
+    equal to index_add_ and identical from run to run"""
+    B, E, n_cls = 64, 384, 10
+    dact, emb = synth.normal("lt.dact", (B, E)).to(DEV), synth.normal("lt.emb", (B, E)).to(DEV)
+    idx = synth.integers("lt.idx", (B,), n_cls).to(DEV)  # 64 samples over 10 classes: every row is hit several times
+    g = dact * (torch.sigmoid(emb) * (1 + emb * (1 - torch.sigmoid(emb))))
+    outs = []
+    for _ in range(2):
+        table = torch.ones(n_cls + 1, E, device=DEV)
+        demb, demb16 = torch.empty(B, E, device=DEV), torch.empty(B, E, device=DEV, dtype=torch.bfloat16)
+        ops.cond_combine_bwd(dact, emb, idx, demb, demb16, table)
+        outs.append(table)
+        assert rel(demb, g) < 1e-5
+    ref = torch.ones(n_cls + 1, E, device=DEV).index_add_(0, idx, g)
+    assert rel(outs[0], ref) < 1e-5 and torch.equal(outs[0], outs[1]) and torch.equal(outs[0][n_cls], torch.ones(E, device=DEV))
