@@ -165,6 +165,7 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
 
     rec: list[tuple[str, torch.cuda.Event, torch.cuda.Event, float]] = []
     tn_shapes: dict[tuple[str, int, int, int], int] = {}  # weight-gradient launches of the replay: (kernel, R, M, N) -> count
+    last_group: list = []  # [probs, slab] of the last grouped weight-gradient launch
     orig = {n: getattr(ops, n) for n in ("gemm_nt", "gemm_nt_swiglu", "gemm_tn", "attn_fwd_qkv", "attn_bwd_qkv", "attn_fwd", "attn_bwd",
                                          "mlp_dswiglu_recompute", "ln_modulate_gemm_fwd", "ln_modulate_gemm_bwd",
                                          "gemm_nt_qk_norm_rope", "gemm_tn_group")}
@@ -189,6 +190,7 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
                 name, fl = "gemm_tn_group_k", sum(2.0 * dy.shape[0] * g.shape[0] * g.shape[1] for dy, _, g in a)
                 tn_shapes[(name, a[0][0].shape[0], tuple((g.shape[0], g.shape[1]) for _, _, g in a), 0)] = \
                     tn_shapes.get((name, a[0][0].shape[0], tuple((g.shape[0], g.shape[1]) for _, _, g in a), 0), 0) + 1
+                last_group[:] = [list(a), b]  # the operands of this launch stay valid in the workspace: re-timed alone below
             elif kind == "mlp_dswiglu_recompute":  # (x, wp, dt, w2t, du): u tile recomputed (2 M 2F K) + dh tile (2 M F K)
                 name, fl = "mlp_dswiglu_rc_k", 6.0 * a.shape[0] * rest[1].shape[0] * a.shape[1]
             elif kind.startswith("attn_"):  # (q, k, ..., B, H, N, dh, scale): 4 N^2 dh per head forward, 10 N^2 dh backward
@@ -296,14 +298,15 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
     # critical path: the step time is the main chain's).  `achieved` above is that in-step figure; the same launches alone on the
     # whole chip (same shapes and counts, uncapped, nothing else resident) are reported next to it.
     alone = None
-    if dom == "gemm_tn_group_k" and tn_shapes:
+    if dom == "gemm_tn_group_k" and tn_shapes and last_group:
+        # the operands of the step itself (a block's activations and their gradients, still in the workspace): the chip's clock --
+        # and with it the rate -- depends on the data (random normal operands toggle more bits and run ~25 % slower)
         t_ms, t_fl = 0.0, 0.0
         for (name, R, shapes, _), cnt in tn_shapes.items():
             if name != dom:
                 continue
-            probs = [(torch.randn(R, M, device="cuda").to(torch.bfloat16), torch.randn(R, N, device="cuda").to(torch.bfloat16),
-                      torch.zeros(M, N, device="cuda")) for M, N in shapes]
-            slab = torch.empty(8 * sum(M * N for M, N in shapes), device="cuda")
+            probs = [(dy, x, torch.zeros_like(g)) for dy, x, g in last_group[0]]
+            slab = last_group[1]
             for _ in range(3):
                 ops.gemm_tn_group(probs, slab)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -318,7 +321,7 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
         if t_ms > 0:
             alone = {"achieved": round(t_fl / (t_ms * 1e-3) / 1e12, 1), "frac": round(t_fl / (t_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                      "avg_launch_us": round(t_ms * 1e3 / sum(c for (n, *_), c in tn_shapes.items() if n == dom), 2),
-                     "note": "same launches (+ fold) alone on the whole chip, random operands"}
+                     "note": "the same launch (+ its fold) alone on the whole chip, on the step's own operands"}
     elif dom.startswith("gemm_tn") and tn_shapes:
         t_ms, t_fl = 0.0, 0.0
         for (name, R, M, N), cnt in tn_shapes.items():
@@ -343,7 +346,8 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
                      "avg_launch_us": round(t_ms * 1e3 / sum(c for (n, *_), c in tn_shapes.items() if n == dom), 2),
                      "note": "same launches alone on the whole chip; in the step they share it with the main chain on a side stream"}
     step_ach = images_per_s_per_gpu * train_flops_per_image() / 1e12
-    return {"bound": "mfma", "kernel": dom + " (largest summed launch time of the step; rocprof ranks it first)",
+    label = dom + (" (+ tn_group_fold_k: one C call)" if dom == "gemm_tn_group_k" else "")
+    return {"bound": "mfma", "kernel": label + " (largest summed launch time of the step's instrumented launches)",
             "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
             "traffic": traffic, "traffic_unit": f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{tsrc})",
             "flops_per_launch": round(fl / n_l), "launches_per_step": n_l // reps, "avg_launch_us": round(ms * 1e3 / n_l, 2),

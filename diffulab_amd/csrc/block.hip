@@ -17,6 +17,7 @@
 
 static thread_local hipEvent_t g_blk_event = nullptr;
 static int fork_to_side(hipStream_t main, hipStream_t side) {
+  if (main == side) return 0;
   if (!g_blk_event && hipEventCreateWithFlags(&g_blk_event, hipEventDisableTiming) != hipSuccess) return -1;
   if (hipEventRecord(g_blk_event, main) != hipSuccess) return -1;
   return hipStreamWaitEvent(side, g_blk_event, 0) == hipSuccess ? 0 : -1;
@@ -92,8 +93,8 @@ extern "C" int dl_dit_block_fwd(const dl_dit_block_t* b, int train, dl_stream_t 
 }
 
 extern "C" int dl_dit_block_bwd(const dl_dit_block_t* b, dl_stream_t main_, dl_stream_t side_, int side_wgs) {
-  DL_CHECK_ARG(b && side_, "dl_dit_block_bwd: null block / side stream");
-  hipStream_t main = (hipStream_t)main_, side = (hipStream_t)side_;
+  DL_CHECK_ARG(b, "dl_dit_block_bwd: null block");
+  hipStream_t main = (hipStream_t)main_, side = (hipStream_t)side_;  // (side == main: everything inline on one stream)
   const int64_t B = b->B, N = b->N, D = b->D, H = b->H, F = b->F, M = B * N, dh = D / H;
   const float sm = 0.125f;
   // With a slab the four weight gradients of the block are ONE atomics-free launch (dl_gemm_tn_group) behind the last of their

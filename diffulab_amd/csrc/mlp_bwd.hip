@@ -270,12 +270,17 @@ extern "C" int dl_mlp_dswiglu_recompute(const void* X, int64_t ldx, const void* 
   grid &= ~7;
   // column groups per launch (see the kernel): the widest split that keeps whole column tiles and whole row panels per XCD
   const int panels = (int)(M / RC_TBM), tiles_n = (int)(F / TU);
-  // column groups per XCD (see the kernel).  Measured at the headline shape (M = 65536, F = 1536): csplit 1 / 2 / 4 = 321 / 326 /
-  // 336 us alone and 21.65 / 21.58 / 21.73 ms per step -- halving or quartering the weights an XCD re-reads (the over-fetch the PMC
-  // pass counts) buys nothing: the kernel waits for the ISSUE of its operand stream, not for L2 misses.  One group.
-  const int csplit = 1;
+  // column groups per XCD (see the kernel).  Measured at the headline shape (M = 65536, F = 1536; PMC FETCH_SIZE per launch against
+  // 128 MB of operands): csplit 1 / 2 / 4 = 610 / 389 / 526 MB fetched, 321 / 326 / 336 us alone, 21.65 / 21.58 / 21.73 ms per step.
+  // Two groups fetch the least; the launch time does not follow the fetch (the kernel waits for the ISSUE of its operand stream,
+  // not for L2 misses), so this only takes traffic off the fabric that the side-stream weight gradients share.
+  int csplit = 1;
+  for (int c = 2; c >= 1; c >>= 1)
+    if (tiles_n % c == 0) {
+      csplit = c;
+      break;
+    }
   (void)panels;
-  (void)tiles_n;
   hipLaunchKernelGGL(mlp_dswiglu_rc_k<TU>, grid, RC_THREADS, 2 * (RC_TBM + 2 * TU) * 128, (hipStream_t)stream, (const bf16_t*)X, ldx,
                      (const bf16_t*)Wp, ldwp, (const bf16_t*)dT, ldt, (const bf16_t*)W2t, ldw2, (bf16_t*)dU, lddu, (int)M, (int)F, (int)K1,
                      (int)K2, csplit);

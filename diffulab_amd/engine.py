@@ -765,12 +765,13 @@ class DiTEngine:
                 self.reducer.ready(w_mod + i * 6 * D * E, w_mod + (i + 1) * 6 * D * E, flush=i < 3)
 
         native = self._native_blocks() and not serial and dx is w["dxa"]
+        inline_wgrad = os.environ.get("DL_WGRAD_INLINE", "0") == "1"  # TUNING: the grouped weight gradients on the main stream
         defer_fold = fused and self.reducer is None  # LayerNorm-affine partials of every block: one batched fold after the loop
         for i in reversed(range(L)):
             if native:
                 blk = self._block_args(i, True)
                 blk.set(dfeat=dfeats.get(i - 1))
-                ops.dit_block_bwd(blk, main.cuda_stream, side.cuda_stream, side_wgs)
+                ops.dit_block_bwd(blk, main.cuda_stream, main.cuda_stream if inline_wgrad else side.cuda_stream, side_wgs)
                 block_done(i)
                 continue
             a = w["layers"][i]

@@ -590,7 +590,8 @@ typedef struct dl_dit_block_t {
  * (x1 + gate2 * t2) is NOT applied: it is the next block's (or the final LayerNorm's) pending triple. */
 DL_API int dl_dit_block_fwd(const dl_dit_block_t* blk, int train, dl_stream_t stream);
 /* backward of one block on `main`; the weight-gradient GEMMs and LayerNorm-affine folds are issued on `side` behind events
- * (join `side` before the gradients are consumed); side_workgroups caps the persistent wgrad workgroups (0 = one per CU) */
+ * (join `side` before the gradients are consumed; side_stream == main_stream issues everything inline on one stream);
+ * side_workgroups caps the persistent wgrad workgroups (0 = one per CU) */
 DL_API int dl_dit_block_bwd(const dl_dit_block_t* blk, dl_stream_t main_stream, dl_stream_t side_stream, int side_workgroups);
 
 #ifdef __cplusplus
