@@ -225,6 +225,8 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
         "qk_norm_rope_bwd": lambda dq, dk, dv, qkv, sq, sk, cos, sin, rrms, dqkv, *a, **kw: nbytes(dq, dk, dv)
         + nbytes(qkv, dqkv) * (1.0 if dv is not None else 2 / 3),
     }
+    # (round 3: the in-place QK-norm backward reads the q, k thirds of qkv and of dqkv and writes the latter back)
+    row_bytes["qk_norm_rope_bwd_inplace"] = lambda qkv, sq, sk, cos, sin, rrms, dqkv, *a, **kw: nbytes(qkv) * 2 / 3 + nbytes(dqkv) * 4 / 3
     orig_rows = {n: getattr(ops, n) for n in row_bytes}
 
     def timed_row(kind: str):

@@ -210,6 +210,8 @@ class JointEngine(DiTEngine):
             w["dse"], w["demb"], w["demb16"] = z(Bp, E, dtype=f32), z(Bp, E, dtype=f32), z(Bp, E)
             w["dh1"], w["dpre1"] = z(Bp, E, dtype=f32), z(Bp, E)
             w["scr_last"], w["scr_conv"] = z(_rup(Fo, 8), D, dtype=f32), z(D, self._ki, dtype=f32)
+            if D % 384 == 0 and F % 192 == 0 and os.environ.get("DL_WGRAD_GROUP", "1") != "0":  # (D = 768: the joint configurations)
+                w["tn_slab"] = torch.empty(ops.WgradGroups.slab_floats(D, F), device=self.dev, dtype=f32)
         self.ws, self._ws_key = w, key
         self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)
         self.jgeo = (Lc, T, Tp)
@@ -344,11 +346,21 @@ class JointEngine(DiTEngine):
         side.wait_stream(main)
         side_wgs = int(os.environ.get("DL_SIDE_WGS", "128"))
 
-        def wgrad(x_grad: Tensor, x_in: Tensor, gname: str) -> None:
+        def on_side(fn) -> None:
             ev = main.record_event()
             with torch.cuda.stream(side):
                 side.wait_event(ev)
-                ops.gemm_tn(x_grad, x_in, self.G(gname), max_wgs=side_wgs)
+                fn()
+
+        # the four linears of a stream as ONE atomics-free launch once its last operand (dqkv) exists (ops.WgradGroups); widths the
+        # 384 x 192 tile does not divide keep one atomic launch per linear
+        groups = ops.WgradGroups(w["tn_slab"], on_side, max_wgs=side_wgs) if w.get("tn_slab") is not None else None
+
+        def wgrad(x_grad: Tensor, x_in: Tensor, gname: str) -> None:
+            if groups is not None:
+                groups.add(x_grad, x_in, self.G(gname))
+            else:
+                on_side(lambda: ops.gemm_tn(x_grad, x_in, self.G(gname), max_wgs=side_wgs))
 
         def fold_norm(partial: Tensor, gname: str) -> None:
             ev = main.record_event()
@@ -408,6 +420,8 @@ class JointEngine(DiTEngine):
                                     dmod[:, mo + D : mo + 2 * D], a["dwb"][0], **nxt)
                 fold_norm(a["dwb"][0], pre + f"{st}_norm_1.weight")
                 dx[st] = nx
+            if groups is not None:
+                groups.flush()
             if self.reducer is not None:
                 self.reducer.ready(*self.layer_ranges[i], extra_events=(side.record_event(),))
         main.wait_stream(side)

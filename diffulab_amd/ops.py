@@ -244,6 +244,8 @@ def gemm_tn_group(probs: list[tuple[Tensor, Tensor, Tensor]], slab: Tensor, max_
     import ctypes
 
     arr = (_WGrad * len(probs))()
+    if probs[0][0].shape[0] % 64:  # leading slices of zero-padded row buffers: widen to the parents like gemm_tn
+        probs = [(_padded_rows(dy), _padded_rows(x), g) for dy, x, g in probs]
     R = probs[0][0].shape[0]
     for q, (dy, x, g) in zip(arr, probs):
         assert dy.shape[0] == R and x.shape[0] == R and g.is_contiguous()
@@ -258,6 +260,49 @@ def gemm_tn_group(probs: list[tuple[Tensor, Tensor, Tensor]], slab: Tensor, max_
     if rc != 0:
         raise RuntimeError(f"dl_gemm_tn_group failed ({rc}): {_LIB.cdll.dl_last_error().decode()}")
     return True
+
+
+class WgradGroups:
+    """Collects the weight-gradient problems (dy, x, g) an engine's backward produces and issues them as dl_gemm_tn_group launches:
+    up to four problems over the SAME token rows per launch, no atomics, bit-reproducible (csrc/gemm_w4.hip).  Problems are keyed
+    by their row count (the two token streams of a joint block have different ones); a key's list is launched when it holds four
+    problems and at flush().  `launch(fn)` runs fn where the engine wants its weight gradients (side stream behind an event).
+    Shapes the 384 x 192 tile does not divide fall back to one dl_gemm_tn_ex launch per problem."""
+
+    def __init__(self, slab: Tensor, launch, max_wgs: int = 0) -> None:
+        self.slab, self.launch, self.max_wgs = slab, launch, max_wgs
+        self.pending: dict[int, list[tuple[Tensor, Tensor, Tensor]]] = {}
+
+    @staticmethod
+    def slab_floats(D: int, F: int, ranges: int = 8) -> int:
+        """scratch for the four linears of a block with inner width D and MLP width F (qkv, proj, up, down) at `ranges` token ranges"""
+        return ranges * (4 * D * D + 3 * D * F)
+
+    @staticmethod
+    def shapes_ok(D: int, F: int, rows: int) -> bool:
+        return D % 384 == 0 and F % 192 == 0 and rows % 32 == 0 and rows >= 2048
+
+    def add(self, dy: Tensor, x: Tensor, g: Tensor) -> None:
+        lst = self.pending.setdefault(dy.shape[0], [])
+        lst.append((dy, x, g))
+        if len(lst) == 4:
+            self._issue(dy.shape[0])
+
+    def _issue(self, key: int) -> None:
+        probs = self.pending.pop(key, [])
+        if not probs:
+            return
+
+        def run() -> None:
+            if not gemm_tn_group(probs, self.slab, max_wgs=self.max_wgs):
+                for dy, x, g in probs:
+                    gemm_tn(dy, x, g, max_wgs=self.max_wgs)
+
+        self.launch(run)
+
+    def flush(self) -> None:
+        for key in list(self.pending):
+            self._issue(key)
 
 
 # ------------------------------------------------------------------ block kernels

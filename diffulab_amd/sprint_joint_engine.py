@@ -247,6 +247,8 @@ class SprintJointEngine(DiTEngine):
             w["dse"], w["demb"], w["demb16"] = z(Bp, E, dtype=f32), z(Bp, E, dtype=f32), z(Bp, E)
             w["dh1"], w["dpre1"] = z(Bp, E, dtype=f32), z(Bp, E)
             w["scr_last"], w["scr_conv"] = z(_rup(Fo, 8), D, dtype=f32), z(D, self._ki, dtype=f32)
+            if D % 384 == 0 and F % 192 == 0 and os.environ.get("DL_WGRAD_GROUP", "1") != "0":  # grouped weight gradients (ops.WgradGroups)
+                w["tn_slab"] = torch.empty(ops.WgradGroups.slab_floats(D, F), device=self.dev, dtype=f32)
         self.ws, self._ws_key = w, key
         self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)
         if len(self._ws_cache) >= 8:
@@ -385,6 +387,7 @@ class SprintJointEngine(DiTEngine):
                                     dmod[:, mo + D : mo + 2 * D], a["dwb"][0], **nxt)
                 fold_norm(a["dwb"][0], pre + f"{st}_norm_1.weight")
                 dx[st] = nx_
+            getattr(wgrad, "flush", lambda: None)()  # (grouped weight gradients: whatever of this block is still pending)
             if self.reducer is not None:
                 self.reducer.ready(*self.layer_ranges[bi], extra_events=(side.record_event(),))
         return dx["input"], dx["context"]
@@ -471,6 +474,7 @@ class SprintJointEngine(DiTEngine):
                                 a["mean"], a["rstd"], dx, nx_, dmod[:, mo : mo + D], dmod[:, mo + D : mo + 2 * D], a["dwb"][0], **nxt)
             fold_norm(a["dwb"][0], pre + "norm.weight")
             dx = nx_
+            getattr(wgrad, "flush", lambda: None)()  # (grouped weight gradients: whatever of this block is still pending)
             if self.reducer is not None:
                 self.reducer.ready(*self.layer_ranges[bi], extra_events=(side.record_event(),))
         return dx
@@ -582,11 +586,23 @@ class SprintJointEngine(DiTEngine):
         side.wait_stream(main)
         side_wgs = int(os.environ.get("DL_SIDE_WGS", "128"))
 
-        def wgrad(x_grad: Tensor, x_in: Tensor, gname: str) -> None:
+        def on_side(fn) -> None:
             ev = main.record_event()
             with torch.cuda.stream(side):
                 side.wait_event(ev)
-                ops.gemm_tn(x_grad, x_in, self.G(gname), max_wgs=side_wgs)
+                fn()
+
+        # the linears of a block (per token stream) as ONE atomics-free launch (ops.WgradGroups) where the 384 x 192 tile divides
+        # them; the stages call wgrad.flush() at every block end
+        groups = ops.WgradGroups(w["tn_slab"], on_side, max_wgs=side_wgs) if w.get("tn_slab") is not None else None
+
+        def wgrad(x_grad: Tensor, x_in: Tensor, gname: str) -> None:
+            if groups is not None:
+                groups.add(x_grad, x_in, self.G(gname))
+            else:
+                on_side(lambda: ops.gemm_tn(x_grad, x_in, self.G(gname), max_wgs=side_wgs))
+
+        wgrad.flush = groups.flush if groups is not None else (lambda: None)
 
         def fold_norm(partial: Tensor, gname: str) -> None:
             ev = main.record_event()
@@ -737,6 +753,8 @@ class JointStackEngine(SprintJointEngine):
             w["dse"], w["demb"], w["demb16"] = z(Bp, E, dtype=f32), z(Bp, E, dtype=f32), z(Bp, E)
             w["dh1"], w["dpre1"] = z(Bp, E, dtype=f32), z(Bp, E)
             w["scr_last"], w["scr_conv"] = z(_rup(Fo, 8), D, dtype=f32), z(D, self._ki, dtype=f32)
+            if D % 384 == 0 and F % 192 == 0 and os.environ.get("DL_WGRAD_GROUP", "1") != "0":  # grouped weight gradients (ops.WgradGroups)
+                w["tn_slab"] = torch.empty(ops.WgradGroups.slab_floats(D, F), device=self.dev, dtype=f32)
         self.ws, self._ws_key = w, key
         self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)
         if len(self._ws_cache) >= 8:
@@ -827,11 +845,23 @@ class JointStackEngine(SprintJointEngine):
         side.wait_stream(main)
         side_wgs = int(os.environ.get("DL_SIDE_WGS", "128"))
 
-        def wgrad(x_grad: Tensor, x_in: Tensor, gname: str) -> None:
+        def on_side(fn) -> None:
             ev = main.record_event()
             with torch.cuda.stream(side):
                 side.wait_event(ev)
-                ops.gemm_tn(x_grad, x_in, self.G(gname), max_wgs=side_wgs)
+                fn()
+
+        # the linears of a block (per token stream) as ONE atomics-free launch (ops.WgradGroups) where the 384 x 192 tile divides
+        # them; the stages call wgrad.flush() at every block end
+        groups = ops.WgradGroups(w["tn_slab"], on_side, max_wgs=side_wgs) if w.get("tn_slab") is not None else None
+
+        def wgrad(x_grad: Tensor, x_in: Tensor, gname: str) -> None:
+            if groups is not None:
+                groups.add(x_grad, x_in, self.G(gname))
+            else:
+                on_side(lambda: ops.gemm_tn(x_grad, x_in, self.G(gname), max_wgs=side_wgs))
+
+        wgrad.flush = groups.flush if groups is not None else (lambda: None)
 
         def fold_norm(partial: Tensor, gname: str) -> None:
             ev = main.record_event()
