@@ -79,27 +79,29 @@ def test_repa_loss_with_flow_loss_against_reference_fixture(golden):
     assert not m.layers[0]._forward_hooks
 
 
-def test_repa_config_dims_against_oracle():
-    """dims of configs/train_imagenet_flow_matching_repa.yaml (DC-AE latents 32x8x8, patch 1 -> 64 tokens, inner 768, 12 heads,
-    embedding 256) at depth 3, REPA hooked on block 2 with hidden 1024 / target dim 1024 (no resampler): losses and every
-    gradient against the CPU oracle -- covers the D = 768 row kernels and the 64-token attention"""
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("depth,align,B", [(3, 2, 4), (12, 8, 128)])
+def test_repa_config_dims_against_oracle(depth, align, B):
+    """dims of configs/train_imagenet_flow_matching_repa.yaml (BASELINE config 4: DC-AE latents 32x8x8, patch 1 -> 64 tokens, inner
+    768, 12 heads, embedding 256), REPA with hidden 1024 / target dim 1024 (no resampler): losses and every gradient against the CPU
+    oracle -- at depth 3 / B=4 (quick) and at the CONFIG's depth 12, alignment layer 8 and batch 128 (it had only run
+    at depth 3, B=4).  Covers the D = 768 row kernels, the 64-token attention and, at B=128, the grouped weight gradients."""
     from diffulab_amd import Diffuser, MMDiT
     from diffulab_amd.training.losses import RepaLoss
     from oracle import diffusion as od
 
     kw = dict(input_channels=32, output_channels=32, inner_dim=768, embedding_dim=256, num_heads=12, mlp_ratio=4, patch_size=1,
-              depth=3, n_classes=1000, classifier_free=True)
+              depth=depth, n_classes=1000, classifier_free=True)
     cfg = odit.DiTConfig(**kw)
     P = synth.dit_params(odit.param_shapes(cfg), seed=13)
     R = synth.generic_params(orepa.param_shapes(768, 1024, 1024), seed=43)
     m = MMDiT(simple_dit=True, **kw)
     m.load_state_dict(P)
     m = m.to(DEV)
-    rl = RepaLoss(alignment_layer=2, denoiser_dimension=768, hidden_dim=1024, load_dino=False, embedding_dim=1024, coeff=0.5)
+    rl = RepaLoss(alignment_layer=align, denoiser_dimension=768, hidden_dim=1024, load_dino=False, embedding_dim=1024, coeff=0.5)
     rl.load_state_dict(R)
     rl = rl.to(DEV)
     rl.set_model(m)
-    B = 4
     x0, noise = synth.normal("rb.x0", (B, 32, 8, 8)), synth.normal("rb.noise", (B, 32, 8, 8))
     y, t = synth.integers("rb.y", (B,), 1000), synth.uniform("rb.t", (B,), lo=0.05, hi=0.95)
     dst = synth.normal("rb.dst", (B, 64, 1024))
@@ -112,7 +114,7 @@ def test_repa_config_dims_against_oracle():
     taps: dict = {}
     pred = odit.dit_forward(Pr, od.flow_add_noise(x0, t, noise), t, y, cfg, taps=taps)
     ref_loss = od.flow_loss(pred, x0, noise)
-    ref_repa = orepa.repa_loss(Rr, taps["layer1"], dst, coeff=0.5)
+    ref_repa = orepa.repa_loss(Rr, taps[f"layer{align - 1}"], dst, coeff=0.5)
     (ref_loss + ref_repa).backward()
     assert abs(losses["loss"].item() - ref_loss.item()) / ref_loss.item() < 2e-3
     assert abs(losses["RepaLoss"].item() - ref_repa.item()) / ref_repa.item() < 2e-3
