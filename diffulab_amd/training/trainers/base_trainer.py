@@ -11,6 +11,7 @@ with backward.
 from __future__ import annotations
 
 import logging
+from contextlib import contextmanager
 from typing import TYPE_CHECKING, Iterable
 
 import torch
@@ -92,70 +93,89 @@ class BaseTrainer(Trainer):
     ) -> None:
         if val_step_shift is not None:
             assert diffuser.model_type == "rectified_flow", "Time-shifting during validation is only supported for flow-based models."
-        if not diffuser.denoiser.classifier_free:
-            p_classifier_free_guidance = 0
+        p_cfg = p_classifier_free_guidance if diffuser.denoiser.classifier_free else 0
+        ema = self._setup_run(diffuser, optimizer, train_embedder, optimizer_ckpt, denoiser_ckpt, ema_ckpt)
+        meter, best = AverageMeter(), float("inf")
+        logging.info("Begin training")
+        for epoch in range(epoch_start, self.n_epoch):
+            self._train_epoch(diffuser, optimizer, train_dataloader, meter, p_cfg, scheduler, per_batch_scheduler, ema)
+            self._log_group(meter, "train/", epoch + 1)
+            meter.reset()
+            if val_dataloader is not None:
+                with self._validating(diffuser, ema) as online:
+                    for val_batch in self.even_batches(val_dataloader):
+                        self.validation_step(diffuser=diffuser, val_batch=val_batch, tracker=meter)
+                    val_total = self._log_group(meter, "val/", epoch + 1)
+                    if log_validation_images and self.is_main_process:
+                        logging.info("creating validation images")
+                        self.log_images(diffuser, val_dataloader, epoch, val_steps, step_shift=val_step_shift,
+                                        guidance_scale=4 if online.classifier_free else 0)
+                if val_total < best:  # (the checkpoint holds the online weights AND the EMA copy, base_trainer.py:246-251)
+                    best = val_total
+                    self.save_model(optimizer, diffuser, ema, scheduler)
+                meter.reset()
+            self.wait_for_everyone()
+        logging.info("Training complete")
+
+    # ---- the pieces of train() (reference: one function, base_trainer.py:277-399; same order of effects)
+    def _setup_run(self, diffuser: "Diffuser", optimizer: Optimizer, train_embedder: bool, optimizer_ckpt: str | None,
+                   denoiser_ckpt: str | None, ema_ckpt: str | None) -> EMA | None:
+        """checkpoints in, device placement / rank-0 broadcast / reducer (``prepare``), the EMA copy, auxiliary loss heads hooked
+        onto the denoiser, a frozen context embedder unless it is trained"""
         if denoiser_ckpt:
             diffuser.denoiser.load_state_dict(torch.load(denoiser_ckpt))
         self.prepare(diffuser, optimizer)
         if optimizer_ckpt:  # after prepare(): the state follows the parameters' device (and the arena exists)
             optimizer.load_state_dict(torch.load(optimizer_ckpt, weights_only=False))
+        ema = None
         if self.use_ema:
-            ema_denoiser = EMA(diffuser.denoiser, beta=self.ema_rate, update_after_step=self.ema_update_after_step,
-                               update_every=self.ema_update_every).to(self.device)
+            ema = EMA(diffuser.denoiser, beta=self.ema_rate, update_after_step=self.ema_update_after_step,
+                      update_every=self.ema_update_every).to(self.device)
             if ema_ckpt:
-                ema_denoiser.ema_model.load_state_dict(torch.load(ema_ckpt, weights_only=True))
-        else:
-            ema_denoiser = None
-        for loss in diffuser.extra_losses:  # accelerator.prepare(loss) in the reference: device placement, then the hooks
-            loss.to(self.device)
-            loss.set_model(diffuser.denoiser)
+                ema.ema_model.load_state_dict(torch.load(ema_ckpt, weights_only=True))
+        for head in diffuser.extra_losses:  # accelerator.prepare(loss) in the reference: device placement, then the hooks
+            head.to(self.device)
+            head.set_model(diffuser.denoiser)
         self.broadcast_extra_losses(diffuser)
-        if getattr(diffuser.denoiser, "context_embedder", None) is not None and not train_embedder:
-            for param in diffuser.denoiser.context_embedder.parameters():
-                param.requires_grad = False
+        embedder = getattr(diffuser.denoiser, "context_embedder", None)
+        if embedder is not None and not train_embedder:
+            for q in embedder.parameters():
+                q.requires_grad = False
+        return ema
 
-        best_val_loss = float("inf")
-        tracker = AverageMeter()
-        logging.info("Begin training")
-        for epoch in range(epoch_start, self.n_epoch):
-            diffuser.train()
-            for batch in self.iterate(train_dataloader):
-                self.training_step(diffuser=diffuser, optimizer=optimizer, batch=batch, tracker=tracker,
-                                   p_classifier_free_guidance=p_classifier_free_guidance, scheduler=scheduler,
-                                   per_batch_scheduler=per_batch_scheduler, ema_denoiser=ema_denoiser)
-            if scheduler is not None and not per_batch_scheduler:
-                scheduler.step()
-            for key, value in tracker.avg.items():
-                if key.startswith("train/"):
-                    self.log({key: self.gather_mean(value)}, step=epoch + 1)
-            tracker.reset()
+    def _train_epoch(self, diffuser: "Diffuser", optimizer: Optimizer, loader: Iterable[BatchData], meter: AverageMeter, p_cfg: float,
+                     scheduler: LRScheduler | None, per_batch_scheduler: bool, ema: EMA | None) -> None:
+        diffuser.train()
+        for batch in self.iterate(loader):
+            self.training_step(diffuser=diffuser, optimizer=optimizer, batch=batch, tracker=meter, p_classifier_free_guidance=p_cfg,
+                               scheduler=scheduler, per_batch_scheduler=per_batch_scheduler, ema_denoiser=ema)
+        if scheduler is not None and not per_batch_scheduler:
+            scheduler.step()
 
-            if val_dataloader is not None:
-                diffuser.eval()
-                original_model = diffuser.denoiser
-                if ema_denoiser is not None:
-                    diffuser.denoiser = ema_denoiser.ema_model.eval()
-                    for loss in diffuser.extra_losses:
-                        loss.set_model(ema_denoiser.ema_model)
-                for val_batch in self.even_batches(val_dataloader):
-                    self.validation_step(diffuser=diffuser, val_batch=val_batch, tracker=tracker)
-                total_loss = 0.0
-                for key, value in tracker.avg.items():
-                    if key.startswith("val/"):
-                        g = self.gather_mean(value)
-                        self.log({key: g}, step=epoch + 1)
-                        total_loss += g
-                if log_validation_images and self.is_main_process:
-                    logging.info("creating validation images")
-                    self.log_images(diffuser, val_dataloader, epoch, val_steps, step_shift=val_step_shift,
-                                    guidance_scale=4 if original_model.classifier_free else 0)
-                if ema_denoiser is not None:
-                    diffuser.denoiser = original_model
-                    for loss in diffuser.extra_losses:
-                        loss.set_model(original_model)
-                if total_loss < best_val_loss:
-                    best_val_loss = total_loss
-                    self.save_model(optimizer, diffuser, ema_denoiser, scheduler)
-                tracker.reset()
-            self.wait_for_everyone()
-        logging.info("Training complete")
+    def _log_group(self, meter: AverageMeter, prefix: str, step: int) -> float:
+        """log the rank-mean of every tracked average under ``prefix``; returns their sum (the validation criterion)"""
+        total = 0.0
+        for key, value in meter.avg.items():
+            if key.startswith(prefix):
+                mean = self.gather_mean(value)
+                self.log({key: mean}, step=step)
+                total += mean
+        return total
+
+    @contextmanager
+    def _validating(self, diffuser: "Diffuser", ema: EMA | None):
+        """eval mode with the EMA weights in place of the online ones (and the auxiliary heads hooked onto them); yields the online
+        denoiser and puts everything back on exit"""
+        diffuser.eval()
+        online = diffuser.denoiser
+        if ema is not None:
+            diffuser.denoiser = ema.ema_model.eval()
+            for head in diffuser.extra_losses:
+                head.set_model(ema.ema_model)
+        try:
+            yield online
+        finally:
+            if ema is not None:
+                diffuser.denoiser = online
+                for head in diffuser.extra_losses:
+                    head.set_model(online)
