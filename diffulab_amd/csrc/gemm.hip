@@ -1082,24 +1082,58 @@ extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t 
 // gradient over 65536 tokens, the conditioning path's [256, 384] product over K = 28416); by default the splits meet in f32 atomics,
 // whose order varies from run to run.  The *_det entry points give every split its own partial image in a caller-owned scratch
 // (plain stores) and fold the images in a fixed order -- two runs are bit-identical.
+// S = split lanes per element (threads that share one output element and walk the partial images S apart; combined in LDS in a
+// fixed tree): 1 for a handful of images of a large matrix, 16 for hundreds of images of a few dozen elements (a bias gradient
+// over 512 row slabs: one thread per element would issue 512 dependent-latency loads)
+template <int S>
 __global__ __launch_bounds__(256) void fold_partials_k(const float* __restrict__ part, int64_t stride, int splits, int64_t M, int N,
                                                        int64_t ldp, float* __restrict__ C, int64_t ldc, int accumulate) {
+  constexpr int E = 256 / S;
+  __shared__ float red[S][E];
+  const int el = threadIdx.x % E, sl = threadIdx.x / E;
   const int64_t total = M * N;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = i / N;
-    const int n = (int)(i - m * N);
-    const float* p = part + m * ldp + n;
-    float s = p[0];
-    for (int k = 1; k < splits; ++k) s += p[(int64_t)k * stride];
-    float* c = C + m * ldc + n;
-    *c = accumulate ? *c + s : s;
+  for (int64_t base = (int64_t)blockIdx.x * E; base < total; base += (int64_t)gridDim.x * E) {
+    const int64_t i = base + el;
+    float s = 0.f;
+    int64_t m = 0;
+    int n = 0;
+    if (i < total) {
+      m = i / N;
+      n = (int)(i - m * N);
+      const float* p = part + m * ldp + n;
+      for (int k = sl; k < splits; k += S) s += p[(int64_t)k * stride];
+    }
+    if (S > 1) {
+      red[sl][el] = s;
+      __syncthreads();
+      if (sl == 0) {
+#pragma unroll
+        for (int w = S / 2; w >= 1; w >>= 1)  // fixed tree over the lanes: ((0+1)+(2+3))+...
+#pragma unroll
+          for (int q = 0; q < w; ++q) red[q][el] = red[2 * q][el] + red[2 * q + 1][el];
+        s = red[0][el];
+      }
+    }
+    if (sl == 0 && i < total) {
+      float* c = C + m * ldc + n;
+      *c = accumulate ? *c + s : s;
+    }
+    if (S > 1) __syncthreads();
   }
 }
 int launch_fold_partials(const float* part, int64_t stride, int splits, int64_t M, int64_t N, int64_t ldp, float* C, int64_t ldc,
                          int accumulate, hipStream_t stream) {
-  int64_t g = (M * N + 255) / 256;
-  if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(fold_partials_k, (int)g, 256, 0, stream, part, stride, splits, M, (int)N, ldp, C, ldc, accumulate);
+  const int64_t total = M * N;
+#define FOLD_GO(S_)                                                                                                            \
+  do {                                                                                                                         \
+    int64_t g = (total + 256 / S_ - 1) / (256 / S_);                                                                           \
+    if (g > 4096) g = 4096;                                                                                                    \
+    hipLaunchKernelGGL(fold_partials_k<S_>, (int)g, 256, 0, stream, part, stride, splits, M, (int)N, ldp, C, ldc, accumulate); \
+  } while (0)
+  if (splits <= 4) FOLD_GO(1);
+  else if (splits <= 32) FOLD_GO(4);
+  else FOLD_GO(16);
+#undef FOLD_GO
   return hipGetLastError() == hipSuccess ? DL_OK : DL_ERR_LAUNCH;
 }
 

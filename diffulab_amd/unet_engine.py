@@ -376,7 +376,9 @@ class UNetEngine:
         dyp = self._padded(dy, Mp, co8)
 
         def wgrad() -> None:  # bias + weight gradient: off the dependency chain of the backward
-            ops.colsum(dy, self.Gr(name[:-6] + "bias"), M, co)
+            # (DL_UNET_DET_COLSUM=1: row-slab partials + fixed-order fold instead of f32 atomics -- reproducible, but two launches per
+            #  bias gradient: 35.4 vs 34.7 ms per MNIST-DDPM step, so the atomic form stays the default here)
+            ops.colsum(dy, self.Gr(name[:-6] + "bias"), M, co, scratch=self._scr("colsum_part", 512 * co, torch.float32) if os.environ.get("DL_UNET_DET_COLSUM", "0") == "1" else None)
             g = self._new(ldk, co8, dtype=torch.float32, zero=True)  # transposed: 9*Ci rows fit the 384-row wgrad tiles
             if not ops.conv3x3_wgrad_tn(x, B, H, W, ci, dyp, co8, g, self._zero, max_wgs=192):  # (0: 35.4 ms/step, 192: 34.9, 128: 36.5)
                 cols = self._new(Mp, ldk)
@@ -410,7 +412,9 @@ class UNetEngine:
         dyp, xp = self._padded(dy, Mp, dy.shape[1]), self._padded(x, Mp, x.shape[1])
 
         def wgrad() -> None:
-            ops.colsum(dy, self.Gr(name[:-6] + "bias"), M, co)
+            # (DL_UNET_DET_COLSUM=1: row-slab partials + fixed-order fold instead of f32 atomics -- reproducible, but two launches per
+            #  bias gradient: 35.4 vs 34.7 ms per MNIST-DDPM step, so the atomic form stays the default here)
+            ops.colsum(dy, self.Gr(name[:-6] + "bias"), M, co, scratch=self._scr("colsum_part", 512 * co, torch.float32) if os.environ.get("DL_UNET_DET_COLSUM", "0") == "1" else None)
             ops.gemm_tn(dyp, xp, self.Gr(name).view(co, ci), M=co, N=ci)
 
         self._off_chain(wgrad, dy, dyp, xp)
