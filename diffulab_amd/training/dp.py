@@ -33,6 +33,14 @@ class GradReducer:
             from .._comm import Communicator
 
             self.comm = Communicator(dist.get_rank(group), self.world, flat_grad.device.index)
+        # DIFFULAB_DP_BUCKET_MB overrides the bucket size; a value larger than the arena means ONE all-reduce in finish(), after
+        # the backward has ended (nothing overlaps).  Why one might want that: every heavy kernel of the step is one workgroup per
+        # CU with all of the CU's registers, so RCCL's workgroups cannot co-reside with them -- they
+        # take whole CUs at kernel boundaries, and a persistent launch sized for 256 CUs that finds fewer free runs a second round.
+        # Unmeasured (no multi-GPU box was available to the builder): the knob makes the A/B a one-line experiment.
+        mb = os.environ.get("DIFFULAB_DP_BUCKET_MB")
+        if mb:
+            bucket_bytes = int(float(mb) * (1 << 20))
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.enabled = self.world > 1
         self.sync = True  # False inside a gradient-accumulation micro-step (no_sync)
