@@ -850,7 +850,13 @@ class DiTEngine:
             e_main.record(main)
             e_side.record(side)
             self._tail_probe = (e_main, e_side)
-        main.wait_stream(side)
+        # Without a gradient reducer nothing reads the weight gradients before the optimizer, so the join with the side stream comes
+        # LAST: the LayerNorm-affine fold and the conditioning backward (~0.3 ms of small main-stream kernels) run under the grouped
+        # weight-gradient launch of the first block instead of behind it.  (Data parallel: _cond_bwd ends in reducer.finish(), which
+        # must see every range final -- the join stays in front.)
+        join_last = self.reducer is None and os.environ.get("DL_JOIN_LAST", "1") != "0"
+        if not join_last:
+            main.wait_stream(side)
         if defer_fold:  # dwb [2L, B, 2, D]: rows 2i -> norm_1 of block i, 2i + 1 -> norm_2; [w; b] of a norm are adjacent in the arena
             ent = self.layout.entries
             stride = ent[self.prefixes[1] + "norm_1.weight"][0] - ent[self.prefixes[0] + "norm_1.weight"][0] if L > 1 else 0
@@ -858,6 +864,8 @@ class DiTEngine:
                 ops.reduce_rows_batched_f32(w["dwb"][j], 2 * B * 2 * D, self.G(self.prefixes[0] + nm), stride, L, B, 2 * D)
 
         self._cond_bwd(dx)
+        if join_last:
+            main.wait_stream(side)
 
     def _cond_bwd(self, dx: Tensor, extra_demb: Tensor | None = None) -> None:
         """backward of _stem_fwd: dx = gradient of the patch-embedded tokens; the modulation gradient was accumulated in
