@@ -8,6 +8,7 @@ There is no fallback path: a missing library or a CPU tensor raises.
 
 from __future__ import annotations
 
+import ctypes
 import os
 
 import torch
@@ -229,20 +230,17 @@ def gemm_tn(a: Tensor, b: Tensor, out: Tensor, *, M: int | None = None, N: int |
     return out
 
 
-class _WGrad(__import__("ctypes").Structure):
+class _WGrad(ctypes.Structure):
     """ctypes mirror of dl_wgrad_t (include/diffulab_hip.h)"""
-    import ctypes as _c
 
-    _fields_ = [("dy", _c.c_void_p), ("ld_dy", _c.c_int64), ("x", _c.c_void_p), ("ld_x", _c.c_int64), ("g", _c.c_void_p),
-                ("m_out", _c.c_int64), ("n_in", _c.c_int64)]
+    _fields_ = [("dy", ctypes.c_void_p), ("ld_dy", ctypes.c_int64), ("x", ctypes.c_void_p), ("ld_x", ctypes.c_int64),
+                ("g", ctypes.c_void_p), ("m_out", ctypes.c_int64), ("n_in", ctypes.c_int64)]
 
 
 def gemm_tn_group(probs: list[tuple[Tensor, Tensor, Tensor]], slab: Tensor, max_wgs: int = 0) -> bool:
     """g_p[M_p, N_p] (f32, contiguous) += dy_p[R, M_p]^T @ x_p[R, N_p] for up to four (dy, x, g) over the same R rows in ONE launch
     without atomics (bit-reproducible): partial tiles per token range go to `slab` (f32 scratch, >= sum M_p N_p elements; 8 x that
     fills the chip) and are folded in a fixed order.  False: the 384 x 192 tile does not divide a shape (nothing was launched)."""
-    import ctypes
-
     arr = (_WGrad * len(probs))()
     if probs[0][0].shape[0] % 64:  # leading slices of zero-padded row buffers: widen to the parents like gemm_tn
         probs = [(_padded_rows(dy), _padded_rows(x), g) for dy, x, g in probs]
@@ -448,14 +446,10 @@ def attn_fwd_fp8(q8, k8, v8t, scales, out, lse, B, H, Nq, Nk, dh, scale, key_bia
 
 def dit_block_fwd(blk, train: bool) -> None:
     """one adaLN-zero DiT block forward issued by the library (blk: diffulab_amd._block.DitBlock)"""
-    import ctypes
-
     _call("dl_dit_block_fwd", ctypes.addressof(blk), int(train), _s())
 
 
 def dit_block_bwd(blk, main_stream: int, side_stream: int, side_wgs: int) -> None:
-    import ctypes
-
     _call("dl_dit_block_bwd", ctypes.addressof(blk), main_stream, side_stream, int(side_wgs))
 
 
