@@ -62,3 +62,26 @@ def test_comm_library_exports_every_symbol_of_its_header():
     for name in declared:
         assert hasattr(cdll, name), name
     assert _comm.lib().dl_comm_rank(None) == -1
+
+
+def test_probe_library_is_separate_from_the_product_abi():
+    """the lab probes live in their own library (include/diffulab_probe.h -> libdiffulab_probe.so); the product header
+    declares none of them, the product library exports none of them, nothing under diffulab_amd/ loads the probe library, and the
+    product sources read no environment variable"""
+    ptext = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "diffulab_probe.h")).read(), flags=re.S)
+    probes = set(re.findall(r"\b(dl_probe_[a-z0-9_]+)\s*\(", ptext))
+    assert {"dl_probe_tr16", "dl_probe_mfma_f8", "dl_probe_mfma", "dl_probe_dma", "dl_probe_last_error"} <= probes
+    plib = ctypes.CDLL(os.path.join(ROOT, "diffulab_amd", "libdiffulab_probe.so"))
+    for name in probes:
+        assert hasattr(plib, name), name
+    assert not any(n.startswith("dl_probe") for n in _lib.parse_header())
+    prod = ctypes.CDLL(_lib.LIB_PATH)
+    for name in probes:
+        assert not hasattr(prod, name), f"{name} is exported by the product library"
+    for dp, _, files in os.walk(os.path.join(ROOT, "diffulab_amd")):
+        for f in files:
+            path = os.path.join(dp, f)
+            if f.endswith(".py"):
+                assert "libdiffulab_probe" not in open(path).read(), path
+            if f.endswith((".hip", ".cc", ".h")) and os.sep + "lab" + os.sep not in path:
+                assert "getenv" not in open(path).read(), f"{path} reads the environment"
