@@ -102,7 +102,7 @@ extern "C" int dl_dit_block_bwd(const dl_dit_block_t* b, dl_stream_t main_, dl_s
   // issued as soon as its operands exist.
   dl_wgrad_t wg[4];
   int nwg = 0;
-  bool grouped = P(TN_SLAB) != nullptr && D % 384 == 0 && F % 192 == 0 && M % 32 == 0 && M >= 2048;
+  bool grouped = P(TN_SLAB) != nullptr && ((D % 384 == 0 && F % 192 == 0) || (D % 256 == 0 && F % 256 == 0)) && M % 32 == 0 && M >= 2048;
   auto wgrad = [&](const void* dy, int64_t ldy, const void* x, int64_t ldx, void* g, int64_t Mo, int64_t No) -> int {
     if (grouped) {
       wg[nwg++] = dl_wgrad_t{dy, ldy, x, ldx, (float*)g, Mo, No};

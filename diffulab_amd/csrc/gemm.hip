@@ -1145,7 +1145,7 @@ extern "C" int dl_gemm_tn_det(const void* A, int64_t lda, const void* B, int64_t
                "dl_gemm_tn_det: M,N,lda,ldb must be multiples of 8 (M=%lld N=%lld)", (long long)M, (long long)N);
   DL_CHECK_ARG((((uintptr_t)A | (uintptr_t)B) & 15) == 0, "dl_gemm_tn_det: 16-byte alignment");
   DL_CHECK_ARG(scratch_floats >= M * N, "dl_gemm_tn_det: scratch of %lld floats < one [M, N] image", (long long)scratch_floats);
-  if (M % 384 == 0 && N % 192 == 0 && R % 32 == 0 && R / 32 >= 64) {  // the 384 x 192 ring kernel's own atomics-free form
+  if (((M % 384 == 0 && N % 192 == 0) || (M % 256 == 0 && N % 256 == 0)) && R % 32 == 0 && R / 32 >= 64) {  // the ring kernel's atomics-free form
     const dl_wgrad_t one{A, lda, B, ldb, C, M, N};
     if (ldc == N) return dl_gemm_tn_group(&one, 1, R, scratch, scratch_floats, 0, stream);
   }

@@ -68,13 +68,13 @@ __device__ __forceinline__ void wait_vmcnt_w4() {
 #define W4_WAVES 8
 #define W4_BNW 192
 #define W4_LDS (W4_NST * W4_BK * (W4_AM + W4_BNW) * 2)
-template <int BNW>
+template <int AM, int BNW>
 __device__ __forceinline__ void w4_tile(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Bm, int64_t ldb,
                                         int m0, int n0, int s_begin, int s_end, char* smem,
-                                        f32x16_t (&acc)[W4_AM / (W4_WAVES / 2) / 32][BNW / 64]) {
+                                        f32x16_t (&acc)[AM / (W4_WAVES / 2) / 32][BNW / 64]) {
   constexpr int WAVES = W4_WAVES, WM = WAVES / 2;     // waves along m (2 along n)
-  constexpr int IM = W4_AM / WM / 32, JN = BNW / 64;  // MFMA tiles per wave
-  constexpr int PA = W4_AM * 2, PB = BNW * 2;        // image row pitches (bytes)
+  constexpr int IM = AM / WM / 32, JN = BNW / 64;    // MFMA tiles per wave
+  constexpr int PA = AM * 2, PB = BNW * 2;           // image row pitches (bytes)
   constexpr int A_BYTES = W4_BK * PA;                // 24 KiB
   constexpr int STAGE = W4_BK * (PA + PB);           // 36 | 40 KiB
   constexpr int ACH = A_BYTES / 1024;                // 1 KiB DMA chunks of the A image
@@ -118,7 +118,7 @@ __device__ __forceinline__ void w4_tile(const bf16_t* __restrict__ A, int64_t ld
   int aoff[IM], boff[JN];
 #pragma unroll
   for (int i = 0; i < IM; ++i) {
-    const int col = wm * (W4_AM / WM) + i * 32 + (g & 1) * 16 + (li & 3) * 4;
+    const int col = wm * (AM / WM) + i * 32 + (g & 1) * 16 + (li & 3) * 4;
     aoff[i] = rl * PA + (((col >> 3) ^ ((rl & 3) << 2)) << 4) + (col & 7) * 2;
   }
 #pragma unroll
@@ -236,14 +236,14 @@ __device__ __forceinline__ void w4_tile(const bf16_t* __restrict__ A, int64_t ld
 
 }
 
-// acc[i][j][r] = C[m][n]: n = lane & 31 (128 contiguous bytes per half-wave), m from r and the lane half
-#define W4_FOR_ACC(STMT)                                                                        \
-  _Pragma("unroll") for (int i = 0; i < 3; ++i) _Pragma("unroll") for (int j = 0; j < 3; ++j) { \
-    const int nn = n0 + wn * (W4_BNW / 2) + j * 32 + (lane & 31);                               \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                            \
-      const int m = m0 + wm * 96 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);           \
-      STMT;                                                                                     \
-    }                                                                                           \
+// acc[i][j][r] = C[m][n]: n = lane & 31 (128 contiguous bytes per half-wave), m from r and the lane half; AM_ / BNW_ = the tile
+#define W4_FOR_ACC(AM_, BNW_, STMT)                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < (AM_) / 128; ++i) _Pragma("unroll") for (int j = 0; j < (BNW_) / 64; ++j) {    \
+    const int nn = n0 + wn * ((BNW_) / 2) + j * 32 + (lane & 31);                                                      \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                   \
+      const int m = m0 + wm * ((AM_) / 4) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);                         \
+      STMT;                                                                                                            \
+    }                                                                                                                  \
   }
 
 // =====================================================================================================
@@ -280,9 +280,9 @@ __global__ __launch_bounds__(W4_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
   s_end = s_end < nsteps_total ? s_end : nsteps_total;
   if (s_begin >= s_end) return;
   f32x16_t acc[3][3];
-  w4_tile<W4_BNW>(A, lda, Bm, ldb, m0, n0, s_begin, s_end, smem, acc);
+  w4_tile<W4_AM, W4_BNW>(A, lda, Bm, ldb, m0, n0, s_begin, s_end, smem, acc);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-  W4_FOR_ACC(unsafeAtomicAdd(&C[(int64_t)m * ldc + nn], acc[i][j][r]));
+  W4_FOR_ACC(W4_AM, W4_BNW, unsafeAtomicAdd(&C[(int64_t)m * ldc + nn], acc[i][j][r]));
 }
 
 // =====================================================================================================
@@ -303,6 +303,9 @@ struct W4Group {
   int64_t slab_stride;  // floats between the slabs of two token ranges
   float* slab;
 };
+// AM x BNW = 384 x 192 (inner widths that are multiples of 384: 3 x 3 MFMA tiles per wave, 128 FLOP per staged byte) or 256 x 256
+// (multiples of 256 -- the 512-wide configurations: 2 x 4 tiles per wave, 102 FLOP per staged byte, 32 KiB stages)
+template <int AM, int BNW>
 __global__ __launch_bounds__(W4_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn_group_k(W4Group g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int u = xcd_remap(blockIdx.x, gridDim.x);
@@ -312,16 +315,16 @@ __global__ __launch_bounds__(W4_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
   if (g.nprob > 2 && tile >= g.p[2].tile0) pr = g.p[2];
   if (g.nprob > 3 && tile >= g.p[3].tile0) pr = g.p[3];
   const int lt = tile - pr.tile0, mt = lt / pr.tiles_n, nt = lt - mt * pr.tiles_n;
-  const int m0 = mt * W4_AM, n0 = nt * W4_BNW;
+  const int m0 = mt * AM, n0 = nt * BNW;
   const int s_begin = split * g.steps_per_split;
   int s_end = s_begin + g.steps_per_split;
   s_end = s_end < g.nsteps ? s_end : g.nsteps;  // (the host sizes the grid so that every range owns at least one stage)
-  f32x16_t acc[3][3];
-  w4_tile<W4_BNW>(pr.A, pr.lda, pr.B, pr.ldb, m0, n0, s_begin, s_end, smem, acc);
+  f32x16_t acc[AM / 128][BNW / 64];
+  w4_tile<AM, BNW>(pr.A, pr.lda, pr.B, pr.ldb, m0, n0, s_begin, s_end, smem, acc);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
   float* C = g.slab + (int64_t)split * g.slab_stride + pr.off;
   const int64_t ldc = pr.No;
-  W4_FOR_ACC(C[(int64_t)m * ldc + nn] = acc[i][j][r]);
+  W4_FOR_ACC(AM, BNW, C[(int64_t)m * ldc + nn] = acc[i][j][r]);
 }
 
 // g_p[i] += ((slab_0[off_p + i] + slab_1[..]) + ...) + slab_{S-1}[..]: a fixed summation order, one pass
@@ -353,7 +356,9 @@ static int w4_cus() {
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (n_cu <= 0) n_cu = 256;
     (void)hipFuncSetAttribute((const void*)gemm_tn_w4_k, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_tn_group_k, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_group_k<384, 192>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_group_k<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              W4_NST * W4_BK * (256 + 256) * 2);
   }
   return n_cu;
 }
@@ -397,10 +402,16 @@ extern "C" int dl_gemm_tn_group(const dl_wgrad_t* probs, int n_probs, int64_t R,
   W4Fold f{};
   int ntile = 0;
   int64_t total = 0;
+  bool t384 = true, t256 = true;  // which tile divides every problem
+  for (int i = 0; i < n_probs; ++i) {
+    t384 = t384 && probs[i].m_out % 384 == 0 && probs[i].n_in % 192 == 0;
+    t256 = t256 && probs[i].m_out % 256 == 0 && probs[i].n_in % 256 == 0;
+  }
+  if (!t384 && !t256) return DL_ERR_UNSUPPORTED;
+  const int AMt = t384 ? 384 : 256, BNt = t384 ? 192 : 256;
   for (int i = 0; i < n_probs; ++i) {
     const dl_wgrad_t& q = probs[i];
     DL_CHECK_ARG(q.dy && q.x && q.g && q.m_out > 0 && q.n_in > 0, "dl_gemm_tn_group: null operand in problem %d", i);
-    if (q.m_out % W4_AM || q.n_in % W4_BNW) return DL_ERR_UNSUPPORTED;
     DL_CHECK_ARG(q.ld_dy % 8 == 0 && q.ld_x % 8 == 0 && q.ld_dy >= q.m_out && q.ld_x >= q.n_in && q.ld_dy < (1ll << 31) &&
                      q.ld_x < (1ll << 31),
                  "dl_gemm_tn_group: leading dimensions of problem %d", i);
@@ -411,12 +422,12 @@ extern "C" int dl_gemm_tn_group(const dl_wgrad_t* probs, int n_probs, int64_t R,
     p.lda = (int)q.ld_dy;
     p.ldb = (int)q.ld_x;
     p.No = (int)q.n_in;
-    p.tiles_n = (int)(q.n_in / W4_BNW);
+    p.tiles_n = (int)(q.n_in / BNt);
     p.tile0 = ntile;
     p.off = total;
     f.dst[i] = q.g;
     f.off[i] = total;
-    ntile += (int)(q.m_out / W4_AM) * p.tiles_n;
+    ntile += (int)(q.m_out / AMt) * p.tiles_n;
     total += q.m_out * q.n_in;
   }
   f.off[n_probs] = total;
@@ -436,7 +447,10 @@ extern "C" int dl_gemm_tn_group(const dl_wgrad_t* probs, int n_probs, int64_t R,
   g.nsteps = nsteps;
   g.slab_stride = total;
   g.slab = slab;
-  hipLaunchKernelGGL(gemm_tn_group_k, splits * ntile, W4_WAVES * 64, W4_LDS, (hipStream_t)stream, g);
+  if (t384)
+    hipLaunchKernelGGL((gemm_tn_group_k<384, 192>), splits * ntile, W4_WAVES * 64, W4_LDS, (hipStream_t)stream, g);
+  else
+    hipLaunchKernelGGL((gemm_tn_group_k<256, 256>), splits * ntile, W4_WAVES * 64, W4_NST * W4_BK * (256 + 256) * 2, (hipStream_t)stream, g);
   int64_t fg = ((total >> 2) + 255) / 256;
   if (fg > 1024) fg = 1024;
   hipLaunchKernelGGL(tn_group_fold_k, (int)fg, 256, 0, (hipStream_t)stream, slab, total, splits, f);

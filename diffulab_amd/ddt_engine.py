@@ -211,6 +211,7 @@ class PerTokenDecoder:
                                     **nxt)
             fold(a["dwbp"][0], pre + "norm_1.weight", N_PART)
             dx, dx_alt = dx_alt, dx
+            getattr(wgrad, "flush", lambda: None)()
             if self.reducer is not None:
                 self.reducer.ready(*self.layer_ranges[bi], extra_events=(side.record_event(),))
         # decoder patch embedding
@@ -315,6 +316,8 @@ class DDTEngine(SprintEngine, PerTokenDecoder):
             w["scr_last"], w["scr_conv"] = z(_rup(Fo, 8), D, dtype=f32), z(D, self._ki, dtype=f32)
             # scratch of the bit-reproducible (and faster) small GEMMs / column sums of the conditioning backward (engine._cond_bwd)
             w["det_scr"] = torch.empty(max(2 * self.layout.mod_rows * d.embedding_dim, 1 << 22), device=self.dev, dtype=f32)
+            if ops.WgradGroups.widths_ok(D, F) and os.environ.get("DL_WGRAD_GROUP", "1") != "0":  # grouped weight gradients (ops.WgradGroups)
+                w["tn_slab"] = torch.empty(ops.WgradGroups.slab_floats(D, F), device=self.dev, dtype=f32)
         self.ws, self._ws_key = w, key
         self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)
         if len(self._ws_cache) >= 8:
@@ -367,11 +370,13 @@ class DDTEngine(SprintEngine, PerTokenDecoder):
         side.wait_stream(main)
         side_wgs = int(os.environ.get("DL_SIDE_WGS", "128"))
 
-        def wgrad(x_grad: Tensor, x_in: Tensor, gname: str) -> None:
+        def on_side(fn) -> None:
             ev = main.record_event()
             with torch.cuda.stream(side):
                 side.wait_event(ev)
-                ops.gemm_tn(x_grad, x_in, self.G(gname), max_wgs=side_wgs)
+                fn()
+
+        wgrad = ops.grouped_wgrad_fn(self.G, w.get("tn_slab"), on_side, side_wgs)  # (one atomics-free launch per block where the tile divides)
 
         def fold(partial: Tensor, gname: str, groups: int) -> None:
             ev = main.record_event()
@@ -593,6 +598,8 @@ class DDTJointEngine(SprintJointEngine, PerTokenDecoder):
             w["scr_last"], w["scr_conv"] = z(_rup(Fo, 8), D, dtype=f32), z(D, self._ki, dtype=f32)
             # scratch of the bit-reproducible (and faster) small GEMMs / column sums of the conditioning backward (engine._cond_bwd)
             w["det_scr"] = torch.empty(max(2 * self.layout.mod_rows * d.embedding_dim, 1 << 22), device=self.dev, dtype=f32)
+            if ops.WgradGroups.widths_ok(D, F) and os.environ.get("DL_WGRAD_GROUP", "1") != "0":  # grouped weight gradients (ops.WgradGroups)
+                w["tn_slab"] = torch.empty(ops.WgradGroups.slab_floats(D, F), device=self.dev, dtype=f32)
         self.ws, self._ws_key = w, key
         self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)
         if len(self._ws_cache) >= 8:
@@ -649,11 +656,13 @@ class DDTJointEngine(SprintJointEngine, PerTokenDecoder):
         side.wait_stream(main)
         side_wgs = int(os.environ.get("DL_SIDE_WGS", "128"))
 
-        def wgrad(x_grad: Tensor, x_in: Tensor, gname: str) -> None:
+        def on_side(fn) -> None:
             ev = main.record_event()
             with torch.cuda.stream(side):
                 side.wait_event(ev)
-                ops.gemm_tn(x_grad, x_in, self.G(gname), max_wgs=side_wgs)
+                fn()
+
+        wgrad = ops.grouped_wgrad_fn(self.G, w.get("tn_slab"), on_side, side_wgs)  # (one atomics-free launch per block where the tile divides)
 
         def fold(partial: Tensor, gname: str, groups: int) -> None:
             ev = main.record_event()

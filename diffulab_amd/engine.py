@@ -578,8 +578,7 @@ class DiTEngine:
         """the four weight gradients of a block as ONE launch without atomics (csrc/gemm_w4.hip, dl_gemm_tn_group): every linear of
         the block must be a whole number of 384 x 192 tiles.  DL_WGRAD_GROUP=0 is the A/B switch back to four atomic launches."""
         D, F = self.d.inner_dim, self.d.mlp_ratio * self.d.inner_dim
-        return (type(self) is DiTEngine and D % 384 == 0 and F % 192 == 0 and M % 32 == 0 and M >= 2048
-                and os.environ.get("DL_WGRAD_GROUP", "1") != "0")
+        return (type(self) is DiTEngine and ops.WgradGroups.shapes_ok(D, F, M) and os.environ.get("DL_WGRAD_GROUP", "1") != "0")
 
     def _row_gemms(self, M: int, N: int) -> bool:
         """the row-complete GEMM path (csrc/gemm_ln.hip): LayerNorm-modulate forward / backward and QK-norm + RoPE run as epilogues

@@ -277,8 +277,13 @@ class WgradGroups:
         return ranges * (4 * D * D + 3 * D * F)
 
     @staticmethod
+    def widths_ok(D: int, F: int) -> bool:
+        """the four linears of a block with inner width D and MLP width F are whole 384 x 192 tiles, or whole 256 x 256 tiles"""
+        return (D % 384 == 0 and F % 192 == 0) or (D % 256 == 0 and F % 256 == 0)
+
+    @staticmethod
     def shapes_ok(D: int, F: int, rows: int) -> bool:
-        return D % 384 == 0 and F % 192 == 0 and rows % 32 == 0 and rows >= 2048
+        return WgradGroups.widths_ok(D, F) and rows % 32 == 0 and rows >= 2048
 
     def add(self, dy: Tensor, x: Tensor, g: Tensor) -> None:
         lst = self.pending.setdefault(dy.shape[0], [])
@@ -301,6 +306,23 @@ class WgradGroups:
     def flush(self) -> None:
         for key in list(self.pending):
             self._issue(key)
+
+
+def grouped_wgrad_fn(G, slab: Tensor | None, on_side, max_wgs: int = 0):
+    """the `wgrad(dy, x, parameter name)` hook of an engine's backward: with a slab the block's linears are collected and issued as
+    atomics-free dl_gemm_tn_group launches (WgradGroups; `wgrad.flush()` issues what is pending -- call it at every block end and
+    before the side stream is joined), without one each is a dl_gemm_tn_ex launch.  G(name) -> the f32 gradient view; on_side(fn)
+    runs fn where the engine wants its weight gradients (side stream behind an event of the main stream)."""
+    groups = WgradGroups(slab, on_side, max_wgs=max_wgs) if slab is not None else None
+
+    def wgrad(x_grad: Tensor, x_in: Tensor, gname: str) -> None:
+        if groups is not None:
+            groups.add(x_grad, x_in, G(gname))
+        else:
+            on_side(lambda: gemm_tn(x_grad, x_in, G(gname), max_wgs=max_wgs))
+
+    wgrad.flush = groups.flush if groups is not None else (lambda: None)
+    return wgrad
 
 
 # ------------------------------------------------------------------ block kernels

@@ -249,7 +249,7 @@ class SprintJointEngine(DiTEngine):
             w["scr_last"], w["scr_conv"] = z(_rup(Fo, 8), D, dtype=f32), z(D, self._ki, dtype=f32)
             # scratch of the bit-reproducible (and faster) small GEMMs / column sums of the conditioning backward (engine._cond_bwd)
             w["det_scr"] = torch.empty(max(2 * self.layout.mod_rows * d.embedding_dim, 1 << 22), device=self.dev, dtype=f32)
-            if D % 384 == 0 and F % 192 == 0 and os.environ.get("DL_WGRAD_GROUP", "1") != "0":  # grouped weight gradients (ops.WgradGroups)
+            if ops.WgradGroups.widths_ok(D, F) and os.environ.get("DL_WGRAD_GROUP", "1") != "0":  # grouped weight gradients (ops.WgradGroups)
                 w["tn_slab"] = torch.empty(ops.WgradGroups.slab_floats(D, F), device=self.dev, dtype=f32)
         self.ws, self._ws_key = w, key
         self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)
@@ -757,7 +757,7 @@ class JointStackEngine(SprintJointEngine):
             w["scr_last"], w["scr_conv"] = z(_rup(Fo, 8), D, dtype=f32), z(D, self._ki, dtype=f32)
             # scratch of the bit-reproducible (and faster) small GEMMs / column sums of the conditioning backward (engine._cond_bwd)
             w["det_scr"] = torch.empty(max(2 * self.layout.mod_rows * d.embedding_dim, 1 << 22), device=self.dev, dtype=f32)
-            if D % 384 == 0 and F % 192 == 0 and os.environ.get("DL_WGRAD_GROUP", "1") != "0":  # grouped weight gradients (ops.WgradGroups)
+            if ops.WgradGroups.widths_ok(D, F) and os.environ.get("DL_WGRAD_GROUP", "1") != "0":  # grouped weight gradients (ops.WgradGroups)
                 w["tn_slab"] = torch.empty(ops.WgradGroups.slab_floats(D, F), device=self.dev, dtype=f32)
         self.ws, self._ws_key = w, key
         self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)

@@ -138,8 +138,9 @@ DL_API int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t ldb,
 /* Up to four nn.Linear weight gradients over the SAME R token rows in ONE launch, WITHOUT atomics (the four linears of a
  * transformer block: mmdit.py:75-104 qkv / proj_out, mmdit.py:260-264 the two MLP linears):  g_p[m,n] += sum_r dy_p[r,m] x_p[r,n].
  * Every (token range, 384 x 192 tile) workgroup writes its f32 partial tile into slab[range] with plain stores and a fold kernel adds
- * the ranges in a fixed order, so two runs give bit-identical gradients.  m_out % 384 == 0, n_in % 192 == 0, R % 32 == 0, R >= 2048
- * -- otherwise DL_ERR_UNSUPPORTED (the caller keeps dl_gemm_tn_ex per problem).  slab: caller-owned f32 scratch of slab_floats >=
+ * the ranges in a fixed order, so two runs give bit-identical gradients.  EVERY problem a whole number of 384 x 192 tiles (m_out %
+ * 384 == 0, n_in % 192 == 0: inner widths 384, 768, ...) or every problem a whole number of 256 x 256 tiles (512-wide models);
+ * R % 32 == 0, R >= 2048 -- otherwise DL_ERR_UNSUPPORTED (the caller keeps dl_gemm_tn_ex per problem).  slab: caller-owned f32 scratch of slab_floats >=
  * sum_p m_out_p * n_in_p elements (contents irrelevant on entry, undefined on return); the number of token ranges is
  * min(workgroup budget / tiles, slab_floats / that sum), so 8 x the sum lets one launch fill the chip at D = 384.  max_workgroups
  * caps the grid like dl_gemm_tn_ex (0 = one workgroup per CU). */

@@ -137,13 +137,16 @@ def test_gemm_tn_ring_kernel(ops, R, M, N, cap):
     assert rel(c, ref) < 2e-5
 
 
-@pytest.mark.parametrize("R,cap,ranges", [(4096 + 32 * 7, 0, 8), (8192, 128, 8), (2048, 64, 8), (4096, 0, 1), (16384, 0, 3)])
-def test_gemm_tn_group_is_exact_and_bit_reproducible(ops, R, cap, ranges):
-    """dl_gemm_tn_group (csrc/gemm_w4.hip): the four weight gradients of a DiT-S block (qkv, proj_out, MLP up / down: 32 tiles of
-    384 x 192) in ONE launch, partial tiles per token range in a slab, folded in a fixed order.  += semantics, column windows of
-    wider operands, ragged last token range, a slab that only has room for `ranges` partial images, the workgroup cap -- and two
-    runs are bit-identical (the one-problem launches meet in f32 atomics and are not)"""
-    D, F = 384, 1536
+@pytest.mark.parametrize("R,cap,ranges,D", [(4096 + 32 * 7, 0, 8, 384), (8192, 128, 8, 384), (2048, 64, 8, 384), (4096, 0, 1, 384),
+                                            (16384, 0, 3, 384), (8192, 0, 8, 512), (2048 + 32 * 5, 192, 2, 512), (4096, 0, 8, 768),
+                                            (4096, 0, 8, 256)])
+def test_gemm_tn_group_is_exact_and_bit_reproducible(ops, R, cap, ranges, D):
+    """dl_gemm_tn_group (csrc/gemm_w4.hip): the four weight gradients of a DiT block (qkv, proj_out, MLP up / down) in ONE launch --
+    32 tiles of 384 x 192 at D = 384 (768: 128 tiles), 64 tiles of 256 x 256 at D = 512 (the CIFAR / SPRINT / DDT width; 256: 16 tiles)
+    -- partial tiles per token range in a slab, folded in a fixed order.  += semantics, column windows of wider operands, ragged last
+    token range, a slab that only has room for `ranges` partial images, the workgroup cap -- and two runs are bit-identical (the
+    one-problem launches meet in f32 atomics and are not)"""
+    F = 4 * D
     shapes = [(3 * D, D), (D, D), (2 * F, D), (D, F)]
     probs, refs = [], []
     for i, (Mo, No) in enumerate(shapes):
@@ -163,7 +166,7 @@ def test_gemm_tn_group_is_exact_and_bit_reproducible(ops, R, cap, ranges):
         assert rel(g0, ref) < 2e-5
         assert torch.equal(g0, g1)
     # a shape the tile does not divide: nothing is launched, the caller keeps the per-problem path
-    g = torch.zeros(128, 384, device=DEV)
+    g = torch.zeros(128, D, device=DEV)
     assert not ops.gemm_tn_group([(probs[0][0][:, :128], probs[0][1], g)], slab)
     assert float(g.abs().max()) == 0.0
 
