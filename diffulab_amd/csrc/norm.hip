@@ -915,15 +915,32 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_inplace_k(QKI_ARGS) {
   qk_norm_rope_bwd_inplace_body<3>(qkv, sq, sk, cs, sn, rrms, dqkv, partials, M, N, H, dh, rot, pos);
 }
 // (capped at 128 VGPRs for four waves per SIMD it spills 84 bytes per lane inside the row loop: 165 us instead of 110)
-// out[j] += sum_g partial[g * n + j] with ONE writer per element and a fixed order (4 interleaved row lanes, then a fixed tree)
-__global__ __launch_bounds__(256) void fold_rows_k(const float* __restrict__ partial, float* __restrict__ out, int G, int n) {
-  __shared__ float red[4][64];
+// out[j] += sum_g partial[g * n + j] with ONE writer per element and a fixed order: 16 interleaved row lanes with four independent
+// chains each (48 loads per thread at 768 partial rows, 12 deep), then a fixed tree.  (Four row lanes with one chain each -- 192
+// dependent loads per thread on 12 workgroups -- took 49 us per block on the main chain: 0.6 ms of every DiT-S/2 step.)
+#define FOLD_LANES 16
+__global__ __launch_bounds__(64 * FOLD_LANES) void fold_rows_k(const float* __restrict__ partial, float* __restrict__ out, int G, int n) {
+  __shared__ float red[FOLD_LANES][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
-  float acc = 0.f;
-  if (c < n)
-    for (int g = rl; g < G; g += 4) acc += partial[(size_t)g * n + c];
-  red[rl][cl] = acc;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < n) {
+    const float* p = partial + c;
+    int g = rl;
+    for (; g + 3 * FOLD_LANES < G; g += 4 * FOLD_LANES) {
+      a0 += p[(size_t)g * n];
+      a1 += p[(size_t)(g + FOLD_LANES) * n];
+      a2 += p[(size_t)(g + 2 * FOLD_LANES) * n];
+      a3 += p[(size_t)(g + 3 * FOLD_LANES) * n];
+    }
+    for (; g < G; g += FOLD_LANES) a0 += p[(size_t)g * n];
+  }
+  red[rl][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  float t = 0.f;  // fixed tree: 16 -> 4 -> 1
+  if (rl < 4) t = (red[rl][cl] + red[rl + 4][cl]) + (red[rl + 8][cl] + red[rl + 12][cl]);
+  __syncthreads();
+  if (rl < 4) red[rl][cl] = t;
   __syncthreads();
   if (rl == 0 && c < n) out[c] += (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
@@ -948,7 +965,7 @@ extern "C" int dl_qk_norm_rope_bwd_inplace(const void* qkv, const float* scale_q
   const size_t lds = (size_t)4 * 2 * D * sizeof(float);
   hipLaunchKernelGGL(qk_norm_rope_bwd_inplace_k, grid, 256, lds, (hipStream_t)stream, (const bf16_t*)qkv, scale_q, scale_k, cos, sin,
                      rrms, (bf16_t*)dqkv, dscale_partials, M, (int)N, (int)H, (int)dh, (int)rot, pos);
-  hipLaunchKernelGGL(fold_rows_k, cdiv(2 * D, 64), 256, 0, (hipStream_t)stream, dscale_partials, dscale, grid, (int)(2 * D));
+  hipLaunchKernelGGL(fold_rows_k, cdiv(2 * D, 64), 64 * FOLD_LANES, 0, (hipStream_t)stream, dscale_partials, dscale, grid, (int)(2 * D));
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
