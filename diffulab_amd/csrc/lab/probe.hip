@@ -288,3 +288,14 @@ extern "C" int dl_probe_mfma_f8(const void* a, const void* b, float* d, dl_strea
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- CU holder
+__global__ void probe_spin_k(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+extern "C" int dl_probe_spin(int n_wgs, int threads, int usec, dl_stream_t stream) {
+  if (n_wgs <= 0 || threads <= 0 || threads > 1024 || usec <= 0) return -1;
+  hipLaunchKernelGGL(probe_spin_k, n_wgs, threads, 0, (hipStream_t)stream, (long long)usec * 100);  // wall_clock64: 100 MHz
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -16,3 +16,6 @@ for q, lst in sorted(byq.items(), key=lambda kv: -len(kv[1])):
     print(f"== queue {q}: {len(lst)} kernels, busy {sum(b - a for a, b, _, _ in lst) / 1e6:.3f} ms")
     for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
         print(f"   {t / 1e6:7.3f} ms  {c:4d} x {t / c / 1e3:7.1f} us  {n}")
+if len(sys.argv) > 2:  # the launch sequence of the step, small kernels only (name, queue, start offset us, duration us)
+    for a, b, n, q in step:
+        if b - a < int(sys.argv[2]) * 1000: print(f"   +{(a - s) / 1e3:9.1f} us  q{q}  {(b - a) / 1e3:7.1f} us  {n}")
