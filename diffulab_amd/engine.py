@@ -17,13 +17,12 @@ mmdit.py:288-309 (DiTBlock), mmdit.py:75-104 (DiTAttention), mmdit.py:542-549 (M
 from __future__ import annotations
 
 import math
-import os
 from dataclasses import dataclass, field
 
 import torch
 from torch import Tensor
 
-from . import ops
+from . import ops, tuning
 
 
 _PARAM_EPOCH = 0
@@ -269,7 +268,7 @@ class DiTEngine:
 
     def _side_stream(self) -> "torch.cuda.Stream":
         if getattr(self, "_side", None) is None:
-            mask = os.environ.get("DL_SIDE_CU_MASK", "")  # e.g. "i4" = every 4th CU, "b128" = the first 128 CUs
+            mask = tuning.text("DL_SIDE_CU_MASK")  # e.g. "i4" = every 4th CU, "b128" = the first 128 CUs
             if mask:
                 self._side = ops.masked_stream(mask, self.dev)
             else:
@@ -347,7 +346,7 @@ class DiTEngine:
             # N <= 256 and D <= 512: dQ / dK / dV leave the attention backward token-major inside the dqkv rows and the QK-norm
             # backward works in place (its per-workgroup scale-gradient partials land in qk_part): no dq / dk buffers
             # (from 32768 token rows: at the CIFAR config's 8192 rows the in-place pair is 5 % of a 6.7 ms step SLOWER)
-            if ops.v_in_place(N) and D <= 512 and M >= 32768 and type(self) is DiTEngine and os.environ.get("DL_QK_INPLACE", "1") != "0":
+            if ops.v_in_place(N) and D <= 512 and M >= 32768 and type(self) is DiTEngine and tuning.on("DL_QK_INPLACE"):
                 w["qk_part"] = torch.empty(1024 * 2 * D, device=dev, dtype=f32)
                 w["dq"] = w["dk"] = None
             else:
@@ -404,7 +403,7 @@ class DiTEngine:
     def _native_blocks(self) -> bool:
         """one C call per block and direction (dl_dit_block_fwd / _bwd) instead of ~25 launches from Python; DL_NATIVE_BLOCK=0 is the
         A/B switch back to the Python-issued sequence (identical kernels, identical order)"""
-        return type(self) is DiTEngine and os.environ.get("DL_NATIVE_BLOCK", "1") != "0"
+        return type(self) is DiTEngine and tuning.on("DL_NATIVE_BLOCK")
 
     def _block_args(self, i: int, train: bool):
         """the dl_dit_block_t of block i on the current workspace (cached: every pointer is fixed once arena and workspace exist)"""
@@ -461,7 +460,7 @@ class DiTEngine:
             # bit 1: QK-norm + RoPE in the qkv epilogue (measured slightly slower inside the step: opt-in); bit 2: the LayerNorm-affine
             # partials of all blocks are folded by ONE launch at the end of the backward (not with a gradient reducer attached: it
             # wants every block's range final as soon as the block is done)
-            blk.row_gemms = 1 | (2 if os.environ.get("DL_ROW_GEMM_QK", "0") == "1" else 0) | (4 if self.reducer is None else 0)
+            blk.row_gemms = 1 | (2 if tuning.on("DL_ROW_GEMM_QK") else 0) | (4 if self.reducer is None else 0)
         if train and self.grads is not None:
             g, dmod = w["wg"][i], w["dmod32"]
             blk.ld_dmod = dmod.stride(0)
@@ -578,7 +577,7 @@ class DiTEngine:
         """the four weight gradients of a block as ONE launch without atomics (csrc/gemm_w4.hip, dl_gemm_tn_group): every linear of
         the block must be a whole number of 384 x 192 tiles.  DL_WGRAD_GROUP=0 is the A/B switch back to four atomic launches."""
         D, F = self.d.inner_dim, self.d.mlp_ratio * self.d.inner_dim
-        return (type(self) is DiTEngine and ops.WgradGroups.shapes_ok(D, F, M) and os.environ.get("DL_WGRAD_GROUP", "1") != "0")
+        return (type(self) is DiTEngine and ops.WgradGroups.shapes_ok(D, F, M) and tuning.on("DL_WGRAD_GROUP"))
 
     def _row_gemms(self, M: int, N: int) -> bool:
         """the row-complete GEMM path (csrc/gemm_ln.hip): LayerNorm-modulate forward / backward and QK-norm + RoPE run as epilogues
@@ -597,7 +596,7 @@ class DiTEngine:
         xs = w["x"]
         lay = lambda i: w["layers"][i if train else 0]  # noqa: E731
         xbuf = lambda i: xs[i] if train else xs[i & 1]  # noqa: E731
-        fused_qk = os.environ.get("DL_ROW_GEMM_QK", "0") == "1"
+        fused_qk = tuning.on("DL_ROW_GEMM_QK")
         a0 = lay(0)
         _must(ops.ln_modulate_gemm_fwd(w["tokP"], sh[self._conv_name + "|f"], None, None, self.P("layers.0.norm_1.weight"),
                                         self.P("layers.0.norm_1.bias"), mod[:, 0:D], mod[:, D : 2 * D], N, 1e-5, None, xbuf(0),
@@ -698,9 +697,9 @@ class DiTEngine:
         # 24.4, 192: 24.8, 256: 25.8 ms/step (round 2).  The grouped launch (one per block, no atomics) wants the whole chip: every
         # kernel of the step is then one workgroup per CU and the two streams simply take turns (64: 23.8, 96: 22.4, 128: 22.3,
         # 192: 22.1, 256: 21.7 ms/step; the same launches inline on the main stream: 21.9)
-        side_wgs = int(os.environ.get("DL_SIDE_WGS", "256" if w.get("tn_slab") is not None else "128"))
+        side_wgs = tuning.integer("DL_SIDE_WGS", 256 if w.get("tn_slab") is not None else 128)
 
-        serial = os.environ.get("DL_WGRAD_SERIAL") == "1"  # A/B switch: weight gradients inline on the main stream
+        serial = tuning.on("DL_WGRAD_SERIAL")  # A/B switch: weight gradients inline on the main stream
 
         tn_slab = w.get("tn_slab")
         pending: list[tuple[Tensor, Tensor, Tensor]] = []  # (dy, x, g) of the current block, launched together once dqkv exists
@@ -742,7 +741,7 @@ class DiTEngine:
         # block's backward is (its MLP gate chunk was written by the block above), so the block's slice of the weight gradient is
         # computed right there on the side stream and handed to the reducer with the block's own range; the last three blocks ask
         # for an immediate flush, which leaves a few megabytes for finish().
-        early_mod = self.reducer is not None and type(self) is DiTEngine and os.environ.get("DL_DP_EARLY_MOD", "1") != "0"
+        early_mod = self.reducer is not None and type(self) is DiTEngine and tuning.on("DL_DP_EARLY_MOD")
         self._early_mod_done = early_mod
         w_mod = self.layout.entries[self.mod_name][0]
         b_mod = self.layout.entries[self.layout.mod_b0][0]
@@ -765,7 +764,7 @@ class DiTEngine:
                 self.reducer.ready(w_mod + i * 6 * D * E, w_mod + (i + 1) * 6 * D * E, flush=i < 3)
 
         native = self._native_blocks() and not serial and dx is w["dxa"]
-        inline_wgrad = os.environ.get("DL_WGRAD_INLINE", "0") == "1"  # TUNING: the grouped weight gradients on the main stream
+        inline_wgrad = tuning.on("DL_WGRAD_INLINE")  # TUNING: the grouped weight gradients on the main stream
         defer_fold = fused and self.reducer is None  # LayerNorm-affine partials of every block: one batched fold after the loop
         for i in reversed(range(L)):
             if native:
@@ -844,16 +843,11 @@ class DiTEngine:
             fold_norm(w["dwb"][2 * i], pre + "norm_1.weight")
             dx, dx_alt = dx_alt, dx
             block_done(i)  # this block's gradient range is final once BOTH streams are past this point
-        if os.environ.get("DL_TAIL_PROBE") == "1":  # how long the side stream's wgrads run on after the main chain is done
-            e_main, e_side = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e_main.record(main)
-            e_side.record(side)
-            self._tail_probe = (e_main, e_side)
         # Without a gradient reducer nothing reads the weight gradients before the optimizer, so the join with the side stream comes
         # LAST: the LayerNorm-affine fold and the conditioning backward (~0.3 ms of small main-stream kernels) run under the grouped
         # weight-gradient launch of the first block instead of behind it.  (Data parallel: _cond_bwd ends in reducer.finish(), which
         # must see every range final -- the join stays in front.)
-        join_last = self.reducer is None and os.environ.get("DL_JOIN_LAST", "1") != "0"
+        join_last = self.reducer is None and tuning.on("DL_JOIN_LAST")
         if not join_last:
             main.wait_stream(side)
         if defer_fold:  # dwb [2L, B, 2, D]: rows 2i -> norm_1 of block i, 2i + 1 -> norm_2; [w; b] of a norm are adjacent in the arena

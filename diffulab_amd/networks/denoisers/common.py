@@ -4,13 +4,13 @@ from __future__ import annotations
 
 import copy
 import logging
-import os
 from abc import ABC, abstractmethod
 from typing import Any, TypedDict
 
 import torch
 import torch.nn as nn
 from torch import Tensor
+from ... import tuning
 
 try:  # python >= 3.11
     from typing import NotRequired, Required
@@ -221,7 +221,7 @@ class FlatArenaDenoiser(Denoiser):
         and replayed (sampler loops at small batch are launch-bound: ~110 launches per DiT-S forward).  DL_HIPGRAPH=0
         disables the capture."""
         extra = self._graph_key(eng)
-        if os.environ.get("DL_HIPGRAPH", "1") == "0" or extra is None:
+        if not tuning.on("DL_HIPGRAPH") or extra is None:
             return eng.forward(x, t, y_eff, train=False).clone()
         graphs = self.__dict__.get("_graphs")
         if graphs is None:

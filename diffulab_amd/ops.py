@@ -15,6 +15,7 @@ import torch
 from torch import Tensor
 
 from ._lib import lib
+from . import tuning
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
@@ -176,7 +177,7 @@ def mlp_recompute_ok(M: int, D: int, F: int) -> bool:
     # F % 128: the recompute kernel's unit tile (the fused MLP-up forward takes any 2F % 128 with >= 64 tiles).  D <= 512: measured
     # -3 % on the DiT-S/2 step (D = 384, F = 1536); at D = 768, F = 3072 it is neutral (DiT-B + REPA, B = 128) to +3..5 % (joint MMDiT:
     # the wider contraction makes the recomputed GEMM cost more than the bytes it saves).
-    return (os.environ.get("DL_MLP_RECOMPUTE", "1") != "0" and M % 256 == 0 and D % 64 == 0 and D <= 512 and F % 128 == 0
+    return (tuning.on("DL_MLP_RECOMPUTE") and M % 256 == 0 and D % 64 == 0 and D <= 512 and F % 128 == 0
             and (M // 256) * (F // 128) >= 64)
 
 
@@ -348,7 +349,7 @@ def ln_modulate_bwd(dout, x, w, b, scale, rows_per_mod, mean, rstd, dres, dx, ds
 def row_gemm_ok(M: int, D: int, rows_per_mod: int) -> bool:
     """shapes served by the row-complete GEMMs (csrc/gemm_ln.hip): a 256 x 384 tile is a whole sample's whole rows.
     DL_ROW_GEMM=0 restores the GEMM + row-kernel launch pairs (A/B switch)"""
-    return os.environ.get("DL_ROW_GEMM", "1") != "0" and D == 384 and rows_per_mod == 256 and M % 256 == 0 and M // 256 >= 8
+    return tuning.on("DL_ROW_GEMM") and D == 384 and rows_per_mod == 256 and M % 256 == 0 and M // 256 >= 8
 
 
 def ln_modulate_gemm_fwd(a, w_sh, resid, gate, ln_w, ln_b, scale, shift, rows_per_mod, eps, t_out, x_out, xm_out, mean, rstd,
@@ -453,7 +454,7 @@ def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, N, dh, scale):
 def v_in_place(N: int) -> bool:
     """up to 256 tokens the attention kernels address V / dV inside the token-major qkv / dqkv rows (no head-split copy of V);
     DL_ATTN_V_IN_PLACE=0 restores the head-major V buffers (A/B switch)"""
-    return N <= 256 and os.environ.get("DL_ATTN_V_IN_PLACE", "1") != "0"
+    return N <= 256 and tuning.on("DL_ATTN_V_IN_PLACE")
 
 
 def attn_fp8_quantize(q, k, v, q8, k8, v8t, scales, B, H, Nq, Nk, dh=64):

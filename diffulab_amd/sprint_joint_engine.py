@@ -15,13 +15,12 @@ is the identity); RoPE rows of the kept tokens come from a position index, the k
 from __future__ import annotations
 
 import math
-import os
 from dataclasses import dataclass
 
 import torch
 from torch import Tensor
 
-from . import ops
+from . import ops, tuning
 from .engine import DiTEngine, _rup
 from .mmdit_engine import STREAMS, JointDims, joint_rope_tables
 from .sprint_engine import Route
@@ -249,7 +248,7 @@ class SprintJointEngine(DiTEngine):
             w["scr_last"], w["scr_conv"] = z(_rup(Fo, 8), D, dtype=f32), z(D, self._ki, dtype=f32)
             # scratch of the bit-reproducible (and faster) small GEMMs / column sums of the conditioning backward (engine._cond_bwd)
             w["det_scr"] = torch.empty(max(2 * self.layout.mod_rows * d.embedding_dim, 1 << 22), device=self.dev, dtype=f32)
-            if ops.WgradGroups.widths_ok(D, F) and os.environ.get("DL_WGRAD_GROUP", "1") != "0":  # grouped weight gradients (ops.WgradGroups)
+            if ops.WgradGroups.widths_ok(D, F) and tuning.on("DL_WGRAD_GROUP"):  # grouped weight gradients (ops.WgradGroups)
                 w["tn_slab"] = torch.empty(ops.WgradGroups.slab_floats(D, F), device=self.dev, dtype=f32)
         self.ws, self._ws_key = w, key
         self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)
@@ -586,7 +585,7 @@ class SprintJointEngine(DiTEngine):
         main = torch.cuda.current_stream()
         side = self._side_stream()
         side.wait_stream(main)
-        side_wgs = int(os.environ.get("DL_SIDE_WGS", "128"))
+        side_wgs = tuning.integer("DL_SIDE_WGS", 128)
 
         def on_side(fn) -> None:
             ev = main.record_event()
@@ -757,7 +756,7 @@ class JointStackEngine(SprintJointEngine):
             w["scr_last"], w["scr_conv"] = z(_rup(Fo, 8), D, dtype=f32), z(D, self._ki, dtype=f32)
             # scratch of the bit-reproducible (and faster) small GEMMs / column sums of the conditioning backward (engine._cond_bwd)
             w["det_scr"] = torch.empty(max(2 * self.layout.mod_rows * d.embedding_dim, 1 << 22), device=self.dev, dtype=f32)
-            if ops.WgradGroups.widths_ok(D, F) and os.environ.get("DL_WGRAD_GROUP", "1") != "0":  # grouped weight gradients (ops.WgradGroups)
+            if ops.WgradGroups.widths_ok(D, F) and tuning.on("DL_WGRAD_GROUP"):  # grouped weight gradients (ops.WgradGroups)
                 w["tn_slab"] = torch.empty(ops.WgradGroups.slab_floats(D, F), device=self.dev, dtype=f32)
         self.ws, self._ws_key = w, key
         self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)
@@ -847,7 +846,7 @@ class JointStackEngine(SprintJointEngine):
         main = torch.cuda.current_stream()
         side = self._side_stream()
         side.wait_stream(main)
-        side_wgs = int(os.environ.get("DL_SIDE_WGS", "128"))
+        side_wgs = tuning.integer("DL_SIDE_WGS", 128)
 
         def on_side(fn) -> None:
             ev = main.record_event()

@@ -1,0 +1,45 @@
+"""A/B switches of the engines: environment variables read when an engine builds a workspace or issues a step.
+
+Every switch is listed here with its shipped default and what it selects; the engines read them only through `on()` / `integer()` /
+`text()`, so an unknown name is a programming error, not a silent default.  None of them changes what is computed beyond f32 summation
+order; they exist so that a measured decision can be re-measured on other hardware with one variable.  The C ABI
+reads no environment (tests/test_abi.py): a switch becomes an argument of the call it affects.
+"""
+
+from __future__ import annotations
+
+import os
+
+SWITCHES: dict[str, tuple[str, str]] = {
+    # name: (default, meaning)
+    "DL_NATIVE_BLOCK": ("1", "DiT blocks issued by the C ABI's block drivers (dl_dit_block_fwd / _bwd) instead of one Python call per kernel"),
+    "DL_ROW_GEMM": ("1", "LayerNorm-modulate forward / backward as epilogues of the row-complete 256x384 GEMMs (D = 384, 256 tokens per sample)"),
+    "DL_ROW_GEMM_QK": ("0", "QK-norm + RoPE as the epilogue of the qkv GEMM (measured slower than the separate row kernel)"),
+    "DL_MLP_RECOMPUTE": ("1", "SwiGLU backward recomputes the MLP-up pre-activations instead of storing them in the forward"),
+    "DL_ATTN_V_IN_PLACE": ("1", "attention reads V / writes dV inside the token-major qkv rows (N <= 256)"),
+    "DL_QK_INPLACE": ("1", "attention backward writes dQ / dK token-major and the QK-norm backward runs in place on the dqkv rows"),
+    "DL_WGRAD_GROUP": ("1", "the four weight gradients of a block as one atomics-free launch (dl_gemm_tn_group)"),
+    "DL_WGRAD_INLINE": ("0", "grouped weight gradients on the main stream instead of the side stream"),
+    "DL_WGRAD_SERIAL": ("0", "per-problem weight gradients on the main stream (engines without the grouped form)"),
+    "DL_SIDE_WGS": ("", "workgroup cap of the side-stream weight gradients (default: 256 grouped, 128 per-problem)"),
+    "DL_SIDE_CU_MASK": ("", "CU mask of the side stream (dl_stream_create_masked): 'i4' = every 4th CU, 'b128' = the first 128"),
+    "DL_JOIN_LAST": ("1", "single GPU: the side stream is joined after the conditioning backward instead of before it"),
+    "DL_DP_EARLY_MOD": ("1", "data parallel: each block's adaLN rows are reduced as the block finishes"),
+    "DL_HIPGRAPH": ("1", "samplers replay the denoiser forward as a captured hipGraph"),
+    "DL_UNET_SIDE": ("1", "UNet weight gradients on a side stream"),
+    "DL_UNET_SPLITK": ("0", "split-K convolutions at the UNet's low-resolution levels (measured slower)"),
+    "DL_UNET_DET_COLSUM": ("0", "UNet bias gradients through the bit-reproducible column sum (measured 2 % slower)"),
+}
+
+
+def text(name: str) -> str:
+    return os.environ.get(name, SWITCHES[name][0])
+
+
+def on(name: str) -> bool:
+    return text(name) not in ("", "0")
+
+
+def integer(name: str, default: int) -> int:
+    v = text(name)
+    return int(v) if v else default

@@ -16,13 +16,12 @@ wiring), :832-853 (forward), :215-237 (ResBlock._forward), :296-322 (AttentionBl
 from __future__ import annotations
 
 import math
-import os
 from dataclasses import dataclass, field
 
 import torch
 from torch import Tensor
 
-from . import engine as _eng
+from . import engine as _eng, tuning
 from . import ops
 from .engine import _rup
 
@@ -319,7 +318,7 @@ class UNetEngine:
     def _splitk(self, M: int, n: int) -> Tensor | None:
         """f32 scratch for the split-K path of the low-resolution convolutions.  Measured on the MNIST-DDPM config: the atomics
         and the second pass cost more than the idle CUs (45.6 vs 43.7 ms/step), so it is opt-in (DL_UNET_SPLITK=1)."""
-        if M > 16384 or os.environ.get("DL_UNET_SPLITK", "0") != "1":
+        if M > 16384 or not tuning.on("DL_UNET_SPLITK"):
             return None
         return self._scr("splitk", M * n, torch.float32)
 
@@ -367,7 +366,7 @@ class UNetEngine:
 
     @property
     def _use_side(self) -> bool:
-        return os.environ.get("DL_UNET_SIDE", "1") != "0"
+        return tuning.on("DL_UNET_SIDE")
 
     def _conv3_bwd(self, dy: Tensor, x: Tensor, B: int, H: int, W: int, ci: int, name: str, co: int,
                    need_dx: bool = True) -> Tensor | None:
@@ -378,7 +377,7 @@ class UNetEngine:
         def wgrad() -> None:  # bias + weight gradient: off the dependency chain of the backward
             # (DL_UNET_DET_COLSUM=1: row-slab partials + fixed-order fold instead of f32 atomics -- reproducible, but two launches per
             #  bias gradient: 35.4 vs 34.7 ms per MNIST-DDPM step, so the atomic form stays the default here)
-            ops.colsum(dy, self.Gr(name[:-6] + "bias"), M, co, scratch=self._scr("colsum_part", 512 * co, torch.float32) if os.environ.get("DL_UNET_DET_COLSUM", "0") == "1" else None)
+            ops.colsum(dy, self.Gr(name[:-6] + "bias"), M, co, scratch=self._scr("colsum_part", 512 * co, torch.float32) if tuning.on("DL_UNET_DET_COLSUM") else None)
             g = self._new(ldk, co8, dtype=torch.float32, zero=True)  # transposed: 9*Ci rows fit the 384-row wgrad tiles
             if not ops.conv3x3_wgrad_tn(x, B, H, W, ci, dyp, co8, g, self._zero, max_wgs=192):  # (0: 35.4 ms/step, 192: 34.9, 128: 36.5)
                 cols = self._new(Mp, ldk)
@@ -414,7 +413,7 @@ class UNetEngine:
         def wgrad() -> None:
             # (DL_UNET_DET_COLSUM=1: row-slab partials + fixed-order fold instead of f32 atomics -- reproducible, but two launches per
             #  bias gradient: 35.4 vs 34.7 ms per MNIST-DDPM step, so the atomic form stays the default here)
-            ops.colsum(dy, self.Gr(name[:-6] + "bias"), M, co, scratch=self._scr("colsum_part", 512 * co, torch.float32) if os.environ.get("DL_UNET_DET_COLSUM", "0") == "1" else None)
+            ops.colsum(dy, self.Gr(name[:-6] + "bias"), M, co, scratch=self._scr("colsum_part", 512 * co, torch.float32) if tuning.on("DL_UNET_DET_COLSUM") else None)
             ops.gemm_tn(dyp, xp, self.Gr(name).view(co, ci), M=co, N=ci)
 
         self._off_chain(wgrad, dy, dyp, xp)

@@ -85,3 +85,25 @@ def test_probe_library_is_separate_from_the_product_abi():
                 assert "libdiffulab_probe" not in open(path).read(), path
             if f.endswith((".hip", ".cc", ".h")) and os.sep + "lab" + os.sep not in path:
                 assert "getenv" not in open(path).read(), f"{path} reads the environment"
+
+
+def test_engine_switches_are_registered_and_documented():
+    """every A/B switch an engine reads goes through diffulab_amd.tuning (name, default, meaning in one table); no module reads a
+    DL_* variable from the environment on its own"""
+    from diffulab_amd import tuning
+
+    used = set()
+    for dp, _, files in os.walk(os.path.join(ROOT, "diffulab_amd")):
+        for f in files:
+            if f.endswith(".py") and f != "tuning.py":
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"os\.environ[^\n]*\"DL_", src), os.path.join(dp, f)
+                used |= set(re.findall(r"tuning\.(?:on|text|integer)\(\"([A-Z_0-9]+)\"", src))
+    assert used and used <= set(tuning.SWITCHES), used - set(tuning.SWITCHES)
+    assert set(tuning.SWITCHES) <= used, set(tuning.SWITCHES) - used  # no stale entries
+    assert tuning.on("DL_WGRAD_GROUP") and not tuning.on("DL_ROW_GEMM_QK") and tuning.integer("DL_SIDE_WGS", 128) == 128
+    try:
+        tuning.on("DL_NOT_A_SWITCH")
+        raise AssertionError("expected KeyError")
+    except KeyError:
+        pass
