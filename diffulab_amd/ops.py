@@ -261,6 +261,11 @@ def gemm_tn_group(probs: list[tuple[Tensor, Tensor, Tensor]], slab: Tensor, max_
     return True
 
 
+def wgrad_tile_ok(m_out: int, n_in: int) -> bool:
+    """dl_gemm_tn_group has a tile for a [m_out, n_in] weight gradient (whole 384 x 192 or whole 256 x 256 tiles)"""
+    return (m_out % 384 == 0 and n_in % 192 == 0) or (m_out % 256 == 0 and n_in % 256 == 0)
+
+
 class WgradGroups:
     """Collects the weight-gradient problems (dy, x, g) an engine's backward produces and issues them as dl_gemm_tn_group launches:
     up to four problems over the SAME token rows per launch, no atomics, bit-reproducible (csrc/gemm_w4.hip).  Problems are keyed

@@ -713,6 +713,28 @@ def test_small_gemms_and_column_sums_have_bit_reproducible_forms(ops):
         assert rel(outs[0], init + x.float().sum(0)) < 1e-5 and torch.equal(outs[0], outs[1]), (R, C)
 
 
+@pytest.mark.parametrize("R,C,ld", [(4096 + 37, 13312, 13312), (8192, 512, 1536), (65536, 16, 16), (1000, 24, 32), (300, 8, 8),
+                                    (2048, 520, 528), (5000, 12, 16)])  # the last: C % 8 != 0 -> the one-element-per-lane kernel
+def test_colsum_bf16_vector_path(ops, R, C, ld):
+    """dl_colsum / dl_colsum_det on bf16 rows: 16 bytes per lane, VL lanes across the columns and 256 / VL thread rows down the slab
+    (colsum_vec_k); += semantics, column windows of wider rows, ragged last slab, widths from one lane to 1664 lanes; the scratch form
+    is identical from run to run"""
+    x = synth.normal(f"csv.{R}{C}", (R, ld))
+    init = synth.normal(f"csv.o{C}", (C,))
+    ref = init + bf(x)[:, :C].sum(0)
+    xd = dev_bf(x)[:, :C]
+    o = init.to(DEV).clone()
+    ops.colsum(xd, o, R, C)
+    assert rel(o, ref) < 1e-5
+    scr = torch.full((1 << 22,), float("nan"), device=DEV)
+    outs = []
+    for _ in range(2):
+        o = init.to(DEV).clone()
+        ops.colsum(xd, o, R, C, scratch=scr)
+        outs.append(o)
+    assert rel(outs[0], ref) < 1e-5 and torch.equal(outs[0], outs[1])
+
+
 def test_label_table_gradient_without_atomics(ops):
     """dl_cond_combine_bwd: nn.Embedding's backward (repeated labels add up) with one writer per table row and a fixed order:
     equal to index_add_ and identical from run to run"""
