@@ -16,7 +16,7 @@ import torch
 from torch import Tensor
 
 from . import ops, tuning
-from .engine import DiTDims, _rup, rope_grid_tables
+from .engine import DiTDims, _must, _rup, rope_grid_tables
 from .sprint_engine import SprintEngine
 
 N_PART = 32  # partial slabs of the affine LayerNorm gradients of a per-token LayerNorm backward
@@ -154,6 +154,7 @@ class PerTokenDecoder:
         rot = sum(d.rope_axes_dim)
         ne, L = first, first + nd
         tm, dtm = w["tmod"], w["dtmod"]
+        inplace_qk = ops.qk_inplace_ok(w, B, N)
         Fo8 = _rup(Fo, 8)
         ops.patchify(dpred, w["dO"], d.patch_size, ops.PATCH_PPC)
         gl = self.G("last_layer.linear.weight")
@@ -189,15 +190,21 @@ class PerTokenDecoder:
             dx, dx_alt = dx_alt, dx
             wgrad(g["dt1"], a["a"], pre + "attention.proj_out.weight")
             ops.gemm_nt(g["dt1"], sh[pre + "attention.proj_out.weight|t"], s["da"])
-            if ops.v_in_place(N):
-                ops.attn_bwd_qkv(a["q"], a["k"], a["qkv"], a["a"], s["da"], a["lse"], s["dq"], s["dk"], g["dqkv"], B, Hh, N, 64,
-                                 64**-0.5)
+            if inplace_qk:  # dQ, dK, dV token-major into dqkv; the QK-norm backward transforms the q / k thirds in place
+                ops.attn_bwd_tok(a["q"], a["k"], a["qkv"], a["a"], s["da"], a["lse"], g["dqkv"], B, Hh, N, 64, 64**-0.5)
+                _must(ops.qk_norm_rope_bwd_inplace(a["qkv"], self.P(pre + "attention.qk_norm.query_norm.scale"),
+                                                    self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], g["dqkv"],
+                                                    self.G(pre + "attention.qk_norm.query_norm.scale"), w["qk_part"], B, N, Hh, 64, rot))
             else:
-                ops.attn_bwd(a["q"], a["k"], a["v"], a["a"], s["da"], a["lse"], s["dq"], s["dk"], s["dv"], B, Hh, N, 64, 64**-0.5)
-            ops.qk_norm_rope_bwd(s["dq"], s["dk"], None if ops.v_in_place(N) else s["dv"], a["qkv"],
-                                 self.P(pre + "attention.qk_norm.query_norm.scale"),
-                                 self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], g["dqkv"],
-                                 self.G(pre + "attention.qk_norm.query_norm.scale"), B, N, Hh, 64, rot)
+                if ops.v_in_place(N):
+                    ops.attn_bwd_qkv(a["q"], a["k"], a["qkv"], a["a"], s["da"], a["lse"], s["dq"], s["dk"], g["dqkv"], B, Hh, N, 64,
+                                     64**-0.5)
+                else:
+                    ops.attn_bwd(a["q"], a["k"], a["v"], a["a"], s["da"], a["lse"], s["dq"], s["dk"], s["dv"], B, Hh, N, 64, 64**-0.5)
+                ops.qk_norm_rope_bwd(s["dq"], s["dk"], None if ops.v_in_place(N) else s["dv"], a["qkv"],
+                                     self.P(pre + "attention.qk_norm.query_norm.scale"),
+                                     self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], g["dqkv"],
+                                     self.G(pre + "attention.qk_norm.query_norm.scale"), B, N, Hh, 64, rot)
             wgrad(g["dqkv"], a["xm1"], pre + "attention.qkv.weight")
             ops.gemm_nt(g["dqkv"], sh[pre + "attention.qkv.weight|t"], s["dxm"])
             nxt = {}
@@ -321,6 +328,8 @@ class DDTEngine(SprintEngine, PerTokenDecoder):
             w["det_scr"] = torch.empty(max(2 * self.layout.mod_rows * d.embedding_dim, 1 << 22), device=self.dev, dtype=f32)
             if ops.WgradGroups.widths_ok(D, F) and tuning.on("DL_WGRAD_GROUP"):  # grouped weight gradients (ops.WgradGroups)
                 w["tn_slab"] = torch.empty(ops.WgradGroups.slab_floats(D, F), device=self.dev, dtype=f32)
+            if D <= 512 and tuning.on("DL_QK_INPLACE"):  # scale-gradient partials of the in-place QK-norm backward (ops.qk_inplace_ok)
+                w["qk_part"] = torch.empty(1024 * 2 * D, device=self.dev, dtype=f32)
         self.ws, self._ws_key = w, key
         self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)
         if len(self._ws_cache) >= 8:
@@ -605,6 +614,8 @@ class DDTJointEngine(SprintJointEngine, PerTokenDecoder):
             w["det_scr"] = torch.empty(max(2 * self.layout.mod_rows * d.embedding_dim, 1 << 22), device=self.dev, dtype=f32)
             if ops.WgradGroups.widths_ok(D, F) and tuning.on("DL_WGRAD_GROUP"):  # grouped weight gradients (ops.WgradGroups)
                 w["tn_slab"] = torch.empty(ops.WgradGroups.slab_floats(D, F), device=self.dev, dtype=f32)
+            if D <= 512 and tuning.on("DL_QK_INPLACE"):  # scale-gradient partials of the in-place QK-norm backward (ops.qk_inplace_ok)
+                w["qk_part"] = torch.empty(1024 * 2 * D, device=self.dev, dtype=f32)
         self.ws, self._ws_key = w, key
         self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)
         if len(self._ws_cache) >= 8:

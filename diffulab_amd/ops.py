@@ -500,6 +500,12 @@ def attn_bwd_tok(q, k, qkv, out, dout, lse, dqkv, B, H, N, dh, scale):
     _call("dl_attn_bwd_tok", _p(q), _p(k), _p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), B, H, N, dh, float(scale), _s())
 
 
+def qk_inplace_ok(ws: dict, B: int, tokens: int) -> bool:
+    """an engine with the partials scratch ws["qk_part"] takes the token-major attention backward + in-place QK-norm backward for
+    this launch: V in place (<= 256 tokens per sample) and at least 32768 token rows (below that the two-kernel form is faster)"""
+    return ws.get("qk_part") is not None and v_in_place(tokens) and B * tokens >= 32768
+
+
 def qk_norm_rope_bwd_inplace(qkv, scale_q, scale_k, cos, sin, rrms, dqkv, dscale, partials, B, N, H, dh, rot, pos=None) -> bool:
     """the q / k thirds of dqkv: gradient after norm + RoPE (token-major) -> gradient of the pre-norm q / k, in place; dscale f32
     [2, D] += the scale gradients through `partials` (f32 scratch >= 1024 * 2 * D) in a fixed order.  False: inner width > 512"""

@@ -18,7 +18,7 @@ import torch
 from torch import Tensor
 
 from . import ops, tuning
-from .engine import DiTDims, DiTEngine, ParamLayout, _rup, rope_grid_tables
+from .engine import DiTDims, DiTEngine, ParamLayout, _must, _rup, rope_grid_tables
 
 
 @dataclass
@@ -129,6 +129,8 @@ class SprintEngine(DiTEngine):
             w["det_scr"] = torch.empty(max(2 * self.layout.mod_rows * d.embedding_dim, 1 << 22), device=self.dev, dtype=f32)
             if ops.WgradGroups.widths_ok(D, F) and tuning.on("DL_WGRAD_GROUP"):  # grouped weight gradients (ops.WgradGroups)
                 w["tn_slab"] = torch.empty(ops.WgradGroups.slab_floats(D, F), device=self.dev, dtype=f32)
+            if D <= 512 and tuning.on("DL_QK_INPLACE"):  # scale-gradient partials of the in-place QK-norm backward (ops.qk_inplace_ok)
+                w["qk_part"] = torch.empty(1024 * 2 * D, device=self.dev, dtype=f32)
         self.ws, self._ws_key = w, key
         self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)
         if len(self._ws_cache) >= 8:
@@ -196,6 +198,7 @@ class SprintEngine(DiTEngine):
         s = w[f"s{nt}"]
         blocks = list(blocks)
         last = blocks[-1]
+        inplace_qk = ops.qk_inplace_ok(w, B, nt)
         if last in dfe:
             ops.add_bf16(dx, dfe[last], dx)
         ml = last * 6 * D
@@ -222,15 +225,22 @@ class SprintEngine(DiTEngine):
             dx = dx_alt
             wgrad(g["dt1"], a["a"], pre + "attention.proj_out.weight")
             ops.gemm_nt(g["dt1"], sh[pre + "attention.proj_out.weight|t"], s["da"])
-            if ops.v_in_place(nt):
-                ops.attn_bwd_qkv(a["q"], a["k"], a["qkv"], a["a"], s["da"], a["lse"], s["dq"], s["dk"], g["dqkv"], B, Hh, nt, 64,
-                                 64**-0.5)
+            if inplace_qk:  # dQ, dK, dV token-major into dqkv; the QK-norm backward transforms the q / k thirds in place
+                ops.attn_bwd_tok(a["q"], a["k"], a["qkv"], a["a"], s["da"], a["lse"], g["dqkv"], B, Hh, nt, 64, 64**-0.5)
+                _must(ops.qk_norm_rope_bwd_inplace(a["qkv"], self.P(pre + "attention.qk_norm.query_norm.scale"),
+                                                    self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], g["dqkv"],
+                                                    self.G(pre + "attention.qk_norm.query_norm.scale"), w["qk_part"], B, nt, Hh, 64, rot,
+                                                    pos=pos))
             else:
-                ops.attn_bwd(a["q"], a["k"], a["v"], a["a"], s["da"], a["lse"], s["dq"], s["dk"], s["dv"], B, Hh, nt, 64, 64**-0.5)
-            ops.qk_norm_rope_bwd(s["dq"], s["dk"], None if ops.v_in_place(nt) else s["dv"], a["qkv"],
-                                 self.P(pre + "attention.qk_norm.query_norm.scale"),
-                                 self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], g["dqkv"],
-                                 self.G(pre + "attention.qk_norm.query_norm.scale"), B, nt, Hh, 64, rot, pos=pos)
+                if ops.v_in_place(nt):
+                    ops.attn_bwd_qkv(a["q"], a["k"], a["qkv"], a["a"], s["da"], a["lse"], s["dq"], s["dk"], g["dqkv"], B, Hh, nt, 64,
+                                     64**-0.5)
+                else:
+                    ops.attn_bwd(a["q"], a["k"], a["v"], a["a"], s["da"], a["lse"], s["dq"], s["dk"], s["dv"], B, Hh, nt, 64, 64**-0.5)
+                ops.qk_norm_rope_bwd(s["dq"], s["dk"], None if ops.v_in_place(nt) else s["dv"], a["qkv"],
+                                     self.P(pre + "attention.qk_norm.query_norm.scale"),
+                                     self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], g["dqkv"],
+                                     self.G(pre + "attention.qk_norm.query_norm.scale"), B, nt, Hh, 64, rot, pos=pos)
             wgrad(g["dqkv"], a["xm1"], pre + "attention.qkv.weight")
             ops.gemm_nt(g["dqkv"], sh[pre + "attention.qkv.weight|t"], s["dxm"])
             nxt = {}

@@ -193,3 +193,38 @@ def test_ddt_joint_encoder_against_reference_fixture_and_oracle(golden):
     m.context_embedder._draw_drop = lambda batch_size, p, device: g["b_u"].to(device) < p
     with torch.no_grad():
         assert rel(m(x=x.to(DEV), timesteps=t.to(DEV), initial_context=ic, p=0.5)["x"], g["b_pred"]) < 1.5e-2
+
+
+@pytest.mark.parametrize("family", ["ddt", "sprint"])
+def test_in_place_qk_backward_path_equals_the_two_kernel_path(family, monkeypatch):
+    """From 32768 token rows per launch the DDT / SPRINT engines take the token-major attention backward + in-place QK-norm backward
+    (ops.qk_inplace_ok) instead of head-major dQ / dK + qk_norm_rope_bwd.  The fixtures above run 1024 rows, i.e. the two-kernel
+    path; here both paths run the same step at B = 128 x 256 tokens and every gradient agrees to bf16 rounding of dQ / dK."""
+    from diffulab_amd import DDT, SprintDiT
+
+    B, H = 128, 32
+    x, t, y = synth.normal("ip.x", (B, 4, H, H)), synth.uniform("ip.t", (B,), lo=0.05, hi=0.95), synth.integers("ip.y", (B,), 10)
+    dy = synth.normal("ip.dy", (B, 4, H, H))
+    grads = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DL_QK_INPLACE", flag)
+        if family == "ddt":
+            m = DDT(simple_ddt=True, **KW)
+        else:
+            m = SprintDiT(simple_dit=True, input_channels=4, output_channels=4, inner_dim=128, embedding_dim=128, num_heads=2, mlp_ratio=4,
+                          patch_size=2, encoder_depth=1, deep_layers_depth=1, decoder_depth=1, n_classes=10, classifier_free=True,
+                          drop_rate=0.75)
+            scores = synth.normal("ip.scores", (B, 256))
+            m._draw_scores = lambda Bn, S, device: scores.to(device)
+        # (adaLN-zero would leave the attention branch without gradient: every parameter gets seeded noise, norm weights around 1)
+        m.load_state_dict({k: synth.normal("ip.p." + k, tuple(v.shape)) * (v.shape[-1] ** -0.5 if v.dim() > 1 else 0.1)
+                           + (1.0 if k.endswith(("norm_1.weight", "norm_2.weight", "scale")) else 0.0) for k, v in m.state_dict().items()})
+        m = m.to(DEV)
+        m.train()
+        pred = m(x=x.to(DEV), timesteps=t.to(DEV), y=y.to(DEV), p=0.0)["x"]
+        (pred * dy.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        assert (m.engine.ws.get("qk_part") is not None) == (flag == "1")
+        grads[flag] = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+    bad = [(n, rel(g, grads["0"][n])) for n, g in grads["1"].items() if rel(g, grads["0"][n]) > 4e-3]
+    assert not bad, bad
