@@ -200,6 +200,9 @@ class PerceiverResampler(nn.Module):
             dy2 = dy2.to(bf).contiguous()
         dlat = self._ln_bwd(dy2, lat_f, self.norm, my, ry, None, grads)
         dx = None
+        # weight gradients through the partial-image forms (dl_gemm_tn_det: the atomics-free tiled kernel where its tile divides,
+        # four token ranges of the widest matrix fill the chip)
+        scr = ops.shared_scratch(dev, 4 * max(D * F, 2 * I * D))
         for i in reversed(range(self.depth)):
             attn, ff = self.layers[i]
             (_, tq), (_, tkv), (_, to), (_, t1), (_, t2) = sh[5 * i: 5 * i + 5]
@@ -208,11 +211,11 @@ class PerceiverResampler(nn.Module):
             dgl = torch.empty(Ml, F, device=dev, dtype=f32)
             ops.gemm_nt(dlat, t2, dgl)
             dw2 = torch.zeros(D, F, device=dev)
-            ops.gemm_tn(dlat, gl, dw2)
+            ops.gemm_tn(dlat, gl, dw2, scratch=scr)
             dpre = torch.empty(Ml, F, device=dev, dtype=bf)
             ops.gelu_bwd(dgl, pre, dpre)
             dw1 = torch.zeros(F, D, device=dev)
-            ops.gemm_tn(dpre, h, dw1)
+            ops.gemm_tn(dpre, h, dw1, scratch=scr)
             dh = torch.empty(Ml, D, device=dev, dtype=bf)
             ops.gemm_nt(dpre, t1, dh)
             del dgl, dpre
@@ -221,7 +224,7 @@ class PerceiverResampler(nn.Module):
             datt = torch.empty(Ml, I, device=dev, dtype=bf)
             ops.gemm_nt(dlat2, to, datt)
             dwo = torch.zeros(D, I, device=dev)
-            ops.gemm_tn(dlat2, att, dwo)
+            ops.gemm_tn(dlat2, att, dwo, scratch=scr)
             dq = torch.empty(B, H, m, 64, device=dev, dtype=bf)
             dk, dv = torch.empty(B, H, Nk, 64, device=dev, dtype=bf), torch.empty(B, H, Nk, 64, device=dev, dtype=bf)
             ops.attn_bwd_ex(q, k, v, att, datt, lse, dq, dk, dv, B, H, m, Nk, 64, scale, kb)
@@ -232,9 +235,9 @@ class PerceiverResampler(nn.Module):
             ops.heads_merge_rope_bwd(dk, dkvx[:, :I], B, H, n, 0, cos, sin, rot)
             ops.heads_merge_rope_bwd(dv, dkvx[:, I:], B, H, n, 0)
             dwq, dwkv = torch.zeros(I, D, device=dev), torch.zeros(2 * I, D, device=dev)
-            ops.gemm_tn(dqf, ln, dwq)
-            ops.gemm_tn(dkvx, xn, dwkv)
-            ops.gemm_tn(dkvl, ln, dwkv)
+            ops.gemm_tn(dqf, ln, dwq, scratch=scr)
+            ops.gemm_tn(dkvx, xn, dwkv, scratch=scr)
+            ops.gemm_tn(dkvl, ln, dwkv, scratch=scr)
             dln0, dln = torch.empty(Ml, D, device=dev, dtype=bf), torch.empty(Ml, D, device=dev, dtype=bf)
             ops.gemm_nt(dqf, tq, dln0)
             ops.gemm_nt(dkvl, tkv, dln, resid=dln0)

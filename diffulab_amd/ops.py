@@ -261,6 +261,21 @@ def gemm_tn_group(probs: list[tuple[Tensor, Tensor, Tensor]], slab: Tensor, max_
     return True
 
 
+_SCRATCH: dict = {}
+
+
+def shared_scratch(device, floats: int) -> Tensor:
+    """grow-only f32 scratch per device for the partial-image forms (gemm_tn / gemm_nt / colsum with scratch=) of modules that own
+    no workspace (REPA projection head, Perceiver resampler).  Its users run on one stream in issue order, each launch pair
+    (partials, fold) completes before the next begins, so one buffer serves them all."""
+    key = (torch.device(device).type, torch.device(device).index)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < floats:
+        buf = torch.empty(int(floats), device=device, dtype=torch.float32)
+        _SCRATCH[key] = buf
+    return buf
+
+
 def wgrad_tile_ok(m_out: int, n_in: int) -> bool:
     """dl_gemm_tn_group has a tile for a [m_out, n_in] weight gradient (whole 384 x 192 or whole 256 x 256 tiles)"""
     return (m_out % 384 == 0 and n_in % 192 == 0) or (m_out % 256 == 0 and n_in % 256 == 0)

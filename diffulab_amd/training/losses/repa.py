@@ -71,22 +71,23 @@ class _ProjMLP(torch.autograd.Function):
             pad[:, :E] = dproj
             dproj = pad
         E8 = _rup(E, 8)
+        scr = ops.shared_scratch(dev, 4 * max(Hd * Hd, Hd * D, E8 * Hd))  # partial images of the weight gradients (dl_gemm_tn_det)
         dw3, db3 = torch.zeros(E8, Hd, device=dev), torch.zeros(E, device=dev)
-        ops.gemm_tn(dproj, h2, dw3, M=E8, N=Hd)
+        ops.gemm_tn(dproj, h2, dw3, M=E8, N=Hd, scratch=scr)
         ops.colsum(dproj, db3, M, E)
         dh2 = torch.empty(M, Hd, device=dev)
         ops.gemm_nt(dproj, t3, dh2, M=M, N=Hd, K=E64)
         dpre2 = torch.empty(M, Hd, device=dev, dtype=bf)
         ops.silu_bwd(dh2, pre2, dpre2)
         dw2, db2 = torch.zeros(Hd, Hd, device=dev), torch.zeros(Hd, device=dev)
-        ops.gemm_tn(dpre2, h1, dw2)
+        ops.gemm_tn(dpre2, h1, dw2, scratch=scr)
         ops.colsum(dpre2, db2, M, Hd)
         dh1 = dh2  # reuse
         ops.gemm_nt(dpre2, t2, dh1)
         dpre1 = torch.empty(M, Hd, device=dev, dtype=bf)
         ops.silu_bwd(dh1, pre1, dpre1)
         dw1, db1 = torch.zeros(Hd, D, device=dev), torch.zeros(Hd, device=dev)
-        ops.gemm_tn(dpre1, x, dw1)
+        ops.gemm_tn(dpre1, x, dw1, scratch=scr)
         ops.colsum(dpre1, db1, M, Hd)
         dfeat = torch.empty(M, D, device=dev, dtype=bf)
         ops.gemm_nt(dpre1, t1, dfeat)
