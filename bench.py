@@ -19,7 +19,8 @@ Extra objects on the JSON line:
                   img/s) as `step_achieved`.
   cpu_baseline -- the CPU oracle (a port of the reference path, oracle/) timed on this host's cores by the protocol of
                   BASELINE.md section 3 / SURVEY 8(d): B=32, 1 warm-up + 3 timed steps, thread count printed; rank 0 at N=1 only.
-  dp           -- N>1: rccl_ranks and the exposed (non-overlapped) part of the gradient all-reduce per step (`--dp-backend gloo`
+  dp           -- N>1: rccl_ranks, the exposed (non-overlapped) part of the gradient all-reduce per step and which schedule of the
+                  exchange the warm-up measurement kept (overlapped buckets | one exchange after the backward) (`--dp-backend gloo`
                   is the dry mode of this branch for boxes with fewer GPUs than ranks; a GPU test runs it on 2 ranks).
   config.loss_curve_rel_err -- 20 AdamW steps of DiT-S/2 against the reference's own fp32 loss curve (committed fixture): the
                   largest / mean per-step relative error of the bf16 HIP path (N=1, outside the timed region).
@@ -459,7 +460,10 @@ def main() -> None:
         tail = reducer.exposed_ms()
         reducer.measure = False
         dp = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "grad_bytes_per_step": model._flat_grad.numel() * 4,
-              "exposed_allreduce_ms_per_step": None if tail is None else round(tail, 3)}
+              "exposed_allreduce_ms_per_step": None if tail is None else round(tail, 3),
+              # how the exchange was scheduled in the timed region: decided by measurement during warm-up steps 4-11 (training/dp.py)
+              "exchange": reducer.tuned or {"mode": "overlapped" if reducer.overlap else "after_backward", "decided": "not tuned (fewer "
+                                            "than 11 warm-up steps or DIFFULAB_DP_OVERLAP pinned)"}}
 
     roof = None
     if rank == 0 and not args.no_roofline:

@@ -13,6 +13,7 @@ micro-step reduces (`no_sync` otherwise).
 from __future__ import annotations
 
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -50,6 +51,16 @@ class GradReducer:
         self._works = []
         self.measure = False  # bench: record how long the compute stream waits in finish() = the exposed part of the reduction
         self.tail_events: list[tuple] = []
+        # Overlap or not is decided by measurement (DIFFULAB_DP_OVERLAP=auto, the default): every heavy kernel of the step is one
+        # workgroup per CU with the CU's whole register file, so a resident communication workgroup makes the kernels beside it
+        # run a second round (foreign workgroups on 8 CUs for half of the step cost 22 %), while the single
+        # exchange after the backward costs its transfer time.  Which is cheaper depends on RCCL's residency on the node at hand:
+        # synchronising steps 4-7 run overlapped, 8-11 with one exchange after the backward, the faster mode (MAX over ranks)
+        # stays.  "1" / "0" pin a mode.
+        mode = os.environ.get("DIFFULAB_DP_OVERLAP", "auto")
+        self.overlap = mode != "0"
+        self.tuned: dict | None = None
+        self._tune = {"step": 0, "marks": []} if (mode == "auto" and self.enabled) else None
 
     # -- called by the engine's backward, ranges arrive high-to-low as blocks finish
     def ready(self, lo: int, hi: int, extra_events=(), flush: bool = False) -> None:
@@ -61,7 +72,7 @@ class GradReducer:
         if hi > lo:
             self._pending.append((lo, hi))
         self._extra.extend(extra_events)
-        if flush or sum(h - l for l, h in self._pending) >= self.bucket_elems:
+        if self.overlap and (flush or sum(h - l for l, h in self._pending) >= self.bucket_elems):
             self._flush()
 
     def _flush(self) -> None:
@@ -110,6 +121,7 @@ class GradReducer:
         self._flush()
         if self.comm is not None:
             self.comm.wait(torch.cuda.current_stream().cuda_stream)
+            self._tune_tick()
             return
         e0 = None
         if self.measure and self.comm_stream is not None:
@@ -124,6 +136,41 @@ class GradReducer:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             self.tail_events.append((e0, e1))
+        self._tune_tick()
+
+    TUNE_SKIP, TUNE_STEPS = 2, 4
+
+    def _tune_tick(self) -> None:
+        """one mark per synchronising step (a stream event: no host sync until the decision); see __init__"""
+        st = self._tune
+        if st is None:
+            return
+        if self.flat.is_cuda:
+            mark = torch.cuda.Event(enable_timing=True)
+            mark.record()
+        else:
+            mark = time.perf_counter()
+        st["marks"].append(mark)
+        st["step"] += 1
+        a, b = self.TUNE_SKIP + self.TUNE_STEPS, self.TUNE_SKIP + 2 * self.TUNE_STEPS
+        if st["step"] == a + 1:  # marks[SKIP .. a] bracket the overlapped steps
+            self.overlap = False
+        elif st["step"] == b + 1:
+            m = st["marks"]
+
+            def span(i: int, j: int) -> float:
+                if self.flat.is_cuda:
+                    m[j].synchronize()
+                    return m[i].elapsed_time(m[j]) / (j - i)
+                return (m[j] - m[i]) * 1e3 / (j - i)
+
+            t = torch.tensor([span(self.TUNE_SKIP, a), span(a, b)], dtype=torch.float64, device=self.flat.device if self.flat.is_cuda else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)  # every rank takes the same decision
+            t_overlap, t_after = float(t[0]), float(t[1])
+            self.overlap = t_overlap <= 1.01 * t_after
+            self.tuned = {"mode": "overlapped" if self.overlap else "after_backward", "overlapped_ms_per_step": round(t_overlap, 3),
+                          "after_backward_ms_per_step": round(t_after, 3)}
+            self._tune = None
 
     def exposed_ms(self) -> float | None:
         """mean time the compute stream spent waiting for the collectives in finish() over the measured steps"""

@@ -54,6 +54,33 @@ def _worker(rank: int, world: int, port: int, out):
     red2.ready(0, n)
     red2.finish()
     ok &= bool((g2 == rank + 1).all())
+    # overlapped buckets or one exchange after the backward is decided by measurement (DIFFULAB_DP_OVERLAP=auto): synchronising steps
+    # 4-7 run overlapped, 8-11 with everything reduced in finish(), then every rank keeps the same (MAX-over-ranks faster) mode;
+    # the sums are right in every step of either mode
+    g4 = torch.zeros(n)
+    red4 = GradReducer(g4, bucket_bytes=4 * 300)
+    modes = []
+    for it in range(13):
+        g4.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1) + it)
+        for lo, hi in ranges:
+            red4.ready(lo, hi, flush=(lo == 100))
+        modes.append((red4.overlap, len(red4._works) > 0))
+        red4.ready(0, 100)
+        red4.finish()
+        ok &= bool(torch.equal(g4, expect + world * it))
+    ok &= all(o and wk for o, wk in modes[:7]) and all((not o) and (not wk) for o, wk in modes[7:11])  # (works in flight <=> overlapped)
+    ok &= red4.tuned is not None and red4.tuned["mode"] in ("overlapped", "after_backward") and red4._tune is None
+    ok &= modes[11][0] == (red4.tuned["mode"] == "overlapped") == modes[12][0]
+    out[f"mode{rank}"] = red4.tuned["mode"] if red4.tuned else None
+    os.environ["DIFFULAB_DP_OVERLAP"] = "0"  # pinned: nothing is reduced before finish(), not even on flush=True
+    g5 = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    red5 = GradReducer(g5, bucket_bytes=4 * 300)
+    red5.ready(400, 1000, flush=True)
+    ok &= (not red5._works) and len(red5._pending) == 1 and red5._tune is None
+    red5.ready(0, 400)
+    red5.finish()
+    ok &= bool(torch.equal(g5, expect))
+    os.environ.pop("DIFFULAB_DP_OVERLAP")
     out[rank] = ok
     dist.destroy_process_group()
 
@@ -65,3 +92,4 @@ def test_grad_reducer_two_ranks_gloo():
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     assert all(out[r] for r in range(world)), dict(out)
+    assert out["mode0"] == out["mode1"] and out["mode0"] is not None

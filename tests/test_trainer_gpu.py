@@ -512,17 +512,20 @@ def test_bench_data_parallel_branch_runs_on_two_ranks(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = 29000 + (hash(str(tmp_path)) % 2000)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "16",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "11", "--batch", "16",
            "--dp-backend", "gloo", "--no-roofline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=800, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 3 and line["warmup"] == 2
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 3 and line["warmup"] == 11
     assert line["config"]["global_batch"] == 32 and line["config"]["per_gpu_batch"] == 16 and line["config"]["parallelism"] == "dp2"
     assert abs(line["value"] - 32 * 1e3 / line["ms_per_step"]) / line["value"] < 1e-2  # whole-job images/s over the max-rank time
     dp = line["dp"]
     assert dp["rccl_ranks"] == 2 and dp["backend"] == "gloo" and dp["grad_bytes_per_step"] > 100e6
     assert isinstance(dp["exposed_allreduce_ms_per_step"], float) and dp["exposed_allreduce_ms_per_step"] >= 0.0
+    # the schedule of the exchange was decided by the warm-up measurement (training/dp.py: steps 4-7 overlapped, 8-11 after the backward)
+    ex = dp["exchange"]
+    assert ex["mode"] in ("overlapped", "after_backward") and ex["overlapped_ms_per_step"] > 0 and ex["after_backward_ms_per_step"] > 0
     assert np.isfinite(line["config"]["final_loss"]) and "DRY MODE" in line["data"]
 
 
