@@ -168,7 +168,7 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
     tn_shapes: dict[tuple[str, int, int, int], int] = {}  # weight-gradient launches of the replay: (kernel, R, M, N) -> count
     last_group: list = []  # [probs, slab] of the last grouped weight-gradient launch
     orig = {n: getattr(ops, n) for n in ("gemm_nt", "gemm_nt_swiglu", "gemm_tn", "attn_fwd_qkv", "attn_bwd_qkv", "attn_fwd", "attn_bwd",
-                                         "mlp_dswiglu_recompute", "ln_modulate_gemm_fwd", "ln_modulate_gemm_bwd",
+                                         "attn_bwd_tok", "mlp_dswiglu_recompute", "ln_modulate_gemm_fwd", "ln_modulate_gemm_bwd",
                                          "gemm_nt_qk_norm_rope", "gemm_tn_group")}
 
     def timed(kind: str):
@@ -294,6 +294,14 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
         if rows:
             traffic = round(sum(v["launches"] * (v["fetch_MB"] + v["write_MB"]) for v in rows) * 1e6
                             / sum(v["launches"] for v in rows))
+    if tfiles:  # both roofline fractions per kernel: HBM bytes per launch of the committed PMC pass over this run's launch time
+        for k, v in kernels.items():
+            rows = [r for n, r in t.items() if n.startswith(k.replace(",", ", "))]
+            if rows:
+                mb = sum(r["launches"] * (r["fetch_MB"] + r["write_MB"]) for r in rows) / sum(r["launches"] for r in rows)
+                v["hbm_GBps"] = round(mb * 1e6 / (v["avg_launch_us"] * 1e-6) / 1e9, 1)
+                v["hbm_frac_of_8TBps"] = round(v["hbm_GBps"] / 8000.0, 3)
+                v["mfma_frac"] = round(v["tflops"] / PEAK_BF16_TFLOPS, 3)
     hbm_kernels = {k: {"launches_per_step": v[0] // reps, "avg_launch_us": round(v[1] * 1e3 / v[0], 2),
                        "achieved_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1), "frac_of_8TBps": round(v[2] / (v[1] * 1e-3) / 8e12, 3)}
                    for k, v in sorted(hb.items())}
