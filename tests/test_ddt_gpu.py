@@ -228,3 +228,37 @@ def test_in_place_qk_backward_path_equals_the_two_kernel_path(family, monkeypatc
         grads[flag] = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
     bad = [(n, rel(g, grads["0"][n])) for n, g in grads["1"].items() if rel(g, grads["0"][n]) > 4e-3]
     assert not bad, bad
+
+
+def test_ddt_training_step_at_tiled_weight_gradient_dims_against_oracle():
+    """The fixture dims (128 wide, 256 token rows) are below every tiled weight-gradient form.  256 wide / 4 heads at B = 8 x 256 tokens
+    (2048 rows) is the smallest DDT the engine issues like the 512-wide configurations: the blocks' four weight gradients as one
+    atomics-free launch on 256 x 256 tiles (ops.WgradGroups) and the stacked per-token adaLN weight gradient [2048, 3584]^T [2048, 256]
+    through the same kernel (ws["tmod_slab"]); prediction and every parameter gradient against the fp32 oracle."""
+    from diffulab_amd import DDT
+
+    kw = dict(KW, inner_dim=256, num_heads=4)
+    cfg = oddt.DDTConfig(**kw)
+    shapes = oddt.param_shapes(cfg)
+    m = DDT(simple_ddt=True, **kw)
+    m.load_state_dict(synth.dit_params(shapes, seed=93))
+    m = m.to(DEV)
+    B, H = 8, 32
+    x, t, y = synth.normal("dt.x", (B, 4, H, H)), synth.uniform("dt.t", (B,), lo=0.05, hi=0.95), synth.integers("dt.y", (B,), 10)
+    dy = synth.normal("dt.dy", (B, 4, H, H))
+    m.train()
+    pred = m(x=x.to(DEV), timesteps=t.to(DEV), y=y.to(DEV), p=0.0)["x"]
+    (pred * dy.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    ws = m.engine.ws
+    assert ws.get("tn_slab") is not None and ws.get("tmod_slab") is not None  # the tiled forms were the ones that ran
+    Pr = {k: v.requires_grad_(True) for k, v in synth.dit_params(shapes, seed=93).items()}
+    ref = oddt.ddt_forward(Pr, x, t, y, cfg)
+    (ref * dy).sum().backward()
+    assert rel(pred, ref) < 1.5e-2
+    bad = []
+    for n, p in m.named_parameters():
+        tol = 8e-2 if n.endswith(("bias", "scale")) or "norm" in n else 4e-2
+        if rel(p.grad, Pr[n].grad) > tol:
+            bad.append((n, rel(p.grad, Pr[n].grad)))
+    assert not bad, bad

@@ -353,3 +353,40 @@ def test_sprint_joint_ragged_context_length_against_oracle():
     assert rel(pred, po) < 1.5e-2
     (po * dy).sum().backward()
     _check_grads(m, {n: v.grad for n, v in Pr.items()}, {n for n, v in Pr.items() if v.grad is None})
+
+
+def test_sprint_training_step_at_tiled_weight_gradient_dims_against_oracle():
+    """256 wide / 4 heads at B = 32 x 256 tokens: the encoder / decoder stages run 8192 token rows and the deep stage 2048 (64 kept
+    tokens per sample), so every block's four weight gradients go through ONE atomics-free launch on 256 x 256 tiles (ops.WgradGroups,
+    the form the 512-wide configurations train with) -- the fixture dims above (128 wide) never reach it.  Prediction and every
+    parameter gradient against the fp32 oracle."""
+    from diffulab_amd import SprintDiT
+
+    kw = dict(KW, inner_dim=256, embedding_dim=128, num_heads=4)
+    cfg = osprint.SprintConfig(**kw)
+    shapes = osprint.param_shapes(cfg)
+    P0 = synth.dit_params({k: v for k, v in shapes.items() if k != "mask_token"}, seed=67)
+    P0["mask_token"] = synth.normal("sp.mask2", shapes["mask_token"]) * 0.5
+    m = SprintDiT(simple_dit=True, **kw)
+    m.load_state_dict(P0)
+    m = m.to(DEV)
+    B, H = 32, 32
+    x, t, y = synth.normal("sq.x", (B, 4, H, H)), synth.uniform("sq.t", (B,), lo=0.05, hi=0.95), synth.integers("sq.y", (B,), 10)
+    dy = synth.normal("sq.dy", (B, 4, H, H))
+    scores = synth.normal("sq.scores", (B, 256))
+    m.train()
+    _inject(m, scores=scores)
+    pred = m(x=x.to(DEV), timesteps=t.to(DEV), y=y.to(DEV), p=0.0)["x"]
+    (pred * dy.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    assert m.engine.ws.get("tn_slab") is not None
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P0.items()}
+    ref = osprint.sprint_forward(Pr, x, t, y, cfg, kept=osprint.kept_indices(scores, 64))
+    (ref * dy).sum().backward()
+    assert rel(pred, ref) < 1.5e-2
+    bad = []
+    for n, p in m.named_parameters():
+        tol = 8e-2 if n.endswith(("bias", "scale", "mask_token")) or "norm" in n else 4e-2
+        if rel(p.grad, Pr[n].grad) > tol:
+            bad.append((n, rel(p.grad, Pr[n].grad)))
+    assert not bad, bad
