@@ -34,8 +34,13 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# the host driver of this pool only supports dmabuf IPC: without this RCCL's buffer exchange between the ranks' processes fails with
+# `hipIpcGetMemHandle: invalid argument`.  It is exported on the boxes already; a launch line that builds its own environment
+# (torch.distributed.run --no-python, a scheduler wrapper) may drop it, so it is pinned before the HIP runtime loads.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
