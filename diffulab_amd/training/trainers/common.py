@@ -81,6 +81,8 @@ class Trainer(ABC):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world > 1:  # RCCL between the ranks' processes needs dmabuf IPC on hosts whose driver has no legacy IPC (a no-op elsewhere;
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # read when the HIP runtime initialises, i.e. before the first GPU call)
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
             self.device = torch.device("cuda", local)
