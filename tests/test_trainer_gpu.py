@@ -567,7 +567,16 @@ def test_graphed_training_step_follows_the_eager_trajectory():
             losses.append(out["loss"].item())
         captured = graphed and any(v not in (None, False) for v in gs._graphs.values())
         st = [v for v in opt.state.values() if "m" in v and v["m"].numel() == m._flat.numel()][0]
-        return m._flat.clone(), losses, int(st["step"]), captured
+        res = (m._flat.clone(), losses, int(st["step"]), captured)
+        if graphed:  # the captured graphs die before the buffers their nodes point to, on an idle device
+            torch.cuda.synchronize()
+            gs._graphs.clear()
+            del gs
+            import gc
+
+            gc.collect()
+            torch.cuda.synchronize()
+        return res
 
     pe, le, se, _ = run(False)
     pg, lg, sg, captured = run(True)
