@@ -372,6 +372,39 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
             "hbm_bound_kernels": hbm_kernels, "dominant_kernel_alone": alone}
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without an external launcher: the parent starts N fresh child processes of this script (one rank
+    per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), relays their output -- rank 0 prints the JSON
+    line -- and returns the worst exit status.  The parent has not initialised the HIP runtime (importing torch does not) and
+    replaces no process image: the ranks are ordinary children (accelerate's `split_batches=True` launch, trainers/common.py:103-109,
+    is one process per GPU as well)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:  # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    codes = []
+    try:
+        for p in procs:
+            codes.append(p.wait())
+            if codes[-1] != 0:  # a rank died: the others would wait in a collective forever
+                for q in procs:
+                    if q.poll() is None:
+                        q.terminate()
+    except KeyboardInterrupt:
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        raise
+    return max((abs(c) for c in codes), default=1)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -386,12 +419,20 @@ def main() -> None:
                     "(tests/test_trainer_gpu.py); its throughput number means nothing")
     ap.add_argument("--trainer-mode", action="store_true", help="secondary number: the step as BaseTrainer.training_step runs it "
                     "with the shipped defaults (per-loss .item() read-back every step, fused EMA update every step)")
+    ap.add_argument("--launch-check", action="store_true", help="print this rank's launch environment and exit before any GPU "
+                    "call (tests/test_host_logic.py checks the self-launch path on the CPU container with it)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))  # plain `python bench.py --gpus N`: this process becomes the launcher (never touches a GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run or without WORLD_SIZE"
+    if args.launch_check:
+        print(json.dumps({"rank": rank, "local_rank": local, "world": world, "master": os.environ.get("MASTER_ADDR"),
+                          "port": os.environ.get("MASTER_PORT"), "cuda_initialized": torch.cuda.is_initialized()}), flush=True)
+        return
     if args.dp_backend == "gloo":
         local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
@@ -472,11 +513,12 @@ def main() -> None:
             step()
         tail = reducer.exposed_ms()
         reducer.measure = False
+        assert dist.get_world_size() == args.gpus
         dp = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "grad_bytes_per_step": model._flat_grad.numel() * 4,
               "exposed_allreduce_ms_per_step": None if tail is None else round(tail, 3),
-              # how the exchange was scheduled in the timed region: decided by measurement during warm-up steps 4-11 (training/dp.py)
+              # how the exchange was scheduled in the timed region: decided by measurement during warm-up steps 2-13 (training/dp.py)
               "exchange": reducer.tuned or {"mode": "overlapped" if reducer.overlap else "after_backward", "decided": "not tuned (fewer "
-                                            "than 11 warm-up steps or DIFFULAB_DP_OVERLAP pinned)"}}
+                                            "than 14 warm-up steps or DIFFULAB_DP_OVERLAP pinned)"}}
 
     roof = None
     if rank == 0 and not args.no_roofline:
@@ -493,8 +535,8 @@ def main() -> None:
             "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "DiT-S/2 (MMDiT simple_dit 384/6 heads/12 blocks, patch 2, 39.9M params) rectified-flow "
-                                   "train step on 4x32x32 latents (256 tokens), AdamW, label-drop 0.1",
+            # (< 120 characters: the driver's parser cuts longer strings and drops the keys behind them)
+            "config": {"workload": "DiT-S/2 384/6h/12L p2 39.9M rectified-flow train step, 4x32x32 latents, AdamW, p_drop 0.1",
                        "global_batch": world * B, "per_gpu_batch": B, "tokens_per_image": 256,
                        "parallelism": f"dp{world}", "flops_per_image": train_flops_per_image(), "final_loss": final_loss,
                        "loss_curve_rel_err": curve},

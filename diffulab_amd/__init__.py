@@ -4,7 +4,14 @@ Same plugin API as the reference (`Diffuser` / `Denoiser` / `Sampler`), hand-wri
 (`libdiffulab_hip.so`, C ABI in include/diffulab_hip.h).  See DESIGN.md.
 """
 
-from . import ops  # noqa: F401
+import os as _os
+
+# RCCL between one-process-per-GPU ranks needs dmabuf IPC on hosts whose driver has no legacy IPC (`hipIpcGetMemHandle: invalid
+# argument` otherwise).  The HIP runtime reads the variable when it initialises, so it is pinned at import time -- before the first
+# GPU call of an ordinary script -- and not in the Trainer (where a script that had already touched the GPU got a silent no-op).
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+from . import ops  # noqa: E402,F401
 from .datasets import BaseDataset, CIFAR10Dataset, ImageNetLatentREPA, MNISTDataset, SyntheticDataset  # noqa: F401
 from .diffuse import Diffuser, Flow, GaussianDiffusion  # noqa: F401
 from .networks import PerceiverResampler, PrecomputedEmbedder  # noqa: F401

@@ -952,11 +952,10 @@ bool launch_attn_small_mfma_fwd(const void* q, const void* k, const void* v, int
                                 float* probs, int64_t B, int64_t n, int64_t H, int64_t dh, float scale, hipStream_t stream) {
   if (dh % 64 || dh > 512 || n > 64 || ldq % 8 || ldkv % 8 || ldo % 4) return false;
   const int lds = 64 * ASM_PITCH * 4 + (int)dh * 128;
-  static bool attr = false;
-  if (!attr) {
-    attr = true;
+  static DevOnce once;
+  (void)dev_cus(once, [] {
     (void)hipFuncSetAttribute((const void*)attn_small_mfma_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * ASM_PITCH * 4 + 512 * 128);
-  }
+  });
   hipLaunchKernelGGL(attn_small_mfma_fwd_k, (int)(B * H), 256, lds, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq,
                      ldkv, (bf16_t*)out, ldo, probs, (int)n, (int)H, (int)dh, scale);
   return true;
@@ -966,11 +965,10 @@ bool launch_attn_small_mfma_bwd(const void* q, const void* k, const void* v, int
                                 int64_t dh, float scale, hipStream_t stream) {
   if (dh % 64 || dh > 512 || n > 64 || ldq % 8 || ldkv % 8 || ldo % 8) return false;
   const int lds = 2 * 64 * ASM_PITCH * 4 + (int)dh * 128;
-  static bool attr = false;
-  if (!attr) {
-    attr = true;
+  static DevOnce once;
+  (void)dev_cus(once, [] {
     (void)hipFuncSetAttribute((const void*)attn_small_mfma_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * ASM_PITCH * 4 + 512 * 128);
-  }
+  });
   hipLaunchKernelGGL(attn_small_mfma_bwd_k, (int)(B * H), 256, lds, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq,
                      ldkv, (const bf16_t*)dout, ldo, probs, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, (int)n, (int)H, (int)dh, scale);
   return true;

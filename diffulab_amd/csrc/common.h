@@ -120,4 +120,26 @@ __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf
 __device__ __forceinline__ float dgelu_f(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
+// One-time launch setup per DEVICE (CU count + the dynamic-LDS attribute of kernels that need more than 64 KiB): keyed on the
+// device that is current at the call, so a host that drives a second GPU from the same process gets the attribute there too; two
+// threads racing the first call both run `setup` (idempotent) and agree on the count.  The only cached state of the library.
+#include <atomic>
+#define DL_MAX_DEVICES 16
+struct DevOnce {
+  std::atomic<int> cus[DL_MAX_DEVICES];
+};
+template <class F>
+static inline int dev_cus(DevOnce& st, F&& setup) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const int slot = (dev >= 0 && dev < DL_MAX_DEVICES) ? dev : -1;
+  int n = slot >= 0 ? st.cus[slot].load(std::memory_order_acquire) : 0;
+  if (n == 0) {
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n <= 0) n = 256;
+    setup();
+    if (slot >= 0) st.cus[slot].store(n, std::memory_order_release);
+  }
+  return n;
+}
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

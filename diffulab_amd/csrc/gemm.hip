@@ -580,16 +580,12 @@ template <int TN_, int NST>
 static int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                       int64_t N, int64_t K, const NtEpilogue& ep_in, int epi, hipStream_t stream) {
   constexpr int LDS = NST * (TBM + TN_) * 128;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n_cu <= 0) n_cu = 256;
+  static DevOnce once;
+  const int n_cu = dev_cus(once, [] {
     (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-  }
+  });
   const int ntiles = (int)((M / TBM) * (N / TN_));
   int grid = n_cu < ntiles ? n_cu : ntiles;
   grid &= ~7;
@@ -1029,14 +1025,10 @@ extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t 
                "dl_gemm_tn: M,N,lda,ldb must be multiples of 8 (M=%lld N=%lld)", (long long)M, (long long)N);
   DL_CHECK_ARG((((uintptr_t)A | (uintptr_t)B) & 15) == 0, "dl_gemm_tn: 16-byte alignment");
   {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-      int dev = 0;
-      (void)hipGetDevice(&dev);
-      (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-      if (n_cu <= 0) n_cu = 256;
+    static DevOnce once;
+    const int n_cu = dev_cus(once, [] {
       (void)hipFuncSetAttribute((const void*)gemm_tn_big_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE);
-    }
+    });
     {  // 384 x 192 ring kernel (gemm_w4.hip) for the shapes its tile divides
       const int rc = launch_tn_w4(A, lda, B, ldb, C, ldc, M, N, R, max_workgroups, (hipStream_t)stream);
       if (rc <= 0) return rc;
@@ -1267,14 +1259,10 @@ extern "C" int dl_conv3x3_wgrad_tn(const void* x, int64_t ldx, int64_t Bn, int64
   const ConvGeom cg = make_conv_geom(H, W, Ci, ldx, Bn * H * W, zero);
   const int nsteps = (int)(R / BK);
   {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-      int dev = 0;
-      (void)hipGetDevice(&dev);
-      (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-      if (n_cu <= 0) n_cu = 256;
+    static DevOnce once;
+    const int n_cu = dev_cus(once, [] {
       (void)hipFuncSetAttribute((const void*)gemm_tn_big_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE);
-    }
+    });
     if (M % WBM == 0 && N % WBN == 0 && nsteps >= 64) {  // same unit / split budget as dl_gemm_tn
       const int tiles_m = (int)(M / WBM), tiles_n = (int)(N / WBN);
       const int budget = (max_workgroups > 0 && max_workgroups < n_cu) ? max_workgroups : n_cu;

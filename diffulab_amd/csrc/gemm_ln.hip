@@ -497,14 +497,10 @@ template <int MODE>
 static int rk_launch(const void* A, int64_t lda, const void* W, int64_t ldw, int64_t M, int64_t N, int64_t K, const RowEpi& ep,
                      hipStream_t stream) {
   constexpr int LDS = 2 * RK_STAGE;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0, n = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+  static DevOnce once;
+  const int n_cu = dev_cus(once, [] {
     (void)hipFuncSetAttribute((const void*)gemm_nt_rows_k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    n_cu = n > 0 ? n : 256;
-  }
+  });
   const int ntiles = (int)((M / RK_BM) * (N / RK_BN));
   int grid = n_cu < ntiles ? n_cu : ntiles;
   grid &= ~7;

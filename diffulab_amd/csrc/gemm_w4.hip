@@ -349,18 +349,13 @@ __global__ __launch_bounds__(256) void tn_group_fold_k(const float* __restrict__
 }
 
 static int w4_cus() {
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n_cu <= 0) n_cu = 256;
+  static DevOnce once;
+  return dev_cus(once, [] {
     (void)hipFuncSetAttribute((const void*)gemm_tn_w4_k, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_tn_group_k<384, 192>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_tn_group_k<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               W4_NST * W4_BK * (256 + 256) * 2);
-  }
-  return n_cu;
+  });
 }
 
 // returns 1 when the shape is not this kernel's (the caller keeps its own path), else the launch status
@@ -397,7 +392,10 @@ extern "C" int dl_gemm_tn_group(const dl_wgrad_t* probs, int n_probs, int64_t R,
                                 dl_stream_t stream) {
   DL_CHECK_ARG(probs && n_probs >= 1 && n_probs <= 4 && slab && R > 0, "dl_gemm_tn_group: 1..4 problems and a slab");
   const int n_cu = w4_cus();
-  if (R % W4_BK || R / W4_BK < 64 || R >= (1ll << 31)) return DL_ERR_UNSUPPORTED;
+  if (R % W4_BK || R / W4_BK < 64 || R >= (1ll << 31)) {
+    dl_set_error("dl_gemm_tn_group: R=%lld must be a multiple of %d, >= %d and < 2^31", (long long)R, W4_BK, 64 * W4_BK);
+    return DL_ERR_UNSUPPORTED;
+  }
   W4Group g{};
   W4Fold f{};
   int ntile = 0;
@@ -407,7 +405,10 @@ extern "C" int dl_gemm_tn_group(const dl_wgrad_t* probs, int n_probs, int64_t R,
     t384 = t384 && probs[i].m_out % 384 == 0 && probs[i].n_in % 192 == 0;
     t256 = t256 && probs[i].m_out % 256 == 0 && probs[i].n_in % 256 == 0;
   }
-  if (!t384 && !t256) return DL_ERR_UNSUPPORTED;
+  if (!t384 && !t256) {
+    dl_set_error("dl_gemm_tn_group: the problems are neither all whole 384 x 192 tiles nor all whole 256 x 256 tiles");
+    return DL_ERR_UNSUPPORTED;
+  }
   const int AMt = t384 ? 384 : 256, BNt = t384 ? 192 : 256;
   for (int i = 0; i < n_probs; ++i) {
     const dl_wgrad_t& q = probs[i];

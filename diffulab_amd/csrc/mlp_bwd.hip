@@ -257,14 +257,10 @@ extern "C" int dl_mlp_dswiglu_recompute(const void* X, int64_t ldx, const void* 
                  (long long)K2);
     return DL_ERR_UNSUPPORTED;
   }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n_cu <= 0) n_cu = 256;
+  static DevOnce once;
+  const int n_cu = dev_cus(once, [] {
     (void)hipFuncSetAttribute((const void*)mlp_dswiglu_rc_k<TU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (RC_TBM + 2 * TU) * 128);
-  }
+  });
   const int ntiles = (int)((M / RC_TBM) * (F / TU));
   int grid = n_cu < ntiles ? n_cu : ntiles;
   grid &= ~7;

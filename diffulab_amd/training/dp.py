@@ -55,8 +55,8 @@ class GradReducer:
         # workgroup per CU with the CU's whole register file, so a resident communication workgroup makes the kernels beside it
         # run a second round (foreign workgroups on 8 CUs for half of the step cost 22 %), while the single
         # exchange after the backward costs its transfer time.  Which is cheaper depends on RCCL's residency on the node at hand:
-        # synchronising steps 4-7 run overlapped, 8-11 with one exchange after the backward, the faster mode (MAX over ranks)
-        # stays.  "1" / "0" pin a mode.
+        # synchronising steps 2-7 run overlapped, 8-13 with one exchange after the backward (median of the backward-to-finish
+        # interval per mode, MAX over ranks); the overlapped default is only left when the single exchange wins by > 3 %.  "1" / "0" pin a mode.
         mode = os.environ.get("DIFFULAB_DP_OVERLAP", "auto")
         self.overlap = mode != "0"
         self.tuned: dict | None = None
@@ -69,6 +69,7 @@ class GradReducer:
         backward, so that what is left for finish() -- the exposed part of the exchange -- is small)."""
         if not (self.enabled and self.sync):
             return
+        self._tune_begin()
         if hi > lo:
             self._pending.append((lo, hi))
         self._extra.extend(extra_events)
@@ -138,38 +139,63 @@ class GradReducer:
             self.tail_events.append((e0, e1))
         self._tune_tick()
 
-    TUNE_SKIP, TUNE_STEPS = 2, 4
+    TUNE_SKIP, TUNE_STEPS, TUNE_MARGIN = 2, 6, 1.03
 
-    def _tune_tick(self) -> None:
-        """one mark per synchronising step (a stream event: no host sync until the decision); see __init__"""
+    def _tune_begin(self) -> None:
+        """first ready() of a synchronising step: the start mark of the interval the decision is taken on -- from the first final
+        gradient range to the end of finish(), i.e. the part of the step the exchange can influence.  Dataloader stalls, loss
+        read-backs, EMA and logging between two backward passes are outside of it."""
         st = self._tune
-        if st is None:
+        if st is None or st.get("open") is not None:
             return
         if self.flat.is_cuda:
             mark = torch.cuda.Event(enable_timing=True)
             mark.record()
         else:
             mark = time.perf_counter()
-        st["marks"].append(mark)
+        st["open"] = mark
+
+    def _tune_tick(self) -> None:
+        """end mark of a synchronising step (stream events: no host sync until the decision); see __init__"""
+        st = self._tune
+        if st is None:
+            return
+        start = st.pop("open", None)
+        if self.flat.is_cuda:
+            mark = torch.cuda.Event(enable_timing=True)
+            mark.record()
+        else:
+            mark = time.perf_counter()
+        if start is not None:
+            st["marks"].append((start, mark))
         st["step"] += 1
         a, b = self.TUNE_SKIP + self.TUNE_STEPS, self.TUNE_SKIP + 2 * self.TUNE_STEPS
-        if st["step"] == a + 1:  # marks[SKIP .. a] bracket the overlapped steps
+        if st["step"] == a:  # steps [SKIP, a) ran overlapped
             self.overlap = False
-        elif st["step"] == b + 1:
+        elif st["step"] == b:
             m = st["marks"]
 
-            def span(i: int, j: int) -> float:
+            def median_ms(i: int, j: int) -> float:
                 if self.flat.is_cuda:
-                    m[j].synchronize()
-                    return m[i].elapsed_time(m[j]) / (j - i)
-                return (m[j] - m[i]) * 1e3 / (j - i)
+                    m[j - 1][1].synchronize()
+                    v = sorted(x.elapsed_time(y) for x, y in m[i:j])
+                else:
+                    v = sorted((y - x) * 1e3 for x, y in m[i:j])
+                return v[len(v) // 2] if v else 0.0
 
-            t = torch.tensor([span(self.TUNE_SKIP, a), span(a, b)], dtype=torch.float64, device=self.flat.device if self.flat.is_cuda else "cpu")
+            t = torch.tensor([median_ms(self.TUNE_SKIP, a), median_ms(a, b)], dtype=torch.float64,
+                             device=self.flat.device if self.flat.is_cuda else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)  # every rank takes the same decision
             t_overlap, t_after = float(t[0]), float(t[1])
-            self.overlap = t_overlap <= 1.01 * t_after
+            # the overlapped schedule is the default and is only left for a clear win of the single exchange
+            self.overlap = t_overlap <= self.TUNE_MARGIN * t_after
             self.tuned = {"mode": "overlapped" if self.overlap else "after_backward", "overlapped_ms_per_step": round(t_overlap, 3),
-                          "after_backward_ms_per_step": round(t_after, 3)}
+                          "after_backward_ms_per_step": round(t_after, 3),
+                          "interval": "first final gradient range -> end of finish(), median of %d steps per mode" % self.TUNE_STEPS}
+            if (dist.get_rank(self.group) if dist.is_initialized() else 0) == 0:
+                import logging
+
+                logging.getLogger("diffulab_amd.dp").info("gradient exchange schedule: %s", self.tuned)
             self._tune = None
 
     def exposed_ms(self) -> float | None:

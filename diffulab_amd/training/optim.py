@@ -116,6 +116,16 @@ class FusedAdamW(torch.optim.Optimizer):
         st.clear()
         st["step"], st["m"], st["v"] = (steps.pop() if steps else 0), m, v
 
+    @staticmethod
+    def _adopt_reference_param_state(st: dict, p: Tensor) -> None:
+        """a parameter OUTSIDE the arena (REPA projector / resampler tensors that share the denoiser's param group,
+        examples/train_repa.py) resumed from a torch.optim.AdamW checkpoint: rename exp_avg / exp_avg_sq to this class's m / v"""
+        if "m" not in st and "exp_avg" in st and "exp_avg_sq" in st:
+            st["m"] = st.pop("exp_avg").to(device=p.device, dtype=torch.float32).contiguous()
+            st["v"] = st.pop("exp_avg_sq").to(device=p.device, dtype=torch.float32).contiguous()
+            st.pop("max_exp_avg_sq", None)
+            st["step"] = int(st.get("step", 0))
+
     def _flat(self, group) -> tuple[Tensor, Tensor, list] | None:
         """(param arena, grad arena, parameters NOT in it) when (most of) the group lives in one flat arena -- e.g. a denoiser's
         arena plus the few tensors of an auxiliary loss head (REPA projector) in the same param group -- else None"""
@@ -164,10 +174,13 @@ class FusedAdamW(torch.optim.Optimizer):
                 if flat is not None:
                     pb, gb, rest = flat
                     st = self.state[self._arena_key(group, rest)]
+                    if "m" not in st:
+                        raise RuntimeError("graph mode needs the arena moments: run one eager step() after loading a checkpoint")
                     ops.adamw_step_dev(pb, gb, st["m"], st["v"], hyper)
                 for p in rest:
                     if p.grad is not None:
                         st = self.state[p]
+                        self._adopt_reference_param_state(st, p)
                         ops.adamw_step_dev(p.data, p.grad, st["m"], st["v"], hyper)
                 continue
             flat = self._flat(group)
@@ -200,6 +213,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     if p.grad is None:
                         continue
                     st = self.state[p]
+                    self._adopt_reference_param_state(st, p)
                     if not st:
                         st["step"], st["m"], st["v"] = 0, torch.zeros_like(p.data), torch.zeros_like(p.data)
                     if st["m"].device != p.device:

@@ -81,8 +81,13 @@ class Trainer(ABC):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world > 1:  # RCCL between the ranks' processes needs dmabuf IPC on hosts whose driver has no legacy IPC (a no-op elsewhere;
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # read when the HIP runtime initialises, i.e. before the first GPU call)
+        if self.world > 1 and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0" and torch.cuda.is_initialized():
+            # (diffulab_amd/__init__.py pins the variable at import; a script that initialised the GPU before importing the package
+            # and runs on a host without legacy IPC would fail much later inside RCCL with `hipIpcGetMemHandle: invalid argument`)
+            import logging
+
+            logging.warning("HSA_ENABLE_IPC_MODE_LEGACY is not '0' and the HIP runtime is already initialised: export "
+                            "HSA_ENABLE_IPC_MODE_LEGACY=0 in the launcher environment if RCCL fails with hipIpcGetMemHandle errors")
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
             self.device = torch.device("cuda", local)

@@ -11,6 +11,13 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+import faulthandler  # noqa: E402
+
+# a host-side crash of the python process (one unreproduced segfault of the GPU suite in round 3) leaves the Python stack of every
+# thread in the driver's pytest.log instead of a bare "Segmentation fault"
+faulthandler.enable(all_threads=True)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -55,12 +55,13 @@ def _worker(rank: int, world: int, port: int, out):
     red2.finish()
     ok &= bool((g2 == rank + 1).all())
     # overlapped buckets or one exchange after the backward is decided by measurement (DIFFULAB_DP_OVERLAP=auto): synchronising steps
-    # 4-7 run overlapped, 8-11 with everything reduced in finish(), then every rank keeps the same (MAX-over-ranks faster) mode;
+    # 2-7 run overlapped, 8-13 with everything reduced in finish() (median of the first-range-to-finish interval per mode), then every
+    # rank keeps the same mode (MAX over ranks; the overlapped default is only left for a > 3 % win of the single exchange);
     # the sums are right in every step of either mode
     g4 = torch.zeros(n)
     red4 = GradReducer(g4, bucket_bytes=4 * 300)
     modes = []
-    for it in range(13):
+    for it in range(16):
         g4.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1) + it)
         for lo, hi in ranges:
             red4.ready(lo, hi, flush=(lo == 100))
@@ -68,9 +69,9 @@ def _worker(rank: int, world: int, port: int, out):
         red4.ready(0, 100)
         red4.finish()
         ok &= bool(torch.equal(g4, expect + world * it))
-    ok &= all(o and wk for o, wk in modes[:7]) and all((not o) and (not wk) for o, wk in modes[7:11])  # (works in flight <=> overlapped)
+    ok &= all(o and wk for o, wk in modes[:8]) and all((not o) and (not wk) for o, wk in modes[8:14])  # (works in flight <=> overlapped)
     ok &= red4.tuned is not None and red4.tuned["mode"] in ("overlapped", "after_backward") and red4._tune is None
-    ok &= modes[11][0] == (red4.tuned["mode"] == "overlapped") == modes[12][0]
+    ok &= modes[14][0] == (red4.tuned["mode"] == "overlapped") == modes[15][0]
     out[f"mode{rank}"] = red4.tuned["mode"] if red4.tuned else None
     os.environ["DIFFULAB_DP_OVERLAP"] = "0"  # pinned: nothing is reduced before finish(), not even on flush=True
     g5 = torch.arange(n, dtype=torch.float32) * (rank + 1)

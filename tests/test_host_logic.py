@@ -3,6 +3,7 @@ respacing, module/state_dict contract, flat-arena layout, optimizer/arena plumbi
 reference outputs (tests/golden/schedules.npz) -- bit-exact."""
 
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -120,3 +121,25 @@ def test_module_contract_and_layout():
         DiTDims(inner_dim=384, num_heads=4).validate()
     with pytest.raises(RuntimeError):
         m(x=torch.zeros(1, 4, 32, 32), timesteps=torch.zeros(1), y=torch.zeros(1, dtype=torch.long))  # CPU: no fallback
+
+
+def test_bench_launches_its_own_ranks_without_touching_a_gpu():
+    """`python bench.py --gpus N` (no external launcher): the parent spawns N children with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set on 127.0.0.1, never initialises the HIP runtime itself and returns the children's status."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--launch-check"], capture_output=True,
+                         text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = sorted((json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")), key=lambda r: r["rank"])
+    assert [r["rank"] for r in rows] == [0, 1, 2] and [r["local_rank"] for r in rows] == [0, 1, 2]
+    assert all(r["world"] == 3 and r["master"] == "127.0.0.1" and not r["cuda_initialized"] for r in rows)
+    assert len({r["port"] for r in rows}) == 1
+    # a failing rank is the launcher's exit status
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check", "--steps", "x"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert bad.returncode != 0
