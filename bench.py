@@ -22,8 +22,9 @@ Extra objects on the JSON line:
   dp           -- N>1: rccl_ranks, the exposed (non-overlapped) part of the gradient all-reduce per step and which schedule of the
                   exchange the warm-up measurement kept (overlapped buckets | one exchange after the backward) (`--dp-backend gloo`
                   is the dry mode of this branch for boxes with fewer GPUs than ranks; a GPU test runs it on 2 ranks).
-  config.loss_curve_rel_err -- 20 AdamW steps of DiT-S/2 against the reference's own fp32 loss curve (committed fixture): the
-                  largest / mean per-step relative error of the bf16 HIP path (N=1, outside the timed region).
+  config.loss_curve_rel_err[_fp32] -- 20 AdamW steps of DiT-S/2 against the reference's own fp32 loss curve (committed fixture): the
+                  largest / mean per-step relative error of the bf16 regime (the timed one) and of the fp32 regime (precision_type="no",
+                  the reference's default; north_star's 1e-4 bar) -- N=1, outside the timed region.
 """
 
 from __future__ import annotations
@@ -106,7 +107,7 @@ def cpu_baseline(batch: int = 32, n_timed: int = 3, budget_s: float = 150.0) -> 
             "sample": f"oracle fp32 DiT-S/2 flow train step, B={batch}, {len(times) - len(timed)} warm-up + {len(timed)} timed steps"}
 
 
-def loss_curve_rel_err(dev) -> dict:
+def loss_curve_rel_err(dev, precision: str = "bf16") -> dict:
     """SURVEY 8(c)(viii) / north_star "loss curve matching CPU reference": 20 AdamW steps of DiT-S/2 (B=4, fixed synthetic data)
     on the HIP path against the curve the REFERENCE itself produced in fp32 (tests/golden/loss_curve.npz, written by
     tests/golden/make_golden.py from /root/reference); returns the largest and the mean per-step relative error.  The oracle
@@ -121,6 +122,7 @@ def loss_curve_rel_err(dev) -> dict:
     ref = np.load(os.path.join(ROOT, "tests", "golden", "loss_curve.npz"))["losses"]
     m = MMDiT(**S2)
     m.load_state_dict(synth.dit_params(odit.param_shapes(odit.DiTConfig()), seed=7))
+    m.set_precision(precision)  # "bf16": the timed regime; "fp32": precision_type="no", the reference's default (engine_f32.py)
     m = m.to(dev)
     opt = FusedAdamW(m.parameters(), lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8)
     d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=50)
@@ -137,7 +139,7 @@ def loss_curve_rel_err(dev) -> dict:
         got.append(loss.item())
     err = np.abs(np.array(got) - ref) / ref
     return {"steps": len(ref), "max": float(f"{err.max():.3e}"), "mean": float(f"{err.mean():.3e}"),
-            "against": "the reference's fp32 curve (tests/golden/loss_curve.npz); compute dtype here: bf16"}
+            "against": "the reference's fp32 curve (tests/golden/loss_curve.npz)", "compute": precision}
 
 
 def _tn_variant(R: int, M: int, N: int) -> str:
@@ -524,10 +526,11 @@ def main() -> None:
     if rank == 0 and not args.no_roofline:
         roof = roofline_replay(step, model, value / world)
 
-    cpu, curve = None, None
+    cpu, curve, curve32 = None, None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
-        curve = loss_curve_rel_err(dev)
+        curve = loss_curve_rel_err(dev, "bf16")
+        curve32 = loss_curve_rel_err(dev, "fp32")
 
     if rank == 0:
         out = {
@@ -539,7 +542,7 @@ def main() -> None:
             "config": {"workload": "DiT-S/2 384/6h/12L p2 39.9M rectified-flow train step, 4x32x32 latents, AdamW, p_drop 0.1",
                        "global_batch": world * B, "per_gpu_batch": B, "tokens_per_image": 256,
                        "parallelism": f"dp{world}", "flops_per_image": train_flops_per_image(), "final_loss": final_loss,
-                       "loss_curve_rel_err": curve},
+                       "loss_curve_rel_err": curve, "loss_curve_rel_err_fp32": curve32},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if dp is not None:

@@ -1,0 +1,879 @@
+// The fp32-class precision regime of the DiT hot path (the reference's DEFAULT: `precision_type="no"`, training/trainers/common.py:76,105;
+// configs/trainer/default.yaml:4): every activation, every GEMM operand and every accumulation is f32.
+//
+//   * GEMMs run on the f32-input matrix instruction of CDNA4, v_mfma_f32_32x32x2_f32 (exact f32: bit-for-bit a k-ordered fmaf chain,
+//     157 TF/s dense peak = 1/16 of the bf16 rate; no xf32 / TF32 exists on gfx950), straight on the f32 parameter arena and the f32
+//     activations -- no bf16 shadows, no split operands.  One kernel family serves every product of the step through two layout flags
+//     (NT = nn.Linear forward, NN = its data gradient, TN = its weight gradient) and a two-level batch stride (sample, head), which also
+//     gives the attention matmuls (scores, P V and their four gradients) without a head split or transpose pass.
+//   * attention materialises the [B, H, N, N] probabilities in HBM (288 GB: a DiT-S/2 block at B = 256 keeps 403 MB of them for the
+//     backward); the regime exists for numerical parity with the reference's fp32 path (north-star: loss curve to 1e-4), not for speed.
+//   * row kernels (LayerNorm + modulate, QK-RMSNorm + RoPE, SwiGLU, softmax) are one wave per token row with f32 I/O; every per-sample
+//     column sum has ONE writer (a workgroup owns a sample), so the regime is bit-reproducible without atomics.
+//
+// Reference arithmetic restated per kernel: see the entry points' comments in include/diffulab_hip.h.
+#include "common.h"
+
+// ============================================================================================================ GEMM
+#define FG_BM 128
+#define FG_BN 128
+#define FG_BK 16
+#define FG_LD (FG_BM + 4)  // LDS pitch of a k-row (floats): 16-byte aligned rows, +4 breaks the power-of-two stride
+
+struct F32GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  int64_t lda, ldb, ldc;
+  int M, N, K;
+  int nb2;
+  int64_t sa1, sa2, sb1, sb2, sc1, sc2;
+  float alpha;
+  const float* bias;
+  int act;
+  float* pre_out;
+  int accumulate;
+  int splits;
+  int kchunk;             // K range of one split (multiple of FG_BK)
+  int64_t split_stride;   // floats between the partial images of two splits (>= M * N); splits > 1: C is the scratch, ldc == N
+};
+
+// operand tile -> registers: 2 x float4 per thread.  KMAJOR: the operand is [rows, K] with K contiguous (float4 along k);
+// else [K, rows] with rows contiguous (float4 along the row index).
+template <bool KMAJOR, bool VEC>
+__device__ __forceinline__ void fg_load(const float* __restrict__ P, int64_t ld, int row0, int nrows, int k0, int kend, int tid,
+                                        f32x4_t (&r)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 256 * i;
+    int row, k;
+    if (KMAJOR) {
+      row = row0 + (idx >> 2);
+      k = k0 + ((idx & 3) << 2);
+    } else {
+      k = k0 + (idx >> 5);
+      row = row0 + ((idx & 31) << 2);
+    }
+    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+    if (KMAJOR) {
+      if (row < nrows) {
+        const float* p = P + (int64_t)row * ld + k;
+        if (VEC) {
+          if (k < kend) v = *(const f32x4_t*)p;  // (VEC: K % 4 == 0 and kchunk % 16 == 0, a float4 is inside or outside)
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (k + c < kend) v[c] = p[c];
+        }
+      }
+    } else {
+      if (k < kend) {
+        const float* p = P + (int64_t)k * ld + row;
+        if (VEC) {
+          if (row < nrows) v = *(const f32x4_t*)p;  // (VEC: rows % 4 == 0)
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (row + c < nrows) v[c] = p[c];
+        }
+      }
+    }
+    r[i] = v;
+  }
+}
+// registers -> LDS image [FG_BK][FG_LD] (k-major planes: the MFMA fragment reads are then 32 consecutive floats per half-wave)
+template <bool KMAJOR>
+__device__ __forceinline__ void fg_stage(float* __restrict__ S, int tid, const f32x4_t (&r)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 256 * i;
+    if (KMAJOR) {
+      const int row = idx >> 2, k = (idx & 3) << 2;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) S[(k + c) * FG_LD + row] = r[i][c];
+    } else {
+      const int k = idx >> 5, row = (idx & 31) << 2;
+      *(f32x4_t*)(S + k * FG_LD + row) = r[i];
+    }
+  }
+}
+
+// C[M, N] = alpha * opA(A) opB(B) (+ bias, activation, accumulate) on v_mfma_f32_32x32x2_f32: 128 x 128 tile per 256-thread
+// workgroup, 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles (64 accumulator registers); k-steps of 16 through a two-slot LDS
+// ring (one barrier per step), the next step's operands prefetched into registers under the current step's 32 MFMAs
+// (32 x 64 = 2048 matrix-pipe cycles per wave and step against 4 global loads and 32 ds_read_b32: the loop is MFMA-bound).
+template <bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(256) void f32_gemm_k(const F32GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2][FG_BK * FG_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.y * FG_BM, n0 = blockIdx.x * FG_BN;
+  int z = blockIdx.z;
+  const int sp = z % g.splits;
+  z /= g.splits;
+  const int b1 = z / g.nb2, b2 = z - b1 * g.nb2;
+  const float* A = g.A + b1 * g.sa1 + b2 * g.sa2;
+  const float* B = g.B + b1 * g.sb1 + b2 * g.sb2;
+  const int kbeg = sp * g.kchunk;
+  const int kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+  const int nsteps = (kend - kbeg + FG_BK - 1) / FG_BK;
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4_t ra[2], rb[2];
+  if (nsteps > 0) {
+    fg_load<!TA, VEC>(A, g.lda, m0, g.M, kbeg, kend, tid, ra);
+    fg_load<!TB, VEC>(B, g.ldb, n0, g.N, kbeg, kend, tid, rb);
+    fg_stage<!TA>(lds[0][0], tid, ra);
+    fg_stage<!TB>(lds[0][1], tid, rb);
+  }
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < nsteps) {
+      fg_load<!TA, VEC>(A, g.lda, m0, g.M, kbeg + (s + 1) * FG_BK, kend, tid, ra);
+      fg_load<!TB, VEC>(B, g.ldb, n0, g.N, kbeg + (s + 1) * FG_BK, kend, tid, rb);
+    }
+    const float* As = lds[cur][0] + wr * 64 + li;
+    const float* Bs = lds[cur][1] + wc * 64 + li;
+#pragma unroll
+    for (int kk = 0; kk < FG_BK / 2; ++kk) {
+      const int k = 2 * kk + lh;
+      const float a0 = As[k * FG_LD], a1 = As[k * FG_LD + 32];
+      const float b0 = Bs[k * FG_LD], b1v = Bs[k * FG_LD + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1v, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1v, acc[1][1], 0, 0, 0);
+    }
+    if (s + 1 < nsteps) {
+      fg_stage<!TA>(lds[cur ^ 1][0], tid, ra);
+      fg_stage<!TB>(lds[cur ^ 1][1], tid, rb);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane (li, lh) holds C[(r & 3) + 8 (r >> 2) + 4 lh][li] of every 32 x 32 tile: 128-byte row segments per store
+  float* C = g.C + (g.splits > 1 ? (int64_t)z * g.splits * g.split_stride + (int64_t)sp * g.split_stride : b1 * g.sc1 + b2 * g.sc2);
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int col = n0 + wc * 64 + tj * 32 + li;
+      if (col >= g.N) continue;
+      const float bias = (g.bias && g.splits == 1) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row >= g.M) continue;
+        const int64_t o = (int64_t)row * g.ldc + col;
+        if (g.splits > 1) {
+          C[o] = acc[ti][tj][r];
+          continue;
+        }
+        float v = g.alpha * acc[ti][tj][r] + bias;
+        if (g.pre_out) g.pre_out[b1 * g.sc1 + b2 * g.sc2 + o] = v;
+        if (g.act == DL_ACT_SILU) v = v / (1.0f + expf(-v));
+        if (g.accumulate) v += C[o];
+        C[o] = v;
+      }
+    }
+}
+
+// second stage of a split-K launch: C (+)= act(alpha * sum_p partial_p + bias), partials added in a fixed order
+__global__ void f32_gemm_fold_k(const float* __restrict__ part, int splits, int64_t stride, float* __restrict__ C, int64_t ldc, int M,
+                                int N, float alpha, const float* __restrict__ bias, int act, float* __restrict__ pre_out,
+                                int accumulate) {
+  const int64_t n = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
+    float s = part[i];
+    for (int p = 1; p < splits; ++p) s += part[(int64_t)p * stride + i];
+    float v = alpha * s + (bias ? bias[col] : 0.f);
+    const int64_t o = (int64_t)row * ldc + col;
+    if (pre_out) pre_out[o] = v;
+    if (act == DL_ACT_SILU) v = v / (1.0f + expf(-v));
+    if (accumulate) v += C[o];
+    C[o] = v;
+  }
+}
+
+static inline int grid_1d(int64_t n, int per_block = 256, int cap = 4096) {
+  int64_t g = (n + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  return (int)(g > cap ? cap : g);
+}
+
+extern "C" int dl_f32_gemm(const dl_f32_gemm_t* d, dl_stream_t stream) {
+  DL_CHECK_ARG(d && d->A && d->B && d->C, "dl_f32_gemm: null operand");
+  DL_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0 && d->M < (1ll << 31) && d->N < (1ll << 31) && d->K < (1ll << 31),
+               "dl_f32_gemm: M=%lld N=%lld K=%lld", (long long)d->M, (long long)d->N, (long long)d->K);
+  DL_CHECK_ARG(d->lda >= (d->trans_a ? d->M : d->K) && d->ldb >= (d->trans_b ? d->N : d->K) && d->ldc >= d->N,
+               "dl_f32_gemm: leading dimension below the logical width (lda=%lld ldb=%lld ldc=%lld)", (long long)d->lda,
+               (long long)d->ldb, (long long)d->ldc);
+  DL_CHECK_ARG(d->batch1 >= 1 && d->batch2 >= 1 && d->batch1 * d->batch2 <= 65535, "dl_f32_gemm: batch %lld x %lld",
+               (long long)d->batch1, (long long)d->batch2);
+  DL_CHECK_ARG(d->act == DL_ACT_NONE || d->act == DL_ACT_SILU, "dl_f32_gemm: activation %d", d->act);
+  DL_CHECK_ARG((((uintptr_t)d->A | (uintptr_t)d->B | (uintptr_t)d->C | (uintptr_t)d->bias | (uintptr_t)d->pre_out) & 3) == 0,
+               "dl_f32_gemm: 4-byte alignment");
+  const int64_t nbatch = d->batch1 * d->batch2;
+  F32GemmArgs g;
+  g.A = d->A; g.B = d->B; g.C = d->C;
+  g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc;
+  g.M = (int)d->M; g.N = (int)d->N; g.K = (int)d->K;
+  g.nb2 = (int)d->batch2;
+  g.sa1 = d->stride_a1; g.sa2 = d->stride_a2; g.sb1 = d->stride_b1; g.sb2 = d->stride_b2; g.sc1 = d->stride_c1; g.sc2 = d->stride_c2;
+  g.alpha = d->alpha; g.bias = d->bias; g.act = d->act; g.pre_out = d->pre_out; g.accumulate = d->accumulate;
+  g.splits = 1; g.kchunk = (g.K + FG_BK - 1) / FG_BK * FG_BK; g.split_stride = 0;
+  const int tm = cdiv(d->M, FG_BM), tn = cdiv(d->N, FG_BN);
+  // split the contraction when the output has too few tiles to fill the chip (weight gradients over all tokens): every split stores
+  // its partial image into the caller's scratch, a fold adds them in a fixed order (no atomics)
+  const int64_t tiles = (int64_t)tm * tn * nbatch;
+  if (d->scratch && nbatch == 1 && tiles < 192 && d->K >= 1024) {
+    int64_t want = (256 + tiles - 1) / tiles;
+    const int64_t by_k = d->K / 256, by_mem = d->scratch_floats / (d->M * d->N);
+    if (want > by_k) want = by_k;
+    if (want > by_mem) want = by_mem;
+    if (want > 64) want = 64;
+    if (want >= 2) {
+      g.splits = (int)want;
+      g.kchunk = (int)(((d->K + want - 1) / want + FG_BK - 1) / FG_BK * FG_BK);
+      g.splits = (int)((d->K + g.kchunk - 1) / g.kchunk);
+      g.split_stride = d->M * d->N;
+      g.C = d->scratch;
+      g.ldc = d->N;
+    }
+  }
+  const bool vec = (((uintptr_t)d->A | (uintptr_t)d->B) & 15) == 0 && d->lda % 4 == 0 && d->ldb % 4 == 0 && d->stride_a1 % 4 == 0 &&
+                   d->stride_a2 % 4 == 0 && d->stride_b1 % 4 == 0 && d->stride_b2 % 4 == 0 &&
+                   (d->trans_a ? d->M % 4 == 0 : d->K % 4 == 0) && (d->trans_b ? d->N % 4 == 0 : d->K % 4 == 0);
+  const dim3 grid(tn, tm, (unsigned)(nbatch * g.splits));
+  DL_CHECK_ARG(tm <= 65535, "dl_f32_gemm: M=%lld needs more than 65535 row tiles", (long long)d->M);
+#define FG_GO(TA, TB, V) hipLaunchKernelGGL((f32_gemm_k<TA, TB, V>), grid, 256, 0, (hipStream_t)stream, g)
+#define FG_PICK(V)                                 \
+  do {                                             \
+    if (!d->trans_a && !d->trans_b) FG_GO(false, false, V); \
+    else if (!d->trans_a && d->trans_b) FG_GO(false, true, V);  \
+    else if (d->trans_a && !d->trans_b) FG_GO(true, false, V);  \
+    else FG_GO(true, true, V);                     \
+  } while (0)
+  if (vec) FG_PICK(true);
+  else FG_PICK(false);
+#undef FG_PICK
+#undef FG_GO
+  DL_LAUNCH_CHECK();
+  if (g.splits > 1) {
+    hipLaunchKernelGGL(f32_gemm_fold_k, grid_1d(d->M * d->N), 256, 0, (hipStream_t)stream, d->scratch, g.splits, g.split_stride, d->C,
+                       d->ldc, (int)d->M, (int)d->N, d->alpha, d->bias, d->act, d->pre_out, d->accumulate);
+    DL_LAUNCH_CHECK();
+  }
+  return DL_OK;
+}
+
+// ============================================================================================================ row helpers
+#define FR_NJ 4  // float4 chunks per lane: D <= 1024
+template <class T>
+__device__ __forceinline__ void fr_load(const float* __restrict__ p, int D4, int lane, f32x4_t (&v)[FR_NJ], T fill) {
+#pragma unroll
+  for (int j = 0; j < FR_NJ; ++j) {
+    const int c = lane + 64 * j;
+    if (p && c < D4) v[j] = *(const f32x4_t*)(p + 4 * c);
+    else v[j] = f32x4_t{fill, fill, fill, fill};
+  }
+}
+__device__ __forceinline__ void fr_store(float* __restrict__ p, int D4, int lane, const f32x4_t (&v)[FR_NJ]) {
+#pragma unroll
+  for (int j = 0; j < FR_NJ; ++j) {
+    const int c = lane + 64 * j;
+    if (c < D4) *(f32x4_t*)(p + 4 * c) = v[j];
+  }
+}
+__device__ __forceinline__ float fr_sum(const f32x4_t (&v)[FR_NJ]) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < FR_NJ; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+  return wave_sum(s);
+}
+__device__ __forceinline__ float silu32(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float dsilu32(float x) {
+  const float s = 1.0f / (1.0f + expf(-x));
+  return s * (1.0f + x * (1.0f - s));
+}
+
+// ============================================================================================================ LayerNorm + modulate
+// out = (LN(x') w + b) (1 + scale[g]) + shift[g], x' = x + gate[g] t when t != NULL (written to x_out); one wave per row
+__global__ __launch_bounds__(256) void f32_ln_mod_fwd_k(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int64_t ld_mod, int64_t rows_per_mod,
+                                                        float eps, float* __restrict__ out, float* __restrict__ mean_o,
+                                                        float* __restrict__ rstd_o, const float* __restrict__ t,
+                                                        const float* __restrict__ gate, int64_t ld_gate, float* __restrict__ x_out,
+                                                        int64_t M, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D4 = D >> 2;
+  const float invD = 1.0f / (float)D;
+  f32x4_t wv[FR_NJ], bv[FR_NJ];
+  fr_load(w, D4, lane, wv, 1.0f);
+  fr_load(b, D4, lane, bv, 0.0f);
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+    const int64_t grp = row / rows_per_mod;
+    f32x4_t xv[FR_NJ], sc[FR_NJ], sh[FR_NJ];
+    fr_load(x + row * D, D4, lane, xv, 0.f);
+    if (t) {
+      f32x4_t tv[FR_NJ], gv[FR_NJ];
+      fr_load(t + row * D, D4, lane, tv, 0.f);
+      fr_load(gate + grp * ld_gate, D4, lane, gv, 0.f);
+#pragma unroll
+      for (int j = 0; j < FR_NJ; ++j) xv[j] = xv[j] + tv[j] * gv[j];  // mmdit.py:302,308: x + f(...) * gate
+      fr_store(x_out + row * D, D4, lane, xv);
+    }
+    fr_load(scale + grp * ld_mod, D4, lane, sc, 0.f);
+    fr_load(shift + grp * ld_mod, D4, lane, sh, 0.f);
+    const float mu = fr_sum(xv) * invD;
+    f32x4_t dv[FR_NJ];
+#pragma unroll
+    for (int j = 0; j < FR_NJ; ++j) {
+      const bool on = (lane + 64 * j) < D4;
+      dv[j] = on ? xv[j] - mu : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4_t sq[FR_NJ];
+#pragma unroll
+    for (int j = 0; j < FR_NJ; ++j) sq[j] = dv[j] * dv[j];
+    const float rs = 1.0f / sqrtf(fr_sum(sq) * invD + eps);
+#pragma unroll
+    for (int j = 0; j < FR_NJ; ++j) {
+      const f32x4_t y = dv[j] * rs * wv[j] + bv[j];
+      xv[j] = y * (1.0f + sc[j]) + sh[j];
+    }
+    fr_store(out + row * D, D4, lane, xv);
+    if (lane == 0) {
+      mean_o[row] = mu;
+      rstd_o[row] = rs;
+    }
+  }
+}
+
+extern "C" int dl_f32_ln_modulate_fwd(const float* x, const float* w, const float* b, const float* scale, const float* shift,
+                                      int64_t ld_mod, int64_t rows_per_mod, float eps, float* out, float* mean, float* rstd,
+                                      const float* t, const float* gate, int64_t ld_gate, float* x_out, int64_t M, int64_t D,
+                                      dl_stream_t stream) {
+  DL_CHECK_ARG(x && scale && shift && out && mean && rstd && M > 0, "dl_f32_ln_modulate_fwd: null operand");
+  DL_CHECK_ARG(!t || (gate && x_out && ld_gate % 4 == 0), "dl_f32_ln_modulate_fwd: the gated residual needs t, gate and x_out");
+  DL_CHECK_ARG((w == nullptr) == (b == nullptr), "dl_f32_ln_modulate_fwd: w and b must both be given or both NULL");
+  DL_CHECK_ARG(D % 4 == 0 && D > 0 && D <= 256 * FR_NJ && ld_mod % 4 == 0 && rows_per_mod > 0, "dl_f32_ln_modulate_fwd: D=%lld",
+               (long long)D);
+  DL_CHECK_ARG((((uintptr_t)x | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)out | (uintptr_t)w | (uintptr_t)b | (uintptr_t)t |
+                 (uintptr_t)gate | (uintptr_t)x_out) & 15) == 0, "dl_f32_ln_modulate_fwd: 16-byte alignment");
+  hipLaunchKernelGGL(f32_ln_mod_fwd_k, grid_1d(M, 4), 256, 0, (hipStream_t)stream, x, w, b, scale, shift, ld_mod, rows_per_mod, eps, out,
+                     mean, rstd, t, gate, ld_gate, x_out, M, (int)D);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// backward.  One workgroup (8 waves) owns one modulation group (a sample's rows): dx rows + the group's column sums
+//   S1 = sum d, S2 = sum d xhat, S3 = sum dx_new t   ->   dscale = w S2 + b S1, dshift = S1, dw_partial = (1 + scale) S2,
+//   db_partial = (1 + scale) S1, dgate = S3, every one written by its single producer.
+#define FLB_WAVES 8
+__global__ __launch_bounds__(64 * FLB_WAVES) void f32_ln_mod_bwd_k(
+    const float* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+    const float* __restrict__ scale, int64_t ld_mod, int64_t rows_per_mod, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ dres, float* __restrict__ dx, float* __restrict__ dscale, float* __restrict__ dshift, int64_t ld_dmod,
+    float* __restrict__ dwb, const float* __restrict__ gt, const float* __restrict__ ggate, int64_t ld_gate, float* __restrict__ gdt,
+    float* __restrict__ dgate, int64_t M, int D) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = (float*)smem;  // [FLB_WAVES][3][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D4 = D >> 2;
+  const float invD = 1.0f / (float)D;
+  const int64_t grp = blockIdx.x;
+  f32x4_t wv[FR_NJ], sc[FR_NJ], gv[FR_NJ];
+  fr_load(w, D4, lane, wv, 1.0f);
+  fr_load(scale + grp * ld_mod, D4, lane, sc, 0.f);
+  fr_load(gt ? ggate + grp * ld_gate : nullptr, D4, lane, gv, 0.f);
+  f32x4_t s1[FR_NJ], s2[FR_NJ], s3[FR_NJ];
+#pragma unroll
+  for (int j = 0; j < FR_NJ; ++j) s1[j] = s2[j] = s3[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int64_t r0 = grp * rows_per_mod;
+  const int64_t r1 = (r0 + rows_per_mod < M) ? r0 + rows_per_mod : M;
+  for (int64_t row = r0 + wave; row < r1; row += FLB_WAVES) {
+    f32x4_t d[FR_NJ], xv[FR_NJ];
+    fr_load(dout + row * D, D4, lane, d, 0.f);
+    fr_load(x + row * D, D4, lane, xv, 0.f);
+    const float mu = mean[row], rs = rstd[row];
+    f32x4_t xh[FR_NJ], dy[FR_NJ], t1[FR_NJ], t2[FR_NJ];
+#pragma unroll
+    for (int j = 0; j < FR_NJ; ++j) {
+      const bool on = (lane + 64 * j) < D4;
+      xh[j] = on ? (xv[j] - mu) * rs : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      dy[j] = d[j] * (1.0f + sc[j]) * wv[j];  // gradient w.r.t. xhat
+      t1[j] = dy[j];
+      t2[j] = dy[j] * xh[j];
+      s1[j] += d[j];
+      s2[j] += d[j] * xh[j];
+    }
+    const float m1 = fr_sum(t1) * invD, m2 = fr_sum(t2) * invD;
+    f32x4_t r[FR_NJ];
+    fr_load(dres ? dres + row * D : nullptr, D4, lane, r, 0.f);
+#pragma unroll
+    for (int j = 0; j < FR_NJ; ++j) r[j] = r[j] + (dy[j] - m1 - xh[j] * m2) * rs;
+    fr_store(dx + row * D, D4, lane, r);
+    if (gt) {  // x_in = x_prev + gate * t  ->  dt = gate * dx, dgate += dx * t
+      f32x4_t tv[FR_NJ];
+      fr_load(gt + row * D, D4, lane, tv, 0.f);
+#pragma unroll
+      for (int j = 0; j < FR_NJ; ++j) {
+        s3[j] += r[j] * tv[j];
+        tv[j] = r[j] * gv[j];
+      }
+      fr_store(gdt + row * D, D4, lane, tv);
+    }
+  }
+  // workgroup reduction of the three column sums through LDS, then one writer per column
+#pragma unroll
+  for (int j = 0; j < FR_NJ; ++j) {
+    const int c = lane + 64 * j;
+    if (c < D4) {
+      *(f32x4_t*)(red + (wave * 3 + 0) * D + 4 * c) = s1[j];
+      *(f32x4_t*)(red + (wave * 3 + 1) * D + 4 * c) = s2[j];
+      *(f32x4_t*)(red + (wave * 3 + 2) * D + 4 * c) = s3[j];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 64 * FLB_WAVES) {
+    float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int wv_ = 0; wv_ < FLB_WAVES; ++wv_) {
+      a1 += red[(wv_ * 3 + 0) * D + c];
+      a2 += red[(wv_ * 3 + 1) * D + c];
+      a3 += red[(wv_ * 3 + 2) * D + c];
+    }
+    const float wc = w ? w[c] : 1.0f, bc = b ? b[c] : 0.f, s = 1.0f + scale[grp * ld_mod + c];
+    dscale[grp * ld_dmod + c] = wc * a2 + bc * a1;
+    dshift[grp * ld_dmod + c] = a1;
+    if (dwb) {
+      dwb[(grp * 2 + 0) * D + c] = s * a2;
+      dwb[(grp * 2 + 1) * D + c] = s * a1;
+    }
+    if (gt) dgate[grp * ld_dmod + c] = a3;
+  }
+}
+
+extern "C" int dl_f32_ln_modulate_bwd(const float* dout, const float* x, const float* w, const float* b, const float* scale,
+                                      int64_t ld_mod, int64_t rows_per_mod, const float* mean, const float* rstd, const float* dres,
+                                      float* dx, float* dscale, float* dshift, int64_t ld_dmod, float* dwb_partial, const float* gate_t,
+                                      const float* gate, int64_t ld_gate, float* dt, float* dgate, int64_t M, int64_t D,
+                                      dl_stream_t stream) {
+  DL_CHECK_ARG(dout && x && scale && mean && rstd && dx && dscale && dshift && M > 0, "dl_f32_ln_modulate_bwd: null operand");
+  DL_CHECK_ARG((w == nullptr) == (b == nullptr) && (w != nullptr || dwb_partial == nullptr), "dl_f32_ln_modulate_bwd: affine operands");
+  DL_CHECK_ARG(!gate_t || (gate && dt && dgate && ld_gate % 4 == 0), "dl_f32_ln_modulate_bwd: the gate backward needs gate, dt and dgate");
+  DL_CHECK_ARG(D % 4 == 0 && D > 0 && D <= 256 * FR_NJ && ld_mod % 4 == 0 && rows_per_mod > 0 && M % rows_per_mod == 0,
+               "dl_f32_ln_modulate_bwd: D=%lld M=%lld rows_per_mod=%lld", (long long)D, (long long)M, (long long)rows_per_mod);
+  DL_CHECK_ARG((((uintptr_t)dout | (uintptr_t)x | (uintptr_t)scale | (uintptr_t)dres | (uintptr_t)dx | (uintptr_t)w | (uintptr_t)gate_t |
+                 (uintptr_t)gate | (uintptr_t)dt) & 15) == 0, "dl_f32_ln_modulate_bwd: 16-byte alignment");
+  const int groups = (int)(M / rows_per_mod);
+  static DevOnce once;  // (8 waves x 3 sums x D floats: above the 64 KiB default from D = 704)
+  (void)dev_cus(once, [] {
+    (void)hipFuncSetAttribute((const void*)f32_ln_mod_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, FLB_WAVES * 3 * 256 * FR_NJ * 4);
+  });
+  hipLaunchKernelGGL(f32_ln_mod_bwd_k, groups, 64 * FLB_WAVES, FLB_WAVES * 3 * (int)D * 4, (hipStream_t)stream, dout, x, w, b, scale,
+                     ld_mod, rows_per_mod, mean, rstd, dres, dx, dscale, dshift, ld_dmod, dwb_partial, gate_t, gate, ld_gate, dt, dgate,
+                     M, (int)D);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ============================================================================================================ QK-RMSNorm + RoPE
+// qkv [M, ld] (q at columns [0, D), k at [D, 2D)); out qk [M, 2D]: RMSNorm over the full D-wide row (nn.py:427-431), * scale, then the
+// rotation of interleaved pairs of the first `rot` channels of every head (nn.py:345-353).  One wave per token; a lane's float4 is
+// two rotation pairs.  part 0 = q, 1 = k.
+__global__ __launch_bounds__(256) void f32_qk_norm_rope_fwd_k(const float* __restrict__ qkv, int64_t ld, const float* __restrict__ sq,
+                                                              const float* __restrict__ sk, const float* __restrict__ cs,
+                                                              const float* __restrict__ sn, float* __restrict__ qk,
+                                                              float* __restrict__ rrms, int64_t M, int N, int D, int dh, int rot,
+                                                              float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D4 = D >> 2, half = rot >> 1;
+  const float invD = 1.0f / (float)D;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+    const int n = (int)(row % N);
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      f32x4_t v[FR_NJ], sc[FR_NJ], sqv[FR_NJ];
+      fr_load(qkv + row * ld + part * D, D4, lane, v, 0.f);
+      fr_load(part ? sk : sq, D4, lane, sc, 0.f);
+#pragma unroll
+      for (int j = 0; j < FR_NJ; ++j) sqv[j] = v[j] * v[j];
+      const float r = 1.0f / sqrtf(fr_sum(sqv) * invD + eps);
+#pragma unroll
+      for (int j = 0; j < FR_NJ; ++j) {
+        const int c = lane + 64 * j;
+        if (c >= D4) continue;
+        f32x4_t y = v[j] * r * sc[j];
+        const int d0 = (4 * c) % dh;  // channel inside the head
+        if (d0 < rot) {
+          const int p0 = d0 >> 1;  // pair index
+          const float c0 = cs[(int64_t)n * half + p0], s0 = sn[(int64_t)n * half + p0];
+          const float c1 = cs[(int64_t)n * half + p0 + 1], s1 = sn[(int64_t)n * half + p0 + 1];
+          const float a0 = y[0], b0 = y[1], a1 = y[2], b1 = y[3];
+          y[0] = a0 * c0 - b0 * s0;
+          y[1] = a0 * s0 + b0 * c0;
+          y[2] = a1 * c1 - b1 * s1;
+          y[3] = a1 * s1 + b1 * c1;
+        }
+        *(f32x4_t*)(qk + row * 2 * D + part * D + 4 * c) = y;
+      }
+      if (lane == 0) rrms[row * 2 + part] = r;
+    }
+  }
+}
+
+extern "C" int dl_f32_qk_norm_rope_fwd(const float* qkv, int64_t ld, const float* scale_q, const float* scale_k, const float* cos,
+                                       const float* sin, float* qk, float* rrms, int64_t B, int64_t N, int64_t H, int64_t dh,
+                                       int64_t rot, float eps, dl_stream_t stream) {
+  const int64_t D = H * dh, M = B * N;
+  DL_CHECK_ARG(qkv && scale_q && scale_k && qk && rrms && M > 0, "dl_f32_qk_norm_rope_fwd: null operand");
+  DL_CHECK_ARG(rot == 0 || (cos && sin), "dl_f32_qk_norm_rope_fwd: rot > 0 needs the cos / sin tables");
+  DL_CHECK_ARG(D % 4 == 0 && D <= 256 * FR_NJ && dh % 4 == 0 && rot % 4 == 0 && rot <= dh && ld % 4 == 0 && ld >= 2 * D,
+               "dl_f32_qk_norm_rope_fwd: D=%lld dh=%lld rot=%lld ld=%lld", (long long)D, (long long)dh, (long long)rot, (long long)ld);
+  DL_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)qk | (uintptr_t)scale_q | (uintptr_t)scale_k) & 15) == 0,
+               "dl_f32_qk_norm_rope_fwd: 16-byte alignment");
+  hipLaunchKernelGGL(f32_qk_norm_rope_fwd_k, grid_1d(M, 4), 256, 0, (hipStream_t)stream, qkv, ld, scale_q, scale_k, cos, sin, qk, rrms, M,
+                     (int)N, (int)D, (int)dh, (int)rot, eps);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// backward: dqk [M, 2D] = gradient of the normalised + rotated q, k.  Inverse rotation (the transpose), then with y = x r s:
+//   dscale += g x r ;  gx = g s ;  dx = r (gx - x r^2 mean(gx x))      (RMSNorm backward over the full row)
+// dq, dk go to columns [0, 2D) of dqkv (row stride ld_d); one workgroup per sample writes its scale-gradient partial [2, D].
+__global__ __launch_bounds__(256) void f32_qk_norm_rope_bwd_k(const float* __restrict__ dqk, const float* __restrict__ qkv, int64_t ld,
+                                                              const float* __restrict__ sq, const float* __restrict__ sk,
+                                                              const float* __restrict__ cs, const float* __restrict__ sn,
+                                                              const float* __restrict__ rrms, float* __restrict__ dqkv, int64_t ld_d,
+                                                              float* __restrict__ dscale_part, int N, int D, int dh, int rot) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = (float*)smem;  // [4 waves][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D4 = D >> 2, half = rot >> 1;
+  const float invD = 1.0f / (float)D;
+  const int64_t b = blockIdx.x;
+  f32x4_t acc[2][FR_NJ];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int j = 0; j < FR_NJ; ++j) acc[p][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int n = wave; n < N; n += 4) {
+    const int64_t row = b * N + n;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      f32x4_t g[FR_NJ], x[FR_NJ], sc[FR_NJ], gx[FR_NJ], pr[FR_NJ];
+      fr_load(dqk + row * 2 * D + part * D, D4, lane, g, 0.f);
+      fr_load(qkv + row * ld + part * D, D4, lane, x, 0.f);
+      fr_load(part ? sk : sq, D4, lane, sc, 0.f);
+      const float r = rrms[row * 2 + part];
+#pragma unroll
+      for (int j = 0; j < FR_NJ; ++j) {
+        const int c = lane + 64 * j;
+        const int d0 = (4 * c) % dh;
+        if (c < D4 && d0 < rot) {  // transpose of the rotation
+          const int p0 = d0 >> 1;
+          const float c0 = cs[(int64_t)n * half + p0], s0 = sn[(int64_t)n * half + p0];
+          const float c1 = cs[(int64_t)n * half + p0 + 1], s1 = sn[(int64_t)n * half + p0 + 1];
+          const float a0 = g[j][0], b0 = g[j][1], a1 = g[j][2], b1 = g[j][3];
+          g[j][0] = a0 * c0 + b0 * s0;
+          g[j][1] = -a0 * s0 + b0 * c0;
+          g[j][2] = a1 * c1 + b1 * s1;
+          g[j][3] = -a1 * s1 + b1 * c1;
+        }
+        acc[part][j] += g[j] * x[j] * r;
+        gx[j] = g[j] * sc[j];
+        pr[j] = gx[j] * x[j];
+      }
+      const float m = fr_sum(pr) * invD;
+#pragma unroll
+      for (int j = 0; j < FR_NJ; ++j) gx[j] = r * (gx[j] - x[j] * (r * r * m));
+      fr_store(dqkv + row * ld_d + part * D, D4, lane, gx);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int j = 0; j < FR_NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < D4) *(f32x4_t*)(red + (wave * 2 + p) * D + 4 * c) = acc[p][j];
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += 256) {
+    const int p = i / D, c = i - p * D;
+    dscale_part[b * 2 * D + i] = (red[(0 * 2 + p) * D + c] + red[(1 * 2 + p) * D + c]) + (red[(2 * 2 + p) * D + c] + red[(3 * 2 + p) * D + c]);
+  }
+}
+
+extern "C" int dl_f32_qk_norm_rope_bwd(const float* dqk, const float* qkv, int64_t ld, const float* scale_q, const float* scale_k,
+                                       const float* cos, const float* sin, const float* rrms, float* dqkv, int64_t ld_d,
+                                       float* dscale_partials, int64_t B, int64_t N, int64_t H, int64_t dh, int64_t rot,
+                                       dl_stream_t stream) {
+  const int64_t D = H * dh;
+  DL_CHECK_ARG(dqk && qkv && scale_q && scale_k && rrms && dqkv && dscale_partials && B > 0 && N > 0, "dl_f32_qk_norm_rope_bwd: null operand");
+  DL_CHECK_ARG(rot == 0 || (cos && sin), "dl_f32_qk_norm_rope_bwd: rot > 0 needs the cos / sin tables");
+  DL_CHECK_ARG(D % 4 == 0 && D <= 256 * FR_NJ && dh % 4 == 0 && rot % 4 == 0 && rot <= dh && ld % 4 == 0 && ld >= 2 * D && ld_d % 4 == 0 &&
+               ld_d >= 2 * D, "dl_f32_qk_norm_rope_bwd: D=%lld dh=%lld rot=%lld", (long long)D, (long long)dh, (long long)rot);
+  DL_CHECK_ARG((((uintptr_t)dqk | (uintptr_t)qkv | (uintptr_t)dqkv | (uintptr_t)scale_q | (uintptr_t)scale_k) & 15) == 0,
+               "dl_f32_qk_norm_rope_bwd: 16-byte alignment");
+  hipLaunchKernelGGL(f32_qk_norm_rope_bwd_k, (int)B, 256, 4 * 2 * (int)D * 4, (hipStream_t)stream, dqk, qkv, ld, scale_q, scale_k, cos, sin,
+                     rrms, dqkv, ld_d, dscale_partials, (int)N, (int)D, (int)dh, (int)rot);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ============================================================================================================ softmax rows
+// in place over rows of `cols` floats (cols <= 4096): p = exp(s - max) / sum; one wave per row, values kept in registers
+#define FS_NJ 16
+__global__ __launch_bounds__(256) void f32_softmax_fwd_k(float* __restrict__ s, int64_t rows, int cols) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C4 = cols >> 2;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    float* p = s + row * cols;
+    f32x4_t v[FS_NJ];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < FS_NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C4) {
+        v[j] = *(const f32x4_t*)(p + 4 * c);
+        mx = fmaxf(mx, fmaxf(fmaxf(v[j][0], v[j][1]), fmaxf(v[j][2], v[j][3])));
+      }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < FS_NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[j][e] = expf(v[j][e] - mx);
+        sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+      }
+    }
+    const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+    for (int j = 0; j < FS_NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C4) *(f32x4_t*)(p + 4 * c) = v[j] * inv;
+    }
+  }
+}
+// dS = P * (dP - rowsum(dP * P)), written over dP
+__global__ __launch_bounds__(256) void f32_softmax_bwd_k(const float* __restrict__ P, float* __restrict__ dP, int64_t rows, int cols) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C4 = cols >> 2;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float* p = P + row * cols;
+    float* d = dP + row * cols;
+    f32x4_t pv[FS_NJ], dv[FS_NJ];
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < FS_NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C4) {
+        pv[j] = *(const f32x4_t*)(p + 4 * c);
+        dv[j] = *(const f32x4_t*)(d + 4 * c);
+        const f32x4_t m = pv[j] * dv[j];
+        dot += (m[0] + m[1]) + (m[2] + m[3]);
+      }
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int j = 0; j < FS_NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C4) *(f32x4_t*)(d + 4 * c) = pv[j] * (dv[j] - dot);
+    }
+  }
+}
+
+extern "C" int dl_f32_softmax_fwd(float* s, int64_t rows, int64_t cols, dl_stream_t stream) {
+  DL_CHECK_ARG(s && rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 256 * FS_NJ && ((uintptr_t)s & 15) == 0,
+               "dl_f32_softmax_fwd: rows=%lld cols=%lld (cols %% 4 == 0, <= %d)", (long long)rows, (long long)cols, 256 * FS_NJ);
+  hipLaunchKernelGGL(f32_softmax_fwd_k, grid_1d(rows, 4, 16384), 256, 0, (hipStream_t)stream, s, rows, (int)cols);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_f32_softmax_bwd(const float* p, float* dp, int64_t rows, int64_t cols, dl_stream_t stream) {
+  DL_CHECK_ARG(p && dp && rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 256 * FS_NJ && (((uintptr_t)p | (uintptr_t)dp) & 15) == 0,
+               "dl_f32_softmax_bwd: rows=%lld cols=%lld", (long long)rows, (long long)cols);
+  hipLaunchKernelGGL(f32_softmax_bwd_k, grid_1d(rows, 4, 16384), 256, 0, (hipStream_t)stream, p, dp, rows, (int)cols);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ============================================================================================================ elementwise
+// PackedSwiGLU nn.py:484-486: h = silu(u[:, :F]) * u[:, F:]
+__global__ void f32_swiglu_fwd_k(const float* __restrict__ u, float* __restrict__ h, int64_t M, int F) {
+  const int F4 = F >> 2;
+  const int64_t n = M * F4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / F4;
+    const int c = (int)(i - row * F4);
+    const f32x4_t x1 = *(const f32x4_t*)(u + row * 2 * F + 4 * c), x3 = *(const f32x4_t*)(u + row * 2 * F + F + 4 * c);
+    f32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = silu32(x1[e]) * x3[e];
+    *(f32x4_t*)(h + row * F + 4 * c) = o;
+  }
+}
+__global__ void f32_swiglu_bwd_k(const float* __restrict__ dh, const float* __restrict__ u, float* __restrict__ du, int64_t M, int F) {
+  const int F4 = F >> 2;
+  const int64_t n = M * F4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / F4;
+    const int c = (int)(i - row * F4);
+    const f32x4_t x1 = *(const f32x4_t*)(u + row * 2 * F + 4 * c), x3 = *(const f32x4_t*)(u + row * 2 * F + F + 4 * c);
+    const f32x4_t g = *(const f32x4_t*)(dh + row * F + 4 * c);
+    f32x4_t d1, d3;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      d1[e] = g[e] * x3[e] * dsilu32(x1[e]);
+      d3[e] = g[e] * silu32(x1[e]);
+    }
+    *(f32x4_t*)(du + row * 2 * F + 4 * c) = d1;
+    *(f32x4_t*)(du + row * 2 * F + F + 4 * c) = d3;
+  }
+}
+extern "C" int dl_f32_swiglu_fwd(const float* u, float* h, int64_t M, int64_t F, dl_stream_t stream) {
+  DL_CHECK_ARG(u && h && M > 0 && F > 0 && F % 4 == 0 && (((uintptr_t)u | (uintptr_t)h) & 15) == 0, "dl_f32_swiglu_fwd: bad args");
+  hipLaunchKernelGGL(f32_swiglu_fwd_k, grid_1d(M * F / 4), 256, 0, (hipStream_t)stream, u, h, M, (int)F);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_f32_swiglu_bwd(const float* dh, const float* u, float* du, int64_t M, int64_t F, dl_stream_t stream) {
+  DL_CHECK_ARG(dh && u && du && M > 0 && F > 0 && F % 4 == 0 && (((uintptr_t)u | (uintptr_t)dh | (uintptr_t)du) & 15) == 0,
+               "dl_f32_swiglu_bwd: bad args");
+  hipLaunchKernelGGL(f32_swiglu_bwd_k, grid_1d(M * F / 4), 256, 0, (hipStream_t)stream, dh, u, du, M, (int)F);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// mode 0: out = a + b ; 1: out = silu(a) ; 2: out = a * silu'(b)   (a = dy, b = pre-activation)
+__global__ void f32_ew_k(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int64_t n, int mode) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = a[i];
+    o[i] = mode == 0 ? x + b[i] : (mode == 1 ? silu32(x) : x * dsilu32(b[i]));
+  }
+}
+extern "C" int dl_f32_add(const float* a, const float* b, float* out, int64_t n, dl_stream_t stream) {
+  DL_CHECK_ARG(a && b && out && n > 0, "dl_f32_add: bad args");
+  hipLaunchKernelGGL(f32_ew_k, grid_1d(n), 256, 0, (hipStream_t)stream, a, b, out, n, 0);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_f32_silu_bwd(const float* dy, const float* pre, float* dx, int64_t n, dl_stream_t stream) {
+  DL_CHECK_ARG(dy && pre && dx && n > 0, "dl_f32_silu_bwd: bad args");
+  hipLaunchKernelGGL(f32_ew_k, grid_1d(n), 256, 0, (hipStream_t)stream, dy, pre, dx, n, 2);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ============================================================================================================ stem / conditioning
+// im2row of the patch convolution (order DL_PATCH_CPP, mmdit.py:757-765) and the transpose of unpatchify (DL_PATCH_PPC,
+// mmdit.py:778-787): x f32 [B, C, H, W] -> tok f32 [B gh gw, ld], columns >= C p p zeroed
+__global__ void f32_patchify_k(const float* __restrict__ x, float* __restrict__ tok, int B, int C, int H, int W, int p, int ld,
+                               int order) {
+  const int gh = H / p, gw = W / p, F = C * p * p;
+  const int64_t n = (int64_t)B * gh * gw * ld;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % ld);
+    const int64_t t = i / ld;
+    float v = 0.f;
+    if (f < F) {
+      int c, p1, p2;
+      if (order == DL_PATCH_CPP) {
+        c = f / (p * p);
+        p1 = (f / p) % p;
+        p2 = f % p;
+      } else {
+        p1 = f / (p * C);
+        p2 = (f / C) % p;
+        c = f % C;
+      }
+      const int w_ = (int)(t % gw), h_ = (int)((t / gw) % gh), b = (int)(t / ((int64_t)gw * gh));
+      v = x[(((int64_t)b * C + c) * H + h_ * p + p1) * W + w_ * p + p2];
+    }
+    tok[i] = v;
+  }
+}
+extern "C" int dl_f32_patchify(const float* x, float* tok, int64_t B, int64_t C, int64_t H, int64_t W, int64_t p, int64_t ld, int order,
+                               dl_stream_t stream) {
+  DL_CHECK_ARG(x && tok && B > 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0 && ld >= C * p * p &&
+               (order == DL_PATCH_CPP || order == DL_PATCH_PPC), "dl_f32_patchify: bad args");
+  hipLaunchKernelGGL(f32_patchify_k, grid_1d(B * (H / p) * (W / p) * ld), 256, 0, (hipStream_t)stream, x, tok, (int)B, (int)C, (int)H, (int)W,
+                     (int)p, (int)ld, order);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// timestep_embedding nn.py:106-114: [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(max_period) i / half), f32
+__global__ void f32_timestep_embedding_k(const float* __restrict__ t, float* __restrict__ out, int B, int dim, float neg_log_p) {
+  const int half = dim / 2;
+  const int64_t n = (int64_t)B * dim;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / dim), j = (int)(i % dim);
+    float v = 0.f;
+    if (j < 2 * half) {
+      const int k = j < half ? j : j - half;
+      const float f = expf((float)k * neg_log_p / (float)half);
+      const float a = t[b] * f;
+      v = j < half ? cosf(a) : sinf(a);
+    }
+    out[i] = v;
+  }
+}
+extern "C" int dl_f32_timestep_embedding(const float* t, float* out, int64_t B, int64_t dim, float max_period, dl_stream_t stream) {
+  DL_CHECK_ARG(t && out && B > 0 && dim > 1, "dl_f32_timestep_embedding: bad args");
+  hipLaunchKernelGGL(f32_timestep_embedding_k, grid_1d(B * dim), 256, 0, (hipStream_t)stream, t, out, (int)B, (int)dim, -logf(max_period));
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// emb = e + table[idx] (mmdit.py:867-868, nn.py:162-163), act = silu(emb) (input of every Modulation / adaLN linear, nn.py:531)
+__global__ void f32_cond_combine_fwd_k(const float* __restrict__ e, const float* __restrict__ table, const int64_t* __restrict__ idx,
+                                       float* __restrict__ emb, float* __restrict__ act, int B, int E) {
+  const int64_t n = (int64_t)B * E;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / E), c = (int)(i % E);
+    float v = e[i];
+    if (table) v += table[idx[b] * E + c];
+    emb[i] = v;
+    act[i] = silu32(v);
+  }
+}
+// demb = dact * silu'(emb); dtable[idx[b], :] += demb[b, :] in batch order (one thread owns a column: no atomics, fixed order)
+__global__ void f32_cond_combine_bwd_k(const float* __restrict__ dact, const float* __restrict__ emb, const int64_t* __restrict__ idx,
+                                       float* __restrict__ demb, float* __restrict__ dtable, int B, int E) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= E) return;
+  for (int b = 0; b < B; ++b) {
+    const float g = dact[(int64_t)b * E + c] * dsilu32(emb[(int64_t)b * E + c]);
+    demb[(int64_t)b * E + c] = g;
+    if (dtable) dtable[idx[b] * E + c] += g;
+  }
+}
+extern "C" int dl_f32_cond_combine_fwd(const float* e, const float* table, const int64_t* idx, float* emb, float* act, int64_t B,
+                                       int64_t E, dl_stream_t stream) {
+  DL_CHECK_ARG(e && emb && act && B > 0 && E > 0 && ((table == nullptr) == (idx == nullptr)), "dl_f32_cond_combine_fwd: bad args");
+  hipLaunchKernelGGL(f32_cond_combine_fwd_k, grid_1d(B * E), 256, 0, (hipStream_t)stream, e, table, idx, emb, act, (int)B, (int)E);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_f32_cond_combine_bwd(const float* dact, const float* emb, const int64_t* idx, float* demb, float* dtable, int64_t B,
+                                       int64_t E, dl_stream_t stream) {
+  DL_CHECK_ARG(dact && emb && demb && B > 0 && E > 0 && ((dtable == nullptr) || idx), "dl_f32_cond_combine_bwd: bad args");
+  hipLaunchKernelGGL(f32_cond_combine_bwd_k, cdiv(E, 128), 128, 0, (hipStream_t)stream, dact, emb, idx, demb, dtable, (int)B, (int)E);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}

@@ -90,6 +90,27 @@ class FlatArenaDenoiser(Denoiser):
     def _make_engine(self, device: torch.device):  # pragma: no cover - abstract
         raise NotImplementedError
 
+    # ---- precision regime.  "bf16": bf16 MFMA operands and activations with f32 accumulation / statistics (the reference's
+    #      precision_type="bf16"); "fp32": f32 activations and exact-f32 MFMA products on the f32 parameters (the reference's default
+    #      precision_type="no", trainers/common.py:76,105).  Denoisers that have an fp32 engine list it in `precisions`.
+    precisions: tuple[str, ...] = ("bf16",)
+
+    @property
+    def precision(self) -> str:
+        return self.__dict__.get("_precision", "bf16")
+
+    def set_precision(self, precision: str) -> "FlatArenaDenoiser":
+        if precision not in ("bf16", "fp32"):
+            raise ValueError(f"precision must be 'bf16' or 'fp32' (got {precision!r})")
+        if precision not in self.precisions:
+            raise NotImplementedError(f"diffulab_amd.{type(self).__name__} has no {precision} launch sequence (built: "
+                                      f"{', '.join(self.precisions)}); the fp32-class regime exists for MMDiT(simple_dit=True)")
+        if precision != self.precision:
+            object.__setattr__(self, "_precision", precision)
+            object.__setattr__(self, "_engine", None)  # the next forward re-flattens onto the other engine (same arena layout)
+            object.__setattr__(self, "_graphs", None)
+        return self
+
     def __deepcopy__(self, memo):  # EMA wrappers deep-copy the module: copy parameters, not the engine/workspace
         saved = {k: self.__dict__.get(k) for k in ("_engine", "_flat", "_flat_grad", "_anchor", "_graphs", "_plist")}
         for k in saved:
@@ -143,7 +164,7 @@ class FlatArenaDenoiser(Denoiser):
         if dev.type != "cuda":
             raise RuntimeError(f"diffulab_amd.{type(self).__name__} runs on an MI355X only: move the module to 'cuda' "
                                "(no CPU fallback)")
-        if self._engine is None or self._engine.dev != dev:
+        if self._engine is None or self._engine.dev != dev or getattr(self._engine, "precision", "bf16") != self.precision:
             object.__setattr__(self, "_engine", self._make_engine(dev))
         lay = self._engine.layout
         assert set(named) == set(lay.entries), set(named) ^ set(lay.entries)

@@ -241,8 +241,16 @@ class MMDiT(FlatArenaDenoiser):
             for p in module.adaLN_modulation.parameters():
                 p.detach().zero_()
 
+    @property
+    def precisions(self) -> tuple[str, ...]:  # the fp32-class regime is built for the class-conditional DiT (engine_f32.py)
+        return ("bf16", "fp32") if self.simple_dit else ("bf16",)
+
     def _make_engine(self, device: torch.device) -> DiTEngine:
         if self.simple_dit:
+            if self.precision == "fp32":
+                from ...engine_f32 import DiTEngineF32
+
+                return DiTEngineF32(self.dims, device)
             return DiTEngine(self.dims, device)
         if self.n_single_stream_blocks:
             from ...sprint_joint_engine import JointStackEngine

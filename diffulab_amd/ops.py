@@ -824,6 +824,123 @@ def copy2d_bf16(src, dst, rows, cols):
     _call("dl_copy2d_bf16", _p(src), src.stride(0), _p(dst), dst.stride(0), rows, cols, _s())
 
 
+# ------------------------------------------------------------------ fp32-class regime (csrc/f32.hip, dl_f32_*)
+class _F32Gemm(ctypes.Structure):
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("lda", ctypes.c_int64),
+                ("ldb", ctypes.c_int64), ("ldc", ctypes.c_int64), ("M", ctypes.c_int64), ("N", ctypes.c_int64), ("K", ctypes.c_int64),
+                ("trans_a", ctypes.c_int32), ("trans_b", ctypes.c_int32), ("batch1", ctypes.c_int64), ("batch2", ctypes.c_int64),
+                ("stride_a1", ctypes.c_int64), ("stride_a2", ctypes.c_int64), ("stride_b1", ctypes.c_int64),
+                ("stride_b2", ctypes.c_int64), ("stride_c1", ctypes.c_int64), ("stride_c2", ctypes.c_int64), ("alpha", ctypes.c_float),
+                ("bias", ctypes.c_void_p), ("act", ctypes.c_int32), ("pre_out", ctypes.c_void_p), ("accumulate", ctypes.c_int32),
+                ("scratch", ctypes.c_void_p), ("scratch_floats", ctypes.c_int64)]
+
+
+def _addr(t, off: int = 0) -> int:
+    """device address of element `off` of an f32 tensor (or of a raw int address)"""
+    if isinstance(t, int):
+        return t + 4 * off
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError("dl_f32_* ops take f32 device tensors (no CPU fallback exists)")
+    return t.data_ptr() + 4 * off
+
+
+def f32_gemm(A, B, C, M: int, N: int, K: int, *, lda: int, ldb: int, ldc: int, ta: bool = False, tb: bool = False, a_off: int = 0,
+             b_off: int = 0, c_off: int = 0, batch: tuple[int, int] = (1, 1), sa=(0, 0), sb=(0, 0), sc=(0, 0), alpha: float = 1.0,
+             bias=None, act: int = ACT_NONE, pre_out=None, accumulate: bool = False, scratch=None) -> None:
+    """C[M, N] = act(alpha * op(A) op(B) + bias) (+= with accumulate) on the exact-f32 MFMA; ta: A is [K, M]; tb: B is [K, N]
+    (default: A [M, K], B [N, K] = torch Linear weight); *_off: element offsets into the tensors (column windows of token rows);
+    batch = (b1, b2) with element strides sa / sb / sc per level"""
+    d = _F32Gemm(_addr(A, a_off), _addr(B, b_off), _addr(C, c_off), lda, ldb, ldc, M, N, K, int(ta), int(tb), batch[0], batch[1],
+                 sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], float(alpha), _p(bias), act, _p(pre_out), int(accumulate),
+                 _p(scratch), scratch.numel() if scratch is not None else 0)
+    _call("dl_f32_gemm", ctypes.addressof(d), _s())
+
+
+def f32_linear(x, w, out, *, bias=None, act: int = ACT_NONE, pre_out=None, M: int | None = None) -> None:
+    """out[M, out_f] = act(x[M, in_f] w[out_f, in_f]^T + bias)   (nn.Linear forward)"""
+    M = x.shape[0] if M is None else M
+    f32_gemm(x, w, out, M, w.shape[0], w.shape[1], lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=bias, act=act,
+             pre_out=pre_out)
+
+
+def f32_linear_dgrad(dy, w, dx, *, M: int | None = None, scratch=None) -> None:
+    """dx[M, in_f] = dy[M, out_f] w[out_f, in_f]"""
+    M = dy.shape[0] if M is None else M
+    f32_gemm(dy, w, dx, M, w.shape[1], w.shape[0], lda=dy.stride(0), ldb=w.stride(0), ldc=dx.stride(0), tb=True, scratch=scratch)
+
+
+def f32_linear_wgrad(dy, x, g, *, R: int | None = None, scratch=None) -> None:
+    """g[out_f, in_f] += dy[R, out_f]^T x[R, in_f]"""
+    R = dy.shape[0] if R is None else R
+    f32_gemm(dy, x, g, g.shape[0], g.shape[1], R, lda=dy.stride(0), ldb=x.stride(0), ldc=g.stride(0), ta=True, tb=True,
+             accumulate=True, scratch=scratch)
+
+
+def f32_ln_modulate_fwd(x, w, b, scale, shift, rows_per_mod, eps, out, mean, rstd, t=None, gate=None, x_out=None):
+    M, D = x.shape
+    _call("dl_f32_ln_modulate_fwd", _p(x), _p(w), _p(b), _p(scale), _p(shift), scale.stride(0), rows_per_mod, float(eps), _p(out),
+          _p(mean), _p(rstd), _p(t), _p(gate), gate.stride(0) if gate is not None else 0, _p(x_out), M, D, _s())
+
+
+def f32_ln_modulate_bwd(dout, x, w, b, scale, rows_per_mod, mean, rstd, dres, dx, dscale, dshift, dwb_partial, gate_t=None,
+                        gate=None, dt=None, dgate=None):
+    M, D = x.shape
+    _call("dl_f32_ln_modulate_bwd", _p(dout), _p(x), _p(w), _p(b), _p(scale), scale.stride(0), rows_per_mod, _p(mean), _p(rstd),
+          _p(dres), _p(dx), _p(dscale), _p(dshift), dscale.stride(0), _p(dwb_partial), _p(gate_t), _p(gate),
+          gate.stride(0) if gate is not None else 0, _p(dt), _p(dgate), M, D, _s())
+
+
+def f32_qk_norm_rope_fwd(qkv, scale_q, scale_k, cos, sin, qk, rrms, B, N, H, dh, rot, eps=1e-6):
+    _call("dl_f32_qk_norm_rope_fwd", _p(qkv), qkv.stride(0), _p(scale_q), _p(scale_k), _p(cos), _p(sin), _p(qk), _p(rrms), B, N, H, dh,
+          rot, float(eps), _s())
+
+
+def f32_qk_norm_rope_bwd(dqk, qkv, scale_q, scale_k, cos, sin, rrms, dqkv, partials, B, N, H, dh, rot):
+    _call("dl_f32_qk_norm_rope_bwd", _p(dqk), _p(qkv), qkv.stride(0), _p(scale_q), _p(scale_k), _p(cos), _p(sin), _p(rrms), _p(dqkv),
+          dqkv.stride(0), _p(partials), B, N, H, dh, rot, _s())
+
+
+def f32_softmax_fwd(s, rows, cols):
+    _call("dl_f32_softmax_fwd", _p(s), rows, cols, _s())
+
+
+def f32_softmax_bwd(p, dp, rows, cols):
+    _call("dl_f32_softmax_bwd", _p(p), _p(dp), rows, cols, _s())
+
+
+def f32_swiglu_fwd(u, h):
+    _call("dl_f32_swiglu_fwd", _p(u), _p(h), u.shape[0], h.shape[1], _s())
+
+
+def f32_swiglu_bwd(dh, u, du):
+    _call("dl_f32_swiglu_bwd", _p(dh), _p(u), _p(du), u.shape[0], dh.shape[1], _s())
+
+
+def f32_add(a, b, out):
+    _call("dl_f32_add", _p(a), _p(b), _p(out), a.numel(), _s())
+
+
+def f32_silu_bwd(dy, pre, dx):
+    _call("dl_f32_silu_bwd", _p(dy), _p(pre), _p(dx), dy.numel(), _s())
+
+
+def f32_patchify(x, tok, p, order):
+    B, C, H, W = x.shape
+    _call("dl_f32_patchify", _p(x), _p(tok), B, C, H, W, p, tok.stride(0), order, _s())
+
+
+def f32_timestep_embedding(t, out, max_period=10000.0):
+    _call("dl_f32_timestep_embedding", _p(t), _p(out), out.shape[0], out.shape[1], float(max_period), _s())
+
+
+def f32_cond_combine_fwd(e, table, idx, emb, act):
+    _call("dl_f32_cond_combine_fwd", _p(e), _p(table), _p(idx), _p(emb), _p(act), e.shape[0], e.shape[1], _s())
+
+
+def f32_cond_combine_bwd(dact, emb, idx, demb, dtable):
+    _call("dl_f32_cond_combine_bwd", _p(dact), _p(emb), _p(idx), _p(demb), _p(dtable), dact.shape[0], dact.shape[1], _s())
+
+
 def masked_stream(pattern: str, device) -> "torch.cuda.Stream":
     """torch stream object over a CU-masked HIP stream; pattern "i<k>" enables every k-th CU, "b<n>" the first n CUs"""
     import ctypes

@@ -16,11 +16,12 @@ Mirrors ``training/trainers/common.py:25-271`` of the reference (same constructo
     with the mean gradient of the k micro-batches.  In both modes the loss is divided by k, only the synchronising micro-step
     reduces across ranks / steps the optimizer and the scheduler, and the last batch of a dataloader pass always synchronises
     (Accelerate's ``sync_with_dataloader``);
-  * mixed precision: the HIP path computes in bf16 MFMA with f32 accumulation, f32 master weights, f32 norm statistics / softmax
-    / loss head -- the reference's ``precision_type="bf16"`` regime, and the only one there is.  ``precision_type="no"`` (the
-    reference's fp32 default) RAISES instead of silently training in bf16 (the fp32 loss curve differs by up to ~3e-3 per step,
-    tests/test_dit_gpu.py); the default of this class is therefore "bf16", and configs/trainer/default.yaml says so; "fp16" is
-    refused as well;
+  * precision: ``precision_type="no"`` (the reference's default, common.py:76,105 / configs/trainer/default.yaml:4) selects the
+    fp32-class regime -- f32 activations, exact-f32 MFMA products on the f32 parameters (engine_f32.py, csrc/f32.hip) -- which exists
+    for ``MMDiT(simple_dit=True)``; a denoiser without it raises at ``prepare`` and names the override
+    (``trainer.precision_type=bf16``).  ``"bf16"`` = bf16 MFMA operands and activations with f32 accumulation, f32 master weights,
+    f32 norm statistics / softmax / loss head (what accelerate's bf16 autocast computes); ``"fp16"`` / ``"fp8"`` are refused (not
+    built: they would silently be something else);
   * ``compile`` / ``dynamo_plugin_kwargs`` are accepted and ignored (no tracing compiler: the launch sequences are static);
   * wandb (absent, no network) is replaced by a JSON-lines log under ``save_path/metrics.jsonl``.
 """
@@ -53,7 +54,7 @@ class Trainer(ABC):
         self,
         n_epoch: int,
         gradient_accumulation_step: int = 1,
-        precision_type: str = "bf16",
+        precision_type: str = "no",
         save_path: str | Path = Path.home() / "experiments" / f"{datetime.now().strftime('%Y%m%d_%H%M%S')}",
         project_name: str = "my_project",
         run_config: dict[str, Any] | None = None,
@@ -65,11 +66,12 @@ class Trainer(ABC):
         compile: bool = False,
         dynamo_plugin_kwargs: dict[str, Any] = {},
     ) -> None:
-        if precision_type != "bf16":
+        if precision_type not in ("no", "bf16"):
             raise NotImplementedError(
-                f"precision_type={precision_type!r}: the HIP path has ONE precision regime -- bf16 MFMA operands with f32 accumulation, "
-                "f32 master weights, f32 norm statistics, softmax and loss (the reference's precision_type='bf16').  An fp32 ('no') or "
-                "fp16 run would not be what was asked for, so it is refused: set trainer.precision_type=bf16.")
+                f"precision_type={precision_type!r}: the HIP path has two precision regimes -- 'no' (fp32: f32 activations, exact-f32 "
+                "MFMA products) and 'bf16' (bf16 MFMA operands with f32 accumulation, f32 master weights, f32 norm statistics, softmax "
+                "and loss).  An fp16 / fp8 run would not be what was asked for, so it is refused.")
+        self.precision_type = precision_type
         self.n_epoch = n_epoch
         self.use_ema = use_ema
         self.ema_rate = ema_rate
@@ -132,6 +134,13 @@ class Trainer(ABC):
     def prepare(self, diffuser: "Diffuser", optimizer: Optimizer) -> None:
         """accelerator.prepare(denoiser, ..., optimizer): device placement, rank-0 broadcast, gradient reducer"""
         den = diffuser.denoiser
+        want = "fp32" if self.precision_type == "no" else "bf16"
+        if hasattr(den, "set_precision"):
+            try:
+                den.set_precision(want)
+            except NotImplementedError as e:
+                raise NotImplementedError(f"{e}.  Set trainer.precision_type=bf16 for this denoiser (the reference's default "
+                                          "precision_type='no' is the fp32 regime).") from None
         den.to(self.device)
         if hasattr(den, "engine") and self.device.type == "cuda":
             eng = den.engine  # flattens the parameters into the arena

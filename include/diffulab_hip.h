@@ -532,6 +532,79 @@ DL_API int dl_add_bf16(const void* a, const void* b, void* out, int64_t n, dl_st
 DL_API int dl_copy2d_bf16(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols,
                           dl_stream_t stream);
 
+/* ------------------------------------------------------------------ fp32-class regime (csrc/f32.hip)
+ * The reference's DEFAULT precision (`precision_type="no"`: training/trainers/common.py:76,105, configs/trainer/default.yaml:4):
+ * f32 activations, f32 GEMM operands straight from the parameter arena (no bf16 shadows), f32 accumulation.  Every product of the
+ * step runs on the exact-f32 matrix instruction v_mfma_f32_32x32x2_f32 through ONE strided, batched entry point: */
+typedef struct dl_f32_gemm_t {
+  const float* A;          /* trans_a == 0: [M, K] row-major (K contiguous, row stride lda); != 0: [K, M] (M contiguous) */
+  const float* B;          /* trans_b == 0: [N, K] row-major (torch Linear weight layout); != 0: [K, N] (N contiguous) */
+  float* C;                /* [M, N], row stride ldc */
+  int64_t lda, ldb, ldc;
+  int64_t M, N, K;
+  int32_t trans_a, trans_b;
+  /* two-level batch: problem (i, j), i < batch1, j < batch2, starts at X + i * stride_x1 + j * stride_x2 (elements).  The attention
+   * matmuls use (sample, head) with the head stride 64 inside token-major rows: no head split / transpose pass (mmdit.py:85-100) */
+  int64_t batch1, batch2;
+  int64_t stride_a1, stride_a2, stride_b1, stride_b2, stride_c1, stride_c2;
+  float alpha;             /* C = act(alpha * A.B + bias) [+ C when accumulate] */
+  const float* bias;       /* f32 [N] or NULL */
+  int32_t act;             /* DL_ACT_NONE | DL_ACT_SILU */
+  float* pre_out;          /* optional: alpha * A.B + bias before the activation (layout of C), saved for the backward */
+  int32_t accumulate;      /* != 0: C += (parameter gradients accumulate into the arena) */
+  float* scratch;          /* optional caller-owned f32 scratch: unbatched products with few output tiles and a long contraction
+                            * (weight gradients over all tokens) split K over workgroups, every split stores its partial image and
+                            * a fold adds them in a fixed order (no atomics, bit-reproducible) */
+  int64_t scratch_floats;
+} dl_f32_gemm_t;
+/* nn.Linear forward (trans 0,0: mmdit.py:81,102,260-264, nn.py:530), data gradient (0,1: dX = dY W), weight gradient (1,1 with
+ * A = dY [R, out], B = X [R, in], accumulate), and F.scaled_dot_product_attention's matmuls (mmdit.py:92-100) over materialised
+ * probabilities: S = alpha Q K^T (0,0), O = P V (0,1), dP = dO V^T (0,0), dQ = alpha dS K (0,1), dK = alpha dS^T Q (1,1), dV = P^T dO. */
+DL_API int dl_f32_gemm(const dl_f32_gemm_t* desc, dl_stream_t stream);
+/* modulate(LayerNorm(x)) in f32 (mmdit.py:299,305,547 + nn.py:539), same contract as dl_ln_modulate_fwd with f32 rows everywhere
+ * (modulation rows included); t != NULL applies the previous sub-layer's gated residual first (mmdit.py:302,308) */
+DL_API int dl_f32_ln_modulate_fwd(const float* x, const float* w, const float* b, const float* scale, const float* shift,
+                                  int64_t ld_mod, int64_t rows_per_mod, float eps, float* out, float* mean, float* rstd,
+                                  const float* t, const float* gate, int64_t ld_gate, float* x_out, int64_t M, int64_t D,
+                                  dl_stream_t stream);
+/* its backward (contract of dl_ln_modulate_bwd, f32): one workgroup per modulation group, so dscale / dshift / dgate rows [group, :]
+ * (row stride ld_dmod) and dwb_partial [groups, 2, D] are WRITTEN by their single producer (no atomics); M % rows_per_mod == 0 */
+DL_API int dl_f32_ln_modulate_bwd(const float* dout, const float* x, const float* w, const float* b, const float* scale,
+                                  int64_t ld_mod, int64_t rows_per_mod, const float* mean, const float* rstd, const float* dres,
+                                  float* dx, float* dscale, float* dshift, int64_t ld_dmod, float* dwb_partial, const float* gate_t,
+                                  const float* gate, int64_t ld_gate, float* dt, float* dgate, int64_t M, int64_t D,
+                                  dl_stream_t stream);
+/* QKNorm (nn.py:427-431,473-475: RMS over the full inner dim) + N-D RoPE on interleaved pairs (nn.py:345-353) in f32: qkv [B*N, ld]
+ * (q in columns [0, D), k in [D, 2D)) -> qk [B*N, 2D] token-major (heads stay column blocks: dl_f32_gemm addresses them by stride);
+ * rrms f32 [B*N, 2]; cos / sin f32 [N, rot/2] */
+DL_API int dl_f32_qk_norm_rope_fwd(const float* qkv, int64_t ld, const float* scale_q, const float* scale_k, const float* cos,
+                                   const float* sin, float* qk, float* rrms, int64_t B, int64_t N, int64_t H, int64_t dh,
+                                   int64_t rot, float eps, dl_stream_t stream);
+/* backward: dqk [B*N, 2D] -> columns [0, 2D) of dqkv (row stride ld_d); dscale_partials f32 [B, 2, D] written (one workgroup per
+ * sample), folded by dl_reduce_rows_f32 */
+DL_API int dl_f32_qk_norm_rope_bwd(const float* dqk, const float* qkv, int64_t ld, const float* scale_q, const float* scale_k,
+                                   const float* cos, const float* sin, const float* rrms, float* dqkv, int64_t ld_d,
+                                   float* dscale_partials, int64_t B, int64_t N, int64_t H, int64_t dh, int64_t rot,
+                                   dl_stream_t stream);
+/* softmax over the last dimension of the scaled scores (mmdit.py:92-100), in place; backward dS = P (dP - rowsum(dP P)) over dP */
+DL_API int dl_f32_softmax_fwd(float* s, int64_t rows, int64_t cols, dl_stream_t stream);
+DL_API int dl_f32_softmax_bwd(const float* p, float* dp, int64_t rows, int64_t cols, dl_stream_t stream);
+/* PackedSwiGLU nn.py:484-486 in f32: u [M, 2F] -> h [M, F]; backward du [M, 2F] */
+DL_API int dl_f32_swiglu_fwd(const float* u, float* h, int64_t M, int64_t F, dl_stream_t stream);
+DL_API int dl_f32_swiglu_bwd(const float* dh, const float* u, float* du, int64_t M, int64_t F, dl_stream_t stream);
+/* out = a + b ; dx = dy * silu'(pre) */
+DL_API int dl_f32_add(const float* a, const float* b, float* out, int64_t n, dl_stream_t stream);
+DL_API int dl_f32_silu_bwd(const float* dy, const float* pre, float* dx, int64_t n, dl_stream_t stream);
+/* dl_patchify / dl_timestep_embedding / dl_cond_combine_{fwd,bwd} with f32 outputs (mmdit.py:757-765, nn.py:106-114,
+ * mmdit.py:867-868); the label-table gradient is added in batch order by one thread per column (no atomics) */
+DL_API int dl_f32_patchify(const float* x, float* tok, int64_t B, int64_t C, int64_t H, int64_t W, int64_t p, int64_t ld, int order,
+                           dl_stream_t stream);
+DL_API int dl_f32_timestep_embedding(const float* t, float* out, int64_t B, int64_t dim, float max_period, dl_stream_t stream);
+DL_API int dl_f32_cond_combine_fwd(const float* e, const float* table, const int64_t* idx, float* emb, float* act, int64_t B,
+                                   int64_t E, dl_stream_t stream);
+DL_API int dl_f32_cond_combine_bwd(const float* dact, const float* emb, const int64_t* idx, float* demb, float* dtable, int64_t B,
+                                   int64_t E, dl_stream_t stream);
+
 /* ------------------------------------------------------------------ fused block driver */
 /* One adaLN-zero DiT block (DiTBlock._forward mmdit.py:288-309, DiTAttention mmdit.py:75-104, MLP mmdit.py:260-264) as ONE call
  * per direction: the library issues the block's launch sequence itself (csrc/block.hip) -- the SURVEY section 8b "fused driver".

@@ -1,0 +1,413 @@
+"""The fp32-class regime (`precision_type="no"`, the reference's default: training/trainers/common.py:76,105; configs/trainer/default.yaml:4)
+through the C ABI: the exact-f32 MFMA GEMM family and f32 row kernels of csrc/f32.hip, the DiT launch sequences of engine_f32.py, the
+trainer switch, the sampler loop and the x-prediction branch (flow.py:300-303) -- against (1) the committed outputs of the imported
+reference (tests/golden/*.npz) and (2) the CPU oracle on seeded inputs.
+
+Bars (north_star): per-tensor relative L2 <= 1e-5 against the fp32 reference / oracle ("HIP fp32-mode kernels <= 1e-5");
+the 20-step AdamW loss curve <= 1e-4 per step against the reference's own fp32 curve.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import diffusion as od  # noqa: E402
+from oracle import dit as odit  # noqa: E402
+from oracle import synth  # noqa: E402
+
+DEV = "cuda"
+TOL = 1e-5  # "HIP fp32-mode kernels <= 1e-5"
+SMALL = dict(input_channels=4, output_channels=4, inner_dim=128, embedding_dim=64, num_heads=2, mlp_ratio=4,
+             patch_size=2, depth=2, n_classes=10, classifier_free=True)
+S2 = dict(input_channels=4, output_channels=4, inner_dim=384, embedding_dim=384, num_heads=6, mlp_ratio=4,
+          patch_size=2, depth=12, n_classes=1000, classifier_free=True)
+
+
+def rel(a, b):
+    a = a.detach().double().cpu() if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a)).double()
+    b = b.detach().double().cpu() if isinstance(b, torch.Tensor) else torch.as_tensor(np.asarray(b)).double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def build(cfg_kwargs, seed, precision="fp32"):
+    from diffulab_amd import MMDiT
+
+    m = MMDiT(simple_dit=True, **cfg_kwargs)
+    P = synth.dit_params(odit.param_shapes(odit.DiTConfig(**cfg_kwargs)), seed=seed)
+    m.load_state_dict(P)
+    m.set_precision(precision)
+    return m.to(DEV), P
+
+
+# ------------------------------------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(256, 384, 128), (100, 70, 37), (130, 129, 513), (8, 16, 4)])
+def test_f32_gemm_layouts_and_ragged_shapes(ta, tb, M, N, K):
+    """every layout pair of dl_f32_gemm (NT = Linear forward, NN = data gradient, TN / TT = weight gradients), tile-aligned and
+    ragged (scalar-load path), padded leading dimensions, against an fp64 product: f32 MFMA = a k-ordered fmaf chain"""
+    from diffulab_amd import ops
+
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    pad = 4 if (M % 4 == 0 and N % 4 == 0 and K % 4 == 0) else 3
+    A = torch.randn((K, M + pad) if ta else (M, K + pad), generator=g)
+    B = torch.randn((K, N + pad) if tb else (N, K + pad), generator=g)
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    C = torch.full((M, N + 5), 7.0, device=DEV)
+    ops.f32_gemm(Ad, Bd, C, M, N, K, lda=Ad.stride(0), ldb=Bd.stride(0), ldc=C.stride(0), ta=ta, tb=tb, alpha=0.5)
+    a = (A[:, :M].t() if ta else A[:, :K]).double()
+    b = (B[:, :N] if tb else B[:, :K].t()).double()
+    ref = 0.5 * (a @ b)
+    assert rel(C[:, :N], ref) < 2e-6
+    assert bool((C[:, N:] == 7.0).all()), "columns beyond N must stay untouched"
+
+
+def test_f32_gemm_epilogue_batch_and_split_k():
+    from diffulab_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    # bias + SiLU + saved pre-activation, then accumulate
+    M, N, K = 192, 160, 96
+    A, B, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    C, pre = torch.zeros(M, N, device=DEV), torch.zeros(M, N, device=DEV)
+    ops.f32_gemm(A.to(DEV), B.to(DEV), C, M, N, K, lda=K, ldb=K, ldc=N, bias=bias.to(DEV), act=ops.ACT_SILU, pre_out=pre)
+    p = A.double() @ B.double().t() + bias.double()
+    assert rel(pre, p) < 2e-6 and rel(C, p * torch.sigmoid(p)) < 2e-6
+    C0 = C.clone()
+    ops.f32_gemm(A.to(DEV), B.to(DEV), C, M, N, K, lda=K, ldb=K, ldc=N, accumulate=True)
+    assert rel(C, C0.double().cpu() + A.double() @ B.double().t()) < 2e-6
+    # two-level batch with head strides inside token-major rows: S[b, h] = q[b, :, h] k[b, :, h]^T (the attention scores)
+    Bn, H, Nt, dh = 3, 2, 64, 64
+    D = H * dh
+    qk = torch.randn(Bn * Nt, 2 * D, generator=g)
+    S = torch.zeros(Bn, H, Nt, Nt, device=DEV)
+    qkd = qk.to(DEV)
+    ops.f32_gemm(qkd, qkd, S, Nt, Nt, dh, lda=2 * D, ldb=2 * D, ldc=Nt, b_off=D, batch=(Bn, H), sa=(Nt * 2 * D, dh),
+                 sb=(Nt * 2 * D, dh), sc=(H * Nt * Nt, Nt * Nt), alpha=0.125)
+    q = qk[:, :D].reshape(Bn, Nt, H, dh).permute(0, 2, 1, 3).double()
+    k = qk[:, D:].reshape(Bn, Nt, H, dh).permute(0, 2, 1, 3).double()
+    assert rel(S, 0.125 * q @ k.transpose(-1, -2)) < 2e-6
+    # split-K weight gradient (few output tiles, long contraction) through the caller's scratch: deterministic fold
+    R, Mo, Ni = 8192, 96, 64
+    dy, x = torch.randn(R, Mo, generator=g).to(DEV), torch.randn(R, Ni, generator=g).to(DEV)
+    scr = torch.empty(32 * Mo * Ni, device=DEV)
+    g1, g2 = torch.ones(Mo, Ni, device=DEV), torch.ones(Mo, Ni, device=DEV)
+    ops.f32_linear_wgrad(dy, x, g1, scratch=scr)
+    ops.f32_linear_wgrad(dy, x, g2, scratch=scr)
+    assert torch.equal(g1, g2), "the split-K fold adds the partial images in a fixed order"
+    assert rel(g1, 1.0 + dy.double().cpu().t() @ x.double().cpu()) < 2e-6
+    g3 = torch.ones(Mo, Ni, device=DEV)
+    ops.f32_linear_wgrad(dy, x, g3)  # unsplit
+    assert rel(g3, g1) < 2e-6
+
+
+def test_f32_row_kernels_against_torch_autograd():
+    """LayerNorm + modulate (+ gated residual) forward / backward, QK-RMSNorm + RoPE forward / backward, softmax, SwiGLU: f32 kernels
+    vs the oracle's functions under fp64 autograd"""
+    from diffulab_amd import ops
+    from diffulab_amd.engine import rope_grid_tables
+
+    g = torch.Generator().manual_seed(11)
+    Bn, N, D, H = 3, 16, 128, 2
+    M, dh = Bn * N, D // H
+    rn = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    x, t, w, b = rn(M, D), rn(M, D), rn(D), rn(D)
+    mod = 0.3 * rn(Bn, 3 * D)  # scale | shift | gate
+    dout, dres = rn(M, D), rn(M, D)
+    # ---- reference (fp64 autograd)
+    xr, tr, wr, br, modr = (v.double().requires_grad_(True) for v in (x, t, w, b, mod))
+    sc, sh, gt = (modr[:, i * D : (i + 1) * D].repeat_interleave(N, 0) for i in range(3))
+    xn = xr + gt * tr
+    out_ref = odit.layer_norm(xn, wr, br, 1e-5) * (1 + sc) + sh
+    ((out_ref * dout.double()).sum() + (xn * dres.double()).sum()).backward()
+    # ---- HIP
+    d = lambda v: v.to(DEV).contiguous()  # noqa: E731
+    xd, td, wd, bd, modd = d(x), d(t), d(w), d(b), d(mod)
+    out, x_out = torch.empty(M, D, device=DEV), torch.empty(M, D, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.f32_ln_modulate_fwd(xd, wd, bd, modd[:, :D], modd[:, D : 2 * D], N, 1e-5, out, mean, rstd, t=td, gate=modd[:, 2 * D :], x_out=x_out)
+    assert rel(out, out_ref) < 1e-6 and rel(x_out, xn) < 1e-6
+    dx, dt = torch.empty(M, D, device=DEV), torch.empty(M, D, device=DEV)
+    dmod, dwb = torch.zeros(Bn, 3 * D, device=DEV), torch.empty(Bn, 2, D, device=DEV)
+    ops.f32_ln_modulate_bwd(d(dout), x_out, wd, bd, modd[:, :D], N, mean, rstd, d(dres), dx, dmod[:, :D], dmod[:, D : 2 * D], dwb,
+                            gate_t=td, gate=modd[:, 2 * D :], dt=dt, dgate=dmod[:, 2 * D :])
+    assert rel(dx, xr.grad) < 2e-6 and rel(dt, tr.grad) < 2e-6 and rel(dmod, modr.grad) < 2e-6
+    assert rel(dwb.sum(0)[0], wr.grad) < 2e-6 and rel(dwb.sum(0)[1], br.grad) < 2e-6
+    # ---- QK norm + RoPE
+    qkv = rn(M, 3 * D)
+    sq, sk = 1 + 0.1 * rn(D), 1 + 0.1 * rn(D)
+    cos, sin = rope_grid_tables(4, 4, [dh // 2, dh // 2], 10000.0)
+    dqk = rn(M, 2 * D)
+    qr, sqr, skr = qkv.double().requires_grad_(True), sq.double().requires_grad_(True), sk.double().requires_grad_(True)
+
+    def norm_rope(z, s):
+        z = odit.rms_norm(z, s).reshape(Bn, N, H, dh)
+        return odit.apply_rope(z, cos.double(), sin.double()).reshape(M, D)
+
+    ref_qk = torch.cat([norm_rope(qr[:, :D], sqr), norm_rope(qr[:, D : 2 * D], skr)], 1)
+    (ref_qk * dqk.double()).sum().backward()
+    qkvd, qk_o, rr = d(qkv), torch.empty(M, 2 * D, device=DEV), torch.empty(M, 2, device=DEV)
+    ops.f32_qk_norm_rope_fwd(qkvd, d(sq), d(sk), d(cos), d(sin), qk_o, rr, Bn, N, H, dh, dh)
+    assert rel(qk_o, ref_qk) < 1e-6
+    dqkv, part = torch.zeros(M, 3 * D, device=DEV), torch.empty(Bn, 2, D, device=DEV)
+    ops.f32_qk_norm_rope_bwd(d(dqk), qkvd, d(sq), d(sk), d(cos), d(sin), rr, dqkv, part, Bn, N, H, dh, dh)
+    assert rel(dqkv[:, : 2 * D], qr.grad[:, : 2 * D]) < 2e-6 and float(dqkv[:, 2 * D :].abs().sum()) == 0.0
+    assert rel(part.sum(0)[0], sqr.grad) < 2e-6 and rel(part.sum(0)[1], skr.grad) < 2e-6
+    # ---- softmax rows (incl. a width above 256 and a peaked row) and SwiGLU
+    for cols in (64, 256, 1024):
+        s = 4 * rn(37, cols)
+        s[0, 5] = 80.0
+        sr = s.double().requires_grad_(True)
+        pr = torch.softmax(sr, -1)
+        dp = rn(37, cols)
+        (pr * dp.double()).sum().backward()
+        sd = d(s)
+        ops.f32_softmax_fwd(sd, 37, cols)
+        assert rel(sd, pr) < 1e-6
+        dpd = d(dp)
+        ops.f32_softmax_bwd(sd, dpd, 37, cols)
+        assert rel(dpd, sr.grad) < 2e-6
+    u, dh_ = rn(M, 2 * 96), rn(M, 96)
+    ur = u.double().requires_grad_(True)
+    hr = odit.silu(ur[:, :96]) * ur[:, 96:]
+    (hr * dh_.double()).sum().backward()
+    ud, hd, dud = d(u), torch.empty(M, 96, device=DEV), torch.empty(M, 192, device=DEV)
+    ops.f32_swiglu_fwd(ud, hd)
+    ops.f32_swiglu_bwd(d(dh_), ud, dud)
+    assert rel(hd, hr) < 1e-6 and rel(dud, ur.grad) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ whole model
+def test_small_model_fp32_against_reference_fixture(golden):
+    """flow loss / prediction / EVERY parameter gradient of the fp32 regime vs the REFERENCE's fp32 outputs (dit_small16.npz)"""
+    from diffulab_amd import Diffuser
+
+    g = golden("dit_small16")
+    m, _ = build(SMALL, seed=5)
+    assert m.precision == "fp32" and type(m.engine).__name__ == "DiTEngineF32"
+    B, H = 4, 16
+    x0, noise = synth.normal("s16.x0", (B, 4, H, H)), synth.normal("s16.noise", (B, 4, H, H))
+    t, y = synth.uniform("s16.t", (B,), lo=0.02, hi=0.98), synth.integers("s16.y", (B,), 10)
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=50)
+    inputs = {"x": x0.to(DEV), "y": y.to(DEV), "p": 0.0}
+    loss = d.compute_loss(inputs, timesteps=t, noise=noise.to(DEV))["loss"]
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) / float(g["loss"]) < TOL
+    with torch.no_grad():
+        pred = m(x=inputs["x"], timesteps=t.to(DEV), y=y.to(DEV))["x"]
+    assert rel(pred, g["pred"]) < TOL
+    errs = {name: rel(p.grad, g["g_" + name]) for name, p in m.named_parameters()}
+    top = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print("fp32 regime, largest per-tensor gradient errors vs the reference:", top)
+    assert top[0][1] < TOL, top
+    # bit-reproducible: no atomics anywhere in the regime
+    g1 = m._flat_grad.clone()
+    m.zero_grad()
+    inputs = {"x": x0.to(DEV), "y": y.to(DEV), "p": 0.0}
+    d.compute_loss(inputs, timesteps=t, noise=noise.to(DEV))["loss"].backward()
+    assert torch.equal(g1, m._flat_grad)
+
+
+@pytest.mark.timeout(900)
+def test_dit_s2_fp32_against_reference_fixture_and_oracle(golden):
+    """BASELINE config dims (DiT-S/2, 4x32x32 latents, 256 tokens): loss, prediction and gradients vs the reference fixture
+    (dit_s2.npz: full small tensors, strided samples of the big ones) AND every gradient tensor vs the CPU oracle"""
+    from diffulab_amd import Diffuser
+
+    g = golden("dit_s2")
+    m, P = build(S2, seed=7)
+    B = 2
+    x0, noise = synth.normal("s2.x0", (B, 4, 32, 32)), synth.normal("s2.noise", (B, 4, 32, 32))
+    t, y = synth.uniform("s2.t", (B,), lo=0.05, hi=0.95), synth.integers("s2.y", (B,), 1000)
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=50)
+    inputs = {"x": x0.to(DEV), "y": y.to(DEV), "p": 0.0}
+    loss = d.compute_loss(inputs, timesteps=t, noise=noise.to(DEV))["loss"]
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) / float(g["loss"]) < TOL
+    with torch.no_grad():
+        pred = m(x=inputs["x"], timesteps=t.to(DEV), y=y.to(DEV))["x"]
+    assert rel(pred, g["pred"]) < TOL
+    params = dict(m.named_parameters())
+    norms = dict(zip(g["grad_names"].tolist(), g["grad_norms"].tolist()))
+    for n, ref in norms.items():
+        got = params[n].grad.double().norm().item()
+        assert abs(got - ref) <= TOL * max(ref, 1e-12), (n, got, ref)
+    errs = {}
+    for k in g:
+        if k.startswith("g_"):
+            errs[k] = rel(params[k[2:]].grad, g[k])
+        elif k.startswith("gs_"):  # strided 512-entry sample of a big tensor, measured against the tensor's RMS scale
+            gr = params[k[3:]].grad
+            smp = gr.flatten()[:: max(1, gr.numel() // 512)][:512].double().cpu()
+            ref_s = torch.from_numpy(g[k]).double()
+            scale = norms[k[3:]] * (ref_s.numel() / gr.numel()) ** 0.5
+            errs[k] = ((smp - ref_s).norm() / max(scale, ref_s.norm().item())).item()
+    top = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    print("fp32 regime at DiT-S/2, largest gradient errors vs the reference fixture:", top)
+    assert top[0][1] < TOL, top
+    # every tensor, in full, against the oracle
+    cfg = odit.DiTConfig(**S2)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = od.flow_loss(odit.dit_forward(Pr, od.flow_add_noise(x0, t, noise), t, y, cfg), x0, noise)
+    ref.backward()
+    e2 = sorted(((rel(p.grad, Pr[n].grad), n) for n, p in m.named_parameters()), reverse=True)
+    print("vs oracle:", e2[:4])
+    assert e2[0][0] < TOL, e2[:4]
+
+
+@pytest.mark.timeout(900)
+def test_loss_curve_fp32_meets_the_north_star_bar(golden):
+    """north_star: "loss curve matching CPU reference to 1e-4 rel".  20 AdamW steps of DiT-S/2 on fixed synthetic data in the fp32
+    regime against the REFERENCE's own fp32 curve (tests/golden/loss_curve.npz): <= 1e-4 at EVERY step; the trained qkv weights of
+    block 0 agree with the reference's after the 20 updates."""
+    from diffulab_amd import Diffuser
+    from diffulab_amd.training import FusedAdamW
+
+    g = golden("loss_curve")
+    m, _ = build(S2, seed=7)
+    opt = FusedAdamW(m.parameters(), lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8)
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=50)
+    B = 4
+    x0, y = synth.normal("curve.x0", (B, 4, 32, 32)).to(DEV), synth.integers("curve.y", (B,), 1000).to(DEV)
+    got = []
+    for s in range(len(g["losses"])):
+        noise = synth.normal(f"curve.noise{s}", (B, 4, 32, 32)).to(DEV)
+        t = synth.uniform(f"curve.t{s}", (B,), lo=0.02, hi=0.98)
+        opt.zero_grad()
+        loss = d.compute_loss({"x": x0, "y": y, "p": 0.0}, timesteps=t, noise=noise)["loss"]
+        loss.backward()
+        opt.step()
+        got.append(loss.item())
+    err = np.abs(np.array(got) - g["losses"]) / g["losses"]
+    print("fp32 loss curve rel err per step:", err)
+    assert len(err) == 20 and err.max() < 1e-4, err
+    w = m.layers[0].attention.qkv.weight.detach().flatten()[: g["final_qkv0"].size].cpu().numpy()
+    print("final qkv0 rel err", np.linalg.norm(w - g["final_qkv0"]) / np.linalg.norm(g["final_qkv0"]))
+
+
+def test_cifar_dims_fp32_against_oracle():
+    """configs/model/dit.yaml dims (RGB 32x32, patch 2 -> 12 features per patch: the ragged / scalar-load GEMM path, D = 512, no
+    classifier-free row) at depth 2, label drop p = 1 not used: loss + every gradient vs the oracle"""
+    from diffulab_amd import Diffuser
+
+    kw = dict(input_channels=3, output_channels=3, inner_dim=512, embedding_dim=512, num_heads=8, mlp_ratio=4, patch_size=2,
+              depth=2, n_classes=10, classifier_free=False)
+    m, P = build(kw, seed=11)
+    cfg = odit.DiTConfig(**kw)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    B = 4
+    x0, noise = synth.normal("cf.x0", (B, 3, 32, 32)), synth.normal("cf.noise", (B, 3, 32, 32))
+    y, t = synth.integers("cf.y", (B,), 10), synth.uniform("cf.t", (B,), lo=0.05, hi=0.95)
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=100)
+    loss = d.compute_loss({"x": x0.to(DEV), "y": y.to(DEV), "p": 0.0}, timesteps=t, noise=noise.to(DEV))["loss"]
+    loss.backward()
+    ref = od.flow_loss(odit.dit_forward(Pr, od.flow_add_noise(x0, t, noise), t, y, cfg), x0, noise)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) / ref.item() < TOL
+    worst = max((rel(p.grad, Pr[n].grad), n) for n, p in m.named_parameters())
+    assert worst[0] < TOL, worst
+
+
+@pytest.mark.parametrize("precision,tol_loss,tol_grad", [("fp32", 1e-5, 1e-5), ("bf16", 2e-3, 3e-2)])
+def test_x_prediction_end_to_end(precision, tol_loss, tol_grad):
+    """Flow(prediction_type="x") (flow.py:168-197 clamp 0.05, :300-303 x -> v): loss and every gradient through
+    Diffuser.compute_loss -> _XToV -> dl_flow_x_to_v_bwd vs the oracle, in both regimes"""
+    from diffulab_amd import Diffuser
+
+    m, P = build(SMALL, seed=5, precision=precision)
+    cfg = odit.DiTConfig(**SMALL)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    B, H = 4, 16
+    x0, noise = synth.normal("xp.x0", (B, 4, H, H)), synth.normal("xp.noise", (B, 4, H, H))
+    y = synth.integers("xp.y", (B,), 10)
+    torch.manual_seed(5)
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=10, extra_args={"prediction_type": "x"})
+    t = d.draw_timesteps(B)
+    assert float(t.min()) >= 0.05  # the x-prediction clamp
+    loss = d.compute_loss({"x": x0.to(DEV), "y": y.to(DEV), "p": 0.0}, timesteps=t, noise=noise.to(DEV))["loss"]
+    loss.backward()
+    z = od.flow_add_noise(x0, t, noise)
+    ref = od.flow_loss(od.flow_x_to_v(z, odit.dit_forward(Pr, z, t, y, cfg), t), x0, noise)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) / ref.item() < tol_loss
+    worst = max((rel(p.grad, Pr[n].grad), n) for n, p in m.named_parameters())
+    print(precision, "x-prediction worst gradient error", worst)
+    assert worst[0] < tol_grad, worst
+    # sampling with an x-predicting model: v = (x - xhat) / max(t, 0.05) (flow.py:224-226)
+    with torch.no_grad():
+        out = d.generate({"x": noise.to(DEV), "y": y.to(DEV)}, use_tqdm=False)["x"]
+    xs = noise.clone()
+    ts = od.flow_timesteps(10)
+    Pc = {k: v for k, v in P.items()}
+    for tc, tp in zip(ts[:-1], ts[1:]):
+        xh = odit.dit_forward(Pc, xs, torch.full((B,), tc), y, cfg)
+        v = (xs - xh) / max(tc, 0.05)
+        xs = od.euler_step(xs, v, tc, tp)["x_prev"]
+    assert rel(out, xs) < (1e-5 if precision == "fp32" else 3e-2)
+
+
+def test_euler_sampler_loop_fp32_against_reference_fixture(golden):
+    """Flow.denoise + Euler.step with classifier-free guidance (two forwards per step) in the fp32 regime vs the reference loop"""
+    from diffulab_amd import Diffuser
+
+    g = golden("dit_small16")
+    m, _ = build(SMALL, seed=5)
+    m.eval()
+    B, H = 4, 16
+    y = synth.integers("s16.y", (B,), 10).to(DEV)
+    x_init = synth.normal("s16.init", (B, 4, H, H))
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=4)
+    out = d.generate({"x": x_init.to(DEV), "y": y}, use_tqdm=False, guidance_scale=2.0, return_intermediates=True)
+    assert rel(out["x"], g["loop_euler_x"]) < TOL and rel(out["estimated_x0"], g["loop_euler_x0"]) < TOL
+    out2 = d.generate({"x": x_init.to(DEV), "y": y}, use_tqdm=False, guidance_scale=2.0)  # second call: hipGraph replay
+    assert torch.equal(out2["x"], out["x"])
+
+
+def test_trainer_default_precision_trains_in_fp32(tmp_path):
+    """BaseTrainer() with the reference's default precision_type ("no") switches the DiT to the fp32 engine at prepare() and trains:
+    two training_steps follow the oracle's AdamW trajectory to fp32 accuracy; switching the module back restores the bf16 engine on
+    the same arena"""
+    from diffulab_amd import Diffuser
+    from diffulab_amd.training import BaseTrainer, FusedAdamW
+
+    m, P = build(SMALL, seed=5, precision="bf16")
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=4)
+    opt = FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+    tr = BaseTrainer(n_epoch=1, gradient_accumulation_step=1, save_path=tmp_path, project_name="fp32", use_ema=False)
+    assert tr.precision_type == "no"
+    tr.prepare(d, opt)
+    assert m.precision == "fp32"
+    B, H = 4, 16
+    x0, y = synth.normal("tr.x0", (B, 4, H, H)), synth.integers("tr.y", (B,), 10)
+    cfg = odit.DiTConfig(**SMALL)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ropt = torch.optim.AdamW(list(Pr.values()), lr=1e-3, weight_decay=0.01)
+    from diffulab_amd.training.utils import AverageMeter
+
+    meter = AverageMeter()
+    for s in range(2):
+        noise = synth.normal(f"tr.n{s}", (B, 4, H, H))
+        torch.manual_seed(100 + s)
+        t = d.draw_timesteps(B)
+        ropt.zero_grad()
+        ref = od.flow_loss(odit.dit_forward(Pr, od.flow_add_noise(x0, t, noise), t, y, cfg), x0, noise)
+        ref.backward()
+        ropt.step()
+        torch.manual_seed(100 + s)  # training_step draws its timesteps from the CPU generator (base_trainer.py:140)
+        orig = torch.randn_like
+        torch.randn_like = lambda ref_, **kw: noise.to(ref_.device)  # noqa: E731  (the noise the oracle used)
+        try:
+            meter.reset()
+            tr.training_step(d, opt, {"model_inputs": {"x": x0.to(DEV), "y": y.to(DEV)}, "extra": {}}, meter,
+                             p_classifier_free_guidance=0.0)
+        finally:
+            torch.randn_like = orig
+        assert abs(meter.avg["train/loss"] - ref.item()) / ref.item() < 1e-5, (s, meter.avg, ref.item())
+    worst = max((rel(p, Pr[n]), n) for n, p in m.named_parameters())
+    assert worst[0] < 1e-5, worst
+    flat = m._flat.clone()
+    m.set_precision("bf16")
+    with torch.no_grad():
+        m(x=x0.to(DEV), timesteps=torch.full((B,), 0.5, device=DEV), y=y.to(DEV))
+    assert type(m.engine).__name__ == "DiTEngine" and torch.equal(m._flat, flat), "same parameters, other launch sequence"

@@ -1,6 +1,7 @@
 """Host-side logic of the trainer mirror (no GPU): config composition, ``_target_`` resolution, EMA decay schedule of
 ema_pytorch (restated), batch sharding with ``split_batches=True`` semantics, accumulation boundaries."""
 
+import copy
 import os
 
 import pytest
@@ -199,17 +200,30 @@ def test_true_accumulation_switch_differs_from_the_reference(tmp_path):
     np.testing.assert_allclose(w[1], m.weight.detach().numpy(), atol=2e-7)
 
 
-def test_fp32_precision_is_refused_not_silently_downgraded(tmp_path):
-    """``precision_type="no"`` (the reference's fp32 default) used to be accepted and run in bf16.  The HIP path has
-    one precision regime; asking for another raises at construction, and the shipped trainer config names the regime."""
+def test_precision_types_follow_the_reference_default(tmp_path):
+    """``precision_type="no"`` (the reference's fp32 default, trainers/common.py:76,105; configs/trainer/default.yaml:4) is a
+    regime of its own since round 4 (engine_f32.py): the trainer accepts it, defaults to it like the reference, and asks the denoiser
+    for its fp32 launch sequence at prepare(); a denoiser that has only the bf16 regime refuses there and names the override.
+    fp16 / fp8 are still refused at construction (they would silently be something else)."""
     import yaml
 
+    from diffulab_amd import MMDiT, UNetModel
     from diffulab_amd.training import BaseTrainer
 
-    for bad in ("no", "fp16", "fp8"):
+    for bad in ("fp16", "fp8"):
         with pytest.raises(NotImplementedError, match="bf16"):
             BaseTrainer(n_epoch=1, precision_type=bad, save_path=tmp_path, project_name="p")
-    BaseTrainer(n_epoch=1, precision_type="bf16", save_path=tmp_path, project_name="p")
-    BaseTrainer(n_epoch=1, save_path=tmp_path, project_name="p")  # the default is the regime that exists
+    assert BaseTrainer(n_epoch=1, precision_type="bf16", save_path=tmp_path, project_name="p").precision_type == "bf16"
+    assert BaseTrainer(n_epoch=1, save_path=tmp_path, project_name="p").precision_type == "no"  # the reference's default
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    assert yaml.safe_load(open(os.path.join(root, "configs", "trainer", "default.yaml")))["precision_type"] == "bf16"
+    assert yaml.safe_load(open(os.path.join(root, "configs", "trainer", "default.yaml")))["precision_type"] == "no"
+    # the module-level switch the trainer drives
+    dit = MMDiT(simple_dit=True, input_channels=4, inner_dim=128, embedding_dim=64, num_heads=2, patch_size=2, depth=1, n_classes=10)
+    assert dit.precision == "bf16" and dit.precisions == ("bf16", "fp32")
+    assert dit.set_precision("fp32").precision == "fp32" and copy.deepcopy(dit).precision == "fp32"
+    with pytest.raises(ValueError):
+        dit.set_precision("fp64")
+    unet = UNetModel(image_size=[32, 32], in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1, attention_resolutions=[],
+                     channel_mult="1,2", n_classes=10)
+    with pytest.raises(NotImplementedError, match="fp32"):
+        unet.set_precision("fp32")
