@@ -282,8 +282,10 @@ def test_loss_curve_fp32_meets_the_north_star_bar(golden):
     err = np.abs(np.array(got) - g["losses"]) / g["losses"]
     print("fp32 loss curve rel err per step:", err)
     assert len(err) == 20 and err.max() < 1e-4, err
-    w = m.layers[0].attention.qkv.weight.detach().flatten()[: g["final_qkv0"].size].cpu().numpy()
-    print("final qkv0 rel err", np.linalg.norm(w - g["final_qkv0"]) / np.linalg.norm(g["final_qkv0"]))
+    w = m.layers[0].attention.qkv.weight.detach().flatten()[::577][:256].cpu().numpy()  # (the fixture's strided sample)
+    e_w = np.linalg.norm(w - g["final_qkv0"]) / np.linalg.norm(g["final_qkv0"])
+    print("trained qkv weights of block 0 after 20 AdamW steps, rel err vs the reference:", e_w)
+    assert e_w < 1e-5
 
 
 def test_cifar_dims_fp32_against_oracle():
