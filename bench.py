@@ -364,6 +364,23 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
                      "avg_launch_us": round(t_ms * 1e3 / sum(c for (n, *_), c in tn_shapes.items() if n == dom), 2),
                      "note": "same launches alone on the whole chip; in the step they share it with the main chain on a side stream"}
     step_ach = images_per_s_per_gpu * train_flops_per_image() / 1e12
+    # The two floors of THIS dataflow and where the step stands against the larger one (the step is the SUM of its
+    # kernels' MFMA and HBM phases; max(floors) is what a perfectly overlapped execution of the same bytes and FLOPs would take):
+    #   hbm_floor_ms  = HBM bytes per step of the newest committed PMC pass (every kernel; the trace's step count comes from its
+    #                   adamw_k launches; fills of the model build excluded) / 6.3 TB/s (achievable of the 8 TB/s peak)
+    #   mfma_floor_ms = MFMA FLOPs the step EXECUTES (instrumented launches, recomputed MLP pre-activations included) / 2.5 PF/s
+    floors = None
+    if tfiles:
+        steps_in_trace = max(1, sum(v["launches"] for k_, v in t.items() if k_.startswith("adamw_k")))
+        gb = sum(v["launches"] * (v["fetch_MB"] + v["write_MB"]) for k_, v in t.items()
+                 if not k_.startswith("at::native") and "FillFunctor" not in k_) / 1e3 / steps_in_trace
+        exec_tf = sum(v[2] for v in per.values()) / reps / 1e12
+        step_ms = 1e3 * model.engine.geo[0] / images_per_s_per_gpu
+        hbm_ms, mfma_ms = gb / 6.3, exec_tf / PEAK_BF16_TFLOPS * 1e3
+        floors = {"hbm_GB_per_step": round(gb, 1), "hbm_floor_ms": round(hbm_ms, 2), "executed_TFLOP_per_step": round(exec_tf, 2),
+                  "mfma_floor_ms": round(mfma_ms, 2), "step_ms": round(step_ms, 2),
+                  "frac_of_max_floor": round(max(hbm_ms, mfma_ms) / step_ms, 3),
+                  "sum_of_floors_ms": round(hbm_ms + mfma_ms, 2)}
     label = dom + (" (+ tn_group_fold_k: one C call)" if dom == "gemm_tn_group_k" else "")
     return {"bound": "mfma", "kernel": label + " (largest summed launch time of the step's instrumented launches)",
             "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
@@ -371,7 +388,7 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
             "flops_per_launch": round(fl / n_l), "launches_per_step": n_l // reps, "avg_launch_us": round(ms * 1e3 / n_l, 2),
             "ms_per_step": round(ms / reps, 3), "kernels": kernels,
             "step_achieved": round(step_ach, 1), "step_frac": round(step_ach / PEAK_BF16_TFLOPS, 4),
-            "hbm_bound_kernels": hbm_kernels, "dominant_kernel_alone": alone}
+            "hbm_bound_kernels": hbm_kernels, "dominant_kernel_alone": alone, "floors": floors}
 
 
 def self_launch(n: int) -> int:

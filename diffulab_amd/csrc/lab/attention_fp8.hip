@@ -6,10 +6,10 @@
 // Reference op: F.scaled_dot_product_attention on the joint sequence, mmdit.py:172-190 (MMDiTAttention.forward).
 //
 // Data flow
-//   dl_attn_fp8_quantize : q, k, v bf16 [B,H,N,64]  ->  q8, k8 fp8 [B,H,N,64] (64-byte rows), v8t fp8 [B,H,64,N] (V transposed,
+//   dl_probe_attn_fp8_quantize : q, k, v bf16 [B,H,N,64]  ->  q8, k8 fp8 [B,H,N,64] (64-byte rows), v8t fp8 [B,H,64,N] (V transposed,
 //                          keys of every 64-key block stored in the ORDER THE P REGISTERS HOLD THEM, see below), scales f32 [B,H,3]
 //                          = amax / 448 of each tensor per head (two launches: amax, then quantize)
-//   dl_attn_fwd_fp8      : one workgroup per (b, h, 256-query chunk), 8 waves x 32 queries; K / V^T chunks of 256 keys are DMA'd
+//   dl_probe_attn_fwd_fp8      : one workgroup per (b, h, 256-query chunk), 8 waves x 32 queries; K / V^T chunks of 256 keys are DMA'd
 //                          into LDS (16 KiB each); transposed orientation as in attention.hip: the 32x32 accumulator of S^T holds
 //                          per lane one query column and 16 keys, so the softmax statistics are in-register and the exponentiated
 //                          tile, converted to fp8, IS the B operand of the next MFMA: k-slot (16 t + r) of lane half hi <-> key
@@ -18,7 +18,8 @@
 // P is quantised as p * 2^8 (e4m3 keeps 3 mantissa bits down to 2^-6; p <= 1 would waste the top of the range); the row sum l is
 // accumulated from the UNQUANTISED p in f32 and the 2^-8 is folded into the final normalisation.
 // The backward stays bf16 (dl_attn_bwd_ex recomputes S from the bf16 q, k with the lse written here).
-#include "common.h"
+#include "../common.h"
+#include "../../../include/diffulab_probe.h"
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
@@ -121,12 +122,12 @@ __global__ __launch_bounds__(256) void f8_quant_vt_k(const bf16_t* __restrict__ 
   *(u32x4_t*)(v8t + ((int64_t)bh * DH + c) * Nk + blk * 64 + pg * 16) = o;
 }
 
-extern "C" int dl_attn_fp8_quantize(const void* q, const void* k, const void* v, void* q8, void* k8, void* v8t, float* scales,
+extern "C" int dl_probe_attn_fp8_quantize(const void* q, const void* k, const void* v, void* q8, void* k8, void* v8t, float* scales,
                                     int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t dh, dl_stream_t stream) {
-  DL_CHECK_ARG(q && k && v && q8 && k8 && v8t && scales && B > 0 && H > 0, "dl_attn_fp8_quantize: null operand");
-  DL_CHECK_ARG(dh == DH && Nq % 64 == 0 && Nk % 64 == 0 && Nq > 0 && Nk > 0, "dl_attn_fp8_quantize: dh=64, N %% 64 == 0");
+  DL_CHECK_ARG(q && k && v && q8 && k8 && v8t && scales && B > 0 && H > 0, "dl_probe_attn_fp8_quantize: null operand");
+  DL_CHECK_ARG(dh == DH && Nq % 64 == 0 && Nk % 64 == 0 && Nq > 0 && Nk > 0, "dl_probe_attn_fp8_quantize: dh=64, N %% 64 == 0");
   DL_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)q8 | (uintptr_t)k8 | (uintptr_t)v8t) & 15) == 0,
-               "dl_attn_fp8_quantize: 16-byte alignment");
+               "dl_probe_attn_fp8_quantize: 16-byte alignment");
   const int64_t nbh = B * H;
   hipLaunchKernelGGL(f8_amax_k, (int)(nbh * 3), 256, 0, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                      scales, (int)Nq, (int)Nk);
@@ -264,13 +265,13 @@ __global__ __launch_bounds__(512) void attn_fwd_fp8_k(const uint8_t* __restrict_
   if (hi == 0) lse[(int64_t)bh * Nq + qrow] = (m_run + log2f(l_tot)) * LN2;
 }
 
-extern "C" int dl_attn_fwd_fp8(const void* q8, const void* k8, const void* v8t, const float* scales, void* out, float* lse,
+extern "C" int dl_probe_attn_fwd_fp8(const void* q8, const void* k8, const void* v8t, const float* scales, void* out, float* lse,
                                int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t dh, float scale, const float* key_bias,
                                dl_stream_t stream) {
-  DL_CHECK_ARG(q8 && k8 && v8t && scales && out && lse && B > 0 && H > 0, "dl_attn_fwd_fp8: null operand");
-  DL_CHECK_ARG(dh == DH, "dl_attn_fwd_fp8: head_dim %lld unsupported (64 only)", (long long)dh);
+  DL_CHECK_ARG(q8 && k8 && v8t && scales && out && lse && B > 0 && H > 0, "dl_probe_attn_fwd_fp8: null operand");
+  DL_CHECK_ARG(dh == DH, "dl_probe_attn_fwd_fp8: head_dim %lld unsupported (64 only)", (long long)dh);
   DL_CHECK_ARG(Nq % FCH == 0 && Nk % FCH == 0 && Nq > 0 && Nk > 0 && Nq <= 4096 && Nk <= 4096,
-               "dl_attn_fwd_fp8: Nq=%lld Nk=%lld must be multiples of 256 up to 4096 (pad and mask)", (long long)Nq, (long long)Nk);
+               "dl_probe_attn_fwd_fp8: Nq=%lld Nk=%lld must be multiples of 256 up to 4096 (pad and mask)", (long long)Nq, (long long)Nk);
   const int lds = 2 * FCH * DH + FCH * (int)sizeof(float);
   hipLaunchKernelGGL(attn_fwd_fp8_k, (int)(B * H * (Nq / FCH)), 512, lds, (hipStream_t)stream, (const uint8_t*)q8,
                      (const uint8_t*)k8, (const uint8_t*)v8t, scales, (bf16_t*)out, lse, (int)H, (int)Nq, (int)Nk, scale, key_bias);

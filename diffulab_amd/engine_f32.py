@@ -136,7 +136,7 @@ class DiTEngineF32:
             w["dse"], w["demb"], w["dh1"], w["dpre1"] = z(B, E), z(B, E), z(B, E), z(B, E)
             # split-K scratch of the weight gradients over all tokens (and of the conditioning path's long contraction): up to 64
             # partial images of the largest weight (dl_f32_gemm folds them in a fixed order)
-            big = max(2 * F * D, R * E if B >= 64 else 0, 1 << 20)
+            big = max(2 * F * D, B * E, B * R // 8, 1 << 18)
             w["scr"] = torch.empty(min(64, max(2, M // 256)) * big, device=dev, dtype=torch.float32)
         self.ws, self._ws_key = w, key
         self.geo = (B, H, W, gh, gw, N, M, Fi, Fo)
@@ -241,7 +241,7 @@ class DiTEngineF32:
         # head: last linear (mmdit.py:548) + final adaLN (mmdit.py:543-547)
         ops.f32_patchify(dpred, w["dO"], d.patch_size, ops.PATCH_PPC)
         ops.f32_linear_wgrad(w["dO"], w["xf"], GW("last_layer.linear.weight"), scratch=scr)
-        ops.colsum(w["dO"], G("last_layer.linear.bias"), M, Fo)
+        ops.colsum(w["dO"], G("last_layer.linear.bias"), M, Fo, scratch=scr)
         ops.f32_linear_dgrad(w["dO"], Wt("last_layer.linear.weight"), w["dxm"])
         mo, ml = L * 6 * D, (L - 1) * 6 * D
         dx, dx_alt = w["dxa"], w["dxb"]
@@ -262,7 +262,7 @@ class DiTEngineF32:
                                     N, a["mean2"], a["rstd2"], dx, dx_alt, dmod[:, mo + 3 * D : mo + 4 * D],
                                     dmod[:, mo + 4 * D : mo + 5 * D], w["dwb"], gate_t=a["t1"], gate=mod[:, mo + 2 * D : mo + 3 * D],
                                     dt=w["dt1"], dgate=dmod[:, mo + 2 * D : mo + 3 * D])
-            ops.reduce_rows_f32(w["dwb"], G(pre + "norm_2.weight"), B, 2 * D)  # [w; b] are adjacent in the arena
+            ops.reduce_rows_batched_f32(w["dwb"], 0, G(pre + "norm_2.weight"), 0, 1, B, 2 * D)  # [w; b] adjacent; fixed-order fold
             dx, dx_alt = dx_alt, dx
             # attention branch (mmdit.py:75-104)
             ops.f32_linear_wgrad(w["dt1"], a["a"], GW(pre + "attention.proj_out.weight"), scratch=scr)
@@ -283,7 +283,7 @@ class DiTEngineF32:
             ops.f32_qk_norm_rope_bwd(w["dqk"], a["qkv"], P(pre + "attention.qk_norm.query_norm.scale"),
                                      P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], w["dqkv"], w["dqs"], B, N, Hh, dh,
                                      rot)
-            ops.reduce_rows_f32(w["dqs"], G(pre + "attention.qk_norm.query_norm.scale"), B, 2 * D)  # [q; k] scales adjacent
+            ops.reduce_rows_batched_f32(w["dqs"], 0, G(pre + "attention.qk_norm.query_norm.scale"), 0, 1, B, 2 * D)  # [q; k] adjacent
             ops.f32_linear_wgrad(w["dqkv"], a["xm1"], GW(pre + "attention.qkv.weight"), scratch=scr)
             ops.f32_linear_dgrad(w["dqkv"], Wt(pre + "attention.qkv.weight"), w["dxm"])
             if i - 1 in dfeats:  # auxiliary-loss gradient on the output of block i-1 (= this block's input)
@@ -296,7 +296,7 @@ class DiTEngineF32:
             ops.f32_ln_modulate_bwd(w["dxm"], xs[i], P(pre + "norm_1.weight"), P(pre + "norm_1.bias"), mod[:, mo : mo + D], N,
                                     a["mean1"], a["rstd1"], dx, dx_alt, dmod[:, mo : mo + D], dmod[:, mo + D : mo + 2 * D], w["dwb"],
                                     **nxt)
-            ops.reduce_rows_f32(w["dwb"], G(pre + "norm_1.weight"), B, 2 * D)
+            ops.reduce_rows_batched_f32(w["dwb"], 0, G(pre + "norm_1.weight"), 0, 1, B, 2 * D)
             dx, dx_alt = dx_alt, dx
 
         # stem (no gradient flows to the input latents) and conditioning path
@@ -304,17 +304,17 @@ class DiTEngineF32:
         g_modw, g_modb = self._mod_matrix(self.grads)
         mod_w, _ = self._mod_matrix(self.params)
         ops.f32_linear_wgrad(dmod, w["se"], g_modw)
-        ops.colsum(dmod, g_modb, B, self.layout.mod_rows)
+        ops.colsum(dmod, g_modb, B, self.layout.mod_rows, scratch=scr)
         ops.f32_linear_dgrad(dmod, mod_w, w["dse"], scratch=scr)
         table = d.n_classes is not None
         ops.f32_cond_combine_bwd(w["dse"], w["emb"], self._yeff if table else None, w["demb"],
                                  G("label_embed.embedding.weight") if table else None)
-        ops.colsum(w["demb"], G("time_embed.2.bias"), B, E)
+        ops.colsum(w["demb"], G("time_embed.2.bias"), B, E, scratch=scr)
         ops.f32_linear_wgrad(w["demb"], w["h1"], GW("time_embed.2.weight"))
         ops.f32_linear_dgrad(w["demb"], Wt("time_embed.2.weight"), w["dh1"])
         ops.f32_silu_bwd(w["dh1"], w["pre1"], w["dpre1"])
         ops.f32_linear_wgrad(w["dpre1"], w["temb"], GW("time_embed.0.weight"))
-        ops.colsum(w["dpre1"], G("time_embed.0.bias"), B, E)
+        ops.colsum(w["dpre1"], G("time_embed.0.bias"), B, E, scratch=scr)
         if self.reducer is not None:  # data parallel: one exchange over the whole arena once the backward has ended
             self.reducer.ready(0, self.layout.size)
             self.reducer.finish()

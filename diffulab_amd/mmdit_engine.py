@@ -278,7 +278,7 @@ class JointEngine(DiTEngine):
                 ops.qk_norm_rope_fwd(a["qkv"], self.P(pre + f"attention.qk_norm_{st}.query_norm.scale"),
                                      self.P(pre + f"attention.qk_norm_{st}.key_norm.scale"), cos[off:], sin[off:], q, k, v, a["rrms"],
                                      B, nt, Hh, 64, rot, n_off=off)
-            ops.attn_fwd_joint(q, k, v, per["ao"], per["lse"], B, Hh, Tp, Tp, 64, 64**-0.5, kb)
+            ops.attn_fwd_ex(q, k, v, per["ao"], per["lse"], B, Hh, Tp, Tp, 64, 64**-0.5, kb)
             for st, nt, off, mc in streams:
                 if st == "context" and i == L - 1:  # feeds nothing (the reference computes and discards it)
                     continue

@@ -477,16 +477,6 @@ def v_in_place(N: int) -> bool:
     return N <= 256 and tuning.on("DL_ATTN_V_IN_PLACE")
 
 
-def attn_fp8_quantize(q, k, v, q8, k8, v8t, scales, B, H, Nq, Nk, dh=64):
-    """q, k, v bf16 [B,H,N,64] -> e4m3 copies (v transposed and key-permuted) + per-head scales f32 [B,H,3]"""
-    _call("dl_attn_fp8_quantize", _p(q), _p(k), _p(v), _p(q8), _p(k8), _p(v8t), _p(scales), B, H, Nq, Nk, dh, _s())
-
-
-def attn_fwd_fp8(q8, k8, v8t, scales, out, lse, B, H, Nq, Nk, dh, scale, key_bias=None):
-    """fp8 MFMA attention forward (same outputs as attn_fwd_ex)"""
-    _call("dl_attn_fwd_fp8", _p(q8), _p(k8), _p(v8t), _p(scales), _p(out), _p(lse), B, H, Nq, Nk, dh, float(scale), _p(key_bias), _s())
-
-
 def dit_block_fwd(blk, train: bool) -> None:
     """one adaLN-zero DiT block forward issued by the library (blk: diffulab_amd._block.DitBlock)"""
     _call("dl_dit_block_fwd", ctypes.addressof(blk), int(train), _s())
@@ -532,33 +522,6 @@ def qk_norm_rope_bwd_inplace(qkv, scale_q, scale_k, cos, sin, rrms, dqkv, dscale
 def attn_fwd_ex(q, k, v, out, lse, B, H, Nq, Nk, dh, scale, key_bias=None):
     """Nq queries against Nk keys (multiples of 256), optional additive key bias f32 [B, Nk] (0 / -inf)"""
     _call("dl_attn_fwd_ex", _p(q), _p(k), _p(v), _p(out), _p(lse), B, H, Nq, Nk, dh, float(scale), _p(key_bias), _s())
-
-
-_FP8_WS: dict[tuple, tuple] = {}
-
-
-def fp8_attention_enabled() -> bool:
-    """DIFFULAB_FP8_ATTENTION=1: the joint text-image attention forward (BASELINE config 5) runs on the fp8 MFMA kernel"""
-    return os.environ.get("DIFFULAB_FP8_ATTENTION", "0") == "1"
-
-
-def attn_fwd_joint(q, k, v, out, lse, B, H, Nq, Nk, dh, scale, key_bias=None):
-    """forward of the joint-sequence attention: dl_attn_fwd_ex (bf16), or -- with DIFFULAB_FP8_ATTENTION=1 -- the e4m3 quantisation
-    pre-pass + dl_attn_fwd_fp8 (the backward is dl_attn_bwd_ex on the bf16 tensors either way).  The fp8 copies live in a per-shape
-    scratch that is allocated on first use (before any hipGraph capture of that shape)."""
-    if not fp8_attention_enabled():
-        return attn_fwd_ex(q, k, v, out, lse, B, H, Nq, Nk, dh, scale, key_bias)
-    key = (q.device.index, B, H, Nq, Nk)
-    ws = _FP8_WS.get(key)
-    if ws is None:
-        with torch.inference_mode(False):
-            u8 = dict(device=q.device, dtype=torch.uint8)
-            ws = (torch.empty(B, H, Nq, dh, **u8), torch.empty(B, H, Nk, dh, **u8), torch.empty(B, H, dh, Nk, **u8),
-                  torch.empty(B, H, 3, device=q.device, dtype=torch.float32))
-        _FP8_WS[key] = ws
-    q8, k8, v8t, sc = ws
-    attn_fp8_quantize(q, k, v, q8, k8, v8t, sc, B, H, Nq, Nk, dh)
-    attn_fwd_fp8(q8, k8, v8t, sc, out, lse, B, H, Nq, Nk, dh, scale, key_bias)
 
 
 def attn_bwd_ex(q, k, v, out, dout, lse, dq, dk, dv, B, H, Nq, Nk, dh, scale, key_bias=None):
@@ -629,6 +592,12 @@ def colsum(x, out, R=None, C=None, scratch=None):
 
 def reduce_rows_f32(partial, out, G, n, clear=False):
     _call("dl_reduce_rows_f32", _p(partial), _p(out), G, n, int(clear), _s())
+
+
+def add_transposed_f32(src, dst):
+    """dst[c, r] += src[r, c] (small f32 matrices)"""
+    R, C = src.shape
+    _call("dl_add_transposed_f32", _p(src), src.stride(0), _p(dst), dst.stride(0), R, C, _s())
 
 
 def reduce_rows_batched_f32(partial, partial_stride, out, out_stride, K, G, n):

@@ -294,7 +294,7 @@ class SprintJointEngine(DiTEngine):
                 ops.qk_norm_rope_fwd(a["qkv"], self.P(pre + f"attention.qk_norm_{st}.query_norm.scale"),
                                      self.P(pre + f"attention.qk_norm_{st}.key_norm.scale"), cos[off:], sin[off:], per["q"], per["k"],
                                      per["v"], a["rrms"], B, nt, Hh, 64, rot, pos=ps, n_off=off)
-            ops.attn_fwd_joint(per["q"], per["k"], per["v"], per["ao"], per["lse"], B, Hh, Tp, Tp, 64, 64**-0.5, kb)
+            ops.attn_fwd_ex(per["q"], per["k"], per["v"], per["ao"], per["lse"], B, Hh, Tp, Tp, 64, 64**-0.5, kb)
             for st, nt, off, mc, ps in streams:
                 if st == "context" and c_out is None and bi == blocks[-1]:
                     continue
@@ -419,7 +419,7 @@ class SprintJointEngine(DiTEngine):
             ops.qk_norm_rope_fwd(a["qkv"], self.P(pre + "attention.qk_norm.query_norm.scale"),
                                  self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["q"], a["k"], a["v"], a["rrms"], B, T, Hh,
                                  64, rot, pos=pos, n_off=0)
-            ops.attn_fwd_joint(a["q"], a["k"], a["v"], a["ao"], a["lse"], B, Hh, Tp, Tp, 64, 64**-0.5, kb)
+            ops.attn_fwd_ex(a["q"], a["k"], a["v"], a["ao"], a["lse"], B, Hh, Tp, Tp, 64, 64**-0.5, kb)
             ops.copy_rows3d(a["ao"], Tp * D, D, a["a"], T * D, D, B, T, D)
             ops.gemm_nt(a["a"], sh[pre + "attention.proj_out.weight|f"], a["ta"])
             if not ops.gemm_nt_swiglu(a["m"], sh[pre + "mlp.0.weight|g"], a["u"] if self._train else None, a["h"]):

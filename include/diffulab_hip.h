@@ -295,17 +295,6 @@ DL_API int dl_attn_fwd_ex(const void* q, const void* k, const void* v, void* out
 DL_API int dl_attn_bwd_ex(const void* q, const void* k, const void* v, const void* out, const void* dout,
                           const float* lse, void* dq, void* dk, void* dv, int64_t B, int64_t H, int64_t Nq, int64_t Nk,
                           int64_t dh, float scale, const float* key_bias, dl_stream_t stream);
-/* fp8 (OCP e4m3) forward of the general form for the long joint text-image sequences (BASELINE config 5; mmdit.py:172-190) on the
- * CDNA4 block-scaled matrix instruction v_mfma_scale_f32_32x32x64_f8f6f4 (one MFMA contracts a whole 64-wide head dimension).
- * dl_attn_fp8_quantize: q [B,H,Nq,64], k, v [B,H,Nk,64] bf16 -> q8, k8 (same row layout, 1 byte per element), v8t [B,H,64,Nk]
- * (V transposed, the keys of every 64-key block in the order the kernel's P registers hold them) and scales f32 [B,H,3]
- * (amax / 448 of q, k, v per head).  dl_attn_fwd_fp8: same outputs as dl_attn_fwd_ex (out bf16 [B,Nq,H*64], lse f32 [B,H,Nq]);
- * Nq, Nk multiples of 256 up to 4096; key_bias as in dl_attn_fwd_ex.  The backward stays dl_attn_bwd_ex on the bf16 tensors. */
-DL_API int dl_attn_fp8_quantize(const void* q, const void* k, const void* v, void* q8, void* k8, void* v8t, float* scales,
-                                int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t dh, dl_stream_t stream);
-DL_API int dl_attn_fwd_fp8(const void* q8, const void* k8, const void* v8t, const float* scales, void* out, float* lse,
-                           int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t dh, float scale, const float* key_bias,
-                           dl_stream_t stream);
 /* the N <= 256 kernels with V (and dV) addressed in place: head (b, h) of V starts at element b*v_batch_stride +
  * h*v_head_stride of `v`, its rows are v_pitch elements apart.  With v = qkv + 2*D, strides {N*3D, 64, 3D} the attention
  * reads the v third of the token-major qkv rows [B*N, 3D] (the reference's `qkv.chunk(3)`, mmdit.py:85-93) and the backward
@@ -364,6 +353,10 @@ DL_API int dl_colsum(const void* x, int dtype, int64_t ld, float* out, int64_t R
 /* out[j] += sum_g partial[g, j]   (second stage of the LayerNorm affine gradients); clear_partial != 0 zeroes `partial`
  * as it is read, so accumulate-into partial buffers need no memset */
 DL_API int dl_reduce_rows_f32(float* partial, float* out, int64_t G, int64_t n, int clear_partial, dl_stream_t stream);
+/* dst[c, r] += src[r, c] (f32, small): a weight gradient computed transposed because the transposed product has the friendlier
+ * shape -- the patch-embedding convolution's [D, C p p] gradient (mmdit.py:757-765) is taken as tok^T dX = [C p p, D] */
+DL_API int dl_add_transposed_f32(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t R, int64_t C,
+                                 dl_stream_t stream);
 /* K such folds in one launch, deterministic (one writer per element, fixed order):
  * out[k * out_stride + j] += sum_{g < G} partial[k * partial_stride + g * n + j]  for k < K, j < n (strides in elements) */
 DL_API int dl_reduce_rows_batched_f32(const float* partial, int64_t partial_stride, float* out, int64_t out_stride, int64_t K,

@@ -37,6 +37,19 @@ DL_API int dl_probe_dma(int kb, const void* A, const void* Bw, int64_t M, int64_
  * one-workgroup-per-CU kernels (scripts/lab/occupied_cus.py). */
 DL_API int dl_probe_spin(int n_wgs, int threads, int usec, dl_stream_t stream);
 
+/* LAB (rounds 2-3, not used by any engine: forward-only, breaks even end to end once its quantisation pre-pass is counted; the
+ * product's config-5 attention is the bf16 kernel).  fp8 (OCP e4m3) forward of the general form for the long joint text-image sequences (BASELINE config 5; mmdit.py:172-190) on the
+ * CDNA4 block-scaled matrix instruction v_mfma_scale_f32_32x32x64_f8f6f4 (one MFMA contracts a whole 64-wide head dimension).
+ * dl_probe_attn_fp8_quantize: q [B,H,Nq,64], k, v [B,H,Nk,64] bf16 -> q8, k8 (same row layout, 1 byte per element), v8t [B,H,64,Nk]
+ * (V transposed, the keys of every 64-key block in the order the kernel's P registers hold them) and scales f32 [B,H,3]
+ * (amax / 448 of q, k, v per head).  dl_probe_attn_fwd_fp8: same outputs as dl_attn_fwd_ex (out bf16 [B,Nq,H*64], lse f32 [B,H,Nq]);
+ * Nq, Nk multiples of 256 up to 4096; key_bias as in dl_attn_fwd_ex.  The backward stays dl_attn_bwd_ex on the bf16 tensors. */
+DL_API int dl_probe_attn_fp8_quantize(const void* q, const void* k, const void* v, void* q8, void* k8, void* v8t, float* scales,
+                                int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t dh, dl_stream_t stream);
+DL_API int dl_probe_attn_fwd_fp8(const void* q8, const void* k8, const void* v8t, const float* scales, void* out, float* lse,
+                           int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t dh, float scale, const float* key_bias,
+                           dl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

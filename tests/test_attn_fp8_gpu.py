@@ -1,11 +1,12 @@
-"""fp8 (e4m3) MFMA attention forward for the long joint sequences (BASELINE config 5; mmdit.py:172-190): semantics of the CDNA4
+"""LAB kernel (libdiffulab_probe.so since round 4: no engine uses it, the product's config-5 attention is the bf16 kernel -- the fp8
+forward broke even end to end once its quantisation pre-pass was counted and has no fp8 backward).
+fp8 (e4m3) MFMA attention forward for the long joint sequences (BASELINE config 5; mmdit.py:172-190): semantics of the CDNA4
 block-scaled matrix instruction, the quantisation pre-pass, and the kernel against an fp64 softmax attention on the same bf16
 inputs.  Tolerance: e4m3 keeps 3 mantissa bits, so per-element products carry ~3 % noise that averages over 64-wide dot products and
 hundreds of keys.  Stated tolerance: 6e-2 relative L2 of the attention output on WHITE-NOISE q, k, v (measured 5.3e-2: the worst
 case -- the output is then an average of ~N independent values and every quantisation error is as large as the signal's own spread),
 1e-1 on peaked attention patterns (scores with 3x the spread: the ~4 % rms error of an e4m3 dot product is multiplied by the score
-scale before the exponential; measured 8.1e-2), lse within 6e-2 / 0.5 absolute; through the joint MMDiT (reference fixture) the prediction moves by less than
-3e-2 and the loss by less than 1e-2 against the bf16 path."""
+scale before the exponential; measured 8.1e-2), lse within 6e-2 / 0.5 absolute."""
 
 import pytest
 import torch
@@ -32,22 +33,39 @@ def test_mfma_scale_f8_operand_layout_probe(probe_lib):
     assert torch.equal(d.cpu(), a @ b.T)  # exact: every product and partial sum is representable
 
 
+def _fp8(probe_lib):
+    import ctypes
+
+    v, q, f = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float
+    probe_lib.dl_probe_attn_fp8_quantize.argtypes = [v] * 7 + [q] * 5 + [v]
+    probe_lib.dl_probe_attn_fwd_fp8.argtypes = [v] * 6 + [q] * 5 + [f, v, v]
+    st = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
+    p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+
+    def quant(q_, k_, v_, q8, k8, v8t, sc, B, H, Nq, Nk):
+        assert probe_lib.dl_probe_attn_fp8_quantize(p(q_), p(k_), p(v_), p(q8), p(k8), p(v8t), p(sc), B, H, Nq, Nk, 64, st()) == 0
+
+    def fwd(q8, k8, v8t, sc, out, lse, B, H, Nq, Nk, dh, scale, bias):
+        assert probe_lib.dl_probe_attn_fwd_fp8(p(q8), p(k8), p(v8t), p(sc), p(out), p(lse), B, H, Nq, Nk, dh, scale, p(bias), st()) == 0
+
+    return quant, fwd
+
+
 def _inputs(B, H, Nq, Nk, seed):
     g = torch.Generator().manual_seed(seed)
     mk = lambda n: (torch.randn(B, H, n, 64, generator=g)).to(torch.bfloat16).to(DEV)  # noqa: E731
     return mk(Nq), mk(Nk), mk(Nk)
 
 
-def test_quantize_layouts_and_scales():
-    from diffulab_amd import ops
-
+def test_quantize_layouts_and_scales(probe_lib):
+    quant, _ = _fp8(probe_lib)
     B, H, N = 2, 3, 256
     q, k, v = _inputs(B, H, N, N, 1)
     v = v * 3.0
     q8, k8 = (torch.empty(B, H, N, 64, device=DEV, dtype=torch.uint8) for _ in range(2))
     v8t = torch.empty(B, H, 64, N, device=DEV, dtype=torch.uint8)
     sc = torch.empty(B, H, 3, device=DEV)
-    ops.attn_fp8_quantize(q, k, v, q8, k8, v8t, sc, B, H, N, N)
+    quant(q, k, v, q8, k8, v8t, sc, B, H, N, N)
     torch.cuda.synchronize()
     for i, t in enumerate((q, k, v)):
         amax = t.float().abs().amax(dim=(2, 3))
@@ -65,9 +83,10 @@ def test_quantize_layouts_and_scales():
 
 @pytest.mark.parametrize("shape", [(2, 3, 256, 512, False, 1.0), (2, 12, 1280, 1280, True, 1.0), (1, 2, 512, 256, True, 1.0),
                                    (2, 4, 512, 512, True, 3.0)])
-def test_fp8_attention_forward_against_fp64_softmax(shape):
+def test_fp8_attention_forward_against_fp64_softmax(shape, probe_lib):
     from diffulab_amd import ops
 
+    quant, fwd8 = _fp8(probe_lib)
     B, H, Nq, Nk, masked, sharp = shape
     q, k, v = _inputs(B, H, Nq, Nk, 7)
     q = (q.float() * sharp).to(torch.bfloat16)  # sharp > 1: peaked attention (a few keys carry each query)
@@ -84,8 +103,8 @@ def test_fp8_attention_forward_against_fp64_softmax(shape):
     q8, k8 = torch.empty(B, H, Nq, 64, device=DEV, dtype=torch.uint8), torch.empty(B, H, Nk, 64, device=DEV, dtype=torch.uint8)
     v8t, sc = torch.empty(B, H, 64, Nk, device=DEV, dtype=torch.uint8), torch.empty(B, H, 3, device=DEV)
     out, lse = torch.empty(B, Nq, H * 64, device=DEV, dtype=torch.bfloat16), torch.empty(B, H, Nq, device=DEV)
-    ops.attn_fp8_quantize(q, k, v, q8, k8, v8t, sc, B, H, Nq, Nk)
-    ops.attn_fwd_fp8(q8, k8, v8t, sc, out, lse, B, H, Nq, Nk, 64, scale, bias)
+    quant(q, k, v, q8, k8, v8t, sc, B, H, Nq, Nk)
+    fwd8(q8, k8, v8t, sc, out, lse, B, H, Nq, Nk, 64, scale, bias)
     out16, lse16 = torch.empty_like(out), torch.empty_like(lse)
     ops.attn_fwd_ex(q, k, v, out16, lse16, B, H, Nq, Nk, 64, scale, bias)
     torch.cuda.synchronize()
@@ -94,27 +113,3 @@ def test_fp8_attention_forward_against_fp64_softmax(shape):
     assert e8 < (6e-2 if sharp == 1.0 else 1e-1)
     assert float((lse.double() - ref_lse).abs().max()) < (6e-2 if sharp == 1.0 else 0.5)
     assert bool(torch.isfinite(out.float()).all())
-
-
-def test_joint_mmdit_with_fp8_attention_stays_close_to_the_bf16_path(monkeypatch, golden):
-    """the joint text-image MMDiT (reference fixture mmdit_joint: ragged key-padding mask) with DIFFULAB_FP8_ATTENTION=1: forward in
-    fp8, backward in bf16 with the fp8 forward's lse.  Against the REFERENCE's prediction and gradients at the fp8 tolerances."""
-    import test_mmdit_joint_gpu as tj
-
-    g = {k: torch.as_tensor(v) for k, v in golden("mmdit_joint").items()}
-    x, t, ctx, keep, dy = tj._inputs()
-    res = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("DIFFULAB_FP8_ATTENTION", mode)
-        m = tj._model()
-        m.train()
-        pred = m(x=x.to(DEV), timesteps=t.to(DEV), initial_context={"embeddings": ctx.to(DEV), "attn_mask": keep.to(DEV)}, p=0.0)["x"]
-        (pred * dy.to(DEV)).sum().backward()
-        torch.cuda.synchronize()
-        res[mode] = (pred.detach().float().cpu(), {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()})
-    e_pred8, e_pred16 = rel(res["1"][0], g["a_pred"]), rel(res["0"][0], g["a_pred"])
-    errs = sorted(rel(res["1"][1][n], g["a_g_" + n]) for n in res["1"][1] if "a_g_" + n in g)
-    print(f"joint MMDiT prediction vs reference: fp8 attention {e_pred8:.3e}, bf16 {e_pred16:.3e}; gradient rel-L2 with fp8 attention: "
-          f"median {errs[len(errs) // 2]:.3e}, max {errs[-1]:.3e}")
-    assert e_pred8 < 3e-2 and errs[len(errs) // 2] < 6e-2 and errs[-1] < 0.2
-    assert not torch.equal(res["0"][0], res["1"][0])  # the switch really changed the attention kernel
