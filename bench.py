@@ -457,6 +457,9 @@ def main() -> None:
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
+        from diffulab_amd.training.dp import configure_rccl_env
+
+        configure_rccl_env()  # RCCL's channel workgroups fit into the CUs the persistent grids leave free
         if args.dp_backend == "gloo":
             dist.init_process_group("gloo")
         else:

@@ -25,7 +25,7 @@ def slots() -> dict[str, int]:
 class DitBlock(ctypes.Structure):
     _fields_ = [("p", ctypes.c_void_p * 96)] + [(n, ctypes.c_int64) for n in
                 ("B", "N", "D", "H", "F", "ld_mod", "ld_dmod", "ldw_d", "ldw_f", "ldwt_d", "ldwt_f2", "ldwt_3d", "rot")] + [
-                    ("eps", ctypes.c_float), ("next_eps", ctypes.c_float), ("row_gemms", ctypes.c_int32), ("tn_slab_floats", ctypes.c_int64)]
+                    ("eps", ctypes.c_float), ("next_eps", ctypes.c_float), ("row_gemms", ctypes.c_int32), ("tn_slab_floats", ctypes.c_int64), ("max_workgroups", ctypes.c_int32)]
 
     def set(self, **ptrs) -> "DitBlock":
         """slot name (lower case) -> tensor / int address / None"""

@@ -34,6 +34,7 @@ extern "C" int dl_dit_block_fwd(const dl_dit_block_t* b, int train, dl_stream_t 
   DL_CHECK_ARG(b, "dl_dit_block_fwd: null block");
   const int64_t B = b->B, N = b->N, D = b->D, H = b->H, F = b->F, M = B * N, dh = D / H;
   DL_CHECK_ARG(B > 0 && N > 0 && D > 0 && H > 0 && F > 0 && dh == 64, "dl_dit_block_fwd: bad dims (head_dim must be 64)");
+  const DlWgCapScope cap_scope(b->max_workgroups);
   const float sm = 0.125f;  // 64^-0.5
   if (b->row_gemms & 1) {
     // Row-complete GEMMs (csrc/gemm_ln.hip): every LayerNorm-modulate is the epilogue of the GEMM in front of it.  XM1 / MEAN1 /
@@ -95,6 +96,7 @@ extern "C" int dl_dit_block_fwd(const dl_dit_block_t* b, int train, dl_stream_t 
 extern "C" int dl_dit_block_bwd(const dl_dit_block_t* b, dl_stream_t main_, dl_stream_t side_, int side_wgs) {
   DL_CHECK_ARG(b, "dl_dit_block_bwd: null block");
   hipStream_t main = (hipStream_t)main_, side = (hipStream_t)side_;  // (side == main: everything inline on one stream)
+  const DlWgCapScope cap_scope(b->max_workgroups);
   const int64_t B = b->B, N = b->N, D = b->D, H = b->H, F = b->F, M = B * N, dh = D / H;
   const float sm = 0.125f;
   // With a slab the four weight gradients of the block are ONE atomics-free launch (dl_gemm_tn_group) behind the last of their

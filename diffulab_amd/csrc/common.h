@@ -142,4 +142,17 @@ static inline int dev_cus(DevOnce& st, F&& setup) {
   }
   return n;
 }
+// Workgroup budget of the PERSISTENT main-chain kernels (one workgroup per CU: gemm_nt_big_k, gemm_nt_rows_k, mlp_dswiglu_rc_k) for
+// the calls a block driver issues: dl_dit_block_{fwd,bwd} set it from dl_dit_block_t::max_workgroups for their own duration
+// (thread-local, restored on return).  A data-parallel host leaves a few CUs to the communication library's workgroups: a grid
+// sized for every CU that finds some of them taken runs a SECOND ROUND on the first CUs that free up (+19-22 % per step measured
+// with 8-64 foreign workgroups), a grid of CUs - r costs r / CUs.
+int dl_wg_budget(int n_cu);
+void dl_set_wg_cap(int cap);  // 0 = no cap; returns nothing, callers save / restore through DlWgCapScope
+int dl_get_wg_cap();
+struct DlWgCapScope {
+  int saved;
+  explicit DlWgCapScope(int cap) : saved(dl_get_wg_cap()) { if (cap > 0) dl_set_wg_cap(cap); }
+  ~DlWgCapScope() { dl_set_wg_cap(saved); }
+};
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -15,6 +15,13 @@ void dl_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* dl_last_error(void) { return g_err; }
+static thread_local int g_wg_cap = 0;
+void dl_set_wg_cap(int cap) { g_wg_cap = cap > 0 ? cap : 0; }
+int dl_get_wg_cap() { return g_wg_cap; }
+int dl_wg_budget(int n_cu) {
+  int n = (g_wg_cap > 0 && g_wg_cap < n_cu) ? g_wg_cap : n_cu;
+  return n < 8 ? 8 : n;
+}
 extern "C" int dl_version(void) { return 100; }
 extern "C" int dl_device_info(int device, int* cu, int* lds, int64_t* hbm, char* arch, int arch_len) {
   hipDeviceProp_t p;

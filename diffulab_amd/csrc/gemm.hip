@@ -587,7 +587,8 @@ static int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, vo
     (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   });
   const int ntiles = (int)((M / TBM) * (N / TN_));
-  int grid = n_cu < ntiles ? n_cu : ntiles;
+  const int budget = dl_wg_budget(n_cu);
+  int grid = budget < ntiles ? budget : ntiles;
   grid &= ~7;
   NtEpilogue ep = ep_in;
   // phase skew of the tile starts (sleep units per k-step and phase group): pays only when every workgroup walks many tiles

@@ -502,7 +502,8 @@ static int rk_launch(const void* A, int64_t lda, const void* W, int64_t ldw, int
     (void)hipFuncSetAttribute((const void*)gemm_nt_rows_k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   });
   const int ntiles = (int)((M / RK_BM) * (N / RK_BN));
-  int grid = n_cu < ntiles ? n_cu : ntiles;
+  const int budget = dl_wg_budget(n_cu);
+  int grid = budget < ntiles ? budget : ntiles;
   grid &= ~7;
   hipLaunchKernelGGL((gemm_nt_rows_k<MODE>), grid, RK_THREADS, LDS, stream, (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (int)M,
                      (int)N, (int)K, ep);

@@ -262,7 +262,8 @@ extern "C" int dl_mlp_dswiglu_recompute(const void* X, int64_t ldx, const void* 
     (void)hipFuncSetAttribute((const void*)mlp_dswiglu_rc_k<TU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (RC_TBM + 2 * TU) * 128);
   });
   const int ntiles = (int)((M / RC_TBM) * (F / TU));
-  int grid = n_cu < ntiles ? n_cu : ntiles;
+  const int budget = dl_wg_budget(n_cu);
+  int grid = budget < ntiles ? budget : ntiles;
   grid &= ~7;
   // column groups per launch (see the kernel): the widest split that keeps whole column tiles and whole row panels per XCD
   const int panels = (int)(M / RC_TBM), tiles_n = (int)(F / TU);

@@ -400,6 +400,19 @@ class DiTEngine:
         ops.gemm_nt(w["se"], sh["@mod|f"], w["mod"], bias=mod_bias, M=B, N=self.layout.mod_rows, K=E)
         return w["mod"]
 
+    def _main_wgs(self) -> int:
+        """workgroup budget of the persistent main-chain kernels (0 = one per CU).  With a gradient reducer attached the grids leave
+        DL_DP_RESERVE_CUS compute units to RCCL's channel workgroups (training/dp.py caps the channels to match): an exchange that
+        is resident under the backward then costs reserve / CUs instead of a second round of every one-workgroup-per-CU launch"""
+        explicit = tuning.integer("DL_MAIN_WGS", 0)
+        if explicit:
+            return explicit
+        if self.reducer is not None and getattr(self.reducer, "enabled", True):
+            if getattr(self, "_cus", None) is None:
+                self._cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+            return max(8, (self._cus - tuning.integer("DL_DP_RESERVE_CUS", 8)) & ~7)
+        return 0
+
     # ------------------------------------------------------------------ native block driver (csrc/block.hip)
     def _native_blocks(self) -> bool:
         """one C call per block and direction (dl_dit_block_fwd / _bwd) instead of ~25 launches from Python; DL_NATIVE_BLOCK=0 is the
@@ -408,7 +421,7 @@ class DiTEngine:
 
     def _block_args(self, i: int, train: bool):
         """the dl_dit_block_t of block i on the current workspace (cached: every pointer is fixed once arena and workspace exist)"""
-        key = (self._ws_key, i, self.reducer is None)
+        key = (self._ws_key, i, self.reducer is None, self._main_wgs())
         blk = self._blk_cache.get(key)
         if blk is not None:
             return blk
@@ -430,6 +443,7 @@ class DiTEngine:
         blk.ldwt_d, blk.ldwt_f2 = sh[pre + "attention.proj_out.weight|t"].stride(0), sh[pre + "mlp_input.0.weight|t"].stride(0)
         blk.ldwt_3d = sh[pre + "attention.qkv.weight|t"].stride(0)
         blk.rot, blk.eps = sum(d.rope_axes_dim), 1e-5
+        blk.max_workgroups = self._main_wgs()
         prev = None
         if i > 0:
             ap = w["layers"][(i - 1) if train else 0]

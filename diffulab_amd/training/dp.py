@@ -20,6 +20,18 @@ import torch.distributed as dist
 from torch import Tensor
 
 
+def configure_rccl_env() -> None:
+    """call BEFORE the process group creates its RCCL communicator (bench.py, Trainer.__init__): cap RCCL's channels -- one resident
+    workgroup each -- at the number of compute units the engines leave free for them (DL_DP_RESERVE_CUS, engine._main_wgs).  The
+    exchange moves ~160 MB per 20 ms step (~14 GB/s per GPU with reduce-scatter + all-gather at 8 ranks): a few channels carry that;
+    what matters is that their workgroups never take a CU a one-workgroup-per-CU kernel was sized for.
+    An explicit NCCL_MAX_NCHANNELS in the environment wins."""
+    from .. import tuning
+
+    channels = max(1, tuning.integer("DL_DP_RESERVE_CUS", 8))
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", str(channels))
+
+
 class GradReducer:
     def __init__(self, flat_grad: Tensor, bucket_bytes: int = 48 << 20, group=None, backend: str | None = None, comm=None) -> None:
         """backend "torch" (default): torch.distributed collectives (backend nccl = RCCL);  "abi" (or DIFFULAB_DP_BACKEND=abi):

@@ -96,6 +96,9 @@ class Trainer(ABC):
         else:  # host-logic tests only: every denoiser forward raises without a GPU
             self.device = torch.device("cpu")
         if self.world > 1 and not dist.is_initialized():
+            from ..dp import configure_rccl_env
+
+            configure_rccl_env()
             dist.init_process_group(backend="nccl" if self.device.type == "cuda" else "gloo")
         self.is_main_process = self.rank == 0
 

@@ -652,6 +652,10 @@ typedef struct dl_dit_block_t {
                                   * partials DWB1 / DWB2 unfolded (the caller folds all blocks at once: dl_reduce_rows_batched_f32) */
   int64_t tn_slab_floats;        /* size of DL_BLK_TN_SLAB; with a slab the block's four weight gradients are ONE atomics-free launch
                                   * (dl_gemm_tn_group) issued on `side` once dqkv exists */
+  int32_t max_workgroups;        /* > 0: workgroup budget of the block's persistent main-chain kernels (one workgroup per CU by default).
+                                  * Data parallel: CUs - r leaves r CUs to the communication library's workgroups, so a gradient
+                                  * exchange that runs under the backward costs r / CUs instead of a second round of every launch
+                                  * (base_trainer.py:277-279: the DDP all-reduce overlaps the backward) */
 } dl_dit_block_t;
 /* forward of one block; train != 0 keeps the MLP pre-activations U for the backward.  The MLP branch's gated residual
  * (x1 + gate2 * t2) is NOT applied: it is the next block's (or the final LayerNorm's) pending triple. */

@@ -42,8 +42,9 @@ def run(n_wgs, threads, frac, steps=10):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
 
+cap = os.environ.get("DL_MAIN_WGS", "")
 base = run(0, 0, 0)
-print(f"no spinner: {base:.2f} ms/step")
+print(f"persistent main-chain grids: {cap or 'all CUs'};  no spinner: {base:.2f} ms/step")
 for n, th, fr in ((8, 256, 0.5), (16, 256, 0.5), (32, 256, 0.5), (32, 512, 0.5), (64, 256, 0.5), (32, 256, 0.1), (32, 256, 1.0)):
     ms = run(n, th, fr)
     print(f"spinner {n:3d} WGs x {th} threads for {fr:.0%} of the step: {ms:.2f} ms/step ({(ms / base - 1) * 100:+.1f} %)")
