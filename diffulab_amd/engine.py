@@ -401,16 +401,20 @@ class DiTEngine:
         return w["mod"]
 
     def _main_wgs(self) -> int:
-        """workgroup budget of the persistent main-chain kernels (0 = one per CU).  With a gradient reducer attached the grids leave
-        DL_DP_RESERVE_CUS compute units to RCCL's channel workgroups (training/dp.py caps the channels to match): an exchange that
-        is resident under the backward then costs reserve / CUs instead of a second round of every one-workgroup-per-CU launch"""
+        """workgroup budget of the persistent main-chain kernels (0 = one per CU).  DL_DP_RESERVE_CUS = r > 0: with a gradient reducer
+        attached the grids leave r compute units to RCCL's channel workgroups.  Measured with the stand-in of scripts/lab/occupied_cus.py
+        (round 4): the headline shape's tile counts are whole multiples of 256, so 248 workgroups run an extra, nearly empty round --
+        20.7 -> 24.1 ms per step WITHOUT any foreign workgroup, 26.2 vs 24.6 ms with 16 of them resident for half the step -- a loss;
+        the shipped default is therefore 0 and the reducer's measured choice between overlapped buckets and one exchange after the
+        backward (training/dp.py) stays the mechanism."""
         explicit = tuning.integer("DL_MAIN_WGS", 0)
         if explicit:
             return explicit
-        if self.reducer is not None and getattr(self.reducer, "enabled", True):
+        reserve = tuning.integer("DL_DP_RESERVE_CUS", 0)
+        if reserve and self.reducer is not None and getattr(self.reducer, "enabled", True):
             if getattr(self, "_cus", None) is None:
                 self._cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
-            return max(8, (self._cus - tuning.integer("DL_DP_RESERVE_CUS", 8)) & ~7)
+            return max(8, (self._cus - reserve) & ~7)
         return 0
 
     # ------------------------------------------------------------------ native block driver (csrc/block.hip)

@@ -28,8 +28,9 @@ def configure_rccl_env() -> None:
     An explicit NCCL_MAX_NCHANNELS in the environment wins."""
     from .. import tuning
 
-    channels = max(1, tuning.integer("DL_DP_RESERVE_CUS", 8))
-    os.environ.setdefault("NCCL_MAX_NCHANNELS", str(channels))
+    channels = tuning.integer("DL_DP_RESERVE_CUS", 0)
+    if channels > 0:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(channels))
 
 
 class GradReducer:

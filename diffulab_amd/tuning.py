@@ -24,7 +24,8 @@ SWITCHES: dict[str, tuple[str, str]] = {
     "DL_SIDE_WGS": ("", "workgroup cap of the side-stream weight gradients (default: 256 grouped, 128 per-problem)"),
     "DL_SIDE_CU_MASK": ("", "CU mask of the side stream (dl_stream_create_masked): 'i4' = every 4th CU, 'b128' = the first 128"),
     "DL_JOIN_LAST": ("1", "single GPU: the side stream is joined after the conditioning backward instead of before it"),
-    "DL_DP_RESERVE_CUS": ("8", "data parallel: CUs left to the communication library's workgroups (persistent main-chain grids shrink by it)"),
+    "DL_DP_RESERVE_CUS": ("0", "data parallel: CUs left to the communication library's workgroups (persistent main-chain grids shrink by it; "
+                          "measured a loss at the headline shape, whose tile counts are whole multiples of 256: DESIGN.md section 5)"),
     "DL_MAIN_WGS": ("", "workgroup budget of the persistent main-chain kernels (experiments; default: all CUs, or CUs - reserve with a reducer)"),
     "DL_DP_EARLY_MOD": ("1", "data parallel: each block's adaLN rows are reduced as the block finishes"),
     "DL_HIPGRAPH": ("1", "samplers replay the denoiser forward as a captured hipGraph"),

@@ -160,9 +160,10 @@ def test_base_trainer_train_loop_checkpoints_and_logs(tmp_path):
     imgs = torch.load(out / "val_images_epoch1.pt")
     assert imgs.shape == (16, 4, 16, 16) and float(imgs.min()) >= 0 and float(imgs.max()) <= 1
     # a fresh module restores from the checkpoint and reproduces the trained model's output
+    assert m.precision == "fp32"  # the trainer's default precision_type is the reference's "no": the whole loop ran the fp32 regime
     m2 = MMDiT(simple_dit=True, **SMALL)
     m2.load_state_dict(sd)
-    m2 = m2.to(DEV)
+    m2 = m2.set_precision(m.precision).to(DEV)
     x = synth.normal("ck.x", (2, 4, 16, 16)).to(DEV)
     kw = dict(timesteps=torch.tensor([0.3, 0.7], device=DEV), y=torch.tensor([1, 2], device=DEV))
     with torch.no_grad():
