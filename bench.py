@@ -176,7 +176,7 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
     last_group: list = []  # [probs, slab] of the last grouped weight-gradient launch
     orig = {n: getattr(ops, n) for n in ("gemm_nt", "gemm_nt_swiglu", "gemm_tn", "attn_fwd_qkv", "attn_bwd_qkv", "attn_fwd", "attn_bwd",
                                          "attn_bwd_tok", "mlp_dswiglu_recompute", "ln_modulate_gemm_fwd", "ln_modulate_gemm_bwd",
-                                         "gemm_nt_qk_norm_rope", "gemm_tn_group")}
+                                         "gemm_nt_qk_norm_rope", "gemm_tn_group", "gemm_nt_ssq", "attn_fwd_qkn")}
 
     def timed(kind: str):
         fn = orig[kind]
@@ -192,6 +192,11 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
             elif kind in ("ln_modulate_gemm_fwd", "ln_modulate_gemm_bwd"):  # (a [M, K], w [384, K], ...): row-complete 256x384 tiles
                 K = kw.get("K") or a.shape[1]
                 name, fl = "gemm_nt_rows_k<%d>" % (0 if kind.endswith("fwd") else 1), 2.0 * a.shape[0] * 384 * K
+            elif kind == "gemm_nt_ssq":  # (a [M, K], w [N, K], out, ssq): the qkv GEMM + QK-norm row statistics
+                name, fl = "gemm_nt_big_k<384,2,3>", 2.0 * a.shape[0] * b.shape[0] * a.shape[1]
+            elif kind == "attn_fwd_qkn":  # (qkv, ssq, sq, sk, cos, sin, q, k, rrms, out, lse, B, H, N, dh, rot, scale)
+                Bq, Hq, Nq, dq = rest[9], rest[10], rest[11], rest[12]
+                name, fl = "attn_fwd_qkn_k", 4.0 * Bq * Hq * Nq * Nq * dq
             elif kind == "gemm_nt_qk_norm_rope":
                 name, fl = "gemm_nt_rows_k<2>", 2.0 * a.shape[0] * b.shape[0] * a.shape[1]
             elif kind == "gemm_tn_group":  # (probs = [(dy, x, g), ...], slab): one launch + the fold

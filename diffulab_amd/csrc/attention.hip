@@ -343,6 +343,176 @@ extern "C" int dl_attn_fwd_sv(const void* q, const void* k, const void* v, int64
   return DL_OK;
 }
 
+// ------------------------------------------------------------------------------ forward with QK-RMSNorm + RoPE on load
+// attn_fwd_k that reads the PRE-NORM q and k straight out of the token-major qkv rows (like V) and applies the QK-norm and the
+// rotary embedding itself (mmdit.py:81-91: q = rms_norm(q) * scale over the full D-wide row, nn.py:427-431, then the rotation of
+// interleaved pairs, nn.py:345-353): the separate qk_norm_rope_fwd pass over qkv (200 MB per launch at the headline shape) is gone.
+// The row statistics come from the qkv GEMM's epilogue (dl_gemm_nt_ssq: sums of squares of the q / k rows), so a (batch, head)
+// workgroup never has to see the other heads: r = rsqrt(ssq / D + eps).  K: the raw tile is DMA'd like V, then every thread
+// transforms its four 16-byte chunks in place in LDS; Q: every lane transforms the four fragments of its query row in registers.
+// The arithmetic is qk_norm_rope_fwd_k's ((x r) s, then a c - b s / a s + b c in f32, one rounding to bf16).  The normalised q, k
+// are also written head-major (the backward kernels read them) and head 0's workgroups store r as rrms [M, 2] for the QK-norm
+// backward.
+struct QkNorm {
+  const float* ssq;   // f32 [B*N, 2]: sums of squares of the q / k rows
+  const float* sq;    // f32 [D] query_norm.scale
+  const float* sk;    // f32 [D] key_norm.scale
+  const float* cs;    // f32 [N, rot/2]
+  const float* sn;
+  bf16_t* qo;         // [B, H, N, 64] normalised + rotated q (kept for the backward)
+  bf16_t* ko;
+  float* rrms;        // f32 [B*N, 2]
+  float inv_d, eps;
+  int rot;
+  int pitch;          // elements between token rows of qkv (3 D)
+};
+__device__ __forceinline__ u32x4_t qk_xform8(u32x4_t raw, float r, const float* __restrict__ s8, const float* __restrict__ c4,
+                                             const float* __restrict__ n4, bool rotary) {
+  float x[8];
+  unpack8(raw, x);
+  const f32x4_t s0 = *(const f32x4_t*)s8, s1 = *(const f32x4_t*)(s8 + 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    x[e] = x[e] * r * s0[e];
+    x[4 + e] = x[4 + e] * r * s1[e];
+  }
+  if (rotary) {
+    const f32x4_t cc = *(const f32x4_t*)c4, ss = *(const f32x4_t*)n4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a = x[2 * i], b = x[2 * i + 1];
+      x[2 * i] = a * cc[i] - b * ss[i];
+      x[2 * i + 1] = a * ss[i] + b * cc[i];
+    }
+  }
+  return pack8(x);
+}
+
+__global__ __launch_bounds__(512) void attn_fwd_qkn_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
+                                                      int H, int N, float scale, QkNorm qn) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* kt = smem;
+  char* vt = smem + N * ROWB;
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int D = H * DH, half = qn.rot >> 1;
+  const bf16_t* base = qkv + (int64_t)b * N * qn.pitch + h * DH;  // q of this head; k at + D, v at + 2 D
+  tile_dma(base + D, qn.pitch, kt, N, wave, nwaves, lane);
+  tile_dma(base + 2 * D, qn.pitch, vt, N, wave, nwaves, lane);
+
+  // ---- this wave's query rows: raw fragments out of the token-major rows, normalised + rotated in registers
+  const int q0 = wave * 32, qrow = q0 + (lane & 31);
+  const int64_t tok = (int64_t)b * N + qrow;
+  const float rq = rsqrtf(qn.ssq[tok * 2] * qn.inv_d + qn.eps);
+  bf16x8_t qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int d0 = ks * 16 + hi * 8;
+    const u32x4_t raw = *(const u32x4_t*)(base + (int64_t)qrow * qn.pitch + d0);
+    const u32x4_t t = qk_xform8(raw, rq, qn.sq + h * DH + d0, qn.cs + (int64_t)qrow * half + (d0 >> 1), qn.sn + (int64_t)qrow * half + (d0 >> 1),
+                                d0 < qn.rot);
+    qf[ks] = __builtin_bit_cast(bf16x8_t, t);
+    *(u32x4_t*)(qn.qo + ((int64_t)bh * N + qrow) * DH + d0) = t;
+  }
+  if (h == 0 && hi == 0) qn.rrms[tok * 2] = rq;
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // ---- K tile: in place in LDS (source slot `slot` of row `row` sits at tile_off(row, slot))
+  for (int id = threadIdx.x; id < N * 8; id += blockDim.x) {
+    const int row = id >> 3, slot = id & 7, d0 = slot * 8;
+    const int64_t tk = (int64_t)b * N + row;
+    const float rk = rsqrtf(qn.ssq[tk * 2 + 1] * qn.inv_d + qn.eps);
+    char* p = kt + tile_off(row, slot);
+    const u32x4_t t = qk_xform8(*(const u32x4_t*)p, rk, qn.sk + h * DH + d0, qn.cs + (int64_t)row * half + (d0 >> 1),
+                                qn.sn + (int64_t)row * half + (d0 >> 1), d0 < qn.rot);
+    *(u32x4_t*)p = t;
+    *(u32x4_t*)(qn.ko + ((int64_t)bh * N + row) * DH + d0) = t;
+    if (h == 0 && slot == 0) qn.rrms[tk * 2 + 1] = rk;
+  }
+  __syncthreads();
+
+  const float c = scale * LOG2E;
+  f32x16_t o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[0][r] = o[1][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  for (int kb = 0; kb < N; kb += 64) {
+    f32x16_t s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s[t] = MFMA(frag_rows(kt, kb + t * 32 + (lane & 31), ks, hi), qf[ks], s[t]);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[t][r] *= c;
+        mx = fmaxf(mx, s[t][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = fast_exp2(m_run - m_new);
+    m_run = m_new;
+    float ps = 0.f;
+    float p[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[t][r] = fast_exp2(s[t][r] - m_new);
+        ps += p[t][r];
+      }
+    l_run = l_run * alpha + ps;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o[0][r] *= alpha;
+      o[1][r] *= alpha;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kg2 = 0; kg2 < 2; ++kg2) {
+        const bf16x8_t pf = pack_frag(&p[t][kg2 * 8]);
+        const int rbase = kb + t * 32 + kg2 * 16;
+        o[0] = MFMA(frag_cols(vt, rbase, 0, lane), pf, o[0]);
+        o[1] = MFMA(frag_cols(vt, rbase, 32, lane), pf, o[1]);
+      }
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  store_rows64(out + ((int64_t)b * N + qrow) * (H * DH) + h * DH, o, inv, hi);
+  if (hi == 0) lse[(int64_t)bh * N + qrow] = (m_run + log2f(l_tot)) * LN2;
+}
+
+/* DiTAttention.forward mmdit.py:81-100 from the pre-norm qkv rows: QK-RMSNorm (row statistics = ssq of dl_gemm_nt_ssq) + RoPE applied
+ * on load, softmax(q k^T scale) v; also writes the normalised q, k head-major and rrms for the backward.  N % 64 == 0 up to 256. */
+extern "C" int dl_attn_fwd_qkn(const void* qkv, const float* ssq, const float* scale_q, const float* scale_k, const float* cos,
+                               const float* sin, float eps, int64_t rot, void* q_out, void* k_out, float* rrms, void* out, float* lse,
+                               int64_t B, int64_t H, int64_t N, int64_t dh, float scale, dl_stream_t stream) {
+  DL_CHECK_ARG(qkv && ssq && scale_q && scale_k && q_out && k_out && rrms && out && lse && B > 0 && H > 0, "dl_attn_fwd_qkn: null operand");
+  DL_CHECK_ARG(rot == 0 || (cos && sin), "dl_attn_fwd_qkn: rot > 0 needs the cos / sin tables");
+  DL_CHECK_ARG(dh == DH && rot % 8 == 0 && rot <= DH, "dl_attn_fwd_qkn: head_dim 64, rot %% 8 == 0 (dh=%lld rot=%lld)", (long long)dh,
+               (long long)rot);
+  DL_CHECK_ARG(N % 64 == 0 && N >= 64 && N <= 256, "dl_attn_fwd_qkn: N=%lld must be a multiple of 64 up to 256", (long long)N);
+  DL_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)q_out | (uintptr_t)k_out | (uintptr_t)out | (uintptr_t)scale_q | (uintptr_t)scale_k |
+                 (uintptr_t)cos | (uintptr_t)sin) & 15) == 0, "dl_attn_fwd_qkn: 16-byte alignment");
+  const int lds = (int)(2 * N * ROWB);
+  static DevOnce once;
+  (void)dev_cus(once, [] { (void)hipFuncSetAttribute((const void*)attn_fwd_qkn_k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * ROWB); });
+  const int64_t D = H * DH;
+  QkNorm qn{ssq, scale_q, scale_k, cos, sin, (bf16_t*)q_out, (bf16_t*)k_out, rrms, 1.0f / (float)D, eps, (int)rot, (int)(3 * D)};
+  hipLaunchKernelGGL(attn_fwd_qkn_k, (int)(B * H), (int)(N / 32) * 64, lds, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, (int)H,
+                     (int)N, scale, qn);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
 // ====================================================================================== backward
 // global-memory version of frag_rows: row-major [N][64] matrix with row pitch `pitch` elements
 __device__ __forceinline__ bf16x8_t frag_rows_g(const bf16_t* __restrict__ g, int64_t pitch, int row, int ks, int hi) {

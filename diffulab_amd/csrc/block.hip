@@ -42,7 +42,11 @@ extern "C" int dl_dit_block_fwd(const dl_dit_block_t* b, int train, dl_stream_t 
     // GEMM the gated residual of the MLP branch and the LayerNorm that follows the block.
     DL_CHECK_ARG(P(V) == nullptr && P(NEXT_X) && P(NEXT_XM) && P(NEXT_SCALE) && P(NEXT_SHIFT) && P(NEXT_MEAN) && P(NEXT_RSTD),
                  "dl_dit_block_fwd: row_gemms needs V in place and the DL_BLK_NEXT_* slots");
-    if (b->row_gemms & 2) {
+    if (P(SSQ)) {  // QK-norm statistics leave with the qkv GEMM, the norm + RoPE are applied as the attention stages q and k
+      RUN(dl_gemm_nt_ssq(P(XM1), D, P(W_QKV), b->ldw_d, P(QKV), 3 * D, M, 3 * D, D, (float*)P(SSQ), 2, stream));
+      RUN(dl_attn_fwd_qkn(P(QKV), (const float*)P(SSQ), (const float*)P(QN_SCALE), (const float*)P(KN_SCALE), (const float*)P(ROPE_COS),
+                          (const float*)P(ROPE_SIN), 1e-6f, b->rot, P(Q), P(K), (float*)P(RRMS), P(A), (float*)P(LSE), B, H, N, dh, sm, stream));
+    } else if (b->row_gemms & 2) {
       RUN(dl_gemm_nt_qk_norm_rope(P(XM1), D, P(W_QKV), b->ldw_d, B, N, H, dh, b->rot, 1e-6f, (const float*)P(QN_SCALE),
                                   (const float*)P(KN_SCALE), (const float*)P(ROPE_COS), (const float*)P(ROPE_SIN), P(QKV), P(Q), P(K),
                                   (float*)P(RRMS), N, 0, stream));
@@ -52,7 +56,8 @@ extern "C" int dl_dit_block_fwd(const dl_dit_block_t* b, int train, dl_stream_t 
       RUN(dl_qk_norm_rope_fwd(P(QKV), (const float*)P(QN_SCALE), (const float*)P(KN_SCALE), (const float*)P(ROPE_COS),
                               (const float*)P(ROPE_SIN), P(Q), P(K), nullptr, (float*)P(RRMS), B, N, H, dh, b->rot, 1e-6f, stream));
     }
-    RUN(dl_attn_fwd_sv(P(Q), P(K), (const char*)P(QKV) + 2 * D * 2, N * 3 * D, dh, 3 * D, P(A), (float*)P(LSE), B, H, N, dh, sm, stream));
+    if (!P(SSQ))
+      RUN(dl_attn_fwd_sv(P(Q), P(K), (const char*)P(QKV) + 2 * D * 2, N * 3 * D, dh, 3 * D, P(A), (float*)P(LSE), B, H, N, dh, sm, stream));
     RUN(dl_ln_modulate_gemm_fwd(P(A), D, P(W_PROJ), b->ldw_d, M, D, P(X_IN), P(GATE1), b->ld_mod, (const float*)P(LN2_W),
                                 (const float*)P(LN2_B), P(SCALE2), P(SHIFT2), b->ld_mod, N, b->eps, P(T1), P(X1), P(XM2), (float*)P(MEAN2),
                                 (float*)P(RSTD2), D, stream));

@@ -49,6 +49,11 @@ struct NtEpilogue {
   // 128x128 kernel with a split contraction (blockIdx.y): > 0 = every split stores its partial tile with plain stores at
   // C + split * part_stride (floats; the caller folds the images in a fixed order: bit-reproducible); 0 = f32 atomics into C
   int64_t part_stride;
+  // EPI 3 (384-wide persistent tiles): plain bf16 stores + per-row sums of squares of the ROUNDED outputs of the first `ssq_tiles`
+  // column tiles, added into ssq[m * ssq_tiles + tile] (f32, zeroed by the caller): the statistics of the QK-RMSNorm (nn.py:427-431)
+  // leave with the qkv GEMM.  Two addends per element (the tile's two column waves) on a zeroed word: order-independent.
+  float* ssq;
+  int ssq_tiles;
 };
 
 // implicit-GEMM view of a 3x3 / pad 1 convolution over NHWC rows: the A operand "cols[p, (tap, ci)]" is never materialised,
@@ -321,6 +326,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int JN, int TN_, int EPI>
 __device__ __forceinline__ void nt_epilogue_regs(f32x16_t (&acc)[JN][2], int m_base, int n_base, int lane, void* C,
                                                  int64_t ldc, const NtEpilogue& ep);
+template <int JN, int TN_>
+__device__ __forceinline__ void nt_epilogue_ssq(f32x16_t (&acc)[JN][2], int m_base, int n_base, int lane, void* C, int64_t ldc,
+                                                const NtEpilogue& ep);
 
 template <int TN_, int NST, int EPI>
 __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __restrict__ A, int64_t lda,
@@ -453,8 +461,11 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
       after_epi = true;
       // ---- epilogue of `tile` straight from registers: acc[j][i][r] = C[m][n] with
       //      m = m0 + wm*64 + i*32 + (lane&31),  n = n0 + wn*TN/2 + j*32 + 8*(r>>2) + 4*hi + (r&3)
-      nt_epilogue_regs<JN, TN_, EPI>(acc, (tile / tiles_n) * TBM + wm * 64, (tile % tiles_n) * TN_ + wn * (TN_ / 2), lane, C, ldc,
-                                     ep);
+      if constexpr (EPI == 3)
+        nt_epilogue_ssq<JN, TN_>(acc, (tile / tiles_n) * TBM + wm * 64, (tile % tiles_n) * TN_ + wn * (TN_ / 2), lane, C, ldc, ep);
+      else
+        nt_epilogue_regs<JN, TN_, EPI>(acc, (tile / tiles_n) * TBM + wm * 64, (tile % tiles_n) * TN_ + wn * (TN_ / 2), lane, C, ldc,
+                                       ep);
       if (EPI && EPI != 2) wait_vmcnt<0>();  // unknown number of epilogue memory ops: drain so the counted waits stay exact
       tile += G;
     }
@@ -576,6 +587,44 @@ __device__ __forceinline__ void nt_epilogue_regs(f32x16_t (&acc)[JN][2], int m_b
   }
 }
 
+// EPI 3: the plain epilogue + row sums of squares (see NtEpilogue::ssq)
+template <int JN, int TN_>
+__device__ __forceinline__ void nt_epilogue_ssq(f32x16_t (&acc)[JN][2], int m_base, int n_base, int lane, void* C, int64_t ldc,
+                                                const NtEpilogue& ep) {
+  const int hi = lane >> 5;
+  const int tile = n_base / TN_;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m_base + i * 32 + (lane & 31);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned x = __float_as_uint(acc[j][i][8 * gp + e]), y = __float_as_uint(acc[j][i][8 * gp + 4 + e]);
+          auto sw = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+          v[e] = __uint_as_float(sw[0]);
+          v[4 + e] = __uint_as_float(sw[1]);
+          acc[j][i][8 * gp + e] = 0.f;
+          acc[j][i][8 * gp + 4 + e] = 0.f;
+        }
+        const u32x4_t pk = pack8(v);
+        *(u32x4_t*)((bf16_t*)C + (int64_t)m * ldc + n_base + j * 32 + 16 * gp + 8 * hi) = pk;
+        float r[8];
+        unpack8(pk, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += r[e] * r[e];
+      }
+    if (tile < ep.ssq_tiles) {
+      s = xor32_sum(s);  // the row's other 96 columns of this wave live in the other lane half
+      if (hi == 0) unsafeAtomicAdd(ep.ssq + (int64_t)m * ep.ssq_tiles + tile, s);
+    }
+  }
+}
+
 template <int TN_, int NST>
 static int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                       int64_t N, int64_t K, const NtEpilogue& ep_in, int epi, hipStream_t stream) {
@@ -585,6 +634,8 @@ static int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, vo
     (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if constexpr (TN_ == 384)
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_k<TN_, NST, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   });
   const int ntiles = (int)((M / TBM) * (N / TN_));
   const int budget = dl_wg_budget(n_cu);
@@ -599,7 +650,10 @@ static int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, vo
                      ldb, C, ldc, (int)M, (int)N, (int)K, ep)
   if (epi == 0) BIG_GO(0);
   else if (epi == 1) BIG_GO(1);
-  else BIG_GO(2);
+  else if (epi == 3) {
+    if constexpr (TN_ == 384) BIG_GO(3);
+    else return 1;
+  } else BIG_GO(2);
 #undef BIG_GO
   DL_LAUNCH_CHECK();
   return DL_OK;
@@ -681,6 +735,26 @@ extern "C" int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb
                      (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep, ksplit, ConvGeom{});
   DL_LAUNCH_CHECK();
   return DL_OK;
+}
+
+/* the plain bf16 product on the persistent 256 x 384 tiles + per-row sums of squares of the first `ssq_tiles` 384-wide column tiles
+ * (the QK-RMSNorm statistics of the qkv GEMM, mmdit.py:81-88, nn.py:427-431); DL_ERR_UNSUPPORTED for other shapes */
+extern "C" int dl_gemm_nt_ssq(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+                              int64_t K, float* ssq, int64_t ssq_tiles, dl_stream_t stream) {
+  DL_CHECK_ARG(A && B && C && ssq && M > 0 && N > 0 && K > 0, "dl_gemm_nt_ssq: null/empty operand");
+  DL_CHECK_ARG(K % BK == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && lda >= K && ldb >= K && ldc >= N,
+               "dl_gemm_nt_ssq: K %% 64, leading dims (lda=%lld ldb=%lld ldc=%lld)", (long long)lda, (long long)ldb, (long long)ldc);
+  DL_CHECK_ARG((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0 && ssq_tiles >= 1 && ssq_tiles <= N / 384 + 1,
+               "dl_gemm_nt_ssq: alignment / ssq_tiles");
+  if (M % TBM || N % 384 || (M / TBM) * (N / 384) < 64) {
+    dl_set_error("dl_gemm_nt_ssq: needs M %% 256 == 0, N %% 384 == 0 and >= 64 tiles (M=%lld N=%lld)", (long long)M, (long long)N);
+    return DL_ERR_UNSUPPORTED;
+  }
+  NtEpilogue ep{};
+  ep.rows_per_gate = 1;
+  ep.ssq = ssq;
+  ep.ssq_tiles = (int)ssq_tiles;
+  return launch_big<384, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, 3, (hipStream_t)stream);
 }
 
 /* fused MLP-up + PackedSwiGLU forward: U = X W1^T (reference layout [x1 | x3]) and H = silu(x1) * x3 in one pass.

@@ -331,6 +331,10 @@ class DiTEngine:
                 "u": None if rc_u else z(M, 2 * d.mlp_ratio * D), "h": z(M, d.mlp_ratio * D), "t2": z(M, D),
             })
         w["layers"] = per
+        # QK-norm on load (dl_gemm_nt_ssq + dl_attn_fwd_qkn): per-block sums of squares of the q / k rows, zeroed once per forward (one
+        # buffer per block also in inference: the GEMM epilogues ADD into it)
+        if self._qkn_on_load(M, N):
+            w["ssq_all"] = z(L, M, 2, dtype=f32)
         w["meanf"], w["rstdf"] = z(M, dtype=f32), z(M, dtype=f32)
         w["xf"] = z(M, D)
         w["otok"] = z(M, _rup(Fo, 8), dtype=f32)
@@ -463,7 +467,8 @@ class DiTEngine:
                 wt_qkv=sh[pre + "attention.qkv.weight|t"], wt_proj=sh[pre + "attention.proj_out.weight|t"],
                 wt_up=sh[pre + "mlp_input.0.weight|t"], wt_down=sh[pre + "mlp_input.2.weight|t"], rope_cos=cos, rope_sin=sin,
                 xm1=a["xm1"], mean1=a["mean1"], rstd1=a["rstd1"], qkv=a["qkv"], q=a["q"], k=a["k"], v=a["v"], rrms=a["rrms"], a=a["a"],
-                lse=a["lse"], t1=a["t1"], x1=a["x1"], xm2=a["xm2"], mean2=a["mean2"], rstd2=a["rstd2"], u=a["u"], h=a["h"], t2=a["t2"])
+                lse=a["lse"], t1=a["t1"], x1=a["x1"], xm2=a["xm2"], mean2=a["mean2"], rstd2=a["rstd2"], u=a["u"], h=a["h"], t2=a["t2"],
+                ssq=w["ssq_all"][i] if "ssq_all" in w else None)
         rows = self._row_gemms(M, N)
         blk.row_gemms = 0
         if rows:
@@ -523,6 +528,8 @@ class DiTEngine:
         self._yeff = y_eff
 
         fused = self._row_gemms(M, N)
+        if "ssq_all" in w:
+            w["ssq_all"].zero_()
         mod = self._stem_fwd(x, t, y_eff, patch_gemm=not fused)
         xs = w["x"]
         if fused:
@@ -598,6 +605,11 @@ class DiTEngine:
         D, F = self.d.inner_dim, self.d.mlp_ratio * self.d.inner_dim
         return (type(self) is DiTEngine and ops.WgradGroups.shapes_ok(D, F, M) and tuning.on("DL_WGRAD_GROUP"))
 
+    def _qkn_on_load(self, M: int, N: int) -> bool:
+        # (dl_gemm_nt_ssq runs the persistent 256 x 384 tiles: it wants >= 64 of them, i.e. 22 samples of 256 tokens at D = 384)
+        return (self._row_gemms(M, N) and self.d.inner_dim % 384 == 0 and (M // 256) * (3 * self.d.inner_dim // 384) >= 64
+                and tuning.on("DL_QKN_ON_LOAD") and not tuning.on("DL_ROW_GEMM_QK"))
+
     def _row_gemms(self, M: int, N: int) -> bool:
         """the row-complete GEMM path (csrc/gemm_ln.hip): LayerNorm-modulate forward / backward and QK-norm + RoPE run as epilogues
         of the GEMMs that feed them.  D == 384 with 256 tokens per sample (one 256 x 384 tile = one sample's whole rows)"""
@@ -622,7 +634,13 @@ class DiTEngine:
                                         a0["xm1"], a0["mean1"], a0["rstd1"], K=self._ki))
         for i in range(L):
             a, xin, pre, mo = lay(i), xbuf(i), f"layers.{i}.", i * 6 * D
-            if fused_qk:
+            if "ssq_all" in w:
+                ssq = w["ssq_all"][i]
+                _must(ops.gemm_nt_ssq(a["xm1"], sh[pre + "attention.qkv.weight|f"], a["qkv"], ssq))
+                ops.attn_fwd_qkn(a["qkv"], ssq, self.P(pre + "attention.qk_norm.query_norm.scale"),
+                                 self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["q"], a["k"], a["rrms"], a["a"], a["lse"], B,
+                                 Hh, N, 64, rot, 64**-0.5)
+            elif fused_qk:
                 _must(ops.gemm_nt_qk_norm_rope(a["xm1"], sh[pre + "attention.qkv.weight|f"],
                                                 self.P(pre + "attention.qk_norm.query_norm.scale"),
                                                 self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["qkv"], a["q"], a["k"],
@@ -632,7 +650,8 @@ class DiTEngine:
                 ops.qk_norm_rope_fwd(a["qkv"], self.P(pre + "attention.qk_norm.query_norm.scale"),
                                      self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["q"], a["k"], None, a["rrms"], B, N,
                                      Hh, 64, rot)
-            ops.attn_fwd_qkv(a["q"], a["k"], a["qkv"], a["a"], a["lse"], B, Hh, N, 64, 64**-0.5)
+            if "ssq_all" not in w:
+                ops.attn_fwd_qkv(a["q"], a["k"], a["qkv"], a["a"], a["lse"], B, Hh, N, 64, 64**-0.5)
             _must(ops.ln_modulate_gemm_fwd(a["a"], sh[pre + "attention.proj_out.weight|f"], xin, mod[:, mo + 2 * D : mo + 3 * D],
                                             self.P(pre + "norm_2.weight"), self.P(pre + "norm_2.bias"), mod[:, mo + 3 * D : mo + 4 * D],
                                             mod[:, mo + 4 * D : mo + 5 * D], N, 1e-5, a["t1"], a["x1"], a["xm2"], a["mean2"], a["rstd2"]))
@@ -890,7 +909,7 @@ class DiTEngine:
         # stem: conv_proj weight gradient (no gradient flows to the input latents)
         Fi = d.input_channels * d.patch_size**2
         gc = self.G(self._conv_name).view(D, Fi)
-        if Fi % 8 == 0 and det is not None:
+        if Fi % 8 == 0 and det is not None and "scr_conv_t" in w:
             # taken TRANSPOSED, tok^T dX = [Fi, D], and added back through a 32 x 32 transposing kernel: the [D, Fi] form (Fi = 16: 64-byte
             # rows of the 342 partial images) took 222 us at the headline shape, this one 22 us + 3 us (r03 kernel trace)
             sc = w["scr_conv_t"][:Fi]

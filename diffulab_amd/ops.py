@@ -493,6 +493,21 @@ def attn_fwd_qkv(q, k, qkv, out, lse, B, H, N, dh, scale):
           float(scale), _s())
 
 
+def gemm_nt_ssq(a, w_sh, out, ssq) -> bool:
+    """out[M, N] = a w_sh^T (bf16, persistent 256 x 384 tiles) + ssq[M, T] += row sums of squares of the first T = ssq.shape[1] 384-wide
+    column tiles (ssq f32, zeroed by the caller): the qkv GEMM that also leaves the QK-RMSNorm statistics.  False: no such kernel for
+    the shape (the caller keeps gemm_nt + qk_norm_rope_fwd)"""
+    return _maybe("dl_gemm_nt_ssq", _p(a), a.stride(0), _p(w_sh), w_sh.stride(0), _p(out), out.stride(0), a.shape[0], w_sh.shape[0],
+                  a.shape[1], _p(ssq), ssq.shape[1], _s())
+
+
+def attn_fwd_qkn(qkv, ssq, scale_q, scale_k, cos, sin, q, k, rrms, out, lse, B, H, N, dh, rot, scale, eps=1e-6):
+    """attention forward from the PRE-NORM token-major qkv rows: QK-RMSNorm (statistics = ssq of gemm_nt_ssq) + RoPE applied as q
+    and k are staged; writes the normalised q, k head-major and rrms [M, 2] for the backward kernels (N <= 256)"""
+    _call("dl_attn_fwd_qkn", _p(qkv), _p(ssq), _p(scale_q), _p(scale_k), _p(cos), _p(sin), float(eps), rot, _p(q), _p(k), _p(rrms), _p(out),
+          _p(lse), B, H, N, dh, float(scale), _s())
+
+
 def attn_bwd_qkv(q, k, qkv, out, dout, lse, dq, dk, dqkv, B, H, N, dh, scale):
     """N <= 256: V read from qkv, dV written into the v third of dqkv [B*N, 3*H*dh] (qk_norm_rope_bwd then takes dv=None)"""
     D = H * dh

@@ -15,6 +15,8 @@ SWITCHES: dict[str, tuple[str, str]] = {
     "DL_NATIVE_BLOCK": ("1", "DiT blocks issued by the C ABI's block drivers (dl_dit_block_fwd / _bwd) instead of one Python call per kernel"),
     "DL_ROW_GEMM": ("1", "LayerNorm-modulate forward / backward as epilogues of the row-complete 256x384 GEMMs (D = 384, 256 tokens per sample)"),
     "DL_ROW_GEMM_QK": ("0", "QK-norm + RoPE as the epilogue of the qkv GEMM (measured slower than the separate row kernel)"),
+    "DL_QKN_ON_LOAD": ("1", "QK-RMSNorm statistics leave with the qkv GEMM (dl_gemm_nt_ssq) and norm + RoPE are applied as the attention "
+                       "forward stages q and k (dl_attn_fwd_qkn): no qk_norm_rope_fwd pass (row-complete path, <= 256 tokens)"),
     "DL_MLP_RECOMPUTE": ("1", "SwiGLU backward recomputes the MLP-up pre-activations instead of storing them in the forward"),
     "DL_ATTN_V_IN_PLACE": ("1", "attention reads V / writes dV inside the token-major qkv rows (N <= 256)"),
     "DL_QK_INPLACE": ("1", "attention backward writes dQ / dK token-major and the QK-norm backward runs in place on the dqkv rows"),

@@ -312,6 +312,19 @@ DL_API int dl_attn_bwd_sv(const void* q, const void* k, const void* v, int64_t v
  * head-major dq / dk buffers, and the QK-norm backward reads whole 2D-wide rows instead of H 128-byte segments per row. */
 DL_API int dl_attn_bwd_tok(const void* q, const void* k, const void* qkv, const void* out, const void* dout, const float* lse,
                            void* dqkv, int64_t B, int64_t H, int64_t N, int64_t dh, float scale, dl_stream_t stream);
+/* ---- QK-RMSNorm + RoPE without a pass of its own (round 4).  dl_gemm_nt_ssq: the plain bf16 product C = A B^T on the persistent
+ * 256 x 384 tiles (the qkv GEMM, mmdit.py:81) whose epilogue also adds the per-row sums of squares of the rounded outputs of the first
+ * `ssq_tiles` 384-wide column tiles into ssq f32 [M, ssq_tiles] (the caller zeroes it; two addends per element: bit-reproducible) --
+ * the statistics of RMSNorm over the full D-wide q / k row (nn.py:427-431).  M % 256 == 0, N % 384 == 0, >= 64 tiles, else
+ * DL_ERR_UNSUPPORTED.  dl_attn_fwd_qkn: DiTAttention.forward mmdit.py:81-100 from the PRE-NORM token-major qkv rows [B*N, 3D]: q and k
+ * are normalised with r = rsqrt(ssq / D + eps), scaled and rotated (nn.py:345-353) as they are staged (K in LDS, Q in registers),
+ * then softmax(q k^T scale) v as dl_attn_fwd_sv; the normalised q, k are also written head-major [B, H, N, 64] and r as rrms [B*N, 2]
+ * (inputs of the backward kernels).  N % 64 == 0 up to 256, dh = 64. */
+DL_API int dl_gemm_nt_ssq(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+                          int64_t K, float* ssq, int64_t ssq_tiles, dl_stream_t stream);
+DL_API int dl_attn_fwd_qkn(const void* qkv, const float* ssq, const float* scale_q, const float* scale_k, const float* cos,
+                           const float* sin, float eps, int64_t rot, void* q_out, void* k_out, float* rrms, void* out, float* lse,
+                           int64_t B, int64_t H, int64_t N, int64_t dh, float scale, dl_stream_t stream);
 /* PackedSwiGLU nn.py:484-486: h = silu(u[:, :F]) * u[:, F:] ; u bf16 [M, 2F] */
 DL_API int dl_swiglu_fwd(const void* u, void* h, int64_t M, int64_t F, dl_stream_t stream);
 DL_API int dl_swiglu_bwd(const void* dh, const void* u, void* du, int64_t M, int64_t F, dl_stream_t stream);
@@ -634,6 +647,8 @@ enum {
   DL_BLK_TN_SLAB,     /* f32 [tn_slab_floats] scratch of dl_gemm_tn_group, or NULL: the four weight gradients as dl_gemm_tn_ex launches */
   DL_BLK_QK_PARTIALS, /* f32 [1024 * 2 * D] scratch of dl_qk_norm_rope_bwd_inplace, or NULL; with it (V in place, D <= 512) dQ / dK /
                        * dV are written token-major into DQKV (dl_attn_bwd_tok) and DQ / DK are not used */
+  DL_BLK_SSQ,         /* f32 [M, 2] ZEROED by the caller before dl_dit_block_fwd, or NULL; with it (row_gemms, V in place) the forward
+                       * runs dl_gemm_nt_ssq + dl_attn_fwd_qkn: no QK-norm + RoPE pass of its own */
   DL_BLK_NPTR
 };
 typedef struct dl_dit_block_t {

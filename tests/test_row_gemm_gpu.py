@@ -179,3 +179,51 @@ def test_row_gemms_decline_other_shapes(ops):
     a, w = dev_bf(torch.zeros(M, D)), dev_bf(torch.zeros(D, D))
     o = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
     assert not ops.ln_modulate_gemm_fwd(a, w, None, None, None, None, mod[:, :D], mod[:, D : 2 * D], 64, 1e-5, None, o, o, mu, mu)
+
+
+@pytest.mark.parametrize("B,gh,gw", [(24, 16, 16), (64, 8, 8)])
+def test_qkv_gemm_with_row_statistics_and_attention_with_qk_norm_on_load(ops, B, gh, gw):
+    """round 4: dl_gemm_nt_ssq + dl_attn_fwd_qkn (QK-RMSNorm statistics from the qkv GEMM's epilogue, norm + RoPE applied as the
+    attention stages q and k) against the sequence they replace, dl_gemm_nt -> dl_qk_norm_rope_fwd -> dl_attn_fwd_sv: qkv bit for
+    bit, rrms to 1e-6, the normalised q / k to a bf16 ulp on a few elements per thousand, the attention output and lse to the
+    accuracy those ulps allow; two runs give identical bits (two addends per statistics word)"""
+    H, dh = 6, 64
+    Nt = gh * gw
+    M = B * Nt
+    a = dev_bf(synth.normal("qn.a", (M, D)))
+    w = dev_bf(synth.normal("qn.w", (3 * D, D), std=D**-0.5))
+    sq = (1 + synth.normal("qn.sq", (D,), std=0.1)).to(DEV)
+    sk = (1 + synth.normal("qn.sk", (D,), std=0.1)).to(DEV)
+    cos, sin = (t.to(DEV) for t in odit.rope_tables(gh, gw, [32, 32], 10_000.0))
+    bf = dict(device=DEV, dtype=torch.bfloat16)
+
+    qkv0 = torch.empty(M, 3 * D, **bf)
+    q0, k0 = (torch.empty(B, H, Nt, dh, **bf) for _ in range(2))
+    r0, o0, l0 = torch.zeros(M, 2, device=DEV), torch.empty(M, D, **bf), torch.empty(B, H, Nt, device=DEV)
+    ops.gemm_nt(a, w, qkv0)
+    ops.qk_norm_rope_fwd(qkv0, sq, sk, cos, sin, q0, k0, None, r0, B, Nt, H, dh, 64)
+    ops.attn_fwd_qkv(q0, k0, qkv0, o0, l0, B, H, Nt, dh, dh**-0.5)
+
+    def fused():
+        qkv1 = torch.full((M, 3 * D), 7.0, **bf)
+        q1, k1 = (torch.full((B, H, Nt, dh), 7.0, **bf) for _ in range(2))
+        ssq = torch.zeros(M, 2, device=DEV)
+        r1, o1, l1 = torch.zeros(M, 2, device=DEV), torch.empty(M, D, **bf), torch.empty(B, H, Nt, device=DEV)
+        assert ops.gemm_nt_ssq(a, w, qkv1, ssq)
+        ops.attn_fwd_qkn(qkv1, ssq, sq, sk, cos, sin, q1, k1, r1, o1, l1, B, H, Nt, dh, 64, dh**-0.5)
+        torch.cuda.synchronize()
+        return qkv1, ssq, q1, k1, r1, o1, l1
+
+    qkv1, ssq, q1, k1, r1, o1, l1 = fused()
+    assert same(qkv1, qkv0)
+    ref_ssq = torch.stack([qkv0[:, :D].float().square().sum(1), qkv0[:, D : 2 * D].float().square().sum(1)], 1)
+    assert rel(ssq, ref_ssq) < 1e-6
+    assert close_f32(r1, r0, 2e-6)
+    assert same_to_an_ulp(q1, q0), rel(q1.float(), q0.float())
+    assert same_to_an_ulp(k1, k0), rel(k1.float(), k0.float())
+    assert rel(o1.float(), o0.float()) < 2e-3 and float((l1 - l0).abs().max()) < 2e-3
+    again = fused()
+    assert all(same(x, y) for x, y in zip((qkv1, ssq, q1, k1, r1, o1, l1), again))
+    # shapes without the persistent 384-wide tiling decline (the engine keeps the launch pair)
+    small = dev_bf(torch.zeros(8 * 256, D))
+    assert not ops.gemm_nt_ssq(small, w, torch.empty(8 * 256, 3 * D, **bf), torch.zeros(8 * 256, 2, device=DEV))
