@@ -401,17 +401,41 @@ __global__ __launch_bounds__(512) void attn_fwd_qkn_k(const bf16_t* __restrict__
   tile_dma(base + D, qn.pitch, kt, N, wave, nwaves, lane);
   tile_dma(base + 2 * D, qn.pitch, vt, N, wave, nwaves, lane);
 
-  // ---- this wave's query rows: raw fragments out of the token-major rows, normalised + rotated in registers
+  // ---- everything the two transforms read from global memory is requested NOW, under the flight of the tile DMA: the raw q
+  //      fragments of this wave's query rows, the row statistics, the rotary table rows and the scales of (up to) four K chunks per
+  //      thread (chunk id = thread + i * blockDim: row id >> 3, 16-byte slot id & 7 -- the slot is the same for all of a thread's
+  //      chunks because blockDim is a multiple of 8)
   const int q0 = wave * 32, qrow = q0 + (lane & 31);
   const int64_t tok = (int64_t)b * N + qrow;
-  const float rq = rsqrtf(qn.ssq[tok * 2] * qn.inv_d + qn.eps);
+  const float ssq_q = qn.ssq[tok * 2];
+  u32x4_t qraw[4];
+  f32x4_t qc[4], qs[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int d0 = ks * 16 + hi * 8;
+    qraw[ks] = *(const u32x4_t*)(base + (int64_t)qrow * qn.pitch + d0);
+    qc[ks] = *(const f32x4_t*)(qn.cs + (int64_t)qrow * half + (d0 >> 1));
+    qs[ks] = *(const f32x4_t*)(qn.sn + (int64_t)qrow * half + (d0 >> 1));
+  }
+  const int kslot = threadIdx.x & 7, kd0 = kslot * 8, krow0 = threadIdx.x >> 3, kstep = blockDim.x >> 3;
+  float kssq[4];
+  f32x4_t kc[4], kn[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = krow0 + i * kstep;
+    if (row < N) {
+      kssq[i] = qn.ssq[((int64_t)b * N + row) * 2 + 1];
+      kc[i] = *(const f32x4_t*)(qn.cs + (int64_t)row * half + (kd0 >> 1));
+      kn[i] = *(const f32x4_t*)(qn.sn + (int64_t)row * half + (kd0 >> 1));
+    }
+  }
+  // ---- this wave's query rows: normalised + rotated in registers
+  const float rq = rsqrtf(ssq_q * qn.inv_d + qn.eps);
   bf16x8_t qf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     const int d0 = ks * 16 + hi * 8;
-    const u32x4_t raw = *(const u32x4_t*)(base + (int64_t)qrow * qn.pitch + d0);
-    const u32x4_t t = qk_xform8(raw, rq, qn.sq + h * DH + d0, qn.cs + (int64_t)qrow * half + (d0 >> 1), qn.sn + (int64_t)qrow * half + (d0 >> 1),
-                                d0 < qn.rot);
+    const u32x4_t t = qk_xform8(qraw[ks], rq, qn.sq + h * DH + d0, (const float*)&qc[ks], (const float*)&qs[ks], d0 < qn.rot);
     qf[ks] = __builtin_bit_cast(bf16x8_t, t);
     *(u32x4_t*)(qn.qo + ((int64_t)bh * N + qrow) * DH + d0) = t;
   }
@@ -420,16 +444,17 @@ __global__ __launch_bounds__(512) void attn_fwd_qkn_k(const bf16_t* __restrict__
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // ---- K tile: in place in LDS (source slot `slot` of row `row` sits at tile_off(row, slot))
-  for (int id = threadIdx.x; id < N * 8; id += blockDim.x) {
-    const int row = id >> 3, slot = id & 7, d0 = slot * 8;
-    const int64_t tk = (int64_t)b * N + row;
-    const float rk = rsqrtf(qn.ssq[tk * 2 + 1] * qn.inv_d + qn.eps);
-    char* p = kt + tile_off(row, slot);
-    const u32x4_t t = qk_xform8(*(const u32x4_t*)p, rk, qn.sk + h * DH + d0, qn.cs + (int64_t)row * half + (d0 >> 1),
-                                qn.sn + (int64_t)row * half + (d0 >> 1), d0 < qn.rot);
-    *(u32x4_t*)p = t;
-    *(u32x4_t*)(qn.ko + ((int64_t)bh * N + row) * DH + d0) = t;
-    if (h == 0 && slot == 0) qn.rrms[tk * 2 + 1] = rk;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = krow0 + i * kstep;
+    if (row < N) {
+      const float rk = rsqrtf(kssq[i] * qn.inv_d + qn.eps);
+      char* p = kt + tile_off(row, kslot);
+      const u32x4_t t = qk_xform8(*(const u32x4_t*)p, rk, qn.sk + h * DH + kd0, (const float*)&kc[i], (const float*)&kn[i], kd0 < qn.rot);
+      *(u32x4_t*)p = t;
+      *(u32x4_t*)(qn.ko + ((int64_t)bh * N + row) * DH + kd0) = t;
+      if (h == 0 && kslot == 0) qn.rrms[((int64_t)b * N + row) * 2 + 1] = rk;
+    }
   }
   __syncthreads();
 

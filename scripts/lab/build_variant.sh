@@ -8,7 +8,7 @@ name=$1; flags=$2; shift 2
 make -s ../libdiffulab_hip.so
 mkdir -p build/lab_$name
 objs=""
-for src in elementwise gemm gemm_ln gemm_w4 mlp_bwd norm attention attention_fp8 embed unet tokens block; do
+for src in elementwise gemm gemm_ln gemm_w4 mlp_bwd norm attention embed unet tokens block f32; do
   if [[ " $* " == *" $src.hip "* ]]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -fvisibility=hidden -Wall -Wno-unused-function \
       -Wno-unused-variable $flags -c $src.hip -o build/lab_$name/$src.o &

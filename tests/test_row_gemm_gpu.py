@@ -181,7 +181,7 @@ def test_row_gemms_decline_other_shapes(ops):
     assert not ops.ln_modulate_gemm_fwd(a, w, None, None, None, None, mod[:, :D], mod[:, D : 2 * D], 64, 1e-5, None, o, o, mu, mu)
 
 
-@pytest.mark.parametrize("B,gh,gw", [(24, 16, 16), (64, 8, 8)])
+@pytest.mark.parametrize("B,gh,gw", [(24, 16, 16), (40, 16, 16)])
 def test_qkv_gemm_with_row_statistics_and_attention_with_qk_norm_on_load(ops, B, gh, gw):
     """round 4: dl_gemm_nt_ssq + dl_attn_fwd_qkn (QK-RMSNorm statistics from the qkv GEMM's epilogue, norm + RoPE applied as the
     attention stages q and k) against the sequence they replace, dl_gemm_nt -> dl_qk_norm_rope_fwd -> dl_attn_fwd_sv: qkv bit for
@@ -219,8 +219,10 @@ def test_qkv_gemm_with_row_statistics_and_attention_with_qk_norm_on_load(ops, B,
     ref_ssq = torch.stack([qkv0[:, :D].float().square().sum(1), qkv0[:, D : 2 * D].float().square().sum(1)], 1)
     assert rel(ssq, ref_ssq) < 1e-6
     assert close_f32(r1, r0, 2e-6)
-    assert same_to_an_ulp(q1, q0), rel(q1.float(), q0.float())
-    assert same_to_an_ulp(k1, k0), rel(k1.float(), k0.float())
+    # (the statistics are summed in another order than the row kernel's wave reduction: r differs in its last bits, so a few per cent
+    # of the normalised elements may land on the neighbouring bf16)
+    assert same_to_an_ulp(q1, q0, frac=5e-2) and rel(q1.float(), q0.float()) < 1e-4
+    assert same_to_an_ulp(k1, k0, frac=5e-2) and rel(k1.float(), k0.float()) < 1e-4
     assert rel(o1.float(), o0.float()) < 2e-3 and float((l1 - l0).abs().max()) < 2e-3
     again = fused()
     assert all(same(x, y) for x, y in zip((qkv1, ssq, q1, k1, r1, o1, l1), again))
