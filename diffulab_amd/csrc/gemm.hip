@@ -368,34 +368,10 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
   int s_tile = slot0, s_kt = 0, s_it = 0;
   const bf16_t* s_ta = A + (int64_t)((s_tile / tiles_n) * TBM) * lda;
   const bf16_t* s_tb = Bm + (int64_t)((s_tile % tiles_n) * TN_) * ldb;
-#ifdef NT_ASYM
-  // LAB (round 4): asymmetric stage issue.  Waves w and w + 4 share a SIMD; in the symmetric loop both sit in the issue of their ten
-  // 1 KiB DMA chunks at the same time (the vector-memory path takes them at ~64 B/clk: ~1300 cycles per 80 KiB stage) and the
-  // SIMD's matrix pipe idles until they are through.  Here waves 0-3 issue ALL chunks of a stage while waves 4-7 go straight to
-  // their MFMAs, so the pipe has work during the issue.  Chunk addresses are recomputed (no per-chunk register arrays):
-  // row r = 8 cc + (lane >> 3), source slot (lane & 7) ^ ((r >> 1) & 7) = (lane & 7) ^ ((4 (cc & 1) + (lane >> 4)) & 7).
-  constexpr int CHT = (TBM + TN_) / 8;
-  const bool loader = wave < 4;
-  const int l8 = lane >> 3, qe = (lane & 7) ^ ((lane >> 4) & 7), qo = (lane & 7) ^ ((4 + (lane >> 4)) & 7);
-#endif
   auto stage_next = [&]() {
     char* base = smem + (s_it % NST) * STAGE;
-#ifdef NT_ASYM
-    if (loader) {
-#pragma unroll
-      for (int i = 0; i < CHT / 4; ++i) {
-        const int c = wave * (CHT / 4) + i;
-        const bool a = c < TBM / 8;
-        const int cc = a ? c : c - TBM / 8;
-        const int64_t ld = a ? lda : ldb;
-        const int64_t off = (int64_t)(cc * 8 + l8) * ld + (((cc & 1) ? qo : qe) << 3);
-        glds16((a ? s_ta : s_tb) + off + s_kt * BK, base + (a ? 0 : TBM * 128) + cc * 1024);
-      }
-    }
-#else
 #pragma unroll
     for (int i = 0; i < CH; ++i) glds16((is_a[i] ? s_ta : s_tb) + src_off[i] + s_kt * BK, base + lds_off[i]);
-#endif
     ++s_it;
     if (++s_kt == nk) {
       s_kt = 0;
@@ -404,23 +380,6 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
       s_tb = Bm + (int64_t)((s_tile % tiles_n) * TN_) * ldb;
     }
   };
-#ifdef NT_DEAL
-  // LAB (round 4): ONE DMA chunk behind every NT_DEAL-th MFMA pair instead of all ten up front: a wave that asks for one chunk while
-  // the queue has room does not stall, and the partner wave on its SIMD keeps the matrix pipe busy meanwhile
-  auto stage_chunk = [&](int i) {
-    char* base = smem + (s_it % NST) * STAGE;
-    glds16((is_a[i] ? s_ta : s_tb) + src_off[i] + s_kt * BK, base + lds_off[i]);
-  };
-  auto stage_advance = [&]() {
-    ++s_it;
-    if (++s_kt == nk) {
-      s_kt = 0;
-      s_tile += G;
-      s_ta = A + (int64_t)((s_tile / tiles_n) * TBM) * lda;
-      s_tb = Bm + (int64_t)((s_tile % tiles_n) * TN_) * ldb;
-    }
-  };
-#endif
 
   if (ep.stagger > 0) {
     // every tile costs the same time, so without a skew all 256 workgroups compute together and then store together (a
@@ -467,11 +426,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
     __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would drain vmcnt (the DMA counts as an LDS write)
     // NST >= 3: the DMA for stage it+NST-1 is issued AFTER this step's MFMAs are queued (its issue is bound by the
     // 64 B/clk vector-memory path; up front it would hold every wave off the matrix pipe for ~900 cycles)
-#ifdef NT_DEAL
-    const bool deal = NST < 3 && s_it < total;
-#else
     if (NST < 3 && s_it < total) stage_next();  // into the slot whose stage was consumed in iteration it-1
-#endif
     const char* sa = smem + (it % NST) * STAGE;
     const char* sb = sa + TBM * 128;
     {
@@ -498,18 +453,8 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
         if (kk < 3 && j < 2) xq[(kk + 1) & 1][j] = rd_x(kk + 1, j);
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s % 3], xq[kk & 1][i], acc[j][i], 0, 0, 0);
-#ifdef NT_DEAL
-        if (deal && (s % NT_DEAL) == NT_DEAL - 1 && s / NT_DEAL < CH) stage_chunk(s / NT_DEAL);
-#endif
       }
       __builtin_amdgcn_sched_barrier(0);
-#ifdef NT_DEAL
-      if (deal) {
-#pragma unroll
-        for (int i = (4 * JN) / NT_DEAL; i < CH; ++i) stage_chunk(i);  // (narrow tiles: more chunks than deal slots)
-        stage_advance();
-      }
-#endif
     }
     if (NST >= 3 && s_it < total) stage_next();
     after_epi = false;
