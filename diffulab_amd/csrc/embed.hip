@@ -390,26 +390,6 @@ __global__ void reduce_rows_k(float* __restrict__ partial, float* __restrict__ o
   __syncthreads();
   if (rl == 0 && c < n) unsafeAtomicAdd(&out[c], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
-// dst[c, r] += src[r, c] for a small f32 matrix (32 x 32 tiles through LDS): a weight gradient that was computed transposed because
-// the transposed product has the friendlier shape (conv_proj: [D, 16] as [16, D])
-__global__ void add_transposed_k(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst, int64_t ldd, int R, int C) {
-  __shared__ float t[32][33];
-  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  for (int i = ty; i < 32; i += 8)
-    t[i][tx] = (r0 + i < R && c0 + tx < C) ? src[(int64_t)(r0 + i) * lds_ + c0 + tx] : 0.f;
-  __syncthreads();
-  for (int i = ty; i < 32; i += 8)
-    if (c0 + i < C && r0 + tx < R) dst[(int64_t)(c0 + i) * ldd + r0 + tx] += t[tx][i];
-}
-extern "C" int dl_add_transposed_f32(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t R, int64_t C,
-                                     dl_stream_t stream) {
-  DL_CHECK_ARG(src && dst && R > 0 && C > 0 && ld_src >= C && ld_dst >= R, "dl_add_transposed_f32: bad args");
-  hipLaunchKernelGGL(add_transposed_k, dim3(cdiv(C, 32), cdiv(R, 32)), 256, 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, (int)R, (int)C);
-  DL_LAUNCH_CHECK();
-  return DL_OK;
-}
-
 extern "C" int dl_reduce_rows_f32(float* partial, float* out, int64_t G, int64_t n, int clear_partial, dl_stream_t stream) {
   DL_CHECK_ARG(partial && out && G > 0 && n > 0, "dl_reduce_rows_f32: bad args");
   hipLaunchKernelGGL(reduce_rows_k, dim3(cdiv(n, 64), cdiv(G, 64)), 256, 0, (hipStream_t)stream, partial, out, (int)G, n,

@@ -374,7 +374,6 @@ class DiTEngine:
             w["det_scr"] = torch.empty(max(2 * self.layout.mod_rows * E, 1 << 22), device=dev, dtype=f32)
             w["scr_last"] = z(_rup(Fo, 8), D, dtype=f32)
             w["scr_conv"] = z(D, self._ki, dtype=f32)
-            w["scr_conv_t"] = z(self._ki, D, dtype=f32)
         self.ws, self._ws_key = w, key
         self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)
         if len(self._ws_cache) >= 8:  # bound the cache: drop the oldest shape (its graphs are dropped by the module too)
@@ -909,14 +908,7 @@ class DiTEngine:
         # stem: conv_proj weight gradient (no gradient flows to the input latents)
         Fi = d.input_channels * d.patch_size**2
         gc = self.G(self._conv_name).view(D, Fi)
-        if Fi % 8 == 0 and det is not None and "scr_conv_t" in w:
-            # taken TRANSPOSED, tok^T dX = [Fi, D], and added back through a 32 x 32 transposing kernel: the [D, Fi] form (Fi = 16: 64-byte
-            # rows of the 342 partial images) took 222 us at the headline shape, this one 22 us + 3 us (r03 kernel trace)
-            sc = w["scr_conv_t"][:Fi]
-            sc.zero_()
-            ops.gemm_tn(w["tokP"], dx, sc, M=Fi, N=D, scratch=det)
-            ops.add_transposed_f32(sc, gc)
-        elif Fi % 8 == 0:
+        if Fi % 8 == 0:
             ops.gemm_tn(dx, w["tokP"], gc, M=D, N=Fi, scratch=det)
         else:
             w["scr_conv"].zero_()

@@ -609,12 +609,6 @@ def reduce_rows_f32(partial, out, G, n, clear=False):
     _call("dl_reduce_rows_f32", _p(partial), _p(out), G, n, int(clear), _s())
 
 
-def add_transposed_f32(src, dst):
-    """dst[c, r] += src[r, c] (small f32 matrices)"""
-    R, C = src.shape
-    _call("dl_add_transposed_f32", _p(src), src.stride(0), _p(dst), dst.stride(0), R, C, _s())
-
-
 def reduce_rows_batched_f32(partial, partial_stride, out, out_stride, K, G, n):
     """K folds in one launch: out[k * out_stride + j] += sum_g partial[k * partial_stride + g * n + j] (deterministic)"""
     _call("dl_reduce_rows_batched_f32", _p(partial), partial_stride, _p(out), out_stride, K, G, n, _s())

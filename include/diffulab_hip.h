@@ -366,10 +366,6 @@ DL_API int dl_colsum(const void* x, int dtype, int64_t ld, float* out, int64_t R
 /* out[j] += sum_g partial[g, j]   (second stage of the LayerNorm affine gradients); clear_partial != 0 zeroes `partial`
  * as it is read, so accumulate-into partial buffers need no memset */
 DL_API int dl_reduce_rows_f32(float* partial, float* out, int64_t G, int64_t n, int clear_partial, dl_stream_t stream);
-/* dst[c, r] += src[r, c] (f32, small): a weight gradient computed transposed because the transposed product has the friendlier
- * shape -- the patch-embedding convolution's [D, C p p] gradient (mmdit.py:757-765) is taken as tok^T dX = [C p p, D] */
-DL_API int dl_add_transposed_f32(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t R, int64_t C,
-                                 dl_stream_t stream);
 /* K such folds in one launch, deterministic (one writer per element, fixed order):
  * out[k * out_stride + j] += sum_{g < G} partial[k * partial_stride + g * n + j]  for k < K, j < n (strides in elements) */
 DL_API int dl_reduce_rows_batched_f32(const float* partial, int64_t partial_stride, float* out, int64_t out_stride, int64_t K,
