@@ -209,6 +209,52 @@ extern "C" int dl_probe_dma(int kb, const void* A, const void* Bw, int64_t M, in
   return DL_OK;
 }
 
+// ---- round 4: does the operand stream scale with the number of RESIDENT waves / workgroups per CU?  A workgroup of `blockDim` threads
+// walks row panels of `rows_a` activation rows (tile t: rows [t rows_a, ...)) and stages, per 64-deep k-step, rows_a + rows_b rows of
+// 128 bytes (the weight rows are the same rows_b rows for every tile: L2-resident) into an `nslot`-deep ring; nothing is computed.
+// grid = 256 * wgs_per_cu.  What the asymmetric-issue experiment suggested: the stream's rate follows the number of issuing waves.
+__global__ void dma_probe2_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bw, int M, int K, int rows_a, int rows_b,
+                             int nslot, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+  const int rows = rows_a + rows_b, stage = rows * 128, nch = rows / 8;
+  const int nk = K / 64, ntiles = M / rows_a;
+  int it = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int kt = 0; kt < nk; ++kt, ++it) {
+      char* base = smem + (it % nslot) * stage;
+      for (int c = wave; c < nch; c += nwaves) {
+        const int row = c * 8 + (lane >> 3);
+        const bf16_t* src = row < rows_a ? A + (int64_t)(tile * rows_a + row) * K : Bw + (int64_t)(row - rows_a) * K;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(src + kt * 64 + (lane & 7) * 8), (lds_void_t*)(base + c * 1024), 16, 0, 0);
+      }
+      if (nslot == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      } else if ((it % nslot) == nslot - 1) {  // (every nslot stages: let all but the youngest stage land)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  out[(blockIdx.x * blockDim.x + threadIdx.x) & (256 * 512 - 1)] = ((float*)smem)[threadIdx.x];
+}
+extern "C" int dl_probe_dma2(int wgs_per_cu, int threads, int rows_a, int rows_b, int nslot, const void* A, const void* Bw, int64_t M,
+                             int64_t K, float* out, dl_stream_t stream) {
+  DL_CHECK_ARG(A && Bw && out && wgs_per_cu >= 1 && threads % 64 == 0 && threads <= 1024 && rows_a % 8 == 0 && rows_b % 8 == 0 &&
+               nslot >= 1 && M % rows_a == 0 && K % 64 == 0, "dl_probe_dma2: bad args");
+  const int lds = (rows_a + rows_b) * 128 * nslot;
+  DL_CHECK_ARG(lds <= 163840 / wgs_per_cu, "dl_probe_dma2: %d bytes of LDS per workgroup do not fit %d times", lds, wgs_per_cu);
+  (void)hipFuncSetAttribute((const void*)dma_probe2_k, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+  hipLaunchKernelGGL(dma_probe2_k, 256 * wgs_per_cu, threads, lds, (hipStream_t)stream, (const bf16_t*)A, (const bf16_t*)Bw, (int)M, (int)K,
+                     rows_a, rows_b, nslot, out);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
 extern "C" int dl_probe_mfma(int mode, int iters, const void* src, float* out, dl_stream_t stream) {
   DL_CHECK_ARG(out && iters > 0 && mode >= 0 && mode <= 9 && (mode < 3 || mode > 7 || src), "dl_probe_mfma: bad args");
   if (mode >= 8) {  // store-pattern probe: out is a bf16 [65536, 1152] buffer

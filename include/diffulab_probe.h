@@ -32,6 +32,11 @@ DL_API int dl_probe_mfma(int mode, int iters, const void* src, float* out, dl_st
  * with 64-byte row segments / 4 ring slots); out: >= 256*512 floats */
 DL_API int dl_probe_dma(int kb, const void* A, const void* Bw, int64_t M, int64_t K, float* out, dl_stream_t stream);
 
+/* the same stream with a free geometry (round 4): 256 * wgs_per_cu workgroups of `threads` threads, tiles of rows_a activation rows +
+ * rows_b (shared, L2-resident) weight rows per 64-deep stage, an nslot-deep LDS ring; nothing is computed.  Answers whether the
+ * L2 -> LDS operand rate of a CU scales with the number of resident / issuing waves.  out: >= 256*512 floats */
+DL_API int dl_probe_dma2(int wgs_per_cu, int threads, int rows_a, int rows_b, int nslot, const void* A, const void* Bw, int64_t M,
+                         int64_t K, float* out, dl_stream_t stream);
 /* `n_wgs` workgroups of `threads` threads that do nothing but hold their CU slots for `usec` microseconds (wall clock): a stand-in
  * for a communication kernel (RCCL's channel workgroups) beside the compute stream, to measure what co-residency costs the
  * one-workgroup-per-CU kernels (scripts/lab/occupied_cus.py). */

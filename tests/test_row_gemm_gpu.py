@@ -221,8 +221,13 @@ def test_qkv_gemm_with_row_statistics_and_attention_with_qk_norm_on_load(ops, B,
     assert close_f32(r1, r0, 2e-6)
     # (the statistics are summed in another order than the row kernel's wave reduction: r differs in its last bits, so a few per cent
     # of the normalised elements may land on the neighbouring bf16)
-    assert same_to_an_ulp(q1, q0, frac=5e-2) and rel(q1.float(), q0.float()) < 1e-4
-    assert same_to_an_ulp(k1, k0, frac=5e-2) and rel(k1.float(), k0.float()) < 1e-4
+    for got, want in ((q1, q0), (k1, k0)):
+        g32, w32 = got.float(), want.float()
+        diff = (g32 - w32).abs()
+        # at most a few per cent of the elements on the neighbouring bf16, by one ulp of the element or -- where the rotation
+        # a c - b s cancels -- of the operands' magnitude
+        assert float((diff > 0).float().mean()) < 5e-2 and bool((diff <= 2.0**-6 * w32.abs().clamp_min(0.05 * float(w32.abs().mean()))).all())
+        assert rel(g32, w32) < 1e-4
     assert rel(o1.float(), o0.float()) < 2e-3 and float((l1 - l0).abs().max()) < 2e-3
     again = fused()
     assert all(same(x, y) for x, y in zip((qkv1, ssq, q1, k1, r1, o1, l1), again))
