@@ -877,3 +877,310 @@ extern "C" int dl_f32_cond_combine_bwd(const float* dact, const float* emb, cons
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
+
+// ============================================================================================================ UNet (fp32 regime)
+// NHWC f32 token rows [B*H*W, C].  A 3x3 / pad-1 convolution (nn.Conv2d, unet.py:187,208,594,745) is im2col + dl_f32_gemm against the
+// weight in its NATIVE layout [Co, Ci, 3, 3] = [Co, Ci*9] (no shadow): cols[p, ci*9 + ky*3 + kx] = x[p + (ky-1, kx-1), ci].
+__global__ void f32_im2col3x3_k(const float* __restrict__ x, int64_t ldx, float* __restrict__ cols, int B, int H, int W, int C) {
+  const int64_t n = (int64_t)B * H * W * C * 9;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % 9);
+    const int64_t r = i / 9;
+    const int c = (int)(r % C);
+    const int64_t p = r / C;
+    const int xx = (int)(p % W), yy = (int)((p / W) % H);
+    const int64_t b = p / ((int64_t)W * H);
+    const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
+    cols[i] = (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) ? x[((b * H + y2) * W + x2) * ldx + c] : 0.f;
+  }
+}
+// adjoint (data gradient): dx[p', ci] = sum_tap dcols[p' - (ky-1, kx-1), ci*9 + tap] -- a gather, one writer per element
+__global__ void f32_col2im3x3_k(const float* __restrict__ dcols, float* __restrict__ dx, int64_t ldd, int B, int H, int W, int C) {
+  const int64_t n = (int64_t)B * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    const int xx = (int)(p % W), yy = (int)((p / W) % H);
+    const int64_t b = p / ((int64_t)W * H);
+    float s = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int y2 = yy - (tap / 3 - 1), x2 = xx - (tap % 3 - 1);
+      if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) s += dcols[(((b * H + y2) * W + x2) * (int64_t)C + c) * 9 + tap];
+    }
+    dx[p * ldd + c] = s;
+  }
+}
+extern "C" int dl_f32_im2col3x3(const float* x, int64_t ldx, float* cols, int64_t B, int64_t H, int64_t W, int64_t C,
+                                dl_stream_t stream) {
+  DL_CHECK_ARG(x && cols && B > 0 && H > 0 && W > 0 && C > 0 && ldx >= C, "dl_f32_im2col3x3: bad args");
+  hipLaunchKernelGGL(f32_im2col3x3_k, grid_1d(B * H * W * C * 9, 256, 16384), 256, 0, (hipStream_t)stream, x, ldx, cols, (int)B, (int)H, (int)W,
+                     (int)C);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_f32_col2im3x3(const float* dcols, float* dx, int64_t ld_dx, int64_t B, int64_t H, int64_t W, int64_t C,
+                                dl_stream_t stream) {
+  DL_CHECK_ARG(dcols && dx && B > 0 && H > 0 && W > 0 && C > 0 && ld_dx >= C, "dl_f32_col2im3x3: bad args");
+  hipLaunchKernelGGL(f32_col2im3x3_k, grid_1d(B * H * W * C, 256, 16384), 256, 0, (hipStream_t)stream, dcols, dx, ld_dx, (int)B, (int)H, (int)W,
+                     (int)C);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// block-wide sum in a fixed order (256 threads): wave sums, then the four waves through LDS
+__device__ __forceinline__ float f32_block_sum(float v, float* red4) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red4[0] + red4[1]) + (red4[2] + red4[3]);
+}
+// GroupNorm32 statistics (nn.py:11-13): per (sample, group) over C/G channels x HW pixels, two passes like the reference
+__global__ __launch_bounds__(256) void f32_gn_stats_k(const float* __restrict__ x, float* __restrict__ stats, int HW, int C, int G,
+                                                      float eps) {
+  __shared__ float red4[4];
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G, Cg = C / G;
+  const int64_t n = (int64_t)HW * Cg;
+  const float* base = x + (int64_t)b * HW * C + g * Cg;
+  float s = 0.f;
+  for (int64_t e = threadIdx.x; e < n; e += 256) s += base[(e / Cg) * C + (e % Cg)];
+  const float mu = f32_block_sum(s, red4) / (float)n;
+  float q = 0.f;
+  for (int64_t e = threadIdx.x; e < n; e += 256) {
+    const float d = base[(e / Cg) * C + (e % Cg)] - mu;
+    q += d * d;
+  }
+  const float var = f32_block_sum(q, red4) / (float)n;
+  if (threadIdx.x == 0) {
+    stats[blockIdx.x * 2] = mu;
+    stats[blockIdx.x * 2 + 1] = 1.0f / sqrtf(var + eps);
+  }
+}
+// out = act((xhat w + b)(1 + film_scale[b, c]) + film_shift[b, c])   (unet.py:215-237, 296-322)
+__global__ void f32_gn_apply_k(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ w,
+                               const float* __restrict__ bb, const float* __restrict__ fs, const float* __restrict__ fh, int64_t ldf,
+                               int act, float* __restrict__ out, int B, int HW, int C, int G) {
+  const int Cg = C / G;
+  const int64_t n = (int64_t)B * HW * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t b = i / ((int64_t)HW * C);
+    const float mu = stats[(b * G + c / Cg) * 2], rs = stats[(b * G + c / Cg) * 2 + 1];
+    float y = (x[i] - mu) * rs * w[c] + bb[c];
+    if (fs) y = y * (1.0f + fs[b * ldf + c]) + fh[b * ldf + c];
+    out[i] = act ? silu32(y) : y;
+  }
+}
+// backward of stats + apply; one workgroup per (sample, group).  Thread t owns channel t % Cg of the group and the pixels
+// t / Cg, t / Cg + R, ... (R = 256 / Cg pixel lanes): per-channel sums meet in LDS in a fixed order, group sums through the block sum.
+// dwp / dbp [B, C] per-sample partials of the affine gradients (WRITTEN; folded in a fixed order afterwards), dfs / dfh [B, ldf]
+// written; dx = dres + gradient through the norm.
+__global__ __launch_bounds__(256) void f32_gn_bwd_k(const float* __restrict__ dout, const float* __restrict__ x,
+                                                    const float* __restrict__ stats, const float* __restrict__ w,
+                                                    const float* __restrict__ bb, const float* __restrict__ fs,
+                                                    const float* __restrict__ fh, int64_t ldf, int act, const float* __restrict__ dres,
+                                                    float* __restrict__ dx, float* __restrict__ dwp, float* __restrict__ dbp,
+                                                    float* __restrict__ dfs, float* __restrict__ dfh, int HW, int C, int G) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = (float*)smem;  // [4][R][Cg] per-channel partials, then red4
+  __shared__ float red4[4];
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G, Cg = C / G;
+  const int R = 256 / Cg > 0 ? 256 / Cg : 1;  // (Cg <= 256)
+  const int cl = threadIdx.x % Cg, r = threadIdx.x / Cg;
+  const bool live = r < R;
+  const int c = g * Cg + cl;
+  const float mu = stats[blockIdx.x * 2], rs = stats[blockIdx.x * 2 + 1];
+  const float wc = w[c], bc = bb[c];
+  const float f1 = fs ? 1.0f + fs[(int64_t)b * ldf + c] : 1.0f, f0 = fs ? fh[(int64_t)b * ldf + c] : 0.f;
+  const int64_t base = (int64_t)b * HW * C + c;
+  float s_dz = 0.f, s_dzy = 0.f, s_dy = 0.f, s_dyx = 0.f;  // per channel: sum dz, sum dz y, sum dy, sum dy xhat
+  float g1 = 0.f, g2 = 0.f;                                  // per group: sum dxh, sum dxh xhat
+  if (live)
+    for (int p = r; p < HW; p += R) {
+      const float xh = (x[base + (int64_t)p * C] - mu) * rs;
+      const float y = xh * wc + bc, z = y * f1 + f0;
+      const float dz = dout[base + (int64_t)p * C] * (act ? dsilu32(z) : 1.0f);
+      const float dy = dz * f1, dxh = dy * wc;
+      s_dz += dz;
+      s_dzy += dz * y;
+      s_dy += dy;
+      s_dyx += dy * xh;
+      g1 += dxh;
+      g2 += dxh * xh;
+    }
+  const float n = (float)HW * (float)Cg;
+  const float m1 = f32_block_sum(g1, red4) / n;
+  const float m2 = f32_block_sum(g2, red4) / n;
+  if (live)
+    for (int p = r; p < HW; p += R) {
+      const float xh = (x[base + (int64_t)p * C] - mu) * rs;
+      const float y = xh * wc + bc, z = y * f1 + f0;
+      const float dz = dout[base + (int64_t)p * C] * (act ? dsilu32(z) : 1.0f);
+      const float dxh = dz * f1 * wc;
+      dx[base + (int64_t)p * C] = (dres ? dres[base + (int64_t)p * C] : 0.f) + rs * (dxh - m1 - xh * m2);
+    }
+  // per-channel sums over the R pixel lanes, fixed order
+  __syncthreads();
+  if (live) {
+    red[(0 * R + r) * Cg + cl] = s_dz;
+    red[(1 * R + r) * Cg + cl] = s_dzy;
+    red[(2 * R + r) * Cg + cl] = s_dy;
+    red[(3 * R + r) * Cg + cl] = s_dyx;
+  }
+  __syncthreads();
+  if (threadIdx.x < Cg) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int k = 0; k < R; ++k) {
+      a0 += red[(0 * R + k) * Cg + cl];
+      a1 += red[(1 * R + k) * Cg + cl];
+      a2 += red[(2 * R + k) * Cg + cl];
+      a3 += red[(3 * R + k) * Cg + cl];
+    }
+    if (dfs) {
+      dfs[(int64_t)b * ldf + c] = a1;
+      dfh[(int64_t)b * ldf + c] = a0;
+    }
+    dwp[(int64_t)b * C + c] = a3;
+    dbp[(int64_t)b * C + c] = a2;
+  }
+}
+extern "C" int dl_f32_gn_stats(const float* x, float* stats, int64_t B, int64_t HW, int64_t C, int64_t G, float eps, dl_stream_t stream) {
+  DL_CHECK_ARG(x && stats && B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "dl_f32_gn_stats: bad args");
+  hipLaunchKernelGGL(f32_gn_stats_k, (int)(B * G), 256, 0, (hipStream_t)stream, x, stats, (int)HW, (int)C, (int)G, eps);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_f32_gn_apply_fwd(const float* x, const float* stats, const float* w, const float* b, const float* film_scale,
+                                   const float* film_shift, int64_t ld_film, int act_silu, float* out, int64_t B, int64_t HW, int64_t C,
+                                   int64_t G, dl_stream_t stream) {
+  DL_CHECK_ARG(x && stats && w && b && out && B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 &&
+               ((film_scale == nullptr) == (film_shift == nullptr)), "dl_f32_gn_apply_fwd: bad args");
+  hipLaunchKernelGGL(f32_gn_apply_k, grid_1d(B * HW * C, 256, 16384), 256, 0, (hipStream_t)stream, x, stats, w, b, film_scale, film_shift,
+                     ld_film, act_silu, out, (int)B, (int)HW, (int)C, (int)G);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_f32_gn_bwd(const float* dout, const float* x, const float* stats, const float* w, const float* b,
+                             const float* film_scale, const float* film_shift, int64_t ld_film, int act_silu, const float* dres, float* dx,
+                             float* dw_partial, float* db_partial, float* dfilm_scale, float* dfilm_shift, int64_t B, int64_t HW, int64_t C,
+                             int64_t G, dl_stream_t stream) {
+  DL_CHECK_ARG(dout && x && stats && w && b && dx && dw_partial && db_partial && B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 &&
+               C / G <= 256, "dl_f32_gn_bwd: bad args (C / G <= 256)");
+  DL_CHECK_ARG(((film_scale == nullptr) == (film_shift == nullptr)) && ((dfilm_scale == nullptr) == (dfilm_shift == nullptr)) &&
+               (dfilm_scale == nullptr || film_scale != nullptr), "dl_f32_gn_bwd: FiLM operands come in pairs");
+  const int Cg = (int)(C / G), R = 256 / Cg > 0 ? 256 / Cg : 1;
+  hipLaunchKernelGGL(f32_gn_bwd_k, (int)(B * G), 256, 4 * R * Cg * 4, (hipStream_t)stream, dout, x, stats, w, b, film_scale, film_shift,
+                     ld_film, act_silu, dres, dx, dw_partial, db_partial, dfilm_scale, dfilm_shift, (int)HW, (int)C, (int)G);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// 2x2 resampling family on NHWC rows (nn.py:28-88): mode 0 reduce (out[yo, xo] = scale * sum of the 2x2 window of x [2Ho, 2Wo]: avg-pool
+// forward / nearest-upsample backward), 1 expand (out[y, x] = scale * x[y/2, x/2]: nearest upsample / avg-pool backward), 2 pick
+// (out[yo, xo] = x[2yo, 2xo]: the stride-2 sampling of a stride-1 convolution), 3 stuff (its adjoint: zeros except the even pixels)
+__global__ void f32_resample2x2_k(const float* __restrict__ x, float* __restrict__ o, int B, int Hs, int Ws, int C, float scale, int mode) {
+  // Hs, Ws: the SMALL resolution
+  const bool small_out = mode == 0 || mode == 2;
+  const int Ho = small_out ? Hs : 2 * Hs, Wo = small_out ? Ws : 2 * Ws;
+  const int64_t n = (int64_t)B * Ho * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t r = i / C;
+    const int xo = (int)(r % Wo), yo = (int)((r / Wo) % Ho);
+    const int64_t b = r / ((int64_t)Wo * Ho);
+    float v;
+    if (mode == 0) {
+      const int64_t q = ((b * 2 * Hs + 2 * yo) * 2 * Ws + 2 * xo) * (int64_t)C + c;
+      v = scale * ((x[q] + x[q + C]) + (x[q + (int64_t)2 * Ws * C] + x[q + (int64_t)2 * Ws * C + C]));
+    } else if (mode == 1) {
+      v = scale * x[((b * Hs + yo / 2) * Ws + xo / 2) * (int64_t)C + c];
+    } else if (mode == 2) {
+      v = x[((b * 2 * Hs + 2 * yo) * 2 * Ws + 2 * xo) * (int64_t)C + c];
+    } else {
+      v = ((yo | xo) & 1) ? 0.f : x[((b * Hs + yo / 2) * Ws + xo / 2) * (int64_t)C + c];
+    }
+    o[i] = v;
+  }
+}
+extern "C" int dl_f32_resample2x2(const float* x, float* out, int64_t B, int64_t Hs, int64_t Ws, int64_t C, float scale, int mode,
+                                  dl_stream_t stream) {
+  DL_CHECK_ARG(x && out && B > 0 && Hs > 0 && Ws > 0 && C > 0 && mode >= 0 && mode <= 3, "dl_f32_resample2x2: bad args");
+  const int64_t n = B * Hs * Ws * C * ((mode == 0 || mode == 2) ? 1 : 4);
+  hipLaunchKernelGGL(f32_resample2x2_k, grid_1d(n, 256, 16384), 256, 0, (hipStream_t)stream, x, out, (int)B, (int)Hs, (int)Ws, (int)C, scale, mode);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// layout converts at the boundary (unet.py:832): NCHW f32 <-> NHWC rows with leading dimension ld; strided 2-D copy (channel concat /
+// split of the skip connections); additive ResBlock conditioning h + emb_out (unet.py:235-237) and its backward for emb_out
+__global__ void f32_layout_k(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int HW, int64_t ld, int to_nhwc) {
+  const int64_t n = (int64_t)B * C * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (to_nhwc) {  // i indexes the NHWC side (c fastest)
+      const int c = (int)(i % C);
+      const int64_t r = i / C;
+      const int p = (int)(r % HW);
+      const int64_t b = r / HW;
+      dst[r * ld + c] = src[(b * C + c) * HW + p];
+    } else {        // i indexes the NCHW side (p fastest)
+      const int p = (int)(i % HW);
+      const int64_t r = i / HW;
+      const int c = (int)(r % C);
+      const int64_t b = r / C;
+      dst[i] = src[(b * HW + p) * ld + c];
+    }
+  }
+}
+__global__ void f32_copy2d_k(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst, int64_t ldd, int64_t rows, int cols) {
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[(i / cols) * ldd + (i % cols)] = src[(i / cols) * lds_ + (i % cols)];
+}
+__global__ void f32_rowbias_add_k(const float* __restrict__ x, const float* __restrict__ e, int64_t lde, float* __restrict__ o, int B,
+                                  int HW, int C) {
+  const int64_t n = (int64_t)B * HW * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    o[i] = x[i] + e[(i / ((int64_t)HW * C)) * lde + (i % C)];
+}
+// de[b, c] = sum_p dy[b, p, c]: one thread per (b, c), pixels in order (deterministic)
+__global__ void f32_rowbias_bwd_k(const float* __restrict__ dy, float* __restrict__ de, int64_t lde, int B, int HW, int C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * C) return;
+  const int c = (int)(i % C);
+  const int64_t b = i / C;
+  float s = 0.f;
+  for (int p = 0; p < HW; ++p) s += dy[(b * HW + p) * C + c];
+  de[b * lde + c] = s;
+}
+extern "C" int dl_f32_nchw_to_nhwc(const float* x, float* out, int64_t B, int64_t C, int64_t HW, int64_t ld, dl_stream_t stream) {
+  DL_CHECK_ARG(x && out && B > 0 && C > 0 && HW > 0 && ld >= C, "dl_f32_nchw_to_nhwc: bad args");
+  hipLaunchKernelGGL(f32_layout_k, grid_1d(B * C * HW, 256, 16384), 256, 0, (hipStream_t)stream, x, out, (int)B, (int)C, (int)HW, ld, 1);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_f32_nhwc_to_nchw(const float* x, float* out, int64_t B, int64_t C, int64_t HW, int64_t ld, dl_stream_t stream) {
+  DL_CHECK_ARG(x && out && B > 0 && C > 0 && HW > 0 && ld >= C, "dl_f32_nhwc_to_nchw: bad args");
+  hipLaunchKernelGGL(f32_layout_k, grid_1d(B * C * HW, 256, 16384), 256, 0, (hipStream_t)stream, x, out, (int)B, (int)C, (int)HW, ld, 0);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_f32_copy2d(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int64_t cols, dl_stream_t stream) {
+  DL_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= cols, "dl_f32_copy2d: bad args");
+  hipLaunchKernelGGL(f32_copy2d_k, grid_1d(rows * cols, 256, 16384), 256, 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, rows, (int)cols);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_f32_rowbias_add(const float* x, const float* e, int64_t lde, float* out, int64_t B, int64_t HW, int64_t C,
+                                  dl_stream_t stream) {
+  DL_CHECK_ARG(x && e && out && B > 0 && HW > 0 && C > 0 && lde >= C, "dl_f32_rowbias_add: bad args");
+  hipLaunchKernelGGL(f32_rowbias_add_k, grid_1d(B * HW * C, 256, 16384), 256, 0, (hipStream_t)stream, x, e, lde, out, (int)B, (int)HW, (int)C);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_f32_rowbias_bwd(const float* dy, float* de, int64_t lde, int64_t B, int64_t HW, int64_t C, dl_stream_t stream) {
+  DL_CHECK_ARG(dy && de && B > 0 && HW > 0 && C > 0 && lde >= C, "dl_f32_rowbias_bwd: bad args");
+  hipLaunchKernelGGL(f32_rowbias_bwd_k, cdiv(B * C, 256), 256, 0, (hipStream_t)stream, dy, de, lde, (int)B, (int)HW, (int)C);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}

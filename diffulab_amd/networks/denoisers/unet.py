@@ -140,7 +140,13 @@ class UNetModel(FlatArenaDenoiser):
             p.detach().zero_()
         self.out = nn.Sequential(nn.GroupNorm(32, plan.final_ch), nn.SiLU(), conv)
 
+    precisions = ("bf16", "fp32")  # the fp32-class regime: unet_engine_f32.py (round 4)
+
     def _make_engine(self, device: torch.device) -> UNetEngine:
+        if self.precision == "fp32":
+            from ...unet_engine_f32 import UNetEngineF32
+
+            return UNetEngineF32(self.dims, device)
         return UNetEngine(self.dims, device)
 
     # ------------------------------------------------------------------ forward (unet.py:749-853)

@@ -919,6 +919,56 @@ def f32_cond_combine_bwd(dact, emb, idx, demb, dtable):
     _call("dl_f32_cond_combine_bwd", _p(dact), _p(emb), _p(idx), _p(demb), _p(dtable), dact.shape[0], dact.shape[1], _s())
 
 
+# ---- fp32-class regime of the UNet: same call shapes as the bf16 wrappers above (unet_engine_f32.py swaps them in by name)
+def f32_im2col3x3(x, cols, B, H, W, C):
+    _call("dl_f32_im2col3x3", _p(x), x.stride(0), _p(cols), B, H, W, C, _s())
+
+
+def f32_col2im3x3(dcols, dx, B, H, W, C):
+    _call("dl_f32_col2im3x3", _p(dcols), _p(dx), dx.stride(0), B, H, W, C, _s())
+
+
+def f32_gn_stats(x, stats, B, HW, C, G=32, eps=1e-5):
+    _call("dl_f32_gn_stats", _p(x), _p(stats), B, HW, C, G, float(eps), _s())
+
+
+def f32_gn_apply_fwd(x, stats, w, b, film_scale, film_shift, silu, out, B, HW, C, G=32):
+    _call("dl_f32_gn_apply_fwd", _p(x), _p(stats), _p(w), _p(b), _p(film_scale), _p(film_shift),
+          film_scale.stride(0) if film_scale is not None else 0, int(silu), _p(out), B, HW, C, G, _s())
+
+
+def f32_gn_bwd(dout, x, stats, w, b, film_scale, film_shift, silu, dres, dx, dw_partial, db_partial, dfilm_scale, dfilm_shift, B, HW, C,
+               G=32):
+    assert dfilm_scale is None or dfilm_scale.stride(0) == film_scale.stride(0)
+    _call("dl_f32_gn_bwd", _p(dout), _p(x), _p(stats), _p(w), _p(b), _p(film_scale), _p(film_shift),
+          film_scale.stride(0) if film_scale is not None else 0, int(silu), _p(dres), _p(dx), _p(dw_partial), _p(db_partial),
+          _p(dfilm_scale), _p(dfilm_shift), B, HW, C, G, _s())
+
+
+def f32_resample2x2(x, out, B, Hs, Ws, C, scale, mode):
+    _call("dl_f32_resample2x2", _p(x), _p(out), B, Hs, Ws, C, float(scale), mode, _s())
+
+
+def f32_nchw_to_nhwc(x, out, B, C, HW):
+    _call("dl_f32_nchw_to_nhwc", _p(x), _p(out), B, C, HW, out.stride(0), _s())
+
+
+def f32_nhwc_to_nchw(x, out, B, C, HW):
+    _call("dl_f32_nhwc_to_nchw", _p(x), _p(out), B, C, HW, x.stride(0), _s())
+
+
+def f32_copy2d(src, dst, rows, cols):
+    _call("dl_f32_copy2d", _p(src), src.stride(0), _p(dst), dst.stride(0), rows, cols, _s())
+
+
+def f32_rowbias_add(x, e, out, B, HW, C):
+    _call("dl_f32_rowbias_add", _p(x), _p(e), e.stride(0), _p(out), B, HW, C, _s())
+
+
+def f32_rowbias_bwd(dy, de, B, HW, C):
+    _call("dl_f32_rowbias_bwd", _p(dy), _p(de), de.stride(0), B, HW, C, _s())
+
+
 def masked_stream(pattern: str, device) -> "torch.cuda.Stream":
     """torch stream object over a CU-masked HIP stream; pattern "i<k>" enables every k-th CU, "b<n>" the first n CUs"""
     import ctypes

@@ -227,6 +227,7 @@ class UNetEngine:
         self._scratch: dict[str, Tensor] = {}
         self._saved: dict | None = None
         self._zero = torch.zeros(64, device=self.dev, dtype=torch.bfloat16)  # out-of-image taps of the implicit-GEMM convs
+        self.o = ops  # resampling / layout / attention entry points of the block orchestration (the fp32 engine swaps in f32 forms)
         self._build_shadows()
 
     # ------------------------------------------------------------------ parameters
@@ -462,11 +463,11 @@ class UNetEngine:
             H2, W2 = (2 * H, 2 * W) if b.up else (H // 2, W // 2)
             hp, x2 = self._new(B * H2 * W2, b.cin), self._new(B * H2 * W2, b.cin)
             if b.up:
-                ops.expand2x2(h, hp, B, H, W, b.cin, 1.0)
-                ops.expand2x2(x, x2, B, H, W, b.cin, 1.0)
+                self.o.expand2x2(h, hp, B, H, W, b.cin, 1.0)
+                self.o.expand2x2(x, x2, B, H, W, b.cin, 1.0)
             else:
-                ops.reduce2x2(h, hp, B, H2, W2, b.cin, 0.25)
-                ops.reduce2x2(x, x2, B, H2, W2, b.cin, 0.25)
+                self.o.reduce2x2(h, hp, B, H2, W2, b.cin, 0.25)
+                self.o.reduce2x2(x, x2, B, H2, W2, b.cin, 0.25)
             h = hp
         h2 = self._conv3(h, B, H2, W2, b.cin, p + "in_layers.2.weight", b.cout)
         if self.d.use_scale_shift_norm:
@@ -474,7 +475,7 @@ class UNetEngine:
         else:  # h + emb_out in front of the plain GroupNorm -> SiLU (unet.py:235-237)
             film, pre = None, h2
             h2 = self._new(B * H2 * W2, b.cout)
-            ops.rowbias_add(pre, eo[:, b.emb_off : b.emb_off + b.cout], h2, B, H2 * W2, b.cout)
+            self.o.rowbias_add(pre, eo[:, b.emb_off : b.emb_off + b.cout], h2, B, H2 * W2, b.cout)
         h3, st2 = self._gn(h2, B, H2 * W2, b.cout, p + "out_layers.0.", film=film)
         skip = x2 if b.cin == b.cout else self._lin_fwd(x2, p + "skip_connection.weight", b.cout, b.cin)
         out = self._conv3(h3, B, H2, W2, b.cout, p + "out_layers.3.weight", b.cout, resid=skip)  # x + h fused (unet.py:237)
@@ -494,16 +495,16 @@ class UNetEngine:
             dh2 = self._gn_bwd(dh3, h2, st2, B, H2 * W2, b.cout, p + "out_layers.0.", film=film, dfilm=dfilm)
         else:  # h2 is the conv output + emb_out: the GroupNorm gradient is both d(conv output) and, summed over pixels, d(emb_out)
             dh2 = self._gn_bwd(dh3, h2, st2, B, H2 * W2, b.cout, p + "out_layers.0.")
-            ops.rowbias_bwd(dh2, deo[:, o : o + b.cout], B, H2 * W2, b.cout)
+            self.o.rowbias_bwd(dh2, deo[:, o : o + b.cout], B, H2 * W2, b.cout)
         dh = self._conv3_bwd(dh2, h, B, H2, W2, b.cin, p + "in_layers.2.weight", b.cout)
         if b.up or b.down:
             dhp, dxs = self._new(B * H * W, b.cin), self._new(B * H * W, b.cin)
             if b.up:  # backward of nearest upsample: sum of the 2x2 window
-                ops.reduce2x2(dh, dhp, B, H, W, b.cin, 1.0)
-                ops.reduce2x2(dx2, dxs, B, H, W, b.cin, 1.0)
+                self.o.reduce2x2(dh, dhp, B, H, W, b.cin, 1.0)
+                self.o.reduce2x2(dx2, dxs, B, H, W, b.cin, 1.0)
             else:  # backward of avg-pool: broadcast / 4
-                ops.expand2x2(dh, dhp, B, H2, W2, b.cin, 0.25)
-                ops.expand2x2(dx2, dxs, B, H2, W2, b.cin, 0.25)
+                self.o.expand2x2(dh, dhp, B, H2, W2, b.cin, 0.25)
+                self.o.expand2x2(dx2, dxs, B, H2, W2, b.cin, 0.25)
             dh, dx2 = dhp, dxs
         return self._gn_bwd(dh, x, st1, B, H * W, b.cin, p + "in_layers.0.", dres=dx2)
 
@@ -516,14 +517,14 @@ class UNetEngine:
             H2, W2 = H // 2, W // 2
             out = self._new(B * H2 * W2, c)
             if self.d.conv_resample:
-                ops.pick2x2(self._conv3(x, B, H, W, c, name, c), out, B, H2, W2, c)
+                self.o.pick2x2(self._conv3(x, B, H, W, c, name, c), out, B, H2, W2, c)
             else:
-                ops.reduce2x2(x, out, B, H2, W2, c, 0.25)
+                self.o.reduce2x2(x, out, B, H2, W2, c, 0.25)
             xin = x
         else:
             H2, W2 = 2 * H, 2 * W
             xin = self._new(B * H2 * W2, c)
-            ops.expand2x2(x, xin, B, H, W, c, 1.0)
+            self.o.expand2x2(x, xin, B, H, W, c, 1.0)
             out = self._conv3(xin, B, H2, W2, c, name, c) if self.d.conv_resample else xin
         if save is not None:
             save.append((xin if self.d.conv_resample else None, H, W))
@@ -536,13 +537,13 @@ class UNetEngine:
         if b.kind == "down":
             if self.d.conv_resample:
                 dfull = self._new(B * H * W, c)
-                ops.stuff2x2(dout, dfull, B, H // 2, W // 2, c)
+                self.o.stuff2x2(dout, dfull, B, H // 2, W // 2, c)
                 return self._conv3_bwd(dfull, xin, B, H, W, c, name, c)
-            ops.expand2x2(dout, dx, B, H // 2, W // 2, c, 0.25)
+            self.o.expand2x2(dout, dx, B, H // 2, W // 2, c, 0.25)
             return dx
         if self.d.conv_resample:
             dout = self._conv3_bwd(dout, xin, B, 2 * H, 2 * W, c, name, c)
-        ops.reduce2x2(dout, dx, B, H, W, c, 1.0)
+        self.o.reduce2x2(dout, dx, B, H, W, c, 1.0)
         return dx
 
     def _attn_fwd(self, b: _Blk, x: Tensor, B: int, H: int, W: int, save: list | None) -> Tensor:
@@ -554,7 +555,7 @@ class UNetEngine:
         kv = self._lin_fwd(nc, p + "to_kv.weight", 2 * c, c)
         att = self._new(B * n, c)
         probs = self._new(B, nh, n, n, dtype=torch.float32)
-        ops.attn_small_fwd(q, kv[:, :c], kv[:, c:], att, probs, B, n, nh, c // nh)
+        self.o.attn_small_fwd(q, kv[:, :c], kv[:, c:], att, probs, B, n, nh, c // nh)
         out = self._lin_fwd(att, p + "to_out.0.weight", c, c, resid=x)
         if save is not None:
             save.append((x, st, nx, nc, q, kv, att, probs, H, W))
@@ -567,7 +568,7 @@ class UNetEngine:
         n = H * W
         datt = self._lin_bwd(dout, att, p + "to_out.0.weight", c, c)
         dq, dkv = self._new(B * n, c), self._new(B * n, 2 * c)
-        ops.attn_small_bwd(q, kv[:, :c], kv[:, c:], datt, probs, dq, dkv[:, :c], dkv[:, c:], B, n, nh, c // nh)
+        self.o.attn_small_bwd(q, kv[:, :c], kv[:, c:], datt, probs, dq, dkv[:, :c], dkv[:, c:], B, n, nh, c // nh)
         dnx = self._lin_bwd(dq, nx, p + "to_q.weight", c, c)
         dnc = self._lin_bwd(dkv, nc, p + "to_kv.weight", 2 * c, c)
         dx = self._gn_bwd(dnx, x, st, B, n, c, p + "norm_x.", silu=False, dres=dout)
@@ -601,18 +602,12 @@ class UNetEngine:
                 dh = self._attn_bwd(b, dh, B, s)
         return dh
 
-    # ------------------------------------------------------------------ forward (unet.py:832-853)
-    def forward(self, x: Tensor, t: Tensor, y_eff: Tensor | None, train: bool, refresh: bool = True) -> Tensor:
-        """x f32 [B, in_channels, H, W], t f32 [B], y_eff int64 [B] or None -> prediction f32 [B, out_channels, H, W]"""
-        d, plan = self.d, self.plan
-        B, Cin, H, W = x.shape
-        assert (H, W) == tuple(d.image_size) and Cin == d.in_channels
-        if refresh:
-            self.refresh_shadows(force=train)
+    def _cond_fwd(self, t: Tensor, y_eff: Tensor | None, B: int):
+        """emb = time_embed(timestep_embedding(t)) + label_embed(y); returns the stacked FiLM / additive projections of every ResBlock
+        (eo [B, >= emb_rows]) and the tensors the conditioning backward needs"""
+        d = self.d
         mc, te = d.model_channels, 4 * d.model_channels
         Bp = _rup(B, 64)
-        save: list | None = [] if train else None
-
         # conditioning: emb = time_embed(timestep_embedding(t)) + label_embed(y) ; every ResBlock consumes silu(emb)
         temb = self._new(Bp, _rup(mc, 64), zero=True)
         if mc % 64 == 0:
@@ -635,8 +630,24 @@ class UNetEngine:
         eo = self._new(B, _rup(R, 64))  # (additive conditioning: R is a multiple of 32 only; the row stride stays GEMM-aligned)
         ops.gemm_nt(se, self.sh["@emb|f"], eo, bias=self.params[off : off + R], M=B, N=R, K=_rup(te, 64))
 
+        return eo, dict(temb=temb, pre1=pre1, h1=h1, emb=emb, se=se)
+
+    # ------------------------------------------------------------------ forward (unet.py:832-853)
+    def forward(self, x: Tensor, t: Tensor, y_eff: Tensor | None, train: bool, refresh: bool = True) -> Tensor:
+        """x f32 [B, in_channels, H, W], t f32 [B], y_eff int64 [B] or None -> prediction f32 [B, out_channels, H, W]"""
+        d, plan = self.d, self.plan
+        B, Cin, H, W = x.shape
+        assert (H, W) == tuple(d.image_size) and Cin == d.in_channels
+        if refresh:
+            self.refresh_shadows(force=train)
+        mc, te = d.model_channels, 4 * d.model_channels
+        Bp = _rup(B, 64)
+        save: list | None = [] if train else None
+
+        eo, cs = self._cond_fwd(t, y_eff, B)
+
         h = self._new(B * H * W, Cin)
-        ops.nchw_to_nhwc(x, h, B, Cin, H * W)
+        self.o.nchw_to_nhwc(x, h, B, Cin, H * W)
         hs: list[tuple[Tensor, int]] = []
         for grp in plan.input_blocks:
             h, H, W = self._group_fwd(grp, h, B, H, W, eo, save)
@@ -646,17 +657,16 @@ class UNetEngine:
         for grp in plan.output_blocks:
             skip, ich = hs.pop()
             cat = self._new(B * H * W, ch + ich)  # torch.cat([h, hs.pop()], dim=1)
-            ops.copy2d_bf16(h, cat[:, :ch], B * H * W, ch)
-            ops.copy2d_bf16(skip, cat[:, ch:], B * H * W, ich)
+            self.o.copy2d_bf16(h, cat[:, :ch], B * H * W, ch)
+            self.o.copy2d_bf16(skip, cat[:, ch:], B * H * W, ich)
             h, H, W = self._group_fwd(grp, cat, B, H, W, eo, save)
             ch = grp[-1].cout
         hf, stf = self._gn(h, B, H * W, ch, "out.0.")
         o = self._conv3(hf, B, H, W, ch, "out.2.weight", d.out_channels)
         pred = self._new(B, d.out_channels, H, W, dtype=torch.float32)
-        ops.nhwc_to_nchw(o, pred, B, d.out_channels, H * W)
+        self.o.nhwc_to_nchw(o, pred, B, d.out_channels, H * W)
         if train:
-            self._saved = dict(B=B, H=H, W=W, save=save, temb=temb, pre1=pre1, h1=h1, emb=emb, se=se, eo=eo, y=y_eff, h=h,
-                               stf=stf, hf=hf)
+            self._saved = dict(B=B, H=H, W=W, save=save, eo=eo, y=y_eff, h=h, stf=stf, hf=hf, **cs)
         return pred
 
     # ------------------------------------------------------------------ backward
@@ -673,7 +683,7 @@ class UNetEngine:
         deo = self._new(Bp, _rup(R, 64), zero=True)
         co8 = _rup(d.out_channels, 8)
         do = self._new(B * H * W, co8, zero=True)
-        ops.nchw_to_nhwc(dpred, do, B, d.out_channels, H * W)
+        self.o.nchw_to_nhwc(dpred, do, B, d.out_channels, H * W)
         ch0 = plan.final_ch
         dhf = self._conv3_bwd(do, s["hf"], B, H, W, ch0, "out.2.weight", d.out_channels)
         dh = self._gn_bwd(dhf, s["h"], s["stf"], B, H * W, ch0, "out.0.")
@@ -686,8 +696,8 @@ class UNetEngine:
             ich = self._skip_widths[len(dskips)]
             ch = ctot - ich
             dh, dsk = self._new(M, ch), self._new(M, ich)
-            ops.copy2d_bf16(dcat[:, :ch], dh, M, ch)
-            ops.copy2d_bf16(dcat[:, ch:], dsk, M, ich)
+            self.o.copy2d_bf16(dcat[:, :ch], dh, M, ch)
+            self.o.copy2d_bf16(dcat[:, ch:], dsk, M, ich)
             dskips.append(dsk)
         dh = self._group_bwd(plan.middle, dh, B, save, eo, deo)
         for grp in plan.input_blocks[::-1]:
@@ -695,6 +705,18 @@ class UNetEngine:
             dh = self._group_bwd(grp, dh, B, save, eo, deo)
         assert not save and not dskips
 
+        self._cond_bwd(deo, s, B)
+        if self._use_side:
+            torch.cuda.current_stream().wait_stream(self._side_stream())
+        if self.reducer is not None:
+            self.reducer.ready(0, self.layout.size)
+            self.reducer.finish()
+
+    def _cond_bwd(self, deo: Tensor, s: dict, B: int) -> None:
+        d = self.d
+        mc, te = d.model_channels, 4 * d.model_channels
+        Bp = _rup(B, 64)
+        R = self.layout.emb_rows
         # FiLM projections (one stacked GEMM pair), then the conditioning MLP
         w0, b0 = self.layout.entries[self.layout.emb_w0][0], self.layout.entries[self.layout.emb_b0][0]
         ops.gemm_tn(deo, s["se"], self.grads[w0 : w0 + R * te].view(R, te), M=R)
@@ -713,11 +735,6 @@ class UNetEngine:
         ops.silu_bwd(dh1, s["pre1"][:B], dpre1[:B])
         ops.gemm_tn(dpre1, s["temb"], self.Gr("time_embed.0.weight"), M=te, N=mc)
         ops.colsum(dpre1, self.Gr("time_embed.0.bias"), B, te)
-        if self._use_side:
-            torch.cuda.current_stream().wait_stream(self._side_stream())
-        if self.reducer is not None:
-            self.reducer.ready(0, self.layout.size)
-            self.reducer.finish()
 
     @property
     def _skip_widths(self) -> list[int]:

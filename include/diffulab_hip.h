@@ -607,6 +607,39 @@ DL_API int dl_f32_cond_combine_fwd(const float* e, const float* table, const int
 DL_API int dl_f32_cond_combine_bwd(const float* dact, const float* emb, const int64_t* idx, float* demb, float* dtable, int64_t B,
                                    int64_t E, dl_stream_t stream);
 
+/* ---- fp32-class regime of the UNet (networks/denoisers/unet.py, networks/utils/nn.py:11-88): NHWC f32 rows [B*H*W, C].
+ * A 3x3 / pad-1 convolution (unet.py:187,208,594,745) = dl_f32_im2col3x3 + dl_f32_gemm against the weight in its native [Co, Ci*9]
+ * layout: cols[p, ci*9 + ky*3 + kx] = x[p + (ky-1, kx-1), ci] (zero outside the image); data gradient = dl_f32_gemm(dY, W) into dcols
+ * + dl_f32_col2im3x3 (the adjoint gather, one writer per element); weight gradient = dl_f32_gemm(dY^T cols), accumulated. */
+DL_API int dl_f32_im2col3x3(const float* x, int64_t ldx, float* cols, int64_t B, int64_t H, int64_t W, int64_t C, dl_stream_t stream);
+DL_API int dl_f32_col2im3x3(const float* dcols, float* dx, int64_t ld_dx, int64_t B, int64_t H, int64_t W, int64_t C,
+                            dl_stream_t stream);
+/* GroupNorm32 (nn.py:11-13) in f32: statistics per (sample, group) f32 [B, G, 2] = mean, rstd (two passes, as the reference);
+ * out = act((xhat w + b)(1 + film_scale[b, c]) + film_shift[b, c]) (unet.py:215-237; film NULL: plain GroupNorm, unet.py:296-322);
+ * backward: dx = dres + gradient through the norm, dfilm_scale / dfilm_shift [B, ld_film] written, dw_partial / db_partial [B, C]
+ * per-sample partials WRITTEN (the caller folds them in a fixed order: dl_reduce_rows_batched_f32) -- no atomics */
+DL_API int dl_f32_gn_stats(const float* x, float* stats, int64_t B, int64_t HW, int64_t C, int64_t G, float eps, dl_stream_t stream);
+DL_API int dl_f32_gn_apply_fwd(const float* x, const float* stats, const float* w, const float* b, const float* film_scale,
+                               const float* film_shift, int64_t ld_film, int act_silu, float* out, int64_t B, int64_t HW, int64_t C,
+                               int64_t G, dl_stream_t stream);
+DL_API int dl_f32_gn_bwd(const float* dout, const float* x, const float* stats, const float* w, const float* b,
+                         const float* film_scale, const float* film_shift, int64_t ld_film, int act_silu, const float* dres, float* dx,
+                         float* dw_partial, float* db_partial, float* dfilm_scale, float* dfilm_shift, int64_t B, int64_t HW, int64_t C,
+                         int64_t G, dl_stream_t stream);
+/* 2x2 resampling (nn.py:28-88) at the SMALL resolution Hs x Ws: mode 0 reduce (scale * sum of the 2x2 window: avg-pool forward 0.25 /
+ * nearest-upsample backward 1), 1 expand (scale * x[y/2, x/2]), 2 pick (x[2y, 2x]: stride-2 sampling of a stride-1 conv, nn.py:79),
+ * 3 stuff (adjoint of pick) */
+DL_API int dl_f32_resample2x2(const float* x, float* out, int64_t B, int64_t Hs, int64_t Ws, int64_t C, float scale, int mode,
+                              dl_stream_t stream);
+/* boundary layout converts (unet.py:832), strided 2-D copy (torch.cat / split of the skip connections, unet.py:846-851), additive
+ * ResBlock conditioning h + emb_out (unet.py:235-237) and its per-sample pixel sum */
+DL_API int dl_f32_nchw_to_nhwc(const float* x, float* out, int64_t B, int64_t C, int64_t HW, int64_t ld, dl_stream_t stream);
+DL_API int dl_f32_nhwc_to_nchw(const float* x, float* out, int64_t B, int64_t C, int64_t HW, int64_t ld, dl_stream_t stream);
+DL_API int dl_f32_copy2d(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int64_t cols, dl_stream_t stream);
+DL_API int dl_f32_rowbias_add(const float* x, const float* e, int64_t lde, float* out, int64_t B, int64_t HW, int64_t C,
+                              dl_stream_t stream);
+DL_API int dl_f32_rowbias_bwd(const float* dy, float* de, int64_t lde, int64_t B, int64_t HW, int64_t C, dl_stream_t stream);
+
 /* ------------------------------------------------------------------ fused block driver */
 /* One adaLN-zero DiT block (DiTBlock._forward mmdit.py:288-309, DiTAttention mmdit.py:75-104, MLP mmdit.py:260-264) as ONE call
  * per direction: the library issues the block's launch sequence itself (csrc/block.hip) -- the SURVEY section 8b "fused driver".
