@@ -34,14 +34,17 @@ def _announced_everything(rec, size):
 
 
 @pytest.mark.timeout(900)
-def test_unet_at_config1_dims_b64_learns_and_announces_the_arena():
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_unet_at_config1_dims_b64_learns_and_announces_the_arena(precision):
+    """precision "fp32" = the reference's default `precision_type="no"`, which configuration 1 inherits (unet_engine_f32.py); the two
+    regimes start from the same parameters and see the same batch: their first losses agree to what bf16 allows"""
     from diffulab_amd import Diffuser
     from diffulab_amd.config import instantiate, load_config
     from diffulab_amd.training import FusedAdamW
 
     torch.manual_seed(0)
     cfg = load_config(os.path.join(ROOT, "configs"), "train_mnist_ddpm")
-    m = instantiate(cfg.model).to(DEV)
+    m = instantiate(cfg.model).set_precision(precision).to(DEV)
     assert sum(p.numel() for p in m.parameters()) == 276_690_433  # SURVEY Appendix B: UNet MNIST
     d = Diffuser(m, sampling_method="ddpm", model_type="gaussian_diffusion", n_steps=1000)
     opt = FusedAdamW(m.parameters(), lr=1e-4, weight_decay=0.01)
