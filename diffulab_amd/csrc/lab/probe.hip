@@ -214,15 +214,19 @@ extern "C" int dl_probe_dma(int kb, const void* A, const void* Bw, int64_t M, in
 // 128 bytes (the weight rows are the same rows_b rows for every tile: L2-resident) into an `nslot`-deep ring; nothing is computed.
 // grid = 256 * wgs_per_cu.  What the asymmetric-issue experiment suggested: the stream's rate follows the number of issuing waves.
 __global__ void dma_probe2_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bw, int M, int K, int rows_a, int rows_b,
-                             int nslot, float* __restrict__ out) {
+                             int nslot, float* __restrict__ out, int rot) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
   const int rows = rows_a + rows_b, stage = rows * 128, nch = rows / 8;
   const int nk = K / 64, ntiles = M / rows_a;
   int it = 0;
+  // rot > 0: workgroup w of an XCD walks the k-steps from k-step (rot * w) % nk on -- the 32 workgroups of an XCD then read
+  // DIFFERENT lines of the shared weight panel at any moment instead of the same ones (L2 channel hot spot?)
+  const int k0 = (rot * (int)(blockIdx.x >> 3)) % nk;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    for (int kt = 0; kt < nk; ++kt, ++it) {
+    for (int kq = 0; kq < nk; ++kq, ++it) {
+      const int kt = (kq + k0) % nk;
       char* base = smem + (it % nslot) * stage;
       for (int c = wave; c < nch; c += nwaves) {
         const int row = c * 8 + (lane >> 3);
@@ -242,15 +246,83 @@ __global__ void dma_probe2_k(const bf16_t* __restrict__ A, const bf16_t* __restr
   __syncthreads();
   out[(blockIdx.x * blockDim.x + threadIdx.x) & (256 * 512 - 1)] = ((float*)smem)[threadIdx.x];
 }
-extern "C" int dl_probe_dma2(int wgs_per_cu, int threads, int rows_a, int rows_b, int nslot, const void* A, const void* Bw, int64_t M,
-                             int64_t K, float* out, dl_stream_t stream) {
+static int probe_dma2(int wgs_per_cu, int threads, int rows_a, int rows_b, int nslot, int rot, const void* A, const void* Bw, int64_t M,
+                      int64_t K, float* out, dl_stream_t stream) {
   DL_CHECK_ARG(A && Bw && out && wgs_per_cu >= 1 && threads % 64 == 0 && threads <= 1024 && rows_a % 8 == 0 && rows_b % 8 == 0 &&
                nslot >= 1 && M % rows_a == 0 && K % 64 == 0, "dl_probe_dma2: bad args");
   const int lds = (rows_a + rows_b) * 128 * nslot;
   DL_CHECK_ARG(lds <= 163840 / wgs_per_cu, "dl_probe_dma2: %d bytes of LDS per workgroup do not fit %d times", lds, wgs_per_cu);
   (void)hipFuncSetAttribute((const void*)dma_probe2_k, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
   hipLaunchKernelGGL(dma_probe2_k, 256 * wgs_per_cu, threads, lds, (hipStream_t)stream, (const bf16_t*)A, (const bf16_t*)Bw, (int)M, (int)K,
-                     rows_a, rows_b, nslot, out);
+                     rows_a, rows_b, nslot, out, rot);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_probe_dma2(int wgs_per_cu, int threads, int rows_a, int rows_b, int nslot, const void* A, const void* Bw, int64_t M,
+                             int64_t K, float* out, dl_stream_t stream) {
+  return probe_dma2(wgs_per_cu, threads, rows_a, rows_b, nslot, 0, A, Bw, M, K, out, stream);
+}
+extern "C" int dl_probe_dma2_rot(int wgs_per_cu, int threads, int rows_a, int rows_b, int nslot, int rot, const void* A, const void* Bw,
+                                 int64_t M, int64_t K, float* out, dl_stream_t stream) {
+  DL_CHECK_ARG(rot >= 0, "dl_probe_dma2_rot: rot < 0");
+  return probe_dma2(wgs_per_cu, threads, rows_a, rows_b, nslot, rot, A, Bw, M, K, out, stream);
+}
+
+// The same 256 + 384-row tile walk with PLAIN loads into registers (nothing goes to the LDS): is the L2 -> CU path itself faster than
+// the direct-to-LDS form?  PAT 0: the DMA's address pattern (8 rows x 128 B per wave instruction); PAT 1: the MFMA fragment pattern
+// (32 rows x 32 B per wave instruction: lane l reads row l & 31, 16 bytes at 16 (2 kk + (l >> 5))), i.e. what a kernel that feeds
+// one operand straight from L1 / L2 would issue.  DEPTH stages' loads are issued before the oldest stage's registers are consumed.
+template <int PAT, int DEPTH>
+__global__ __launch_bounds__(512, 2) void ld_probe_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bw, int M, int K,
+                                                     float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nk = K / 64, ntiles = M / 256;
+  u32x4_t acc = {0u, 0u, 0u, 0u};
+  u32x4_t ring[DEPTH][10];
+  int it = 0;
+  const int total = ((ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * nk;
+  auto issue = [&](int s, u32x4_t (&dst)[10]) {
+    s = s < total ? s : s - total;  // (the run-ahead of the last stages wraps: every load stays in bounds, no branch in the loop)
+    const int tile = blockIdx.x + (s / nk) * gridDim.x, kt = s % nk;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int c = wave * 10 + i;  // 80 chunks of 1 KiB: 32 of the activation tile, 48 of the weight panel
+      int row, piece;
+      if (PAT == 0) {
+        row = c * 8 + (lane >> 3);
+        piece = lane & 7;
+      } else {
+        row = (c >> 2) * 32 + (lane & 31);
+        piece = 2 * (c & 3) + (lane >> 5);
+      }
+      const bf16_t* src = row < 256 ? A + (int64_t)(tile * 256 + row) * K : Bw + (int64_t)(row - 256) * K;
+      dst[i] = *(const u32x4_t*)(src + kt * 64 + piece * 8);
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH - 1; ++d) issue(d, ring[d]);
+  for (it = 0; it < total; it += DEPTH) {  // total % DEPTH == 0 (checked by the host)
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      issue(it + d + DEPTH - 1, ring[(d + DEPTH - 1) % DEPTH]);
+      __builtin_amdgcn_sched_barrier(0);  // (the scheduler would otherwise sink the loads to their uses)
+#pragma unroll
+      for (int i = 0; i < 10; ++i) acc ^= ring[d][i];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  out[(blockIdx.x * blockDim.x + threadIdx.x) & (256 * 512 - 1)] = __uint_as_float(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]);
+}
+extern "C" int dl_probe_ld(int pattern, int depth, const void* A, const void* Bw, int64_t M, int64_t K, float* out, dl_stream_t stream) {
+  DL_CHECK_ARG(A && Bw && out && M % 256 == 0 && K % 64 == 0 && (pattern == 0 || pattern == 1) && (depth == 2 || depth == 3) &&
+               ((M / 256 + 255) / 256 * (K / 64)) % depth == 0 && (M / 256) % 256 == 0, "dl_probe_ld: bad args");
+#define GO(P, D) hipLaunchKernelGGL((ld_probe_k<P, D>), 256, 512, 0, (hipStream_t)stream, (const bf16_t*)A, (const bf16_t*)Bw, (int)M, (int)K, out)
+  if (pattern == 0 && depth == 2) GO(0, 2);
+  else if (pattern == 0) GO(0, 3);
+  else if (depth == 2) GO(1, 2);
+  else GO(1, 3);
+#undef GO
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

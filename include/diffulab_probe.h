@@ -37,6 +37,14 @@ DL_API int dl_probe_dma(int kb, const void* A, const void* Bw, int64_t M, int64_
  * L2 -> LDS operand rate of a CU scales with the number of resident / issuing waves.  out: >= 256*512 floats */
 DL_API int dl_probe_dma2(int wgs_per_cu, int threads, int rows_a, int rows_b, int nslot, const void* A, const void* Bw, int64_t M,
                          int64_t K, float* out, dl_stream_t stream);
+/* dl_probe_dma2 with the k-steps of workgroup w of an XCD rotated by (rot * w) % (K / 64): the workgroups of an XCD then read different
+ * lines of the shared weight panel at any moment (is the operand stream bound by a hot L2 channel?) */
+DL_API int dl_probe_dma2_rot(int wgs_per_cu, int threads, int rows_a, int rows_b, int nslot, int rot, const void* A, const void* Bw,
+                             int64_t M, int64_t K, float* out, dl_stream_t stream);
+/* the 256 + 384-row tile walk of dl_probe_dma with PLAIN 16-byte loads into registers instead of direct-to-LDS loads (nothing is
+ * written to the LDS): pattern 0 = the DMA's addresses (8 rows x 128 B per wave instruction), 1 = the MFMA fragment pattern (32 rows x
+ * 32 B); depth = stages of loads in flight per wave (2 | 3).  Is the L2 -> CU path faster than its direct-to-LDS form? */
+DL_API int dl_probe_ld(int pattern, int depth, const void* A, const void* Bw, int64_t M, int64_t K, float* out, dl_stream_t stream);
 /* `n_wgs` workgroups of `threads` threads that do nothing but hold their CU slots for `usec` microseconds (wall clock): a stand-in
  * for a communication kernel (RCCL's channel workgroups) beside the compute stream, to measure what co-residency costs the
  * one-workgroup-per-CU kernels (scripts/lab/occupied_cus.py). */
