@@ -519,6 +519,12 @@ def main() -> None:
 
     for _ in range(args.warmup):
         step()
+    extra_warmup = 0
+    while world > 1 and reducer.tuning and extra_warmup < 32:
+        # the reducer measures its two schedules on the first 14 steps (training/dp.py): with a shorter --warmup the decision would fall
+        # into the timed region, so the untimed part is extended until it is taken (same count on every rank)
+        step()
+        extra_warmup += 1
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -544,8 +550,9 @@ def main() -> None:
         dp = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "grad_bytes_per_step": model._flat_grad.numel() * 4,
               "exposed_allreduce_ms_per_step": None if tail is None else round(tail, 3),
               # how the exchange was scheduled in the timed region: decided by measurement during warm-up steps 2-13 (training/dp.py)
-              "exchange": reducer.tuned or {"mode": "overlapped" if reducer.overlap else "after_backward", "decided": "not tuned (fewer "
-                                            "than 14 warm-up steps or DIFFULAB_DP_OVERLAP pinned)"}}
+              "exchange": reducer.tuned or {"mode": "overlapped" if reducer.overlap else "after_backward",
+                                            "decided": "DIFFULAB_DP_OVERLAP pinned"},
+              "untimed_steps_before_timing": args.warmup + extra_warmup}
 
     roof = None
     if rank == 0 and not args.no_roofline:

@@ -154,6 +154,11 @@ class GradReducer:
 
     TUNE_SKIP, TUNE_STEPS, TUNE_MARGIN = 2, 6, 1.03
 
+    @property
+    def tuning(self) -> bool:
+        """True while the schedule decision is still being measured (the first TUNE_SKIP + 2 TUNE_STEPS synchronising steps)"""
+        return self._tune is not None
+
     def _tune_begin(self) -> None:
         """first ready() of a synchronising step: the start mark of the interval the decision is taken on -- from the first final
         gradient range to the end of finish(), i.e. the part of the step the exchange can influence.  Dataloader stalls, loss

@@ -43,12 +43,13 @@ if N <= 256:  # V / dV in place inside token-major qkv / dqkv rows
     us = timeit(lambda: ops.attn_bwd_qkv(q, k, qkv, out, do, lse, dq, dk, dqkv, B, H, N, dh, scale))
     print(f"attn_bwd_qkv N={N}: {us:7.1f} us")
 
-if N >= 512:  # long joint sequences: the fp8 MFMA forward (quantisation pre-pass timed separately) against the bf16 kernel
-    q8, k8 = torch.empty(B, H, N, dh, device=dev, dtype=torch.uint8), torch.empty(B, H, N, dh, device=dev, dtype=torch.uint8)
-    v8t, sc = torch.empty(B, H, dh, N, device=dev, dtype=torch.uint8), torch.empty(B, H, 3, device=dev)
-    us_q = timeit(lambda: ops.attn_fp8_quantize(q, k, v, q8, k8, v8t, sc, B, H, N, N))
-    us_f = timeit(lambda: ops.attn_fwd_fp8(q8, k8, v8t, sc, out, lse, B, H, N, N, dh, scale))
-    us_b = timeit(lambda: ops.attn_fwd_ex(q, k, v, out, lse, B, H, N, N, dh, scale))
-    print(f"attn_fwd_ex  bf16 N={N}: {us_b:7.1f} us  {fl / us_b / 1e6:6.1f} TFLOP/s")
-    print(f"attn_fwd_fp8      N={N}: {us_f:7.1f} us  {fl / us_f / 1e6:6.1f} TFLOP/s ({fl / us_f / 1e6 / 5000:.3f} of the 5 PF fp8 peak)"
-          f"  + quantise {us_q:6.1f} us  -> {fl / (us_f + us_q) / 1e6:6.1f} TFLOP/s end to end")
+if N <= 256:  # the training step's pair: QK-norm + RoPE on load (forward), token-major dQ / dK / dV (backward)
+    from diffulab_amd.engine import rope_grid_tables
+    D = H * dh
+    ssq = (torch.rand(B * N, 2, device=dev) + 0.5) * D
+    sq, sk = torch.ones(D, device=dev), torch.ones(D, device=dev)
+    side = int(N ** 0.5)
+    cos, sin = (z.to(dev) for z in rope_grid_tables(side, side, [32, 32], 10_000.0))
+    rr = torch.empty(B * N, 2, device=dev)
+    us = timeit(lambda: ops.attn_fwd_qkn(qkv, ssq, sq, sk, cos, sin, q, k, rr, out, lse, B, H, N, dh, 64, scale))
+    print(f"attn_fwd_qkn N={N}: {us:7.1f} us")
