@@ -496,12 +496,12 @@ __global__ __launch_bounds__(256) void f32_qk_norm_rope_fwd_k(const float* __res
                                                               const float* __restrict__ sk, const float* __restrict__ cs,
                                                               const float* __restrict__ sn, float* __restrict__ qk,
                                                               float* __restrict__ rrms, int64_t M, int N, int D, int dh, int rot,
-                                                              float eps) {
+                                                              float eps, const int* __restrict__ pos) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D4 = D >> 2, half = rot >> 1;
   const float invD = 1.0f / (float)D;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
-    const int n = (int)(row % N);
+    const int n = pos ? pos[row] : (int)(row % N);  // rotary table row of this token
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
       f32x4_t v[FR_NJ], sc[FR_NJ], sqv[FR_NJ];
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) void f32_qk_norm_rope_fwd_k(const float* __res
 
 extern "C" int dl_f32_qk_norm_rope_fwd(const float* qkv, int64_t ld, const float* scale_q, const float* scale_k, const float* cos,
                                        const float* sin, float* qk, float* rrms, int64_t B, int64_t N, int64_t H, int64_t dh,
-                                       int64_t rot, float eps, dl_stream_t stream) {
+                                       int64_t rot, float eps, const int32_t* pos, dl_stream_t stream) {
   const int64_t D = H * dh, M = B * N;
   DL_CHECK_ARG(qkv && scale_q && scale_k && qk && rrms && M > 0, "dl_f32_qk_norm_rope_fwd: null operand");
   DL_CHECK_ARG(rot == 0 || (cos && sin), "dl_f32_qk_norm_rope_fwd: rot > 0 needs the cos / sin tables");
@@ -544,7 +544,7 @@ extern "C" int dl_f32_qk_norm_rope_fwd(const float* qkv, int64_t ld, const float
   DL_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)qk | (uintptr_t)scale_q | (uintptr_t)scale_k) & 15) == 0,
                "dl_f32_qk_norm_rope_fwd: 16-byte alignment");
   hipLaunchKernelGGL(f32_qk_norm_rope_fwd_k, grid_1d(M, 4), 256, 0, (hipStream_t)stream, qkv, ld, scale_q, scale_k, cos, sin, qk, rrms, M,
-                     (int)N, (int)D, (int)dh, (int)rot, eps);
+                     (int)N, (int)D, (int)dh, (int)rot, eps, pos);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
@@ -556,7 +556,8 @@ __global__ __launch_bounds__(256) void f32_qk_norm_rope_bwd_k(const float* __res
                                                               const float* __restrict__ sq, const float* __restrict__ sk,
                                                               const float* __restrict__ cs, const float* __restrict__ sn,
                                                               const float* __restrict__ rrms, float* __restrict__ dqkv, int64_t ld_d,
-                                                              float* __restrict__ dscale_part, int N, int D, int dh, int rot) {
+                                                              float* __restrict__ dscale_part, int N, int D, int dh, int rot,
+                                                              const int* __restrict__ pos) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = (float*)smem;  // [4 waves][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -570,6 +571,7 @@ __global__ __launch_bounds__(256) void f32_qk_norm_rope_bwd_k(const float* __res
     for (int j = 0; j < FR_NJ; ++j) acc[p][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   for (int n = wave; n < N; n += 4) {
     const int64_t row = b * N + n;
+    const int tr = pos ? pos[row] : n;  // rotary table row of this token
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
       f32x4_t g[FR_NJ], x[FR_NJ], sc[FR_NJ], gx[FR_NJ], pr[FR_NJ];
@@ -583,8 +585,8 @@ __global__ __launch_bounds__(256) void f32_qk_norm_rope_bwd_k(const float* __res
         const int d0 = (4 * c) % dh;
         if (c < D4 && d0 < rot) {  // transpose of the rotation
           const int p0 = d0 >> 1;
-          const float c0 = cs[(int64_t)n * half + p0], s0 = sn[(int64_t)n * half + p0];
-          const float c1 = cs[(int64_t)n * half + p0 + 1], s1 = sn[(int64_t)n * half + p0 + 1];
+          const float c0 = cs[(int64_t)tr * half + p0], s0 = sn[(int64_t)tr * half + p0];
+          const float c1 = cs[(int64_t)tr * half + p0 + 1], s1 = sn[(int64_t)tr * half + p0 + 1];
           const float a0 = g[j][0], b0 = g[j][1], a1 = g[j][2], b1 = g[j][3];
           g[j][0] = a0 * c0 + b0 * s0;
           g[j][1] = -a0 * s0 + b0 * c0;
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(256) void f32_qk_norm_rope_bwd_k(const float* __res
 extern "C" int dl_f32_qk_norm_rope_bwd(const float* dqk, const float* qkv, int64_t ld, const float* scale_q, const float* scale_k,
                                        const float* cos, const float* sin, const float* rrms, float* dqkv, int64_t ld_d,
                                        float* dscale_partials, int64_t B, int64_t N, int64_t H, int64_t dh, int64_t rot,
-                                       dl_stream_t stream) {
+                                       const int32_t* pos, dl_stream_t stream) {
   const int64_t D = H * dh;
   DL_CHECK_ARG(dqk && qkv && scale_q && scale_k && rrms && dqkv && dscale_partials && B > 0 && N > 0, "dl_f32_qk_norm_rope_bwd: null operand");
   DL_CHECK_ARG(rot == 0 || (cos && sin), "dl_f32_qk_norm_rope_bwd: rot > 0 needs the cos / sin tables");
@@ -627,7 +629,137 @@ extern "C" int dl_f32_qk_norm_rope_bwd(const float* dqk, const float* qkv, int64
   DL_CHECK_ARG((((uintptr_t)dqk | (uintptr_t)qkv | (uintptr_t)dqkv | (uintptr_t)scale_q | (uintptr_t)scale_k) & 15) == 0,
                "dl_f32_qk_norm_rope_bwd: 16-byte alignment");
   hipLaunchKernelGGL(f32_qk_norm_rope_bwd_k, (int)B, 256, 4 * 2 * (int)D * 4, (hipStream_t)stream, dqk, qkv, ld, scale_q, scale_k, cos, sin,
-                     rrms, dqkv, ld_d, dscale_partials, (int)N, (int)D, (int)dh, (int)rot);
+                     rrms, dqkv, ld_d, dscale_partials, (int)N, (int)D, (int)dh, (int)rot, pos);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+// ============================================================================================================ SPRINT token routing
+// f32 forms of csrc/tokens.hip (sprint.py:317-387).  The gather needs none: rows are copied bytewise, dl_gather_tokens on 2 D "bf16"
+// columns is the f32 gather.  Every sum has one producer (no atomics): partial images are folded by the caller in a fixed order.
+// dst[b, idx[b, j], :] += src[b, j, :]
+__global__ void f32_scatter_tokens_add_k(const float* __restrict__ src, int64_t ld_src, const int* __restrict__ idx, float* __restrict__ dst,
+                                         int64_t ld_dst, int N, int k, int D4, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D4);
+    const int64_t row = i / D4, b = row / k;
+    float* p = dst + (b * N + idx[row]) * ld_dst + 4 * c;
+    *(f32x4_t*)p = *(const f32x4_t*)p + *(const f32x4_t*)(src + row * ld_src + 4 * c);
+  }
+}
+// out[b, n, :] = inv[b, n] >= 0 ? xd[b, inv[b, n], :] : mask[:]
+__global__ void f32_restore_tokens_k(const float* __restrict__ xd, int64_t ld_xd, const int* __restrict__ inv, const float* __restrict__ mask,
+                                     float* __restrict__ out, int64_t ld_out, int N, int k, int D4, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D4);
+    const int64_t row = i / D4, b = row / N;
+    const int j = inv[row];
+    *(f32x4_t*)(out + row * ld_out + 4 * c) = j >= 0 ? *(const f32x4_t*)(xd + (b * k + j) * ld_xd + 4 * c) : *(const f32x4_t*)(mask + 4 * c);
+  }
+}
+// part[slab, c] = sum over the slab's rows with sel[row] < 0 of x[row, c], rows taken in order by four row lanes (fixed combination)
+__global__ void f32_masked_colsum_part_k(const float* __restrict__ x, int64_t ld, const int* __restrict__ sel, float* __restrict__ part,
+                                         int64_t R, int C, int rows_per_slab) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_slab;
+  const int64_t r1 = r0 + rows_per_slab < R ? r0 + rows_per_slab : R;
+  float acc = 0.f;
+  if (c < C)
+    for (int64_t r = r0 + rl; r < r1; r += 4)
+      if (sel[r] < 0) acc += x[r * ld + c];
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < C) part[(int64_t)blockIdx.y * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+// out[m, :] = x[m, :] + gate[m / rows_per_mod, :] * t[m, :]
+__global__ void f32_gated_residual_k(const float* __restrict__ x, const float* __restrict__ t, const float* __restrict__ gate,
+                                     int64_t ld_gate, int64_t rows_per_mod, float* __restrict__ out, int64_t ld_out, int D4, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D4);
+    const int64_t row = i / D4;
+    const f32x4_t g = *(const f32x4_t*)(gate + (row / rows_per_mod) * ld_gate + 4 * c);
+    *(f32x4_t*)(out + row * ld_out + 4 * c) = *(const f32x4_t*)(x + row * D4 * 4 + 4 * c) + g * *(const f32x4_t*)(t + row * D4 * 4 + 4 * c);
+  }
+}
+// backward of the gated residual: dt[m, :] = gate[g, :] dout[m, :]; dgate[g, :] = sum_{m in g} dout[m, :] t[m, :] (written).  One
+// workgroup per modulation group, eight row lanes, fixed-order combination.
+__global__ __launch_bounds__(512) void f32_gate_bwd_k(const float* __restrict__ dout, const float* __restrict__ t, const float* __restrict__ gate,
+                                                      int64_t ld_gate, int64_t rows_per_mod, float* __restrict__ dt, float* __restrict__ dgate,
+                                                      int64_t ld_dgate, int D) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = (float*)smem;  // [8][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D4 = D >> 2;
+  const int64_t grp = blockIdx.x;
+  f32x4_t gv[FR_NJ], acc[FR_NJ];
+  fr_load(gate + grp * ld_gate, D4, lane, gv, 0.f);
+#pragma unroll
+  for (int j = 0; j < FR_NJ; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = wave; r < rows_per_mod; r += 8) {
+    const int64_t row = grp * rows_per_mod + r;
+    f32x4_t dv[FR_NJ], tv[FR_NJ];
+    fr_load(dout + row * D, D4, lane, dv, 0.f);
+    fr_load(t + row * D, D4, lane, tv, 0.f);
+#pragma unroll
+    for (int j = 0; j < FR_NJ; ++j) {
+      acc[j] += dv[j] * tv[j];
+      dv[j] = dv[j] * gv[j];
+    }
+    fr_store(dt + row * D, D4, lane, dv);
+  }
+  fr_store(red + wave * D, D4, lane, acc);
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 512)
+    dgate[grp * ld_dgate + c] = ((red[c] + red[D + c]) + (red[2 * D + c] + red[3 * D + c])) +
+                                ((red[4 * D + c] + red[5 * D + c]) + (red[6 * D + c] + red[7 * D + c]));
+}
+#define F32_AL16(p) ((((uintptr_t)(p)) & 15) == 0)
+extern "C" int dl_f32_scatter_tokens_add(const float* src, int64_t ld_src, const int32_t* idx, float* dst, int64_t ld_dst, int64_t B,
+                                         int64_t N, int64_t k, int64_t D, dl_stream_t stream) {
+  DL_CHECK_ARG(src && idx && dst && B > 0 && N > 0 && k > 0 && D > 0 && D % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && ld_src >= D &&
+               ld_dst >= D && F32_AL16(src) && F32_AL16(dst), "dl_f32_scatter_tokens_add: bad args");
+  const int64_t total = B * k * (D / 4);
+  hipLaunchKernelGGL(f32_scatter_tokens_add_k, grid_1d(total), 256, 0, (hipStream_t)stream, src, ld_src, idx, dst, ld_dst, (int)N, (int)k,
+                     (int)(D / 4), total);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_f32_restore_tokens(const float* xd, int64_t ld_xd, const int32_t* inv, const float* mask, float* out, int64_t ld_out,
+                                     int64_t B, int64_t N, int64_t k, int64_t D, dl_stream_t stream) {
+  DL_CHECK_ARG(xd && inv && mask && out && B > 0 && N > 0 && k > 0 && D > 0 && D % 4 == 0 && ld_xd % 4 == 0 && ld_out % 4 == 0 &&
+               ld_xd >= D && ld_out >= D && F32_AL16(xd) && F32_AL16(out) && F32_AL16(mask), "dl_f32_restore_tokens: bad args");
+  const int64_t total = B * N * (D / 4);
+  hipLaunchKernelGGL(f32_restore_tokens_k, grid_1d(total), 256, 0, (hipStream_t)stream, xd, ld_xd, inv, mask, out, ld_out, (int)N, (int)k,
+                     (int)(D / 4), total);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_f32_masked_colsum_partials(const float* x, int64_t ld, const int32_t* sel, float* partials, int64_t slabs, int64_t R,
+                                             int64_t C, dl_stream_t stream) {
+  DL_CHECK_ARG(x && sel && partials && R > 0 && C > 0 && ld >= C && slabs >= 1 && slabs <= 65535, "dl_f32_masked_colsum_partials: bad args");
+  const int rps = (int)((R + slabs - 1) / slabs);
+  hipLaunchKernelGGL(f32_masked_colsum_part_k, dim3(cdiv(C, 64), (int)slabs), 256, 0, (hipStream_t)stream, x, ld, sel, partials, R, (int)C, rps);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_f32_gated_residual_fwd(const float* x, const float* t, const float* gate, int64_t ld_gate, int64_t rows_per_mod,
+                                         float* out, int64_t ld_out, int64_t M, int64_t D, dl_stream_t stream) {
+  DL_CHECK_ARG(x && t && gate && out && M > 0 && D > 0 && D % 4 == 0 && ld_gate % 4 == 0 && ld_out % 4 == 0 && ld_out >= D &&
+               rows_per_mod > 0 && F32_AL16(x) && F32_AL16(t) && F32_AL16(gate) && F32_AL16(out), "dl_f32_gated_residual_fwd: bad args");
+  const int64_t total = M * (D / 4);
+  hipLaunchKernelGGL(f32_gated_residual_k, grid_1d(total), 256, 0, (hipStream_t)stream, x, t, gate, ld_gate, rows_per_mod, out, ld_out,
+                     (int)(D / 4), total);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_f32_gate_bwd(const float* dout, const float* t, const float* gate, int64_t ld_gate, int64_t rows_per_mod, float* dt,
+                               float* dgate, int64_t ld_dgate, int64_t M, int64_t D, dl_stream_t stream) {
+  DL_CHECK_ARG(dout && t && gate && dt && dgate && M > 0 && D > 0 && D % 4 == 0 && D <= 256 * FR_NJ && ld_gate % 4 == 0 && rows_per_mod > 0 &&
+               M % rows_per_mod == 0 && F32_AL16(dout) && F32_AL16(t) && F32_AL16(gate) && F32_AL16(dt), "dl_f32_gate_bwd: bad args");
+  hipLaunchKernelGGL(f32_gate_bwd_k, (int)(M / rows_per_mod), 512, 8 * (int)D * 4, (hipStream_t)stream, dout, t, gate, ld_gate, rows_per_mod,
+                     dt, dgate, ld_dgate, (int)D);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

@@ -138,7 +138,15 @@ class SprintDiT(FlatArenaDenoiser):
         self.decoder_layers = nn.ModuleList([jb() for _ in range(decoder_depth)])
         self.apply(MMDiT._init_weights)
 
+    @property
+    def precisions(self) -> tuple[str, ...]:  # the fp32-class regime exists for the class-conditional form
+        return ("bf16", "fp32") if self.simple_dit else ("bf16",)
+
     def _make_engine(self, device: torch.device):
+        if self.precision == "fp32":
+            from ...sprint_engine_f32 import SprintEngineF32
+
+            return SprintEngineF32(self.dims, device)
         return SprintEngine(self.dims, device) if self.simple_dit else SprintJointEngine(self.dims, device)
 
     # ------------------------------------------------------------------ random decisions of a step (device RNG, as the reference)

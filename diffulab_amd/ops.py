@@ -868,14 +868,46 @@ def f32_ln_modulate_bwd(dout, x, w, b, scale, rows_per_mod, mean, rstd, dres, dx
           gate.stride(0) if gate is not None else 0, _p(dt), _p(dgate), M, D, _s())
 
 
-def f32_qk_norm_rope_fwd(qkv, scale_q, scale_k, cos, sin, qk, rrms, B, N, H, dh, rot, eps=1e-6):
+def f32_qk_norm_rope_fwd(qkv, scale_q, scale_k, cos, sin, qk, rrms, B, N, H, dh, rot, eps=1e-6, pos=None):
+    """pos: int32 [B*N] rotary table row of every token (SPRINT's kept tokens) or None"""
     _call("dl_f32_qk_norm_rope_fwd", _p(qkv), qkv.stride(0), _p(scale_q), _p(scale_k), _p(cos), _p(sin), _p(qk), _p(rrms), B, N, H, dh,
-          rot, float(eps), _s())
+          rot, float(eps), _p(pos), _s())
 
 
-def f32_qk_norm_rope_bwd(dqk, qkv, scale_q, scale_k, cos, sin, rrms, dqkv, partials, B, N, H, dh, rot):
+def f32_qk_norm_rope_bwd(dqk, qkv, scale_q, scale_k, cos, sin, rrms, dqkv, partials, B, N, H, dh, rot, pos=None):
     _call("dl_f32_qk_norm_rope_bwd", _p(dqk), _p(qkv), qkv.stride(0), _p(scale_q), _p(scale_k), _p(cos), _p(sin), _p(rrms), _p(dqkv),
-          dqkv.stride(0), _p(partials), B, N, H, dh, rot, _s())
+          dqkv.stride(0), _p(partials), B, N, H, dh, rot, _p(pos), _s())
+
+
+def f32_gather_tokens(src, idx, dst, B, N, k, D, keep=None):
+    """dst[b, j, :] = src[b, idx[b, j], :] on f32 rows: a bytewise row copy, i.e. dl_gather_tokens over 2 D two-byte columns"""
+    _call("dl_gather_tokens", _p(src), 2 * src.stride(0), _p(idx), _p(keep), _p(dst), 2 * dst.stride(0), B, N, k, 2 * D, _s())
+
+
+def f32_scatter_tokens_add(src, idx, dst, B, N, k, D):
+    _call("dl_f32_scatter_tokens_add", _p(src), src.stride(0), _p(idx), _p(dst), dst.stride(0), B, N, k, D, _s())
+
+
+def f32_restore_tokens(xd, inv, mask, out, B, N, k, D):
+    _call("dl_f32_restore_tokens", _p(xd), xd.stride(0), _p(inv), _p(mask), _p(out), out.stride(0), B, N, k, D, _s())
+
+
+def f32_masked_colsum(x, sel, out, R, C, scratch):
+    """out[c] += sum over rows with sel[row] < 0 of x[row, c]: partial images per 256-row slab in `scratch`, fixed-order fold"""
+    slabs = min(512, (R + 255) // 256)
+    assert scratch.numel() >= slabs * C
+    _call("dl_f32_masked_colsum_partials", _p(x), x.stride(0), _p(sel), _p(scratch), slabs, R, C, _s())
+    reduce_rows_batched_f32(scratch, 0, out, 0, 1, slabs, C)
+
+
+def f32_gated_residual_fwd(x, t, gate, rows_per_mod, out):
+    M, D = x.shape
+    _call("dl_f32_gated_residual_fwd", _p(x), _p(t), _p(gate), gate.stride(0), rows_per_mod, _p(out), out.stride(0), M, D, _s())
+
+
+def f32_gate_bwd(dout, t, gate, rows_per_mod, dt, dgate):
+    M, D = dout.shape
+    _call("dl_f32_gate_bwd", _p(dout), _p(t), _p(gate), gate.stride(0), rows_per_mod, _p(dt), _p(dgate), dgate.stride(0), M, D, _s())
 
 
 def f32_softmax_fwd(s, rows, cols):

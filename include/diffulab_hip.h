@@ -578,16 +578,31 @@ DL_API int dl_f32_ln_modulate_bwd(const float* dout, const float* x, const float
                                   dl_stream_t stream);
 /* QKNorm (nn.py:427-431,473-475: RMS over the full inner dim) + N-D RoPE on interleaved pairs (nn.py:345-353) in f32: qkv [B*N, ld]
  * (q in columns [0, D), k in [D, 2D)) -> qk [B*N, 2D] token-major (heads stay column blocks: dl_f32_gemm addresses them by stride);
- * rrms f32 [B*N, 2]; cos / sin f32 [N, rot/2] */
+ * rrms f32 [B*N, 2]; cos / sin f32 [rows, rot/2]; pos int32 [B*N] = rotary table row of every token (SPRINT's kept tokens,
+ * sprint.py:347-349) or NULL (row n of the table for token n of its sample) */
 DL_API int dl_f32_qk_norm_rope_fwd(const float* qkv, int64_t ld, const float* scale_q, const float* scale_k, const float* cos,
                                    const float* sin, float* qk, float* rrms, int64_t B, int64_t N, int64_t H, int64_t dh,
-                                   int64_t rot, float eps, dl_stream_t stream);
+                                   int64_t rot, float eps, const int32_t* pos, dl_stream_t stream);
 /* backward: dqk [B*N, 2D] -> columns [0, 2D) of dqkv (row stride ld_d); dscale_partials f32 [B, 2, D] written (one workgroup per
  * sample), folded by dl_reduce_rows_f32 */
 DL_API int dl_f32_qk_norm_rope_bwd(const float* dqk, const float* qkv, int64_t ld, const float* scale_q, const float* scale_k,
                                    const float* cos, const float* sin, const float* rrms, float* dqkv, int64_t ld_d,
                                    float* dscale_partials, int64_t B, int64_t N, int64_t H, int64_t dh, int64_t rot,
-                                   dl_stream_t stream);
+                                   const int32_t* pos, dl_stream_t stream);
+/* SPRINT token routing in f32 (sprint.py:317-387; the bf16 forms: dl_scatter_tokens_add, dl_restore_tokens, dl_masked_colsum,
+ * dl_gated_residual_fwd, dl_gate_bwd -- same argument meaning; the gather copies rows bytewise, so dl_gather_tokens with 2 D columns
+ * IS the f32 gather).  No atomics: dl_f32_masked_colsum_partials writes partials f32 [slabs, C] (slab s = rows [s ceil(R / slabs),
+ * ...)) for a fixed-order fold (dl_reduce_rows_batched_f32); dl_f32_gate_bwd WRITES dgate (one workgroup per modulation group). */
+DL_API int dl_f32_scatter_tokens_add(const float* src, int64_t ld_src, const int32_t* idx, float* dst, int64_t ld_dst, int64_t B,
+                                     int64_t N, int64_t k, int64_t D, dl_stream_t stream);
+DL_API int dl_f32_restore_tokens(const float* xd, int64_t ld_xd, const int32_t* inv, const float* mask, float* out, int64_t ld_out,
+                                 int64_t B, int64_t N, int64_t k, int64_t D, dl_stream_t stream);
+DL_API int dl_f32_masked_colsum_partials(const float* x, int64_t ld, const int32_t* sel, float* partials, int64_t slabs, int64_t R,
+                                         int64_t C, dl_stream_t stream);
+DL_API int dl_f32_gated_residual_fwd(const float* x, const float* t, const float* gate, int64_t ld_gate, int64_t rows_per_mod,
+                                     float* out, int64_t ld_out, int64_t M, int64_t D, dl_stream_t stream);
+DL_API int dl_f32_gate_bwd(const float* dout, const float* t, const float* gate, int64_t ld_gate, int64_t rows_per_mod, float* dt,
+                           float* dgate, int64_t ld_dgate, int64_t M, int64_t D, dl_stream_t stream);
 /* softmax over the last dimension of the scaled scores (mmdit.py:92-100), in place; backward dS = P (dP - rowsum(dP P)) over dP */
 DL_API int dl_f32_softmax_fwd(float* s, int64_t rows, int64_t cols, dl_stream_t stream);
 DL_API int dl_f32_softmax_bwd(const float* p, float* dp, int64_t rows, int64_t cols, dl_stream_t stream);

@@ -92,7 +92,7 @@ def apply_rope(x: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
 
     x: [B, N, H, dh]; cos/sin: [N, P], or [B, N, P] per-sample tables (SPRINT's gathered rows, sprint.py:348-353).
     """
-    rot = 2 * cos.shape[1]
+    rot = 2 * cos.shape[-1]
     xr, xp = x[..., :rot], x[..., rot:]
     a = xr[..., 0::2]
     b = xr[..., 1::2]

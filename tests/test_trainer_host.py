@@ -226,9 +226,11 @@ def test_precision_types_follow_the_reference_default(tmp_path):
     unet = UNetModel(image_size=[32, 32], in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1, attention_resolutions=[],
                      channel_mult="1,2", n_classes=10)
     assert unet.precisions == ("bf16", "fp32") and unet.set_precision("fp32").precision == "fp32"
-    from diffulab_amd import SprintDiT
+    from diffulab_amd import DDT, SprintDiT
 
     sprint = SprintDiT(simple_dit=True, input_channels=4, inner_dim=128, embedding_dim=64, num_heads=2, patch_size=2, n_classes=10,
                        encoder_depth=1, deep_layers_depth=1, decoder_depth=1)
+    assert sprint.precisions == ("bf16", "fp32") and sprint.set_precision("fp32").precision == "fp32"
+    ddt = DDT(simple_ddt=True, input_channels=4, inner_dim=128, num_heads=2, patch_size=2, n_classes=10, encoder_depth=1, decoder_depth=1)
     with pytest.raises(NotImplementedError, match="fp32"):
-        sprint.set_precision("fp32")
+        ddt.set_precision("fp32")
