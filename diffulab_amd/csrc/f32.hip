@@ -715,6 +715,53 @@ __global__ __launch_bounds__(512) void f32_gate_bwd_k(const float* __restrict__ 
     dgate[grp * ld_dgate + c] = ((red[c] + red[D + c]) + (red[2 * D + c] + red[3 * D + c])) +
                                 ((red[4 * D + c] + red[5 * D + c]) + (red[6 * D + c] + red[7 * D + c]));
 }
+// DDT decoder conditioning in f32 (ddt.py:423-424 + the SiLU inside Modulation nn.py:530): u = enc + temb[b], z = silu(u), out = silu(z)
+__global__ void f32_ddt_cond_fwd_k(const float* __restrict__ enc, int64_t ld, const float* __restrict__ temb, int64_t ld_t, int N,
+                                   float* __restrict__ out, int D4, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D4);
+    const int64_t row = i / D4;
+    f32x4_t v = *(const f32x4_t*)(enc + row * ld + 4 * c) + *(const f32x4_t*)(temb + (row / N) * ld_t + 4 * c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = silu32(silu32(v[e]));
+    *(f32x4_t*)(out + row * (int64_t)D4 * 4 + 4 * c) = v;
+  }
+}
+// denc = dsz silu'(z) silu'(u); dtemb[b, :] = sum_n denc[b, n, :] (written).  One workgroup per sample, eight row lanes, fixed-order fold.
+__global__ __launch_bounds__(512) void f32_ddt_cond_bwd_k(const float* __restrict__ dsz, const float* __restrict__ enc, int64_t ld,
+                                                          const float* __restrict__ temb, int64_t ld_t, int N, float* __restrict__ denc,
+                                                          float* __restrict__ dtemb, int D) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = (float*)smem;  // [8][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D4 = D >> 2;
+  const int64_t b = blockIdx.x;
+  f32x4_t tv[FR_NJ], acc[FR_NJ];
+  fr_load(temb + b * ld_t, D4, lane, tv, 0.f);
+#pragma unroll
+  for (int j = 0; j < FR_NJ; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int n = wave; n < N; n += 8) {
+    const int64_t row = b * N + n;
+    f32x4_t ev[FR_NJ], dv[FR_NJ];
+    fr_load(enc + row * ld, D4, lane, ev, 0.f);
+    fr_load(dsz + row * D, D4, lane, dv, 0.f);
+#pragma unroll
+    for (int j = 0; j < FR_NJ; ++j) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float u = ev[j][e] + tv[j][e];
+        dv[j][e] = dv[j][e] * dsilu32(silu32(u)) * dsilu32(u);
+      }
+      acc[j] += dv[j];
+    }
+    fr_store(denc + row * D, D4, lane, dv);
+  }
+  fr_store(red + wave * D, D4, lane, acc);
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 512)
+    dtemb[b * ld_t + c] = ((red[c] + red[D + c]) + (red[2 * D + c] + red[3 * D + c])) +
+                          ((red[4 * D + c] + red[5 * D + c]) + (red[6 * D + c] + red[7 * D + c]));
+}
 #define F32_AL16(p) ((((uintptr_t)(p)) & 15) == 0)
 extern "C" int dl_f32_scatter_tokens_add(const float* src, int64_t ld_src, const int32_t* idx, float* dst, int64_t ld_dst, int64_t B,
                                          int64_t N, int64_t k, int64_t D, dl_stream_t stream) {
@@ -760,6 +807,24 @@ extern "C" int dl_f32_gate_bwd(const float* dout, const float* t, const float* g
                M % rows_per_mod == 0 && F32_AL16(dout) && F32_AL16(t) && F32_AL16(gate) && F32_AL16(dt), "dl_f32_gate_bwd: bad args");
   hipLaunchKernelGGL(f32_gate_bwd_k, (int)(M / rows_per_mod), 512, 8 * (int)D * 4, (hipStream_t)stream, dout, t, gate, ld_gate, rows_per_mod,
                      dt, dgate, ld_dgate, (int)D);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+extern "C" int dl_f32_ddt_cond_fwd(const float* enc, int64_t ld, const float* temb, int64_t ld_t, int64_t B, int64_t N, int64_t D,
+                                   float* out, dl_stream_t stream) {
+  DL_CHECK_ARG(enc && temb && out && B > 0 && N > 0 && D > 0 && D % 4 == 0 && ld % 4 == 0 && ld >= D && ld_t % 4 == 0 && F32_AL16(enc) &&
+               F32_AL16(temb) && F32_AL16(out), "dl_f32_ddt_cond_fwd: bad args");
+  const int64_t total = B * N * (D / 4);
+  hipLaunchKernelGGL(f32_ddt_cond_fwd_k, grid_1d(total), 256, 0, (hipStream_t)stream, enc, ld, temb, ld_t, (int)N, out, (int)(D / 4), total);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+extern "C" int dl_f32_ddt_cond_bwd(const float* dsz, const float* enc, int64_t ld, const float* temb, int64_t ld_t, int64_t B, int64_t N,
+                                   int64_t D, float* denc, float* dtemb, dl_stream_t stream) {
+  DL_CHECK_ARG(dsz && enc && temb && denc && dtemb && B > 0 && N > 0 && D > 0 && D % 4 == 0 && D <= 256 * FR_NJ && ld % 4 == 0 && ld >= D &&
+               ld_t % 4 == 0 && F32_AL16(dsz) && F32_AL16(enc) && F32_AL16(temb) && F32_AL16(denc), "dl_f32_ddt_cond_bwd: bad args");
+  hipLaunchKernelGGL(f32_ddt_cond_bwd_k, (int)B, 512, 8 * (int)D * 4, (hipStream_t)stream, dsz, enc, ld, temb, ld_t, (int)N, denc, dtemb, (int)D);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

@@ -23,6 +23,7 @@ from .engine import DiTDims, ParamLayout, rope_grid_tables
 
 class DiTEngineF32:
     precision = "fp32"
+    _conv_name = "conv_proj.weight"  # the patch embedding behind the block stack (DDT: its encoder's)
 
     def __init__(self, dims: DiTDims, device: torch.device | str = "cuda") -> None:
         D = dims.inner_dim
@@ -172,7 +173,7 @@ class DiTEngineF32:
         nn.py:106-114, 530-531)"""
         d, w, P, Wt = self.d, self.ws, self.P, self.W
         ops.f32_patchify(x, w["tokP"], d.patch_size, ops.PATCH_CPP)
-        ops.f32_linear(w["tokP"], Wt("conv_proj.weight"), x0)
+        ops.f32_linear(w["tokP"], Wt(self._conv_name), x0)
         ops.f32_timestep_embedding(t, w["temb"])
         ops.f32_linear(w["temb"], Wt("time_embed.0.weight"), w["h1"], bias=P("time_embed.0.bias"), act=ops.ACT_SILU, pre_out=w["pre1"])
         ops.f32_linear(w["h1"], Wt("time_embed.2.weight"), w["e"], bias=P("time_embed.2.bias"))
@@ -182,22 +183,25 @@ class DiTEngineF32:
         ops.f32_linear(w["se"], mod_w, w["mod"], bias=mod_b)
         return w["mod"]
 
-    def _blk_fwd(self, a: dict, pre: str, mo: int, xin: Tensor, pend, B: int, nt: int, pos: Tensor | None = None):
+    def _blk_fwd(self, a: dict, pre: str, mo: int, xin: Tensor, pend, B: int, nt: int, pos: Tensor | None = None,
+                 mod: Tensor | None = None, rpm: int | None = None):
         """one DiTBlock (mmdit.py:288-309) over B * nt tokens.  pend = (x_base, t, gate) of the previous sub-layer whose gated
         residual this block's first LayerNorm kernel applies (and writes to xin), or None when xin already holds the block input;
-        returns this block's own pending residual."""
+        returns this block's own pending residual.  mod / rpm: the modulation matrix and the token rows that share one of its rows
+        (default: the per-sample matrix ws["mod"], nt rows; DDT's decoder: one row per token)."""
         d, P, Wt = self.d, self.P, self.W
         D, Hh, dh = d.inner_dim, d.num_heads, d.head_dim
         gh, gw = self.geo[3], self.geo[4]
         cos, sin = self._rope[(gh, gw)]
         rot = sum(d.rope_axes_dim)
-        mod = self.ws["mod"]
+        mod = self.ws["mod"] if mod is None else mod
+        rpm = nt if rpm is None else rpm
         if pend is None:
             ops.f32_ln_modulate_fwd(xin, P(pre + "norm_1.weight"), P(pre + "norm_1.bias"), mod[:, mo : mo + D],
-                                    mod[:, mo + D : mo + 2 * D], nt, 1e-5, a["xm1"], a["mean1"], a["rstd1"])
+                                    mod[:, mo + D : mo + 2 * D], rpm, 1e-5, a["xm1"], a["mean1"], a["rstd1"])
         else:
             ops.f32_ln_modulate_fwd(pend[0], P(pre + "norm_1.weight"), P(pre + "norm_1.bias"), mod[:, mo : mo + D],
-                                    mod[:, mo + D : mo + 2 * D], nt, 1e-5, a["xm1"], a["mean1"], a["rstd1"], t=pend[1],
+                                    mod[:, mo + D : mo + 2 * D], rpm, 1e-5, a["xm1"], a["mean1"], a["rstd1"], t=pend[1],
                                     gate=pend[2], x_out=xin)
         ops.f32_linear(a["xm1"], Wt(pre + "attention.qkv.weight"), a["qkv"])
         ops.f32_qk_norm_rope_fwd(a["qkv"], P(pre + "attention.qk_norm.query_norm.scale"),
@@ -211,21 +215,23 @@ class DiTEngineF32:
                      sa=(Hh * nt * nt, nt * nt), sb=(nt * 3 * D, dh), sc=(nt * D, dh))
         ops.f32_linear(a["a"], Wt(pre + "attention.proj_out.weight"), a["t1"])
         ops.f32_ln_modulate_fwd(xin, P(pre + "norm_2.weight"), P(pre + "norm_2.bias"), mod[:, mo + 3 * D : mo + 4 * D],
-                                mod[:, mo + 4 * D : mo + 5 * D], nt, 1e-5, a["xm2"], a["mean2"], a["rstd2"], t=a["t1"],
+                                mod[:, mo + 4 * D : mo + 5 * D], rpm, 1e-5, a["xm2"], a["mean2"], a["rstd2"], t=a["t1"],
                                 gate=mod[:, mo + 2 * D : mo + 3 * D], x_out=a["x1"])
         ops.f32_linear(a["xm2"], Wt(pre + "mlp_input.0.weight"), a["u"])
         ops.f32_swiglu_fwd(a["u"], a["h"])
         ops.f32_linear(a["h"], Wt(pre + "mlp_input.2.weight"), a["t2"])
         return (a["x1"], a["t2"], mod[:, mo + 5 * D : mo + 6 * D])
 
-    def _head_fwd(self, x: Tensor, pend, N: int) -> Tensor:
-        """ModulatedLastLayer (mmdit.py:542-549) + unpatchify; pend as in _blk_fwd (its residual is written to x)"""
+    def _head_fwd(self, x: Tensor, pend, N: int, mod: Tensor | None = None, rpm: int | None = None, mo: int | None = None) -> Tensor:
+        """ModulatedLastLayer (mmdit.py:542-549) + unpatchify; pend as in _blk_fwd (its residual is written to x); mod / rpm as in
+        _blk_fwd, mo = first column of the layer's [scale | shift] rows"""
         d, w = self.d, self.ws
-        D, mo = d.inner_dim, d.depth * 6 * d.inner_dim
-        mod = w["mod"]
+        D = d.inner_dim
+        mo = d.depth * 6 * D if mo is None else mo
+        mod = w["mod"] if mod is None else mod
         kw = {} if pend is None else dict(t=pend[1], gate=pend[2], x_out=x)
-        ops.f32_ln_modulate_fwd(x if pend is None else pend[0], None, None, mod[:, mo : mo + D], mod[:, mo + D : mo + 2 * D], N, 1e-6,
-                                w["xf"], w["meanf"], w["rstdf"], **kw)
+        ops.f32_ln_modulate_fwd(x if pend is None else pend[0], None, None, mod[:, mo : mo + D], mod[:, mo + D : mo + 2 * D],
+                                N if rpm is None else rpm, 1e-6, w["xf"], w["meanf"], w["rstdf"], **kw)
         ops.f32_linear(w["xf"], self.W("last_layer.linear.weight"), w["otok"], bias=self.P("last_layer.linear.bias"))
         ops.unpatchify(w["otok"], w["pred"], d.patch_size)
         return w["pred"]
@@ -259,11 +265,15 @@ class DiTEngineF32:
         """ping-pong target of the next LayerNorm backward (never the buffer it reads)"""
         return s["dxb"] if cur.data_ptr() == s["dxa"].data_ptr() else s["dxa"]
 
-    def _head_bwd(self, dpred: Tensor, x_last: Tensor, s: dict, N: int, dres: Tensor | None, gate_fused: dict) -> Tensor:
-        """last linear (mmdit.py:548) + final adaLN (mmdit.py:543-547); returns the gradient at the head's input (s["dxa"])"""
+    def _head_bwd(self, dpred: Tensor, x_last: Tensor, s: dict, N: int, dres: Tensor | None, gate_fused: dict,
+                  mods: tuple | None = None, mo: int | None = None) -> Tensor:
+        """last linear (mmdit.py:548) + final adaLN (mmdit.py:543-547); returns the gradient at the head's input (s["dxa"]).
+        mods = (mod, dmod, rows per modulation row) when they are not the per-sample matrices (N rows)"""
         d, w = self.d, self.ws
-        D, M, mo = d.inner_dim, x_last.shape[0], d.depth * 6 * d.inner_dim
-        mod, dmod, scr = w["mod"], w["dmod"], w["scr"]
+        D, M = d.inner_dim, x_last.shape[0]
+        mo = d.depth * 6 * D if mo is None else mo
+        mod, dmod, N = mods if mods is not None else (w["mod"], w["dmod"], N)
+        scr = w["scr"]
         ops.f32_patchify(dpred, w["dO"], d.patch_size, ops.PATCH_PPC)
         ops.f32_linear_wgrad(w["dO"], w["xf"], self.GW("last_layer.linear.weight"), scratch=scr)
         ops.colsum(w["dO"], self.G("last_layer.linear.bias"), M, w["dO"].shape[1], scratch=scr)
@@ -273,15 +283,18 @@ class DiTEngineF32:
         return s["dxa"]
 
     def _blk_bwd(self, a: dict, pre: str, mo: int, xin: Tensor, s: dict, dx: Tensor, B: int, nt: int, pos: Tensor | None,
-                 gate_fused: dict, dxin_aux: Tensor | None = None) -> Tensor:
+                 gate_fused: dict, dxin_aux: Tensor | None = None, mods: tuple | None = None) -> Tensor:
         """backward of _blk_fwd.  On entry s["dt2"] = gradient of this block's MLP output t2 and dx = gradient of the block output
         through the residual path; gate_fused = the gated-residual backward of the PREVIOUS sub-layer fused into the last LayerNorm
         backward (gate_t / gate / dt / dgate), {} at a stage start; dxin_aux = gradient of an auxiliary loss on the block INPUT (it has to
-        pass through that fused gate backward too).  Returns the gradient at the block input."""
+        pass through that fused gate backward too); mods as in _head_bwd.  Returns the gradient at the block input."""
         d, w = self.d, self.ws
         D, Hh, dh, F = d.inner_dim, d.num_heads, d.head_dim, d.mlp_ratio * d.inner_dim
         P, Wt, G, GW = self.P, self.W, self.G, self.GW
-        mod, dmod, scr = w["mod"], w["dmod"], w["scr"]
+        mod, dmod, rpm = mods if mods is not None else (w["mod"], w["dmod"], nt)
+        groups = B * nt // rpm
+        dwb = w["dwb"] if groups == B else w["dwbt"]  # partial [groups, 2, D] sums of the affine LayerNorm gradients
+        scr = w["scr"]
         gh, gw = self.geo[3], self.geo[4]
         cos, sin = self._rope[(gh, gw)]
         rot = sum(d.rope_axes_dim)
@@ -294,10 +307,10 @@ class DiTEngineF32:
         ops.f32_linear_dgrad(s["du"], Wt(pre + "mlp_input.0.weight"), s["dxm"])
         dx_alt = self._other(s, dx)
         ops.f32_ln_modulate_bwd(s["dxm"], a["x1"], P(pre + "norm_2.weight"), P(pre + "norm_2.bias"), mod[:, mo + 3 * D : mo + 4 * D],
-                                nt, a["mean2"], a["rstd2"], dx, dx_alt, dmod[:, mo + 3 * D : mo + 4 * D],
-                                dmod[:, mo + 4 * D : mo + 5 * D], w["dwb"], gate_t=a["t1"], gate=mod[:, mo + 2 * D : mo + 3 * D],
+                                rpm, a["mean2"], a["rstd2"], dx, dx_alt, dmod[:, mo + 3 * D : mo + 4 * D],
+                                dmod[:, mo + 4 * D : mo + 5 * D], dwb, gate_t=a["t1"], gate=mod[:, mo + 2 * D : mo + 3 * D],
                                 dt=s["dt1"], dgate=dmod[:, mo + 2 * D : mo + 3 * D])
-        ops.reduce_rows_batched_f32(w["dwb"], 0, G(pre + "norm_2.weight"), 0, 1, B, 2 * D)  # [w; b] adjacent; fixed-order fold
+        self._fold_groups(dwb, G(pre + "norm_2.weight"), groups, 2 * D)  # [w; b] adjacent; fixed-order fold
         dx = dx_alt
         # attention branch (mmdit.py:75-104)
         ops.f32_linear_wgrad(s["dt1"], a["a"], GW(pre + "attention.proj_out.weight"), scratch=scr)
@@ -324,25 +337,33 @@ class DiTEngineF32:
         if dxin_aux is not None:
             ops.f32_add(dx, dxin_aux, dx)
         dx_alt = self._other(s, dx)
-        ops.f32_ln_modulate_bwd(s["dxm"], xin, P(pre + "norm_1.weight"), P(pre + "norm_1.bias"), mod[:, mo : mo + D], nt,
-                                a["mean1"], a["rstd1"], dx, dx_alt, dmod[:, mo : mo + D], dmod[:, mo + D : mo + 2 * D], w["dwb"],
+        ops.f32_ln_modulate_bwd(s["dxm"], xin, P(pre + "norm_1.weight"), P(pre + "norm_1.bias"), mod[:, mo : mo + D], rpm,
+                                a["mean1"], a["rstd1"], dx, dx_alt, dmod[:, mo : mo + D], dmod[:, mo + D : mo + 2 * D], dwb,
                                 **gate_fused)
-        ops.reduce_rows_batched_f32(w["dwb"], 0, G(pre + "norm_1.weight"), 0, 1, B, 2 * D)
+        self._fold_groups(dwb, G(pre + "norm_1.weight"), groups, 2 * D)
         return dx_alt
 
-    def _prev_gate(self, a_prev: dict, mp: int, s: dict) -> dict:
+    def _prev_gate(self, a_prev: dict, mp: int, s: dict, mods: tuple | None = None) -> dict:
         """arguments that fuse the gated-residual backward of the block in front (its t2 / MLP gate) into a LayerNorm backward"""
         D = self.d.inner_dim
-        return dict(gate_t=a_prev["t2"], gate=self.ws["mod"][:, mp + 5 * D : mp + 6 * D], dt=s["dt2"],
-                    dgate=self.ws["dmod"][:, mp + 5 * D : mp + 6 * D])
+        mod, dmod = (self.ws["mod"], self.ws["dmod"]) if mods is None else mods[:2]
+        return dict(gate_t=a_prev["t2"], gate=mod[:, mp + 5 * D : mp + 6 * D], dt=s["dt2"], dgate=dmod[:, mp + 5 * D : mp + 6 * D])
 
-    def _stem_cond_bwd(self, dx0: Tensor) -> None:
-        """patch-embedding weight gradient (no gradient flows to the input latents) and the conditioning path"""
+    def _fold_groups(self, partial: Tensor, out: Tensor, groups: int, n: int) -> None:
+        """out[:n] += the sum of `groups` partial rows, in a fixed order (per-sample partials: one launch; per-token: slab partials)"""
+        if groups <= 1024:
+            ops.reduce_rows_batched_f32(partial, 0, out, 0, 1, groups, n)
+        else:
+            ops.colsum(partial.view(groups, n), out, groups, n, scratch=self.ws["scr"])
+
+    def _stem_cond_bwd(self, dx0: Tensor, extra_de: Tensor | None = None) -> None:
+        """patch-embedding weight gradient (no gradient flows to the input latents) and the conditioning path; extra_de: a further
+        gradient of the time embedding e (DDT's per-token decoder conditioning)"""
         d, w = self.d, self.ws
         B, E = self.geo[0], d.embedding_dim
         G, GW, Wt = self.G, self.GW, self.W
         dmod, scr = w["dmod"], w["scr"]
-        ops.f32_linear_wgrad(dx0, w["tokP"], GW("conv_proj.weight"), scratch=scr)
+        ops.f32_linear_wgrad(dx0, w["tokP"], GW(self._conv_name), scratch=scr)
         g_modw, g_modb = self._mod_matrix(self.grads)
         mod_w, _ = self._mod_matrix(self.params)
         ops.f32_linear_wgrad(dmod, w["se"], g_modw)
@@ -351,6 +372,8 @@ class DiTEngineF32:
         table = d.n_classes is not None
         ops.f32_cond_combine_bwd(w["dse"], w["emb"], self._yeff if table else None, w["demb"],
                                  G("label_embed.embedding.weight") if table else None)
+        if extra_de is not None:
+            ops.f32_add(w["demb"], extra_de, w["demb"])
         ops.colsum(w["demb"], G("time_embed.2.bias"), B, E, scratch=scr)
         ops.f32_linear_wgrad(w["demb"], w["h1"], GW("time_embed.2.weight"))
         ops.f32_linear_dgrad(w["demb"], Wt("time_embed.2.weight"), w["dh1"])

@@ -104,7 +104,7 @@ class FlatArenaDenoiser(Denoiser):
             raise ValueError(f"precision must be 'bf16' or 'fp32' (got {precision!r})")
         if precision not in self.precisions:
             raise NotImplementedError(f"diffulab_amd.{type(self).__name__} has no {precision} launch sequence (built: "
-                                      f"{', '.join(self.precisions)}); the fp32-class regime exists for MMDiT(simple_dit=True), SprintDiT(simple_dit=True) and UNetModel")
+                                      f"{', '.join(self.precisions)}); the fp32-class regime exists for the class-conditional forms (MMDiT / SprintDiT simple_dit=True, DDT simple_ddt=True) and UNetModel")
         if precision != self.precision:
             object.__setattr__(self, "_precision", precision)
             object.__setattr__(self, "_engine", None)  # the next forward re-flattens onto the other engine (same arena layout)

@@ -116,7 +116,15 @@ class DDT(FlatArenaDenoiser):
         self.decoder_layers = nn.ModuleList([DiTBlock(inner_dim, inner_dim, mlp_ratio) for _ in range(decoder_depth)])
         self.apply(MMDiT._init_weights)
 
+    @property
+    def precisions(self) -> tuple[str, ...]:  # the fp32-class regime exists for the class-conditional form (ddt_engine_f32.py)
+        return ("bf16", "fp32") if self.simple_ddt else ("bf16",)
+
     def _make_engine(self, device: torch.device):
+        if self.precision == "fp32":
+            from ...ddt_engine_f32 import DDTEngineF32
+
+            return DDTEngineF32(self.dims, device)
         return DDTEngine(self.dims, device) if self.simple_ddt else DDTJointEngine(self.dims, device)
 
     def _graph_inputs(self, eng) -> tuple:  # (the context tensors are per-call inputs of the joint launch sequence)

@@ -900,6 +900,14 @@ def f32_masked_colsum(x, sel, out, R, C, scratch):
     reduce_rows_batched_f32(scratch, 0, out, 0, 1, slabs, C)
 
 
+def f32_ddt_cond_fwd(enc, temb, B, N, out):
+    _call("dl_f32_ddt_cond_fwd", _p(enc), enc.stride(0), _p(temb), temb.stride(0), B, N, enc.shape[1], _p(out), _s())
+
+
+def f32_ddt_cond_bwd(dsz, enc, temb, B, N, denc, dtemb):
+    _call("dl_f32_ddt_cond_bwd", _p(dsz), _p(enc), enc.stride(0), _p(temb), temb.stride(0), B, N, enc.shape[1], _p(denc), _p(dtemb), _s())
+
+
 def f32_gated_residual_fwd(x, t, gate, rows_per_mod, out):
     M, D = x.shape
     _call("dl_f32_gated_residual_fwd", _p(x), _p(t), _p(gate), gate.stride(0), rows_per_mod, _p(out), out.stride(0), M, D, _s())

@@ -603,6 +603,12 @@ DL_API int dl_f32_gated_residual_fwd(const float* x, const float* t, const float
                                      float* out, int64_t ld_out, int64_t M, int64_t D, dl_stream_t stream);
 DL_API int dl_f32_gate_bwd(const float* dout, const float* t, const float* gate, int64_t ld_gate, int64_t rows_per_mod, float* dt,
                            float* dgate, int64_t ld_dgate, int64_t M, int64_t D, dl_stream_t stream);
+/* DDT decoder conditioning in f32 (ddt.py:423-424, nn.py:530; the bf16 forms: dl_ddt_cond_fwd / _bwd): out = silu(silu(enc + temb[b]));
+ * backward: denc written, dtemb f32 [B, ld_t] WRITTEN (one workgroup per sample, no atomics) */
+DL_API int dl_f32_ddt_cond_fwd(const float* enc, int64_t ld, const float* temb, int64_t ld_t, int64_t B, int64_t N, int64_t D, float* out,
+                               dl_stream_t stream);
+DL_API int dl_f32_ddt_cond_bwd(const float* dsz, const float* enc, int64_t ld, const float* temb, int64_t ld_t, int64_t B, int64_t N,
+                               int64_t D, float* denc, float* dtemb, dl_stream_t stream);
 /* softmax over the last dimension of the scaled scores (mmdit.py:92-100), in place; backward dS = P (dP - rowsum(dP P)) over dP */
 DL_API int dl_f32_softmax_fwd(float* s, int64_t rows, int64_t cols, dl_stream_t stream);
 DL_API int dl_f32_softmax_bwd(const float* p, float* dp, int64_t rows, int64_t cols, dl_stream_t stream);
