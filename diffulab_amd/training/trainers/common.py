@@ -18,7 +18,7 @@ Mirrors ``training/trainers/common.py:25-271`` of the reference (same constructo
     (Accelerate's ``sync_with_dataloader``);
   * precision: ``precision_type="no"`` (the reference's default, common.py:76,105 / configs/trainer/default.yaml:4) selects the
     fp32-class regime -- f32 activations, exact-f32 MFMA products on the f32 parameters (engine_f32.py, unet_engine_f32.py,
-    csrc/f32.hip) -- which exists for ``MMDiT(simple_dit=True)`` and ``UNetModel``; a denoiser without it raises at ``prepare`` and names the override
+    csrc/f32.hip) -- which exists for the class-conditional ``MMDiT`` / ``SprintDiT`` / ``DDT`` and ``UNetModel``; a denoiser without it raises at ``prepare`` and names the override
     (``trainer.precision_type=bf16``).  ``"bf16"`` = bf16 MFMA operands and activations with f32 accumulation, f32 master weights,
     f32 norm statistics / softmax / loss head (what accelerate's bf16 autocast computes); ``"fp16"`` / ``"fp8"`` are refused (not
     built: they would silently be something else);
