@@ -44,7 +44,7 @@ def test_state_dict_contract_and_init():
     shapes = odit.param_shapes(odit.DiTConfig(**SMALL))
     sd = m.state_dict()
     assert set(sd) == set(shapes) and all(tuple(sd[k].shape) == shapes[k] for k in shapes)
-    assert float(m.layers[0].modulation.lin.weight.abs().sum()) == 0.0
+    assert float(m.layers[0].modulation.lin.weight.detach().abs().sum()) == 0.0
     assert float(m.last_layer.adaLN_modulation[1].weight.abs().sum()) == 0.0
     m = m.to(DEV)
     x = synth.normal("init.x", (4, 4, 16, 16)).to(DEV)
