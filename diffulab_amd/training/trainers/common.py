@@ -147,6 +147,10 @@ class Trainer(ABC):
         den.to(self.device)
         if hasattr(den, "engine") and self.device.type == "cuda":
             eng = den.engine  # flattens the parameters into the arena
+            if self.is_main_process:  # run header of the JSON-lines log: which launch sequences this run trains on
+                with open(self.save_path / "metrics.jsonl", "a") as f:
+                    f.write(json.dumps({"run/precision_type": self.precision_type, "run/regime": getattr(den, "precision", "bf16"),
+                                        "run/engine": type(eng).__name__, "run/world": self.world}) + "\n")
             if self.world > 1:
                 broadcast_arena(den._flat)
                 self._reducer = GradReducer(den._flat_grad)

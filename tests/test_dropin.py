@@ -279,3 +279,34 @@ def test_mds_shards_are_read_like_the_reference_streaming_dataset(tmp_path):
     synth.write_mds(str(tmp_path / "n" / "train"), {"label": "int", "vision_latents": "ndarray:float32", "image": "png"}, smp[:2])
     with pytest.raises(NotImplementedError, match="dst_features"):
         ImageNetLatentREPA(str(tmp_path / "n"), split="train")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("config,dataset,engine,extra", [
+    ("train_mnist_ddpm", "mnist_synthetic", "UNetEngineF32", ["model.model_channels=64"]),
+    ("train_cifar10_flow_matching", "cifar10_synthetic", "DiTEngineF32", []),
+    ("train_cifar10_sprint", "cifar10_synthetic", "SprintEngineF32", []),
+    ("train_cifar10_ddt", "cifar10_synthetic", "DDTEngineF32", []),
+])
+def test_class_conditional_reference_configurations_train_in_their_reference_precision(tmp_path, config, dataset, engine, extra):
+    """`examples/train_diffusion.py` on the configurations whose reference counterparts inherit trainer/default.yaml's
+    precision_type "no": three epochs at the configuration's own model dims (the UNet narrowed to 64 channels) run on the fp32
+    launch sequences -- no override of the precision anywhere --, write the reference's checkpoint files and log a finite, falling
+    epoch loss."""
+    import json
+
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, os.path.join(ROOT, "examples", "train_diffusion.py"), "--config-name", config, f"dataset={dataset}",
+           "trainer.n_epoch=3", "trainer.log_validation_images=false", "optimizer.lr=1e-3", "dataset.train.n_samples=1024",
+           f"+trainer.save_path={tmp_path}", *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=1100)
+    assert out.returncode == 0, out.stderr[-3000:]
+    runs = [p for p in tmp_path.rglob("metrics.jsonl")]
+    assert runs, list(tmp_path.rglob("*"))[:20]
+    rows = [json.loads(line) for line in open(runs[0]) if line.strip()]
+    head = rows[0]
+    assert head["run/precision_type"] == "no" and head["run/regime"] == "fp32" and head["run/engine"] == engine, head
+    losses = [r["train/loss"] for r in rows if "train/loss" in r]
+    assert len(losses) == 3 and all(v == v and v < 1e4 for v in losses) and losses[-1] < losses[0], losses
+    assert list(tmp_path.rglob("denoiser.pt")), "no checkpoint written"
