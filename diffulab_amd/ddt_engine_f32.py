@@ -1,5 +1,6 @@
-"""fp32-class launch sequences of DDT(simple_ddt=True): the reference's default precision for ``configs/train_cifar10_ddt.yaml``
-(`precision_type` inherited from trainer/default.yaml: "no"; reference networks/denoisers/ddt.py:346-464).
+"""fp32-class launch sequences of DDT(simple_ddt=True): the precision the reference's class-conditional configurations give this denoiser
+(``model=ddt`` composed with e.g. train_cifar10_flow_matching.yaml inherits trainer/default.yaml's `precision_type: "no"`; this
+repository's ``configs/train_cifar10_ddt.yaml`` is that composition; reference networks/denoisers/ddt.py:346-464).
 
 Encoder = a stage of DiT blocks with per-sample adaLN rows (`sprint_engine_f32.SprintEngineF32._stage_fwd`).  Decoder = DiT blocks on
 a second patch embedding of the input whose conditioning is PER TOKEN, z = silu(encoder output + time embedding): the adaLN linears of

@@ -1,5 +1,6 @@
-"""fp32-class launch sequences of SprintDiT (simple_dit): the reference's default precision for ``configs/train_cifar10_sprint.yaml``
-(`precision_type` inherited from trainer/default.yaml: "no").  `engine_f32.DiTEngineF32`'s stem / conditioning / block / head pieces
+"""fp32-class launch sequences of SprintDiT (simple_dit): the precision the reference's class-conditional configurations give this
+denoiser (``model=sprint`` composed with e.g. train_cifar10_flow_matching.yaml inherits trainer/default.yaml's `precision_type: "no"`;
+this repository's ``configs/train_cifar10_sprint.yaml`` is that composition).  `engine_f32.DiTEngineF32`'s stem / conditioning / block / head pieces
 composed like `sprint_engine.SprintEngine` (reference networks/denoisers/sprint.py:505-573):
 
     encoder blocks (all N tokens) -> gather the kept tokens -> deep blocks (k tokens, RoPE rows picked by position index)

@@ -1,5 +1,5 @@
-"""The fp32-class regime of DDT(simple_ddt=True) -- the reference's precision for configs/train_cifar10_ddt.yaml (it inherits
-trainer/default.yaml's precision_type "no") -- through the C ABI: the f32 decoder-conditioning kernels and the launch sequences of
+"""The fp32-class regime of DDT(simple_ddt=True) -- the precision `model=ddt` gets in the reference's class-conditional
+configurations (they inherit trainer/default.yaml's precision_type "no"; configs/train_cifar10_ddt.yaml here) -- through the C ABI: the f32 decoder-conditioning kernels and the launch sequences of
 ddt_engine_f32.py (per-token adaLN through the f32 LayerNorm kernels with one modulation row per token) against (1) outputs of the
 reference module (tests/golden/ddt.npz) and (2) the CPU oracle.  Bar: per-tensor relative L2 <= 1e-5."""
 

@@ -1,5 +1,5 @@
-"""The fp32-class regime of SprintDiT(simple_dit=True) -- the reference's precision for configs/train_cifar10_sprint.yaml (it inherits
-trainer/default.yaml's precision_type "no") -- through the C ABI: the f32 token-routing kernels of csrc/f32.hip and the launch
+"""The fp32-class regime of SprintDiT(simple_dit=True) -- the precision `model=sprint` gets in the reference's class-conditional
+configurations (they inherit trainer/default.yaml's precision_type "no"; configs/train_cifar10_sprint.yaml here) -- through the C ABI: the f32 token-routing kernels of csrc/f32.hip and the launch
 sequences of sprint_engine_f32.py against (1) outputs of the reference's own SprintDiT (tests/golden/sprint.npz, random draws recorded
 and injected) and (2) the CPU oracle.  Bar: per-tensor relative L2 <= 1e-5."""
 
