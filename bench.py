@@ -142,6 +142,37 @@ def loss_curve_rel_err(dev, precision: str = "bf16") -> dict:
             "against": "the reference's fp32 curve (tests/golden/loss_curve.npz)", "compute": precision}
 
 
+def fp32_regime_step(dev, B: int, flops_per_image: float) -> dict:
+    """the same training step at the same batch in the fp32-class regime (precision_type="no", the reference's default): a reported
+    side figure -- the timed region and `value` stay the bf16 regime's"""
+    from diffulab_amd import Diffuser, MMDiT
+    from diffulab_amd.training import FusedAdamW
+
+    torch.manual_seed(1)
+    m = MMDiT(**S2)
+    m.set_precision("fp32")
+    m = m.to(dev)
+    opt = FusedAdamW(m.parameters(), lr=1e-4, weight_decay=0.01)
+    d = Diffuser(m, sampling_method="euler", model_type="rectified_flow", n_steps=50, extra_args={"logits_normal": True})
+    x0, y = torch.randn(B, 4, 32, 32, device=dev), torch.randint(0, 1000, (B,), device=dev)
+
+    def step():
+        opt.zero_grad()
+        d.compute_loss({"x": x0, "y": y, "p": 0.1}, timesteps=d.draw_timesteps(B).to(dev))["loss"].backward()
+        opt.step()
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    return {"ms_per_step": round(ms, 2), "images_per_s": round(B / ms * 1e3, 1), "tflops": round(B * flops_per_image / ms / 1e9, 1),
+            "peak_tflops_f32_mfma": 157.3, "steps": n, "engine": type(m.engine).__name__}
+
+
 def _tn_variant(R: int, M: int, N: int) -> str:
     """which kernel dl_gemm_tn dispatches to (csrc/gemm.hip dl_gemm_tn_ex, default variant)"""
     tiles_m = -(-M // 384)
@@ -558,11 +589,12 @@ def main() -> None:
     if rank == 0 and not args.no_roofline:
         roof = roofline_replay(step, model, value / world)
 
-    cpu, curve, curve32 = None, None, None
+    cpu, curve, curve32, fp32_step = None, None, None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
         curve = loss_curve_rel_err(dev, "bf16")
         curve32 = loss_curve_rel_err(dev, "fp32")
+        fp32_step = fp32_regime_step(dev, B, train_flops_per_image())
 
     if rank == 0:
         out = {
@@ -574,7 +606,7 @@ def main() -> None:
             "config": {"workload": "DiT-S/2 384/6h/12L p2 39.9M rectified-flow train step, 4x32x32 latents, AdamW, p_drop 0.1",
                        "global_batch": world * B, "per_gpu_batch": B, "tokens_per_image": 256,
                        "parallelism": f"dp{world}", "flops_per_image": train_flops_per_image(), "final_loss": final_loss,
-                       "loss_curve_rel_err": curve, "loss_curve_rel_err_fp32": curve32},
+                       "loss_curve_rel_err": curve, "loss_curve_rel_err_fp32": curve32, "fp32_regime_step": fp32_step},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if dp is not None:
