@@ -256,7 +256,8 @@ class _RangeRecorder:
         self.finished = True
 
 
-@pytest.mark.parametrize("family", ["dit", "sprint", "ddt", "joint", "sprint_joint", "ddt_joint", "unet"])
+@pytest.mark.parametrize("family", ["dit", "sprint", "ddt", "joint", "sprint_joint", "ddt_joint", "unet", "dit:fp32", "sprint:fp32", "ddt:fp32",
+                                    "unet:fp32"])
 def test_every_engine_hands_the_whole_gradient_arena_to_the_reducer_exactly_once(family):
     """the data-parallel reducer sums the ranges an engine's backward declares final (one all-reduce per contiguous run of a
     flush, dp.py:_flush): every engine must announce every element of [0, size) exactly once -- block ranges high addresses first
@@ -264,6 +265,7 @@ def test_every_engine_hands_the_whole_gradient_arena_to_the_reducer_exactly_once
     import diffulab_amd as da
     from diffulab_amd.networks.embedders import PrecomputedEmbedder
 
+    family, _, precision = family.partition(":")  # (the fp32-class engines announce the whole arena once, at the end)
     torch.manual_seed(0)
     emb = PrecomputedEmbedder(torch.zeros(1, 64, 96), 7)
     small = dict(input_channels=4, output_channels=4, inner_dim=128, num_heads=2, mlp_ratio=4, patch_size=2)
@@ -289,7 +291,10 @@ def test_every_engine_hands_the_whole_gradient_arena_to_the_reducer_exactly_once
                          attention_resolutions=[2], channel_mult="1, 2", num_heads=2, use_scale_shift_norm=True, resblock_updown=True,
                          n_classes=10, classifier_free=True)
         small = dict(input_channels=1)
+    if precision:
+        m.set_precision(precision)
     m = m.to(DEV).train()
+    assert getattr(m.engine, "precision", "bf16") == (precision or "bf16")
     rec = _RangeRecorder()
     m.engine.reducer = rec
     x = torch.randn(B, small["input_channels"], H, H, device=DEV)
