@@ -236,8 +236,10 @@ extern "C" int dl_f32_gemm(const dl_f32_gemm_t* d, dl_stream_t stream) {
   // split the contraction when the output has too few tiles to fill the chip (weight gradients over all tokens): every split stores
   // its partial image into the caller's scratch, a fold adds them in a fixed order (no atomics)
   const int64_t tiles = (int64_t)tm * tn * nbatch;
-  if (d->scratch && nbatch == 1 && tiles < 192 && d->K >= 1024) {
-    int64_t want = (256 + tiles - 1) / tiles;
+  // (the 256-thread workgroups run four to a CU -- one wave per SIMD each: a launch wants ~1024 of them, not 256, before its waves
+  // cover each other's operand loads)
+  if (d->scratch && nbatch == 1 && tiles < 768 && d->K >= 1024) {
+    int64_t want = (1024 + tiles - 1) / tiles;
     const int64_t by_k = d->K / 256, by_mem = d->scratch_floats / (d->M * d->N);
     if (want > by_k) want = by_k;
     if (want > by_mem) want = by_mem;
