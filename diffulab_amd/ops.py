@@ -834,11 +834,12 @@ def f32_gemm(A, B, C, M: int, N: int, K: int, *, lda: int, ldb: int, ldc: int, t
     _call("dl_f32_gemm", ctypes.addressof(d), _s())
 
 
-def f32_linear(x, w, out, *, bias=None, act: int = ACT_NONE, pre_out=None, M: int | None = None) -> None:
-    """out[M, out_f] = act(x[M, in_f] w[out_f, in_f]^T + bias)   (nn.Linear forward)"""
+def f32_linear(x, w, out, *, bias=None, act: int = ACT_NONE, pre_out=None, M: int | None = None, scratch=None) -> None:
+    """out[M, out_f] = act(x[M, in_f] w[out_f, in_f]^T + bias)   (nn.Linear forward); scratch: split-K partial images for products
+    with few output tiles and a long contraction (the deep UNet levels' convolutions)"""
     M = x.shape[0] if M is None else M
     f32_gemm(x, w, out, M, w.shape[0], w.shape[1], lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=bias, act=act,
-             pre_out=pre_out)
+             pre_out=pre_out, scratch=scratch)
 
 
 def f32_linear_dgrad(dy, w, dx, *, M: int | None = None, scratch=None) -> None:

@@ -129,7 +129,9 @@ class UNetEngineF32(UNetEngine):
         cols = self._scr("cols", M * 9 * ci).view(M, 9 * ci)
         ops.f32_im2col3x3(x, cols, B, H, W, ci)
         out = self._new(M, co)
-        ops.f32_linear(cols, self.P(name).view(co, 9 * ci), out, bias=self.P(name[:-6] + "bias"))
+        # (deep levels: few output tiles over a 9 ci contraction -- split-K partials where the product would not fill the chip)
+        ops.f32_linear(cols, self.P(name).view(co, 9 * ci), out, bias=self.P(name[:-6] + "bias"),
+                       scratch=self._wscr(M * co) if M * co <= (1 << 23) else None)
         if resid is not None:  # x + h of the ResBlock (unet.py:237)
             ops.f32_add(out, resid, out)
         return out
@@ -147,7 +149,8 @@ class UNetEngineF32(UNetEngine):
         if not need_dx:
             return None
         dcols = cols  # (the im2col matrix is dead after the weight gradient: reuse its storage)
-        ops.f32_gemm(dyv, w, dcols, M, 9 * ci, co, lda=dy.stride(0), ldb=9 * ci, ldc=9 * ci, tb=True)
+        ops.f32_gemm(dyv, w, dcols, M, 9 * ci, co, lda=dy.stride(0), ldb=9 * ci, ldc=9 * ci, tb=True,
+                     scratch=self._wscr(M * 9 * ci) if M * 9 * ci <= (1 << 23) else None)
         dx = self._new(M, ci)
         ops.f32_col2im3x3(dcols, dx, B, H, W, ci)
         return dx
