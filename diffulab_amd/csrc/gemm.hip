@@ -1266,7 +1266,7 @@ extern "C" int dl_gemm_nt_f32_det(const void* A, int64_t lda, const void* B, int
 /* out[p, co] = bias[co] + sum_{tap, ci} x[p + shift(tap), ci] * Wf[co, tap*Ci + ci] (+ resid[p, co]); x NHWC rows [B*H*W, ldx].
  * Wf is the (tap, ci)-ordered shadow of dl_cast_conv3x3_weight (the rotated one gives the data gradient). */
 // second half of a split-K convolution: out = bf16(acc + bias + resid)
-__global__ void conv_splitk_finalize_k(const float* __restrict__ acc, const float* __restrict__ bias,
+__global__ void conv_splitk_finalize_k(const float* __restrict__ acc, int splits, int64_t stride, const float* __restrict__ bias,
                                        const bf16_t* __restrict__ resid, int64_t ldr, bf16_t* __restrict__ out, int64_t ldc,
                                        int64_t M, int N) {
   const int N8 = N >> 3;
@@ -1277,6 +1277,14 @@ __global__ void conv_splitk_finalize_k(const float* __restrict__ acc, const floa
     float v[8], r[8];
     *(f32x4_t*)&v[0] = *(const f32x4_t*)(acc + m * N + n);
     *(f32x4_t*)&v[4] = *(const f32x4_t*)(acc + m * N + n + 4);
+    for (int p = 1; p < splits; ++p) {  // the partial images in a fixed order
+      const f32x4_t a = *(const f32x4_t*)(acc + p * stride + m * N + n), b = *(const f32x4_t*)(acc + p * stride + m * N + n + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] += a[e];
+        v[4 + e] += b[e];
+      }
+    }
     if (resid) unpack8(*(const u32x4_t*)(resid + m * ldr + n), r);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += (bias ? bias[n + e] : 0.f) + (resid ? r[e] : 0.f);
@@ -1295,24 +1303,26 @@ extern "C" int dl_conv3x3_nt(const void* x, int64_t ldx, int64_t Bn, int64_t H, 
   const int64_t M = Bn * H * W, K = 9 * Ci;
   const ConvGeom cg = make_conv_geom(H, W, Ci, ldx, M, zero);
   const int nwg = cdiv(M, BM) * cdiv(Co, BN);
-  // low-resolution levels: few output tiles with a deep contraction (K = 9*Ci up to 18432) -> split K over blockIdx.y, the
-  // partial tiles meet in the caller's f32 scratch [M, Co] through atomics, a second pass adds bias / residual and rounds
+  // low-resolution levels: few output tiles with a deep contraction (K = 9*Ci up to 18432) -> split K over blockIdx.y; every split
+  // stores its partial [M, Co] image into the caller's f32 scratch (up to four images), a second pass adds them in a fixed order with
+  // bias / residual and rounds (no atomics: bit-reproducible).  The 256-thread workgroups run two to a CU: a launch wants ~512.
   int ksplit = 1;
-  if (splitk_scratch && nwg <= 160 && K >= 4608 && Co % 8 == 0) {
-    ksplit = 384 / nwg;
+  if (splitk_scratch && nwg <= 320 && K >= 2304 && Co % 8 == 0) {
+    ksplit = (512 + nwg - 1) / nwg;
+    if (ksplit > 4) ksplit = 4;
     if (ksplit > (int)(K / 1152)) ksplit = (int)(K / 1152);
     if (ksplit < 2) ksplit = 1;
   }
   if (ksplit > 1) {
-    if (hipMemsetAsync(splitk_scratch, 0, (size_t)M * Co * 4, (hipStream_t)stream) != hipSuccess) return DL_ERR_LAUNCH;
     NtEpilogue ep0{};
     ep0.rows_per_gate = 1;
+    ep0.part_stride = M * Co;
     hipLaunchKernelGGL(gemm_nt_k<true>, dim3(nwg, ksplit), NT_THREADS, NT_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)x, ldx,
                        (const bf16_t*)Wf, ldw, splitk_scratch, Co, (int)M, (int)Co, (int)K, ep0, ksplit, cg);
     int64_t g = (M * (Co / 8) + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(conv_splitk_finalize_k, (int)g, 256, 0, (hipStream_t)stream, splitk_scratch, bias, (const bf16_t*)resid, ldr,
-                       (bf16_t*)out, ldc, M, (int)Co);
+    hipLaunchKernelGGL(conv_splitk_finalize_k, (int)g, 256, 0, (hipStream_t)stream, splitk_scratch, ksplit, M * Co, bias,
+                       (const bf16_t*)resid, ldr, (bf16_t*)out, ldc, M, (int)Co);
     DL_LAUNCH_CHECK();
     return DL_OK;
   }
