@@ -1304,12 +1304,12 @@ extern "C" int dl_conv3x3_nt(const void* x, int64_t ldx, int64_t Bn, int64_t H, 
   const ConvGeom cg = make_conv_geom(H, W, Ci, ldx, M, zero);
   const int nwg = cdiv(M, BM) * cdiv(Co, BN);
   // low-resolution levels: few output tiles with a deep contraction (K = 9*Ci up to 18432) -> split K over blockIdx.y; every split
-  // stores its partial [M, Co] image into the caller's f32 scratch (up to four images), a second pass adds them in a fixed order with
+  // stores its partial [M, Co] image into the caller's f32 scratch (up to eight images), a second pass adds them in a fixed order with
   // bias / residual and rounds (no atomics: bit-reproducible).  The 256-thread workgroups run two to a CU: a launch wants ~512.
   int ksplit = 1;
   if (splitk_scratch && nwg <= 320 && K >= 2304 && Co % 8 == 0) {
     ksplit = (512 + nwg - 1) / nwg;
-    if (ksplit > 4) ksplit = 4;
+    if (ksplit > 8) ksplit = 8;
     if (ksplit > (int)(K / 1152)) ksplit = (int)(K / 1152);
     if (ksplit < 2) ksplit = 1;
   }

@@ -737,9 +737,9 @@ def _maybe(name: str, *args) -> bool:
 
 
 def conv3x3_nt(x, B, H, W, ci, wf, out, co, bias, resid, zero, scratch=None) -> bool:
-    """implicit-GEMM 3x3 conv (forward, or data gradient with the rotated shadow); `scratch` (f32, >= 4*B*H*W*co: up to four
+    """implicit-GEMM 3x3 conv (forward, or data gradient with the rotated shadow); `scratch` (f32, >= 8*B*H*W*co: up to eight
     partial images) lets the low-resolution levels split K.  False -> use im2col3x3 + gemm_nt"""
-    assert scratch is None or (scratch.dtype == torch.float32 and scratch.numel() >= 4 * B * H * W * co)
+    assert scratch is None or (scratch.dtype == torch.float32 and scratch.numel() >= 8 * B * H * W * co)
     return _maybe("dl_conv3x3_nt", _p(x), x.stride(0), B, H, W, ci, _p(wf), wf.stride(0), _p(out), out.stride(0), co, _p(bias),
                   _p(resid), resid.stride(0) if resid is not None else 0, _p(zero), _p(scratch), _s())
 

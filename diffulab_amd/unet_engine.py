@@ -317,10 +317,10 @@ class UNetEngine:
         return t[:numel]
 
     def _splitk(self, M: int, n: int) -> Tensor | None:
-        """f32 scratch (four partial images) for the split-K path of the low-resolution convolutions (DL_UNET_SPLITK)"""
+        """f32 scratch (eight partial images) for the split-K path of the low-resolution convolutions (DL_UNET_SPLITK)"""
         if M > 16384 or not tuning.on("DL_UNET_SPLITK"):
             return None
-        return self._scr("splitk", 4 * M * n, torch.float32)
+        return self._scr("splitk", 8 * M * n, torch.float32)
 
     def _padded(self, x: Tensor, rows: int, cols: int) -> Tensor:
         """x [M, C] -> zero-padded [rows, cols] copy when the GEMM alignment (K % 64, reduction rows % 64) needs it"""
