@@ -25,4 +25,5 @@ torch.cuda.synchronize()
 s = io.StringIO()
 st = pstats.Stats(pr, stream=s).sort_stats("tottime")
 st.print_stats(28)
+st.print_callers("method 'to' of|synchronize|item|cpu'")
 print(s.getvalue()[:6000])
