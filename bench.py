@@ -444,14 +444,23 @@ def self_launch(n: int) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
-    codes = []
+    codes: list[int] = []
     try:
-        for p in procs:
-            codes.append(p.wait())
-            if codes[-1] != 0:  # a rank died: the others would wait in a collective forever
-                for q in procs:
-                    if q.poll() is None:
+        # poll ALL ranks: whichever dies first (device init, out of memory) takes the others down at once -- they would sit in
+        # init_process_group / a collective until the store timeout otherwise
+        live = list(procs)
+        while live:
+            for p in list(live):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                live.remove(p)
+                codes.append(rc)
+                if rc != 0:
+                    for q in live:
                         q.terminate()
+            if live:
+                time.sleep(0.05)
     except KeyboardInterrupt:
         for q in procs:
             if q.poll() is None:

@@ -414,8 +414,13 @@ __global__ __launch_bounds__(512) void attn_fwd_qkn_k(const bf16_t* __restrict__
   for (int ks = 0; ks < 4; ++ks) {
     const int d0 = ks * 16 + hi * 8;
     qraw[ks] = *(const u32x4_t*)(base + (int64_t)qrow * qn.pitch + d0);
-    qc[ks] = *(const f32x4_t*)(qn.cs + (int64_t)qrow * half + (d0 >> 1));
-    qs[ks] = *(const f32x4_t*)(qn.sn + (int64_t)qrow * half + (d0 >> 1));
+    // the tables are [N, rot / 2]: only the rotated channels have an entry (rot < 64: the next row / past the end; rot == 0: NULL)
+    if (d0 < qn.rot) {
+      qc[ks] = *(const f32x4_t*)(qn.cs + (int64_t)qrow * half + (d0 >> 1));
+      qs[ks] = *(const f32x4_t*)(qn.sn + (int64_t)qrow * half + (d0 >> 1));
+    } else {
+      qc[ks] = qs[ks] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
   }
   const int kslot = threadIdx.x & 7, kd0 = kslot * 8, krow0 = threadIdx.x >> 3, kstep = blockDim.x >> 3;
   float kssq[4];
@@ -425,8 +430,12 @@ __global__ __launch_bounds__(512) void attn_fwd_qkn_k(const bf16_t* __restrict__
     const int row = krow0 + i * kstep;
     if (row < N) {
       kssq[i] = qn.ssq[((int64_t)b * N + row) * 2 + 1];
-      kc[i] = *(const f32x4_t*)(qn.cs + (int64_t)row * half + (kd0 >> 1));
-      kn[i] = *(const f32x4_t*)(qn.sn + (int64_t)row * half + (kd0 >> 1));
+      if (kd0 < qn.rot) {
+        kc[i] = *(const f32x4_t*)(qn.cs + (int64_t)row * half + (kd0 >> 1));
+        kn[i] = *(const f32x4_t*)(qn.sn + (int64_t)row * half + (kd0 >> 1));
+      } else {
+        kc[i] = kn[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
     }
   }
   // ---- this wave's query rows: normalised + rotated in registers

@@ -426,7 +426,15 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
     __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would drain vmcnt (the DMA counts as an LDS write)
     // NST >= 3: the DMA for stage it+NST-1 is issued AFTER this step's MFMAs are queued (its issue is bound by the
     // 64 B/clk vector-memory path; up front it would hold every wave off the matrix pipe for ~900 cycles)
+#ifdef NT_DEPHASE
+    // LAB: de-phased operand issue -- waves 0-3 (one per SIMD) issue their share of the next stage up front, waves 4-7 (their SIMD
+    // partners) after NT_DEPHASE of the k-step's 4*JN MFMA pairs, so that on every SIMD one wave is in its matrix phase while the
+    // other sits in the vector-memory issue queue
+    const bool issue_late = wave >= 4;
+    if (NST < 3 && s_it < total && !issue_late) stage_next();
+#else
     if (NST < 3 && s_it < total) stage_next();  // into the slot whose stage was consumed in iteration it-1
+#endif
     const char* sa = smem + (it % NST) * STAGE;
     const char* sb = sa + TBM * 128;
     {
@@ -449,6 +457,9 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
       for (int s = 0; s < 4 * JN; ++s) {
         const int kk = s / JN, j = s % JN;
         __builtin_amdgcn_sched_barrier(0);
+#ifdef NT_DEPHASE
+        if (NST < 3 && s == NT_DEPHASE * JN && issue_late && s_it < total) stage_next();
+#endif
         if (s + 2 < 4 * JN) wq[(s + 2) % 3] = rd_w((s + 2) / JN, (s + 2) % JN);
         if (kk < 3 && j < 2) xq[(kk + 1) & 1][j] = rd_x(kk + 1, j);
 #pragma unroll
@@ -1293,7 +1304,7 @@ __global__ void conv_splitk_finalize_k(const float* __restrict__ acc, int splits
 }
 extern "C" int dl_conv3x3_nt(const void* x, int64_t ldx, int64_t Bn, int64_t H, int64_t W, int64_t Ci, const void* Wf,
                              int64_t ldw, void* out, int64_t ldc, int64_t Co, const float* bias, const void* resid,
-                             int64_t ldr, const void* zero, float* splitk_scratch, dl_stream_t stream) {
+                             int64_t ldr, const void* zero, float* splitk_scratch, int64_t scratch_floats, dl_stream_t stream) {
   DL_CHECK_ARG(x && Wf && out && zero && Bn > 0 && H > 0 && W > 0 && Co > 0, "dl_conv3x3_nt: bad args");
   if (Ci % 64 != 0) return DL_ERR_UNSUPPORTED;  // caller materialises cols with dl_im2col3x3 (e.g. the 1-channel stem)
   DL_CHECK_ARG(ldx % 8 == 0 && ldx >= Ci && ldw % 8 == 0 && ldw >= 9 * Ci && ldc % 8 == 0 && ldc >= Co,
@@ -1311,6 +1322,7 @@ extern "C" int dl_conv3x3_nt(const void* x, int64_t ldx, int64_t Bn, int64_t H, 
     ksplit = (512 + nwg - 1) / nwg;
     if (ksplit > 8) ksplit = 8;
     if (ksplit > (int)(K / 1152)) ksplit = (int)(K / 1152);
+    if (ksplit > scratch_floats / (M * Co)) ksplit = (int)(scratch_floats / (M * Co));  // never more images than the scratch holds
     if (ksplit < 2) ksplit = 1;
   }
   if (ksplit > 1) {

@@ -107,6 +107,7 @@ class FlatArenaDenoiser(Denoiser):
                                       f"{', '.join(self.precisions)}); the fp32-class regime exists for the class-conditional forms (MMDiT / SprintDiT simple_dit=True, DDT simple_ddt=True) and UNetModel")
         if precision != self.precision:
             object.__setattr__(self, "_precision", precision)
+            object.__setattr__(self, "_carried_reducer", getattr(self._engine, "reducer", None))  # (flatten_parameters re-attaches it)
             object.__setattr__(self, "_engine", None)  # the next forward re-flattens onto the other engine (same arena layout)
             object.__setattr__(self, "_graphs", None)
         return self
@@ -164,6 +165,10 @@ class FlatArenaDenoiser(Denoiser):
         if dev.type != "cuda":
             raise RuntimeError(f"diffulab_amd.{type(self).__name__} runs on an MI355X only: move the module to 'cuda' "
                                "(no CPU fallback)")
+        # a gradient reducer attached by the trainer's prepare() survives a re-flattening / an engine of the other precision: it
+        # is handed to the new engine and re-pointed at the new gradient arena below (dropping it would silently stop the
+        # data-parallel gradient exchange)
+        reducer = getattr(self._engine, "reducer", None) or self.__dict__.get("_carried_reducer")
         if self._engine is None or self._engine.dev != dev or getattr(self._engine, "precision", "bf16") != self.precision:
             object.__setattr__(self, "_engine", self._make_engine(dev))
         lay = self._engine.layout
@@ -186,6 +191,10 @@ class FlatArenaDenoiser(Denoiser):
         object.__setattr__(self, "_anchor", anchor)
         object.__setattr__(self, "_plist", None)  # (the parameter objects may be new ones: _param_version rebuilds its list)
         self._engine.bind(flat, grad)
+        if reducer is not None:
+            reducer.rebind(grad)
+            self._engine.reducer = reducer
+            object.__setattr__(self, "_carried_reducer", None)
 
     def _prepare_grads(self) -> None:
         """called at the start of every backward: honour optimizer.zero_grad(set_to_none=True) (torch default) by

@@ -27,14 +27,17 @@ class PrecomputedEmbedder(ContextEmbedder):
     def _null_on(self, device: torch.device, dtype: torch.dtype) -> tuple[Tensor, Tensor]:
         """the null embedding and its mask on `device` (precomputed.py:28-29 converts them in every call: from the host tensors
         that is a blocking copy per training step, i.e. a full synchronisation of the device queue -- the joint text-image steps ran
-        52 ms instead of 32 with it).  The copies are kept per (device, dtype) and dropped when the attributes are replaced."""
+        52 ms instead of 32 with it).  The copies are kept per (device, dtype) and dropped when the attributes are replaced or modified in place."""
         src = (self.null_embedding, self.null_embedding_mask)
         cache = self.__dict__.setdefault("_null_cache", {})
         hit = cache.get((device, dtype))
-        if hit is None or hit[0] is not src[0] or hit[1] is not src[1]:
-            hit = (src[0], src[1], src[0].to(device=device, dtype=dtype), src[1].to(device=device))
+        # (identity AND version counter: an in-place update of the attributes -- `.copy_()`, `.mul_()`, loading another null
+        # embedding into the same tensor -- must be seen, as the reference's per-call conversion sees it)
+        key = (src[0], src[1], src[0]._version, src[1]._version)
+        if hit is None or hit[0] is not key[0] or hit[1] is not key[1] or hit[2:4] != key[2:4]:
+            hit = (*key, src[0].to(device=device, dtype=dtype), src[1].to(device=device))
             cache[(device, dtype)] = hit
-        return hit[2], hit[3]
+        return hit[4], hit[5]
 
     def _draw_drop(self, batch_size: int, p: float, device: torch.device) -> Tensor:
         return torch.rand(batch_size, device=device) < p  # precomputed.py:27

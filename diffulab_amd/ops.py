@@ -737,11 +737,13 @@ def _maybe(name: str, *args) -> bool:
 
 
 def conv3x3_nt(x, B, H, W, ci, wf, out, co, bias, resid, zero, scratch=None) -> bool:
-    """implicit-GEMM 3x3 conv (forward, or data gradient with the rotated shadow); `scratch` (f32, >= 8*B*H*W*co: up to eight
-    partial images) lets the low-resolution levels split K.  False -> use im2col3x3 + gemm_nt"""
-    assert scratch is None or (scratch.dtype == torch.float32 and scratch.numel() >= 8 * B * H * W * co)
+    """implicit-GEMM 3x3 conv (forward, or data gradient with the rotated shadow); `scratch` (f32; the library splits K into as many
+    partial images of B*H*W*co floats as it holds, up to eight) lets the low-resolution levels split K.  False -> use im2col3x3 +
+    gemm_nt"""
+    assert scratch is None or scratch.dtype == torch.float32
     return _maybe("dl_conv3x3_nt", _p(x), x.stride(0), B, H, W, ci, _p(wf), wf.stride(0), _p(out), out.stride(0), co, _p(bias),
-                  _p(resid), resid.stride(0) if resid is not None else 0, _p(zero), _p(scratch), _s())
+                  _p(resid), resid.stride(0) if resid is not None else 0, _p(zero), _p(scratch),
+                  scratch.numel() if scratch is not None else 0, _s())
 
 
 def conv3x3_wgrad_tn(x, B, H, W, ci, dy, co, g, zero, max_wgs: int = 0) -> bool:

@@ -75,6 +75,15 @@ class GradReducer:
         self.tuned: dict | None = None
         self._tune = {"step": 0, "marks": []} if (mode == "auto" and self.enabled) else None
 
+    def rebind(self, flat_grad: Tensor) -> None:
+        """point the reducer at a NEW gradient arena of the same layout (the denoiser re-flattened its parameters or switched
+        its precision regime after prepare()): nothing may be in flight"""
+        if self._pending or self._works:
+            raise RuntimeError("GradReducer.rebind: a gradient exchange is in flight (finish() the step first)")
+        if flat_grad.numel() != self.flat.numel():
+            raise RuntimeError(f"GradReducer.rebind: arena size changed ({self.flat.numel()} -> {flat_grad.numel()})")
+        self.flat = flat_grad
+
     # -- called by the engine's backward, ranges arrive high-to-low as blocks finish
     def ready(self, lo: int, hi: int, extra_events=(), flush: bool = False) -> None:
         """[lo, hi) of the arena is final once the current stream AND `extra_events` (side-stream producers) are reached.

@@ -485,13 +485,13 @@ DL_API int dl_cast_conv3x3_weight(const float* w, int64_t Co, int64_t Ci, void* 
 /* implicit-GEMM 3x3 / pad-1 convolution (no cols matrix: the GEMM's operand loads gather the taps, out-of-image taps read
  * the caller's `zero` line of >= 16 zero bytes):  out[p, co] = bias[co] + sum_{tap,ci} x[p + shift(tap), ci] Wf[co, tap*Ci+ci]
  * (+ resid[p, co]).  Wf = forward shadow of dl_cast_conv3x3_weight; with the rotated shadow and x = dY it is the data
- * gradient.  splitk_scratch: optional caller workspace of 8*B*H*W*Co floats; when given, launches with few output tiles and a
- * deep contraction (the low-resolution UNet levels) split K across workgroups into up to eight partial images and finish in a second
- * pass that adds them in a fixed order (no atomics).
+ * gradient.  splitk_scratch: optional caller workspace of `scratch_floats` floats; when given, launches with few output tiles and a
+ * deep contraction (the low-resolution UNet levels) split K across workgroups into min(8, scratch_floats / (B*H*W*Co)) partial images
+ * and finish in a second pass that adds them in a fixed order (no atomics); a scratch smaller than two images is not used.
  * Returns DL_ERR_UNSUPPORTED when Ci % 64 != 0 (caller then uses dl_im2col3x3 + dl_gemm_nt). */
 DL_API int dl_conv3x3_nt(const void* x, int64_t ldx, int64_t B, int64_t H, int64_t W, int64_t Ci, const void* Wf,
                          int64_t ldw, void* out, int64_t ldc, int64_t Co, const float* bias, const void* resid,
-                         int64_t ldr, const void* zero, float* splitk_scratch, dl_stream_t stream);
+                         int64_t ldr, const void* zero, float* splitk_scratch, int64_t scratch_floats, dl_stream_t stream);
 /* implicit-GEMM weight gradient, transposed like dl_conv3x3_wgrad_fold expects:
  * g[(tap, ci), co] += sum_p x[p + shift(tap), ci] dY[p, co]; dY rows [R, ldy], R % 64 == 0, rows >= B*H*W zero; Co % 8 == 0.
  * max_workgroups caps the persistent workgroups like dl_gemm_tn_ex (0 = one per CU).  Returns DL_ERR_UNSUPPORTED when Ci % 128 != 0. */

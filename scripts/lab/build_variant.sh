@@ -1,12 +1,12 @@
 #!/bin/bash
 # LAB: build an A/B copy of the product library with extra compiler flags on some sources:
-#   scripts/lab/build_variant.sh NAME "-DFOO=1" mlp_bwd.hip gemm.hip   ->  diffulab_amd/csrc/build/libdiffulab_hip_NAME.so
-# (load it with DIFFULAB_HIP_LIB=<that path>; build/ is git-ignored and travels to the GPU box)
+#   scripts/lab/build_variant.sh NAME "-DFOO=1" mlp_bwd.hip gemm.hip   ->  diffulab_amd/csrc/variants/libdiffulab_hip_NAME.so
+# (load it with DIFFULAB_HIP_LIB=<that path>; variants/*.so is git-ignored but not gpurun-ignored: it travels to the GPU box)
 set -e
 cd "$(dirname "$0")/../../diffulab_amd/csrc"
 name=$1; flags=$2; shift 2
 make -s ../libdiffulab_hip.so
-mkdir -p build/lab_$name
+mkdir -p build/lab_$name variants
 objs=""
 for src in elementwise gemm gemm_ln gemm_w4 mlp_bwd norm attention embed unet tokens block f32; do
   if [[ " $* " == *" $src.hip "* ]]; then
@@ -18,5 +18,5 @@ for src in elementwise gemm gemm_ln gemm_w4 mlp_bwd norm attention embed unet to
   fi
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o build/libdiffulab_hip_$name.so
-echo "built diffulab_amd/csrc/build/libdiffulab_hip_$name.so"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o variants/libdiffulab_hip_$name.so
+echo "built diffulab_amd/csrc/variants/libdiffulab_hip_$name.so"

@@ -109,6 +109,14 @@ def test_module_contract_and_layout():
 
     emb = PrecomputedEmbedder(torch.zeros(1, 16, 96), null_embedding_seq_len=3)
     assert emb.n_output == 1 and emb.output_size == (96,) and int(emb.null_embedding_mask.sum()) == 3
+    # the per-(device, dtype) copy of the null embedding follows IN-PLACE updates of the attribute (the reference converts per call)
+    ctx = {"embeddings": torch.ones(2, 16, 96), "attn_mask": torch.ones(2, 16, dtype=torch.bool)}
+    assert float(emb.drop_conditions(ctx, 1.0)["embeddings"].abs().sum()) == 0.0
+    emb.null_embedding.add_(2.0)
+    assert bool((emb.drop_conditions(ctx, 1.0)["embeddings"] == 2.0).all())
+    emb.null_embedding_mask[:] = True
+    assert bool(emb.drop_conditions(ctx, 1.0)["attn_mask"].all())
+    emb.null_embedding.zero_()
     jkw = dict(simple_dit=False, context_embedder=emb, input_channels=4, inner_dim=128, embedding_dim=64, num_heads=2, patch_size=2,
                depth=2, rope_axes_dim=[16, 24, 24])
     mj = MMDiT(**jkw)

@@ -156,7 +156,8 @@ def test_gemm_nt_qk_norm_rope_equals_gemm_then_row_kernel(ops, B, gh, gw):
     q0, k0 = (torch.full((B, H, Nt, dh), 7.0, device=DEV, dtype=torch.bfloat16) for _ in range(2))
     r0 = torch.zeros(M, 2, device=DEV)
     ops.gemm_nt(a, w, qkv0)
-    ops.qk_norm_rope_fwd(qkv0, sq, sk, cos, sin, q0, k0, None, r0, B, Nt, H, dh, 64)
+    dummy = torch.zeros(8, device=DEV)  # (the unfused pass wants non-NULL tables even when it rotates nothing)
+    ops.qk_norm_rope_fwd(qkv0, sq, sk, cos if axes else dummy, sin if axes else dummy, q0, k0, None, r0, B, Nt, H, dh, rot)
     qkv1 = torch.full((M, 3 * D), 7.0, device=DEV, dtype=torch.bfloat16)
     q1, k1 = (torch.full((B, H, Nt, dh), 7.0, device=DEV, dtype=torch.bfloat16) for _ in range(2))
     r1 = torch.zeros(M, 2, device=DEV)
@@ -181,12 +182,14 @@ def test_row_gemms_decline_other_shapes(ops):
     assert not ops.ln_modulate_gemm_fwd(a, w, None, None, None, None, mod[:, :D], mod[:, D : 2 * D], 64, 1e-5, None, o, o, mu, mu)
 
 
-@pytest.mark.parametrize("B,gh,gw", [(24, 16, 16), (40, 16, 16)])
-def test_qkv_gemm_with_row_statistics_and_attention_with_qk_norm_on_load(ops, B, gh, gw):
+@pytest.mark.parametrize("B,gh,gw,axes", [(24, 16, 16, [32, 32]), (40, 16, 16, [32, 32]), (24, 16, 16, [16, 16]), (24, 16, 16, None)])
+def test_qkv_gemm_with_row_statistics_and_attention_with_qk_norm_on_load(ops, B, gh, gw, axes):
     """round 4: dl_gemm_nt_ssq + dl_attn_fwd_qkn (QK-RMSNorm statistics from the qkv GEMM's epilogue, norm + RoPE applied as the
     attention stages q and k) against the sequence they replace, dl_gemm_nt -> dl_qk_norm_rope_fwd -> dl_attn_fwd_sv: qkv bit for
     bit, rrms to 1e-6, the normalised q / k to a bf16 ulp on a few elements per thousand, the attention output and lse to the
-    accuracy those ulps allow; two runs give identical bits (two addends per statistics word)"""
+    accuracy those ulps allow; two runs give identical bits (two addends per statistics word).  axes = rope_axes_dim: [16, 16]
+    rotates 32 of the 64 channels of a head (tables [N, 16]: the loads of the un-rotated channels must not touch them), None = no
+    rotary embedding at all (NULL tables)"""
     H, dh = 6, 64
     Nt = gh * gw
     M = B * Nt
@@ -194,14 +197,17 @@ def test_qkv_gemm_with_row_statistics_and_attention_with_qk_norm_on_load(ops, B,
     w = dev_bf(synth.normal("qn.w", (3 * D, D), std=D**-0.5))
     sq = (1 + synth.normal("qn.sq", (D,), std=0.1)).to(DEV)
     sk = (1 + synth.normal("qn.sk", (D,), std=0.1)).to(DEV)
-    cos, sin = (t.to(DEV) for t in odit.rope_tables(gh, gw, [32, 32], 10_000.0))
+    rot = sum(axes) if axes else 0
+    # (the tables are allocated exactly [N, rot / 2]: a read past the end of the last row faults or meets the guard value)
+    cos, sin = (t.to(DEV).contiguous() for t in odit.rope_tables(gh, gw, axes, 10_000.0)) if axes else (None, None)
     bf = dict(device=DEV, dtype=torch.bfloat16)
 
     qkv0 = torch.empty(M, 3 * D, **bf)
     q0, k0 = (torch.empty(B, H, Nt, dh, **bf) for _ in range(2))
     r0, o0, l0 = torch.zeros(M, 2, device=DEV), torch.empty(M, D, **bf), torch.empty(B, H, Nt, device=DEV)
     ops.gemm_nt(a, w, qkv0)
-    ops.qk_norm_rope_fwd(qkv0, sq, sk, cos, sin, q0, k0, None, r0, B, Nt, H, dh, 64)
+    dummy = torch.zeros(8, device=DEV)  # (the unfused pass wants non-NULL tables even when it rotates nothing)
+    ops.qk_norm_rope_fwd(qkv0, sq, sk, cos if axes else dummy, sin if axes else dummy, q0, k0, None, r0, B, Nt, H, dh, rot)
     ops.attn_fwd_qkv(q0, k0, qkv0, o0, l0, B, H, Nt, dh, dh**-0.5)
 
     def fused():
@@ -210,7 +216,7 @@ def test_qkv_gemm_with_row_statistics_and_attention_with_qk_norm_on_load(ops, B,
         ssq = torch.zeros(M, 2, device=DEV)
         r1, o1, l1 = torch.zeros(M, 2, device=DEV), torch.empty(M, D, **bf), torch.empty(B, H, Nt, device=DEV)
         assert ops.gemm_nt_ssq(a, w, qkv1, ssq)
-        ops.attn_fwd_qkn(qkv1, ssq, sq, sk, cos, sin, q1, k1, r1, o1, l1, B, H, Nt, dh, 64, dh**-0.5)
+        ops.attn_fwd_qkn(qkv1, ssq, sq, sk, cos, sin, q1, k1, r1, o1, l1, B, H, Nt, dh, rot, dh**-0.5)
         torch.cuda.synchronize()
         return qkv1, ssq, q1, k1, r1, o1, l1
 

@@ -255,6 +255,39 @@ class _RangeRecorder:
     def finish(self):
         self.finished = True
 
+    def rebind(self, flat_grad):
+        self.rebound = flat_grad
+
+
+def test_reducer_survives_a_precision_switch_after_prepare():
+    """set_precision() after the trainer's prepare() drops the engine the reducer was attached to; the engine that
+    replaces it (and a plain re-flattening) must carry the reducer over, re-pointed at the NEW gradient arena -- otherwise a
+    data-parallel run silently stops exchanging gradients"""
+    import diffulab_amd as da
+
+    m = da.MMDiT(simple_dit=True, input_channels=4, output_channels=4, inner_dim=128, embedding_dim=64, num_heads=2, mlp_ratio=4,
+                 patch_size=2, depth=2, n_classes=10).to(DEV).train()
+    rec = _RangeRecorder()
+    m.engine.reducer = rec
+    old_engine, old_grad = m.engine, m._flat_grad
+    m.set_precision("fp32")
+    eng = m.engine
+    assert eng is not old_engine and eng.reducer is rec and rec.rebound is m._flat_grad and m._flat_grad is not old_grad
+    m.flatten_parameters()  # same engine, new arena
+    assert m.engine.reducer is rec and rec.rebound is m._flat_grad
+    x = torch.randn(4, 4, 16, 16, device=DEV)
+    m(x=x, timesteps=torch.rand(4, device=DEV), y=torch.randint(0, 10, (4,), device=DEV))["x"].square().mean().backward()
+    torch.cuda.synchronize()
+    assert rec.finished and sorted(rec.ranges)[0][0] == 0 and max(hi for _, hi in rec.ranges) == m._flat_grad.numel()
+    from diffulab_amd.training.dp import GradReducer
+
+    red = GradReducer(torch.zeros(8, device=DEV))
+    new = torch.zeros(8, device=DEV)
+    red.rebind(new)
+    assert red.flat is new
+    with pytest.raises(RuntimeError):
+        red.rebind(torch.zeros(9, device=DEV))
+
 
 @pytest.mark.parametrize("family", ["dit", "sprint", "ddt", "joint", "sprint_joint", "ddt_joint", "unet", "dit:fp32", "sprint:fp32", "ddt:fp32",
                                     "unet:fp32"])
