@@ -426,15 +426,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
     __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would drain vmcnt (the DMA counts as an LDS write)
     // NST >= 3: the DMA for stage it+NST-1 is issued AFTER this step's MFMAs are queued (its issue is bound by the
     // 64 B/clk vector-memory path; up front it would hold every wave off the matrix pipe for ~900 cycles)
-#ifdef NT_DEPHASE
-    // LAB: de-phased operand issue -- waves 0-3 (one per SIMD) issue their share of the next stage up front, waves 4-7 (their SIMD
-    // partners) after NT_DEPHASE of the k-step's 4*JN MFMA pairs, so that on every SIMD one wave is in its matrix phase while the
-    // other sits in the vector-memory issue queue
-    const bool issue_late = wave >= 4;
-    if (NST < 3 && s_it < total && !issue_late) stage_next();
-#else
     if (NST < 3 && s_it < total) stage_next();  // into the slot whose stage was consumed in iteration it-1
-#endif
     const char* sa = smem + (it % NST) * STAGE;
     const char* sb = sa + TBM * 128;
     {
@@ -457,9 +449,6 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
       for (int s = 0; s < 4 * JN; ++s) {
         const int kk = s / JN, j = s % JN;
         __builtin_amdgcn_sched_barrier(0);
-#ifdef NT_DEPHASE
-        if (NST < 3 && s == NT_DEPHASE * JN && issue_late && s_it < total) stage_next();
-#endif
         if (s + 2 < 4 * JN) wq[(s + 2) % 3] = rd_w((s + 2) / JN, (s + 2) % JN);
         if (kk < 3 && j < 2) xq[(kk + 1) & 1][j] = rd_x(kk + 1, j);
 #pragma unroll

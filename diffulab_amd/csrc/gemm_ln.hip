@@ -452,12 +452,7 @@ __global__ __launch_bounds__(RK_THREADS, 2) void gemm_nt_rows_k(const bf16_t* __
     for (int kt = 0; kt < nk; ++kt, ++it) {
       rk_wait_vmcnt<0>();             // stage `it` has landed (two-slot ring: nothing younger is in flight)
       __builtin_amdgcn_s_barrier();   // raw barrier: every wave's DMA share has landed and the other slot's readers are done
-#ifdef NT_DEPHASE
-      const bool issue_late = wave >= 4;  // LAB: see gemm_nt_big_k
-      if (s_it < total && !issue_late) stage_next();
-#else
       if (s_it < total) stage_next();
-#endif
       const char* sa = smem + (it & 1) * RK_STAGE;
       const char* sb = sa + RK_BM * 128;
       // fragment software pipeline of gemm_nt_big_k: weight fragment two MFMA pairs ahead, activation fragments one sub-step ahead
@@ -476,9 +471,6 @@ __global__ __launch_bounds__(RK_THREADS, 2) void gemm_nt_rows_k(const bf16_t* __
       for (int s = 0; s < 4 * RK_JN; ++s) {
         const int kk = s / RK_JN, j = s % RK_JN;
         __builtin_amdgcn_sched_barrier(0);
-#ifdef NT_DEPHASE
-        if (s == NT_DEPHASE * RK_JN && issue_late && s_it < total) stage_next();
-#endif
         if (s + 2 < 4 * RK_JN) wq[(s + 2) % 3] = rd_w((s + 2) / RK_JN, (s + 2) % RK_JN);
         if (kk < 3 && j < 2) xq[(kk + 1) & 1][j] = rd_x(kk + 1, j);
 #pragma unroll

@@ -31,15 +31,11 @@ __device__ __forceinline__ void rc_wait_vmcnt() {
 
 // one 64-deep k-step of a wave: acc[j][i] += W rows (32 x JN) . X rows (32 x 2)^T over the four 16-deep sub-steps (the fragment
 // software pipeline of gemm_nt_big_k was measured here as well: 316 vs 317 us, not kept -- the kernel waits for its operand stream)
-struct RcNoMid {
-  __device__ __forceinline__ void operator()() const {}
-};
-template <int JN, class Mid = RcNoMid>
+template <int JN>
 __device__ __forceinline__ void rc_kstep(const char* sa, const char* sb, const int (&xrow)[2], const int (&wrow)[JN], int hi,
-                                         f32x16_t (&acc)[JN][2], int mid_at = -1, Mid mid = Mid()) {
+                                         f32x16_t (&acc)[JN][2]) {
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    if (kk == mid_at) mid();  // LAB (NT_DEPHASE): the late half of the waves issues its share of the next stage here
     bf16x8_t xf[2], wf[JN];
 #pragma unroll
     for (int i = 0; i < 2; ++i) xf[i] = *(const bf16x8_t*)(sa + xrow[i] * 128 + ((((kk << 1) | hi) ^ ((xrow[i] >> 1) & 7)) << 4));
@@ -172,13 +168,8 @@ __global__ __launch_bounds__(RC_THREADS, 2) void mlp_dswiglu_rc_k(const bf16_t* 
       __builtin_amdgcn_s_barrier();
       const char* sa = smem + (g & 1) * RC_STAGE;
       const char* sb = sa + RC_TBM * 128;
-#ifdef NT_DEPHASE
-      if (wave < 4 && c_g < total) issue();
-      rc_kstep<JN1>(sa, sb, xrow, wrow1, hi, acc1, NT_DEPHASE, [&]() __attribute__((always_inline)) { if (wave >= 4 && c_g < total) issue(); });
-#else
       if (c_g < total) issue();
       rc_kstep<JN1>(sa, sb, xrow, wrow1, hi, acc1);
-#endif
     }
     // acc1[j][i][0..7] = x1, [8..15] = x3 of the same 8 units (row = lane & 31 of row block i): round to bf16 like the forward's
     // stored u; pk[j][i][e] = (x1[2e], x1[2e+1]), pk[j][i][4+e] = (x3[2e], x3[2e+1])
@@ -205,13 +196,8 @@ __global__ __launch_bounds__(RC_THREADS, 2) void mlp_dswiglu_rc_k(const bf16_t* 
       __builtin_amdgcn_s_barrier();
       const char* sa = smem + (g & 1) * RC_STAGE;
       const char* sb = sa + RC_TBM * 128;
-#ifdef NT_DEPHASE
-      if (wave < 4 && c_g < total) issue();
-      rc_kstep<JN2>(sa, sb, xrow, wrow2, hi, acc2, NT_DEPHASE, [&]() __attribute__((always_inline)) { if (wave >= 4 && c_g < total) issue(); });
-#else
       if (c_g < total) issue();
       rc_kstep<JN2>(sa, sb, xrow, wrow2, hi, acc2);
-#endif
     }
     // ------------------------------------------------------------------ epilogue: du1 = dh * x3 * silu'(x1), du3 = dh * silu(x1)
     // phase-2 register 8*gp + e of unit tile j2 <-> phase-1 tile 2*j2 + gp, register e; one v_permlane32_swap per register pair

@@ -20,8 +20,8 @@ restatement of the same layout:
                        uint8 code c of the shape's integer type (uint8/16/32/64 = 0..3), uint8 ndim, ndim x (dim - 1) in that
                        type] raw little-endian element data.  dtype codes: uint8, uint16, uint32, uint64, int8, int16, int32,
                        int64, float16, float32, float64 = 0..10.
-Everything is little-endian.  Compressed shards ("compression" / "zip_data" set) and image codecs ("pil", "jpeg", "png") are
-refused when touched: recompress / re-encode with the streaming package, or export the three columns as ``.npy``
+Everything is little-endian.  Compressed shards ("compression" / "zip_data" set) are refused; image codecs ("pil", "jpeg", "png") are never DECODED (asking for
+such a column raises) -- only ``image_size`` reads their header, for the aspect-ratio buckets of ``ImageNetmultiAR``: recompress / re-encode with the streaming package, or export the three columns as ``.npy``
 (``ImageNetLatentREPA.write_split``).  Columns that are not asked for are skipped without decoding, so a shard that also carries
 an ``image`` column is readable."""
 
@@ -94,6 +94,24 @@ class _Shard:
             raise ValueError(f"{self.path}: the shard holds {n} samples, index.json says {self.samples}")
         self._off = np.frombuffer(self._mm[4 : 4 + 4 * (n + 1)], "<u4")
 
+    def sample_raw(self, i: int, column: str) -> bytes:
+        """the undecoded bytes of one column of sample ``i``"""
+        if self._mm is None:
+            self._open()
+        data = bytes(self._mm[int(self._off[i]) : int(self._off[i + 1])])
+        pos, sizes = 0, []
+        for size in self.sizes:
+            if size is None:
+                sizes.append(int(np.frombuffer(data[pos : pos + 4], "<u4")[0]))
+                pos += 4
+            else:
+                sizes.append(int(size))
+        for name, size in zip(self.names, sizes):
+            if name == column:
+                return data[pos : pos + size]
+            pos += size
+        raise KeyError(column)
+
     def sample(self, i: int, columns: tuple[str, ...] | None) -> dict[str, Any]:
         if self._mm is None:
             self._open()
@@ -143,3 +161,55 @@ class MDSDataset:
             raise IndexError(idx)
         s = bisect_right(self._starts, idx) - 1
         return self.shards[s].sample(idx - self._starts[s], self.columns)
+
+    def get(self, idx: int, columns: tuple[str, ...]) -> dict[str, Any]:
+        """sample ``idx`` decoding only ``columns`` (whatever the dataset's own column filter is)"""
+        if not 0 <= idx < len(self):
+            raise IndexError(idx)
+        s = bisect_right(self._starts, idx) - 1
+        return self.shards[s].sample(idx - self._starts[s], columns)
+
+    def image_size(self, idx: int, column: str = "image") -> tuple[int, int]:
+        """(height, width) of an image column of sample ``idx`` from the image's HEADER only (``pil`` / ``jpeg`` / ``png``
+        encodings; the pixels are never decoded) -- what the multi-aspect-ratio dataset buckets by (reference imagenet.py:113-116:
+        ``w, h = sample["image"].size``)"""
+        if not 0 <= idx < len(self):
+            raise IndexError(idx)
+        s = bisect_right(self._starts, idx) - 1
+        sh = self.shards[s]
+        enc = sh.encodings[sh.names.index(column)]
+        raw = sh.sample_raw(idx - self._starts[s], column)
+        return image_size_of(enc, raw)
+
+
+def image_size_of(encoding: str, data: bytes) -> tuple[int, int]:
+    """(height, width) from the first bytes of an MDS image column.  ``pil``: uint32 width | uint32 height | uint32 len(mode) | mode |
+    raw pixels (the streaming package's PIL encoding); ``png``: the IHDR chunk; ``jpeg``: the first start-of-frame marker."""
+    kind = encoding.partition(":")[0]
+    if kind == "pil":
+        w, h = (int(v) for v in np.frombuffer(data[:8], "<u4"))
+        return h, w
+    if kind == "png" or data[:8] == b"\x89PNG\r\n\x1a\n":
+        if data[:8] != b"\x89PNG\r\n\x1a\n" or data[12:16] != b"IHDR":
+            raise ValueError("MDS png column: not a PNG stream")
+        return int.from_bytes(data[20:24], "big"), int.from_bytes(data[16:20], "big")
+    if kind == "jpeg" or data[:2] == b"\xff\xd8":
+        if data[:2] != b"\xff\xd8":
+            raise ValueError("MDS jpeg column: not a JPEG stream")
+        i = 2
+        while i + 9 < len(data):
+            if data[i] != 0xFF:
+                raise ValueError("MDS jpeg column: lost marker synchronisation")
+            m = data[i + 1]
+            if m == 0xFF:  # fill byte
+                i += 1
+                continue
+            if 0xD0 <= m <= 0xD9 or m == 0x01:  # standalone markers
+                i += 2
+                continue
+            seg = int.from_bytes(data[i + 2 : i + 4], "big")
+            if 0xC0 <= m <= 0xCF and m not in (0xC4, 0xC8, 0xCC):  # SOFn: precision | height | width
+                return int.from_bytes(data[i + 5 : i + 7], "big"), int.from_bytes(data[i + 7 : i + 9], "big")
+            i += 2 + seg
+        raise ValueError("MDS jpeg column: no start-of-frame marker")
+    raise NotImplementedError(f"image size of MDS column encoding {encoding!r} (supported: pil, png, jpeg)")

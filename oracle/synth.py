@@ -168,3 +168,15 @@ def write_mds(root: str, columns: dict[str, str], samples: list[dict], shard_sam
         shards.append({**info, "raw_data": {"basename": base, "bytes": len(raw), "hashes": {}}, "samples": len(chunk), "zip_data": None})
     with open(os.path.join(root, "index.json"), "w") as f:
         json.dump({"shards": shards, "version": 2}, f, sort_keys=True)
+
+
+def multiar_buckets() -> dict:
+    """the bucket table both sides of the multi-aspect-ratio fixture use: five (height, width) buckets of 23 / 8 / 1 / 16 / 5 indices
+    (dict order = first appearance in the dataset, as the reference builds it)"""
+    sizes = {(256, 256): 23, (192, 320): 8, (320, 192): 1, (224, 288): 16, (288, 224): 5}
+    order = np.random.default_rng(77).permutation(sum(sizes.values())).tolist()
+    keys = [k for k, n in sizes.items() for _ in range(n)]
+    b: dict = {}
+    for idx, pos in enumerate(order):
+        b.setdefault(keys[pos], []).append(idx)
+    return b

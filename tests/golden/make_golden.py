@@ -296,6 +296,38 @@ def gen_s2_model() -> None:
     save("dit_s2", **o)
 
 
+def gen_autocast() -> None:
+    """THE bf16 YARDSTICK, from the reference itself: the imported reference under
+    ``torch.autocast("cpu", dtype=torch.bfloat16)`` -- what accelerate's bf16 mixed precision runs (trainers/common.py:103-109,
+    SURVEY Appendix D) -- on the inputs of the `dit_small16` and `dit_s2` fixtures; stored: the autocast loss and, per parameter,
+    the relative L2 error of the autocast gradient against the reference's OWN fp32 gradient.  tests/test_oracle_golden.py checks that ``oracle.dit.bf16_autocast()`` reproduces these numbers,
+    tests/test_parity_bf16_gpu.py bounds the HIP path by them."""
+    o = {}
+    for tag, cfg, seed, B, H, lo in (("s16", SMALL, 5, 4, 16, 0.02), ("s2", S2, 7, 2, 32, 0.05)):
+        x0 = synth.normal(f"{tag}.x0", (B, cfg.input_channels, H, H))
+        noise = synth.normal(f"{tag}.noise", (B, cfg.input_channels, H, H))
+        t = synth.uniform(f"{tag}.t", (B,), lo=lo, hi=1.0 - lo)
+        y = synth.integers(f"{tag}.y", (B,), cfg.n_classes)
+        legs = {}
+        for leg in ("fp32", "autocast"):
+            m = build_ref(cfg, seed=seed)
+            if leg == "autocast":
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    loss = flow_loss_ref(m, x0, t, y, noise)
+            else:
+                loss = flow_loss_ref(m, x0, t, y, noise)
+            loss.backward()
+            legs[leg] = (loss.detach().float(), {n: p.grad.detach().float().clone() for n, p in m.named_parameters()})
+        names = list(legs["fp32"][1])
+        errs = [((legs["autocast"][1][n].double() - legs["fp32"][1][n].double()).norm() / legs["fp32"][1][n].double().norm()).item() for n in names]
+        o[f"{tag}_names"], o[f"{tag}_err"] = np.array(names), np.array(errs)
+        o[f"{tag}_loss_fp32"], o[f"{tag}_loss_autocast"] = legs["fp32"][0], legs["autocast"][0]
+        e = np.array(errs)
+        print(f"{tag}: loss fp32 {legs['fp32'][0].item():.6f} autocast {legs['autocast'][0].item():.6f}; per-tensor error median {np.median(e):.3e} "
+              f"max {e.max():.3e}; {int((e > 1e-2).sum())} of {len(e)} tensors above 1e-2")
+    save("dit_autocast", **o)
+
+
 # ------------------------------------------------------------------ (vi) samplers
 def gen_samplers() -> None:
     o = {}
@@ -927,9 +959,55 @@ def gen_datasets() -> None:
     save("datasets", **o)
 
 
+def gen_multiar() -> None:
+    """the reference's MultiARBatchSampler and collate_fn (datasets/imagenet.py:177-236) -- integer / index work on Python's
+    `random`: the epoch's batch lists for four (shuffle, drop_last) settings after random.seed(1234), two consecutive epochs of the
+    shuffling ones, __len__, and the collated tensors of one mixed batch.  `streaming` and `torchvision` are absent here: stubbed,
+    the two objects under test never touch them."""
+    import importlib
+    import random
+
+    st = types.ModuleType("streaming")
+    st.StreamingDataset = object
+    sys.modules.setdefault("streaming", st)
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tvt.ToTensor = lambda: (lambda im: im)
+    tv.transforms = tvt
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.transforms", tvt)
+    dn = types.ModuleType("diffulab.datasets")
+    dn.__path__ = [os.path.join(REF, "diffulab", "datasets")]
+    sys.modules["diffulab.datasets"] = dn
+    im = importlib.import_module("diffulab.datasets.imagenet")
+
+    class DS:
+        buckets = synth.multiar_buckets()
+
+    o = {}
+    for shuffle in (True, False):
+        for drop_last in (True, False):
+            tag = f"s{int(shuffle)}d{int(drop_last)}"
+            smp = im.MultiARBatchSampler(DS(), batch_size=4, shuffle=shuffle, drop_last=drop_last)
+            random.seed(1234)
+            for ep in range(2):
+                batches = list(smp)
+                o[f"{tag}_e{ep}_flat"] = np.array([i for b in batches for i in b], np.int64)
+                o[f"{tag}_e{ep}_lens"] = np.array([len(b) for b in batches], np.int64)
+            o[f"{tag}_len"] = len(smp)
+    g = torch.Generator().manual_seed(5)
+    items = [{"model_inputs": {"x": torch.randn(4, 6, 10, generator=g), "initial_context": f"caption {i}"},
+              "extra": {"dst_features": torch.randn(7, 12, generator=g)} if i != 1 else {}} for i in range(3)]
+    del items[2]["model_inputs"]["initial_context"]  # (a missing caption collates to "")
+    c = im.collate_fn(items)
+    o["col_x"], o["col_feats"] = c["model_inputs"]["x"], c["extra"]["dst_features"]
+    o["col_ctx"] = np.array(c["model_inputs"]["initial_context"])
+    save("multiar", **o)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["datasets", "schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "unet_variants", "curve", "repa", "resampler", "sprint", "mmdit_joint", "sprint_joint", "ddt", "ddt_joint", "mmdit_single"]
-    fns = {"datasets": gen_datasets, "repa": gen_repa, "resampler": gen_resampler, "sprint": gen_sprint, "mmdit_joint": gen_mmdit_joint, "sprint_joint": gen_sprint_joint, "ddt": gen_ddt, "ddt_joint": gen_ddt_joint, "mmdit_single": gen_mmdit_single, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
+    which = sys.argv[1:] or ["datasets", "multiar", "autocast", "schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "unet_variants", "curve", "repa", "resampler", "sprint", "mmdit_joint", "sprint_joint", "ddt", "ddt_joint", "mmdit_single"]
+    fns = {"datasets": gen_datasets, "multiar": gen_multiar, "autocast": gen_autocast, "repa": gen_repa, "resampler": gen_resampler, "sprint": gen_sprint, "mmdit_joint": gen_mmdit_joint, "sprint_joint": gen_sprint_joint, "ddt": gen_ddt, "ddt_joint": gen_ddt_joint, "mmdit_single": gen_mmdit_single, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
            "s2": gen_s2_model, "samplers": gen_samplers, "curve": gen_loss_curve, "unet": gen_unet, "unet_variants": gen_unet_variants}
     for w in which:
         print("==", w)

@@ -172,6 +172,40 @@ def test_small_model_flow_and_ddpm(golden):
     assert rel(P["conv_proj.weight"].grad, g["ddpm_g_conv_proj.weight"]) < 5e-6
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("tag,cfg,seed,B,H,lo", [("s16", SMALL, 5, 4, 16, 0.02), ("s2", S2, 7, 2, 32, 0.05)])
+def test_bf16_autocast_leg_against_the_reference_under_autocast(golden, tag, cfg, seed, B, H, lo):
+    """the bf16 YARDSTICK is pinned to the reference: `dit_autocast.npz` holds what the imported reference loses under
+    ``torch.autocast("cpu", bfloat16)`` against its own fp32 run -- per parameter, on the inputs of the dit_small16 / dit_s2
+    fixtures (s2: median 1.6e-2, 149 of 154 tensors above SURVEY's 1e-2).  ``odit.bf16_autocast()`` -- the leg the bounds of
+    tests/test_parity_bf16_gpu.py were relative to until round 5 -- is the same regime but not the same rounding sequence (explicit
+    softmax instead of SDPA, f32 modulation arithmetic): measured here, it loses 0.57 ... 1.0x of what the reference loses per
+    tensor (median 0.78 / 0.84), i.e. it was the STRICTER yardstick, never a looser one.  Asserted: per tensor within [0.45, 1.15]
+    of the reference's error, median within [0.65, 1.05], loss shift <= max(2x the reference's, 3e-4)."""
+    g = golden("dit_autocast")
+    x0, noise = synth.normal(f"{tag}.x0", (B, 4, H, H)), synth.normal(f"{tag}.noise", (B, 4, H, H))
+    t = synth.uniform(f"{tag}.t", (B,), lo=lo, hi=1.0 - lo)
+    y = synth.integers(f"{tag}.y", (B,), cfg.n_classes)
+    legs = {}
+    for leg in ("fp32", "bf16"):
+        P = {k: v.requires_grad_(True) for k, v in synth.dit_params(odit.param_shapes(cfg), seed=seed).items()}
+        if leg == "bf16":
+            with odit.bf16_autocast():
+                _, loss = _flow_loss(P, cfg, x0, t, y, noise)
+        else:
+            _, loss = _flow_loss(P, cfg, x0, t, y, noise)
+        loss.backward()
+        legs[leg] = (loss.item(), {k: v.grad for k, v in P.items()})
+    l32, lref = float(g[f"{tag}_loss_fp32"]), float(g[f"{tag}_loss_autocast"])
+    assert abs(legs["fp32"][0] - l32) < 1e-6 * l32
+    assert abs(legs["bf16"][0] - l32) <= max(2.0 * abs(lref - l32), 3e-4 * l32)  # (a scalar: either leg can cancel by luck)
+    ref_err = dict(zip(g[f"{tag}_names"].tolist(), g[f"{tag}_err"].tolist()))
+    assert set(ref_err) == set(legs["fp32"][1])
+    ratios = [rel(legs["bf16"][1][n], legs["fp32"][1][n]) / e_ref for n, e_ref in ref_err.items()]
+    assert 0.45 < min(ratios) and max(ratios) < 1.15, (min(ratios), max(ratios))
+    assert 0.65 < float(np.median(ratios)) < 1.05
+
+
 @pytest.mark.timeout(600)
 def test_dit_s2_fwd_bwd(golden):
     g = golden("dit_s2")
