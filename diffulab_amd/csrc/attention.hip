@@ -553,12 +553,35 @@ __device__ __forceinline__ bf16x8_t frag_rows_g(const bf16_t* __restrict__ g, in
   return *(const bf16x8_t*)(g + (int64_t)row * pitch + (ks * 2 + hi) * 8);
 }
 
+// FUSE (dl_attn_bwd_qkn): the QK-RMSNorm + RoPE backward (mmdit.py:81-91, nn.py:345-353,427-431) runs as this kernel's epilogue instead
+// of a pass of its own over the q / k thirds of dqkv (qk_norm_rope_bwd_inplace_k: 307 MB per launch at the headline shape).  What
+// that backward needs beyond a row's own elements is ONE number per token row and tensor, c = sum over the FULL D-wide row of
+// (d q^ . q^) -- all heads -- and it never has to be formed from dq^:  sum_d q^[i,d] dq^[i,d] = sum_j dS[i,j] S[i,j]  (S the scaled
+// logits, dS their gradient; the rotation is orthogonal, so the sum is the same before and after RoPE), and likewise for k with the
+// sum over i.  Phase A / B accumulate those sums beside their dS tiles, every (sample, head) workgroup publishes its 2 N partial
+// sums, the H workgroups of a sample meet on a counter (they are adjacent in dispatch order), add the H partials in head order and
+// then transform the dq^ / dk^ rows THEY wrote (still L2-resident) in place:
+//      g = R^T dq^;  dscale += g x r;  dx = r (s g) - x (r^2 / D) c          (x = pre-norm row of qkv, r = rrms, s = scale)
+// Scale-gradient partials: one [2, D] row per sample, each head its own 64 columns (one writer, folded over samples afterwards).
+struct QknBwd {
+  const bf16_t* qkv;    // [B*N, 3D] pre-norm rows (x)
+  const float* rrms;    // f32 [B*N, 2]
+  const float* sq;      // f32 [D]
+  const float* sk;
+  const float* cs;      // f32 [N, rot/2]
+  const float* sn;
+  float* cpart;         // f32 [B*H, 2, N] exchange buffer
+  unsigned* sync;       // u32 [2*B + 1]: arrive[B] | done[B] | error flag; zero before the first launch, self-resetting
+  float* dscale_part;   // f32 [B, 2, D]
+  int rot;
+};
+template <bool FUSE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                      const bf16_t* __restrict__ v, const bf16_t* __restrict__ out,
                                                      const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                      bf16_t* __restrict__ dq, bf16_t* __restrict__ dk,
                                                      bf16_t* __restrict__ dv, int H, int N, float scale, HeadLayout vl,
-                                                     HeadLayout dvl, HeadLayout dql) {
+                                                     HeadLayout dvl, HeadLayout dql, QknBwd fz) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ta = smem;             // phase A: K   | phase B: Q
   char* tb = ta + N * ROWB;    // phase A: V   | phase B: dO
@@ -606,6 +629,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
     f32x16_t dqa[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqa[0][r] = dqa[1][r] = 0.f;
+    float cq = 0.f;  // FUSE: sum_j dS[i, j] * (q^_i . k^_j) over this lane's keys
     // software pipeline over the key blocks: the S / dP MFMAs of block kb + 32 are issued before the exp / dS arithmetic of block kb
     auto scores = [&](int kb, f32x16_t& st, f32x16_t& dpt) {
 #pragma unroll
@@ -623,6 +647,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
       for (int r = 0; r < 16; ++r) {
         const float p = fast_exp2(st[r] * c - my_lse);
         ds[r] = p * (dpt[r] - my_delta);
+        if (FUSE) cq += ds[r] * st[r];
       }
 #pragma unroll
       for (int kg2 = 0; kg2 < 2; ++kg2) {
@@ -638,6 +663,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
       step(kb + 32, s1, d1, s0, d0);
     }
     store_rows64(dq + b * dql.bs + h * dql.hs + (int64_t)(own + (lane & 31)) * dql.pitch, dqa, scale, hi);
+    if (FUSE) {  // (the other 16 keys of every block sit in the other lane half)
+      cq = xor32_sum(cq) * scale;  // (write-through store: the sample's other heads read it from L2 without an acquire, see below)
+      if (hi == 0) __hip_atomic_store(fz.cpart + ((int64_t)bh * 2) * N + own + (lane & 31), cq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 
   // ------------------------------------------------------------------ swap the resident tiles: Q and dO replace K and V
@@ -659,6 +688,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
     f32x16_t dka[2], dva[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dka[0][r] = dka[1][r] = dva[0][r] = dva[1][r] = 0.f;
+    float ck = 0.f;  // FUSE: sum_i dS[i, j] * (q^_i . k^_j) over this lane's queries
     // (software pipeline as in phase A, on S only: dK / dV / S / dP accumulators leave no room for a second dP tile)
     auto scores_t = [&](int qb, f32x16_t& s) {
 #pragma unroll
@@ -683,6 +713,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
           const int r = g4 * 4 + e;
           p[r] = fast_exp2(s[r] * c - l4[e]);
           ds[r] = p[r] * (dp[r] - d4[e]);
+          if (FUSE) ck += ds[r] * s[r];
         }
       }
 #pragma unroll
@@ -704,6 +735,152 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
     }
     store_rows64(dk + b * dql.bs + h * dql.hs + (int64_t)(own + (lane & 31)) * dql.pitch, dka, scale, hi);
     store_rows64(dv + b * dvl.bs + h * dvl.hs + (int64_t)(own + (lane & 31)) * dvl.pitch, dva, 1.0f, hi);
+    if (FUSE) {
+      ck = xor32_sum(ck) * scale;
+      if (hi == 0) __hip_atomic_store(fz.cpart + ((int64_t)bh * 2 + 1) * N + own + (lane & 31), ck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+#ifndef QKN_LAB
+#define QKN_LAB 0  // LAB: 1 = rendezvous but no transform, 2 = neither (cost split of the fused epilogue; results invalid)
+#endif
+  if constexpr (FUSE && QKN_LAB < 2) {
+    // ---------------------------------------------------------------- publish this head's partial row sums, meet the sample's heads
+    // (MI355X guide, inter-workgroup hand-off: the 2 KB payload is stored WRITE-THROUGH (sc1, agent-scope relaxed atomic stores) ->
+    // every storing wave drains -> barrier -> ticket; the consumers poll the ticket relaxed and read the payload with sc1 loads,
+    // which bypass the per-CU L1: no release fence -- it would write back every dirty line of the XCD's L2, i.e. the dq / dk / dv
+    // rows all resident workgroups have just stored, once per workgroup (measured: +145 us per launch) -- and no acquire.
+    // The H workgroups of a sample have consecutive block ids: with in-order dispatch a waiting workgroup's mates are resident or
+    // next in line; the poll is bounded anyway and a timeout is reported through sync[2 B] instead of hanging the queue.)
+    unsigned* arrive = fz.sync + b;
+    unsigned* done = fz.sync + gridDim.x / H + b;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)H) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++spins > (1 << 21)) {
+          __hip_atomic_store(fz.sync + 2 * (gridDim.x / H), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    // the sample's row sums: thread t adds the H partials of token row t (q and k) in head order.  sc1 loads (served by L2, never
+    // by this CU's L1) as inline assembly: all 2 H requests are in flight together (the compiler serialises relaxed atomic loads)
+    {
+      float cv[2][8];
+      const int nh = H < 8 ? H : 8;
+#pragma unroll
+      for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) {
+          cv[w2][hh] = 0.f;
+          if (hh < nh) {
+            const float* ptr = fz.cpart + (((int64_t)b * H + hh) * 2 + w2) * N + threadIdx.x;
+            asm volatile("global_load_dword %0, %1, off sc1" : "=v"(cv[w2][hh]) : "v"(ptr) : "memory");
+          }
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      float tq = 0.f, tk = 0.f;
+#pragma unroll
+      for (int hh = 0; hh < 8; ++hh) {
+        tq += cv[0][hh];
+        tk += cv[1][hh];
+      }
+      for (int hh = 8; hh < H; ++hh) {  // (more than 8 heads: the rest one by one)
+        tq += __hip_atomic_load(fz.cpart + (((int64_t)b * H + hh) * 2) * N + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tk += __hip_atomic_load(fz.cpart + (((int64_t)b * H + hh) * 2 + 1) * N + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      lse2[threadIdx.x] = tq;   // (lse2 / delta are dead after phase B)
+      delta[threadIdx.x] = tk;
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- QK-norm + RoPE backward of the rows this wave wrote, in place
+    // after store_rows64 a lane holds, of row (lane & 31) of its block, the four 8-column chunks d0 = 32 dt + 16 gp + 8 hi
+    const int D = H * DH, half = fz.rot >> 1;
+    const float inv_d = 1.0f / (float)D;
+    float* red = (float*)smem;  // [4 waves][64 lanes][33]: this wave's per-lane column partials of dscale (K / V / Q / dO tiles are dead)
+    for (int which = 0; which < (QKN_LAB ? 0 : 2); ++which) {
+      float acc[4][8];
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[ci][e] = 0.f;
+      const float* sc = (which ? fz.sk : fz.sq) + h * DH;
+      for (int ob = 0; ob < 2; ++ob) {
+        const int row = (wave * 2 + ob) * 32 + (lane & 31);
+        const int64_t tok = (int64_t)b * N + row;
+        const float ctot = (which ? delta : lse2)[row];
+        const float r = fz.rrms[tok * 2 + which];
+        const float m = ctot * r * r * inv_d;
+        bf16_t* gp_ = (which ? dk : dq) + b * dql.bs + h * dql.hs + (int64_t)row * dql.pitch;
+        const bf16_t* xp = fz.qkv + tok * 3 * D + which * D + h * DH;
+        u32x4_t gr[4], xr[4];
+        f32x4_t cc[4], ss[4];
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+          const int d0 = (ci >> 1) * 32 + (ci & 1) * 16 + 8 * hi;
+          gr[ci] = *(const u32x4_t*)(gp_ + d0);
+          xr[ci] = *(const u32x4_t*)(xp + d0);
+          if (d0 < fz.rot) {
+            cc[ci] = *(const f32x4_t*)(fz.cs + (int64_t)row * half + (d0 >> 1));
+            ss[ci] = *(const f32x4_t*)(fz.sn + (int64_t)row * half + (d0 >> 1));
+          }
+        }
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+          const int d0 = (ci >> 1) * 32 + (ci & 1) * 16 + 8 * hi;
+          float g[8], x[8];
+          unpack8(gr[ci], g);
+          unpack8(xr[ci], x);
+          if (d0 < fz.rot) {  // transpose of the rotation
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float a = g[2 * i], bb = g[2 * i + 1];
+              g[2 * i] = a * cc[ci][i] + bb * ss[ci][i];
+              g[2 * i + 1] = -a * ss[ci][i] + bb * cc[ci][i];
+            }
+          }
+          const f32x4_t s0 = *(const f32x4_t*)(sc + d0), s1 = *(const f32x4_t*)(sc + d0 + 4);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            acc[ci][e] += g[e] * x[e] * r;
+            g[e] = r * (g[e] * (e < 4 ? s0[e] : s1[e - 4])) - x[e] * m;
+          }
+          *(u32x4_t*)(gp_ + d0) = pack8(g);
+        }
+      }
+      // dscale partial of this sample: columns of this head, summed over the 256 token rows in a fixed order
+      __syncthreads();  // (which == 0: the tiles are dead; which == 1: the previous reduction's reads are done)
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(wave * 64 + lane) * 33 + ci * 8 + e] = acc[ci][e];
+      __syncthreads();
+      {
+        const int col = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int chi = (col >> 3) & 1, ci = (col >> 5) * 2 + ((col >> 4) & 1), e = col & 7;
+        float t = 0.f;
+        for (int l = 0; l < 32; ++l) t += red[(w * 64 + chi * 32 + l) * 33 + ci * 8 + e];
+        __syncthreads();
+        red[w * 64 + col] = t;
+        __syncthreads();
+        if (w == 0)
+          fz.dscale_part[((int64_t)b * 2 + which) * D + h * DH + col] = (red[col] + red[64 + col]) + (red[128 + col] + red[192 + col]);
+      }
+    }
+    // ---------------------------------------------------------------- the last head of the sample to finish clears the counters
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned dn = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (dn == (unsigned)H - 1) {
+        __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 
@@ -908,10 +1085,10 @@ static int attn_bwd_launch(const void* q, const void* k, const void* v, HeadLayo
                            const float* lse, void* dq, void* dk, HeadLayout dql, void* dv, HeadLayout dvl, int64_t B, int64_t H,
                            int64_t N, float scale, dl_stream_t stream) {
   const int lds = (int)(2 * N * ROWB + 2 * N * sizeof(float));
-  (void)hipFuncSetAttribute((const void*)attn_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL(attn_bwd_k, (int)(B * H), (int)(N / 64) * 64, lds, (hipStream_t)stream, (const bf16_t*)q,
+  (void)hipFuncSetAttribute((const void*)attn_bwd_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(attn_bwd_k<false>, (int)(B * H), (int)(N / 64) * 64, lds, (hipStream_t)stream, (const bf16_t*)q,
                      (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dq,
-                     (bf16_t*)dk, (bf16_t*)dv, (int)H, (int)N, scale, vl, dvl, dql);
+                     (bf16_t*)dk, (bf16_t*)dv, (int)H, (int)N, scale, vl, dvl, dql, QknBwd{});
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
@@ -940,6 +1117,39 @@ extern "C" int dl_attn_bwd_tok(const void* q, const void* k, const void* qkv, co
   const HeadLayout tok{N * 3 * D, DH, (int)(3 * D)};  // head (b, h) of a third starts at b * N * 3D + h * 64, rows 3D apart
   return attn_bwd_launch(q, k, (const bf16_t*)qkv + 2 * D, tok, out, dout, lse, dqkv, (bf16_t*)dqkv + D, tok, (bf16_t*)dqkv + 2 * D, tok,
                          B, H, N, scale, stream);
+}
+int dl_fold_rows_launch(const float* partial, float* out, int G, int n, hipStream_t stream);  // norm.hip: out[j] += sum_g partial[g, j]
+/* dl_attn_bwd_tok + dl_qk_norm_rope_bwd_inplace as ONE launch (N == 256, the benched shape): see attn_bwd_k<true>.  q, k = the
+ * normalised + rotated head-major tensors of the forward, qkv = the pre-norm rows; dqkv leaves holding the gradient of qkv
+ * (token-major, all three thirds); dscale [2, D] += the QK-norm scale gradients (partials [B, 2, D] folded in a fixed order);
+ * cpart f32 [B * H * 2 * N] and sync u32 [2 B + 1] are caller scratch -- sync ZEROED before the first call, it resets itself;
+ * sync[2 B] != 0 after a call reports a timed-out rendezvous (results invalid). */
+extern "C" int dl_attn_bwd_qkn(const void* q, const void* k, const void* qkv, const void* out, const void* dout, const float* lse,
+                               const float* rrms, const float* scale_q, const float* scale_k, const float* cos, const float* sin,
+                               int64_t rot, void* dqkv, float* dscale, float* dscale_partials, float* cpart, uint32_t* sync, int64_t B,
+                               int64_t H, int64_t N, int64_t dh, float scale, dl_stream_t stream) {
+  DL_CHECK_ARG(q && k && qkv && out && dout && lse && rrms && scale_q && scale_k && dqkv && dscale && dscale_partials && cpart && sync &&
+                   B > 0 && H > 0, "dl_attn_bwd_qkn: null operand");
+  DL_CHECK_ARG(rot == 0 || (cos && sin), "dl_attn_bwd_qkn: rot > 0 needs the cos / sin tables");
+  DL_CHECK_ARG(dh == DH && rot % 8 == 0 && rot <= DH, "dl_attn_bwd_qkn: head_dim 64, rot %% 8 == 0 (dh=%lld rot=%lld)", (long long)dh,
+               (long long)rot);
+  if (N != 256) {
+    dl_set_error("dl_attn_bwd_qkn: N=%lld (the fused epilogue is built for 256-token samples)", (long long)N);
+    return DL_ERR_UNSUPPORTED;
+  }
+  DL_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)dqkv | (uintptr_t)cos | (uintptr_t)sin | (uintptr_t)scale_q | (uintptr_t)scale_k) & 15) == 0,
+               "dl_attn_bwd_qkn: 16-byte alignment");
+  const int64_t D = H * DH;
+  const HeadLayout tok{N * 3 * D, DH, (int)(3 * D)};
+  const int lds = (int)(2 * N * ROWB + 2 * N * sizeof(float));  // 67584 >= the 4 x 64 x 33 floats of the epilogue's reduction
+  static DevOnce once;
+  (void)dev_cus(once, [lds] { (void)hipFuncSetAttribute((const void*)attn_bwd_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
+  const QknBwd fz{(const bf16_t*)qkv, rrms, scale_q, scale_k, cos, sin, cpart, sync, dscale_partials, (int)rot};
+  hipLaunchKernelGGL(attn_bwd_k<true>, (int)(B * H), 256, lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k,
+                     (const bf16_t*)qkv + 2 * D, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, (bf16_t*)dqkv + D,
+                     (bf16_t*)dqkv + 2 * D, (int)H, (int)N, scale, tok, tok, tok, fz);
+  DL_LAUNCH_CHECK();
+  return dl_fold_rows_launch(dscale_partials, dscale, (int)B, (int)(2 * D), (hipStream_t)stream);
 }
 
 // ====================================================================================== small attention (UNet AttentionBlock)

@@ -1265,6 +1265,215 @@ extern "C" int dl_gemm_nt_f32_det(const void* A, int64_t lda, const void* B, int
 // ----------------------------------------------------------------------------------------------------- implicit-GEMM 3x3 conv
 /* out[p, co] = bias[co] + sum_{tap, ci} x[p + shift(tap), ci] * Wf[co, tap*Ci + ci] (+ resid[p, co]); x NHWC rows [B*H*W, ldx].
  * Wf is the (tap, ci)-ordered shadow of dl_cast_conv3x3_weight (the rotated one gives the data gradient). */
+// =====================================================================================================
+// conv3x3_big_k: the 3x3 / pad-1 convolution (forward, and data gradient with the rotated shadow) as a PERSISTENT implicit GEMM on
+// 256 x TN tiles (unet.py:187,208,594,745: nn.Conv2d(Ci, Co, 3, padding=1) over NHWC rows).  The 128x128 kernel above stages 64 FLOP
+// per byte and, at the low-resolution levels of the UNet (8x8 / 4x4 pixels: 8192 / 2048 output rows against contractions of
+// 4608 ... 18432), has a few hundred workgroups of 72 ... 288 k-steps each; here
+//   * a work item is (row tile, column tile, k-split): out[256 x TN] over k-steps [k_lo, k_hi); the items of a launch are walked by
+//     one 512-thread workgroup per CU (8 waves as 4 x 2, 64 x TN/2 each), items that share a row panel are neighbours on one XCD;
+//   * the A operand is gathered by the DMA itself: a 64-deep k-step lies inside one tap (Ci % 64 == 0), every lane's 16 bytes come
+//     from x[p + shift(tap), ci0 ..] or from the caller's zero line when the tap leaves the image -- the in-image bits of a lane's
+//     pixel are recomputed per item, nothing of the geometry lives in memory;
+//   * two-slot LDS ring, fragment software pipeline and register epilogue of gemm_nt_big_k (TN = 256: 128 FLOP per staged byte);
+//   * k-split items store their f32 partial tile at C + split * part_stride (plain stores, conv_splitk_finalize_k adds the images in
+//     a fixed order with bias / residual: no atomics), unsplit items run the full epilogue (bias, residual, bf16).
+// Requires M % 256 == 0, N % TN == 0, Ci % 64 == 0.
+// =====================================================================================================
+// epilogue of conv3x3_big_k straight from the accumulator registers (layout of nt_epilogue_regs: one v_permlane32_swap per register
+// pair gives every lane 8 consecutive columns of one row): F32 = partial image of a k-split (plain f32 stores), else
+// bf16(acc + bias + resid).  Zeroes the accumulators.
+template <int JN, bool F32>
+__device__ __forceinline__ void conv_epilogue(f32x16_t (&acc)[JN][2], int m_base, int n_base, int lane, void* C, int64_t ldc,
+                                              const float* __restrict__ bias, const bf16_t* __restrict__ resid, int64_t ldr) {
+  const int hi = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int64_t m = m_base + i * 32 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j][i][8 * gp + e]), __float_as_uint(acc[j][i][8 * gp + 4 + e]), false, false);
+          v[e] = __uint_as_float(sw[0]);
+          v[4 + e] = __uint_as_float(sw[1]);
+          acc[j][i][8 * gp + e] = 0.f;
+          acc[j][i][8 * gp + 4 + e] = 0.f;
+        }
+        const int n = n_base + j * 32 + 16 * gp + 8 * hi;
+        if (F32) {
+          float* cp = (float*)C + m * ldc + n;
+          *(f32x4_t*)cp = *(f32x4_t*)&v[0];
+          *(f32x4_t*)(cp + 4) = *(f32x4_t*)&v[4];
+        } else {
+          if (bias) {
+            const f32x4_t b0 = *(const f32x4_t*)(bias + n), b1 = *(const f32x4_t*)(bias + n + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] += b0[e];
+              v[4 + e] += b1[e];
+            }
+          }
+          if (resid) {
+            float rr[8];
+            unpack8(*(const u32x4_t*)(resid + m * ldr + n), rr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rr[e];
+          }
+          *(u32x4_t*)((bf16_t*)C + m * ldc + n) = pack8(v);
+        }
+      }
+  }
+}
+static int g_conv_big = 1;
+extern "C" __attribute__((visibility("default"))) void dl_lab_set_conv_big(int on) { g_conv_big = on; }  // LAB A/B switch (not in the header)
+static bool conv_big_enabled() { return g_conv_big != 0; }
+template <int TN_>
+__global__ __launch_bounds__(BIG_THREADS, 2) void conv3x3_big_k(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wf, int64_t ldw,
+                                                                  void* __restrict__ C, int64_t ldc, int M, int N, int K, NtEpilogue ep,
+                                                                  int ksplit, ConvGeom cg) {
+  constexpr int STAGE = (TBM + TN_) * 128;
+  constexpr int CHB = TN_ / 64;  // weight-row DMA chunks per wave and stage (the activation rows: 4)
+  constexpr int JN = TN_ / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = N / TN_, ntiles = (M / TBM) * tiles_n;
+  const int nk_all = K / BK, kc = cg.Ci / BK;  // k-steps per tap
+  const int nitems = ntiles * ksplit;
+  const int G = gridDim.x;
+  const int slot0 = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+
+  // item id -> (row tile tm, split s, column tile tn): n fastest, then the splits of a row panel (they share the panel's pixels)
+  auto item_k = [&](int s, int& k_lo, int& k_hi) {
+    k_lo = (int)((int64_t)nk_all * s / ksplit);
+    k_hi = (int)((int64_t)nk_all * (s + 1) / ksplit);
+  };
+  // ---- DMA cursor (one stage ahead of the compute cursor), with the per-item gather state of this lane's four pixel rows
+  int s_item = slot0, s_k = 0, s_khi = 0, s_it = 0;
+  const bf16_t* a_src[4];
+  int tap_ok[4];
+  const bf16_t* b_src[CHB];
+  auto open_item = [&](int item) {
+    const int tn = item % tiles_n, rest = item / tiles_n, sp = rest % ksplit, tm = rest / ksplit;
+    item_k(sp, s_k, s_khi);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (wave * 4 + i) * 8 + (lane >> 3);
+      const int q = (lane & 7) ^ ((r >> 1) & 7);
+      const int64_t p = (int64_t)tm * TBM + r;
+      a_src[i] = X + p * cg.ldx + q * 8;
+      int px, py;
+      cg.pixel(p, py, px);
+      int ok = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+        if (yy >= 0 && yy < cg.H && xx >= 0 && xx < cg.W && p < cg.npix) ok |= 1 << t;
+      }
+      tap_ok[i] = ok;
+    }
+#pragma unroll
+    for (int i = 0; i < CHB; ++i) {
+      const int r = (wave * CHB + i) * 8 + (lane >> 3);
+      const int q = (lane & 7) ^ ((r >> 1) & 7);
+      b_src[i] = Wf + (int64_t)(tn * TN_ + r) * ldw + q * 8;
+    }
+  };
+  auto stage_next = [&]() {
+    char* base = smem + (s_it & 1) * STAGE;
+    const int tap = s_k / kc, ci0 = (s_k - tap * kc) * BK;  // wave-uniform
+    const int64_t shift = ((int64_t)(tap / 3 - 1) * cg.W + (tap % 3 - 1)) * cg.ldx + ci0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      glds16(((tap_ok[i] >> tap) & 1) ? a_src[i] + shift : cg.zero, base + (wave * 4 + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < CHB; ++i) glds16(b_src[i] + (int64_t)s_k * BK, base + TBM * 128 + (wave * CHB + i) * 1024);
+    ++s_it;
+    if (++s_k == s_khi) {
+      s_item += G;
+      if (s_item < nitems) open_item(s_item);
+    }
+  };
+
+  int xrow[2], wrow[JN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) xrow[i] = wm * 64 + i * 32 + (lane & 31);
+#pragma unroll
+  for (int j = 0; j < JN; ++j) wrow[j] = wn * (TN_ / 2) + j * 32 + (lane & 31);
+  f32x16_t acc[JN][2];
+#pragma unroll
+  for (int j = 0; j < JN; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+  if (s_item < nitems) {
+    open_item(s_item);
+    stage_next();
+  }
+  int it = 0;
+  for (int item = slot0; item < nitems; item += G) {
+    const int tn = item % tiles_n, rest = item / tiles_n, sp = rest % ksplit, tm = rest / ksplit;
+    int k_lo, k_hi;
+    item_k(sp, k_lo, k_hi);
+    for (int kt = k_lo; kt < k_hi; ++kt, ++it) {
+      wait_vmcnt<0>();               // stage `it` has landed (two-slot ring: nothing younger is in flight)
+      __builtin_amdgcn_s_barrier();  // every wave's share landed, the other slot's readers are done
+      if (s_item < nitems) stage_next();
+      const char* sa = smem + (it & 1) * STAGE;
+      const char* sb = sa + TBM * 128;
+      bf16x8_t xq[2][2], wq[3];
+      auto rd_x = [&](int kk, int i) -> bf16x8_t {
+        return *(const bf16x8_t*)(sa + xrow[i] * 128 + ((((kk << 1) | hi) ^ ((xrow[i] >> 1) & 7)) << 4));
+      };
+      auto rd_w = [&](int kk, int j) -> bf16x8_t {
+        return *(const bf16x8_t*)(sb + wrow[j] * 128 + ((((kk << 1) | hi) ^ ((wrow[j] >> 1) & 7)) << 4));
+      };
+      xq[0][0] = rd_x(0, 0);
+      xq[0][1] = rd_x(0, 1);
+      wq[0] = rd_w(0, 0);
+      wq[1] = rd_w(0, 1);
+#pragma unroll
+      for (int s = 0; s < 4 * JN; ++s) {
+        const int kk = s / JN, j = s % JN;
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < 4 * JN) wq[(s + 2) % 3] = rd_w((s + 2) / JN, (s + 2) % JN);
+        if (kk < 3 && j < 2) xq[(kk + 1) & 1][j] = rd_x(kk + 1, j);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s % 3], xq[kk & 1][i], acc[j][i], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue of the item straight from registers (zeroes the accumulators)
+    if (ksplit > 1)
+      conv_epilogue<JN, true>(acc, tm * TBM + wm * 64, tn * TN_ + wn * (TN_ / 2), lane, (float*)C + (int64_t)sp * ep.part_stride, N, nullptr,
+                              nullptr, 0);
+    else
+      conv_epilogue<JN, false>(acc, tm * TBM + wm * 64, tn * TN_ + wn * (TN_ / 2), lane, C, ldc, ep.bias, ep.resid, ep.ldr);
+    wait_vmcnt<0>();  // unknown number of epilogue memory operations: drain (the next stage's DMA is re-counted from zero)
+  }
+}
+template <int TN_>
+static int launch_conv_big(const void* x, const void* Wf, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                           const NtEpilogue& ep, int ksplit, const ConvGeom& cg, hipStream_t stream) {
+  constexpr int LDS = 2 * (TBM + TN_) * 128;
+  static DevOnce once;
+  const int n_cu = dev_cus(once, [] { (void)hipFuncSetAttribute((const void*)conv3x3_big_k<TN_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
+  const int64_t items = (M / TBM) * (N / TN_) * ksplit;
+  int grid = (int)(items < n_cu ? items : n_cu) & ~7;
+  if (grid < 8) return 1;
+  hipLaunchKernelGGL((conv3x3_big_k<TN_>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)x, (const bf16_t*)Wf, ldw, C, ldc, (int)M, (int)N,
+                     (int)K, ep, ksplit, cg);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
 // second half of a split-K convolution: out = bf16(acc + bias + resid)
 __global__ void conv_splitk_finalize_k(const float* __restrict__ acc, int splits, int64_t stride, const float* __restrict__ bias,
                                        const bf16_t* __restrict__ resid, int64_t ldr, bf16_t* __restrict__ out, int64_t ldc,
@@ -1302,6 +1511,44 @@ extern "C" int dl_conv3x3_nt(const void* x, int64_t ldx, int64_t Bn, int64_t H, 
                "dl_conv3x3_nt: 16-byte alignment");
   const int64_t M = Bn * H * W, K = 9 * Ci;
   const ConvGeom cg = make_conv_geom(H, W, Ci, ldx, M, zero);
+  // persistent 256-row tiles (conv3x3_big_k) where the shape tiles: 256 columns wide when that still yields a full round of work
+  // items, the contraction split when the output has few tiles (the low-resolution levels), every split at least 18 k-steps deep
+  if (M % TBM == 0 && Co % 128 == 0 && (!bias || ((uintptr_t)bias & 15) == 0) && conv_big_enabled()) {
+    static DevOnce once;
+    const int n_cu = dev_cus(once, [] {});
+    const int64_t mt = M / TBM;
+    int tn = (Co % 256 == 0 && mt * (Co / 256) >= n_cu) ? 256 : 128;
+    int64_t tiles = mt * (Co / tn);
+    int ksplit = 1;
+    if (tiles < (n_cu * 3) / 4) {
+      if (Co % 256 == 0) {
+        tn = 256;
+        tiles = mt * (Co / 256);
+      }
+      ksplit = (int)((n_cu + tiles - 1) / tiles);
+      if (ksplit > 8) ksplit = 8;
+      if (ksplit > (int)(K / 1152)) ksplit = (int)(K / 1152);
+      if (!splitk_scratch || ksplit > scratch_floats / (M * Co)) ksplit = splitk_scratch ? (int)(scratch_floats / (M * Co)) : 1;
+      if (ksplit < 2) ksplit = 1;
+    }
+    if (tiles * ksplit >= n_cu / 2 || (g_conv_big == 2 && tiles * ksplit >= 8)) {  // (2 = LAB / tests: whenever the shape tiles)
+      NtEpilogue ep{bias, DL_ACT_NONE, 0, nullptr, (const bf16_t*)resid, ldr, nullptr, 0, 1, nullptr, 0, 0};
+      ep.part_stride = M * Co;
+      const int rc = tn == 256 ? launch_conv_big<256>(x, Wf, ldw, ksplit > 1 ? (void*)splitk_scratch : out, ldc, M, Co, K, ep, ksplit, cg, (hipStream_t)stream)
+                               : launch_conv_big<128>(x, Wf, ldw, ksplit > 1 ? (void*)splitk_scratch : out, ldc, M, Co, K, ep, ksplit, cg, (hipStream_t)stream);
+      if (rc < 0) return rc;
+      if (rc == 0) {
+        if (ksplit > 1) {
+          int64_t g = (M * (Co / 8) + 255) / 256;
+          if (g > 4096) g = 4096;
+          hipLaunchKernelGGL(conv_splitk_finalize_k, (int)g, 256, 0, (hipStream_t)stream, splitk_scratch, ksplit, M * Co, bias,
+                             (const bf16_t*)resid, ldr, (bf16_t*)out, ldc, M, (int)Co);
+          DL_LAUNCH_CHECK();
+        }
+        return DL_OK;
+      }
+    }
+  }
   const int nwg = cdiv(M, BM) * cdiv(Co, BN);
   // low-resolution levels: few output tiles with a deep contraction (K = 9*Ci up to 18432) -> split K over blockIdx.y; every split
   // stores its partial [M, Co] image into the caller's f32 scratch (up to eight images), a second pass adds them in a fixed order with

@@ -944,6 +944,11 @@ __global__ __launch_bounds__(64 * FOLD_LANES) void fold_rows_k(const float* __re
   __syncthreads();
   if (rl == 0 && c < n) out[c] += (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
+int dl_fold_rows_launch(const float* partial, float* out, int G, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(fold_rows_k, cdiv(n, 64), 64 * FOLD_LANES, 0, stream, partial, out, G, n);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
 extern "C" int dl_qk_norm_rope_bwd_inplace(const void* qkv, const float* scale_q, const float* scale_k, const float* cos,
                                            const float* sin, const float* rrms, void* dqkv, float* dscale, float* dscale_partials,
                                            int64_t B, int64_t N, int64_t H, int64_t dh, int64_t rot, const int32_t* pos,

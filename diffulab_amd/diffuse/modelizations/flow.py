@@ -97,13 +97,29 @@ class Flow(Diffusion):
             return (model_inputs["x"] - prediction) / max(t_curr, 0.05)
         return prediction
 
+    def _get_v_pair(self, model, model_inputs, t_curr: float):
+        fn = getattr(model, "forward_cfg_pair", None)
+        if fn is None:
+            return None
+        p0 = next(model.parameters())
+        timesteps = torch.full((model_inputs["x"].shape[0],), t_curr, device=p0.device, dtype=p0.dtype)
+        pair = fn(timesteps, **model_inputs)
+        if pair is None or not self.x_prediction:
+            return pair
+        return tuple((model_inputs["x"] - pred) / max(t_curr, 0.05) for pred in pair)
+
     def one_step_denoise(self, model, model_inputs, t_prev: float, t_curr: float, guidance_scale: float,
                          sampler_args: dict[str, Any] = {}) -> StepResult:
-        v = self.get_v(model, {**model_inputs, "p": 0}, t_curr)
-        if guidance_scale > 0:  # second full forward with every label dropped; the combine is fused into the step kernel
-            v_dropped = self.get_v(model, {**model_inputs, "p": 1}, t_curr)
-            return self.sampler.step(model_inputs["x"], v, t_curr, t_prev, v_uncond=v_dropped,
+        if guidance_scale > 0:
+            # flow.py:256-259 makes two forwards (p = 0, then p = 1: every label dropped).  A denoiser whose `p` only reaches the
+            # label drop runs them as ONE forward over [x ; x] (FlatArenaDenoiser.forward_cfg_pair: same values per row, half the
+            # weight streaming); the combine v_u + g (v - v_u) is fused into the step kernel either way.
+            pair = self._get_v_pair(model, model_inputs, t_curr)
+            if pair is None:
+                pair = (self.get_v(model, {**model_inputs, "p": 0}, t_curr), self.get_v(model, {**model_inputs, "p": 1}, t_curr))
+            return self.sampler.step(model_inputs["x"], pair[0], t_curr, t_prev, v_uncond=pair[1],
                                      guidance_scale=guidance_scale, **sampler_args)
+        v = self.get_v(model, {**model_inputs, "p": 0}, t_curr)
         return self.sampler.step(model_inputs["x"], v, t_curr, t_prev, **sampler_args)
 
     def compute_loss(self, model, model_inputs, timesteps: Tensor, noise: Tensor | None = None, extra_losses=[],

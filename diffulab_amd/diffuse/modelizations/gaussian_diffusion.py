@@ -91,11 +91,18 @@ class GaussianDiffusion(Diffusion):
         device = next(model.parameters()).device
         timesteps = torch.full((model_inputs["x"].shape[0],), t, device=device, dtype=torch.int32)
         t_model = self._remap(timesteps)
-        prediction = model(**{**model_inputs, "p": 0}, timesteps=t_model)["x"]
         extra = {}
-        if guidance_scale > 0:  # CFG combine fused into the step kernel
-            extra = {"prediction_uncond": model(**{**model_inputs, "p": 1}, timesteps=t_model)["x"],
-                     "guidance_scale": guidance_scale}
+        pair = None
+        if guidance_scale > 0:  # CFG combine fused into the step kernel; the two forwards as one where the denoiser can (see Flow)
+            fn = getattr(model, "forward_cfg_pair", None)
+            pair = fn(t_model, **model_inputs) if fn is not None else None
+        if pair is not None:
+            prediction, extra = pair[0], {"prediction_uncond": pair[1], "guidance_scale": guidance_scale}
+        else:
+            prediction = model(**{**model_inputs, "p": 0}, timesteps=t_model)["x"]
+            if guidance_scale > 0:
+                extra = {"prediction_uncond": model(**{**model_inputs, "p": 1}, timesteps=t_model)["x"],
+                         "guidance_scale": guidance_scale}
         return self.sampler.step(model_prediction=prediction, timesteps=timesteps, xt=model_inputs["x"], clamp_x=clamp_x,
                                  **extra, **sampler_args)
 

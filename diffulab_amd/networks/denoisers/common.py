@@ -221,6 +221,47 @@ class FlatArenaDenoiser(Denoiser):
             self.flatten_parameters()
         return self._engine
 
+    # ---- classifier-free guidance: the conditional and the label-dropped forward of a sampler step as ONE forward
+    cfg_pair_capable = False  # True where `p` reaches nothing but the label drop (class-conditional MMDiT / DDT / UNetModel)
+
+    def _effective_labels(self, y_eff: Tensor, p: float) -> Tensor:
+        """LabelEmbed.drop_labels (nn.py:149): a torch device draw, the same one as the reference's; inside forward_cfg_pair the
+        second half of the rows is dropped instead (what p = 1 does to every row)"""
+        forced = self.__dict__.get("_forced_drop")
+        if forced is not None:
+            return torch.where(forced, self.n_classes, y_eff)
+        if p > 0:
+            return torch.where(torch.rand(y_eff.size(), device=y_eff.device) < p, self.n_classes, y_eff)
+        return y_eff
+
+    def forward_cfg_pair(self, timesteps: Tensor, **inputs: Any) -> tuple[Tensor, Tensor] | None:
+        """(prediction with the labels, prediction with every label dropped) -- the two forwards a guided sampler step makes
+        (flow.py:256-259, gaussian_diffusion.py one_step_denoise) -- from ONE forward over [x ; x] with the label rows
+        [y ; dropped]: every kernel of the path is per row / per sample, so the two halves are the values of the two separate
+        forwards, while the weights stream once and every launch has twice the rows.  The p = 1 forward's ``torch.rand(B)`` is still
+        drawn (and discarded) so the device RNG stream seen by a stochastic sampler step is the reference's.  None: not applicable
+        to this denoiser / these inputs (the caller then makes the two forwards)."""
+        y = inputs.get("y")
+        if (not self.cfg_pair_capable or not tuning.on("DL_CFG_PAIR") or y is None or inputs.get("initial_context") is not None
+                or getattr(self, "label_embed", None) is None or not getattr(self, "classifier_free", False)
+                or torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())
+                or any(getattr(layer, "_forward_hooks", None) for layer in getattr(self, "layers", ()))):
+            return None
+        x = inputs["x"]
+        B = x.shape[0]
+        dev = self.engine.dev
+        torch.rand(y.size(), device=dev)  # the draw of the p = 1 forward (every row is dropped whatever it returns)
+        two = {k: (torch.cat([v, v], dim=0) if isinstance(v, Tensor) and v.dim() > 0 and v.shape[0] == B else v)
+               for k, v in inputs.items() if k != "p"}
+        forced = torch.zeros(2 * B, dtype=torch.bool, device=dev)
+        forced[B:] = True
+        object.__setattr__(self, "_forced_drop", forced)
+        try:
+            pred = self(**two, timesteps=torch.cat([timesteps, timesteps], dim=0), p=0)["x"]
+        finally:
+            object.__setattr__(self, "_forced_drop", None)
+        return pred[:B], pred[B:]
+
     def _run(self, x: Tensor, t: Tensor, y_eff: Tensor | None, taps: tuple = ()):
         """prediction (and, with taps, the tapped block outputs)"""
         eng = self.engine

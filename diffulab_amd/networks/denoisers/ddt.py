@@ -20,6 +20,8 @@ from .mmdit import DiTBlock, MMDiT, MMDiTBlock, _LabelEmbed, _LastLayer
 
 
 class DDT(FlatArenaDenoiser):
+    cfg_pair_capable = True  # `p` only reaches the label drop: guided sampler steps batch their two forwards (forward_cfg_pair)
+
     def __init__(
         self,
         simple_ddt: bool = False,
@@ -169,10 +171,7 @@ class DDT(FlatArenaDenoiser):
             eng.context = (out["embeddings"].to(device=dev), keep.to(device=dev) if keep is not None else None)
         elif self.label_embed is not None:
             assert y is not None, "class-conditional DDT needs labels `y`"
-            y_eff = y.to(device=dev, dtype=torch.int64)
-            if p > 0:  # LabelEmbed.drop_labels nn.py:149
-                y_eff = torch.where(torch.rand(y_eff.size(), device=dev) < p, self.n_classes, y_eff)
-            y_eff = y_eff.contiguous()
+            y_eff = self._effective_labels(y.to(device=dev, dtype=torch.int64), p).contiguous()  # (drop_labels nn.py:149)
         taps = tuple(i for i, layer in enumerate(self.layers) if layer._forward_hooks)
         if not taps:
             return {"x": self._run(x, t, y_eff)}

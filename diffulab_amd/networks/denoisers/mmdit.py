@@ -133,6 +133,8 @@ class _LastLayer(nn.Module):
 
 
 class MMDiT(FlatArenaDenoiser):
+    cfg_pair_capable = True  # `p` only reaches the label drop: guided sampler steps batch their two forwards (forward_cfg_pair)
+
     def __init__(
         self,
         simple_dit: bool = False,
@@ -317,10 +319,7 @@ class MMDiT(FlatArenaDenoiser):
         y_eff = None
         if self.label_embed is not None:
             assert y is not None, "class-conditional DiT needs labels `y`"
-            y_eff = y.to(device=dev, dtype=torch.int64)
-            if p > 0:  # LabelEmbed.drop_labels nn.py:149 -- torch device RNG, same draw as the reference
-                y_eff = torch.where(torch.rand(y_eff.size(), device=dev) < p, self.n_classes, y_eff)
-            y_eff = y_eff.contiguous()
+            y_eff = self._effective_labels(y.to(device=dev, dtype=torch.int64), p).contiguous()  # (drop_labels nn.py:149)
         # forward hooks registered on a block (RePA: ``denoiser.layers[i].register_forward_hook``, repa.py:133-134) receive the
         # block's output as an extra differentiable output of the engine
         taps = tuple(i for i, layer in enumerate(self.layers) if layer._forward_hooks)

@@ -63,6 +63,8 @@ class _AttentionBlock(nn.Module):  # parameter holder for unet.py:240-322
 
 
 class UNetModel(FlatArenaDenoiser):
+    cfg_pair_capable = True  # `p` only reaches the label drop: guided sampler steps batch their two forwards (forward_cfg_pair)
+
     def __init__(
         self,
         image_size: list[int],
@@ -174,8 +176,5 @@ class UNetModel(FlatArenaDenoiser):
         t = timesteps.to(device=dev, dtype=torch.float32).contiguous()
         y_eff = None
         if self.label_embed is not None:
-            y_eff = y.to(device=dev, dtype=torch.int64)
-            if p > 0:  # LabelEmbed.drop_labels nn.py:149 -- torch device RNG, same draw as the reference
-                y_eff = torch.where(torch.rand(y_eff.size(), device=dev) < p, self.n_classes, y_eff)
-            y_eff = y_eff.contiguous()
+            y_eff = self._effective_labels(y.to(device=dev, dtype=torch.int64), p).contiguous()  # (drop_labels nn.py:149)
         return {"x": self._run(x, t, y_eff)}

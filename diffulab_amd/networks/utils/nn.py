@@ -219,7 +219,7 @@ def qk_norm_rope(qkv: Tensor, qk_norm: QKNorm, cos_sin: tuple[Tensor, Tensor], b
     head split as ONE launch on the packed rows ``qkv`` bf16 [batch * tokens, 3 D] -- the arithmetic of mmdit.py:81-91 -- returning
     q, k, v as bf16 [batch, heads, tokens, head_dim]; cos / sin are the f32 [tokens, rot / 2] tables of ``get_cos_sin_ndim_grid`` for
     one sample (every sample shares them).  Differentiable in qkv and the two scales."""
-    cos, sin = (t.reshape(-1, t.shape[-1]).float().contiguous() for t in cos_sin)
+    cos, sin = (t.reshape(-1, t.shape[-1]).to(device=qkv.device, dtype=torch.float32).contiguous() for t in cos_sin)
     assert qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.shape[0] == batch * tokens and cos.shape[0] == tokens
     return _QkNormRope.apply(qkv.contiguous(), qk_norm.query_norm.scale.float(), qk_norm.key_norm.scale.float(), cos, sin, batch, tokens, heads)
 

@@ -20,6 +20,8 @@ SWITCHES: dict[str, tuple[str, str]] = {
     "DL_MLP_RECOMPUTE": ("1", "SwiGLU backward recomputes the MLP-up pre-activations instead of storing them in the forward"),
     "DL_ATTN_V_IN_PLACE": ("1", "attention reads V / writes dV inside the token-major qkv rows (N <= 256)"),
     "DL_QK_INPLACE": ("1", "attention backward writes dQ / dK token-major and the QK-norm backward runs in place on the dqkv rows"),
+    "DL_ATTN_BWD_QKN": ("1", "256-token samples: the QK-norm + RoPE backward runs as the attention backward's epilogue (dl_attn_bwd_qkn: row "
+                        "sums from the dS / S tiles, exchanged between the heads of a sample) instead of a pass of its own over dqkv"),
     "DL_WGRAD_GROUP": ("1", "the four weight gradients of a block as one atomics-free launch (dl_gemm_tn_group)"),
     "DL_WGRAD_INLINE": ("0", "grouped weight gradients on the main stream instead of the side stream"),
     "DL_WGRAD_SERIAL": ("0", "per-problem weight gradients on the main stream (engines without the grouped form)"),
@@ -31,6 +33,8 @@ SWITCHES: dict[str, tuple[str, str]] = {
     "DL_MAIN_WGS": ("", "workgroup budget of the persistent main-chain kernels (experiments; default: all CUs, or CUs - reserve with a reducer)"),
     "DL_DP_EARLY_MOD": ("1", "data parallel: each block's adaLN rows are reduced as the block finishes"),
     "DL_HIPGRAPH": ("1", "samplers replay the denoiser forward as a captured hipGraph"),
+    "DL_CFG_PAIR": ("1", "guided sampler steps run the conditional and the label-dropped forward as ONE forward over [x ; x] "
+                    "(class-conditional MMDiT / DDT / UNetModel: same values per row, the weights stream once)"),
     "DL_UNET_SIDE": ("1", "UNet weight gradients on a side stream"),
     "DL_UNET_SPLITK": ("1", "split-K convolutions at the UNet's low-resolution levels (partial images + fixed-order fold: -7 % per step)"),
     "DL_UNET_DET_COLSUM": ("0", "UNet bias gradients through the bit-reproducible column sum (measured 2 % slower)"),

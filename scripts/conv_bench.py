@@ -17,12 +17,25 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) * 1e3 / n
 r64 = lambda v: (v + 63) // 64 * 64
 zero = torch.zeros(64, device=dev, dtype=BF)
-for H, ci, co in ((32, 128, 128), (32, 256, 128), (16, 256, 256), (16, 128, 256), (16, 512, 256), (8, 512, 512)):
+lib = ops.lib().cdll
+rows = []
+# every 3x3 convolution shape of the MNIST-DDPM UNet (model_channels 128, channel_mult 1-2-4-8, 32x32 .. 4x4) incl. the decoder's
+# concatenated inputs; old = the 128x128 kernel (+ split-K), big = conv3x3_big_k (persistent 256-row tiles)
+for H, ci, co in ((32, 128, 128), (32, 256, 128), (16, 128, 256), (16, 256, 256), (16, 512, 256), (16, 384, 256), (8, 256, 512), (8, 512, 512),
+                  (8, 1024, 512), (8, 768, 512), (4, 512, 1024), (4, 1024, 1024), (4, 2048, 1024), (4, 1536, 1024)):
     M = B * H * H
     x = torch.randn(M, ci, device=dev).to(BF)
     wf = (torch.randn(co, r64(9 * ci), device=dev) * 0.02).to(BF)
-    out = torch.empty(M, co, device=dev, dtype=BF)
     bias = torch.randn(co, device=dev)
     res = torch.randn(M, co, device=dev).to(BF)
-    us = timeit(lambda: ops.conv3x3_nt(x, B, H, H, ci, wf, out, co, bias, res, zero))
-    print(f"{H}x{H} Ci={ci:4d} Co={co:4d}: {us:7.1f} us  {2.0 * M * co * 9 * ci / us / 1e6:7.1f} TF/s")
+    scr = torch.empty(8 * M * co, device=dev)
+    outs, us = {}, {}
+    for mode, name in ((0, "old"), (1, "big")):
+        lib.dl_lab_set_conv_big(mode)
+        out = torch.empty(M, co, device=dev, dtype=BF)
+        us[name] = timeit(lambda: ops.conv3x3_nt(x, B, H, H, ci, wf, out, co, bias, res, zero, scr))
+        outs[name] = out.float()
+    err = float((outs["big"] - outs["old"]).norm() / outs["old"].norm())
+    fl = 2.0 * M * co * 9 * ci
+    print(f"{H:2d}x{H:<2d} Ci={ci:4d} Co={co:4d}: old {us['old']:7.1f} us {fl / us['old'] / 1e6:7.1f} TF/s   big {us['big']:7.1f} us {fl / us['big'] / 1e6:7.1f} TF/s   rel diff {err:.1e}")
+lib.dl_lab_set_conv_big(1)

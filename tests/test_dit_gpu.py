@@ -156,6 +156,62 @@ def test_sampler_loops_against_reference_fixture(golden, monkeypatch):
     assert rel(out["x"], g["loop_ddpm_x"]) < 3e-2
 
 
+@pytest.mark.parametrize("family", ["dit", "ddt", "unet"])
+def test_guided_step_as_one_paired_forward_equals_the_two_forwards(family, monkeypatch):
+    """a guided sampler step makes two denoiser forwards (p = 0, then p = 1: flow.py:256-259); the class-conditional
+    denoisers run them as ONE forward over [x ; x] with the label rows [y ; dropped] (DL_CFG_PAIR, default on).  Same values -- every
+    kernel of the path is per row / per sample -- and the same device RNG stream (the p = 1 forward's rand(B) is still drawn), checked
+    on a stochastic sampler: Euler-Maruyama for the flow, DDPM for the UNet."""
+    import diffulab_amd as da
+    from diffulab_amd import Diffuser
+
+    torch.manual_seed(0)
+    small = dict(input_channels=4, output_channels=4, inner_dim=128, num_heads=2, mlp_ratio=4, patch_size=2)
+    if family == "dit":
+        m, H = da.MMDiT(simple_dit=True, embedding_dim=64, depth=2, n_classes=10, classifier_free=True, **small), 16
+    elif family == "ddt":
+        m, H = da.DDT(simple_ddt=True, encoder_depth=2, decoder_depth=1, n_classes=10, classifier_free=True, **small), 16
+    else:
+        m, H = da.UNetModel(image_size=[16, 16], in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[2],
+                            channel_mult="1, 2", num_heads=2, use_scale_shift_norm=True, resblock_updown=True, n_classes=10,
+                            classifier_free=True), 16
+    with torch.no_grad():
+        for q in m.parameters():  # (zero-initialised output layers would make every prediction 0)
+            if float(q.abs().sum()) == 0:
+                q.normal_(0, 0.05)
+    m = m.to(DEV).eval()
+    B = 5
+    y = torch.randint(0, 10, (B,), device=DEV)
+    x_init = torch.randn(B, 4, H, H, device=DEV)
+    if family == "unet":
+        d = Diffuser(m, sampling_method="ddpm", model_type="gaussian_diffusion", n_steps=1000)
+        d.set_steps(4)
+    else:
+        d = Diffuser(m, sampling_method="euler_maruyama", model_type="rectified_flow", n_steps=4)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DL_CFG_PAIR", mode)
+        torch.manual_seed(11)
+        outs[mode] = d.generate({"x": x_init.clone(), "y": y}, use_tqdm=False, guidance_scale=2.5)["x"]
+        after = torch.rand(3, device=DEV)
+        outs[mode + "rng"] = after
+    assert torch.isfinite(outs["1"]).all() and float(outs["1"].abs().mean()) > 1e-3
+    assert torch.equal(outs["1rng"], outs["0rng"])  # both modes consumed the same number of device draws
+    # (bf16 kernels: a launch of 2 B rows may take another tile / split-K variant than one of B rows -- another f32 summation order
+    # before the same bf16 rounding; the UNet's low-resolution convolutions do, and four stochastic steps carry the ulps along)
+    tol = 2e-2 if family == "unet" else 2e-3
+    assert rel(outs["1"], outs["0"]) < tol, rel(outs["1"], outs["0"])
+    # and the pair itself, directly
+    t = torch.full((B,), 0.4 if family != "unet" else 7, device=DEV, dtype=torch.float32 if family != "unet" else torch.int32)
+    monkeypatch.setenv("DL_CFG_PAIR", "1")
+    with torch.no_grad():
+        pair = m.forward_cfg_pair(t, x=x_init, y=y)
+        sep = (m(x=x_init, timesteps=t, y=y, p=0)["x"], m(x=x_init, timesteps=t, y=y, p=1)["x"])
+    assert pair is not None and rel(pair[0], sep[0]) < tol and rel(pair[1], sep[1]) < tol and rel(pair[0], pair[1]) > 3e-2
+    monkeypatch.setenv("DL_CFG_PAIR", "0")
+    assert m.forward_cfg_pair(t, x=x_init, y=y) is None
+
+
 @pytest.mark.timeout(900)
 def test_dit_s2_against_reference_fixture(golden):
     """BASELINE config dims (DiT-S/2, 4x32x32 latents, 256 tokens): loss, prediction and gradient norms vs reference."""

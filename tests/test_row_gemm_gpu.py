@@ -156,8 +156,7 @@ def test_gemm_nt_qk_norm_rope_equals_gemm_then_row_kernel(ops, B, gh, gw):
     q0, k0 = (torch.full((B, H, Nt, dh), 7.0, device=DEV, dtype=torch.bfloat16) for _ in range(2))
     r0 = torch.zeros(M, 2, device=DEV)
     ops.gemm_nt(a, w, qkv0)
-    dummy = torch.zeros(8, device=DEV)  # (the unfused pass wants non-NULL tables even when it rotates nothing)
-    ops.qk_norm_rope_fwd(qkv0, sq, sk, cos if axes else dummy, sin if axes else dummy, q0, k0, None, r0, B, Nt, H, dh, rot)
+    ops.qk_norm_rope_fwd(qkv0, sq, sk, cos, sin, q0, k0, None, r0, B, Nt, H, dh, 64)
     qkv1 = torch.full((M, 3 * D), 7.0, device=DEV, dtype=torch.bfloat16)
     q1, k1 = (torch.full((B, H, Nt, dh), 7.0, device=DEV, dtype=torch.bfloat16) for _ in range(2))
     r1 = torch.zeros(M, 2, device=DEV)
