@@ -768,31 +768,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
     }
     __syncthreads();
     // the sample's row sums: thread t adds the H partials of token row t (q and k) in head order.  sc1 loads (served by L2, never
-    // by this CU's L1) as inline assembly: all 2 H requests are in flight together (the compiler serialises relaxed atomic loads)
+    // by this CU's L1), four heads x {q, k} per statement: loads AND their wait in ONE asm statement with early-clobber outputs --
+    // the compiler neither counts an asm load nor knows when its destination lands (MI355X guide, inline asm form (i))
     {
-      float cv[2][8];
-      const int nh = H < 8 ? H : 8;
-#pragma unroll
-      for (int w2 = 0; w2 < 2; ++w2)
-#pragma unroll
-        for (int hh = 0; hh < 8; ++hh) {
-          cv[w2][hh] = 0.f;
-          if (hh < nh) {
-            const float* ptr = fz.cpart + (((int64_t)b * H + hh) * 2 + w2) * N + threadIdx.x;
-            asm volatile("global_load_dword %0, %1, off sc1" : "=v"(cv[w2][hh]) : "v"(ptr) : "memory");
-          }
-        }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
       float tq = 0.f, tk = 0.f;
+      for (int h0 = 0; h0 < H; h0 += 4) {
+        const float* pq[4];
+        const float* pk[4];
 #pragma unroll
-      for (int hh = 0; hh < 8; ++hh) {
-        tq += cv[0][hh];
-        tk += cv[1][hh];
-      }
-      for (int hh = 8; hh < H; ++hh) {  // (more than 8 heads: the rest one by one)
-        tq += __hip_atomic_load(fz.cpart + (((int64_t)b * H + hh) * 2) * N + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tk += __hip_atomic_load(fz.cpart + (((int64_t)b * H + hh) * 2 + 1) * N + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int u = 0; u < 4; ++u) {
+          const int hh = h0 + u < H ? h0 + u : H - 1;  // (past the last head: a valid address, the value is not added)
+          pq[u] = fz.cpart + (((int64_t)b * H + hh) * 2) * N + threadIdx.x;
+          pk[u] = pq[u] + N;
+        }
+        float vq[4], vk[4];
+        asm volatile(
+            "global_load_dword %0, %8, off sc1\n\tglobal_load_dword %1, %9, off sc1\n\tglobal_load_dword %2, %10, off sc1\n\t"
+            "global_load_dword %3, %11, off sc1\n\tglobal_load_dword %4, %12, off sc1\n\tglobal_load_dword %5, %13, off sc1\n\t"
+            "global_load_dword %6, %14, off sc1\n\tglobal_load_dword %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+            : "=&v"(vq[0]), "=&v"(vq[1]), "=&v"(vq[2]), "=&v"(vq[3]), "=&v"(vk[0]), "=&v"(vk[1]), "=&v"(vk[2]), "=&v"(vk[3])
+            : "v"(pq[0]), "v"(pq[1]), "v"(pq[2]), "v"(pq[3]), "v"(pk[0]), "v"(pk[1]), "v"(pk[2]), "v"(pk[3])
+            : "memory");
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (h0 + u < H) {
+            tq += vq[u];
+            tk += vk[u];
+          }
       }
       lse2[threadIdx.x] = tq;   // (lse2 / delta are dead after phase B)
       delta[threadIdx.x] = tk;

@@ -17,6 +17,10 @@ from diffulab_amd.training.optim import FusedAdamW
 
 
 def main() -> None:
+    if os.environ.get("DL_LAB_CONV_BIG"):  # LAB A/B: 0 = the 128x128 implicit-GEMM kernel everywhere, 1 = conv3x3_big_k where it applies
+        from diffulab_amd import ops
+
+        ops.lib().cdll.dl_lab_set_conv_big(int(os.environ["DL_LAB_CONV_BIG"]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--steps", type=int, default=10)
