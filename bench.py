@@ -590,8 +590,11 @@ def main() -> None:
         dp = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "grad_bytes_per_step": model._flat_grad.numel() * 4,
               "exposed_allreduce_ms_per_step": None if tail is None else round(tail, 3),
               # how the exchange was scheduled in the timed region: decided by measurement during warm-up steps 2-13 (training/dp.py)
+              # (a pinned DIFFULAB_DP_OVERLAP still times BOTH schedules during the warm-up: the first run on a multi-GPU node
+              # yields the A/B whatever was pinned)
               "exchange": reducer.tuned or {"mode": "overlapped" if reducer.overlap else "after_backward",
-                                            "decided": "DIFFULAB_DP_OVERLAP pinned"},
+                                            "decided": "DIFFULAB_DP_OVERLAP pinned, DIFFULAB_DP_MEASURE=0 (or fewer warm-up steps than the "
+                                                       "measurement needs)"},
               "untimed_steps_before_timing": args.warmup + extra_warmup}
 
     roof = None

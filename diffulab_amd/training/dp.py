@@ -70,10 +70,16 @@ class GradReducer:
         # exchange after the backward costs its transfer time.  Which is cheaper depends on RCCL's residency on the node at hand:
         # synchronising steps 2-7 run overlapped, 8-13 with one exchange after the backward (median of the backward-to-finish
         # interval per mode, MAX over ranks); the overlapped default is only left when the single exchange wins by > 3 %.  "1" / "0" pin a mode.
+        # A pinned mode is still MEASURED against the other one during the same warm-up steps (both timings land in `tuned`), so the
+        # first run on a multi-GPU node yields the A/B whatever was pinned; the pin then decides.  DIFFULAB_DP_MEASURE=0 skips that.
         mode = os.environ.get("DIFFULAB_DP_OVERLAP", "auto")
         self.overlap = mode != "0"
+        self._pinned: bool | None = None if mode == "auto" else (mode != "0")
         self.tuned: dict | None = None
-        self._tune = {"step": 0, "marks": []} if (mode == "auto" and self.enabled) else None
+        measure = mode == "auto" or os.environ.get("DIFFULAB_DP_MEASURE", "1") != "0"
+        self._tune = {"step": 0, "marks": []} if (measure and self.enabled) else None
+        if self._tune is not None:
+            self.overlap = True  # the measurement starts with the overlapped schedule
 
     def rebind(self, flat_grad: Tensor) -> None:
         """point the reducer at a NEW gradient arena of the same layout (the denoiser re-flattened its parameters or switched
@@ -214,10 +220,14 @@ class GradReducer:
                              device=self.flat.device if self.flat.is_cuda else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)  # every rank takes the same decision
             t_overlap, t_after = float(t[0]), float(t[1])
-            # the overlapped schedule is the default and is only left for a clear win of the single exchange
-            self.overlap = t_overlap <= self.TUNE_MARGIN * t_after
+            # the overlapped schedule is the default and is only left for a clear win of the single exchange; a pinned mode wins
+            # over the measurement (which is reported all the same)
+            measured = t_overlap <= self.TUNE_MARGIN * t_after
+            self.overlap = measured if self._pinned is None else self._pinned
             self.tuned = {"mode": "overlapped" if self.overlap else "after_backward", "overlapped_ms_per_step": round(t_overlap, 3),
                           "after_backward_ms_per_step": round(t_after, 3),
+                          "decided": "measured" if self._pinned is None else "DIFFULAB_DP_OVERLAP pinned (measurement would pick %s)"
+                          % ("overlapped" if measured else "after_backward"),
                           "interval": "first final gradient range -> end of finish(), median of %d steps per mode" % self.TUNE_STEPS}
             if (dist.get_rank(self.group) if dist.is_initialized() else 0) == 0:
                 import logging
