@@ -474,137 +474,6 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_big_k(const bf16_t* __
   }
 }
 
-#ifdef NT_PP
-// LAB (round 5): "ping-pong" main loop for the 256 x 384 tile.  The eight waves form two groups of four (wave w and w + 4 share a SIMD)
-// that run the SAME code one barrier interval apart: while one group reads the eight fragments of a 16-deep sub-step out of the LDS
-// and issues its share of the next stage's DMA (R slot), its SIMD partners run the twelve MFMAs of their sub-step from registers at
-// raised priority (M slot); a k-step is eight such intervals.  In the lock-step loop above both waves of a SIMD issue their DMA,
-// their fragment reads and their MFMAs at the same moments, and a k-step costs DMA-issue time + MFMA time.
-//   slot of group A :  R0 | M0 | R1 | M1 | R2 | M2 | R3 | M3 |
-//   slot of group B :  M3'| R0 | M0 | R1 | M1 | R2 | M2 | R3 |        (' = previous k-step)
-// Stage it + 1 is DMA'd into the other ring slot during R0..R2 of k-step it (4 + 3 + 3 chunks per wave); a wave waits for its own
-// chunks at the end of its R3 slot, the barrier behind group B's R3 publishes the stage to group A's next R0.
-template <int EPI>
-__global__ __launch_bounds__(BIG_THREADS, 2) void gemm_nt_pp_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Bm,
-                                                                 int64_t ldb, void* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                                 NtEpilogue ep) {
-  constexpr int TN_ = 384, STAGE = (TBM + TN_) * 128, CH = 10, JN = 6;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, hi = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const bool late = wave >= 4;  // group B
-  const int tiles_n = N / TN_, ntiles = (M / TBM) * tiles_n;
-  const int nk = K / BK;
-  const int G = gridDim.x;
-  const int slot0 = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-  const int cnt = (ntiles - slot0 + G - 1) / G;
-  const int total = cnt * nk;
-  uint32_t src_off[CH];  // byte offsets inside the row panel
-  int lds_off[CH];
-  bool is_a[CH];
-#pragma unroll
-  for (int i = 0; i < CH; ++i) {
-    const int c = wave * CH + i;
-    is_a[i] = c < TBM / 8;
-    const int cc = is_a[i] ? c : c - TBM / 8;
-    const int r = cc * 8 + (lane >> 3);
-    const int q = (lane & 7) ^ ((r >> 1) & 7);
-    src_off[i] = (uint32_t)(r * (int)(is_a[i] ? lda : ldb) + q * 8) * 2u;
-    lds_off[i] = (is_a[i] ? 0 : TBM * 128) + cc * 1024;
-  }
-  int s_tile = slot0, s_kt = 0, s_it = 0;
-  const bf16_t* s_ta = A + (int64_t)((s_tile / tiles_n) * TBM) * lda;
-  const bf16_t* s_tb = Bm + (int64_t)((s_tile % tiles_n) * TN_) * ldb;
-  auto issue = [&](int lo, int n) {  // chunks [lo, lo + n) of the stage the DMA cursor points at
-    char* base = smem + (s_it & 1) * STAGE;
-    const char* ka = (const char*)(s_ta + s_kt * BK);
-    const char* kb = (const char*)(s_tb + s_kt * BK);
-#pragma unroll
-    for (int i = 0; i < CH; ++i)
-      if (i >= lo && i < lo + n) glds16(is_a[i] ? ka + src_off[i] : kb + src_off[i], base + lds_off[i]);
-  };
-  auto advance = [&]() {
-    ++s_it;
-    if (++s_kt == nk) {
-      s_kt = 0;
-      s_tile += G;
-      s_ta = A + (int64_t)((s_tile / tiles_n) * TBM) * lda;
-      s_tb = Bm + (int64_t)((s_tile % tiles_n) * TN_) * ldb;
-    }
-  };
-  int xrow[2], wrow[JN];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) xrow[i] = wm * 64 + i * 32 + (lane & 31);
-#pragma unroll
-  for (int j = 0; j < JN; ++j) wrow[j] = wn * (TN_ / 2) + j * 32 + (lane & 31);
-  f32x16_t acc[JN][2];
-#pragma unroll
-  for (int j = 0; j < JN; ++j)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-
-  if (total > 0) {
-    issue(0, CH);
-    advance();
-  }
-  wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();              // stage 0 is in the ring
-  if (late) __builtin_amdgcn_s_barrier();    // group B runs one interval behind
-  int tile = slot0, kt = 0;
-  for (int it = 0; it < total; ++it) {
-    const char* sa = smem + (it & 1) * STAGE;
-    const char* sb = sa + TBM * 128;
-    const bool more = s_it < total;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      // ---- R slot: the fragments of sub-step kk, this wave's share of the next stage's DMA
-      bf16x8_t xf[2], wf[JN];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) xf[i] = *(const bf16x8_t*)(sa + xrow[i] * 128 + ((((kk << 1) | hi) ^ ((xrow[i] >> 1) & 7)) << 4));
-#pragma unroll
-      for (int j = 0; j < JN; ++j) wf[j] = *(const bf16x8_t*)(sb + wrow[j] * 128 + ((((kk << 1) | hi) ^ ((wrow[j] >> 1) & 7)) << 4));
-      if (more) {  // NT_PP = 1: 4 + 3 + 3 chunks in R0 .. R2;  2: 5 + 5 in R0, R1;  3: all ten in R0
-        if (NT_PP == 1) {
-          if (kk == 0) issue(0, 4);
-          else if (kk == 1) issue(4, 3);
-          else if (kk == 2) issue(7, 3);
-        } else if (NT_PP == 2) {
-          if (kk == 0) issue(0, 5);
-          else if (kk == 1) issue(5, 5);
-        } else {
-          if (kk == 0) issue(0, 10);
-        }
-      }
-      if (kk == 3) {
-        if (more) advance();
-        wait_vmcnt<0>();  // this wave's chunks of the next stage (issued two or more intervals ago) have landed
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      // ---- M slot
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int j = 0; j < JN; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-    }
-    if (++kt == nk) {
-      kt = 0;
-      nt_epilogue_regs<JN, TN_, EPI>(acc, (tile / tiles_n) * TBM + wm * 64, (tile % tiles_n) * TN_ + wn * (TN_ / 2), lane, C, ldc, ep);
-      tile += G;
-    }
-  }
-  if (!late) __builtin_amdgcn_s_barrier();  // pairs with group B's last interval
-}
-#endif
-
 // register epilogue shared by the big-tile kernels (see gemm_nt_big_k header)
 template <int JN, int TN_, int EPI>
 __device__ __forceinline__ void nt_epilogue_regs(f32x16_t (&acc)[JN][2], int m_base, int n_base, int lane, void* C,
@@ -781,18 +650,6 @@ static int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, vo
 #define BIG_GO(E)                                                                                                     \
   hipLaunchKernelGGL((gemm_nt_big_k<TN_, NST, E>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)A, lda, (const bf16_t*)B, \
                      ldb, C, ldc, (int)M, (int)N, (int)K, ep)
-#ifdef NT_PP
-  if constexpr (TN_ == 384 && NST == 2) {
-    if (epi == 0) {
-      static DevOnce once_pp;
-      (void)dev_cus(once_pp, [] { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
-      hipLaunchKernelGGL((gemm_nt_pp_k<0>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, (int)M,
-                         (int)N, (int)K, ep);
-      DL_LAUNCH_CHECK();
-      return DL_OK;
-    }
-  }
-#endif
   if (epi == 0) BIG_GO(0);
   else if (epi == 1) BIG_GO(1);
   else if (epi == 3) {

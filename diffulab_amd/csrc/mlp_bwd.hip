@@ -147,10 +147,6 @@ __global__ __launch_bounds__(RC_THREADS, 2) void mlp_dswiglu_rc_k(const bf16_t* 
 #pragma unroll
   for (int j = 0; j < JN2; ++j) wrow2[j] = wn * (RC_TU / 2) + j * 32 + (lane & 31);
 
-#ifdef RC_STAGGER
-  // LAB: start-up skew between groups of workgroups so that their du store bursts (128 KB per tile and workgroup) are not in lockstep
-  for (int w = 0; w < ((blockIdx.x >> 3) & 3) * RC_STAGGER; ++w) __builtin_amdgcn_s_sleep(16);
-#endif
   if (total > 0) issue();
   int g = 0;
   bool after_epi = false;
