@@ -446,9 +446,9 @@ __global__ __launch_bounds__(512) void attn_fwd_qkn_k(const bf16_t* __restrict__
     const int d0 = ks * 16 + hi * 8;
     const u32x4_t t = qk_xform8(qraw[ks], rq, qn.sq + h * DH + d0, (const float*)&qc[ks], (const float*)&qs[ks], d0 < qn.rot);
     qf[ks] = __builtin_bit_cast(bf16x8_t, t);
-    *(u32x4_t*)(qn.qo + ((int64_t)bh * N + qrow) * DH + d0) = t;
+    if (qn.qo) *(u32x4_t*)(qn.qo + ((int64_t)bh * N + qrow) * DH + d0) = t;  // (NULL in inference: only the backward reads them)
   }
-  if (h == 0 && hi == 0) qn.rrms[tok * 2] = rq;
+  if (qn.rrms && h == 0 && hi == 0) qn.rrms[tok * 2] = rq;
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -461,8 +461,8 @@ __global__ __launch_bounds__(512) void attn_fwd_qkn_k(const bf16_t* __restrict__
       char* p = kt + tile_off(row, kslot);
       const u32x4_t t = qk_xform8(*(const u32x4_t*)p, rk, qn.sk + h * DH + kd0, (const float*)&kc[i], (const float*)&kn[i], kd0 < qn.rot);
       *(u32x4_t*)p = t;
-      *(u32x4_t*)(qn.ko + ((int64_t)bh * N + row) * DH + kd0) = t;
-      if (h == 0 && kslot == 0) qn.rrms[((int64_t)b * N + row) * 2 + 1] = rk;
+      if (qn.ko) *(u32x4_t*)(qn.ko + ((int64_t)bh * N + row) * DH + kd0) = t;
+      if (qn.rrms && h == 0 && kslot == 0) qn.rrms[((int64_t)b * N + row) * 2 + 1] = rk;
     }
   }
   __syncthreads();
@@ -525,11 +525,13 @@ __global__ __launch_bounds__(512) void attn_fwd_qkn_k(const bf16_t* __restrict__
 }
 
 /* DiTAttention.forward mmdit.py:81-100 from the pre-norm qkv rows: QK-RMSNorm (row statistics = ssq of dl_gemm_nt_ssq) + RoPE applied
- * on load, softmax(q k^T scale) v; also writes the normalised q, k head-major and rrms for the backward.  N % 64 == 0 up to 256. */
+ * on load, softmax(q k^T scale) v; also writes the normalised q, k head-major and rrms for the backward (q_out = k_out = rrms = NULL in
+ * inference: 100 MB of stores per launch at the headline shape that only the backward reads).  N % 64 == 0 up to 256. */
 extern "C" int dl_attn_fwd_qkn(const void* qkv, const float* ssq, const float* scale_q, const float* scale_k, const float* cos,
                                const float* sin, float eps, int64_t rot, void* q_out, void* k_out, float* rrms, void* out, float* lse,
                                int64_t B, int64_t H, int64_t N, int64_t dh, float scale, dl_stream_t stream) {
-  DL_CHECK_ARG(qkv && ssq && scale_q && scale_k && q_out && k_out && rrms && out && lse && B > 0 && H > 0, "dl_attn_fwd_qkn: null operand");
+  DL_CHECK_ARG(qkv && ssq && scale_q && scale_k && out && lse && B > 0 && H > 0, "dl_attn_fwd_qkn: null operand");
+  DL_CHECK_ARG((q_out && k_out && rrms) || (!q_out && !k_out && !rrms), "dl_attn_fwd_qkn: q_out, k_out and rrms are kept together (training) or not at all");
   DL_CHECK_ARG(rot == 0 || (cos && sin), "dl_attn_fwd_qkn: rot > 0 needs the cos / sin tables");
   DL_CHECK_ARG(dh == DH && rot % 8 == 0 && rot <= DH, "dl_attn_fwd_qkn: head_dim 64, rot %% 8 == 0 (dh=%lld rot=%lld)", (long long)dh,
                (long long)rot);

@@ -44,8 +44,10 @@ extern "C" int dl_dit_block_fwd(const dl_dit_block_t* b, int train, dl_stream_t 
                  "dl_dit_block_fwd: row_gemms needs V in place and the DL_BLK_NEXT_* slots");
     if (P(SSQ)) {  // QK-norm statistics leave with the qkv GEMM, the norm + RoPE are applied as the attention stages q and k
       RUN(dl_gemm_nt_ssq(P(XM1), D, P(W_QKV), b->ldw_d, P(QKV), 3 * D, M, 3 * D, D, (float*)P(SSQ), 2, stream));
+      // (inference: the normalised q, k and rrms feed only the backward -- not written)
       RUN(dl_attn_fwd_qkn(P(QKV), (const float*)P(SSQ), (const float*)P(QN_SCALE), (const float*)P(KN_SCALE), (const float*)P(ROPE_COS),
-                          (const float*)P(ROPE_SIN), 1e-6f, b->rot, P(Q), P(K), (float*)P(RRMS), P(A), (float*)P(LSE), B, H, N, dh, sm, stream));
+                          (const float*)P(ROPE_SIN), 1e-6f, b->rot, train ? P(Q) : nullptr, train ? P(K) : nullptr,
+                          train ? (float*)P(RRMS) : nullptr, P(A), (float*)P(LSE), B, H, N, dh, sm, stream));
     } else if (b->row_gemms & 2) {
       RUN(dl_gemm_nt_qk_norm_rope(P(XM1), D, P(W_QKV), b->ldw_d, B, N, H, dh, b->rot, 1e-6f, (const float*)P(QN_SCALE),
                                   (const float*)P(KN_SCALE), (const float*)P(ROPE_COS), (const float*)P(ROPE_SIN), P(QKV), P(Q), P(K),

@@ -640,8 +640,8 @@ class DiTEngine:
                 ssq = w["ssq_all"][i]
                 _must(ops.gemm_nt_ssq(a["xm1"], sh[pre + "attention.qkv.weight|f"], a["qkv"], ssq))
                 ops.attn_fwd_qkn(a["qkv"], ssq, self.P(pre + "attention.qk_norm.query_norm.scale"),
-                                 self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["q"], a["k"], a["rrms"], a["a"], a["lse"], B,
-                                 Hh, N, 64, rot, 64**-0.5)
+                                 self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["q"] if train else None,
+                                 a["k"] if train else None, a["rrms"] if train else None, a["a"], a["lse"], B, Hh, N, 64, rot, 64**-0.5)
             elif fused_qk:
                 _must(ops.gemm_nt_qk_norm_rope(a["xm1"], sh[pre + "attention.qkv.weight|f"],
                                                 self.P(pre + "attention.qk_norm.query_norm.scale"),

@@ -331,7 +331,7 @@ DL_API int dl_attn_bwd_qkn(const void* q, const void* k, const void* qkv, const 
  * DL_ERR_UNSUPPORTED.  dl_attn_fwd_qkn: DiTAttention.forward mmdit.py:81-100 from the PRE-NORM token-major qkv rows [B*N, 3D]: q and k
  * are normalised with r = rsqrt(ssq / D + eps), scaled and rotated (nn.py:345-353) as they are staged (K in LDS, Q in registers),
  * then softmax(q k^T scale) v as dl_attn_fwd_sv; the normalised q, k are also written head-major [B, H, N, 64] and r as rrms [B*N, 2]
- * (inputs of the backward kernels).  N % 64 == 0 up to 256, dh = 64. */
+ * (inputs of the backward kernels; all three NULL = inference, nothing of it is written).  N % 64 == 0 up to 256, dh = 64. */
 DL_API int dl_gemm_nt_ssq(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
                           int64_t K, float* ssq, int64_t ssq_tiles, dl_stream_t stream);
 DL_API int dl_attn_fwd_qkn(const void* qkv, const float* ssq, const float* scale_q, const float* scale_k, const float* cos,
