@@ -595,6 +595,41 @@ extern "C" int dl_cast_conv3x3_weight(const float* w, int64_t Co, int64_t Ci, vo
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
+// every 3x3 convolution weight of a network in ONE launch (the UNet has 56 of them: 56 launches of 3-130 us per step otherwise, each
+// with its launch gap on the main stream): a device table of descriptors, one 32 x 32 channel tile (x 9 taps) per workgroup, the
+// tile arithmetic of cast_conv3x3_tiled_k
+__global__ __launch_bounds__(256) void cast_conv3x3_batched_k(const dl_cast_conv_desc_t* __restrict__ desc, int n_desc) {
+  __shared__ float tile[CW_T * CW_P];
+  int lo = 0, hi = n_desc - 1;  // last descriptor whose tile_begin <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].tile_begin <= (int64_t)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const dl_cast_conv_desc_t d = desc[lo];
+  const int64_t t = (int64_t)blockIdx.x - d.tile_begin;
+  const int Ci = (int)d.Ci, Co = (int)d.Co, tci = Ci / CW_T;
+  const int co0 = (int)(t / tci) * CW_T, ci0 = (int)(t % tci) * CW_T;
+  const float* w = (const float*)d.w;
+  bf16_t* wf = (bf16_t*)d.wf;
+  bf16_t* wd = (bf16_t*)d.wd;
+  for (int i = threadIdx.x; i < CW_T * CW_T * 9; i += 256) {
+    const int col = i / (CW_T * 9), j = i - col * (CW_T * 9);
+    tile[col * CW_P + j] = w[((int64_t)(co0 + col) * Ci + ci0) * 9 + j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < CW_T * CW_T * 9; i += 256) {
+    const int l = i & (CW_T - 1), rest = i / CW_T, tap = rest % 9, o = rest / 9;
+    if (wf) wf[(int64_t)(co0 + o) * d.ldf + tap * Ci + ci0 + l] = f2bf(tile[o * CW_P + l * 9 + tap]);
+    if (wd) wd[(int64_t)(ci0 + o) * d.ldd + (8 - tap) * Co + co0 + l] = f2bf(tile[l * CW_P + o * 9 + tap]);
+  }
+}
+extern "C" int dl_cast_conv3x3_weights_batched(const dl_cast_conv_desc_t* desc_dev, int n_desc, int64_t total_tiles, dl_stream_t stream) {
+  DL_CHECK_ARG(desc_dev && n_desc > 0 && total_tiles > 0 && total_tiles < (1ll << 31), "dl_cast_conv3x3_weights_batched: bad args");
+  hipLaunchKernelGGL(cast_conv3x3_batched_k, (int)total_tiles, 256, 0, (hipStream_t)stream, desc_dev, n_desc);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
 // wgrad lands TRANSPOSED as [(tap, ci), Co] f32 (cols^T dY: its row count 9*Ci is a multiple of the 384-row tile of the big TN
 // GEMM for every 128-multiple channel count); fold it into the reference layout [Co, Ci, 3, 3] (+=)
 __global__ void conv3x3_wgrad_fold_k(const float* __restrict__ g, int64_t ldg, float* __restrict__ dw, int Co, int Ci) {

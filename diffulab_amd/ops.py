@@ -684,6 +684,38 @@ class CastTable:
         _call("dl_cast_weights_batched", _p(self.dev), self.n, self.tiles, _s())
 
 
+class ConvCastTable:
+    """device table for dl_cast_conv3x3_weights_batched: the forward / data-gradient shadows of every 3x3 convolution weight of a
+    network refreshed by ONE launch.  entries: (w f32 [Co, Ci, 3, 3], wf [Co, 9 Ci], wd [Ci, 9 Co]); `accepts` says which weights fit"""
+
+    @staticmethod
+    def accepts(w: Tensor, wf: Tensor, wd: Tensor) -> bool:
+        co, ci = w.shape[0], w.shape[1]
+        return co % 32 == 0 and ci % 32 == 0 and wf.stride(0) == 9 * ci and wd.stride(0) == 9 * co
+
+    def __init__(self, entries: list[tuple[Tensor, Tensor, Tensor]]) -> None:
+        import ctypes
+
+        class Desc(ctypes.Structure):
+            _fields_ = [("w", ctypes.c_void_p), ("Co", ctypes.c_int64), ("Ci", ctypes.c_int64), ("wf", ctypes.c_void_p),
+                        ("ldf", ctypes.c_int64), ("wd", ctypes.c_void_p), ("ldd", ctypes.c_int64), ("tile_begin", ctypes.c_int64)]
+
+        arr = (Desc * len(entries))()
+        tiles = 0
+        self.keep = entries  # the table holds raw pointers: keep the tensors alive
+        for i, (w, wf, wd) in enumerate(entries):
+            assert w.is_contiguous() and w.dtype == torch.float32 and self.accepts(w, wf, wd)
+            co, ci = w.shape[0], w.shape[1]
+            arr[i] = Desc(_p(w), co, ci, _p(wf), wf.stride(0), _p(wd), wd.stride(0), tiles)
+            tiles += (co // 32) * (ci // 32)
+        self.n, self.tiles = len(entries), tiles
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.dev = host.to(entries[0][0].device)
+
+    def run(self) -> None:
+        _call("dl_cast_conv3x3_weights_batched", _p(self.dev), self.n, self.tiles, _s())
+
+
 def cast_weight_swiglu(src, dst):
     _call("dl_cast_weight_swiglu", _p(src), src.shape[0] // 2, src.shape[1], _p(dst), dst.stride(0), _s())
 

@@ -291,15 +291,30 @@ class UNetEngine:
         key = (self.params.data_ptr(), ver, self.manual_version, _eng._PARAM_EPOCH, self.param_version)
         if not force and key == self._shadow_key:
             return
-        for name, (R, C), fwd, dgrad in self._lin:
-            if name == "@emb":
-                off = self.layout.entries[self.layout.emb_w0][0]
-                src = self.params[off : off + R * C].view(R, C)
-            else:
-                src = self.P(name).view(R, C)
-            ops.cast_weight(src, self.sh[name + "|f"] if fwd else None, self.sh[name + "|t"] if dgrad else None)
-        for name, co, ci, _ in self._conv:
-            ops.cast_conv3x3_weight(self.P(name), self.sh[name + "|f"], self.sh[name + "|d"])
+        # every shadow of the network in TWO launches (one table of the linear weights, one of the 3x3 convolution weights; built once
+        # per parameter arena) instead of one launch per weight: 107 launches of 3-130 us and their gaps on the main stream per step
+        tkey = self.params.data_ptr()
+        if getattr(self, "_cast_tables", (None,))[0] != tkey:
+            lin_entries, conv_entries, loose = [], [], []
+            for name, (R, C), fwd, dgrad in self._lin:
+                if name == "@emb":
+                    off = self.layout.entries[self.layout.emb_w0][0]
+                    src = self.params[off : off + R * C].view(R, C)
+                else:
+                    src = self.P(name).view(R, C)
+                lin_entries.append((src, self.sh[name + "|f"] if fwd else None, self.sh[name + "|t"] if dgrad else None, None))
+            for name, co, ci, _ in self._conv:
+                e = (self.P(name), self.sh[name + "|f"], self.sh[name + "|d"])
+                (conv_entries if ops.ConvCastTable.accepts(*e) else loose).append(e)
+            self._cast_tables = (tkey, ops.CastTable(lin_entries) if lin_entries else None,
+                                 ops.ConvCastTable(conv_entries) if conv_entries else None, loose)
+        _, lin_t, conv_t, loose = self._cast_tables
+        if lin_t is not None:
+            lin_t.run()
+        if conv_t is not None:
+            conv_t.run()
+        for w_, wf_, wd_ in loose:  # (channel counts that are not multiples of 32: the 1-channel stem / head)
+            ops.cast_conv3x3_weight(w_, wf_, wd_)
         self._shadow_key = key
 
     # ------------------------------------------------------------------ small helpers

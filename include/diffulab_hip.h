@@ -494,6 +494,20 @@ DL_API int dl_im2col3x3(const void* x, int64_t ldx, void* cols, int64_t B, int64
  * [Ci, ldd] (k = tap*Co + co, kernel rotated by 180 degrees) */
 DL_API int dl_cast_conv3x3_weight(const float* w, int64_t Co, int64_t Ci, void* wf, int64_t ldf, void* wd, int64_t ldd,
                                   dl_stream_t stream);
+/* the shadows of EVERY 3x3 convolution weight of a network in one launch: `desc_dev` is a DEVICE array of n_desc descriptors ordered by
+ * tile_begin; a tile is a 32 x 32 (output x input channel) block of one weight, tiles of a weight numbered co-tile major
+ * ((Co / 32) * (Ci / 32) of them; total_tiles = sum).  Only weights with Co % 32 == 0, Ci % 32 == 0 and unpadded shadows (ldf == 9 Ci,
+ * ldd == 9 Co) belong in the table (the others keep dl_cast_conv3x3_weight); wf / wd may be NULL. */
+typedef struct {
+  const void* w; /* f32 [Co, Ci, 3, 3] */
+  int64_t Co, Ci;
+  void* wf;      /* bf16 [Co, ldf]: k = tap * Ci + ci */
+  int64_t ldf;
+  void* wd;      /* bf16 [Ci, ldd]: k = (8 - tap) * Co + co */
+  int64_t ldd;
+  int64_t tile_begin;
+} dl_cast_conv_desc_t;
+DL_API int dl_cast_conv3x3_weights_batched(const dl_cast_conv_desc_t* desc_dev, int n_desc, int64_t total_tiles, dl_stream_t stream);
 /* implicit-GEMM 3x3 / pad-1 convolution (no cols matrix: the GEMM's operand loads gather the taps, out-of-image taps read
  * the caller's `zero` line of >= 16 zero bytes):  out[p, co] = bias[co] + sum_{tap,ci} x[p + shift(tap), ci] Wf[co, tap*Ci+ci]
  * (+ resid[p, co]).  Wf = forward shadow of dl_cast_conv3x3_weight; with the rotated shadow and x = dY it is the data

@@ -49,11 +49,26 @@ def main() -> None:
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
+    t_issue = (time.perf_counter() - t0) / a.steps  # host time to ISSUE a step (no synchronisation inside the loop)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     print(json.dumps({"workload": "unet-mnist-ddpm train step", "batch": a.batch, "ms_per_step": dt * 1e3,
-                      "images_per_s": a.batch / dt, "params_M": sum(p.numel() for p in m.parameters()) / 1e6,
-                      "loss": float(loss)}))
+                      "images_per_s": a.batch / dt, "host_issue_ms_per_step": t_issue * 1e3,
+                      "params_M": sum(p.numel() for p in m.parameters()) / 1e6, "loss": float(loss)}))
+    if os.environ.get("UNET_HOST_PROFILE"):  # LAB: where the host time of a step goes
+        import cProfile
+        import io
+        import pstats
+
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(3):
+            step()
+        pr.disable()
+        torch.cuda.synchronize()
+        st = io.StringIO()
+        pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(30)
+        print(st.getvalue()[:7000])
 
 
 if __name__ == "__main__":
