@@ -481,8 +481,8 @@ def main() -> None:
                     "path; gloo is the DRY MODE of the data-parallel branch for boxes with fewer GPUs than ranks: the ranks share the "
                     "visible GPUs and exchange through gloo, so the reducer, the overlap instrumentation and the `dp` object run "
                     "(tests/test_trainer_gpu.py); its throughput number means nothing")
-    ap.add_argument("--trainer-mode", action="store_true", help="secondary number: the step as BaseTrainer.training_step runs it "
-                    "with the shipped defaults (per-loss .item() read-back every step, fused EMA update every step)")
+    ap.add_argument("--trainer-mode", action="store_true", help="secondary number (N = 1): the timed step IS BaseTrainer.training_step "
+                    "(loss meter, fused EMA) instead of the bare zero_grad / loss / backward / AdamW sequence")
     ap.add_argument("--launch-check", action="store_true", help="print this rank's launch environment and exit before any GPU "
                     "call (tests/test_host_logic.py checks the self-launch path on the CPU container with it)")
     args = ap.parse_args()
@@ -540,17 +540,21 @@ def main() -> None:
         opt.step()
 
     ema = None
-    if args.trainer_mode:
-        from diffulab_amd.training import EMA
+    if args.trainer_mode and world == 1:
+        # the step as the drop-in trainer runs it: BaseTrainer.training_step itself (zero_grad -> CPU timestep draw -> loss heads ->
+        # meter update -> backward -> optimizer step -> EMA), on a batch that is already on the device (a prefetching loader)
+        import tempfile
 
+        from diffulab_amd.training import EMA, AverageMeter, BaseTrainer
+
+        trainer = BaseTrainer(n_epoch=1, precision_type="bf16", save_path=tempfile.mkdtemp(prefix="bench_trainer_"), use_ema=True)
         ema = EMA(model, beta=0.999, update_after_step=0, update_every=10)
-        base_step = step
+        meter = AverageMeter()
+        batch = {"model_inputs": {"x": x_data, "y": y_data}, "extra": {}}
 
         def step() -> None:  # noqa: F811
-            base_step()
-            float(loss_host)  # (the value of the PREVIOUS copy would do for logging; .item() semantics = wait for this one)
-            torch.cuda.current_stream().synchronize()
-            ema.update()
+            trainer.training_step(diffuser=diffuser, optimizer=opt, batch=batch, tracker=meter, p_classifier_free_guidance=0.1,
+                                  ema_denoiser=ema)
 
     def sync() -> None:
         if world > 1:
@@ -626,7 +630,7 @@ def main() -> None:
             if args.dp_backend == "gloo":
                 out["data"] = "synthetic (DRY MODE of the dp branch: ranks share GPUs, gloo exchange -- not a throughput measurement)"
         if args.trainer_mode:
-            out["config"]["trainer_mode"] = "per-step loss read-back + EMA(update_every=10), as BaseTrainer.training_step with use_ema"
+            out["config"]["trainer_mode"] = "BaseTrainer.training_step itself (loss meter, EMA(update_every=10)) on a device-resident batch"
         print(json.dumps(out))
     if world > 1:
         dist.barrier()  # rank 0 was still replaying / printing: tear the communicator down together

@@ -436,7 +436,10 @@ __global__ void gn_bwd_apply_k(const bf16_t* __restrict__ dout, const bf16_t* __
     *(u32x4_t*)(dx + o) = pack8(xv);
   }
 }
-static bool gn_bwd_fused() { return true; }  // (the three-launch form stays for the shapes the fused kernel does not take)
+static int g_gn_fused = 1;  // 1: fused (128-channel slabs on small maps where they fit, 64-channel slabs on the large maps); 2: fused, 512-channel slabs on
+                             // small maps only (round 4); 0: three launches
+extern "C" __attribute__((visibility("default"))) void dl_lab_set_gn_fused(int mode) { g_gn_fused = mode; }  // LAB A/B switch (not in the header)
+static int gn_bwd_fused() { return g_gn_fused; }  // (the three-launch form stays for the shapes the fused kernel does not take)
 // pixel ranges of gn_bwd_reduce_k: enough workgroups to fill the chip at small batch x channel counts, at least 64 pixels each
 static inline int gn_bwd_ranges(int64_t B, int64_t HW, int64_t C) {
   const int64_t slabs = (C + 63) / 64;
@@ -461,6 +464,26 @@ extern "C" int dl_gn_bwd(const void* dout, const void* x, const float* stats, co
   float* AB = scratch + (int64_t)DL_GN_BWD_MAX_RANGES * B * 4 * C;
   int ns = 1;
   const GnFused none{};
+  if (HW <= 64 && C >= 512 && 128 % (C / G) == 0 && C % 128 == 0 && gn_bwd_fused() == 1) {
+    // 128-channel slabs (whole groups), 16 pixel lanes: four times the workgroups of the 512-channel form below -- at B = 128 that
+    // one launches 128-384 workgroups of 4-16 serial pixel iterations on a 256-CU chip (54 us for 40 MB of traffic)
+    const GnFused fz{dw, db, (bf16_t*)dfilm_scale, (bf16_t*)dfilm_shift, ld_dfilm, (const bf16_t*)dres, (bf16_t*)dx};
+    hipLaunchKernelGGL((gn_bwd_reduce_k<16, true>), dim3((unsigned)(B * (C / 128)), 1u), 256, 0, (hipStream_t)stream,
+                       (const bf16_t*)dout, (const bf16_t*)x, stats, w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift,
+                       ld_film, act_silu, Sp, (int)B, (int)HW, (int)C, (int)G, fz);
+    DL_LAUNCH_CHECK();
+    return DL_OK;
+  }
+  if (HW > 64 && HW <= 1024 && 64 % (C / G) == 0 && C % 64 == 0 && B * (C / 64) >= 128 && (gn_bwd_fused() & 1)) {
+    // high-resolution maps (16 x 16, 32 x 32): the same fusion on 64-channel slabs with 32 pixel lanes -- one launch instead of
+    // reduce (pixel ranges) + group sums + apply; the second pass re-reads the slab's x / dout (up to 2 x 128 KB) through L2 / MALL
+    const GnFused fz{dw, db, (bf16_t*)dfilm_scale, (bf16_t*)dfilm_shift, ld_dfilm, (const bf16_t*)dres, (bf16_t*)dx};
+    hipLaunchKernelGGL((gn_bwd_reduce_k<8, true>), dim3((unsigned)(B * (C / 64)), 1u), 256, 0, (hipStream_t)stream,
+                       (const bf16_t*)dout, (const bf16_t*)x, stats, w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift,
+                       ld_film, act_silu, Sp, (int)B, (int)HW, (int)C, (int)G, fz);
+    DL_LAUNCH_CHECK();
+    return DL_OK;
+  }
   if (HW <= 64 && C >= 512 && 512 % (C / G) == 0 && gn_bwd_fused()) {
     const GnFused fz{dw, db, (bf16_t*)dfilm_scale, (bf16_t*)dfilm_shift, ld_dfilm, (const bf16_t*)dres, (bf16_t*)dx};
     hipLaunchKernelGGL((gn_bwd_reduce_k<64, true>), dim3((unsigned)(B * ((C + 511) / 512)), 1u), 256, 0, (hipStream_t)stream,

@@ -18,7 +18,7 @@ from torch import Tensor
 from ... import ops
 from ..samplers.common import StepResult
 from ..samplers.flow import Euler, EulerMaruyama
-from ..utils import SamplingOutput
+from ..utils import SamplingOutput, to_device
 from .diffusion import Diffusion, mse_head
 
 try:
@@ -129,7 +129,7 @@ class Flow(Diffusion):
         prediction = model(**model_inputs, timesteps=timesteps)
         pred = prediction["x"]
         if self.x_prediction:
-            t_dev = timesteps.to(device=pred.device, dtype=torch.float32).contiguous()
+            t_dev = to_device(timesteps, pred.device, torch.float32)
             pred = _XToV.apply(pred, model_inputs["x"], t_dev) if pred.requires_grad else ops.flow_x_to_v(
                 model_inputs["x"], pred.float().contiguous(), t_dev)
             prediction["x"] = pred
@@ -149,7 +149,7 @@ class Flow(Diffusion):
         noise = noise.to(device=x.device, dtype=torch.float32).contiguous()
         assert noise.shape == x.shape
         assert timesteps.shape[0] == x.shape[0]
-        t = timesteps.to(device=x.device, dtype=torch.float32).contiguous()
+        t = to_device(timesteps, x.device, torch.float32)
         return ops.flow_add_noise(x, noise, t), noise
 
     @torch.inference_mode()

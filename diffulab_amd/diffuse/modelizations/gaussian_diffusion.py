@@ -16,7 +16,7 @@ from torch import Tensor
 from ... import ops
 from ..samplers.common import StepResult
 from ..samplers.gaussian_diffusion import DDIM, DDPM
-from ..utils import SamplingOutput, f32_table
+from ..utils import SamplingOutput, f32_table, to_device
 from .diffusion import Diffusion, mse_head
 from .utils import space_timesteps
 
@@ -125,7 +125,7 @@ class GaussianDiffusion(Diffusion):
         if x.device not in self._dev:
             self._dev[x.device] = (f32_table(self.sqrt_alphas_bar, x.device), f32_table(self.alphas_bar, x.device))
         sab, ab = self._dev[x.device]
-        return ops.ddpm_add_noise(x, noise, timesteps.to(device=x.device, dtype=torch.int32).contiguous(), sab, ab), noise
+        return ops.ddpm_add_noise(x, noise, to_device(timesteps, x.device, torch.int32), sab, ab), noise
 
     # The reference leaves autograd on in this loop (gaussian_diffusion.py:344-447 carries no inference_mode / no_grad, unlike
     # Flow.denoise): outside the trainer's @no_grad image logging it would record a graph through all 1000 steps.  Here the

@@ -26,3 +26,46 @@ def f32_table(table_fp64: Tensor, device: torch.device) -> Tensor:
     """fp64 schedule table -> fp32 device table: the same rounding `extract_into_tensor` applies per gather
     (diffuse/utils.py:16 `.float()`), hoisted out of the loop."""
     return table_fp64.to(torch.float32).to(device).contiguous()
+
+
+class _PinnedRing:
+    """pinned staging slots for small host -> device transfers (per-step timestep vectors): a pageable `.to(device)` blocks the host
+    until the stream has drained everything queued before it, i.e. once per training step the host loses its whole lead over the GPU
+    -- and a step of short kernels (the UNet: 800 launches of 10-90 us) then runs its forward at the host's launch rate.  A slot is
+    reused only after the copy that last read it has completed (an event per slot), so the host may run several steps ahead."""
+
+    SLOTS = 8
+
+    def __init__(self) -> None:
+        self.slots: dict[tuple, list] = {}
+
+    def put(self, t: Tensor, device: torch.device, dtype: torch.dtype) -> Tensor:
+        key = (tuple(t.shape), dtype, device)
+        ring = self.slots.get(key)
+        if ring is None:
+            n = self.SLOTS if t.numel() * t.element_size() <= (1 << 18) else 3  # (batch-sized tensors: three slots are enough)
+            ring = self.slots[key] = [0, [(torch.empty(t.shape, dtype=dtype).pin_memory(), torch.cuda.Event()) for _ in range(n)], [False] * n]
+        i = ring[0]
+        buf, ev = ring[1][i]
+        if ring[2][i]:
+            ev.synchronize()  # (eight transfers ago: completed long since unless the host is that far ahead)
+        buf.copy_(t)  # host-side conversion + copy into the pinned slot
+        out = buf.to(device, non_blocking=True)
+        ev.record(torch.cuda.current_stream(device))
+        ring[2][i] = True
+        ring[0] = (i + 1) % len(ring[1])
+        return out
+
+
+_RING = _PinnedRing()
+
+
+def to_device(t: Tensor, device: torch.device | str, dtype: torch.dtype) -> Tensor:
+    """`t.to(device=device, dtype=dtype).contiguous()` without the host-side synchronisation of a pageable copy (small CPU tensors go
+    through a ring of pinned slots -- timestep vectors, batches of up to 32 MB --, everything else is the plain call): same values,
+    same dtype conversion"""
+    device = torch.device(device)
+    if t.device.type == "cpu" and device.type == "cuda" and t.numel() * t.element_size() <= (32 << 20) and not t.requires_grad and t.numel() > 0:
+        return _RING.put(t.detach(), device, dtype)
+    return t.to(device=device, dtype=dtype).contiguous()
+

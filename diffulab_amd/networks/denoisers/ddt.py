@@ -16,6 +16,7 @@ from torch import Tensor
 
 from ...ddt_engine import DDTDims, DDTEngine, DDTJointDims, DDTJointEngine
 from .common import FlatArenaDenoiser, ModelOutput
+from ...diffuse.utils import to_device
 from .mmdit import DiTBlock, MMDiT, MMDiTBlock, _LabelEmbed, _LastLayer
 
 
@@ -162,7 +163,7 @@ class DDT(FlatArenaDenoiser):
         eng = self.engine
         dev = eng.dev
         x = x.to(device=dev, dtype=torch.float32).contiguous()
-        t = timesteps.to(device=dev, dtype=torch.float32).contiguous()
+        t = to_device(timesteps, dev, torch.float32)
         y_eff = None
         if not self.simple_ddt:
             assert self.context_embedder is not None, "for MMDiT context embedder must be provided"

@@ -23,6 +23,7 @@ from ...engine import DiTDims, DiTEngine
 from ...mmdit_engine import JointDims, JointEngine
 from ...sprint_joint_engine import JointStackDims
 from .common import FlatArenaDenoiser, ModelOutput
+from ...diffuse.utils import to_device
 
 
 class _RMSScale(nn.Module):
@@ -278,7 +279,7 @@ class MMDiT(FlatArenaDenoiser):
         keep = out.get("attn_mask", None)
         eng.context = (emb, keep.to(device=dev) if keep is not None else None)
         x = x.to(device=dev, dtype=torch.float32).contiguous()
-        t = timesteps.to(device=dev, dtype=torch.float32).contiguous()
+        t = to_device(timesteps, dev, torch.float32)
         taps = tuple(i for i, layer in enumerate(self.layers) if layer._forward_hooks)
         if not taps:
             return {"x": self._run(x, t, None)}
@@ -315,7 +316,7 @@ class MMDiT(FlatArenaDenoiser):
         eng = self.engine
         dev = eng.dev
         x = x.to(device=dev, dtype=torch.float32).contiguous()
-        t = timesteps.to(device=dev, dtype=torch.float32).contiguous()  # nn.py:110: timesteps[:, None].float()
+        t = to_device(timesteps, dev, torch.float32)  # nn.py:110: timesteps[:, None].float()
         y_eff = None
         if self.label_embed is not None:
             assert y is not None, "class-conditional DiT needs labels `y`"

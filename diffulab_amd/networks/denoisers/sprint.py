@@ -22,6 +22,7 @@ from torch import Tensor
 from ...sprint_engine import Route, SprintDims, SprintEngine
 from ...sprint_joint_engine import SprintJointDims, SprintJointEngine
 from .common import FlatArenaDenoiser, ModelOutput
+from ...diffuse.utils import to_device
 from .mmdit import DiTBlock, MMDiT, MMDiTBlock, MMDiTSingleStreamBlock, _LabelEmbed, _LastLayer
 
 
@@ -232,7 +233,7 @@ class SprintDiT(FlatArenaDenoiser):
         eng = self.engine
         dev = eng.dev
         x = x.to(device=dev, dtype=torch.float32).contiguous()
-        t = timesteps.to(device=dev, dtype=torch.float32).contiguous()
+        t = to_device(timesteps, dev, torch.float32)
         y_eff = None
         if not self.simple_dit:  # sprint.py:411-424: the embedder (context drop) first, then the routing draws
             assert self.context_embedder is not None, "for MMDiT context embedder must be provided"

@@ -24,6 +24,7 @@ from torch import Tensor
 
 from ...unet_engine import UNetDims, UNetEngine, build_plan
 from .common import FlatArenaDenoiser, ModelOutput
+from ...diffuse.utils import to_device
 from .mmdit import _LabelEmbed
 
 
@@ -173,7 +174,7 @@ class UNetModel(FlatArenaDenoiser):
         assert list(x.shape[2:]) == self.image_size, f"Input shape {x.shape[2:]} does not match model image size {self.image_size}"
         dev = self.engine.dev
         x = x.to(device=dev, dtype=torch.float32).contiguous()
-        t = timesteps.to(device=dev, dtype=torch.float32).contiguous()
+        t = to_device(timesteps, dev, torch.float32)
         y_eff = None
         if self.label_embed is not None:
             y_eff = self._effective_labels(y.to(device=dev, dtype=torch.int64), p).contiguous()  # (drop_labels nn.py:149)

@@ -20,6 +20,7 @@ from torch.optim.optimizer import Optimizer
 
 from ...datasets.base import BatchData
 from ..ema import EMA
+from ...diffuse.utils import to_device
 from ..utils import AverageMeter
 from .common import Trainer
 
@@ -46,12 +47,15 @@ class BaseTrainer(Trainer):
             optimizer.zero_grad()
         batch = self.shard_batch(batch)
         model_inputs = self.move_dict_to_device(dict(batch["model_inputs"]))
-        timesteps = diffuser.draw_timesteps(model_inputs["x"].shape[0]).to(self.device)
+        t_host = diffuser.draw_timesteps(model_inputs["x"].shape[0])
+        timesteps = to_device(t_host, self.device, t_host.dtype)  # (no host synchronisation: pinned staging ring, diffuse/utils.py)
         model_inputs.update({"p": p_classifier_free_guidance})
         extra = self.move_dict_to_device(dict(batch.get("extra", {})))
         losses = diffuser.compute_loss(model_inputs=model_inputs, timesteps=timesteps, extra_args=extra)
         for key, loss in losses.items():
-            tracker.update(loss.item(), key=f"train/{key}")
+            # the reference reads `loss.item()` here (base_trainer.py:122): a host synchronisation between forward and backward of
+            # every step; the meter takes the device scalar and reads it back when it is looked at (same floats, same order)
+            tracker.update(loss.detach(), key=f"train/{key}")
         loss = sum(losses.values())
         (loss / self.gradient_accumulation_step).backward()
         if self.sync_gradients:

@@ -42,6 +42,7 @@ from torch.optim.lr_scheduler import LRScheduler
 from torch.optim.optimizer import Optimizer
 
 from ...datasets.base import BatchData
+from ...diffuse.utils import to_device
 from ..dp import GradReducer, broadcast_arena
 from ..ema import EMA
 
@@ -115,7 +116,8 @@ class Trainer(ABC):
 
     # ------------------------------------------------------------------ accelerate-equivalent plumbing
     def move_dict_to_device(self, batch: dict[str, Any]) -> dict[str, Any]:
-        return {k: v.to(self.device) if isinstance(v, Tensor) else v for k, v in batch.items()}
+        # (host tensors of a batch go through the pinned staging ring: a pageable `.to(device)` would block until the queue has drained)
+        return {k: to_device(v, self.device, v.dtype) if isinstance(v, Tensor) else v for k, v in batch.items()}
 
     def shard_batch(self, batch: dict[str, Any]) -> dict[str, Any]:
         """split_batches=True (common.py:104): rank r keeps rows [r*B/W, (r+1)*B/W) of every tensor / list entry"""

@@ -21,6 +21,10 @@ def main() -> None:
         from diffulab_amd import ops
 
         ops.lib().cdll.dl_lab_set_conv_big(int(os.environ["DL_LAB_CONV_BIG"]))
+    if os.environ.get("DL_LAB_GN_FUSED"):  # LAB A/B: 1 = 128-channel slabs (default), 2 = 512-channel slabs only, 0 = three launches
+        from diffulab_amd import ops
+
+        ops.lib().cdll.dl_lab_set_gn_fused(int(os.environ["DL_LAB_GN_FUSED"]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--steps", type=int, default=10)

@@ -259,6 +259,27 @@ class _RangeRecorder:
         self.rebound = flat_grad
 
 
+def test_average_meter_reads_device_losses_back_lazily_and_identically():
+    """the trainer hands the meter `loss.detach()` (no host synchronisation between forward and backward); the values are read back
+    when the meter is looked at, in the order of the calls, as the floats `.item()` would have produced"""
+    from diffulab_amd.training.utils import AverageMeter
+
+    g = torch.Generator().manual_seed(3)
+    vals = torch.rand(300, generator=g)
+    lazy, eager = AverageMeter(), AverageMeter()
+    for i, v in enumerate(vals):
+        key = "train/loss" if i % 3 else "train/repa"
+        lazy.update(v.to(DEV), key, n=1 + i % 2)
+        eager.update(v.item(), key, n=1 + i % 2)
+        if i == 10:
+            assert lazy._pending and lazy.keys == eager.keys  # nothing read yet, the keys exist
+    assert len(lazy._pending) < AverageMeter.MAX_PENDING  # (flushed once on the way: bounded)
+    assert lazy.avg == eager.avg and lazy.sum == eager.sum and lazy.count == eager.count and not lazy._pending
+    lazy.update(torch.tensor(2.0, device=DEV), "train/loss")
+    lazy.reset()
+    assert lazy.count["train/loss"] == 0 and not lazy._pending
+
+
 def test_reducer_survives_a_precision_switch_after_prepare():
     """set_precision() after the trainer's prepare() drops the engine the reducer was attached to; the engine that
     replaces it (and a plain re-flattening) must carry the reducer over, re-pointed at the NEW gradient arena -- otherwise a

@@ -239,3 +239,20 @@ def test_precision_types_follow_the_reference_default(tmp_path):
                   rope_axes_dim=[16, 24, 24], context_embedder=PrecomputedEmbedder(torch.zeros(8, 64), 4))
     with pytest.raises(NotImplementedError, match="fp32"):  # the joint text-image forms keep the bf16 regime (their configs pin it)
         joint.set_precision("fp32")
+
+
+def test_average_meter_keeps_the_reference_surface():
+    """reference training/utils.py:1-25: keys / avg / sum / count dictionaries, update(val, key, n), reset() -- plain floats and 0-d CPU
+    tensors enter at once; (0-d DEVICE tensors are read back when the meter is looked at: tests/test_trainer_gpu.py)"""
+    from diffulab_amd.training.utils import AverageMeter
+
+    m = AverageMeter()
+    m.update(1.5, "train/loss")
+    m.update(torch.tensor(2.5), "train/loss", n=3)
+    m.update(4.0, "val/loss")
+    assert m.keys == ["train/loss", "val/loss"] and m.avg == {"train/loss": 2.25, "val/loss": 4.0}
+    assert m.sum == {"train/loss": 9.0, "val/loss": 4.0} and m.count == {"train/loss": 4, "val/loss": 1}
+    m.reset()
+    assert m.avg == {"train/loss": 0, "val/loss": 0} and m.count["train/loss"] == 0
+    m.update(3.0, "train/loss")
+    assert m.avg["train/loss"] == 3.0
