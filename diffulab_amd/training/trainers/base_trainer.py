@@ -1,7 +1,7 @@
 """``BaseTrainer``: the training loop of the reference (training/trainers/base_trainer.py:104-399) on the MI355X runtime.
 
 ``training_step`` keeps the reference's order of operations (base_trainer.py:138-153): zero_grad -> draw timesteps (CPU generator)
--> compute_loss -> ``.item()`` of every loss into the tracker -> backward -> optimizer.step -> scheduler -> EMA update.
+-> compute_loss -> every loss into the tracker (the reference's ``.item()``; here a device scalar the meter reads back lazily) -> backward -> optimizer.step -> scheduler -> EMA update.
 What Accelerate did implicitly is spelled out (see trainers/common.py): loss / gradient_accumulation_step before backward,
 ``zero_grad`` / ``step`` / scheduler gated on the synchronising micro-step (so with k > 1 the default reproduces the reference's
 "(1/k) * gradient of the last micro-batch" update), EMA on every micro-step, gradient all-reduce overlapped
@@ -75,7 +75,7 @@ class BaseTrainer(Trainer):
         extra_args = self.move_dict_to_device(dict(val_batch.get("extra", {})))
         val_losses = diffuser.compute_loss(model_inputs=model_inputs, timesteps=timesteps, extra_args=extra_args)
         for key, val_loss in val_losses.items():
-            tracker.update(val_loss.item(), key=f"val/{key}")
+            tracker.update(val_loss.detach(), key=f"val/{key}")  # (read back when the meter is looked at, like the training losses)
 
     def train(
         self,
