@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void gn_stats_k(const bf16_t* __restrict__ x, 
           q[e] += v[e] * v[e];
         }
       }
-      if (cg >= 8) {  // the chunk lies inside one group
+      if (cg % 8 == 0) {  // the chunk lies inside one group (NOT for cg = 12, 20, ...: C = 384 straddles two groups per chunk)
         float S = 0.f, Q = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {

@@ -508,6 +508,45 @@ def gen_unet_variants() -> None:
     save("unet_variants", **o)
 
 
+def gen_unet_full() -> None:
+    """The reference UNet at configs/model/unet.yaml dims (276.7 M parameters), B = 2, DDPM epsilon loss, on the inputs of
+    tests/test_full_dims_gpu.py::test_unet_at_config1_dims_against_the_oracle: (a) its fp32 prediction / loss / per-parameter
+    gradient NORMS (pins the oracle at these dims: the full tensors would be 1.1 GB) and a few small gradient tensors in full;
+    (b) THE bf16 YARDSTICK at these dims: the same model under ``torch.autocast("cpu", dtype=torch.bfloat16)`` -- relative L2 error
+    of its prediction and of every gradient tensor against its own fp32 leg."""
+    cfg = ounet.UNetConfig()
+    B = 2
+    x0, noise = synth.normal("fd.x0", (B, 1, 32, 32)), synth.normal("fd.noise", (B, 1, 32, 32))
+    y = synth.integers("fd.y", (B,), 10)
+    ti = torch.tensor([17, 940], dtype=torch.int32)
+    legs = {}
+    for leg in ("fp32", "autocast"):
+        m = build_unet_ref(cfg, seed=41)
+        gd = Diffuser(m, sampling_method="ddpm", model_type="gaussian_diffusion", n_steps=1000)
+        xt = gd.diffusion.add_noise(x0, ti, noise)[0]
+        if leg == "autocast":
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                pred = m(x=xt, timesteps=ti, y=y, p=0.0)["x"].detach().float()
+                loss = gd.compute_loss({"x": x0.clone(), "y": y, "p": 0.0}, timesteps=ti, noise=noise)["loss"]
+        else:
+            pred = m(x=xt, timesteps=ti, y=y, p=0.0)["x"].detach()
+            loss = gd.compute_loss({"x": x0.clone(), "y": y, "p": 0.0}, timesteps=ti, noise=noise)["loss"]
+        loss.backward()
+        legs[leg] = (pred, loss.detach().float(), {n: p.grad.detach().float().clone() for n, p in m.named_parameters()})
+    f32, ac = legs["fp32"], legs["autocast"]
+    names = list(f32[2])
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()  # noqa: E731
+    o = {"pred": f32[0], "loss": f32[1], "names": np.array(names), "grad_norms": np.array([f32[2][n].double().norm().item() for n in names]),
+         "ac_pred_err": np.float64(rel(ac[0], f32[0])), "ac_loss": ac[1], "ac_err": np.array([rel(ac[2][n], f32[2][n]) for n in names])}
+    for n in names:
+        if f32[2][n].numel() <= 4096:
+            o["g_" + n] = f32[2][n]
+    e = o["ac_err"][o["grad_norms"] > 1e-6 * o["grad_norms"].max()]
+    print(f"unet_full: loss fp32 {f32[1].item():.6f} autocast {ac[1].item():.6f}; autocast prediction error {o['ac_pred_err']:.3e}; per-tensor "
+          f"gradient error median {np.median(e):.3e} max {e.max():.3e}")
+    save("unet_full", **o)
+
+
 # ------------------------------------------------------------------ (viii) loss curve, DiT-S/2 + AdamW
 def gen_loss_curve() -> None:
     cfg = S2
@@ -806,6 +845,104 @@ def gen_sprint_joint() -> None:
     save("sprint_joint", **o)
 
 
+# ------------------------------------------------------------------ DDT / SPRINT configurations at their own yaml dims
+def gen_yaml_dims() -> None:
+    """The reference's DDT and SprintDiT at the dims of this repo's configs/model/{ddt,sprint,ddt_txt,sprint_txt}.yaml (mirrors of the
+    reference's own model nodes) on the inputs of tests/test_full_dims_gpu.py: (a) the fp32 prediction, every gradient norm and the
+    recorded token scores of the SPRINT forms (pins the oracle at these dims); (b) the bf16 yardstick: the same step under
+    ``torch.autocast("cpu", dtype=torch.bfloat16)`` -- relative L2 error of the prediction and of every gradient tensor against the
+    model's own fp32 leg."""
+    import importlib
+    import tempfile
+
+    import yaml
+
+    PE = importlib.import_module("diffulab.networks.embedders.precomputed").PrecomputedEmbedder
+    DDT = importlib.import_module("diffulab.networks.denoisers.ddt").DDT
+    SprintDiT = importlib.import_module("diffulab.networks.denoisers.sprint").SprintDiT
+    from oracle import ddt as oddt
+    from oracle import sprint as osprint
+
+    def node(name):
+        with open(os.path.join(HERE, "..", "..", "configs", "model", name + ".yaml")) as f:
+            kw = yaml.safe_load(f)
+        kw.pop("_target_")
+        return kw
+
+    def okw(kw):
+        return {k: v for k, v in kw.items() if k not in ("simple_dit", "simple_ddt", "use_checkpoint")}
+
+    Lc, Dc = 128, 1024  # embedder node of configs/train_imagenet_repa_txt_to_img*.yaml
+
+    def embedder(tag):
+        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+            torch.save(synth.normal(f"{tag}.null", (1, Lc, Dc)) * 0.5, f.name)
+            return PE(f.name, null_embedding_seq_len=7)
+
+    o = {}
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()  # noqa: E731
+    for tag in ("ddt", "sprint", "ddt_txt", "sprint_txt"):
+        kw = node(tag)
+        joint = tag.endswith("_txt")
+        legs = {}
+        for leg in ("fp32", "autocast"):
+            if tag == "ddt":
+                m, shapes = DDT(**kw), oddt.param_shapes(oddt.DDTConfig(**okw(kw)))
+                P = synth.dit_params(shapes, seed=111)
+            elif tag == "ddt_txt":
+                m, shapes = DDT(context_embedder=embedder("ft"), **kw), oddt.joint_param_shapes(oddt.DDTJointConfig(context_dim=Dc, **okw(kw)))
+                P = synth.dit_params(shapes, seed=117)
+            else:
+                if joint:
+                    m, shapes = SprintDiT(context_embedder=embedder("f5"), **kw), osprint.joint_param_shapes(osprint.SprintJointConfig(context_dim=Dc, **okw(kw)))
+                else:
+                    m, shapes = SprintDiT(**kw), osprint.param_shapes(osprint.SprintConfig(**okw(kw)))
+                P = synth.dit_params({k: v for k, v in shapes.items() if k != "mask_token"}, seed=91 if joint else 113)
+                P["mask_token"] = synth.normal("f5.mask" if joint else "fc.mask", shapes["mask_token"]) * 0.5
+            assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == shapes, set(m.state_dict()) ^ set(shapes)
+            m.load_state_dict(P)
+            m.train()
+            if joint:
+                pre, B = ("ft", 2) if tag == "ddt_txt" else ("f5", 2)
+                x, dy = synth.normal(f"{pre}.x", (B, 128, 32, 32)), synth.normal(f"{pre}.dy", (B, 128, 32, 32))
+                t = torch.tensor([0.27, 0.88] if tag == "ddt_txt" else [0.31, 0.83])
+                keep = torch.arange(Lc)[None, :] < torch.tensor([51, Lc] if tag == "ddt_txt" else [Lc, 37])[:, None]
+                args = dict(x=x, timesteps=t, initial_context={"embeddings": synth.normal(f"{pre}.ctx", (B, Lc, Dc)) * 0.5, "attn_mask": keep}, p=0.0)
+            else:
+                B = 4
+                x, dy = synth.normal("fc.x", (B, 3, 32, 32)), synth.normal("fc.dy", (B, 3, 32, 32))
+                args = dict(x=x, timesteps=synth.uniform("fc.t", (B,), lo=0.05, hi=0.95), y=synth.integers("fc.y", (B,), 10), p=0.0)
+            torch.manual_seed(5)  # both legs draw the same token scores
+            with _RandRecorder() as r:
+                if leg == "autocast":
+                    with torch.autocast("cpu", dtype=torch.bfloat16):
+                        pred = m(**args)["x"]
+                        loss = (pred.float() * dy).sum()
+                else:
+                    pred = m(**args)["x"]
+                    loss = (pred * dy).sum()
+            loss.backward()
+            scores = [d for d in r.draws if d.dim() == 2]
+            legs[leg] = (pred.detach().float(), {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None},
+                         scores[0] if scores else None)
+        f32, ac = legs["fp32"], legs["autocast"]
+        names = list(f32[1])
+        assert f32[2] is None or torch.equal(f32[2], ac[2])
+        o[f"{tag}_pred"] = f32[0]
+        if f32[2] is not None:
+            o[f"{tag}_scores"] = f32[2]
+        o[f"{tag}_names"] = np.array(names)
+        o[f"{tag}_grad_norms"] = np.array([f32[1][n].double().norm().item() for n in names])
+        o[f"{tag}_ac_pred_err"] = np.float64(rel(ac[0], f32[0]))
+        o[f"{tag}_ac_err"] = np.array([rel(ac[1][n], f32[1][n]) for n in names])
+        for n in names:  # the small tensors in full (every norm scale / bias)
+            if f32[1][n].numel() <= 1024:
+                o[f"{tag}_g_{n}"] = f32[1][n]
+        e = o[f"{tag}_ac_err"]
+        print(f"{tag}: autocast prediction error {o[tag + '_ac_pred_err']:.3e}; per-tensor gradient error median {np.median(e):.3e} max {e.max():.3e}")
+    save("yaml_dims", **o)
+
+
 # ------------------------------------------------------------------ (xiv) DDT, simple_ddt (configs/model/ddt.yaml)
 DDT_SMALL = dict(input_channels=4, output_channels=4, inner_dim=128, num_heads=2, mlp_ratio=4, patch_size=2, encoder_depth=2,
                  decoder_depth=2, n_classes=10, classifier_free=True)
@@ -1006,8 +1143,8 @@ def gen_multiar() -> None:
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["datasets", "multiar", "autocast", "schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "unet_variants", "curve", "repa", "resampler", "sprint", "mmdit_joint", "sprint_joint", "ddt", "ddt_joint", "mmdit_single"]
-    fns = {"datasets": gen_datasets, "multiar": gen_multiar, "autocast": gen_autocast, "repa": gen_repa, "resampler": gen_resampler, "sprint": gen_sprint, "mmdit_joint": gen_mmdit_joint, "sprint_joint": gen_sprint_joint, "ddt": gen_ddt, "ddt_joint": gen_ddt_joint, "mmdit_single": gen_mmdit_single, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
+    which = sys.argv[1:] or ["unet_full", "yaml_dims", "datasets", "multiar", "autocast", "schedules", "prims", "block", "small", "small16", "s2", "samplers", "unet", "unet_variants", "curve", "repa", "resampler", "sprint", "mmdit_joint", "sprint_joint", "ddt", "ddt_joint", "mmdit_single"]
+    fns = {"unet_full": gen_unet_full, "yaml_dims": gen_yaml_dims, "datasets": gen_datasets, "multiar": gen_multiar, "autocast": gen_autocast, "repa": gen_repa, "resampler": gen_resampler, "sprint": gen_sprint, "mmdit_joint": gen_mmdit_joint, "sprint_joint": gen_sprint_joint, "ddt": gen_ddt, "ddt_joint": gen_ddt_joint, "mmdit_single": gen_mmdit_single, "schedules": gen_schedules, "prims": gen_prims, "block": gen_block, "small": gen_small_model, "small16": gen_small16,
            "s2": gen_s2_model, "samplers": gen_samplers, "curve": gen_loss_curve, "unet": gen_unet, "unet_variants": gen_unet_variants}
     for w in which:
         print("==", w)

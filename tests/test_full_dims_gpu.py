@@ -116,3 +116,230 @@ def test_sprint_joint_at_config5_dims_b4_learns_and_announces_the_arena():
     with torch.no_grad():
         out = m(x=x0, timesteps=t.to(DEV), initial_context=ctx)["x"]
     assert out.shape == x0.shape and bool(torch.isfinite(out).all())
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_unet_at_config1_dims_against_the_oracle(precision, golden):
+    """PARITY (not only behaviour) at a BASELINE configuration's own dims.  UNet of configs/model/unet.yaml
+    (276.7 M parameters: the 128 / 256 / 512 / 1024-channel stages, the big-tile convolutions, the 512-channel-slab GroupNorm
+    forms none of the 32-channel fixtures reach) at B = 2 under the DDPM epsilon loss: prediction, loss and every parameter
+    gradient against the fp32 oracle (oracle/unet.py; tests/golden/unet_full.npz pins it to the REFERENCE at these very dims and inputs,
+    tests/test_oracle_golden.py).  The bf16 regime is bounded by the reference's own bf16-autocast error on the same step (the
+    fixture's `ac_*` arrays: the yardstick of DESIGN.md section 2, here at configuration-1 dims).  This test found the GroupNorm
+    statistics bug of rounds 2-4 (12 channels per group at C = 384: prediction error 9.4e-2 instead of 1e-2)."""
+    from oracle import diffusion as od
+    from oracle import synth
+    from oracle import unet as ounet
+
+    from diffulab_amd import Diffuser
+    from diffulab_amd.config import instantiate, load_config
+
+    cfg = load_config(os.path.join(ROOT, "configs"), "train_mnist_ddpm")
+    ocfg = ounet.UNetConfig()  # (its defaults ARE configs/model/unet.yaml; the count below checks it)
+    P = synth.generic_params(ounet.param_shapes(ocfg), seed=41)
+    assert sum(v.numel() for v in P.values()) == 276_690_433
+    m = instantiate(cfg.model)
+    m.load_state_dict(P)
+    m = m.set_precision(precision).to(DEV)
+    B = 2
+    x0, noise = synth.normal("fd.x0", (B, 1, 32, 32)), synth.normal("fd.noise", (B, 1, 32, 32))
+    y = synth.integers("fd.y", (B,), 10)
+    ti = torch.tensor([17, 940], dtype=torch.int32)
+    xt = od.ddpm_add_noise(od.GaussianTables(1000), x0, ti, noise)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = ounet.unet_forward(Pr, xt, ti.float(), y, ocfg)
+    ref_loss = ((ref - noise) ** 2).mean()
+    ref_loss.backward()
+    with torch.no_grad():
+        pred = m(x=xt.to(DEV), timesteps=ti.to(DEV), y=y.to(DEV), p=0.0)["x"]
+    g = golden("unet_full")
+    assert _rel(ref, g["pred"]) < 2e-5 and abs(ref_loss.item() - float(g["loss"])) < 2e-5 * float(g["loss"])  # oracle == reference here
+    ac = dict(zip(g["names"].tolist(), g["ac_err"].tolist()))
+    tol_pred = 1.5 * float(g["ac_pred_err"]) if precision == "bf16" else 2e-5
+    assert _rel(pred, ref) < tol_pred, (_rel(pred, ref), float(g["ac_pred_err"]))
+    d = Diffuser(m, sampling_method="ddpm", model_type="gaussian_diffusion", n_steps=1000)
+    loss = d.compute_loss({"x": x0.to(DEV), "y": y.to(DEV), "p": 0.0}, timesteps=ti.to(DEV), noise=noise.to(DEV))["loss"]
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref_loss.item()) / ref_loss.item() < tol_pred
+    gmax = max(v.grad.norm().item() for v in Pr.values())
+    worst = []
+    for n, p in m.named_parameters():
+        rg = Pr[n].grad
+        if rg.norm().item() <= 1e-6 * gmax:  # conv biases in front of a GroupNorm: exactly zero in exact arithmetic
+            assert p.grad.norm().item() <= (1e-2 if precision == "bf16" else 1e-4) * gmax, n
+            continue
+        e = _rel(p.grad, rg)
+        worst.append((e / max(ac[n], 4e-3) if precision == "bf16" else e, e, n))
+    worst.sort(reverse=True)
+    print(f"UNet config-1 dims, {precision} regime, B=2: prediction {_rel(pred, ref):.2e} (reference under bf16 autocast: "
+          f"{float(g['ac_pred_err']):.2e}); largest per-tensor gradient errors" + (" (ratio to the reference's autocast error, error, name):" if precision == "bf16" else ":"),
+          worst[:4])
+    if precision == "bf16":  # per tensor: within 2 x the reference's own autocast error (floor 4e-3 = one bf16 ulp: the
+        # reference keeps dpred in f32 for the bias sums, the engine's NHWC copy of it is bf16), the median ratio below 1.25
+        ratios = sorted(r for r, _, _ in worst)
+        print("  ratio median", ratios[len(ratios) // 2], "max", ratios[-1])
+        assert ratios[-1] < 2.0 and ratios[len(ratios) // 2] < 1.25, worst[:8]
+    else:
+        assert worst[0][0] < 5e-5, worst[:8]
+
+
+@pytest.mark.timeout(900)
+def test_sprint_joint_at_config5_dims_against_the_oracle(golden):
+    """BASELINE config 5 at its own dims (768 wide / 12 heads / 128 latent channels at 32 x 32 = 1024 image tokens + 128 text tokens,
+    2 joint + 8 single-stream + 2 joint blocks), B = 2, ragged text lengths, 256 of 1024 tokens kept by injected scores: prediction
+    and every parameter gradient against the fp32 oracle (oracle/sprint.py, pinned by tests/golden/sprint_joint.npz at fixture dims)"""
+    from oracle import sprint as osprint
+    from oracle import synth
+
+    from diffulab_amd.config import instantiate, load_config
+    from diffulab_amd.networks.embedders import PrecomputedEmbedder
+
+    cfg = load_config(os.path.join(ROOT, "configs"), "train_imagenet_repa_txt_to_img_sprint")
+    ec = cfg.embedder
+    Lc, Dc = ec.context_len, ec.context_dim
+    m = instantiate(cfg.model, context_embedder=PrecomputedEmbedder(synth.normal("f5.null", (1, Lc, Dc)) * 0.5, ec.null_embedding_seq_len))
+    mk = {k: v for k, v in dict(cfg.model).items() if k not in ("_target_", "simple_dit")}
+    mk["rope_axes_dim"] = list(mk["rope_axes_dim"])
+    ocfg = osprint.SprintJointConfig(context_dim=Dc, **mk)
+    shapes = osprint.joint_param_shapes(ocfg)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == shapes
+    P = synth.dit_params({k: v for k, v in shapes.items() if k != "mask_token"}, seed=91)
+    P["mask_token"] = synth.normal("f5.mask", shapes["mask_token"]) * 0.5
+    m.load_state_dict(P)
+    m = m.to(DEV)
+    B, S = 2, 1024
+    x, t = synth.normal("f5.x", (B, 128, 32, 32)), torch.tensor([0.31, 0.83])
+    ctx, dy = synth.normal("f5.ctx", (B, Lc, Dc)) * 0.5, synth.normal("f5.dy", (B, 128, 32, 32))
+    keep = torch.arange(Lc)[None, :] < torch.tensor([Lc, 37])[:, None]
+    scores = torch.as_tensor(golden("yaml_dims")["sprint_txt_scores"])  # the reference's own draw
+    k = osprint.n_kept(S, ocfg.drop_rate)
+    assert k == 256
+    m.train()
+    m._draw_scores = lambda B_, S_, device: scores.to(device)
+    pred = m(x=x.to(DEV), timesteps=t.to(DEV), initial_context={"embeddings": ctx.to(DEV), "attn_mask": keep.to(DEV)}, p=0.0)["x"]
+    (pred * dy.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    Pr = {n: v.clone().requires_grad_(True) for n, v in P.items()}
+    po = osprint.sprint_mmdit_forward(Pr, x, t, ctx, keep, ocfg, kept=osprint.kept_indices(scores, k))
+    (po * dy).sum().backward()
+    _check_against_yardstick(m, Pr, golden("yaml_dims"), "sprint_txt", "SPRINT joint config-5 dims, B=2", pred, po)
+
+
+def _check_against_yardstick(m, Pr, g, tag, label, pred, ref, precision="bf16"):
+    """prediction and every parameter gradient of model `m` against the oracle's (`ref`, `Pr[n].grad`).  The oracle is first checked
+    against the REFERENCE's fp32 prediction at these dims (tests/golden/yaml_dims.npz); the bf16 regime is then bounded, tensor by
+    tensor, by the reference's own error under bf16 autocast on the same step (the fixture's `ac_*` arrays; floor 4e-3 = one bf16 ulp):
+    prediction within 1.25 x, every gradient within 2 x, the median ratio below 1.25.  fp32 regime: 1e-5 / 3e-5."""
+    assert _rel(ref, g[f"{tag}_pred"]) < 2e-5, _rel(ref, g[f"{tag}_pred"])
+    ac = dict(zip(g[f"{tag}_names"].tolist(), g[f"{tag}_ac_err"].tolist()))
+    ac_pred = float(g[f"{tag}_ac_pred_err"])
+    e = _rel(pred, ref)
+    assert e < (1.25 * ac_pred if precision == "bf16" else 1e-5), (e, ac_pred)
+    worst = []
+    for n, p in m.named_parameters():
+        if Pr[n].grad is None:  # no gradient in the reference either: exact zeros here
+            assert n not in ac and float(p.grad.abs().max()) == 0.0, n
+            continue
+        ge = _rel(p.grad, Pr[n].grad)
+        worst.append((ge / max(ac[n], 4e-3) if precision == "bf16" else ge, ge, n))
+    worst.sort(reverse=True)
+    ratios = sorted(r for r, _, _ in worst)
+    print(f"{label}, {precision} regime: prediction {e:.2e} (reference under bf16 autocast: {ac_pred:.2e}); per-tensor gradient "
+          + (f"error / reference autocast error: median {ratios[len(ratios) // 2]:.2f} max {ratios[-1]:.2f}; " if precision == "bf16" else "errors; ")
+          + "worst:", [(round(r, 3), f"{ge:.2e}", n) for r, ge, n in worst[:3]])
+    if precision == "bf16":
+        assert ratios[-1] < 2.0 and ratios[len(ratios) // 2] < 1.25, worst[:8]
+    else:
+        assert worst[0][0] < 3e-5, worst[:8]
+
+
+def _model_kwargs(node):
+    kw = {k: v for k, v in dict(node).items() if k not in ("_target_", "simple_dit", "simple_ddt", "use_checkpoint")}
+    if "rope_axes_dim" in kw:
+        kw["rope_axes_dim"] = list(kw["rope_axes_dim"])
+    return kw
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("family", ["ddt", "sprint"])
+def test_cifar_ddt_and_sprint_at_yaml_dims_against_the_oracle(family, precision, golden):
+    """configs/model/ddt.yaml (512 / 8 heads, 8 encoder + 4 decoder blocks) and configs/model/sprint.yaml (512 / 8, 2 + 8 + 2 blocks,
+    64 of 256 tokens through the deep stage) on CIFAR-shaped input at B = 4: prediction and every parameter gradient against the
+    fp32 oracle, in the bf16 regime and in the fp32 regime these configurations inherit (trainer/default.yaml: precision_type "no")"""
+    from oracle import ddt as oddt
+    from oracle import sprint as osprint
+    from oracle import synth
+
+    from diffulab_amd.config import instantiate, load_config
+
+    cfg = load_config(os.path.join(ROOT, "configs"), f"train_cifar10_{family}")
+    kw = _model_kwargs(cfg.model)
+    B, S = 4, 256
+    x, t, y = synth.normal("fc.x", (B, 3, 32, 32)), synth.uniform("fc.t", (B,), lo=0.05, hi=0.95), synth.integers("fc.y", (B,), 10)
+    dy = synth.normal("fc.dy", (B, 3, 32, 32))
+    m = instantiate(cfg.model)
+    if family == "ddt":
+        ocfg = oddt.DDTConfig(**kw)
+        P = synth.dit_params(oddt.param_shapes(ocfg), seed=111)
+    else:
+        ocfg = osprint.SprintConfig(**kw)
+        shapes = osprint.param_shapes(ocfg)
+        P = synth.dit_params({k: v for k, v in shapes.items() if k != "mask_token"}, seed=113)
+        P["mask_token"] = synth.normal("fc.mask", shapes["mask_token"]) * 0.5
+        scores = torch.as_tensor(golden("yaml_dims")["sprint_scores"])  # the reference's own draw
+        m._draw_scores = lambda B_, S_, device: scores.to(device)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in P.items()}
+    m.load_state_dict(P)
+    m = m.set_precision(precision).to(DEV).train()
+    pred = m(x=x.to(DEV), timesteps=t.to(DEV), y=y.to(DEV), p=0.0)["x"]
+    (pred * dy.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    Pr = {n: v.clone().requires_grad_(True) for n, v in P.items()}
+    if family == "ddt":
+        ref = oddt.ddt_forward(Pr, x, t, y, ocfg)
+    else:
+        ref = osprint.sprint_forward(Pr, x, t, y, ocfg, kept=osprint.kept_indices(scores, osprint.n_kept(S, ocfg.drop_rate)))
+    (ref * dy).sum().backward()
+    _check_against_yardstick(m, Pr, golden("yaml_dims"), family, f"configs/model/{family}.yaml dims, B=4", pred, ref, precision)
+
+
+@pytest.mark.timeout(900)
+def test_ddt_txt_at_yaml_dims_against_the_oracle(golden):
+    """configs/model/ddt_txt.yaml (train_imagenet_repa_txt_to_img.yaml): 640 wide / 10 heads -- a token width no other test runs --
+    8 joint encoder blocks + 4 per-token-modulated decoder blocks on 128-channel 32 x 32 latents (1024 image tokens) + 128 text
+    tokens of ragged length, B = 2: prediction and every parameter gradient against the fp32 oracle"""
+    from oracle import ddt as oddt
+    from oracle import synth
+
+    from diffulab_amd.config import instantiate, load_config
+    from diffulab_amd.networks.embedders import PrecomputedEmbedder
+
+    cfg = load_config(os.path.join(ROOT, "configs"), "train_imagenet_repa_txt_to_img")
+    ec = cfg.embedder
+    Lc, Dc = ec.context_len, ec.context_dim
+    m = instantiate(cfg.model, context_embedder=PrecomputedEmbedder(synth.normal("ft.null", (1, Lc, Dc)) * 0.5, ec.null_embedding_seq_len))
+    ocfg = oddt.DDTJointConfig(context_dim=Dc, **_model_kwargs(cfg.model))
+    shapes = oddt.joint_param_shapes(ocfg)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == shapes
+    P = synth.dit_params(shapes, seed=117)
+    m.load_state_dict(P)
+    m = m.to(DEV).train()
+    B = 2
+    x, t = synth.normal("ft.x", (B, 128, 32, 32)), torch.tensor([0.27, 0.88])
+    ctx, dy = synth.normal("ft.ctx", (B, Lc, Dc)) * 0.5, synth.normal("ft.dy", (B, 128, 32, 32))
+    keep = torch.arange(Lc)[None, :] < torch.tensor([51, Lc])[:, None]
+    pred = m(x=x.to(DEV), timesteps=t.to(DEV), initial_context={"embeddings": ctx.to(DEV), "attn_mask": keep.to(DEV)}, p=0.0)["x"]
+    (pred * dy.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    Pr = {n: v.clone().requires_grad_(True) for n, v in P.items()}
+    ref = oddt.ddt_joint_forward(Pr, x, t, ctx, keep, ocfg)
+    (ref * dy).sum().backward()
+    _check_against_yardstick(m, Pr, golden("yaml_dims"), "ddt_txt", "configs/model/ddt_txt.yaml dims (640 / 10 heads), B=2", pred, ref)

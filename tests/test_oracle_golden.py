@@ -5,6 +5,8 @@ Tolerances: integer / index data bit-exact; fp64 tables bit-exact (same torch op
 fp32 tensors <= 2e-6 relative-L2 (different-but-equivalent op order, e.g. explicit softmax vs SDPA).
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -429,6 +431,93 @@ def test_unet_constructor_default_and_pooling_variants(golden, tag):
     for k in g:
         if k.startswith(pre) and norms[k[len(pre):]] > floor:
             assert rel(P[k[len(pre):]].grad, g[k]) < 2e-5, k
+
+
+def test_unet_at_config1_dims_against_the_reference(golden):
+    """configs/model/unet.yaml dims (276.7 M parameters, the 1024 / 1536 / 2048-channel stages and the 12-channels-per-group GroupNorms
+    the 32-channel fixtures never reach), B = 2, DDPM loss fwd + bwd: the oracle against the reference's own fp32 run
+    (tests/golden/unet_full.npz: prediction, loss, every gradient norm, the small gradient tensors in full)"""
+    from oracle import unet as ounet
+
+    g = golden("unet_full")
+    cfg = ounet.UNetConfig()
+    P = {k: v.requires_grad_(True) for k, v in synth.generic_params(ounet.param_shapes(cfg), seed=41).items()}
+    B = 2
+    x0, noise = synth.normal("fd.x0", (B, 1, 32, 32)), synth.normal("fd.noise", (B, 1, 32, 32))
+    y = synth.integers("fd.y", (B,), 10)
+    ti = torch.tensor([17, 940], dtype=torch.int32)
+    pred = ounet.unet_forward(P, od.ddpm_add_noise(od.GaussianTables(1000), x0, ti, noise), ti, y, cfg)
+    assert rel(pred, g["pred"]) < 1e-5
+    loss = od.mse_loss(pred, noise)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) / float(g["loss"]) < 2e-6
+    norms = dict(zip(g["names"].tolist(), g["grad_norms"].tolist()))
+    assert set(norms) == set(P)
+    floor = 1e-6 * max(norms.values())
+    for n, ref in norms.items():
+        got = P[n].grad.double().norm().item()
+        assert (ref <= floor and got <= 10 * floor) or abs(got - ref) <= 5e-5 * ref, (n, got, ref)
+    for k in g:
+        if k.startswith("g_") and norms[k[2:]] > floor:
+            assert rel(P[k[2:]].grad, g[k]) < 5e-5, k
+
+
+@pytest.mark.parametrize("tag", ["ddt", "sprint", "ddt_txt", "sprint_txt"])
+def test_ddt_and_sprint_at_yaml_dims_against_the_reference(golden, tag):
+    """configs/model/{ddt,sprint,ddt_txt,sprint_txt}.yaml dims (512 / 8, 640 / 10, 768 / 12 heads; 1024 image + 128 text tokens for the
+    txt forms): the oracle's prediction, every gradient norm and the small gradient tensors against the reference's own fp32 run
+    (tests/golden/yaml_dims.npz), token scores as the reference drew them"""
+    import yaml
+
+    from oracle import ddt as oddt
+    from oracle import sprint as osprint
+
+    g = golden("yaml_dims")
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "configs", "model", tag + ".yaml")) as f:
+        kw = {k: v for k, v in yaml.safe_load(f).items() if k not in ("_target_", "simple_dit", "simple_ddt", "use_checkpoint")}
+    Lc, Dc = 128, 1024
+    if tag.endswith("_txt"):
+        pre, B = ("ft", 2) if tag == "ddt_txt" else ("f5", 2)
+        x, dy = synth.normal(f"{pre}.x", (B, 128, 32, 32)), synth.normal(f"{pre}.dy", (B, 128, 32, 32))
+        t = torch.tensor([0.27, 0.88] if tag == "ddt_txt" else [0.31, 0.83])
+        keep = torch.arange(Lc)[None, :] < torch.tensor([51, Lc] if tag == "ddt_txt" else [Lc, 37])[:, None]
+        ctx = synth.normal(f"{pre}.ctx", (B, Lc, Dc)) * 0.5
+    else:
+        B = 4
+        x, dy = synth.normal("fc.x", (B, 3, 32, 32)), synth.normal("fc.dy", (B, 3, 32, 32))
+        t, y = synth.uniform("fc.t", (B,), lo=0.05, hi=0.95), synth.integers("fc.y", (B,), 10)
+    if tag == "ddt":
+        cfg = oddt.DDTConfig(**kw)
+        P = synth.dit_params(oddt.param_shapes(cfg), seed=111)
+        run = lambda Q: oddt.ddt_forward(Q, x, t, y, cfg)  # noqa: E731
+    elif tag == "ddt_txt":
+        cfg = oddt.DDTJointConfig(context_dim=Dc, **kw)
+        P = synth.dit_params(oddt.joint_param_shapes(cfg), seed=117)
+        run = lambda Q: oddt.ddt_joint_forward(Q, x, t, ctx, keep, cfg)  # noqa: E731
+    else:
+        joint = tag == "sprint_txt"
+        cfg = osprint.SprintJointConfig(context_dim=Dc, **kw) if joint else osprint.SprintConfig(**kw)
+        shapes = osprint.joint_param_shapes(cfg) if joint else osprint.param_shapes(cfg)
+        P = synth.dit_params({k: v for k, v in shapes.items() if k != "mask_token"}, seed=91 if joint else 113)
+        P["mask_token"] = synth.normal("f5.mask" if joint else "fc.mask", shapes["mask_token"]) * 0.5
+        scores = torch.as_tensor(g[f"{tag}_scores"])
+        kept = osprint.kept_indices(scores, osprint.n_kept(scores.shape[1], cfg.drop_rate))
+        if joint:
+            run = lambda Q: osprint.sprint_mmdit_forward(Q, x, t, ctx, keep, cfg, kept=kept)  # noqa: E731
+        else:
+            run = lambda Q: osprint.sprint_forward(Q, x, t, y, cfg, kept=kept)  # noqa: E731
+    P = {k: v.requires_grad_(True) for k, v in P.items()}
+    pred = run(P)
+    assert rel(pred, g[f"{tag}_pred"]) < 1e-5
+    (pred * dy).sum().backward()
+    norms = dict(zip(g[f"{tag}_names"].tolist(), g[f"{tag}_grad_norms"].tolist()))
+    assert set(norms) == {n for n, v in P.items() if v.grad is not None}
+    for n, ref in norms.items():
+        assert abs(P[n].grad.double().norm().item() - ref) <= 5e-5 * ref, (n, ref)
+    pre = f"{tag}_g_"
+    for k in g:
+        if k.startswith(pre):
+            assert rel(P[k[len(pre):]].grad, g[k]) < 5e-5, k
 
 
 def test_repa_loss_hooked_into_small_dit(golden):
