@@ -514,11 +514,17 @@ def gen_unet_full() -> None:
     gradient NORMS (pins the oracle at these dims: the full tensors would be 1.1 GB) and a few small gradient tensors in full;
     (b) THE bf16 YARDSTICK at these dims: the same model under ``torch.autocast("cpu", dtype=torch.bfloat16)`` -- relative L2 error
     of its prediction and of every gradient tensor against its own fp32 leg."""
+    out = {}
+    for B, pre in ((2, ""), (128, "b128_")):  # B = 128: the batch of configs/train_mnist_ddpm.yaml (the UNet's benched shape)
+        out.update(_unet_full_legs(B, pre))
+    save("unet_full", **out)
+
+
+def _unet_full_legs(B: int, pre: str) -> dict:
     cfg = ounet.UNetConfig()
-    B = 2
     x0, noise = synth.normal("fd.x0", (B, 1, 32, 32)), synth.normal("fd.noise", (B, 1, 32, 32))
     y = synth.integers("fd.y", (B,), 10)
-    ti = torch.tensor([17, 940], dtype=torch.int32)
+    ti = torch.tensor([17, 940], dtype=torch.int32) if B == 2 else synth.integers("fd.t", (B,), 1000).to(torch.int32)
     legs = {}
     for leg in ("fp32", "autocast"):
         m = build_unet_ref(cfg, seed=41)
@@ -539,12 +545,12 @@ def gen_unet_full() -> None:
     o = {"pred": f32[0], "loss": f32[1], "names": np.array(names), "grad_norms": np.array([f32[2][n].double().norm().item() for n in names]),
          "ac_pred_err": np.float64(rel(ac[0], f32[0])), "ac_loss": ac[1], "ac_err": np.array([rel(ac[2][n], f32[2][n]) for n in names])}
     for n in names:
-        if f32[2][n].numel() <= 4096:
+        if f32[2][n].numel() <= (4096 if B == 2 else 1024):
             o["g_" + n] = f32[2][n]
     e = o["ac_err"][o["grad_norms"] > 1e-6 * o["grad_norms"].max()]
-    print(f"unet_full: loss fp32 {f32[1].item():.6f} autocast {ac[1].item():.6f}; autocast prediction error {o['ac_pred_err']:.3e}; per-tensor "
+    print(f"unet_full B={B}: loss fp32 {f32[1].item():.6f} autocast {ac[1].item():.6f}; autocast prediction error {o['ac_pred_err']:.3e}; per-tensor "
           f"gradient error median {np.median(e):.3e} max {e.max():.3e}")
-    save("unet_full", **o)
+    return {pre + k: v for k, v in o.items()}
 
 
 # ------------------------------------------------------------------ (viii) loss curve, DiT-S/2 + AdamW
