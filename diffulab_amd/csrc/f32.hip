@@ -832,7 +832,8 @@ extern "C" int dl_f32_ddt_cond_bwd(const float* dsz, const float* enc, int64_t l
 }
 
 // ============================================================================================================ softmax rows
-// in place over rows of `cols` floats (cols <= 4096): p = exp(s - max) / sum; one wave per row, values kept in registers
+// in place over rows of `cols` floats: p = exp(s - max) / sum; one wave per row, values kept in registers (cols % 4 == 0, <= 4096;
+// other row lengths: the *_any_k forms below)
 #define FS_NJ 16
 __global__ __launch_bounds__(256) void f32_softmax_fwd_k(float* __restrict__ s, int64_t rows, int cols) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -868,6 +869,31 @@ __global__ __launch_bounds__(256) void f32_softmax_fwd_k(float* __restrict__ s, 
     }
   }
 }
+// any row length (cols % 4 != 0: 1, 9, 25 ... tokens of a 1x1 / 3x3 / 5x5 map; cols > 4096): three passes over the row, which stays in L1 / L2
+__global__ __launch_bounds__(256) void f32_softmax_fwd_any_k(float* __restrict__ s, int64_t rows, int cols) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    float* p = s + row * cols;
+    float mx = -INFINITY;
+    for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, p[c]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < cols; c += 64) sum += expf(p[c] - mx);
+    const float inv = 1.0f / wave_sum(sum);
+    for (int c = lane; c < cols; c += 64) p[c] = expf(p[c] - mx) * inv;
+  }
+}
+__global__ __launch_bounds__(256) void f32_softmax_bwd_any_k(const float* __restrict__ P, float* __restrict__ dP, int64_t rows, int cols) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float* p = P + row * cols;
+    float* d = dP + row * cols;
+    float dot = 0.f;
+    for (int c = lane; c < cols; c += 64) dot += p[c] * d[c];
+    dot = wave_sum(dot);
+    for (int c = lane; c < cols; c += 64) d[c] = p[c] * (d[c] - dot);
+  }
+}
 // dS = P * (dP - rowsum(dP * P)), written over dP
 __global__ __launch_bounds__(256) void f32_softmax_bwd_k(const float* __restrict__ P, float* __restrict__ dP, int64_t rows, int cols) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -897,15 +923,25 @@ __global__ __launch_bounds__(256) void f32_softmax_bwd_k(const float* __restrict
 }
 
 extern "C" int dl_f32_softmax_fwd(float* s, int64_t rows, int64_t cols, dl_stream_t stream) {
-  DL_CHECK_ARG(s && rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 256 * FS_NJ && ((uintptr_t)s & 15) == 0,
-               "dl_f32_softmax_fwd: rows=%lld cols=%lld (cols %% 4 == 0, <= %d)", (long long)rows, (long long)cols, 256 * FS_NJ);
+  DL_CHECK_ARG(s && rows > 0 && cols > 0 && cols < (1ll << 31) && ((uintptr_t)s & 3) == 0, "dl_f32_softmax_fwd: rows=%lld cols=%lld",
+               (long long)rows, (long long)cols);
+  if (cols % 4 != 0 || cols > 256 * FS_NJ || ((uintptr_t)s & 15) != 0) {
+    hipLaunchKernelGGL(f32_softmax_fwd_any_k, grid_1d(rows, 4, 16384), 256, 0, (hipStream_t)stream, s, rows, (int)cols);
+    DL_LAUNCH_CHECK();
+    return DL_OK;
+  }
   hipLaunchKernelGGL(f32_softmax_fwd_k, grid_1d(rows, 4, 16384), 256, 0, (hipStream_t)stream, s, rows, (int)cols);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
 extern "C" int dl_f32_softmax_bwd(const float* p, float* dp, int64_t rows, int64_t cols, dl_stream_t stream) {
-  DL_CHECK_ARG(p && dp && rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 256 * FS_NJ && (((uintptr_t)p | (uintptr_t)dp) & 15) == 0,
+  DL_CHECK_ARG(p && dp && rows > 0 && cols > 0 && cols < (1ll << 31) && (((uintptr_t)p | (uintptr_t)dp) & 3) == 0,
                "dl_f32_softmax_bwd: rows=%lld cols=%lld", (long long)rows, (long long)cols);
+  if (cols % 4 != 0 || cols > 256 * FS_NJ || (((uintptr_t)p | (uintptr_t)dp) & 15) != 0) {
+    hipLaunchKernelGGL(f32_softmax_bwd_any_k, grid_1d(rows, 4, 16384), 256, 0, (hipStream_t)stream, p, dp, rows, (int)cols);
+    DL_LAUNCH_CHECK();
+    return DL_OK;
+  }
   hipLaunchKernelGGL(f32_softmax_bwd_k, grid_1d(rows, 4, 16384), 256, 0, (hipStream_t)stream, p, dp, rows, (int)cols);
   DL_LAUNCH_CHECK();
   return DL_OK;

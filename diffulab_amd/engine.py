@@ -294,8 +294,8 @@ class DiTEngine:
         N = gh * gw
         M = B * N
         if N % 64 or (N > 256 and (N % 256 or N > 2048)):
-            raise NotImplementedError(f"token grid {gh}x{gw}: HIP attention needs N % 64 == 0 up to 256 tokens, or N % 256 == 0 "
-                                      f"up to 2048 (got {N})")
+            raise NotImplementedError(f"token grid {gh}x{gw}: the bf16 regime's attention needs N % 64 == 0 up to 256 tokens, or N % 256 == 0 "
+                                      f"up to 2048 (got {N}); the fp32 regime (precision_type=\"no\" / set_precision(\"fp32\")) takes any grid")
         Bp = _rup(B, 64)
         Fo = p * p * d.output_channels
         bf, f32 = torch.bfloat16, torch.float32

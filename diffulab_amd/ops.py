@@ -961,6 +961,32 @@ def f32_gate_bwd(dout, t, gate, rows_per_mod, dt, dgate):
     _call("dl_f32_gate_bwd", _p(dout), _p(t), _p(gate), gate.stride(0), rows_per_mod, _p(dt), _p(dgate), dgate.stride(0), M, D, _s())
 
 
+def f32_attn_fwd(q, k, v, out, probs, B, n, H, dh):
+    """AttentionBlock core (unet.py:311-318) over f32 token rows for ANY token count / head width: heads are dh-wide column blocks of
+    the rows (addressed by stride in the batched GEMMs); probs f32 [B, H, n, n] = softmax(scale Q K^T) is kept for the backward"""
+    sc = float(dh) ** -0.5
+    f32_gemm(q, k, probs, n, n, dh, lda=q.stride(0), ldb=k.stride(0), ldc=n, batch=(B, H), sa=(n * q.stride(0), dh),
+             sb=(n * k.stride(0), dh), sc=(H * n * n, n * n), alpha=sc)
+    f32_softmax_fwd(probs, B * H * n, n)
+    f32_gemm(probs, v, out, n, dh, n, lda=n, ldb=v.stride(0), ldc=out.stride(0), tb=True, batch=(B, H), sa=(H * n * n, n * n),
+             sb=(n * v.stride(0), dh), sc=(n * out.stride(0), dh))
+
+
+def f32_attn_bwd(q, k, v, dout, probs, dP, dq, dk, dv, B, n, H, dh):
+    """dP: f32 scratch [B, H, n, n] (overwritten: dP, then dS)"""
+    sc = float(dh) ** -0.5
+    pb, hb = (H * n * n, n * n), dict(batch=(B, H))
+    f32_gemm(dout, v, dP, n, n, dh, lda=dout.stride(0), ldb=v.stride(0), ldc=n, sa=(n * dout.stride(0), dh),
+             sb=(n * v.stride(0), dh), sc=pb, **hb)                                                   # dP = dO V^T
+    f32_gemm(probs, dout, dv, n, dh, n, lda=n, ldb=dout.stride(0), ldc=dv.stride(0), ta=True, tb=True, sa=pb,
+             sb=(n * dout.stride(0), dh), sc=(n * dv.stride(0), dh), **hb)                            # dV = P^T dO
+    f32_softmax_bwd(probs, dP, B * H * n, n)                                                          # dS over dP
+    f32_gemm(dP, k, dq, n, dh, n, lda=n, ldb=k.stride(0), ldc=dq.stride(0), tb=True, sa=pb, sb=(n * k.stride(0), dh),
+             sc=(n * dq.stride(0), dh), alpha=sc, **hb)                                               # dQ = scale dS K
+    f32_gemm(dP, q, dk, n, dh, n, lda=n, ldb=q.stride(0), ldc=dk.stride(0), ta=True, tb=True, sa=pb,
+             sb=(n * q.stride(0), dh), sc=(n * dk.stride(0), dh), alpha=sc, **hb)                     # dK = scale dS^T Q
+
+
 def f32_softmax_fwd(s, rows, cols):
     _call("dl_f32_softmax_fwd", _p(s), rows, cols, _s())
 

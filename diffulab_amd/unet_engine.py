@@ -52,11 +52,8 @@ class UNetDims:
         ds = 1
         for level, mult in enumerate(self.channel_mult):
             if ds in self.attention_resolutions:
-                n = (self.image_size[0] // ds) * (self.image_size[1] // ds)
-                if n > 64:
-                    raise NotImplementedError(f"AttentionBlock kernel handles <= 64 tokens (got {n} at downsample {ds})")
-                if (mult * mc) % self.num_heads or (mult * mc // self.num_heads) % 8:
-                    raise NotImplementedError("attention head_dim must be a multiple of 8")
+                if (mult * mc) % self.num_heads:
+                    raise NotImplementedError("attention channels must be divisible by num_heads")
             if level != len(self.channel_mult) - 1:
                 ds *= 2
 
@@ -211,6 +208,7 @@ class UNetLayout:
 
 class UNetEngine:
     G = 32  # GroupNorm32
+    precision = "bf16"
 
     def __init__(self, dims: UNetDims, device: torch.device | str = "cuda") -> None:
         dims.validate()
@@ -560,6 +558,43 @@ class UNetEngine:
         self.o.reduce2x2(dout, dx, B, H, W, c, 1.0)
         return dx
 
+    # attention core: softmax(scale Q K^T) V per (sample, head), heads = column blocks of the token rows.  Up to 64 tokens (the
+    # configurations of the reference: 8 x 8 maps and below) one workgroup per (sample, head) holds the whole problem
+    # (dl_attn_small_*); larger maps -- attention at 16 x 16 / 32 x 32, any head width -- go through the exact-f32 batched GEMMs
+    # + row softmax of the fp32 regime on f32 copies of q / kv (ops.f32_attn_*): general, and more precise than the bf16 regime asks
+    def _attn_small_ok(self, n: int, dh: int) -> bool:
+        return self.precision == "fp32" or (n <= 64 and dh % 8 == 0)
+
+    def _attn_core_fwd(self, q: Tensor, kv: Tensor, att: Tensor, probs: Tensor, B: int, n: int, nh: int, c: int) -> None:
+        if self._attn_small_ok(n, c // nh):
+            self.o.attn_small_fwd(q, kv[:, :c], kv[:, c:], att, probs, B, n, nh, c // nh)
+            return
+        qf = self._scr("attn_qf", B * n * c, torch.float32).view(B * n, c)
+        kvf = self._scr("attn_kvf", B * n * 2 * c, torch.float32).view(B * n, 2 * c)
+        of = self._scr("attn_of", B * n * c, torch.float32).view(B * n, c)
+        ops.cast_bf16_to_f32(q, qf)
+        ops.cast_bf16_to_f32(kv, kvf)
+        ops.f32_attn_fwd(qf, kvf[:, :c], kvf[:, c:], of, probs, B, n, nh, c // nh)
+        ops.cast_f32_to_bf16(of, att)
+
+    def _attn_core_bwd(self, q: Tensor, kv: Tensor, datt: Tensor, probs: Tensor, dq: Tensor, dkv: Tensor, B: int, n: int, nh: int,
+                       c: int) -> None:
+        if self._attn_small_ok(n, c // nh):
+            self.o.attn_small_bwd(q, kv[:, :c], kv[:, c:], datt, probs, dq, dkv[:, :c], dkv[:, c:], B, n, nh, c // nh)
+            return
+        qf = self._scr("attn_qf", B * n * c, torch.float32).view(B * n, c)
+        kvf = self._scr("attn_kvf", B * n * 2 * c, torch.float32).view(B * n, 2 * c)
+        df = self._scr("attn_of", B * n * c, torch.float32).view(B * n, c)
+        dqf = self._scr("attn_dqf", B * n * c, torch.float32).view(B * n, c)
+        dkvf = self._scr("attn_dkvf", B * n * 2 * c, torch.float32).view(B * n, 2 * c)
+        dP = self._scr("attn_dp", B * nh * n * n, torch.float32).view(B, nh, n, n)
+        ops.cast_bf16_to_f32(q, qf)
+        ops.cast_bf16_to_f32(kv, kvf)
+        ops.cast_bf16_to_f32(datt, df)
+        ops.f32_attn_bwd(qf, kvf[:, :c], kvf[:, c:], df, probs, dP, dqf, dkvf[:, :c], dkvf[:, c:], B, n, nh, c // nh)
+        ops.cast_f32_to_bf16(dqf, dq)
+        ops.cast_f32_to_bf16(dkvf, dkv)
+
     def _attn_fwd(self, b: _Blk, x: Tensor, B: int, H: int, W: int, save: list | None) -> Tensor:
         p, c, n = b.prefix, b.cin, H * W
         nh = self.d.num_heads
@@ -569,7 +604,7 @@ class UNetEngine:
         kv = self._lin_fwd(nc, p + "to_kv.weight", 2 * c, c)
         att = self._new(B * n, c)
         probs = self._new(B, nh, n, n, dtype=torch.float32)
-        self.o.attn_small_fwd(q, kv[:, :c], kv[:, c:], att, probs, B, n, nh, c // nh)
+        self._attn_core_fwd(q, kv, att, probs, B, n, nh, c)
         out = self._lin_fwd(att, p + "to_out.0.weight", c, c, resid=x)
         if save is not None:
             save.append((x, st, nx, nc, q, kv, att, probs, H, W))
@@ -582,7 +617,7 @@ class UNetEngine:
         n = H * W
         datt = self._lin_bwd(dout, att, p + "to_out.0.weight", c, c)
         dq, dkv = self._new(B * n, c), self._new(B * n, 2 * c)
-        self.o.attn_small_bwd(q, kv[:, :c], kv[:, c:], datt, probs, dq, dkv[:, :c], dkv[:, c:], B, n, nh, c // nh)
+        self._attn_core_bwd(q, kv, datt, probs, dq, dkv, B, n, nh, c)
         dnx = self._lin_bwd(dq, nx, p + "to_q.weight", c, c)
         dnc = self._lin_bwd(dkv, nc, p + "to_kv.weight", 2 * c, c)
         dx = self._gn_bwd(dnx, x, st, B, n, c, p + "norm_x.", silu=False, dres=dout)

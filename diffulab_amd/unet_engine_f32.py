@@ -50,29 +50,12 @@ class _F32Ops:
     nhwc_to_nchw = staticmethod(ops.f32_nhwc_to_nchw)
     copy2d_bf16 = staticmethod(ops.f32_copy2d)  # (the orchestration's name for "strided 2-D copy")
 
-    # AttentionBlock core (unet.py:311-318): heads are dh-wide column blocks of the token rows; probs f32 [B, H, n, n] kept
-    @staticmethod
-    def attn_small_fwd(q, k, v, out, probs, B, n, H, dh):
-        sc = float(dh) ** -0.5
-        ops.f32_gemm(q, k, probs, n, n, dh, lda=q.stride(0), ldb=k.stride(0), ldc=n, batch=(B, H), sa=(n * q.stride(0), dh),
-                     sb=(n * k.stride(0), dh), sc=(H * n * n, n * n), alpha=sc)
-        ops.f32_softmax_fwd(probs, B * H * n, n)
-        ops.f32_gemm(probs, v, out, n, dh, n, lda=n, ldb=v.stride(0), ldc=out.stride(0), tb=True, batch=(B, H), sa=(H * n * n, n * n),
-                     sb=(n * v.stride(0), dh), sc=(n * out.stride(0), dh))
+    # AttentionBlock core (unet.py:311-318): any token count / head width (ops.f32_attn_fwd / f32_attn_bwd)
+    attn_small_fwd = staticmethod(ops.f32_attn_fwd)
 
     def attn_small_bwd(self, q, k, v, dout, probs, dq, dk, dv, B, n, H, dh):
-        sc = float(dh) ** -0.5
         dP = self.eng._scr("attn_dp", B * H * n * n, torch.float32).view(B, H, n, n)
-        pb, hb = (H * n * n, n * n), dict(batch=(B, H))
-        ops.f32_gemm(dout, v, dP, n, n, dh, lda=dout.stride(0), ldb=v.stride(0), ldc=n, sa=(n * dout.stride(0), dh),
-                     sb=(n * v.stride(0), dh), sc=pb, **hb)                                                   # dP = dO V^T
-        ops.f32_gemm(probs, dout, dv, n, dh, n, lda=n, ldb=dout.stride(0), ldc=dv.stride(0), ta=True, tb=True, sa=pb,
-                     sb=(n * dout.stride(0), dh), sc=(n * dv.stride(0), dh), **hb)                            # dV = P^T dO
-        ops.f32_softmax_bwd(probs, dP, B * H * n, n)                                                          # dS over dP
-        ops.f32_gemm(dP, k, dq, n, dh, n, lda=n, ldb=k.stride(0), ldc=dq.stride(0), tb=True, sa=pb, sb=(n * k.stride(0), dh),
-                     sc=(n * dq.stride(0), dh), alpha=sc, **hb)                                               # dQ = scale dS K
-        ops.f32_gemm(dP, q, dk, n, dh, n, lda=n, ldb=q.stride(0), ldc=dk.stride(0), ta=True, tb=True, sa=pb,
-                     sb=(n * q.stride(0), dh), sc=(n * dk.stride(0), dh), alpha=sc, **hb)                     # dK = scale dS^T Q
+        ops.f32_attn_bwd(q, k, v, dout, probs, dP, dq, dk, dv, B, n, H, dh)
 
 
 class UNetEngineF32(UNetEngine):
