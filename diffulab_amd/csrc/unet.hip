@@ -51,6 +51,10 @@ extern "C" int dl_nhwc_to_nchw(const void* x, float* out, int64_t B, int64_t C, 
 // All four kernels move 16 bytes (8 channels) per lane.  A thread owns an 8-channel chunk and walks pixels; C/G may be
 // smaller than 8 (C = 32..224), so group indices are taken per element.
 #define GN_MAXG 64
+static int g_gn_fused = 1;  // 3 (tests): as 1, also where a launch would not fill the chip; 1: fused (128-channel slabs on small maps where they fit, 64-channel slabs on the large maps); 2: fused, 512-channel slabs on
+                             // small maps only (round 4); 0: the separate launches (forward: statistics + apply; backward: reduce + group sums + apply)
+extern "C" __attribute__((visibility("default"))) void dl_lab_set_gn_fused(int mode) { g_gn_fused = mode; }  // LAB A/B switch (not in the header)
+static int gn_bwd_fused() { return g_gn_fused; }  // (the three-launch form stays for the shapes the fused kernel does not take)
 
 // statistics: one workgroup per sample; thread (pixel lane, chunk) accumulates sum / sum of squares of its 8 channels over
 // its pixels, LDS float atomics fold them per group
@@ -176,6 +180,165 @@ extern "C" int dl_gn_apply_fwd(const void* x, const float* stats, const float* w
   return DL_OK;
 }
 
+// statistics + apply in ONE launch (the training shapes): a workgroup owns a slab of NCH * 8 channels (a whole number of groups) of one
+// sample; every x row of a lane is loaded once and stays in registers (KEEP rows per lane: feature maps of <= KEEP * 256 / NCH pixels)
+// between the statistics pass and the normalise / FiLM / SiLU pass.  Same arithmetic as gn_stats_k + gn_apply_fwd_k (f32 sum and sum of
+// squares per group); statistics are written for the backward.
+template <int NCH, int KEEP>
+__global__ __launch_bounds__(256) void gn_fwd_fused_k(const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bb,
+                                                      const bf16_t* __restrict__ fs, const bf16_t* __restrict__ fh, int64_t ldf, int silu,
+                                                      bf16_t* __restrict__ out, float* __restrict__ st, int HW, int C, int G, float eps) {
+  constexpr int SLAB = NCH * 8, PL = 256 / NCH;
+  constexpr bool POW2 = (NCH & (NCH - 1)) == 0;  // (NCH = 12: 96-channel slabs, 21 pixel lanes + 4 idle threads -- see gn_bwd_fused_k)
+  constexpr int NP = POW2 ? 4 : PL;
+  __shared__ __attribute__((aligned(16))) float part[NP][2][SLAB];  // [wave or pixel lane][sum | sum of squares][channel of the slab]
+  __shared__ float gst[32][2];
+  const int slabs = C / SLAB;
+  const int b = blockIdx.x / slabs, cbase = (blockIdx.x % slabs) * SLAB;
+  const int chunk = threadIdx.x % NCH, pl = threadIdx.x / NCH, wave = threadIdx.x >> 6;
+  const bool live = pl < PL;
+  const int c0 = cbase + (live ? chunk * 8 : 0), cg = C / G;
+  const int64_t row0 = ((int64_t)b * HW) * C + c0;
+  u32x4_t xk[KEEP];
+#pragma unroll
+  for (int i = 0; i < KEEP; ++i) {
+    const int p = pl + i * PL;
+    if (p < HW && live) xk[i] = *(const u32x4_t*)(x + row0 + (int64_t)p * C);
+  }
+  float wv[8], bv[8], sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {  // (requested now, needed after the reduction)
+    wv[e] = w[c0 + e];
+    bv[e] = bb[c0 + e];
+    sc[e] = fs ? bf2f(fs[(int64_t)b * ldf + c0 + e]) : 0.f;
+    sh[e] = fs ? bf2f(fh[(int64_t)b * ldf + c0 + e]) : 0.f;
+  }
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < KEEP; ++i) {
+    if (pl + i * PL < HW && live) {
+      float v[8];
+      unpack8(xk[i], v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s[e] += v[e];
+        q[e] += v[e] * v[e];
+      }
+    }
+  }
+  if constexpr (POW2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int m = NCH; m < 64; m <<= 1) {
+        s[e] += __shfl_xor(s[e], m);
+        q[e] += __shfl_xor(q[e], m);
+      }
+    }
+  }
+  if (POW2 ? (int)(threadIdx.x & 63) < NCH : live) {  // (partial sums in LDS rows of their own: plain stores, no LDS atomics)
+    const int row = POW2 ? wave : pl;
+    *(f32x4_t*)&part[row][0][chunk * 8] = f32x4_t{s[0], s[1], s[2], s[3]};
+    *(f32x4_t*)&part[row][0][chunk * 8 + 4] = f32x4_t{s[4], s[5], s[6], s[7]};
+    *(f32x4_t*)&part[row][1][chunk * 8] = f32x4_t{q[0], q[1], q[2], q[3]};
+    *(f32x4_t*)&part[row][1][chunk * 8 + 4] = f32x4_t{q[4], q[5], q[6], q[7]};
+  }
+  __syncthreads();
+  {
+    const int g = threadIdx.x >> 3, k = threadIdx.x & 7;  // 8 threads per group (<= 32 groups per slab), three shuffles
+    float S = 0.f, Q = 0.f;
+    if (g < SLAB / cg)
+      for (int j = k; j < cg; j += 8) {
+        const int i = g * cg + j;
+#pragma unroll
+        for (int r = 0; r < NP; ++r) {
+          S += part[r][0][i];
+          Q += part[r][1][i];
+        }
+      }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      S += __shfl_xor(S, m);
+      Q += __shfl_xor(Q, m);
+    }
+    if (k == 0 && g < SLAB / cg) {
+      const float n = (float)HW * cg;
+      const float mu = S / n;
+      const float r = rsqrtf(fmaxf(Q / n - mu * mu, 0.f) + eps);
+      gst[g][0] = mu;
+      gst[g][1] = r;
+      float* sg = st + ((int64_t)b * G + cbase / cg + g) * 2;
+      sg[0] = mu;
+      sg[1] = r;
+    }
+  }
+  __syncthreads();
+  float mu[8], rs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    mu[e] = gst[(chunk * 8 + e) / cg][0];
+    rs[e] = gst[(chunk * 8 + e) / cg][1];
+  }
+#pragma unroll
+  for (int i = 0; i < KEEP; ++i) {
+    const int p = pl + i * PL;
+    if (p < HW && live) {
+      float v[8];
+      unpack8(xk[i], v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float y = (v[e] - mu[e]) * rs[e] * wv[e] + bv[e];
+        if (fs) y = y * (1.0f + sc[e]) + sh[e];
+        v[e] = silu ? silu_f(y) : y;
+      }
+      *(u32x4_t*)(out + row0 + (int64_t)p * C) = pack8(v);
+    }
+  }
+}
+/* GroupNorm forward in one call: statistics (written to `stats` f32 [B, G, 2] for the backward) + normalise / FiLM / SiLU.  One launch
+ * where a workgroup can own whole groups of a sample with its rows in registers (every shape of the training configurations); the
+ * two-kernel form (dl_gn_stats + dl_gn_apply_fwd) otherwise. */
+extern "C" int dl_gn_fwd(const void* x, const float* w, const float* b, const void* film_scale, const void* film_shift, int64_t ld_film,
+                         int act_silu, void* out, float* stats, int64_t B, int64_t HW, int64_t C, int64_t G, float eps, dl_stream_t stream) {
+  DL_CHECK_ARG(x && w && b && out && stats && B > 0 && HW > 0 && C > 0 && G > 0 && G <= GN_MAXG && C % G == 0 && C % 8 == 0,
+               "dl_gn_fwd: bad args (C %% 8, C %% G, G <= 64)");
+  DL_CHECK_ARG((film_scale == nullptr) == (film_shift == nullptr), "dl_gn_fwd: scale and shift go together");
+  DL_CHECK_ARG((((uintptr_t)x | (uintptr_t)out | (uintptr_t)w | (uintptr_t)b | (uintptr_t)film_scale | (uintptr_t)film_shift) & 15) == 0 &&
+                   ld_film % 8 == 0,
+               "dl_gn_fwd: 16-byte alignment");
+  DL_CHECK_ARG(B < 65536 && HW * C / 8 < (1ll << 31), "dl_gn_fwd: B < 65536, HW*C/8 < 2^31");
+  const int64_t cg = C / G;
+#define GN_FWD_LAUNCH(NCH_, KEEP_)                                                                                                    \
+  hipLaunchKernelGGL((gn_fwd_fused_k<NCH_, KEEP_>), dim3((unsigned)(B * (C / (NCH_ * 8)))), 256, 0, (hipStream_t)stream,              \
+                     (const bf16_t*)x, w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, (bf16_t*)out,   \
+                     stats, (int)HW, (int)C, (int)G, eps)
+  // (below ~8 M elements the launch is a latency chain: statistics + apply as two launches are faster -- 11 vs 21 us at 4 x 4 x 1024)
+  if (g_gn_fused && B * HW * C >= (1ll << 23) && B * (C / 64) < (1ll << 31)) {
+    if (HW <= 64 && C % 128 == 0 && 128 % cg == 0 && 128 / cg <= 32) {
+      GN_FWD_LAUNCH(16, 4);
+      DL_LAUNCH_CHECK();
+      return DL_OK;
+    }
+    if (C % 96 == 0 && 96 % cg == 0 && 128 % cg != 0 && HW <= 21 * 12) {  // 12 / 24 / 48 channels per group: 96-channel slabs, 21 pixel lanes
+      if (HW <= 84) GN_FWD_LAUNCH(12, 4);
+      else GN_FWD_LAUNCH(12, 12);
+      DL_LAUNCH_CHECK();
+      return DL_OK;
+    }
+    if (C % 64 == 0 && 64 % cg == 0 && 64 / cg <= 32 && HW <= 1024) {
+      if (HW <= 128) GN_FWD_LAUNCH(8, 4);
+      else if (HW <= 256) GN_FWD_LAUNCH(8, 8);
+      else GN_FWD_LAUNCH(8, 32);
+      DL_LAUNCH_CHECK();
+      return DL_OK;
+    }
+  }
+#undef GN_FWD_LAUNCH
+  const int rc = dl_gn_stats(x, stats, B, HW, C, G, eps, stream);
+  if (rc != DL_OK) return rc;
+  return dl_gn_apply_fwd(x, stats, w, b, film_scale, film_shift, ld_film, act_silu, out, B, HW, C, G, stream);
+}
+
 // backward pass 1: per (b, c) sums over pixels:  S[b][0][c] = sum dh*y, [1] = sum dh, [2] = sum dy*xhat, [3] = sum dy
 // (dh = dout * act'(h), dy = dh * (1+scale)).  One workgroup per (b, 64-channel slab, pixel range): 8 chunks x 32 pixel lanes,
 // two pixels per lane and iteration in flight; the pixel ranges (gridDim.y of them, so that small batches still fill the chip)
@@ -183,9 +346,7 @@ extern "C" int dl_gn_apply_fwd(const void* x, const float* stats, const float* w
 // NCH = 16-byte channel chunks per workgroup (256 / NCH pixel lanes): 8 for the high-resolution levels (64-channel slabs, 32 pixel
 // lanes), 64 for feature maps of <= 64 pixels (512-channel slabs, 4 pixel lanes: a wave reads 1 KiB of ONE pixel row and a
 // thread's per-channel setup is spread over 4-16 pixels instead of half a pixel)
-// FUSED (NCH = 64 only, every group of the slab inside it, one pixel range): the workgroup owns whole groups of one sample, so the
-// group sums and the dx pass (gn_group_sums_k + gn_bwd_apply_k) follow in the same launch -- three latency-bound launches of
-// 5-30 us on a few megabytes become one; x / dout are re-read through L2.
+// (The shapes the training configurations run take gn_bwd_fused_k below instead: one launch for all three passes.)
 struct GnFused {
   float* dw;
   float* db;
@@ -195,15 +356,14 @@ struct GnFused {
   const bf16_t* dres;
   bf16_t* dx;
 };
-template <int NCH, bool FUSED = false>
+template <int NCH>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
                                                        const float* __restrict__ st, const float* __restrict__ w,
                                                        const float* __restrict__ bb, const bf16_t* __restrict__ fs,
                                                        const bf16_t* __restrict__ fh, int64_t ldf, int silu,
-                                                       float* __restrict__ Sp, int B, int HW, int C, int G, GnFused fz) {
+                                                       float* __restrict__ Sp, int B, int HW, int C, int G) {
   constexpr int SLAB = NCH * 8, PL = 256 / NCH;
   __shared__ float red[4][SLAB];
-  __shared__ float ab[FUSED ? 64 : 1][2];
   const int slabs = (C + SLAB - 1) / SLAB;
   const int b = blockIdx.x / slabs, cbase = (blockIdx.x % slabs) * SLAB;
   const int chunk = threadIdx.x % NCH, pl = threadIdx.x / NCH;  // NCH chunks x PL pixel lanes
@@ -282,67 +442,224 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_k(const bf16_t* __restrict_
     }
   }
   __syncthreads();
-  if constexpr (!FUSED) {
-    float* S = Sp + (int64_t)blockIdx.y * B * 4 * C;
-    for (int i = threadIdx.x; i < SLAB && cbase + i < C; i += 256) {
+  float* S = Sp + (int64_t)blockIdx.y * B * 4 * C;
+  for (int i = threadIdx.x; i < SLAB && cbase + i < C; i += 256) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) S[((int64_t)b * 4 + k) * C + cbase + i] = red[k][i];
+    for (int k = 0; k < 4; ++k) S[((int64_t)b * 4 + k) * C + cbase + i] = red[k][i];
+  }
+}
+// FUSED form: the workgroup owns whole groups of one sample (a slab of NCH * 8 channels = a whole number of groups, every pixel), so the
+// group sums and the dx pass follow in the same launch -- one launch instead of reduce + group sums + apply.  The launch is a chain of
+// memory latencies, not a stream: at B = 128 a workgroup moves 16-130 KB, so what counts is how short the chain is.
+//   * Only TWO sums per channel are accumulated over the pixels, P = sum dh * xhat and Q = sum dh (dh = dout * act'(h)): scale, w and b
+//     are per-(sample, channel) constants, so S0 = sum dh*y = w P + b Q, S1 = Q, S2 = sum dy*xhat = (1 + scale) P, S3 = (1 + scale) Q.
+//   * The four waves leave their partial sums in LDS rows of their own (plain stores, no LDS atomics, nothing to clear).
+//   * KEEP > 0 (feature maps of <= KEEP * 256 / NCH pixels): every x / dout row of the lane is loaded ONCE, up front, and stays in
+//     registers for the second pass; the residual-gradient rows are requested before the reduction and arrive under it.
+//     KEEP = 0: both passes walk the pixels four rows per lane in flight; the second pass re-reads x / dout through L2.
+//   * The group sums are taken by 8 threads per group (<= 32 groups per slab) and three shuffles.
+template <int NCH, int KEEP>
+__global__ __launch_bounds__(256) void gn_bwd_fused_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
+                                                      const float* __restrict__ st, const float* __restrict__ w,
+                                                      const float* __restrict__ bb, const bf16_t* __restrict__ fs,
+                                                      const bf16_t* __restrict__ fh, int64_t ldf, int silu, int B, int HW, int C, int G,
+                                                      GnFused fz) {
+  // NCH a power of two: a wave holds whole pixel rows of the slab, its pixel lanes meet in shuffles and the four waves leave one partial
+  // each.  NCH = 12 (96-channel slabs: the 12 / 24 / 48-channel groups of C = 384 / 768 / 1536): 21 pixel lanes of 12 chunks (4 threads
+  // idle), every pixel lane leaves its own partial.
+  constexpr int SLAB = NCH * 8, PL = 256 / NCH;
+  constexpr bool POW2 = (NCH & (NCH - 1)) == 0;
+  constexpr int NP = POW2 ? 4 : PL;
+  __shared__ __attribute__((aligned(16))) float part[NP][2][SLAB];  // [wave or pixel lane][P | Q][channel of the slab]
+  __shared__ float prod[2][SLAB];
+  __shared__ float ab[32][2];
+  const int slabs = (C + SLAB - 1) / SLAB;
+  const int b = blockIdx.x / slabs, cbase = (blockIdx.x % slabs) * SLAB;
+  const int chunk = threadIdx.x % NCH, pl = threadIdx.x / NCH, wave = threadIdx.x >> 6;
+  const int c0_raw = cbase + chunk * 8;
+  // (slabs beyond C: chunks with c0 >= C compute on channel 0 of the slab and are dropped at the end, so that every lane of the wave
+  // takes part in the shuffles)
+  const bool live = c0_raw < C && pl < PL;
+  const int c0 = live ? c0_raw : cbase;
+  const int cg = C / G;
+  float mu[8], rs[8], wv[8], bv[8], sc[8], sh[8], aP[8], aQ[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float* sg = st + ((int64_t)b * G + (c0 + e) / cg) * 2;
+    mu[e] = sg[0];
+    rs[e] = sg[1];
+    wv[e] = w[c0 + e];
+    bv[e] = bb[c0 + e];
+    sc[e] = fs ? bf2f(fs[(int64_t)b * ldf + c0 + e]) : 0.f;
+    sh[e] = fs ? bf2f(fh[(int64_t)b * ldf + c0 + e]) : 0.f;
+    aP[e] = aQ[e] = 0.f;
+  }
+  auto accum = [&](const u32x4_t& xr, const u32x4_t& dr) {
+    float xv[8], dv[8];
+    unpack8(xr, xv);
+    unpack8(dr, dv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (xv[e] - mu[e]) * rs[e];
+      const float h = (xh * wv[e] + bv[e]) * (1.0f + sc[e]) + sh[e];
+      const float dh = dv[e] * (silu ? dsilu_f(h) : 1.0f);
+      aP[e] += dh * xh;
+      aQ[e] += dh;
+    }
+  };
+  const int64_t row0 = ((int64_t)b * HW) * C + c0;  // element offset of (pixel 0, chunk) of this sample
+  constexpr int NK = KEEP > 0 ? KEEP : 1;
+  u32x4_t xk[NK], dk[NK], rk[NK];
+  if constexpr (KEEP > 0) {
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) {
+      const int p = pl + i * PL;
+      if (p < HW && pl < PL) {
+        xk[i] = *(const u32x4_t*)(x + row0 + (int64_t)p * C);
+        dk[i] = *(const u32x4_t*)(dout + row0 + (int64_t)p * C);
+      }
+    }
+    if (fz.dres) {
+#pragma unroll
+      for (int i = 0; i < KEEP; ++i) {
+        const int p = pl + i * PL;
+        if (p < HW && pl < PL) rk[i] = *(const u32x4_t*)(fz.dres + row0 + (int64_t)p * C);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i)
+      if (pl + i * PL < HW && pl < PL) accum(xk[i], dk[i]);
+  } else {
+    int p = pl < PL ? pl : HW;  // (the idle threads of the 12-chunk form walk nothing)
+    for (; p + 3 * PL < HW; p += 4 * PL) {  // four rows of this lane in flight
+      u32x4_t xr[4], dr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xr[i] = *(const u32x4_t*)(x + row0 + (int64_t)(p + i * PL) * C);
+        dr[i] = *(const u32x4_t*)(dout + row0 + (int64_t)(p + i * PL) * C);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) accum(xr[i], dr[i]);
+    }
+    for (; p < HW; p += PL) accum(*(const u32x4_t*)(x + row0 + (int64_t)p * C), *(const u32x4_t*)(dout + row0 + (int64_t)p * C));
+  }
+  // fold the pixel lanes of this wave (lane bits log2(NCH)..5; none when a wave is one pixel row) with shuffles; lanes 0 .. NCH-1 of
+  // every wave (all 64 at NCH = 64) store the wave's sums
+  if constexpr (POW2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int m = NCH; m < 64; m <<= 1) {
+        aP[e] += __shfl_xor(aP[e], m);
+        aQ[e] += __shfl_xor(aQ[e], m);
+      }
+    }
+  }
+  if (POW2 ? (int)(threadIdx.x & 63) < NCH : pl < PL) {
+    const int row = POW2 ? wave : pl, col = chunk * 8;
+    const float z = live ? 1.f : 0.f;
+    *(f32x4_t*)&part[row][0][col] = f32x4_t{aP[0] * z, aP[1] * z, aP[2] * z, aP[3] * z};
+    *(f32x4_t*)&part[row][0][col + 4] = f32x4_t{aP[4] * z, aP[5] * z, aP[6] * z, aP[7] * z};
+    *(f32x4_t*)&part[row][1][col] = f32x4_t{aQ[0] * z, aQ[1] * z, aQ[2] * z, aQ[3] * z};
+    *(f32x4_t*)&part[row][1][col + 4] = f32x4_t{aQ[4] * z, aQ[5] * z, aQ[6] * z, aQ[7] * z};
+  }
+  __syncthreads();
+  const int nch = (C - cbase < SLAB) ? C - cbase : SLAB;  // channels of this slab (a whole number of groups)
+  for (int i = threadIdx.x; i < nch; i += 256) {
+    const int c = cbase + i;
+    // (NCH < 64: a wave covers 64 / NCH pixel lanes of every chunk, so the four waves hold four partials of the same channel;
+    //  NCH = 64: the same -- four pixel lanes, one per wave)
+    float P, Q;
+    if constexpr (POW2) {
+      P = (part[0][0][i] + part[1][0][i]) + (part[2][0][i] + part[3][0][i]);
+      Q = (part[0][1][i] + part[1][1][i]) + (part[2][1][i] + part[3][1][i]);
+    } else {
+      P = Q = 0.f;
+#pragma unroll
+      for (int r = 0; r < NP; ++r) {
+        P += part[r][0][i];
+        Q += part[r][1][i];
+      }
+    }
+    const float wc = w[c], bc = bb[c];
+    const float s1 = fs ? 1.0f + bf2f(fs[(int64_t)b * ldf + c]) : 1.0f;
+    if (fz.dfs) {
+      fz.dfs[(int64_t)b * fz.lddf + c] = f2bf(wc * P + bc * Q);  // S0 = sum dh * y
+      fz.dfh[(int64_t)b * fz.lddf + c] = f2bf(Q);                // S1 = sum dh
+    }
+    const float s2 = s1 * P, s3 = s1 * Q;  // sum dy * xhat, sum dy
+    unsafeAtomicAdd(&fz.dw[c], s2);
+    unsafeAtomicAdd(&fz.db[c], s3);
+    prod[0][i] = wc * s3;  // (the group sums below: A = sum_c w[c] S3[c], Bv = sum_c w[c] S2[c])
+    prod[1][i] = wc * s2;
+  }
+  __syncthreads();
+  {
+    const float inv_n = 1.0f / (float)(HW * cg);
+    const int g = threadIdx.x >> 3, k = threadIdx.x & 7;  // (<= 32 groups per slab: 256 threads cover them)
+    float A = 0.f, Bv = 0.f;
+    if (g < nch / cg)
+      for (int j = k; j < cg; j += 8) {
+        A += prod[0][g * cg + j];
+        Bv += prod[1][g * cg + j];
+      }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      A += __shfl_xor(A, m);
+      Bv += __shfl_xor(Bv, m);
+    }
+    if (k == 0 && g < nch / cg) {
+      ab[g][0] = A * inv_n;
+      ab[g][1] = Bv * inv_n;
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  float gA[8], gB[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    gA[e] = ab[(c0 + e - cbase) / cg][0];
+    gB[e] = ab[(c0 + e - cbase) / cg][1];
+  }
+  auto apply = [&](const u32x4_t& xr, const u32x4_t& dr, const u32x4_t& rr) -> u32x4_t {
+    float xv[8], dv[8], rv[8];
+    unpack8(xr, xv);
+    unpack8(dr, dv);
+    if (fz.dres) unpack8(rr, rv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (xv[e] - mu[e]) * rs[e];
+      const float s1 = 1.0f + sc[e];
+      const float h = (xh * wv[e] + bv[e]) * s1 + sh[e];
+      const float dy = dv[e] * (silu ? dsilu_f(h) : 1.0f) * s1;
+      xv[e] = rs[e] * (dy * wv[e] - gA[e] - xh * gB[e]) + (fz.dres ? rv[e] : 0.f);
+    }
+    return pack8(xv);
+  };
+  if constexpr (KEEP > 0) {
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) {
+      const int p = pl + i * PL;
+      if (p < HW) *(u32x4_t*)(fz.dx + row0 + (int64_t)p * C) = apply(xk[i], dk[i], rk[i]);
     }
   } else {
-    const int cg = C / G;
-    const int nch = (C - cbase < SLAB) ? C - cbase : SLAB;  // channels of this slab (a whole number of groups)
-    for (int i = threadIdx.x; i < nch; i += 256) {
-      const int c = cbase + i;
-      if (fz.dfs) {
-        fz.dfs[(int64_t)b * fz.lddf + c] = f2bf(red[0][i]);
-        fz.dfh[(int64_t)b * fz.lddf + c] = f2bf(red[1][i]);
-      }
-      unsafeAtomicAdd(&fz.dw[c], red[2][i]);
-      unsafeAtomicAdd(&fz.db[c], red[3][i]);
-    }
-    const float inv_n = 1.0f / (float)(HW * cg);
-    if ((int)threadIdx.x < nch / cg) {
-      float A = 0.f, Bv = 0.f;
-      for (int j = 0; j < cg; ++j) {
-        const int i = threadIdx.x * cg + j;
-        A += w[cbase + i] * red[3][i];
-        Bv += w[cbase + i] * red[2][i];
-      }
-      ab[threadIdx.x][0] = A * inv_n;
-      ab[threadIdx.x][1] = Bv * inv_n;
-    }
-    __syncthreads();
-    if (c0_raw < C) {
-      const int c0 = c0_raw;
-      float mu[8], rs[8], wv[8], bv[8], sc[8], sh[8], gA[8], gB[8];
+    const u32x4_t zero = {0u, 0u, 0u, 0u};
+    int p = pl;  // (live threads only: pl < PL)
+    for (; p + 3 * PL < HW; p += 4 * PL) {
+      u32x4_t xr[4], dr[4], rr[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float* sg = st + ((int64_t)b * G + (c0 + e) / cg) * 2;
-        mu[e] = sg[0];
-        rs[e] = sg[1];
-        wv[e] = w[c0 + e];
-        bv[e] = bb[c0 + e];
-        sc[e] = fs ? bf2f(fs[(int64_t)b * ldf + c0 + e]) : 0.f;
-        sh[e] = fs ? bf2f(fh[(int64_t)b * ldf + c0 + e]) : 0.f;
-        gA[e] = ab[(c0 + e - cbase) / cg][0];
-        gB[e] = ab[(c0 + e - cbase) / cg][1];
+      for (int i = 0; i < 4; ++i) {
+        const int64_t o = row0 + (int64_t)(p + i * PL) * C;
+        xr[i] = *(const u32x4_t*)(x + o);
+        dr[i] = *(const u32x4_t*)(dout + o);
+        rr[i] = fz.dres ? *(const u32x4_t*)(fz.dres + o) : zero;
       }
-      for (int p = pl; p < HW; p += PL) {
-        const int64_t o = ((int64_t)b * HW + p) * C + c0;
-        float xv[8], dv[8], rv[8];
-        unpack8(*(const u32x4_t*)(x + o), xv);
-        unpack8(*(const u32x4_t*)(dout + o), dv);
-        if (fz.dres) unpack8(*(const u32x4_t*)(fz.dres + o), rv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xh = (xv[e] - mu[e]) * rs[e];
-          const float s1 = 1.0f + sc[e];
-          const float h = (xh * wv[e] + bv[e]) * s1 + sh[e];
-          const float dy = dv[e] * (silu ? dsilu_f(h) : 1.0f) * s1;
-          xv[e] = rs[e] * (dy * wv[e] - gA[e] - xh * gB[e]) + (fz.dres ? rv[e] : 0.f);
-        }
-        *(u32x4_t*)(fz.dx + o) = pack8(xv);
-      }
+      for (int i = 0; i < 4; ++i) *(u32x4_t*)(fz.dx + row0 + (int64_t)(p + i * PL) * C) = apply(xr[i], dr[i], rr[i]);
+    }
+    for (; p < HW; p += PL) {
+      const int64_t o = row0 + (int64_t)p * C;
+      *(u32x4_t*)(fz.dx + o) = apply(*(const u32x4_t*)(x + o), *(const u32x4_t*)(dout + o), fz.dres ? *(const u32x4_t*)(fz.dres + o) : zero);
     }
   }
 }
@@ -436,10 +753,6 @@ __global__ void gn_bwd_apply_k(const bf16_t* __restrict__ dout, const bf16_t* __
     *(u32x4_t*)(dx + o) = pack8(xv);
   }
 }
-static int g_gn_fused = 1;  // 1: fused (128-channel slabs on small maps where they fit, 64-channel slabs on the large maps); 2: fused, 512-channel slabs on
-                             // small maps only (round 4); 0: three launches
-extern "C" __attribute__((visibility("default"))) void dl_lab_set_gn_fused(int mode) { g_gn_fused = mode; }  // LAB A/B switch (not in the header)
-static int gn_bwd_fused() { return g_gn_fused; }  // (the three-launch form stays for the shapes the fused kernel does not take)
 // pixel ranges of gn_bwd_reduce_k: enough workgroups to fill the chip at small batch x channel counts, at least 64 pixels each
 static inline int gn_bwd_ranges(int64_t B, int64_t HW, int64_t C) {
   const int64_t slabs = (C + 63) / 64;
@@ -463,44 +776,58 @@ extern "C" int dl_gn_bwd(const void* dout, const void* x, const float* stats, co
   float* Sp = scratch;
   float* AB = scratch + (int64_t)DL_GN_BWD_MAX_RANGES * B * 4 * C;
   int ns = 1;
-  const GnFused none{};
-  if (HW <= 64 && C >= 512 && 128 % (C / G) == 0 && C % 128 == 0 && gn_bwd_fused() == 1) {
+  if (HW <= 64 && C >= 512 && 128 % (C / G) == 0 && 128 / (C / G) <= 32 && C % 128 == 0 && (gn_bwd_fused() & 1)) {
     // 128-channel slabs (whole groups), 16 pixel lanes: four times the workgroups of the 512-channel form below -- at B = 128 that
     // one launches 128-384 workgroups of 4-16 serial pixel iterations on a 256-CU chip (54 us for 40 MB of traffic)
     const GnFused fz{dw, db, (bf16_t*)dfilm_scale, (bf16_t*)dfilm_shift, ld_dfilm, (const bf16_t*)dres, (bf16_t*)dx};
-    hipLaunchKernelGGL((gn_bwd_reduce_k<16, true>), dim3((unsigned)(B * (C / 128)), 1u), 256, 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((gn_bwd_fused_k<16, 4>), dim3((unsigned)(B * (C / 128)), 1u), 256, 0, (hipStream_t)stream,
                        (const bf16_t*)dout, (const bf16_t*)x, stats, w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift,
-                       ld_film, act_silu, Sp, (int)B, (int)HW, (int)C, (int)G, fz);
+                       ld_film, act_silu, (int)B, (int)HW, (int)C, (int)G, fz);
     DL_LAUNCH_CHECK();
     return DL_OK;
   }
-  if (HW > 64 && HW <= 1024 && 64 % (C / G) == 0 && C % 64 == 0 && B * (C / 64) >= 128 && (gn_bwd_fused() & 1)) {
+  if (HW > 64 && HW <= 1024 && 64 % (C / G) == 0 && 64 / (C / G) <= 32 && C % 64 == 0 && (B * (C / 64) >= 128 || gn_bwd_fused() == 3) && (gn_bwd_fused() & 1)) {
     // high-resolution maps (16 x 16, 32 x 32): the same fusion on 64-channel slabs with 32 pixel lanes -- one launch instead of
     // reduce (pixel ranges) + group sums + apply; the second pass re-reads the slab's x / dout (up to 2 x 128 KB) through L2 / MALL
     const GnFused fz{dw, db, (bf16_t*)dfilm_scale, (bf16_t*)dfilm_shift, ld_dfilm, (const bf16_t*)dres, (bf16_t*)dx};
-    hipLaunchKernelGGL((gn_bwd_reduce_k<8, true>), dim3((unsigned)(B * (C / 64)), 1u), 256, 0, (hipStream_t)stream,
+    // (rows kept in registers -- KEEP = 8 at 16 x 16 -- cost the second wave per SIMD: 42 vs 25 us; both passes stream)
+    hipLaunchKernelGGL((gn_bwd_fused_k<8, 0>), dim3((unsigned)(B * (C / 64)), 1u), 256, 0, (hipStream_t)stream,
                        (const bf16_t*)dout, (const bf16_t*)x, stats, w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift,
-                       ld_film, act_silu, Sp, (int)B, (int)HW, (int)C, (int)G, fz);
+                       ld_film, act_silu, (int)B, (int)HW, (int)C, (int)G, fz);
     DL_LAUNCH_CHECK();
     return DL_OK;
   }
-  if (HW <= 64 && C >= 512 && 512 % (C / G) == 0 && gn_bwd_fused()) {
+  if (C % 96 == 0 && 96 % (C / G) == 0 && HW <= 1024 && (B * (C / 96) >= 128 || gn_bwd_fused() == 3) && (gn_bwd_fused() & 1)) {
+    // 12 / 24 / 48 channels per group (C = 384 / 768 / 1536, the concatenated inputs of the output blocks): 96-channel slabs
     const GnFused fz{dw, db, (bf16_t*)dfilm_scale, (bf16_t*)dfilm_shift, ld_dfilm, (const bf16_t*)dres, (bf16_t*)dx};
-    hipLaunchKernelGGL((gn_bwd_reduce_k<64, true>), dim3((unsigned)(B * ((C + 511) / 512)), 1u), 256, 0, (hipStream_t)stream,
+    if (HW <= 84)
+      hipLaunchKernelGGL((gn_bwd_fused_k<12, 4>), dim3((unsigned)(B * (C / 96)), 1u), 256, 0, (hipStream_t)stream,
+                         (const bf16_t*)dout, (const bf16_t*)x, stats, w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift,
+                         ld_film, act_silu, (int)B, (int)HW, (int)C, (int)G, fz);
+    else
+      hipLaunchKernelGGL((gn_bwd_fused_k<12, 0>), dim3((unsigned)(B * (C / 96)), 1u), 256, 0, (hipStream_t)stream,
+                         (const bf16_t*)dout, (const bf16_t*)x, stats, w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift,
+                         ld_film, act_silu, (int)B, (int)HW, (int)C, (int)G, fz);
+    DL_LAUNCH_CHECK();
+    return DL_OK;
+  }
+  if (HW <= 64 && C >= 512 && 512 % (C / G) == 0 && 512 / (C / G) <= 32 && gn_bwd_fused()) {
+    const GnFused fz{dw, db, (bf16_t*)dfilm_scale, (bf16_t*)dfilm_shift, ld_dfilm, (const bf16_t*)dres, (bf16_t*)dx};
+    hipLaunchKernelGGL((gn_bwd_fused_k<64, 0>), dim3((unsigned)(B * ((C + 511) / 512)), 1u), 256, 0, (hipStream_t)stream,
                        (const bf16_t*)dout, (const bf16_t*)x, stats, w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift,
-                       ld_film, act_silu, Sp, (int)B, (int)HW, (int)C, (int)G, fz);
+                       ld_film, act_silu, (int)B, (int)HW, (int)C, (int)G, fz);
     DL_LAUNCH_CHECK();
     return DL_OK;
   }
   if (HW <= 64 && C >= 512) {
     hipLaunchKernelGGL((gn_bwd_reduce_k<64>), dim3((unsigned)(B * ((C + 511) / 512)), 1u), 256, 0, (hipStream_t)stream,
                        (const bf16_t*)dout, (const bf16_t*)x, stats, w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift,
-                       ld_film, act_silu, Sp, (int)B, (int)HW, (int)C, (int)G, none);
+                       ld_film, act_silu, Sp, (int)B, (int)HW, (int)C, (int)G);
   } else {
     ns = gn_bwd_ranges(B, HW, C);
     hipLaunchKernelGGL((gn_bwd_reduce_k<8>), dim3((unsigned)(B * ((C + 63) / 64)), (unsigned)ns), 256, 0, (hipStream_t)stream,
                        (const bf16_t*)dout, (const bf16_t*)x, stats, w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift,
-                       ld_film, act_silu, Sp, (int)B, (int)HW, (int)C, (int)G, none);
+                       ld_film, act_silu, Sp, (int)B, (int)HW, (int)C, (int)G);
   }
   hipLaunchKernelGGL(gn_group_sums_k, (int)B, 256, 0, (hipStream_t)stream, Sp, ns, (int)B, w, AB, dw, db, (bf16_t*)dfilm_scale,
                      (bf16_t*)dfilm_shift, ld_dfilm, (int)C, (int)G);

@@ -755,6 +755,12 @@ def gn_apply_fwd(x, stats, w, b, film_scale, film_shift, silu, out, B, HW, C, G=
           film_scale.stride(0) if film_scale is not None else 0, int(silu), _p(out), B, HW, C, G, _s())
 
 
+def gn_fwd(x, stats, w, b, film_scale, film_shift, silu, out, B, HW, C, G=32, eps=1e-5):
+    """statistics (written to `stats`) + normalise / FiLM / SiLU in one call"""
+    _call("dl_gn_fwd", _p(x), _p(w), _p(b), _p(film_scale), _p(film_shift), film_scale.stride(0) if film_scale is not None else 0,
+          int(bool(silu)), _p(out), _p(stats), B, HW, C, G, float(eps), _s())
+
+
 def gn_bwd(dout, x, stats, w, b, film_scale, film_shift, silu, dres, dx, dw, db, dfilm_scale, dfilm_shift, scratch, B, HW, C,
            G=32):
     _call("dl_gn_bwd", _p(dout), _p(x), _p(stats), _p(w), _p(b), _p(film_scale), _p(film_shift),

@@ -127,6 +127,34 @@ class FusedAdamW(torch.optim.Optimizer):
             st["step"] = int(st.get("step", 0))
 
     def _flat(self, group) -> tuple[Tensor, Tensor, list] | None:
+        """`_flat_scan(group)`, remembered per group: a hit is re-validated by pointer compares only (every arena parameter's data and
+        gradient still sit at the recorded addresses, the group's parameter list is the same objects) -- the full scan costs 1.7 ms
+        on the UNet's ~500 tensors and ran twice per training step (zero_grad, step)"""
+        cache = self.__dict__.setdefault("_flat_cache", {})
+        hit = cache.get(id(group))
+        if hit is not None:
+            plist, n, pins, res = hit
+            if plist is group["params"] and len(plist) == n:
+                for p, dp, gp in pins:
+                    g = p.grad
+                    if g is None or g.data_ptr() != gp or p.data_ptr() != dp or not p.requires_grad:
+                        break
+                else:
+                    if all(p.grad is None or not p.requires_grad or id(p) in res[3] for p in res[2]):  # (nobody outside joined the arena)
+                        return res[:3]
+        res = self._flat_scan(group)
+        if res is None:
+            cache.pop(id(group), None)
+            return None
+        ids = {id(p) for p in group["params"]} - {id(p) for p in res[2]}
+        inside = [p for p in group["params"] if id(p) in ids]
+        # (outside tensors are re-scanned when one of them gains a gradient: it might be an arena view that had none yet)
+        outside_with_grad = {id(p) for p in res[2] if p.grad is not None and p.requires_grad}
+        cache[id(group)] = (group["params"], len(group["params"]), [(p, p.data_ptr(), p.grad.data_ptr()) for p in inside],
+                            (res[0], res[1], res[2], outside_with_grad))
+        return res
+
+    def _flat_scan(self, group) -> tuple[Tensor, Tensor, list] | None:
         """(param arena, grad arena, parameters NOT in it) when (most of) the group lives in one flat arena -- e.g. a denoiser's
         arena plus the few tensors of an auxiliary loss head (REPA projector) in the same param group -- else None"""
         ps = [p for p in group["params"] if p.requires_grad]

@@ -392,7 +392,7 @@ class UNetEngine:
             #  bias gradient: 35.4 vs 34.7 ms per MNIST-DDPM step, so the atomic form stays the default here)
             ops.colsum(dy, self.Gr(name[:-6] + "bias"), M, co, scratch=self._scr("colsum_part", 512 * co, torch.float32) if tuning.on("DL_UNET_DET_COLSUM") else None)
             g = self._new(ldk, co8, dtype=torch.float32, zero=True)  # transposed: 9*Ci rows fit the 384-row wgrad tiles
-            if not ops.conv3x3_wgrad_tn(x, B, H, W, ci, dyp, co8, g, self._zero, max_wgs=192):  # (0: 35.4 ms/step, 192: 34.9, 128: 36.5)
+            if not ops.conv3x3_wgrad_tn(x, B, H, W, ci, dyp, co8, g, self._zero, max_wgs=tuning.integer("DL_UNET_WGRAD_WGS", 0)):
                 cols = self._new(Mp, ldk)
                 ops.im2col3x3(x, cols, B, H, W, ci)
                 ops.gemm_tn(cols, dyp, g, M=ldk, N=co8)
@@ -439,11 +439,12 @@ class UNetEngine:
         return dx
 
     def _gn(self, x: Tensor, B: int, HW: int, C: int, wname: str, film=None, silu: bool = True, stats: Tensor | None = None):
-        if stats is None:
-            stats = self._new(B, self.G, 2, dtype=torch.float32)
-            ops.gn_stats(x, stats, B, HW, C, self.G)
         out = self._new(B * HW, C)
         fs, fh = film if film is not None else (None, None)
+        if stats is None:
+            stats = self._new(B, self.G, 2, dtype=torch.float32)
+            ops.gn_fwd(x, stats, self.P(wname + "weight"), self.P(wname + "bias"), fs, fh, silu, out, B, HW, C, self.G)
+            return out, stats
         ops.gn_apply_fwd(x, stats, self.P(wname + "weight"), self.P(wname + "bias"), fs, fh, silu, out, B, HW, C, self.G)
         return out, stats
 

@@ -477,6 +477,9 @@ DL_API int dl_gn_stats(const void* x, float* stats, int64_t B, int64_t HW, int64
 DL_API int dl_gn_apply_fwd(const void* x, const float* stats, const float* w, const float* b, const void* film_scale,
                            const void* film_shift, int64_t ld_film, int act_silu, void* out, int64_t B, int64_t HW,
                            int64_t C, int64_t G, dl_stream_t stream);
+/* statistics + apply in one call (one launch on the training shapes; `stats` f32 [B, G, 2] is written for dl_gn_bwd) */
+DL_API int dl_gn_fwd(const void* x, const float* w, const float* b, const void* film_scale, const void* film_shift, int64_t ld_film,
+                     int act_silu, void* out, float* stats, int64_t B, int64_t HW, int64_t C, int64_t G, float eps, dl_stream_t stream);
 /* backward of dl_gn_stats + dl_gn_apply_fwd: dx bf16 (= gradient through the norm + dres when dres != NULL: the residual /
  * skip fan-in of ResBlock and AttentionBlock), dw/db f32 [C] ACCUMULATED (+=), dfilm_* bf16 [B, ld_dfilm] written
  * (required iff film_* given).  scratch: f32 [DL_GN_BWD_MAX_RANGES * B*4*C + B*G*2] (partial sums of the pixel ranges the

@@ -59,6 +59,45 @@ def main() -> None:
     print(json.dumps({"workload": "unet-mnist-ddpm train step", "batch": a.batch, "ms_per_step": dt * 1e3,
                       "images_per_s": a.batch / dt, "host_issue_ms_per_step": t_issue * 1e3,
                       "params_M": sum(p.numel() for p in m.parameters()) / 1e6, "loss": float(loss)}))
+    if os.environ.get("UNET_HOST_SPLIT"):  # LAB: host time to ISSUE each phase of a step (no synchronisation)
+        acc = {"zero_grad": 0.0, "forward": 0.0, "backward": 0.0, "optimizer": 0.0}
+        torch.cuda.synchronize()
+        n = 10
+        for _ in range(n):
+            t0 = time.perf_counter()
+            opt.zero_grad()
+            t1 = time.perf_counter()
+            loss = gd.compute_loss({"x": x0, "y": y, "p": 0.0}, timesteps=gd.draw_timesteps(a.batch))["loss"]
+            t2 = time.perf_counter()
+            loss.backward()
+            t3 = time.perf_counter()
+            opt.step()
+            t4 = time.perf_counter()
+            for k, v in zip(acc, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                acc[k] += v
+        torch.cuda.synchronize()
+        print("host issue ms per step:", {k: round(v / n * 1e3, 2) for k, v in acc.items()})
+        import threading
+
+        import cProfile
+        import io
+        import pstats
+
+        prof = cProfile.Profile()
+        threading.setprofile(lambda *a_: None)  # (the autograd worker thread exists already: profile the backward by running the engine's backward directly)
+        m.zero_grad()
+        loss = gd.compute_loss({"x": x0, "y": y, "p": 0.0}, timesteps=gd.draw_timesteps(a.batch))["loss"]
+        torch.cuda.synchronize()
+        eng = m.engine
+        dpred = torch.randn(a.batch, 1, 32, 32, device=dev)
+        m._prepare_grads()
+        prof.enable()
+        eng.backward(dpred)
+        prof.disable()
+        torch.cuda.synchronize()
+        st = io.StringIO()
+        pstats.Stats(prof, stream=st).sort_stats("tottime").print_stats(28)
+        print(st.getvalue()[:6500])
     if os.environ.get("UNET_HOST_PROFILE"):  # LAB: where the host time of a step goes
         import cProfile
         import io
