@@ -1006,6 +1006,42 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_fold_tiled_k(const float* _
     dw[((int64_t)(co0 + col) * Ci + ci0) * 9 + j] += tile[col * CW_P + j];
   }
 }
+// every convolution's staged weight gradient folded by ONE launch at the end of the backward (the UNet has 56: 56 launches of
+// 20-80 us on the side stream otherwise, 1.6 ms of the step): a device table of descriptors, one 32 x 32 channel tile (x 9 taps) per
+// workgroup; clear != 0 writes zeros back into the staging tile, so the next backward accumulates into a clean stage without a memset
+__global__ __launch_bounds__(256) void conv3x3_wgrad_fold_batched_k(const dl_fold_conv_desc_t* __restrict__ desc, int n_desc, int clear) {
+  __shared__ float tile[CW_T * CW_P];
+  int lo = 0, hi = n_desc - 1;  // last descriptor whose tile_begin <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].tile_begin <= (int64_t)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const dl_fold_conv_desc_t d = desc[lo];
+  const int64_t t = (int64_t)blockIdx.x - d.tile_begin;
+  const int Ci = (int)d.Ci, tci = Ci / CW_T;
+  const int co0 = (int)(t / tci) * CW_T, ci0 = (int)(t % tci) * CW_T;
+  float* g = (float*)d.g;
+  float* dw = (float*)d.dw;
+  for (int i = threadIdx.x; i < CW_T * CW_T * 9; i += 256) {
+    const int col = i & (CW_T - 1), rest = i / CW_T, cil = rest % CW_T, tap = rest / CW_T;
+    float* src = g + (int64_t)(tap * Ci + ci0 + cil) * d.ldg + co0 + col;
+    tile[col * CW_P + cil * 9 + tap] = *src;
+    if (clear) *src = 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < CW_T * CW_T * 9; i += 256) {
+    const int col = i / (CW_T * 9), j = i - col * (CW_T * 9);
+    dw[((int64_t)(co0 + col) * Ci + ci0) * 9 + j] += tile[col * CW_P + j];
+  }
+}
+extern "C" int dl_conv3x3_wgrad_fold_batched(const dl_fold_conv_desc_t* desc_dev, int n_desc, int64_t total_tiles, int clear_stage,
+                                             dl_stream_t stream) {
+  DL_CHECK_ARG(desc_dev && n_desc > 0 && total_tiles > 0 && total_tiles < (1ll << 31), "dl_conv3x3_wgrad_fold_batched: bad args");
+  hipLaunchKernelGGL(conv3x3_wgrad_fold_batched_k, (int)total_tiles, 256, 0, (hipStream_t)stream, desc_dev, n_desc, clear_stage);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
 extern "C" int dl_conv3x3_wgrad_fold(const float* g, int64_t ldg, float* dw, int64_t Co, int64_t Ci, dl_stream_t stream) {
   DL_CHECK_ARG(g && dw && Co > 0 && Ci > 0 && ldg >= Co, "dl_conv3x3_wgrad_fold: bad args");
   if (Co % CW_T == 0 && Ci % CW_T == 0 && Co / CW_T <= 65535) {

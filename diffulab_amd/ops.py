@@ -613,6 +613,19 @@ def colsum(x, out, R=None, C=None, scratch=None):
     _call("dl_colsum", _p(x), F32 if x.dtype == torch.float32 else BF16, x.stride(0), _p(out), R, C, _s())
 
 
+class _ColsumDesc(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("ld", ctypes.c_int64), ("out", ctypes.c_void_p), ("R", ctypes.c_int64), ("C", ctypes.c_int64)]
+
+
+def colsum_batched(items: list) -> None:
+    """items: [(x bf16 [R, ld] rows, out f32 [C], R, C)]: out[c] += sum_r x[r, c] for all of them in one launch per 24"""
+    arr = (_ColsumDesc * len(items))()
+    for i, (x, out, R, C) in enumerate(items):
+        assert x.dtype == torch.bfloat16 and out.dtype == torch.float32
+        arr[i] = _ColsumDesc(_p(x), x.stride(0), _p(out), R, C)
+    _call("dl_colsum_batched", ctypes.cast(arr, ctypes.c_void_p), len(items), _s())
+
+
 def reduce_rows_f32(partial, out, G, n, clear=False):
     _call("dl_reduce_rows_f32", _p(partial), _p(out), G, n, int(clear), _s())
 
@@ -714,6 +727,38 @@ class ConvCastTable:
 
     def run(self) -> None:
         _call("dl_cast_conv3x3_weights_batched", _p(self.dev), self.n, self.tiles, _s())
+
+
+class ConvFoldTable:
+    """device table for dl_conv3x3_wgrad_fold_batched: every staged convolution weight gradient (g f32 [9 Ci, ldg], transposed as
+    dl_conv3x3_wgrad_tn leaves it) folded into its [Co, Ci, 3, 3] gradient by ONE launch.  entries: (g, dw)"""
+
+    @staticmethod
+    def accepts(co: int, ci: int) -> bool:
+        return co % 32 == 0 and ci % 32 == 0
+
+    def __init__(self, entries: list[tuple[Tensor, Tensor]]) -> None:
+        import ctypes
+
+        class Desc(ctypes.Structure):
+            _fields_ = [("g", ctypes.c_void_p), ("ldg", ctypes.c_int64), ("dw", ctypes.c_void_p), ("Co", ctypes.c_int64),
+                        ("Ci", ctypes.c_int64), ("tile_begin", ctypes.c_int64)]
+
+        arr = (Desc * len(entries))()
+        tiles = 0
+        self.keep = entries  # the table holds raw pointers: keep the tensors alive
+        for i, (g, dw) in enumerate(entries):
+            co, ci = dw.shape[0], dw.shape[1]
+            assert dw.is_contiguous() and dw.dtype == torch.float32 and g.dtype == torch.float32 and self.accepts(co, ci)
+            assert g.shape[0] >= 9 * ci and g.stride(0) >= co
+            arr[i] = Desc(_p(g), g.stride(0), _p(dw), co, ci, tiles)
+            tiles += (co // 32) * (ci // 32)
+        self.n, self.tiles = len(entries), tiles
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.dev = host.to(entries[0][0].device)
+
+    def run(self, clear: bool = True) -> None:
+        _call("dl_conv3x3_wgrad_fold_batched", _p(self.dev), self.n, self.tiles, int(clear), _s())
 
 
 def cast_weight_swiglu(src, dst):

@@ -41,6 +41,8 @@ SWITCHES: dict[str, tuple[str, str]] = {
     "DL_UNET_SPLITK": ("1", "split-K convolutions at the UNet's low-resolution levels (partial images + fixed-order fold: -7 % per step)"),
     "DL_UNET_WGRAD_WGS": ("0", "workgroup cap of the UNet's side-stream convolution weight gradients (0 = one per CU; round 5, B = 128: "
                           "0 -> 28.2 ms/step, 224 -> 28.4, 192 -> 28.35, 160 -> 29.0; everything on one stream: 31.1)"),
+    "DL_UNET_FOLD_BATCHED": ("1", "UNet convolution weight gradients stay in a persistent transposed staging arena during the backward; one "
+                             "launch at its end folds all of them into the [Co, Ci, 3, 3] gradients (instead of a zero-fill and a fold per convolution)"),
     "DL_UNET_DET_COLSUM": ("0", "UNet bias gradients through the bit-reproducible column sum (measured 2 % slower)"),
 }
 

@@ -381,6 +381,64 @@ class UNetEngine:
     def _use_side(self) -> bool:
         return tuning.on("DL_UNET_SIDE")
 
+    def _bias_grad(self, dy: Tensor, bname: str, M: int, co: int) -> None:
+        """bias gradient = column sum of dy.  Default: deferred -- the (dy, gradient) pair waits with the staged weight gradients and a
+        stretch of the backward's column sums runs as ONE launch (_fold_staged; 105 launches of 5-40 us per step on the side stream
+        otherwise).  DL_UNET_DET_COLSUM=1: at once, through row-slab partials + a fixed-order fold (bit-reproducible, two launches per
+        bias: measured 2 % slower per step)."""
+        if tuning.on("DL_UNET_DET_COLSUM"):
+            ops.colsum(dy, self.Gr(bname), M, co, scratch=self._scr("colsum_part", 512 * co, torch.float32))
+        elif tuning.on("DL_UNET_FOLD_BATCHED") and dy.dtype == torch.bfloat16:
+            self.__dict__.setdefault("_colsum_pending", []).append((dy, self.Gr(bname), M, co))
+        else:
+            ops.colsum(dy, self.Gr(bname), M, co)
+
+    def _wgrad_stage(self, name: str, ldk: int, co: int, ci: int) -> Tensor | None:
+        """this convolution's slice [ldk, co] f32 of the weight-gradient staging arena (zero between backwards), or None"""
+        if not (tuning.on("DL_UNET_FOLD_BATCHED") and ops.ConvFoldTable.accepts(co, ci)):
+            return None
+        st = self.__dict__.setdefault("_stage", {})
+        g = st.get(name)
+        if g is None:
+            g = st[name] = self._new(ldk, co, dtype=torch.float32, zero=True)
+        self.__dict__.setdefault("_stage_pending", []).append(name)
+        return g
+
+    def _fold_staged(self, min_pending: int = 1) -> None:
+        """every weight gradient staged since the last call into its parameter's gradient, one launch (which also clears the stage).
+        Called after each block group of the backward once `min_pending` convolutions wait (the folds then run under the rest of the
+        backward: only the last, small batch -- the high-resolution input blocks -- is left for the end) and once at the end."""
+        pend = self.__dict__.get("_stage_pending")
+        cs = self.__dict__.get("_colsum_pending")
+        if min_pending <= 1 and cs and not pend:  # (the end of a backward without staged convolutions: only column sums wait)
+            self._colsum_pending = []
+            if self._use_side:
+                with torch.cuda.stream(self._side_stream()):
+                    ops.colsum_batched(cs)
+            else:
+                ops.colsum_batched(cs)
+            return
+        if not pend or len(pend) < min_pending:
+            return
+        key = (self.grads.data_ptr(), tuple(pend))
+        tables = self.__dict__.setdefault("_fold_tables", {})
+        table = tables.get(key)
+        if table is None:
+            if len(tables) > 64:  # (a re-bound gradient arena: the old tables hold dead pointers)
+                tables.clear()
+            table = tables[key] = ops.ConvFoldTable([(self._stage[n], self.Gr(n)) for n in pend])
+        self._stage_pending = []
+        self._colsum_pending = []
+        if self._use_side:
+            with torch.cuda.stream(self._side_stream()):
+                if cs:
+                    ops.colsum_batched(cs)
+                table.run(clear=True)
+        else:
+            if cs:
+                ops.colsum_batched(cs)
+            table.run(clear=True)
+
     def _conv3_bwd(self, dy: Tensor, x: Tensor, B: int, H: int, W: int, ci: int, name: str, co: int,
                    need_dx: bool = True) -> Tensor | None:
         M = B * H * W
@@ -390,13 +448,20 @@ class UNetEngine:
         def wgrad() -> None:  # bias + weight gradient: off the dependency chain of the backward
             # (DL_UNET_DET_COLSUM=1: row-slab partials + fixed-order fold instead of f32 atomics -- reproducible, but two launches per
             #  bias gradient: 35.4 vs 34.7 ms per MNIST-DDPM step, so the atomic form stays the default here)
-            ops.colsum(dy, self.Gr(name[:-6] + "bias"), M, co, scratch=self._scr("colsum_part", 512 * co, torch.float32) if tuning.on("DL_UNET_DET_COLSUM") else None)
-            g = self._new(ldk, co8, dtype=torch.float32, zero=True)  # transposed: 9*Ci rows fit the 384-row wgrad tiles
+            self._bias_grad(dy, name[:-6] + "bias", M, co)
+            # the gradient lands transposed, [(tap, ci), co] f32 (9*Ci rows fit the 384-row wgrad tiles), in this convolution's slice of
+            # a persistent staging arena; ONE launch at the end of the backward folds every slice into its [Co, Ci, 3, 3] gradient and
+            # clears it (_fold_staged).  Channel counts off 32 (the first / last convolution): a temporary stage, folded here.
+            g = self._wgrad_stage(name, ldk, co, ci)
+            staged = g is not None
+            if not staged:
+                g = self._new(ldk, co8, dtype=torch.float32, zero=True)
             if not ops.conv3x3_wgrad_tn(x, B, H, W, ci, dyp, co8, g, self._zero, max_wgs=tuning.integer("DL_UNET_WGRAD_WGS", 0)):
                 cols = self._new(Mp, ldk)
                 ops.im2col3x3(x, cols, B, H, W, ci)
                 ops.gemm_tn(cols, dyp, g, M=ldk, N=co8)
-            ops.conv3x3_wgrad_fold(g, self.Gr(name))
+            if not staged:
+                ops.conv3x3_wgrad_fold(g, self.Gr(name))
 
         self._off_chain(wgrad, dy, dyp, x)
         if not need_dx:
@@ -426,7 +491,7 @@ class UNetEngine:
         def wgrad() -> None:
             # (DL_UNET_DET_COLSUM=1: row-slab partials + fixed-order fold instead of f32 atomics -- reproducible, but two launches per
             #  bias gradient: 35.4 vs 34.7 ms per MNIST-DDPM step, so the atomic form stays the default here)
-            ops.colsum(dy, self.Gr(name[:-6] + "bias"), M, co, scratch=self._scr("colsum_part", 512 * co, torch.float32) if tuning.on("DL_UNET_DET_COLSUM") else None)
+            self._bias_grad(dy, name[:-6] + "bias", M, co)
             ops.gemm_tn(dyp, xp, self.Gr(name).view(co, ci), M=co, N=ci)
 
         self._off_chain(wgrad, dy, dyp, xp)
@@ -749,13 +814,16 @@ class UNetEngine:
             self.o.copy2d_bf16(dcat[:, :ch], dh, M, ch)
             self.o.copy2d_bf16(dcat[:, ch:], dsk, M, ich)
             dskips.append(dsk)
+            self._fold_staged(min_pending=8)
         dh = self._group_bwd(plan.middle, dh, B, save, eo, deo)
         for grp in plan.input_blocks[::-1]:
             dh = self._add(dh, dskips.pop())
             dh = self._group_bwd(grp, dh, B, save, eo, deo)
+            self._fold_staged(min_pending=8)
         assert not save and not dskips
 
         self._cond_bwd(deo, s, B)
+        self._fold_staged()
         if self._use_side:
             torch.cuda.current_stream().wait_stream(self._side_stream())
         if self.reducer is not None:

@@ -375,6 +375,14 @@ DL_API int dl_heads_merge_rope_bwd(const void* dst_grad, void* src_grad, int64_t
 /* out[c] += sum_r x[r,c]  (bias gradients); x bf16 or f32 per dtype */
 DL_API int dl_colsum(const void* x, int dtype, int64_t ld, float* out, int64_t R, int64_t C,
                      dl_stream_t stream);
+/* several bf16 column sums (bias gradients of a stretch of a backward) in one launch per 24 problems; `desc` is a HOST array */
+typedef struct dl_colsum_desc_t {
+  const void* x; /* bf16 [R, ld] */
+  int64_t ld;
+  float* out;    /* f32 [C], accumulated (+=) */
+  int64_t R, C;
+} dl_colsum_desc_t;
+DL_API int dl_colsum_batched(const dl_colsum_desc_t* desc, int n, dl_stream_t stream);
 /* out[j] += sum_g partial[g, j]   (second stage of the LayerNorm affine gradients); clear_partial != 0 zeroes `partial`
  * as it is read, so accumulate-into partial buffers need no memset */
 DL_API int dl_reduce_rows_f32(float* partial, float* out, int64_t G, int64_t n, int clear_partial, dl_stream_t stream);
@@ -529,6 +537,18 @@ DL_API int dl_conv3x3_wgrad_tn(const void* x, int64_t ldx, int64_t B, int64_t H,
                                int max_workgroups, dl_stream_t stream);
 /* weight gradient from dl_gemm_tn(cols, dY) lands transposed as g f32 [(tap, ci), ldg >= Co]: dw[Co, Ci, 3, 3] += g^T */
 DL_API int dl_conv3x3_wgrad_fold(const float* g, int64_t ldg, float* dw, int64_t Co, int64_t Ci, dl_stream_t stream);
+/* The same fold for every convolution of a network in ONE launch (end of the backward): `desc_dev` = device array of n_desc
+ * descriptors, tile_begin = running sum of (Co/32)*(Ci/32) (Co, Ci multiples of 32); total_tiles = the sum over all entries.
+ * clear_stage != 0 zeroes each staging tile as it is read (persistent staging buffers need no memset before the next backward). */
+typedef struct dl_fold_conv_desc_t {
+  void* g;       /* f32 [9*Ci, ldg]: the staged transposed gradient, row = tap * Ci + ci */
+  int64_t ldg;
+  void* dw;      /* f32 [Co, Ci, 3, 3]: accumulated (+=) */
+  int64_t Co, Ci;
+  int64_t tile_begin;
+} dl_fold_conv_desc_t;
+DL_API int dl_conv3x3_wgrad_fold_batched(const dl_fold_conv_desc_t* desc_dev, int n_desc, int64_t total_tiles, int clear_stage,
+                                         dl_stream_t stream);
 /* out[b, yo, xo, c] = scale * sum of the 2x2 window of x [B, 2Ho, 2Wo, C]: avg_pool2d forward (scale 0.25, nn.py:86) and
  * nearest-upsample backward (scale 1) */
 DL_API int dl_reduce2x2(const void* x, void* out, int64_t B, int64_t Ho, int64_t Wo, int64_t C, float scale,
