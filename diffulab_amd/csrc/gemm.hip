@@ -1598,7 +1598,10 @@ extern "C" int dl_conv3x3_wgrad_tn(const void* x, int64_t ldx, int64_t Bn, int64
     const int n_cu = dev_cus(once, [] {
       (void)hipFuncSetAttribute((const void*)gemm_tn_big_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE);
     });
-    if (M % WBM == 0 && N % WBN == 0 && nsteps >= 64) {  // same unit / split budget as dl_gemm_tn
+#ifndef WGRAD_BIG_MIN_STEPS
+#define WGRAD_BIG_MIN_STEPS 64
+#endif
+    if (M % WBM == 0 && N % WBN == 0 && nsteps >= WGRAD_BIG_MIN_STEPS) {  // same unit / split budget as dl_gemm_tn
       const int tiles_m = (int)(M / WBM), tiles_n = (int)(N / WBN);
       const int budget = (max_workgroups > 0 && max_workgroups < n_cu) ? max_workgroups : n_cu;
       int padded_max = (budget / tiles_n) & ~7;
