@@ -125,7 +125,12 @@ class PerTokenDecoder:
                                  self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["q"], a["k"],
                                  None if ops.v_in_place(N) else a["v"], a["rrms"], B, N, Hh,
                                  64, rot)
-            if ops.v_in_place(N):  # V read in place from the qkv rows (engine.py)
+            if ops.attn_needs_padding(N):  # (multi-aspect-ratio buckets: 28 x 36, 24 x 40 ... tokens) q / k / v live in rows padded to a
+                # multiple of 256 per (sample, head); the pad keys are masked, the pad queries' outputs never copied out
+                Np = a["q"].shape[2]
+                ops.attn_fwd_ex(a["q"], a["k"], a["v"], a["ao"], a["lse"], B, Hh, Np, Np, 64, 64**-0.5, w["kb_d"])
+                ops.copy_rows3d(a["ao"], Np * D, D, a["a"], N * D, D, B, N, D)
+            elif ops.v_in_place(N):  # V read in place from the qkv rows (engine.py)
                 ops.attn_fwd_qkv(a["q"], a["k"], a["qkv"], a["a"], a["lse"], B, Hh, N, 64, 64**-0.5)
             else:
                 ops.attn_fwd(a["q"], a["k"], a["v"], a["a"], a["lse"], B, Hh, N, 64, 64**-0.5)
@@ -196,7 +201,12 @@ class PerTokenDecoder:
                                                     self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], g["dqkv"],
                                                     self.G(pre + "attention.qk_norm.query_norm.scale"), w["qk_part"], B, N, Hh, 64, rot))
             else:
-                if ops.v_in_place(N):
+                if ops.attn_needs_padding(N):
+                    Np = a["q"].shape[2]
+                    ops.copy_rows3d(s["da"], N * D, D, w["dao_d"], Np * D, D, B, N, D)  # (the pad rows of dao_d stay zero)
+                    ops.attn_bwd_ex(a["q"], a["k"], a["v"], a["ao"], w["dao_d"], a["lse"], s["dq"], s["dk"], s["dv"], B, Hh, Np, Np, 64,
+                                    64**-0.5, w["kb_d"])
+                elif ops.v_in_place(N):
                     ops.attn_bwd_qkv(a["q"], a["k"], a["qkv"], a["a"], s["da"], a["lse"], s["dq"], s["dk"], g["dqkv"], B, Hh, N, 64,
                                      64**-0.5)
                 else:
@@ -541,9 +551,11 @@ class DDTJointEngine(SprintJointEngine, PerTokenDecoder):
         N = gh * gw
         Tf = Lc + N
         Tpf = _rup(Tf, 256)
-        if Tpf > 2048 or N % 64 or (N > 256 and N % 256) or Lc < 1:
-            raise NotImplementedError(f"joint DDT HIP path: context + image tokens <= 2048 (got {Lc} + {N}), image tokens a multiple of "
-                                      "64 up to 256 or of 256 beyond, batch * context tokens a multiple of 64")
+        if Tpf > 2048 or (B * N) % 64 or Lc < 1:
+            raise NotImplementedError(f"joint DDT HIP path: context + image tokens <= 2048 (got {Lc} + {N}), batch * image tokens a "
+                                      f"multiple of 64 (got {B} * {N})")
+        pad = ops.attn_needs_padding(N)  # decoder attention on rows padded to a multiple of 256 with masked pad keys (_decoder_fwd)
+        Nd = _rup(N, 256) if pad else N
         M, Bp, Fo, F = B * N, _rup(B, 64), p * p * d.output_channels, d.mlp_ratio * D
         bf, f32 = torch.bfloat16, torch.float32
         Hh, R = d.num_heads, self.layout.tmod_rows
@@ -579,13 +591,18 @@ class DDTJointEngine(SprintJointEngine, PerTokenDecoder):
                     per[st] = a
             else:
                 per = {"x0": z(M, D), "mean1": z(M, dtype=f32), "rstd1": z(M, dtype=f32), "xm1": z(M, D), "qkv": z(M, 3 * D),
-                       "q": z(B, Hh, N, 64), "k": z(B, Hh, N, 64), "v": z(B, Hh, N, 64), "rrms": z(M, 2, dtype=f32), "a": z(M, D),
-                       "lse": z(B, Hh, N, dtype=f32), "t1": z(M, D), "x1": z(M, D), "mean2": z(M, dtype=f32), "rstd2": z(M, dtype=f32),
+                       "q": z(B, Hh, Nd, 64), "k": z(B, Hh, Nd, 64), "v": z(B, Hh, Nd, 64), "rrms": z(M, 2, dtype=f32), "a": z(M, D),
+                       "lse": z(B, Hh, Nd, dtype=f32), "t1": z(M, D), "x1": z(M, D), "mean2": z(M, dtype=f32), "rstd2": z(M, dtype=f32),
                        "xm2": z(M, D), "u": ops.mlp_u_buffer(z, M, D, F, train), "h": z(M, F), "t2": z(M, D)}
+                if pad:
+                    per["ao"] = z(B * Nd, D)
                 if train:
                     per["wg"] = {"dt2": z(M, D), "du": z(M, 2 * F), "dt1": z(M, D), "dqkv": z(M, 3 * D)}
                     per["dwbp"] = z(2, N_PART, 2, D, dtype=f32)
             blk.append(per)
+        if pad:
+            w["kb_d"] = z(B, Nd, dtype=f32)
+            w["kb_d"][:, N:] = float("-inf")
         w["blk"] = blk
         w["xdec_in"], w["enc_out"], w["sz"] = z(M, D), z(M, D), z(M, D)
         w["tmod"] = z(M, R)
@@ -596,7 +613,9 @@ class DDTJointEngine(SprintJointEngine, PerTokenDecoder):
         if train:
             w["dO"] = z(M, self._ko)
             w[f"s_x{N}"] = {"dxa": z(M, D), "dxb": z(M, D), "dxm": z(M, D), "dxm2": z(M, D), "da": z(M, D), "dh": z(M, F),
-                            "dq": z(B, Hh, N, 64), "dk": z(B, Hh, N, 64), "dv": z(B, Hh, N, 64)}
+                            "dq": z(B, Hh, Nd, 64), "dk": z(B, Hh, Nd, 64), "dv": z(B, Hh, Nd, 64)}
+            if pad:
+                w["dao_d"] = z(B * Nd, D)
             w["s_c"] = {"dxa": zr(B * Lc, D), "dxb": zr(B * Lc, D), "dxm": zr(B * Lc, D), "da": zr(B * Lc, D), "dh": zr(B * Lc, F)}
             w["dao_f"] = z(B * Tpf, D)
             w["dq_f"], w["dk_f"], w["dv_f"] = (z(B, Hh, Tpf, 64) for _ in range(3))
@@ -614,7 +633,7 @@ class DDTJointEngine(SprintJointEngine, PerTokenDecoder):
             w["det_scr"] = torch.empty(max(2 * self.layout.mod_rows * d.embedding_dim, 1 << 22), device=self.dev, dtype=f32)
             if ops.WgradGroups.widths_ok(D, F) and tuning.on("DL_WGRAD_GROUP"):  # grouped weight gradients (ops.WgradGroups)
                 w["tn_slab"] = torch.empty(ops.WgradGroups.slab_floats(D, F), device=self.dev, dtype=f32)
-            if D <= 512 and tuning.on("DL_QK_INPLACE"):  # scale-gradient partials of the in-place QK-norm backward (ops.qk_inplace_ok)
+            if D <= 512 and tuning.on("DL_QK_INPLACE") and not pad:  # scale-gradient partials of the in-place QK-norm backward (ops.qk_inplace_ok)
                 w["qk_part"] = torch.empty(1024 * 2 * D, device=self.dev, dtype=f32)
         self.ws, self._ws_key = w, key
         self.geo = (B, H, W, gh, gw, N, M, Bp, Fo)

@@ -293,9 +293,17 @@ class DiTEngine:
         gh, gw = H // p, W // p
         N = gh * gw
         M = B * N
-        if N % 64 or (N > 256 and (N % 256 or N > 2048)):
-            raise NotImplementedError(f"token grid {gh}x{gw}: the bf16 regime's attention needs N % 64 == 0 up to 256 tokens, or N % 256 == 0 "
-                                      f"up to 2048 (got {N}); the fp32 regime (precision_type=\"no\" / set_precision(\"fp32\")) takes any grid")
+        # token grids the attention kernels do not take as they are (not a multiple of 64 up to 256 / of 256 beyond: non-square and
+        # multi-aspect-ratio latents): q / k / v rows padded to a multiple of 256 per (sample, head), pad keys masked (dl_attn_*_ex)
+        pad = ops.attn_needs_padding(N)
+        Nd = _rup(N, 256) if pad else N
+        if pad and type(self) is DiTEngine and Nd <= 2048 and M % 64:
+            raise NotImplementedError(f"token grid {gh}x{gw} ({N} tokens) in the bf16 regime: batch * tokens must be a multiple of 64 (got "
+                                      f"{B} * {N}); the fp32 regime (precision_type=\"no\" / set_precision(\"fp32\")) takes any grid and batch")
+        if Nd > 2048 or (pad and type(self) is not DiTEngine):
+            raise NotImplementedError(f"token grid {gh}x{gw}: the bf16 regime's attention takes up to 2048 tokens"
+                                      + ("" if type(self) is DiTEngine else ", N % 64 == 0 up to 256 or N % 256 == 0 beyond, in this engine")
+                                      + f" (got {N}); the fp32 regime (precision_type=\"no\" / set_precision(\"fp32\")) takes any grid")
         Bp = _rup(B, 64)
         Fo = p * p * d.output_channels
         bf, f32 = torch.bfloat16, torch.float32
@@ -324,15 +332,19 @@ class DiTEngine:
         for _ in range(nl):
             per.append({
                 "mean1": z(M, dtype=f32), "rstd1": z(M, dtype=f32), "xm1": z(M, D), "qkv": z(M, 3 * D),
-                "q": z(B, d.num_heads, N, 64), "k": z(B, d.num_heads, N, 64),
-                "v": None if ops.v_in_place(N) else z(B, d.num_heads, N, 64),  # (N <= 256: V is read in place from qkv)
-                "rrms": z(M, 2, dtype=f32), "a": z(M, D), "lse": z(B, d.num_heads, N, dtype=f32), "t1": z(M, D),
+                "q": z(B, d.num_heads, Nd, 64), "k": z(B, d.num_heads, Nd, 64),
+                "v": None if ops.v_in_place(N) else z(B, d.num_heads, Nd, 64),  # (N <= 256: V is read in place from qkv)
+                "ao": z(B * Nd, D) if pad else None,
+                "rrms": z(M, 2, dtype=f32), "a": z(M, D), "lse": z(B, d.num_heads, Nd, dtype=f32), "t1": z(M, D),
                 "x1": z(M, D), "mean2": z(M, dtype=f32), "rstd2": z(M, dtype=f32), "xm2": z(M, D),
                 "u": None if rc_u else z(M, 2 * d.mlp_ratio * D), "h": z(M, d.mlp_ratio * D), "t2": z(M, D),
             })
         w["layers"] = per
         # QK-norm on load (dl_gemm_nt_ssq + dl_attn_fwd_qkn): per-block sums of squares of the q / k rows, zeroed once per forward (one
         # buffer per block also in inference: the GEMM epilogues ADD into it)
+        if pad:
+            w["kb"] = z(B, Nd, dtype=f32)
+            w["kb"][:, N:] = float("-inf")
         if self._qkn_on_load(M, N):
             w["ssq_all"] = z(L, M, 2, dtype=f32)
         w["meanf"], w["rstdf"] = z(M, dtype=f32), z(M, dtype=f32)
@@ -357,8 +369,10 @@ class DiTEngine:
                     w["qkn_cpart"] = torch.empty(B * d.num_heads * 2 * N, device=dev, dtype=f32)
                     w["qkn_sync"] = torch.zeros(2 * B + 1, device=dev, dtype=torch.int32)  # (zeroed once: the kernel resets it)
             else:
-                w["dq"], w["dk"] = z(B, d.num_heads, N, 64), z(B, d.num_heads, N, 64)
-            w["dv"] = None if ops.v_in_place(N) else z(B, d.num_heads, N, 64)
+                w["dq"], w["dk"] = z(B, d.num_heads, Nd, 64), z(B, d.num_heads, Nd, 64)
+            w["dv"] = None if ops.v_in_place(N) else z(B, d.num_heads, Nd, 64)
+            if pad:
+                w["dao"] = z(B * Nd, D)
             w["dmod"] = z(Bp, self.layout.mod_rows)                  # bf16 operand of the modulation GEMMs' backward
             w["dmod32"] = z(Bp, self.layout.mod_rows, dtype=f32)     # f32 accumulator the block kernels add into
             w["dwb"] = z(2 * L, B, 2, D, dtype=f32)  # per-norm partials: folded on the side stream, cleared while read
@@ -427,7 +441,7 @@ class DiTEngine:
     def _native_blocks(self) -> bool:
         """one C call per block and direction (dl_dit_block_fwd / _bwd) instead of ~25 launches from Python; DL_NATIVE_BLOCK=0 is the
         A/B switch back to the Python-issued sequence (identical kernels, identical order)"""
-        return type(self) is DiTEngine and tuning.on("DL_NATIVE_BLOCK")
+        return type(self) is DiTEngine and tuning.on("DL_NATIVE_BLOCK") and not (self.geo is not None and ops.attn_needs_padding(self.geo[5]))
 
     def _block_args(self, i: int, train: bool):
         """the dl_dit_block_t of block i on the current workspace (cached: every pointer is fixed once arena and workspace exist)"""
@@ -577,7 +591,11 @@ class DiTEngine:
             ops.qk_norm_rope_fwd(a["qkv"], self.P(pre + "attention.qk_norm.query_norm.scale"),
                                  self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["q"], a["k"],
                                  None if v_in_place else a["v"], a["rrms"], B, N, Hh, 64, rot)
-            if v_in_place:
+            if a.get("ao") is not None:  # padded rows, masked pad keys (_alloc)
+                Np = a["q"].shape[2]
+                ops.attn_fwd_ex(a["q"], a["k"], a["v"], a["ao"], a["lse"], B, Hh, Np, Np, 64, 64**-0.5, w["kb"])
+                ops.copy_rows3d(a["ao"], Np * D, D, a["a"], N * D, D, B, N, D)
+            elif v_in_place:
                 ops.attn_fwd_qkv(a["q"], a["k"], a["qkv"], a["a"], a["lse"], B, Hh, N, 64, 64**-0.5)
             else:
                 ops.attn_fwd(a["q"], a["k"], a["v"], a["a"], a["lse"], B, Hh, N, 64, 64**-0.5)
@@ -851,7 +869,12 @@ class DiTEngine:
                                                     self.P(pre + "attention.qk_norm.key_norm.scale"), cos, sin, a["rrms"], g["dqkv"],
                                                     self.G(pre + "attention.qk_norm.query_norm.scale"), w["qk_part"], B, N, Hh, 64, rot))
             else:
-                if v_in_place:  # dV goes straight into the v third of dqkv
+                if a.get("ao") is not None:
+                    Np = a["q"].shape[2]
+                    ops.copy_rows3d(w["da"], N * D, D, w["dao"], Np * D, D, B, N, D)  # (the pad rows of dao stay zero)
+                    ops.attn_bwd_ex(a["q"], a["k"], a["v"], a["ao"], w["dao"], a["lse"], w["dq"], w["dk"], w["dv"], B, Hh, Np, Np, 64,
+                                    64**-0.5, w["kb"])
+                elif v_in_place:  # dV goes straight into the v third of dqkv
                     ops.attn_bwd_qkv(a["q"], a["k"], a["qkv"], a["a"], w["da"], a["lse"], w["dq"], w["dk"], g["dqkv"], B, Hh, N, 64,
                                      64**-0.5)
                 else:

@@ -471,10 +471,16 @@ def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, H, N, dh, scale):
           float(scale), _s())
 
 
+def attn_needs_padding(N: int) -> bool:
+    """token counts the resident / tiled attention kernels do not take as they are (multiples of 64 up to 256, of 256 up to 2048):
+    the caller pads q / k / v to a multiple of 256 rows and masks the pad keys (dl_attn_fwd_ex / _bwd_ex with a key bias)"""
+    return N % 64 != 0 or (N > 256 and N % 256 != 0)
+
+
 def v_in_place(N: int) -> bool:
     """up to 256 tokens the attention kernels address V / dV inside the token-major qkv / dqkv rows (no head-split copy of V);
     DL_ATTN_V_IN_PLACE=0 restores the head-major V buffers (A/B switch)"""
-    return N <= 256 and tuning.on("DL_ATTN_V_IN_PLACE")
+    return N <= 256 and N % 64 == 0 and tuning.on("DL_ATTN_V_IN_PLACE")
 
 
 def dit_block_fwd(blk, train: bool) -> None:

@@ -78,7 +78,7 @@ def run_unet(i, rng):
             (pred * dy.to(DEV)).sum().backward()
             torch.cuda.synchronize()
         except NotImplementedError as e:
-            res.append(f"{prec}: refused ({str(e)[:90]})")
+            res.append(f"{prec}: refused ({str(e)[:160]})")
             continue
         gmax = max(v.grad.norm().item() for v in Pr.values() if v.grad is not None)
         live = [(n, p) for n, p in m.named_parameters() if Pr[n].grad is not None and Pr[n].grad.norm().item() > 1e-5 * gmax]
@@ -86,7 +86,7 @@ def run_unet(i, rng):
     return tag, " | ".join(res)
 
 
-def run_tokens(i, rng, family="dit"):
+def run_tokens(i, rng, family="dit", grid=None, batch=None):
     """class-conditional token models: MMDiT(simple_dit), DDT(simple_ddt), SprintDiT(simple_dit)"""
     from oracle import ddt as oddt
     from oracle import sprint as osprint
@@ -103,6 +103,8 @@ def run_tokens(i, rng, family="dit"):
     if kw["n_classes"] is None:
         kw["classifier_free"] = False
     B = rng.choice([1, 2, 3, 5])
+    if grid is not None:
+        (gh, gw), B = grid, batch
     x = synth.normal(f"fd.x{i}", (B, C, gh * patch, gw * patch))
     t = synth.uniform(f"fd.t{i}", (B,), lo=0.05, hi=0.95)
     y = synth.integers(f"fd.y{i}", (B,), 10) if kw["n_classes"] else None
@@ -148,14 +150,14 @@ def run_tokens(i, rng, family="dit"):
             (pred * dy.to(DEV)).sum().backward()
             torch.cuda.synchronize()
         except NotImplementedError as e:
-            res.append(f"{prec}: refused ({str(e)[:90]})")
+            res.append(f"{prec}: refused ({str(e)[:160]})")
             continue
         live = [(n, p) for n, p in m.named_parameters() if Pr[n].grad is not None]
         res.append(_verdict(prec, rel(pred, ref), live, Pr, loose=family == "ddt"))
     return tag, " | ".join(res)
 
 
-def run_joint(i, rng, family="mmdit_joint"):
+def run_joint(i, rng, family="mmdit_joint", grid=None, batch=None):
     """text-image forms behind a precomputed-embedding context embedder (bf16 regime only: their reference configurations pin it):
     MMDiT(simple_dit=False) with 0-2 single-stream blocks, SprintDiT(simple_dit=False), DDT(simple_ddt=False); random context
     lengths (multiples of 64 or not), ragged masks, head counts, grids"""
@@ -174,6 +176,8 @@ def run_joint(i, rng, family="mmdit_joint"):
     Lc = rng.choice([64, 128, 77, 33, 96, 5])
     Dc = rng.choice([32, 96, 160])
     B = rng.choice([1, 2, 3, 4])
+    if grid is not None:
+        (gh, gw), B, patch = grid, batch, 1
     kw = dict(input_channels=C, output_channels=C, inner_dim=D, num_heads=H_, mlp_ratio=rng.choice([2, 4]), patch_size=patch,
               classifier_free=True, rope_axes_dim=[16, 24, 24], rope_base=rng.choice([1000, 2000, 10000]))
     x = synth.normal(f"fj.x{i}", (B, C, gh * patch, gw * patch))
@@ -230,6 +234,40 @@ def run_joint(i, rng, family="mmdit_joint"):
         if Pr[n].grad is None:
             assert float(p.grad.abs().max()) == 0.0, (tag, n)
     return tag, _verdict("bf16", rel(pred, ref), live, Pr, loose=family == "ddt_joint")
+
+
+@pytest.mark.timeout(900)
+def test_class_conditional_dit_on_arbitrary_token_grids():
+    """MMDiT(simple_dit=True) in the bf16 regime on token grids that are not a multiple of 64 (or of 256 above 256): q / k / v rows
+    padded to a multiple of 256 per (sample, head), pad keys masked (engine.py `_alloc`: from round 5; it used to refuse and name the
+    fp32 regime).  batch * tokens must still be a multiple of 64 (the weight-gradient GEMMs' contraction): a refusal that says so."""
+    rng = random.Random("dit-grids")
+    bad = []
+    for i, (grid, batch) in enumerate((((12, 12), 4), ((28, 36), 4), ((6, 10), 16), ((10, 10), 16), ((20, 24), 2), ((24, 40), 2))):
+        tag, out = run_tokens(300 + i, rng, "dit", grid=grid, batch=batch)
+        print(tag, "\n    ->", out, flush=True)
+        if out.count("pred ") != 2 or "BAD" in out:
+            bad.append((tag, out))
+    assert not bad, bad
+    tag, out = run_tokens(310, rng, "dit", grid=(10, 10), batch=3)
+    assert "bf16: refused" in out and "multiple of 64" in out and "fp32: pred" in out, out
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("family", ["mmdit_joint", "sprint_joint", "ddt_joint"])
+def test_joint_forms_on_multi_aspect_ratio_bucket_grids(family):
+    """`ImageNetmultiAR` (datasets/imagenet.py:89-175) batches one aspect-ratio bucket at a time: latent grids like 28 x 36 = 1008 or
+    24 x 40 = 960 image tokens, neither a multiple of 256.  The joint attention runs on rows padded to a multiple of 256 with masked
+    pad keys; the DDT decoder (image tokens only) does the same from round 5 on.  Prediction and every gradient against the oracle;
+    the engines ask for batch * tokens % 64 == 0, which every even batch of these grids satisfies."""
+    rng = random.Random(f"multiar-{family}")
+    bad = []
+    for i, (grid, batch) in enumerate((((28, 36), 4), ((24, 40), 2), ((12, 12), 4), ((20, 48), 2))):
+        tag, out = run_joint(100 + i, rng, family, grid=grid, batch=batch)
+        print(tag, "\n    ->", out, flush=True)
+        if "pred " not in out or "BAD" in out:
+            bad.append((tag, out))
+    assert not bad, bad
 
 
 @pytest.mark.timeout(1200)
