@@ -1091,6 +1091,66 @@ extern "C" int dl_expand2x2(const void* x, void* out, int64_t B, int64_t Hi, int
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
+// 16 bytes (8 channels) per lane; blockIdx.y picks one of up to two (x, out) pairs of the same geometry (a resampling ResBlock moves
+// its h and its x through the same 2 x 2 window: one launch instead of two)
+struct Resample2 {
+  const bf16_t* x[2];
+  bf16_t* o[2];
+};
+template <bool EXPAND>
+__global__ void resample2x2_vec_k(Resample2 a, int B, int Hs, int Ws, int C8, float scale) {
+  // Hs x Ws = the SMALL map (reduce: output; expand: input); the large map is 2Hs x 2Ws
+  const bf16_t* x = a.x[blockIdx.y];
+  bf16_t* o = a.o[blockIdx.y];
+  const int64_t n = (int64_t)B * Hs * Ws * C8 * (EXPAND ? 4 : 1);
+  const int W = 2 * Ws, H = 2 * Hs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8);
+    const int64_t r = i / C8;
+    if (EXPAND) {
+      const int xx = (int)(r % W), yy = (int)((r / W) % H), b = (int)(r / ((int64_t)W * H));
+      float v[8];
+      unpack8(*(const u32x4_t*)(x + ((((int64_t)b * Hs + yy / 2) * Ws + xx / 2) * C8 + c) * 8), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= scale;
+      *(u32x4_t*)(o + i * 8) = pack8(v);
+    } else {
+      const int xo = (int)(r % Ws), yo = (int)((r / Ws) % Hs), b = (int)(r / ((int64_t)Ws * Hs));
+      const int64_t base = ((((int64_t)b * H + 2 * yo) * W + 2 * xo) * C8 + c) * 8;
+      float p0[8], p1[8], p2[8], p3[8];
+      unpack8(*(const u32x4_t*)(x + base), p0);
+      unpack8(*(const u32x4_t*)(x + base + (int64_t)C8 * 8), p1);
+      unpack8(*(const u32x4_t*)(x + base + (int64_t)W * C8 * 8), p2);
+      unpack8(*(const u32x4_t*)(x + base + (int64_t)(W + 1) * C8 * 8), p3);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) p0[e] = scale * (p0[e] + p1[e] + p2[e] + p3[e]);
+      *(u32x4_t*)(o + i * 8) = pack8(p0);
+    }
+  }
+}
+/* dl_reduce2x2 / dl_expand2x2 on two tensors of the same geometry in one launch (x1 / out1 may be NULL: one tensor) */
+extern "C" int dl_resample2x2_pair(const void* x0, void* out0, const void* x1, void* out1, int64_t B, int64_t Hs, int64_t Ws, int64_t C,
+                                   float scale, int expand, dl_stream_t stream) {
+  DL_CHECK_ARG(x0 && out0 && (x1 == nullptr) == (out1 == nullptr) && B > 0 && Hs > 0 && Ws > 0 && C > 0, "dl_resample2x2_pair: bad args");
+  const bool vec = C % 8 == 0 && (((uintptr_t)x0 | (uintptr_t)out0 | (uintptr_t)x1 | (uintptr_t)out1) & 15) == 0;
+  if (!vec) {
+    for (int k = 0; k < (x1 ? 2 : 1); ++k) {
+      const int rc = expand ? dl_expand2x2(k ? x1 : x0, k ? out1 : out0, B, Hs, Ws, C, scale, stream)
+                            : dl_reduce2x2(k ? x1 : x0, k ? out1 : out0, B, Hs, Ws, C, scale, stream);
+      if (rc != DL_OK) return rc;
+    }
+    return DL_OK;
+  }
+  const Resample2 a{{(const bf16_t*)x0, (const bf16_t*)x1}, {(bf16_t*)out0, (bf16_t*)out1}};
+  const int64_t n = B * Hs * Ws * (C / 8) * (expand ? 4 : 1);
+  dim3 grid((unsigned)grid_for(n), x1 ? 2u : 1u);
+  if (expand)
+    hipLaunchKernelGGL(resample2x2_vec_k<true>, grid, 256, 0, (hipStream_t)stream, a, (int)B, (int)Hs, (int)Ws, (int)(C / 8), scale);
+  else
+    hipLaunchKernelGGL(resample2x2_vec_k<false>, grid, 256, 0, (hipStream_t)stream, a, (int)B, (int)Hs, (int)Ws, (int)(C / 8), scale);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
 
 // ---------------------------------------------------------------- stride-2 pick / zero-stuff (Downsample's 3x3 stride-2 conv, nn.py:79)
 // A stride-2 pad-1 3x3 convolution is the stride-1 one sampled at the even positions: forward = conv3x3 at full resolution + pick,

@@ -866,6 +866,11 @@ def expand2x2(x, out, B, Hi, Wi, C, scale):
     _call("dl_expand2x2", _p(x), _p(out), B, Hi, Wi, C, float(scale), _s())
 
 
+def resample2x2_pair(x0, out0, x1, out1, B, Hs, Ws, C, scale, expand: bool):
+    """reduce2x2 / expand2x2 of two tensors of the same geometry (Hs x Ws = the small map) in one launch"""
+    _call("dl_resample2x2_pair", _p(x0), _p(out0), _p(x1), _p(out1), B, Hs, Ws, C, float(scale), int(expand), _s())
+
+
 def pick2x2(x, out, B, Ho, Wo, C):
     _call("dl_pick2x2", _p(x), _p(out), B, Ho, Wo, C, _s())
 

@@ -374,7 +374,8 @@ class UNetEngine:
 
     def _side_stream(self) -> "torch.cuda.Stream":
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.dev)
+            mask = tuning.text("DL_SIDE_CU_MASK")  # (experiments: "b192" = the first 192 CUs, "i2" = every other CU)
+            self._side = ops.masked_stream(mask, self.dev) if mask else torch.cuda.Stream(device=self.dev)
         return self._side
 
     @property
@@ -541,11 +542,9 @@ class UNetEngine:
             H2, W2 = (2 * H, 2 * W) if b.up else (H // 2, W // 2)
             hp, x2 = self._new(B * H2 * W2, b.cin), self._new(B * H2 * W2, b.cin)
             if b.up:
-                self.o.expand2x2(h, hp, B, H, W, b.cin, 1.0)
-                self.o.expand2x2(x, x2, B, H, W, b.cin, 1.0)
+                self.o.resample2x2_pair(h, hp, x, x2, B, H, W, b.cin, 1.0, True)
             else:
-                self.o.reduce2x2(h, hp, B, H2, W2, b.cin, 0.25)
-                self.o.reduce2x2(x, x2, B, H2, W2, b.cin, 0.25)
+                self.o.resample2x2_pair(h, hp, x, x2, B, H2, W2, b.cin, 0.25, False)
             h = hp
         h2 = self._conv3(h, B, H2, W2, b.cin, p + "in_layers.2.weight", b.cout)
         if self.d.use_scale_shift_norm:
@@ -578,11 +577,9 @@ class UNetEngine:
         if b.up or b.down:
             dhp, dxs = self._new(B * H * W, b.cin), self._new(B * H * W, b.cin)
             if b.up:  # backward of nearest upsample: sum of the 2x2 window
-                self.o.reduce2x2(dh, dhp, B, H, W, b.cin, 1.0)
-                self.o.reduce2x2(dx2, dxs, B, H, W, b.cin, 1.0)
+                self.o.resample2x2_pair(dh, dhp, dx2, dxs, B, H, W, b.cin, 1.0, False)
             else:  # backward of avg-pool: broadcast / 4
-                self.o.expand2x2(dh, dhp, B, H2, W2, b.cin, 0.25)
-                self.o.expand2x2(dx2, dxs, B, H2, W2, b.cin, 0.25)
+                self.o.resample2x2_pair(dh, dhp, dx2, dxs, B, H2, W2, b.cin, 0.25, True)
             dh, dx2 = dhp, dxs
         return self._gn_bwd(dh, x, st1, B, H * W, b.cin, p + "in_layers.0.", dres=dx2)
 

@@ -37,6 +37,11 @@ class _F32Ops:
         ops.f32_resample2x2(x, out, B, Ho, Wo, C, scale, 0)
 
     @staticmethod
+    def resample2x2_pair(x0, out0, x1, out1, B, Hs, Ws, C, scale, expand):
+        ops.f32_resample2x2(x0, out0, B, Hs, Ws, C, scale, 1 if expand else 0)
+        ops.f32_resample2x2(x1, out1, B, Hs, Ws, C, scale, 1 if expand else 0)
+
+    @staticmethod
     def pick2x2(x, out, B, Ho, Wo, C):
         ops.f32_resample2x2(x, out, B, Ho, Wo, C, 1.0, 2)
 

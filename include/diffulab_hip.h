@@ -557,6 +557,10 @@ DL_API int dl_reduce2x2(const void* x, void* out, int64_t B, int64_t Ho, int64_t
  * avg_pool2d backward (scale 0.25) */
 DL_API int dl_expand2x2(const void* x, void* out, int64_t B, int64_t Hi, int64_t Wi, int64_t C, float scale,
                         dl_stream_t stream);
+/* dl_reduce2x2 (expand = 0) / dl_expand2x2 (expand != 0) over TWO tensors of the same geometry in one launch (x1 / out1 NULL: one);
+ * Hs x Ws = the small map.  16 bytes per lane when C % 8 == 0. */
+DL_API int dl_resample2x2_pair(const void* x0, void* out0, const void* x1, void* out1, int64_t B, int64_t Hs, int64_t Ws, int64_t C,
+                               float scale, int expand, dl_stream_t stream);
 /* out[b, yo, xo, c] = x[b, 2yo, 2xo, c] for x [B, 2Ho, 2Wo, C], C % 8 == 0: with dl_conv3x3_nt at full resolution in front this
  * is Downsample's 3x3 stride-2 pad-1 convolution (nn.py:79) */
 DL_API int dl_pick2x2(const void* x, void* out, int64_t B, int64_t Ho, int64_t Wo, int64_t C, dl_stream_t stream);
