@@ -788,6 +788,11 @@ class UNetEngine:
         s, d, plan = self._saved, self.d, self.plan
         assert s is not None, "backward without a train-mode forward"
         self._saved = None
+        if self.__dict__.get("_stage_pending") or self.__dict__.get("_colsum_pending"):
+            # a backward that raised half-way left staged gradients behind: drop the references, zero the stage
+            self._stage_pending, self._colsum_pending = [], []
+            for g in self.__dict__.get("_stage", {}).values():
+                g.zero_()
         B, H, W, save, eo = s["B"], s["H"], s["W"], s["save"], s["eo"]
         mc, te = d.model_channels, 4 * d.model_channels
         Bp = _rup(B, 64)
