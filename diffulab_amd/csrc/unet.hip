@@ -56,18 +56,18 @@ static int g_gn_fused = 1;  // 3 (tests): as 1, also where a launch would not fi
 extern "C" __attribute__((visibility("default"))) void dl_lab_set_gn_fused(int mode) { g_gn_fused = mode; }  // LAB A/B switch (not in the header)
 static int gn_bwd_fused() { return g_gn_fused; }  // (the three-launch form stays for the shapes the fused kernel does not take)
 
-// statistics: one workgroup per sample; thread (pixel lane, chunk) accumulates sum / sum of squares of its 8 channels over
-// its pixels, LDS float atomics fold them per group
+// statistics: one workgroup per sample; thread (pixel lane, chunk) accumulates sum / sum of squares of its 8 channels over its pixels
+// and leaves them in an LDS row of its own; thread g then adds group g's channels over the pixel lanes in a fixed order -- no atomics:
+// the statistics (and with them the inference forward) are bit-reproducible.  C <= 2048 (256 chunks); wider rows: LDS float atomics.
 __global__ __launch_bounds__(256) void gn_stats_k(const bf16_t* __restrict__ x, float* __restrict__ st, int HW, int C, int G,
                                                   float eps) {
+  __shared__ float part[2][2048];  // [sum | sum of squares][pixel lane * C + channel]  (npl * C <= 2048)
   __shared__ float rs[GN_MAXG][2];
   const int b = blockIdx.x, cg = C / G, C8 = C >> 3;
-  const int npl = 256 / C8 > 0 ? 256 / C8 : 1;
-  if (threadIdx.x < 2 * GN_MAXG) (&rs[0][0])[threadIdx.x] = 0.f;
-  __syncthreads();
-  for (int ch0 = 0; ch0 < C8; ch0 += 256) {  // C8 > 256 only for C > 2048
-    const int chunk = ch0 + (int)threadIdx.x % (C8 < 256 ? C8 : 256), pl = threadIdx.x / (C8 < 256 ? C8 : 256);
-    if (chunk < C8 && pl < npl) {
+  if (C8 <= 256) {
+    const int npl = 256 / C8;
+    const int chunk = (int)threadIdx.x % C8, pl = (int)threadIdx.x / C8;
+    if (pl < npl) {
       float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int p = pl; p < HW; p += npl) {
         float v[8];
@@ -78,21 +78,46 @@ __global__ __launch_bounds__(256) void gn_stats_k(const bf16_t* __restrict__ x, 
           q[e] += v[e] * v[e];
         }
       }
-      if (cg % 8 == 0) {  // the chunk lies inside one group (NOT for cg = 12, 20, ...: C = 384 straddles two groups per chunk)
-        float S = 0.f, Q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        part[0][pl * C + chunk * 8 + e] = s[e];
+        part[1][pl * C + chunk * 8 + e] = q[e];
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < G) {
+      float S = 0.f, Q = 0.f;
+      for (int r = 0; r < npl; ++r)
+        for (int j = 0; j < cg; ++j) {
+          S += part[0][r * C + threadIdx.x * cg + j];
+          Q += part[1][r * C + threadIdx.x * cg + j];
+        }
+      const float n = (float)HW * cg;
+      const float mu = S / n;
+      st[((int64_t)b * G + threadIdx.x) * 2] = mu;
+      st[((int64_t)b * G + threadIdx.x) * 2 + 1] = rsqrtf(fmaxf(Q / n - mu * mu, 0.f) + eps);
+    }
+    return;
+  }
+  if (threadIdx.x < 2 * GN_MAXG) (&rs[0][0])[threadIdx.x] = 0.f;
+  __syncthreads();
+  for (int ch0 = 0; ch0 < C8; ch0 += 256) {
+    const int chunk = ch0 + (int)threadIdx.x;
+    if (chunk < C8) {
+      float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int p = 0; p < HW; ++p) {
+        float v[8];
+        unpack8(*(const u32x4_t*)(x + ((int64_t)b * HW + p) * C + chunk * 8), v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          S += s[e];
-          Q += q[e];
+          s[e] += v[e];
+          q[e] += v[e] * v[e];
         }
-        atomicAdd(&rs[chunk * 8 / cg][0], S);
-        atomicAdd(&rs[chunk * 8 / cg][1], Q);
-      } else {
+      }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          atomicAdd(&rs[(chunk * 8 + e) / cg][0], s[e]);
-          atomicAdd(&rs[(chunk * 8 + e) / cg][1], q[e]);
-        }
+      for (int e = 0; e < 8; ++e) {  // (a chunk of 8 channels may straddle two groups: booked per element)
+        atomicAdd(&rs[(chunk * 8 + e) / cg][0], s[e]);
+        atomicAdd(&rs[(chunk * 8 + e) / cg][1], q[e]);
       }
     }
   }
