@@ -271,8 +271,8 @@ def test_joint_forms_on_multi_aspect_ratio_bucket_grids(family):
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("family,seed,n", [("unet", 1, 12), ("unet", 7, 12), ("dit", 1, 12), ("ddt", 1, 10), ("sprint", 1, 10),
-                                          ("mmdit_joint", 1, 10), ("sprint_joint", 1, 8), ("ddt_joint", 1, 8)])
+@pytest.mark.parametrize("family,seed,n", [("unet", 1, 6), ("unet", 7, 6), ("dit", 1, 8), ("ddt", 1, 6), ("sprint", 1, 6),
+                                          ("mmdit_joint", 1, 7), ("sprint_joint", 1, 6), ("ddt_joint", 1, 6)])
 def test_random_configurations_against_the_oracle(family, seed, n):
     rng = random.Random(f"{family}-{seed}")
     fn = run_unet if family == "unet" else (lambda i, r: run_joint(i, r, family)) if family.endswith("_joint") else (lambda i, r: run_tokens(i, r, family))
