@@ -454,7 +454,9 @@ extern "C" int dl_gemm_tn_group(const dl_wgrad_t* probs, int n_probs, int64_t R,
     hipLaunchKernelGGL((gemm_tn_group_k<256, 256>), splits * ntile, W4_WAVES * 64, W4_NST * W4_BK * (256 + 256) * 2, (hipStream_t)stream, g);
   int64_t fg = ((total >> 2) + 255) / 256;
   if (fg > 1024) fg = 1024;
+#ifndef W4_LAB_NO_FOLD  // LAB: what the step costs without the per-block fold launch (WRONG gradients)
   hipLaunchKernelGGL(tn_group_fold_k, (int)fg, 256, 0, (hipStream_t)stream, slab, total, splits, f);
+#endif
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
