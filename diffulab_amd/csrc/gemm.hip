@@ -1474,6 +1474,218 @@ static int launch_conv_big(const void* x, const void* Wf, int64_t ldw, void* C, 
   return DL_OK;
 }
 
+// =====================================================================================================
+// conv3x3_halo_k: conv3x3_big_k with the activation operand staged ONCE per 64-channel chunk instead of once per tap.  A 256-row
+// tile is whole image rows (W | 256: `nrow` rows of one image, or 256 / (H W) whole images), so the nine taps of a channel chunk read
+// nine SHIFTED windows of the same pixels: the tile's rows plus a one-pixel border -- the halo, (nrow + 2) x (W + 2) pixels per image
+// segment, 324-400 rows of 128 bytes instead of 9 x 256 -- are staged once (zero line outside the image) and every tap's MFMA
+// fragments are read from it at a per-lane row offset.  The k-steps run channel-chunk-major, tap-minor (the weight shadow is addressed
+// accordingly: column tap * Ci + ci0); a k-step stages only its TN x 64 weight tile plus one 1 KiB chunk per wave of the NEXT channel
+// chunk's halo, which lands in the second halo buffer while the nine taps of the current one compute: 21-37 KiB per k-step against
+// the 48-64 KiB of conv3x3_big_k -- the loop is bound by what a CU can pull out of L2 while its matrix pipe runs.
+// No k-split (the launch must have enough tiles); M % 256 == 0, 256 % W == 0, H W | 256 or 256 | H W, halo <= HALO_MAX rows.
+// =====================================================================================================
+#define HALO_MAX_CHUNKS 50  // 400 halo rows (8 x 8 images, four per tile): 72 chunk slots per channel chunk (9 taps x 8 waves)
+template <int TN_, int NST>
+__global__ __launch_bounds__(BIG_THREADS, 2) void conv3x3_halo_k(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wf, int64_t ldw,
+                                                                   void* __restrict__ C, int64_t ldc, int M, int N, NtEpilogue ep,
+                                                                   ConvGeom cg, int nrow, int nseg, int nchunks) {
+  constexpr int CHB = TN_ / 64, JN = TN_ / 64;
+  constexpr int BSTAGE = TN_ * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int HB = nchunks * 1024;  // bytes of one halo buffer
+  char* const hbuf = smem;
+  char* const bbuf = smem + 2 * HB;
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = N / TN_, nitems = (M / TBM) * tiles_n;
+  const int kc = cg.Ci / BK;  // channel chunks; 9 k-steps each
+  const int G = gridDim.x;
+  const int slot0 = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int W2 = cg.W + 2, seg_rows = (nrow + 2) * W2, HP = nseg * seg_rows;
+
+  // ---- halo geometry of this lane's DMA rows: slot t of a channel chunk is chunk c = t * 8 + wave, LDS row hr = c * 8 + lane / 8
+  int hsrc[9];  // element offset into X of slot t's source for the halo being fetched (channel offset added at issue); -1: zero line
+  auto open_halo = [&](int tm) {
+    const int64_t p0 = (int64_t)tm * TBM;  // first pixel of the tile
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int hr = (t * 8 + wave) * 8 + (lane >> 3);
+      const int q = (lane & 7) ^ ((hr >> 1) & 7);
+      int src = -1;
+      if (hr < HP) {
+        const int seg = hr / seg_rows, rem = hr - seg * seg_rows;
+        const int hy = rem / W2, hx = rem - hy * W2;
+        int64_t img0;  // first pixel of the image the segment belongs to
+        int py;
+        if (nseg > 1) {  // whole images: segment = image
+          img0 = p0 + (int64_t)seg * cg.H * cg.W;
+          py = hy - 1;
+        } else {  // nrow rows of one image
+          const int64_t hw = (int64_t)cg.H * cg.W;
+          img0 = p0 / hw * hw;
+          py = (int)((p0 - img0) / cg.W) + hy - 1;
+        }
+        const int px = hx - 1;
+        if (py >= 0 && py < cg.H && px >= 0 && px < cg.W && img0 < cg.npix) src = (int)((img0 + (int64_t)py * cg.W + px) * cg.ldx + q * 8);
+      }
+      hsrc[t] = src;
+    }
+  };
+  // ---- DMA cursor: stream step s = 9 * (halo number) + tap; stage s = weight tile of (item, cc, tap) + slot `tap` of the NEXT halo
+  int s_item = slot0, s_cc = 0, s_tap = 0, s_it = 0;  // weights
+  int h_item = slot0, h_cc = 0;                        // the halo being fetched (one channel chunk ahead of the weights)
+  const bf16_t* b_src[CHB];
+  auto open_b = [&](int item) {
+    const int tn = item % tiles_n;
+#pragma unroll
+    for (int i = 0; i < CHB; ++i) {
+      const int r = (wave * CHB + i) * 8 + (lane >> 3);
+      const int q = (lane & 7) ^ ((r >> 1) & 7);
+      b_src[i] = Wf + (int64_t)(tn * TN_ + r) * ldw + q * 8;
+    }
+  };
+  auto issue_halo_slot = [&](int t, int buf) {  // (t is a compile-time constant at every call site: hsrc stays in registers)
+    if (t * 8 + wave < nchunks) glds16(hsrc[t] >= 0 ? X + hsrc[t] + h_cc * BK : cg.zero, hbuf + buf * HB + (t * 8 + wave) * 1024);
+  };
+  auto advance_halo = [&]() {  // successor of (h_item, h_cc) in stream order
+    if (++h_cc == kc) {
+      h_cc = 0;
+      const int prev_tm = h_item / tiles_n;
+      h_item += G;
+      if (h_item < nitems && h_item / tiles_n != prev_tm) open_halo(h_item / tiles_n);
+    }
+  };
+  auto stage_next = [&]() {
+    char* base = bbuf + (s_it % NST) * BSTAGE;
+    const int64_t col = (int64_t)s_tap * cg.Ci + s_cc * BK;
+#pragma unroll
+    for (int i = 0; i < CHB; ++i) glds16(b_src[i] + col, base + (wave * CHB + i) * 1024);
+    // the next halo, three chunk slots with the stages of taps 3, 5 and 7 (static slot indices: hsrc stays in registers).  NOT with
+    // taps 0 .. NST-2: those stages are issued while the last taps of the previous channel chunk still read the buffer the next halo
+    // goes into (a stage runs NST - 1 <= 3 steps ahead of the compute).
+    if (h_item < nitems) {
+      const int buf = ((s_it / 9) + 1) & 1;
+      if (s_tap == 3) {
+        issue_halo_slot(0, buf);
+        issue_halo_slot(1, buf);
+        issue_halo_slot(2, buf);
+      } else if (s_tap == 5) {
+        issue_halo_slot(3, buf);
+        issue_halo_slot(4, buf);
+        issue_halo_slot(5, buf);
+      } else if (s_tap == 7) {
+        issue_halo_slot(6, buf);
+        issue_halo_slot(7, buf);
+        issue_halo_slot(8, buf);
+      }
+    }
+    ++s_it;
+    if (++s_tap == 9) {
+      s_tap = 0;
+      advance_halo();
+      if (++s_cc == kc) {
+        s_cc = 0;
+        s_item += G;
+        if (s_item < nitems) open_b(s_item);
+      }
+    }
+  };
+
+  // ---- fragment rows: tile row m -> centre halo row (the same for every tile)
+  int hc[2], wrow[JN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = wm * 64 + i * 32 + (lane & 31);
+    const int seg = m / (nrow * cg.W), rm = m - seg * nrow * cg.W;
+    hc[i] = seg * seg_rows + (rm / cg.W + 1) * W2 + (rm % cg.W) + 1;
+  }
+#pragma unroll
+  for (int j = 0; j < JN; ++j) wrow[j] = wn * (TN_ / 2) + j * 32 + (lane & 31);
+  f32x16_t acc[JN][2];
+#pragma unroll
+  for (int j = 0; j < JN; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+  if (s_item < nitems) {  // prologue: the whole first halo, then the first weight stage (which also starts the second halo)
+    open_halo(h_item / tiles_n);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) issue_halo_slot(t, 0);
+    advance_halo();
+    open_b(s_item);
+#pragma unroll
+    for (int r = 0; r < NST - 1; ++r)
+      if (s_item < nitems) stage_next();
+  }
+  int it = 0;
+  for (int item = slot0; item < nitems; item += G) {
+    const int tn = item % tiles_n, tm = item / tiles_n;
+    for (int cc = 0; cc < kc; ++cc) {
+      const char* ha = hbuf + ((it / 9) & 1) * HB;
+      for (int tap = 0; tap < 9; ++tap, ++it) {
+        // stage `it` has landed: at most the NST - 2 younger weight stages are still in flight (halo chunks among them only make this
+        // wait for more); at the end of the stream fewer stages are in flight than that: drain
+        if (s_item < nitems) wait_vmcnt<(NST - 2) * CHB>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // every wave's share landed, the slot about to be refilled has no readers left
+        if (s_item < nitems) stage_next();
+        const char* sb = bbuf + (it % NST) * BSTAGE;
+        const int delta = (tap / 3 - 1) * W2 + (tap % 3 - 1);
+        const int hr0 = hc[0] + delta, hr1 = hc[1] + delta;
+        const char* x0 = ha + hr0 * 128;
+        const char* x1 = ha + hr1 * 128;
+        const int z0 = (hr0 >> 1) & 7, z1 = (hr1 >> 1) & 7;
+        bf16x8_t xq[2][2], wq[3];
+        auto rd_x = [&](int kk, int i) -> bf16x8_t {
+          return *(const bf16x8_t*)((i ? x1 : x0) + ((((kk << 1) | hi) ^ (i ? z1 : z0)) << 4));
+        };
+        auto rd_w = [&](int kk, int j) -> bf16x8_t {
+          return *(const bf16x8_t*)(sb + wrow[j] * 128 + ((((kk << 1) | hi) ^ ((wrow[j] >> 1) & 7)) << 4));
+        };
+        xq[0][0] = rd_x(0, 0);
+        xq[0][1] = rd_x(0, 1);
+        wq[0] = rd_w(0, 0);
+        wq[1] = rd_w(0, 1);
+#pragma unroll
+        for (int s = 0; s < 4 * JN; ++s) {
+          const int kk = s / JN, j = s % JN;
+          __builtin_amdgcn_sched_barrier(0);
+          if (s + 2 < 4 * JN) wq[(s + 2) % 3] = rd_w((s + 2) / JN, (s + 2) % JN);
+          if (kk < 3 && j < 2) xq[(kk + 1) & 1][j] = rd_x(kk + 1, j);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s % 3], xq[kk & 1][i], acc[j][i], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    conv_epilogue<JN, false>(acc, tm * TBM + wm * 64, tn * TN_ + wn * (TN_ / 2), lane, C, ldc, ep.bias, ep.resid, ep.ldr);
+    wait_vmcnt<0>();
+  }
+}
+static int g_conv_halo_nst = 4;  // LAB: ring depth of the 128-wide halo kernel's weight stages
+extern "C" __attribute__((visibility("default"))) void dl_lab_set_conv_halo_nst(int n) { g_conv_halo_nst = n; }
+static int g_conv_halo = 1;  // LAB switch (not in the header): 0 = never, 1 = conv3x3_halo_k where the shape fits (default), 2 = also for small launches (tests)
+extern "C" __attribute__((visibility("default"))) void dl_lab_set_conv_halo(int on) { g_conv_halo = on; }
+template <int TN_, int NST>
+static int launch_conv_halo(const void* x, const void* Wf, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, const NtEpilogue& ep,
+                            const ConvGeom& cg, int nrow, int nseg, int nchunks, hipStream_t stream) {
+  const int LDS = 2 * nchunks * 1024 + NST * TN_ * 128;
+  if (LDS > 160 * 1024) return 1;
+  static DevOnce once;
+  const int n_cu = dev_cus(once, [] { (void)hipFuncSetAttribute((const void*)conv3x3_halo_k<TN_, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+  const int64_t items = (M / TBM) * (N / TN_);
+  int grid = (int)(items < n_cu ? items : n_cu) & ~7;
+  if (grid < 8) return 1;
+  hipLaunchKernelGGL((conv3x3_halo_k<TN_, NST>), grid, BIG_THREADS, LDS, stream, (const bf16_t*)x, (const bf16_t*)Wf, ldw, C, ldc, (int)M, (int)N, ep,
+                     cg, nrow, nseg, nchunks);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
 // second half of a split-K convolution: out = bf16(acc + bias + resid)
 __global__ void conv_splitk_finalize_k(const float* __restrict__ acc, int splits, int64_t stride, const float* __restrict__ bias,
                                        const bf16_t* __restrict__ resid, int64_t ldr, bf16_t* __restrict__ out, int64_t ldc,
@@ -1519,6 +1731,23 @@ extern "C" int dl_conv3x3_nt(const void* x, int64_t ldx, int64_t Bn, int64_t H, 
     const int64_t mt = M / TBM;
     int tn = (Co % 256 == 0 && mt * (Co / 256) >= n_cu) ? 256 : 128;
     int64_t tiles = mt * (Co / tn);
+    if (g_conv_halo && W <= 256 && TBM % W == 0 && ((H * W) % TBM == 0 || TBM % (H * W) == 0)) {
+      // one staging of the activation rows per channel chunk (conv3x3_halo_k): launches with a full round of unsplit tiles
+      const int nrow = (int)((H * W >= TBM) ? TBM / W : H), nseg = (int)((H * W >= TBM) ? 1 : TBM / (H * W));
+      const int nchunks = (nseg * (nrow + 2) * ((int)W + 2) + 7) / 8;
+      if (nchunks <= HALO_MAX_CHUNKS && M * ldx < (1ll << 31) && (tiles >= (n_cu * 3) / 4 || g_conv_halo == 2)) {
+        NtEpilogue eph{bias, DL_ACT_NONE, 0, nullptr, (const bf16_t*)resid, ldr, nullptr, 0, 1, nullptr, 0, 0};
+        int rc = 1;
+        if (tn == 256) rc = launch_conv_halo<256, 2>(x, Wf, ldw, out, ldc, M, Co, eph, cg, nrow, nseg, nchunks, (hipStream_t)stream);
+        else {
+          if (g_conv_halo_nst == 4) rc = launch_conv_halo<128, 4>(x, Wf, ldw, out, ldc, M, Co, eph, cg, nrow, nseg, nchunks, (hipStream_t)stream);
+          if (rc == 1 && g_conv_halo_nst >= 3) rc = launch_conv_halo<128, 3>(x, Wf, ldw, out, ldc, M, Co, eph, cg, nrow, nseg, nchunks, (hipStream_t)stream);
+          if (rc == 1) rc = launch_conv_halo<128, 2>(x, Wf, ldw, out, ldc, M, Co, eph, cg, nrow, nseg, nchunks, (hipStream_t)stream);
+        }
+        if (rc < 0) return rc;
+        if (rc == 0) return DL_OK;
+      }
+    }
     int ksplit = 1;
     if (tiles < (n_cu * 3) / 4) {
       if (Co % 256 == 0) {

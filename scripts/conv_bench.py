@@ -18,6 +18,8 @@ def timeit(fn, n=20):
 r64 = lambda v: (v + 63) // 64 * 64
 zero = torch.zeros(64, device=dev, dtype=BF)
 lib = ops.lib().cdll
+if os.environ.get("HALO_NST"):
+    lib.dl_lab_set_conv_halo_nst(int(os.environ["HALO_NST"]))
 rows = []
 # every 3x3 convolution shape of the MNIST-DDPM UNet (model_channels 128, channel_mult 1-2-4-8, 32x32 .. 4x4) incl. the decoder's
 # concatenated inputs; old = the 128x128 kernel (+ split-K), big = conv3x3_big_k (persistent 256-row tiles)
@@ -30,12 +32,16 @@ for H, ci, co in ((32, 128, 128), (32, 256, 128), (16, 128, 256), (16, 256, 256)
     res = torch.randn(M, co, device=dev).to(BF)
     scr = torch.empty(8 * M * co, device=dev)
     outs, us = {}, {}
-    for mode, name in ((0, "old"), (1, "big")):
+    for mode, halo, name in ((0, 0, "old"), (1, 0, "big"), (1, 1, "halo")):
         lib.dl_lab_set_conv_big(mode)
+        lib.dl_lab_set_conv_halo(halo)
         out = torch.empty(M, co, device=dev, dtype=BF)
         us[name] = timeit(lambda: ops.conv3x3_nt(x, B, H, H, ci, wf, out, co, bias, res, zero, scr))
         outs[name] = out.float()
     err = float((outs["big"] - outs["old"]).norm() / outs["old"].norm())
     fl = 2.0 * M * co * 9 * ci
-    print(f"{H:2d}x{H:<2d} Ci={ci:4d} Co={co:4d}: old {us['old']:7.1f} us {fl / us['old'] / 1e6:7.1f} TF/s   big {us['big']:7.1f} us {fl / us['big'] / 1e6:7.1f} TF/s   rel diff {err:.1e}")
+    errh = float((outs["halo"] - outs["big"]).norm() / outs["big"].norm())
+    print(f"{H:2d}x{H:<2d} Ci={ci:4d} Co={co:4d}: old {us['old']:7.1f} us {fl / us['old'] / 1e6:7.1f} TF/s   big {us['big']:7.1f} us {fl / us['big'] / 1e6:7.1f} TF/s   "
+          f"halo {us['halo']:7.1f} us {fl / us['halo'] / 1e6:7.1f} TF/s   rel diff big/old {err:.1e} halo/big {errh:.1e}")
 lib.dl_lab_set_conv_big(1)
+lib.dl_lab_set_conv_halo(1)

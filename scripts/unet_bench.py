@@ -21,6 +21,10 @@ def main() -> None:
         from diffulab_amd import ops
 
         ops.lib().cdll.dl_lab_set_conv_big(int(os.environ["DL_LAB_CONV_BIG"]))
+    if os.environ.get("DL_LAB_CONV_HALO"):  # LAB A/B: 1 = conv3x3_halo_k where the shape fits (one activation staging per channel chunk)
+        from diffulab_amd import ops
+
+        ops.lib().cdll.dl_lab_set_conv_halo(int(os.environ["DL_LAB_CONV_HALO"]))
     if os.environ.get("DL_LAB_GN_FUSED"):  # LAB A/B: 1 = 128-channel slabs (default), 2 = 512-channel slabs only, 0 = three launches
         from diffulab_amd import ops
 
