@@ -159,8 +159,8 @@ class FlatArenaDenoiser(Denoiser):
             owners = []
             for mname, mod in self.named_modules():
                 for key, q in mod._parameters.items():
-                    if q is not None:
-                        name = f"{mname}.{key}" if mname else key
+                    name = f"{mname}.{key}" if mname else key
+                    if q is not None and name in lay.entries:  # (a tied parameter's second name is not in the layout: named_parameters() dedups)
                         owners.append((mod._parameters, key, q, 4 * lay.entries[name][0], name))
             object.__setattr__(self, "_owners", owners)
         return owners
