@@ -375,7 +375,9 @@ DL_API int dl_heads_merge_rope_bwd(const void* dst_grad, void* src_grad, int64_t
 /* out[c] += sum_r x[r,c]  (bias gradients); x bf16 or f32 per dtype */
 DL_API int dl_colsum(const void* x, int dtype, int64_t ld, float* out, int64_t R, int64_t C,
                      dl_stream_t stream);
-/* several bf16 column sums (bias gradients of a stretch of a backward) in one launch per 24 problems; `desc` is a HOST array */
+/* several bf16 column sums in one launch per 24 problems: the bias gradients of the nn.Conv2d / conv_nd(1, ...) layers of a stretch of the
+ * UNet's backward (unet.py:187,208,302-305,594,745: what autograd computes as dY.sum over every pixel); `desc` is a HOST array (the
+ * descriptors travel by value in the kernel arguments: the operands are activation gradients whose addresses change per step) */
 typedef struct dl_colsum_desc_t {
   const void* x; /* bf16 [R, ld] */
   int64_t ld;
@@ -485,7 +487,9 @@ DL_API int dl_gn_stats(const void* x, float* stats, int64_t B, int64_t HW, int64
 DL_API int dl_gn_apply_fwd(const void* x, const float* stats, const float* w, const float* b, const void* film_scale,
                            const void* film_shift, int64_t ld_film, int act_silu, void* out, int64_t B, int64_t HW,
                            int64_t C, int64_t G, dl_stream_t stream);
-/* statistics + apply in one call (one launch on the training shapes; `stats` f32 [B, G, 2] is written for dl_gn_bwd) */
+/* GroupNorm32 (nn.py:11-13) + FiLM + SiLU (unet.py:215-237) with the statistics taken in the same call: one launch on the training
+ * shapes (a workgroup owns whole groups of a sample, its rows stay in registers between the two passes), dl_gn_stats + dl_gn_apply_fwd
+ * otherwise; `stats` f32 [B, G, 2] is written for dl_gn_bwd */
 DL_API int dl_gn_fwd(const void* x, const float* w, const float* b, const void* film_scale, const void* film_shift, int64_t ld_film,
                      int act_silu, void* out, float* stats, int64_t B, int64_t HW, int64_t C, int64_t G, float eps, dl_stream_t stream);
 /* backward of dl_gn_stats + dl_gn_apply_fwd: dx bf16 (= gradient through the norm + dres when dres != NULL: the residual /
@@ -557,7 +561,8 @@ DL_API int dl_reduce2x2(const void* x, void* out, int64_t B, int64_t Ho, int64_t
  * avg_pool2d backward (scale 0.25) */
 DL_API int dl_expand2x2(const void* x, void* out, int64_t B, int64_t Hi, int64_t Wi, int64_t C, float scale,
                         dl_stream_t stream);
-/* dl_reduce2x2 (expand = 0) / dl_expand2x2 (expand != 0) over TWO tensors of the same geometry in one launch (x1 / out1 NULL: one);
+/* dl_reduce2x2 (expand = 0) / dl_expand2x2 (expand != 0) over TWO tensors of the same geometry in one launch (x1 / out1 NULL: one) --
+ * a resampling ResBlock moves its h and its x through the same Upsample / Downsample (unet.py:196-203,226-230; nn.py:28-88);
  * Hs x Ws = the small map.  16 bytes per lane when C % 8 == 0. */
 DL_API int dl_resample2x2_pair(const void* x0, void* out0, const void* x1, void* out1, int64_t B, int64_t Hs, int64_t Ws, int64_t C,
                                float scale, int expand, dl_stream_t stream);
