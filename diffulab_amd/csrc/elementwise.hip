@@ -53,6 +53,29 @@ extern "C" int dl_stream_create_masked(const uint32_t* cu_mask, int words, void*
   *stream_out = (void*)st;
   return DL_OK;
 }
+// HIP stream of the LOWEST priority the device offers (the side stream of the weight gradients: when both queues have workgroups
+// ready the dispatcher serves the main chain's first); *range_out = {least, greatest} as hipDeviceGetStreamPriorityRange reports it
+extern "C" int dl_stream_create_low_priority(void** stream_out, int* range_out) {
+  DL_CHECK_ARG(stream_out, "dl_stream_create_low_priority: bad args");
+  int least = 0, greatest = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (e != hipSuccess) {
+    dl_set_error("hipDeviceGetStreamPriorityRange: %s", hipGetErrorString(e));
+    return DL_ERR_LAUNCH;
+  }
+  if (range_out) {
+    range_out[0] = least;
+    range_out[1] = greatest;
+  }
+  hipStream_t st = nullptr;
+  e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least);
+  if (e != hipSuccess) {
+    dl_set_error("hipStreamCreateWithPriority: %s", hipGetErrorString(e));
+    return DL_ERR_LAUNCH;
+  }
+  *stream_out = (void*)st;
+  return DL_OK;
+}
 extern "C" int dl_stream_destroy(void* stream) {
   if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) return DL_ERR_LAUNCH;
   return DL_OK;

@@ -271,6 +271,8 @@ class DiTEngine:
             mask = tuning.text("DL_SIDE_CU_MASK")  # e.g. "i4" = every 4th CU, "b128" = the first 128 CUs
             if mask:
                 self._side = ops.masked_stream(mask, self.dev)
+            elif tuning.on("DL_SIDE_LOW_PRIORITY"):
+                self._side = ops.low_priority_stream(self.dev)
             else:
                 self._side = torch.cuda.Stream(device=self.dev)
         return self._side

@@ -1140,6 +1140,17 @@ def f32_rowbias_bwd(dy, de, B, HW, C):
     _call("dl_f32_rowbias_bwd", _p(dy), _p(de), de.stride(0), B, HW, C, _s())
 
 
+def low_priority_stream(device) -> "torch.cuda.Stream":
+    """torch stream object over a HIP stream of the device's lowest priority"""
+    handle = ctypes.c_void_p()
+    rng = (ctypes.c_int * 2)()
+    with torch.cuda.device(device):
+        lib().call("dl_stream_create_low_priority", ctypes.byref(handle), rng)
+    st = torch.cuda.ExternalStream(handle.value, device=device)
+    st.priority_range = (rng[0], rng[1])
+    return st
+
+
 def masked_stream(pattern: str, device) -> "torch.cuda.Stream":
     """torch stream object over a CU-masked HIP stream; pattern "i<k>" enables every k-th CU, "b<n>" the first n CUs"""
     import ctypes

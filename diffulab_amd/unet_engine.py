@@ -375,7 +375,12 @@ class UNetEngine:
     def _side_stream(self) -> "torch.cuda.Stream":
         if getattr(self, "_side", None) is None:
             mask = tuning.text("DL_SIDE_CU_MASK")  # (experiments: "b192" = the first 192 CUs, "i2" = every other CU)
-            self._side = ops.masked_stream(mask, self.dev) if mask else torch.cuda.Stream(device=self.dev)
+            if mask:
+                self._side = ops.masked_stream(mask, self.dev)
+            elif tuning.on("DL_UNET_SIDE_LOW_PRIORITY"):
+                self._side = ops.low_priority_stream(self.dev)
+            else:
+                self._side = torch.cuda.Stream(device=self.dev)
         return self._side
 
     @property

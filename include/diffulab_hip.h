@@ -46,6 +46,8 @@ DL_API int dl_device_info(int device, int* cu_count, int* lds_bytes_per_cu, int6
 /* a HIP stream whose kernels may only run on the compute units whose bit is set in cu_mask[words] (bit i of word i/32 = CU i);
  * the caller owns the handle (wrap it, e.g. torch.cuda.ExternalStream) and destroys it with dl_stream_destroy */
 DL_API int dl_stream_create_masked(const uint32_t* cu_mask, int words, void** stream_out);
+/* a HIP stream of the device's lowest priority (side stream of the weight gradients); range_out (may be NULL) = {least, greatest} */
+DL_API int dl_stream_create_low_priority(void** stream_out, int* range_out);
 DL_API int dl_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------ diffusion heads (f32 images [B, chw]) */
