@@ -30,7 +30,8 @@ SWITCHES: dict[str, tuple[str, str]] = {
     "DL_SIDE_WGS": ("", "workgroup cap of the side-stream weight gradients (default: 256 grouped, 128 per-problem)"),
     "DL_SIDE_CU_MASK": ("", "CU mask of the side stream (dl_stream_create_masked): 'i4' = every 4th CU, 'b128' = the first 128"),
     "DL_SIDE_LOW_PRIORITY": ("0", "DiT engines: the side stream of the weight gradients is created with the device's lowest stream priority "
-                             "(measured +-0 on the DiT-S/2 step: 20.83 / 20.80 vs 20.73 / 20.77 ms)"),
+                             "(measured +-0: DiT-S/2 20.83 / 20.80 vs 20.73 / 20.77 ms; SPRINT joint 28.77 / 28.58 vs 28.79 / 28.62; DDT 38.93 / 38.97 vs "
+                             "39.01 / 39.00; joint MMDiT 49.14 / 49.13 vs 49.24 / 49.31; REPA 11.71 / 11.68 vs 11.76 / 11.73)"),
     "DL_UNET_SIDE_LOW_PRIORITY": ("1", "UNet: the same (the dispatcher serves the main chain's workgroups first: 26.42 / 26.50 vs 26.66 / 26.64 ms)"),
     "DL_JOIN_LAST": ("1", "single GPU: the side stream is joined after the conditioning backward instead of before it"),
     "DL_DP_RESERVE_CUS": ("0", "data parallel: CUs left to the communication library's workgroups (persistent main-chain grids shrink by it; "
