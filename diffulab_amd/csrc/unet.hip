@@ -337,8 +337,9 @@ extern "C" int dl_gn_fwd(const void* x, const float* w, const float* b, const vo
   hipLaunchKernelGGL((gn_fwd_fused_k<NCH_, KEEP_>), dim3((unsigned)(B * (C / (NCH_ * 8)))), 256, 0, (hipStream_t)stream,              \
                      (const bf16_t*)x, w, b, (const bf16_t*)film_scale, (const bf16_t*)film_shift, ld_film, act_silu, (bf16_t*)out,   \
                      stats, (int)HW, (int)C, (int)G, eps)
-  // (below ~8 M elements the launch is a latency chain: statistics + apply as two launches are faster -- 11 vs 21 us at 4 x 4 x 1024)
-  if (g_gn_fused && B * HW * C >= (1ll << 23) && B * (C / 64) < (1ll << 31)) {
+  // (4 x 4 maps below ~8 M elements: the launch is a latency chain, statistics + apply as two launches are faster -- 11 vs 16 us at
+  //  4 x 4 x 1024; from 8 x 8 on the one launch wins at every width: 12.2 vs 13.0 us at 8 x 8 x 512, 13.0 vs 17.4 at 8 x 8 x 768)
+  if (g_gn_fused && (B * HW * C >= (1ll << 23) || HW >= 64 || g_gn_fused == 3) && B * (C / 64) < (1ll << 31)) {
     if (HW <= 64 && C % 128 == 0 && 128 % cg == 0 && 128 / cg <= 32) {
       GN_FWD_LAUNCH(16, 4);
       DL_LAUNCH_CHECK();

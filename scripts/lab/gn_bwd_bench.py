@@ -9,6 +9,8 @@ from diffulab_amd import ops  # noqa: E402
 
 DEV, BF = "cuda", torch.bfloat16
 B = int(os.environ.get("B", "128"))
+if os.environ.get("DL_LAB_GN_FUSED"):
+    ops.lib().cdll.dl_lab_set_gn_fused(int(os.environ["DL_LAB_GN_FUSED"]))
 print("library:", os.environ.get("DIFFULAB_HIP_LIB", "(product)"))
 for HW, C, film in ((1024, 128, True), (1024, 256, False), (256, 256, True), (256, 384, False), (256, 512, False), (64, 512, True),
                     (64, 1024, False), (64, 768, False), (64, 1536, False), (16, 1024, True), (16, 2048, False), (16, 1536, False)):
