@@ -151,3 +151,36 @@ def test_bench_launches_its_own_ranks_without_touching_a_gpu():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check", "--steps", "x"],
                          capture_output=True, text=True, timeout=300, env=env)
     assert bad.returncode != 0
+
+
+def test_fused_adamw_flat_arena_detection_is_cached_and_revalidated():
+    """FusedAdamW._flat (round 5): the arena scan is remembered per group and a hit is re-validated by pointer compares -- a gradient
+    that was detached, re-pointed or newly attached is seen at the next call (host logic only: no kernel runs here)"""
+    from diffulab_amd.training.optim import FusedAdamW
+
+    flat, gflat = torch.zeros(64), torch.zeros(64)
+    ps = []
+    for i in range(4):
+        p = torch.nn.Parameter(torch.empty(0))
+        p.data = flat[16 * i : 16 * (i + 1)]
+        p.grad = gflat[16 * i : 16 * (i + 1)]
+        ps.append(p)
+    extra = torch.nn.Parameter(torch.zeros(3))  # outside the arena (an auxiliary head in the same group), no gradient yet
+    opt = FusedAdamW(ps + [extra], lr=1e-3)
+    g = opt.param_groups[0]
+    scans = []
+    orig = opt._flat_scan
+    opt._flat_scan = lambda group: (scans.append(1), orig(group))[1]
+    pb, gb, rest = opt._flat(g)
+    assert pb.data_ptr() == flat.data_ptr() and gb.data_ptr() == gflat.data_ptr() and rest == [extra] and len(scans) == 1
+    assert opt._flat(g)[2] == [extra] and len(scans) == 1            # hit: no rescan
+    extra.grad = torch.zeros(3)                                       # an outside tensor gains a gradient: rescan (it might be a view)
+    assert opt._flat(g)[2] == [extra] and len(scans) == 2
+    assert opt._flat(g) is not None and len(scans) == 2
+    ps[2].grad = None                                                 # a detached gradient: the arena no longer holds the whole group
+    r = opt._flat(g)
+    assert len(scans) == 3 and (r is None or ps[2] in r[2])
+    ps[2].grad = gflat[32:48]
+    assert opt._flat(g)[2] == [extra] and len(scans) == 4
+    ps[1].grad = torch.zeros(16)                                      # re-pointed outside the gradient arena
+    assert opt._flat(g) is None and len(scans) == 5
