@@ -484,3 +484,29 @@ def test_qk_norm_on_load_path_native_equals_python_and_matches_the_row_kernel_pa
     lay = m.engine.layout
     for name in Pr:
         assert rel(lay.view(a[1], name), Pr[name].grad) < 2.5e-2, name
+
+
+def test_a_replaced_parameter_object_is_picked_up_by_the_next_forward():
+    """The per-step flat-arena check walks a cached owner list (round 5: `named_parameters()` over the module tree cost milliseconds per
+    step on the UNet).  A parameter OBJECT that is replaced in its module -- `load_state_dict(assign=True)`, a re-registered
+    nn.Parameter -- is no longer a view of the arena: the check must see it (`is not`), re-flatten and compute with the new values;
+    an in-place write through the old object is seen through the version counters as before."""
+    m, P = build(SMALL, seed=5)
+    cfg = odit.DiTConfig(**SMALL)
+    B = 2
+    x, t, y = synth.normal("rp.x", (B, 4, 16, 16)), synth.uniform("rp.t", (B,), lo=0.05, hi=0.95), synth.integers("rp.y", (B,), SMALL["n_classes"])
+    m.eval()
+    with torch.no_grad():
+        out0 = m(x=x.cuda(), timesteps=t.cuda(), y=y.cuda(), p=0.0)["x"].clone()
+        assert rel(out0, odit.dit_forward(P, x, t, y, cfg)) < 1.5e-2
+        name = "layers.0.attention.proj_out.weight"
+        new = synth.normal("rp.w", tuple(P[name].shape), std=P[name].shape[1] ** -0.5)
+        m.layers[0].attention.proj_out.weight = torch.nn.Parameter(new.cuda())  # a NEW object in the module
+        out1 = m(x=x.cuda(), timesteps=t.cuda(), y=y.cuda(), p=0.0)["x"].clone()
+        P1 = dict(P, **{name: new})
+        assert rel(out1, odit.dit_forward(P1, x, t, y, cfg)) < 1.5e-2 and rel(out1, out0) > 1e-2
+        assert m._is_flat()  # re-flattened: the new object is a view of the arena again
+        m.layers[0].attention.proj_out.weight.mul_(0.5)  # in place, through the (new) object
+        out2 = m(x=x.cuda(), timesteps=t.cuda(), y=y.cuda(), p=0.0)["x"].clone()
+        P2 = dict(P1, **{name: 0.5 * new})
+        assert rel(out2, odit.dit_forward(P2, x, t, y, cfg)) < 1.5e-2
