@@ -3,7 +3,7 @@ dl_attn_bwd_tok + dl_qk_norm_rope_bwd_inplace against the fused dl_attn_bwd_qkn.
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from diffulab_amd import ops
-from oracle import dit as odit
+from diffulab_amd.engine import rope_grid_tables
 dev, BF = "cuda", torch.bfloat16
 B, H, N, dh = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 6, 256, 64
 D, M, scale = H * dh, B * N, dh**-0.5
@@ -17,7 +17,7 @@ def timeit(fn, n=30):
     return e0.elapsed_time(e1) * 1e3 / n
 qkv = (torch.randn(M, 3 * D, device=dev)).to(BF)
 sq, sk = 1 + 0.1 * torch.randn(D, device=dev), 1 + 0.1 * torch.randn(D, device=dev)
-cos, sin = (t.to(dev).contiguous() for t in odit.rope_tables(16, 16, [32, 32], 10_000.0))
+cos, sin = (t.to(dev).contiguous() for t in rope_grid_tables(16, 16, [32, 32], 10_000.0))
 q, k = (torch.empty(B, H, N, dh, device=dev, dtype=BF) for _ in range(2))
 rrms = torch.empty(M, 2, device=dev)
 ops.qk_norm_rope_fwd(qkv, sq, sk, cos, sin, q, k, None, rrms, B, N, H, dh, 64)

@@ -8,7 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffulab_amd import ops  # noqa: E402
-from oracle import dit as odit  # noqa: E402  (RoPE tables only)
+from diffulab_amd.engine import rope_grid_tables  # noqa: E402
 
 dev, BF = "cuda", torch.bfloat16
 B, H, N, dh = 256, 6, 256, 64
@@ -30,7 +30,7 @@ def timeit(fn, n=30):
 
 qkv = (torch.randn(M, 3 * D, device=dev) * 0.5).to(BF)
 sq, sk = torch.ones(D, device=dev), torch.ones(D, device=dev)
-cos, sin = (t.to(dev) for t in odit.rope_tables(16, 16, [32, 32], 10_000.0))
+cos, sin = (t.to(dev) for t in rope_grid_tables(16, 16, [32, 32], 10_000.0))
 q, k = (torch.empty(B, H, N, dh, device=dev, dtype=BF) for _ in range(2))
 rrms = torch.empty(M, 2, device=dev)
 ops.qk_norm_rope_fwd(qkv, sq, sk, cos, sin, q, k, None, rrms, B, N, H, dh, 64)
