@@ -23,7 +23,8 @@ if os.environ.get("HALO_NST"):
 rows = []
 # every 3x3 convolution shape of the MNIST-DDPM UNet (model_channels 128, channel_mult 1-2-4-8, 32x32 .. 4x4) incl. the decoder's
 # concatenated inputs; old = the 128x128 kernel (+ split-K), big = conv3x3_big_k (persistent 256-row tiles)
-for H, ci, co in ((32, 128, 128), (32, 256, 128), (16, 128, 256), (16, 256, 256), (16, 512, 256), (16, 384, 256), (8, 256, 512), (8, 512, 512),
+EXTRA = ((32, 128, 256), (16, 256, 512), (16, 128, 512), (32, 128, 384)) if os.environ.get("CONV_BENCH_DGRAD") else ()  # data-gradient shapes: 256-wide tiles
+for H, ci, co in EXTRA + ((32, 128, 128), (32, 256, 128), (16, 128, 256), (16, 256, 256), (16, 512, 256), (16, 384, 256), (8, 256, 512), (8, 512, 512),
                   (8, 1024, 512), (8, 768, 512), (4, 512, 1024), (4, 1024, 1024), (4, 2048, 1024), (4, 1536, 1024)):
     M = B * H * H
     x = torch.randn(M, ci, device=dev).to(BF)
