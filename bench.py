@@ -138,8 +138,16 @@ def loss_curve_rel_err(dev, precision: str = "bf16") -> dict:
         opt.step()
         got.append(loss.item())
     err = np.abs(np.array(got) - ref) / ref
-    return {"steps": len(ref), "max": float(f"{err.max():.3e}"), "mean": float(f"{err.mean():.3e}"),
-            "against": "the reference's fp32 curve (tests/golden/loss_curve.npz)", "compute": precision}
+    out = {"steps": len(ref), "max": float(f"{err.max():.3e}"), "mean": float(f"{err.mean():.3e}"),
+           "against": "the reference's fp32 curve (tests/golden/loss_curve.npz)", "compute": precision}
+    if precision == "bf16":
+        # what the REFERENCE loses on the same loop under torch.autocast("cpu", bfloat16) against its own fp32 curve
+        # (tests/golden/loss_curve_autocast.npz, make_golden.py curve_autocast): the yardstick of the bf16 regime
+        ra = np.load(os.path.join(ROOT, "tests", "golden", "loss_curve_autocast.npz"))["rel_err_vs_fp32"]
+        out["reference_under_autocast"] = {"max": float(f"{ra.max():.3e}"), "mean": float(f"{ra.mean():.3e}"),
+                                           "hip_max_over_reference_max": float(f"{err.max() / ra.max():.3f}"),
+                                           "hip_mean_over_reference_mean": float(f"{err.mean() / ra.mean():.3f}")}
+    return out
 
 
 def fp32_regime_step(dev, B: int, flops_per_image: float) -> dict:
@@ -594,10 +602,9 @@ def main() -> None:
         dp = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "grad_bytes_per_step": model._flat_grad.numel() * 4,
               "exposed_allreduce_ms_per_step": None if tail is None else round(tail, 3),
               # how the exchange was scheduled in the timed region: decided by measurement during warm-up steps 2-13 (training/dp.py)
-              # (a pinned DIFFULAB_DP_OVERLAP still times BOTH schedules during the warm-up: the first run on a multi-GPU node
-              # yields the A/B whatever was pinned)
+              # (a pinned DIFFULAB_DP_OVERLAP is honoured from the first step; DIFFULAB_DP_MEASURE=1 opts into timing both anyway)
               "exchange": reducer.tuned or {"mode": "overlapped" if reducer.overlap else "after_backward",
-                                            "decided": "DIFFULAB_DP_OVERLAP pinned, DIFFULAB_DP_MEASURE=0 (or fewer warm-up steps than the "
+                                            "decided": "DIFFULAB_DP_OVERLAP pinned without DIFFULAB_DP_MEASURE=1 (or fewer warm-up steps than the "
                                                        "measurement needs)"},
               "untimed_steps_before_timing": args.warmup + extra_warmup}
 

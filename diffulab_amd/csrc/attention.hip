@@ -101,6 +101,24 @@ __device__ __forceinline__ void store_rows64(bf16_t* rowp, const f32x16_t (&a)[2
     }
 }
 
+// the same packing without the stores: pk[dt * 2 + gp] = the 16 bytes store_rows64 writes at column 32 dt + 16 gp + 8 hi
+__device__ __forceinline__ void pack_rows64(u32x4_t (&pk)[4], const f32x16_t (&a)[2], float mul) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[dt][8 * gp + e] * mul), __float_as_uint(a[dt][8 * gp + 4 + e] * mul),
+                                                   false, false);
+        v[e] = __uint_as_float(sw[0]);
+        v[4 + e] = __uint_as_float(sw[1]);
+      }
+      pk[dt * 2 + gp] = pack8(v);
+    }
+}
+
 // where head (b, h) of V (or dV) lives: element offset b * bs + h * hs, rows `pitch` elements apart.  Head-major [B, H, N, 64] is
 // {H*N*64, N*64, 64}; the v third of the token-major qkv rows [B*N, 3D] is {N*3D, 64, 3D} on a pointer advanced by 2D, which lets
 // the N <= 256 kernels read V / write dV in place (no head-split copy of V in the QK-norm kernels).
@@ -524,6 +542,226 @@ __global__ __launch_bounds__(512) void attn_fwd_qkn_k(const bf16_t* __restrict__
   if (hi == 0) lse[(int64_t)bh * N + qrow] = (m_run + log2f(l_tot)) * LN2;
 }
 
+// ------------------------------------------------------------------------------ the same forward, persistent + pipelined (round 6)
+// attn_fwd_qkn_k is one dependency chain per (sample, head) workgroup -- tile DMA -> transform -> 4 key blocks -> stores -- with two
+// workgroups per CU to cover each other: 95 us at the headline shape against 49 us for its 311 MB at the HBM rate.  Here ONE 8-wave
+// workgroup per CU walks a contiguous run of (sample, head) items (at B = 256: the six heads of one sample, i.e. whole 2304-byte
+// qkv rows in a burst) with the K / V tiles double-buffered in LDS (2 x 64 KiB): the DMA of item i + 1 and the raw q fragments /
+// row statistics of item i + 1 are in flight under the MFMA / softmax work of item i.  The arithmetic (operation order included) is
+// attn_fwd_qkn_k's: results are bit-identical (tests/test_row_gemm_gpu.py).
+//   * the V fragments come out of ds_read_b64_tr_b16 as INLINE ASM with an explicit lgkmcnt wait: behind an in-flight direct-to-LDS
+//     DMA the compiler puts s_waitcnt vmcnt(0) in front of a transposing read it can see (gemm.hip, lds_tr16), which would wait
+//     for the prefetch before computing;
+//   * an item's O rows are packed and stored ONE ITEM LATE, in front of the next prefetch: the vmcnt(0) at the top of an item then
+//     only ever waits for loads requested a whole item ago (loads and stores share one in-order counter, and across the loop's
+//     back edge the compiler waits with vmcnt(0) whatever is counted by hand);
+//   * the QK-norm scales of all heads sit in LDS (their global loads would be on every item's critical chain);
+//   * rotary table rows and the chunk geometry depend on the token row only: loaded once per workgroup.
+static int g_attn_pipe = 1;  // 1: the persistent forms where they apply; 0: the chain forms everywhere
+extern "C" __attribute__((visibility("default"))) void dl_lab_set_attn_pipe(int mode) { g_attn_pipe = mode; }  // LAB A/B switch (not in the header)
+static int attn_fwd_pipe_on() { return g_attn_pipe & 1; }
+__device__ __forceinline__ s16x4_t attn_lds_tr16(const char* p) {
+  s16x4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)(lds_void_t*)p));
+  return v;
+}
+#define PIPE_N 256
+__global__ __launch_bounds__(512) void attn_fwd_qkn_pipe_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
+                                                           int H, int items, float scale, QkNorm qn) {
+  constexpr int N = PIPE_N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, hi = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int per = (items + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int it0 = blockIdx.x * per, it1 = it0 + per < items ? it0 + per : items;
+  if (it0 >= it1) return;
+  const int D = H * DH, half = qn.rot >> 1;
+  const int qrow = wave * 32 + l31;
+  // ---- loop-invariant: rotary rows of this lane's token row, LDS offsets of the fragment reads.  A thread transforms the SAME
+  //      (row, channel chunk) set of K that it holds of Q -- row qrow, chunks d0 = 16 ks + 8 hi -- so one set of table rows serves both
+  f32x4_t qc[4], qs[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int d0 = ks * 16 + hi * 8;
+    if (d0 < qn.rot) {
+      qc[ks] = *(const f32x4_t*)(qn.cs + (int64_t)qrow * half + (d0 >> 1));
+      qs[ks] = *(const f32x4_t*)(qn.sn + (int64_t)qrow * half + (d0 >> 1));
+    } else {
+      qc[ks] = qs[ks] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  int ro[4];  // frag_rows(tile, base + l31, ks, hi) = tile + base * ROWB + ro[ks]   (base % 32 == 0: the swizzle term is the lane's)
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) ro[ks] = tile_off(l31, ks * 2 + hi);
+  int co[2][2];  // frag_cols(tile, rbase, 32 cb, lane) halves = tile + rbase * ROWB + co[cb][0 / 1]   (rbase % 16 == 0)
+  {
+    const int li = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int col = cb * 32 + (g & 1) * 16 + (li & 3) * 4, r = (g >> 1) * 4 + (li >> 2) + 8 * hh;
+        co[cb][hh] = r * ROWB + (((col >> 3) ^ swz8(r)) << 4) + (col & 7) * 2;
+      }
+  }
+  const float c = scale * LOG2E;
+  // the QK-norm scales of every head in LDS behind the tile buffers (their per-item global loads would sit on the item's chain)
+  float* sq_l = (float*)(smem + 4 * N * ROWB);
+  float* sk_l = sq_l + D;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) {
+    sq_l[i] = qn.sq[i];
+    sk_l[i] = qn.sk[i];
+  }
+
+  u32x4_t qraw[4];
+  float ssq_q, ssq_k;
+  u32x4_t opk[4];       // the previous item's O rows, packed: stored one item late, BEFORE the next prefetch is requested, so that the
+  float lse_pend = 0.f; // wait at the top of an item (vmcnt(0): tiles + registers of this item) never waits for a store just issued
+  auto store_pending = [&](int item) {
+    const int b = item / H, h = item - b * H;
+    bf16_t* rowp = out + ((int64_t)b * N + qrow) * (H * DH) + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) *(u32x4_t*)(rowp + dt * 32 + 16 * gp + 8 * hi) = opk[dt * 2 + gp];
+    if (hi == 0) lse[(int64_t)item * N + qrow] = lse_pend;
+  };
+  auto issue_tiles = [&](int item, int buf) {
+    const int b = item / H, h = item - b * H;
+    const bf16_t* base = qkv + (int64_t)b * N * qn.pitch + h * DH;
+    char* kt = smem + buf * (2 * N * ROWB);
+    tile_dma(base + D, qn.pitch, kt, N, wave, 8, lane);
+    tile_dma(base + 2 * D, qn.pitch, kt + N * ROWB, N, wave, 8, lane);
+  };
+  auto issue_regs = [&](int item) {
+    const int b = item / H, h = item - b * H;
+    const bf16_t* base = qkv + (int64_t)b * N * qn.pitch + h * DH;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qraw[ks] = *(const u32x4_t*)(base + (int64_t)qrow * qn.pitch + ks * 16 + hi * 8);
+    const float2 sq2 = *(const float2*)(qn.ssq + ((int64_t)b * N + qrow) * 2);
+    ssq_q = sq2.x;
+    ssq_k = sq2.y;
+  };
+  issue_regs(it0);
+  issue_tiles(it0, 0);
+
+  for (int it = it0; it < it1; ++it) {
+    const int buf = (it - it0) & 1;
+    char* kt = smem + buf * (2 * N * ROWB);
+    char* vt = kt + N * ROWB;
+    const int b = it / H, h = it - b * H, bh = it;
+    const int64_t tok = (int64_t)b * N + qrow;
+    // the tiles and registers of THIS item were requested one item ago, before that item's main loop; nothing younger is in flight
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // every wave's share of the tiles has landed; every wave is done with the other buffer (and, first item, sq_l / sk_l)
+    // ---- this wave's query rows: normalised + rotated in registers
+    const float rq = rsqrtf(ssq_q * qn.inv_d + qn.eps);
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int d0 = ks * 16 + hi * 8;
+      const u32x4_t t = qk_xform8(qraw[ks], rq, sq_l + h * DH + d0, (const float*)&qc[ks], (const float*)&qs[ks], d0 < qn.rot);
+      qf[ks] = __builtin_bit_cast(bf16x8_t, t);
+      if (qn.qo) *(u32x4_t*)(qn.qo + ((int64_t)bh * N + qrow) * DH + d0) = t;
+    }
+    if (qn.rrms && h == 0 && hi == 0) qn.rrms[tok * 2] = rq;
+    // ---- K tile: in place in LDS (this thread's chunks: row qrow, the fragment slots of its q registers)
+    const float rk = rsqrtf(ssq_k * qn.inv_d + qn.eps);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int d0 = ks * 16 + hi * 8;
+      char* p = kt + wave * 32 * ROWB + ro[ks];
+      const u32x4_t t = qk_xform8(*(const u32x4_t*)p, rk, sk_l + h * DH + d0, (const float*)&qc[ks], (const float*)&qs[ks], d0 < qn.rot);
+      *(u32x4_t*)p = t;
+      if (qn.ko) *(u32x4_t*)(qn.ko + ((int64_t)bh * N + qrow) * DH + d0) = t;
+    }
+    if (qn.rrms && h == 0 && hi == 0) qn.rrms[tok * 2 + 1] = rk;
+    if (it > it0) store_pending(it - 1);
+    // ---- prefetch the next item: raw q fragments + statistics into the registers just consumed, K / V into the other buffer
+    if (it + 1 < it1) issue_regs(it + 1);
+    __syncthreads();
+    if (it + 1 < it1) issue_tiles(it + 1, buf ^ 1);
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[0][r] = o[1][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll 1
+    for (int kb = 0; kb < N; kb += 64) {
+      // V fragments of this key block first (asm: no compiler-side wait), consumed after the softmax arithmetic
+      union {
+        s16x4_t h[2];
+        bf16x8_t v;
+      } vf[2][2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int kg2 = 0; kg2 < 2; ++kg2)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            const char* pb = vt + (kb + t * 32 + kg2 * 16) * ROWB;
+            vf[t][kg2][cb].h[0] = attn_lds_tr16(pb + co[cb][0]);
+            vf[t][kg2][cb].h[1] = attn_lds_tr16(pb + co[cb][1]);
+          }
+      f32x16_t s[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s[t] = MFMA(*(const bf16x8_t*)(kt + (kb + t * 32) * ROWB + ro[ks]), qf[ks], s[t]);
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[t][r] *= c;
+          mx = fmaxf(mx, s[t][r]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = fast_exp2(m_run - m_new);
+      m_run = m_new;
+      float ps = 0.f;
+      float p[2][16];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          p[t][r] = fast_exp2(s[t][r] - m_new);
+          ps += p[t][r];
+        }
+      l_run = l_run * alpha + ps;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[0][r] *= alpha;
+        o[1][r] *= alpha;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int kg2 = 0; kg2 < 2; ++kg2)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) asm volatile("" : "+v"(vf[t][kg2][cb].v));  // (no MFMA on these registers above the wait)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int kg2 = 0; kg2 < 2; ++kg2) {
+          const bf16x8_t pf = pack_frag(&p[t][kg2 * 8]);
+          o[0] = MFMA(vf[t][kg2][0].v, pf, o[0]);
+          o[1] = MFMA(vf[t][kg2][1].v, pf, o[1]);
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    pack_rows64(opk, o, inv);
+    lse_pend = (m_run + log2f(l_tot)) * LN2;
+  }
+  store_pending(it1 - 1);
+}
+
 /* DiTAttention.forward mmdit.py:81-100 from the pre-norm qkv rows: QK-RMSNorm (row statistics = ssq of dl_gemm_nt_ssq) + RoPE applied
  * on load, softmax(q k^T scale) v; also writes the normalised q, k head-major and rrms for the backward (q_out = k_out = rrms = NULL in
  * inference: 100 MB of stores per launch at the headline shape that only the backward reads).  N % 64 == 0 up to 256. */
@@ -543,6 +781,18 @@ extern "C" int dl_attn_fwd_qkn(const void* qkv, const float* ssq, const float* s
   (void)dev_cus(once, [] { (void)hipFuncSetAttribute((const void*)attn_fwd_qkn_k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * ROWB); });
   const int64_t D = H * DH;
   QkNorm qn{ssq, scale_q, scale_k, cos, sin, (bf16_t*)q_out, (bf16_t*)k_out, rrms, 1.0f / (float)D, eps, (int)rot, (int)(3 * D)};
+  const int cus = dev_cus(once, [] {});
+  if (N == PIPE_N && D <= 2048 && B * H >= 3 * (int64_t)cus && attn_fwd_pipe_on()) {
+    // persistent + pipelined form: one workgroup per CU, >= 3 items each (below that the chain form's two workgroups per CU win)
+    static DevOnce once2;
+    (void)dev_cus(once2, [] { (void)hipFuncSetAttribute((const void*)attn_fwd_qkn_pipe_k, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * PIPE_N * ROWB + 8 * 2048); });
+    const int items = (int)(B * H);
+    const int per = (items + cus - 1) / cus, grid = (items + per - 1) / per;
+    hipLaunchKernelGGL(attn_fwd_qkn_pipe_k, grid, 512, 4 * PIPE_N * ROWB + 8 * (int)D, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, (int)H,
+                       items, scale, qn);
+    DL_LAUNCH_CHECK();
+    return DL_OK;
+  }
   hipLaunchKernelGGL(attn_fwd_qkn_k, (int)(B * H), (int)(N / 32) * 64, lds, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, (int)H,
                      (int)N, scale, qn);
   DL_LAUNCH_CHECK();
@@ -555,35 +805,12 @@ __device__ __forceinline__ bf16x8_t frag_rows_g(const bf16_t* __restrict__ g, in
   return *(const bf16x8_t*)(g + (int64_t)row * pitch + (ks * 2 + hi) * 8);
 }
 
-// FUSE (dl_attn_bwd_qkn): the QK-RMSNorm + RoPE backward (mmdit.py:81-91, nn.py:345-353,427-431) runs as this kernel's epilogue instead
-// of a pass of its own over the q / k thirds of dqkv (qk_norm_rope_bwd_inplace_k: 307 MB per launch at the headline shape).  What
-// that backward needs beyond a row's own elements is ONE number per token row and tensor, c = sum over the FULL D-wide row of
-// (d q^ . q^) -- all heads -- and it never has to be formed from dq^:  sum_d q^[i,d] dq^[i,d] = sum_j dS[i,j] S[i,j]  (S the scaled
-// logits, dS their gradient; the rotation is orthogonal, so the sum is the same before and after RoPE), and likewise for k with the
-// sum over i.  Phase A / B accumulate those sums beside their dS tiles, every (sample, head) workgroup publishes its 2 N partial
-// sums, the H workgroups of a sample meet on a counter (they are adjacent in dispatch order), add the H partials in head order and
-// then transform the dq^ / dk^ rows THEY wrote (still L2-resident) in place:
-//      g = R^T dq^;  dscale += g x r;  dx = r (s g) - x (r^2 / D) c          (x = pre-norm row of qkv, r = rrms, s = scale)
-// Scale-gradient partials: one [2, D] row per sample, each head its own 64 columns (one writer, folded over samples afterwards).
-struct QknBwd {
-  const bf16_t* qkv;    // [B*N, 3D] pre-norm rows (x)
-  const float* rrms;    // f32 [B*N, 2]
-  const float* sq;      // f32 [D]
-  const float* sk;
-  const float* cs;      // f32 [N, rot/2]
-  const float* sn;
-  float* cpart;         // f32 [B*H, 2, N] exchange buffer
-  unsigned* sync;       // u32 [2*B + 1]: arrive[B] | done[B] | error flag; zero before the first launch, self-resetting
-  float* dscale_part;   // f32 [B, 2, D]
-  int rot;
-};
-template <bool FUSE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                      const bf16_t* __restrict__ v, const bf16_t* __restrict__ out,
                                                      const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                      bf16_t* __restrict__ dq, bf16_t* __restrict__ dk,
                                                      bf16_t* __restrict__ dv, int H, int N, float scale, HeadLayout vl,
-                                                     HeadLayout dvl, HeadLayout dql, QknBwd fz) {
+                                                     HeadLayout dvl, HeadLayout dql) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ta = smem;             // phase A: K   | phase B: Q
   char* tb = ta + N * ROWB;    // phase A: V   | phase B: dO
@@ -631,7 +858,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
     f32x16_t dqa[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqa[0][r] = dqa[1][r] = 0.f;
-    float cq = 0.f;  // FUSE: sum_j dS[i, j] * (q^_i . k^_j) over this lane's keys
     // software pipeline over the key blocks: the S / dP MFMAs of block kb + 32 are issued before the exp / dS arithmetic of block kb
     auto scores = [&](int kb, f32x16_t& st, f32x16_t& dpt) {
 #pragma unroll
@@ -649,7 +875,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
       for (int r = 0; r < 16; ++r) {
         const float p = fast_exp2(st[r] * c - my_lse);
         ds[r] = p * (dpt[r] - my_delta);
-        if (FUSE) cq += ds[r] * st[r];
       }
 #pragma unroll
       for (int kg2 = 0; kg2 < 2; ++kg2) {
@@ -665,10 +890,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
       step(kb + 32, s1, d1, s0, d0);
     }
     store_rows64(dq + b * dql.bs + h * dql.hs + (int64_t)(own + (lane & 31)) * dql.pitch, dqa, scale, hi);
-    if (FUSE) {  // (the other 16 keys of every block sit in the other lane half)
-      cq = xor32_sum(cq) * scale;  // (write-through store: the sample's other heads read it from L2 without an acquire, see below)
-      if (hi == 0) __hip_atomic_store(fz.cpart + ((int64_t)bh * 2) * N + own + (lane & 31), cq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
   }
 
   // ------------------------------------------------------------------ swap the resident tiles: Q and dO replace K and V
@@ -690,7 +911,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
     f32x16_t dka[2], dva[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dka[0][r] = dka[1][r] = dva[0][r] = dva[1][r] = 0.f;
-    float ck = 0.f;  // FUSE: sum_i dS[i, j] * (q^_i . k^_j) over this lane's queries
     // (software pipeline as in phase A, on S only: dK / dV / S / dP accumulators leave no room for a second dP tile)
     auto scores_t = [&](int qb, f32x16_t& s) {
 #pragma unroll
@@ -715,7 +935,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
           const int r = g4 * 4 + e;
           p[r] = fast_exp2(s[r] * c - l4[e]);
           ds[r] = p[r] * (dp[r] - d4[e]);
-          if (FUSE) ck += ds[r] * s[r];
         }
       }
 #pragma unroll
@@ -737,154 +956,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k(const bf16_t* __restrict__ 
     }
     store_rows64(dk + b * dql.bs + h * dql.hs + (int64_t)(own + (lane & 31)) * dql.pitch, dka, scale, hi);
     store_rows64(dv + b * dvl.bs + h * dvl.hs + (int64_t)(own + (lane & 31)) * dvl.pitch, dva, 1.0f, hi);
-    if (FUSE) {
-      ck = xor32_sum(ck) * scale;
-      if (hi == 0) __hip_atomic_store(fz.cpart + ((int64_t)bh * 2 + 1) * N + own + (lane & 31), ck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-#ifndef QKN_LAB
-#define QKN_LAB 0  // LAB: 1 = rendezvous but no transform, 2 = neither (cost split of the fused epilogue; results invalid)
-#endif
-  if constexpr (FUSE && QKN_LAB < 2) {
-    // ---------------------------------------------------------------- publish this head's partial row sums, meet the sample's heads
-    // (MI355X guide, inter-workgroup hand-off: the 2 KB payload is stored WRITE-THROUGH (sc1, agent-scope relaxed atomic stores) ->
-    // every storing wave drains -> barrier -> ticket; the consumers poll the ticket relaxed and read the payload with sc1 loads,
-    // which bypass the per-CU L1: no release fence -- it would write back every dirty line of the XCD's L2, i.e. the dq / dk / dv
-    // rows all resident workgroups have just stored, once per workgroup (measured: +145 us per launch) -- and no acquire.
-    // The H workgroups of a sample have consecutive block ids: with in-order dispatch a waiting workgroup's mates are resident or
-    // next in line; the poll is bounded anyway and a timeout is reported through sync[2 B] instead of hanging the queue.)
-    unsigned* arrive = fz.sync + b;
-    unsigned* done = fz.sync + gridDim.x / H + b;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int spins = 0;
-      while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)H) {
-        __builtin_amdgcn_s_sleep(16);
-        if (++spins > (1 << 21)) {
-          __hip_atomic_store(fz.sync + 2 * (gridDim.x / H), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-    }
-    __syncthreads();
-    // the sample's row sums: thread t adds the H partials of token row t (q and k) in head order.  sc1 loads (served by L2, never
-    // by this CU's L1), four heads x {q, k} per statement: loads AND their wait in ONE asm statement with early-clobber outputs --
-    // the compiler neither counts an asm load nor knows when its destination lands (MI355X guide, inline asm form (i))
-    {
-      float tq = 0.f, tk = 0.f;
-      for (int h0 = 0; h0 < H; h0 += 4) {
-        const float* pq[4];
-        const float* pk[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int hh = h0 + u < H ? h0 + u : H - 1;  // (past the last head: a valid address, the value is not added)
-          pq[u] = fz.cpart + (((int64_t)b * H + hh) * 2) * N + threadIdx.x;
-          pk[u] = pq[u] + N;
-        }
-        float vq[4], vk[4];
-        asm volatile(
-            "global_load_dword %0, %8, off sc1\n\tglobal_load_dword %1, %9, off sc1\n\tglobal_load_dword %2, %10, off sc1\n\t"
-            "global_load_dword %3, %11, off sc1\n\tglobal_load_dword %4, %12, off sc1\n\tglobal_load_dword %5, %13, off sc1\n\t"
-            "global_load_dword %6, %14, off sc1\n\tglobal_load_dword %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
-            : "=&v"(vq[0]), "=&v"(vq[1]), "=&v"(vq[2]), "=&v"(vq[3]), "=&v"(vk[0]), "=&v"(vk[1]), "=&v"(vk[2]), "=&v"(vk[3])
-            : "v"(pq[0]), "v"(pq[1]), "v"(pq[2]), "v"(pq[3]), "v"(pk[0]), "v"(pk[1]), "v"(pk[2]), "v"(pk[3])
-            : "memory");
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (h0 + u < H) {
-            tq += vq[u];
-            tk += vk[u];
-          }
-      }
-      lse2[threadIdx.x] = tq;   // (lse2 / delta are dead after phase B)
-      delta[threadIdx.x] = tk;
-    }
-    __syncthreads();
-    // ---------------------------------------------------------------- QK-norm + RoPE backward of the rows this wave wrote, in place
-    // after store_rows64 a lane holds, of row (lane & 31) of its block, the four 8-column chunks d0 = 32 dt + 16 gp + 8 hi
-    const int D = H * DH, half = fz.rot >> 1;
-    const float inv_d = 1.0f / (float)D;
-    float* red = (float*)smem;  // [4 waves][64 lanes][33]: this wave's per-lane column partials of dscale (K / V / Q / dO tiles are dead)
-    for (int which = 0; which < (QKN_LAB ? 0 : 2); ++which) {
-      float acc[4][8];
-#pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[ci][e] = 0.f;
-      const float* sc = (which ? fz.sk : fz.sq) + h * DH;
-      for (int ob = 0; ob < 2; ++ob) {
-        const int row = (wave * 2 + ob) * 32 + (lane & 31);
-        const int64_t tok = (int64_t)b * N + row;
-        const float ctot = (which ? delta : lse2)[row];
-        const float r = fz.rrms[tok * 2 + which];
-        const float m = ctot * r * r * inv_d;
-        bf16_t* gp_ = (which ? dk : dq) + b * dql.bs + h * dql.hs + (int64_t)row * dql.pitch;
-        const bf16_t* xp = fz.qkv + tok * 3 * D + which * D + h * DH;
-        u32x4_t gr[4], xr[4];
-        f32x4_t cc[4], ss[4];
-#pragma unroll
-        for (int ci = 0; ci < 4; ++ci) {
-          const int d0 = (ci >> 1) * 32 + (ci & 1) * 16 + 8 * hi;
-          gr[ci] = *(const u32x4_t*)(gp_ + d0);
-          xr[ci] = *(const u32x4_t*)(xp + d0);
-          if (d0 < fz.rot) {
-            cc[ci] = *(const f32x4_t*)(fz.cs + (int64_t)row * half + (d0 >> 1));
-            ss[ci] = *(const f32x4_t*)(fz.sn + (int64_t)row * half + (d0 >> 1));
-          }
-        }
-#pragma unroll
-        for (int ci = 0; ci < 4; ++ci) {
-          const int d0 = (ci >> 1) * 32 + (ci & 1) * 16 + 8 * hi;
-          float g[8], x[8];
-          unpack8(gr[ci], g);
-          unpack8(xr[ci], x);
-          if (d0 < fz.rot) {  // transpose of the rotation
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float a = g[2 * i], bb = g[2 * i + 1];
-              g[2 * i] = a * cc[ci][i] + bb * ss[ci][i];
-              g[2 * i + 1] = -a * ss[ci][i] + bb * cc[ci][i];
-            }
-          }
-          const f32x4_t s0 = *(const f32x4_t*)(sc + d0), s1 = *(const f32x4_t*)(sc + d0 + 4);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            acc[ci][e] += g[e] * x[e] * r;
-            g[e] = r * (g[e] * (e < 4 ? s0[e] : s1[e - 4])) - x[e] * m;
-          }
-          *(u32x4_t*)(gp_ + d0) = pack8(g);
-        }
-      }
-      // dscale partial of this sample: columns of this head, summed over the 256 token rows in a fixed order
-      __syncthreads();  // (which == 0: the tiles are dead; which == 1: the previous reduction's reads are done)
-#pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[(wave * 64 + lane) * 33 + ci * 8 + e] = acc[ci][e];
-      __syncthreads();
-      {
-        const int col = threadIdx.x & 63, w = threadIdx.x >> 6;
-        const int chi = (col >> 3) & 1, ci = (col >> 5) * 2 + ((col >> 4) & 1), e = col & 7;
-        float t = 0.f;
-        for (int l = 0; l < 32; ++l) t += red[(w * 64 + chi * 32 + l) * 33 + ci * 8 + e];
-        __syncthreads();
-        red[w * 64 + col] = t;
-        __syncthreads();
-        if (w == 0)
-          fz.dscale_part[((int64_t)b * 2 + which) * D + h * DH + col] = (red[col] + red[64 + col]) + (red[128 + col] + red[192 + col]);
-      }
-    }
-    // ---------------------------------------------------------------- the last head of the sample to finish clears the counters
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const unsigned dn = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (dn == (unsigned)H - 1) {
-        __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
   }
 }
 
@@ -1089,10 +1160,10 @@ static int attn_bwd_launch(const void* q, const void* k, const void* v, HeadLayo
                            const float* lse, void* dq, void* dk, HeadLayout dql, void* dv, HeadLayout dvl, int64_t B, int64_t H,
                            int64_t N, float scale, dl_stream_t stream) {
   const int lds = (int)(2 * N * ROWB + 2 * N * sizeof(float));
-  (void)hipFuncSetAttribute((const void*)attn_bwd_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL(attn_bwd_k<false>, (int)(B * H), (int)(N / 64) * 64, lds, (hipStream_t)stream, (const bf16_t*)q,
+  (void)hipFuncSetAttribute((const void*)attn_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(attn_bwd_k, (int)(B * H), (int)(N / 64) * 64, lds, (hipStream_t)stream, (const bf16_t*)q,
                      (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dq,
-                     (bf16_t*)dk, (bf16_t*)dv, (int)H, (int)N, scale, vl, dvl, dql, QknBwd{});
+                     (bf16_t*)dk, (bf16_t*)dv, (int)H, (int)N, scale, vl, dvl, dql);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
@@ -1122,40 +1193,6 @@ extern "C" int dl_attn_bwd_tok(const void* q, const void* k, const void* qkv, co
   return attn_bwd_launch(q, k, (const bf16_t*)qkv + 2 * D, tok, out, dout, lse, dqkv, (bf16_t*)dqkv + D, tok, (bf16_t*)dqkv + 2 * D, tok,
                          B, H, N, scale, stream);
 }
-int dl_fold_rows_launch(const float* partial, float* out, int G, int n, hipStream_t stream);  // norm.hip: out[j] += sum_g partial[g, j]
-/* dl_attn_bwd_tok + dl_qk_norm_rope_bwd_inplace as ONE launch (N == 256, the benched shape): see attn_bwd_k<true>.  q, k = the
- * normalised + rotated head-major tensors of the forward, qkv = the pre-norm rows; dqkv leaves holding the gradient of qkv
- * (token-major, all three thirds); dscale [2, D] += the QK-norm scale gradients (partials [B, 2, D] folded in a fixed order);
- * cpart f32 [B * H * 2 * N] and sync u32 [2 B + 1] are caller scratch -- sync ZEROED before the first call, it resets itself;
- * sync[2 B] != 0 after a call reports a timed-out rendezvous (results invalid). */
-extern "C" int dl_attn_bwd_qkn(const void* q, const void* k, const void* qkv, const void* out, const void* dout, const float* lse,
-                               const float* rrms, const float* scale_q, const float* scale_k, const float* cos, const float* sin,
-                               int64_t rot, void* dqkv, float* dscale, float* dscale_partials, float* cpart, uint32_t* sync, int64_t B,
-                               int64_t H, int64_t N, int64_t dh, float scale, dl_stream_t stream) {
-  DL_CHECK_ARG(q && k && qkv && out && dout && lse && rrms && scale_q && scale_k && dqkv && dscale && dscale_partials && cpart && sync &&
-                   B > 0 && H > 0, "dl_attn_bwd_qkn: null operand");
-  DL_CHECK_ARG(rot == 0 || (cos && sin), "dl_attn_bwd_qkn: rot > 0 needs the cos / sin tables");
-  DL_CHECK_ARG(dh == DH && rot % 8 == 0 && rot <= DH, "dl_attn_bwd_qkn: head_dim 64, rot %% 8 == 0 (dh=%lld rot=%lld)", (long long)dh,
-               (long long)rot);
-  if (N != 256) {
-    dl_set_error("dl_attn_bwd_qkn: N=%lld (the fused epilogue is built for 256-token samples)", (long long)N);
-    return DL_ERR_UNSUPPORTED;
-  }
-  DL_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)dqkv | (uintptr_t)cos | (uintptr_t)sin | (uintptr_t)scale_q | (uintptr_t)scale_k) & 15) == 0,
-               "dl_attn_bwd_qkn: 16-byte alignment");
-  const int64_t D = H * DH;
-  const HeadLayout tok{N * 3 * D, DH, (int)(3 * D)};
-  const int lds = (int)(2 * N * ROWB + 2 * N * sizeof(float));  // 67584 >= the 4 x 64 x 33 floats of the epilogue's reduction
-  static DevOnce once;
-  (void)dev_cus(once, [lds] { (void)hipFuncSetAttribute((const void*)attn_bwd_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
-  const QknBwd fz{(const bf16_t*)qkv, rrms, scale_q, scale_k, cos, sin, cpart, sync, dscale_partials, (int)rot};
-  hipLaunchKernelGGL(attn_bwd_k<true>, (int)(B * H), 256, lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k,
-                     (const bf16_t*)qkv + 2 * D, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, (bf16_t*)dqkv + D,
-                     (bf16_t*)dqkv + 2 * D, (int)H, (int)N, scale, tok, tok, tok, fz);
-  DL_LAUNCH_CHECK();
-  return dl_fold_rows_launch(dscale_partials, dscale, (int)B, (int)(2 * D), (hipStream_t)stream);
-}
-
 // ====================================================================================== small attention (UNet AttentionBlock)
 // n <= 64 tokens, head_dim a multiple of 64 up to 512 (unet.py:296-322: 8x8 and 4x4 feature maps, 256..512-wide heads): one
 // workgroup (4 waves) per (batch, head), every matmul on MFMA 32x32x16 in the transposed orientation of the kernels above.

@@ -151,12 +151,7 @@ extern "C" int dl_dit_block_bwd(const dl_dit_block_t* b, dl_stream_t main_, dl_s
   RUN(wgrad(P(DT1), D, P(A), D, P(G_PROJ), D, D));
   RUN(dl_gemm_nt(P(DT1), D, P(WT_PROJ), b->ldwt_d, P(DA), D, M, D, D, nullptr, DL_ACT_NONE, DL_BF16, nullptr, nullptr, 0, nullptr, 0, 1, main));
   const bool v_in_place = P(V) == nullptr;
-  if (v_in_place && P(QK_PARTIALS) && P(QKN_CPART) && P(QKN_SYNC) && N == 256 && B <= 1024) {
-    // one launch: the QK-norm + RoPE backward is the attention backward's epilogue (row sums from dS and S, exchanged between the heads)
-    RUN(dl_attn_bwd_qkn(P(Q), P(K), P(QKV), P(A), P(DA), (const float*)P(LSE), (const float*)P(RRMS), (const float*)P(QN_SCALE),
-                        (const float*)P(KN_SCALE), (const float*)P(ROPE_COS), (const float*)P(ROPE_SIN), b->rot, P(DQKV),
-                        (float*)P(G_QK_SCALE), (float*)P(QK_PARTIALS), (float*)P(QKN_CPART), (uint32_t*)P(QKN_SYNC), B, H, N, dh, sm, main));
-  } else if (v_in_place && P(QK_PARTIALS) && D <= 512) {
+  if (v_in_place && P(QK_PARTIALS) && D <= 512) {
     // every gradient of the attention leaves token-major inside the dqkv rows; the QK-norm backward transforms them in place
     RUN(dl_attn_bwd_tok(P(Q), P(K), P(QKV), P(A), P(DA), (const float*)P(LSE), P(DQKV), B, H, N, dh, sm, main));
     RUN(dl_qk_norm_rope_bwd_inplace(P(QKV), (const float*)P(QN_SCALE), (const float*)P(KN_SCALE), (const float*)P(ROPE_COS),

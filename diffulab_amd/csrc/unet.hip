@@ -823,7 +823,8 @@ extern "C" int dl_gn_bwd(const void* dout, const void* x, const float* stats, co
     DL_LAUNCH_CHECK();
     return DL_OK;
   }
-  if (C % 96 == 0 && 96 % (C / G) == 0 && HW <= 1024 && (B * (C / 96) >= 128 || gn_bwd_fused() == 3) && (gn_bwd_fused() & 1)) {
+  if (C % 96 == 0 && 96 % (C / G) == 0 && 96 / (C / G) <= 32 && HW <= 1024 && (B * (C / 96) >= 128 || gn_bwd_fused() == 3) &&
+      (gn_bwd_fused() & 1)) {
     // 12 / 24 / 48 channels per group (C = 384 / 768 / 1536, the concatenated inputs of the output blocks): 96-channel slabs
     const GnFused fz{dw, db, (bf16_t*)dfilm_scale, (bf16_t*)dfilm_shift, ld_dfilm, (const bf16_t*)dres, (bf16_t*)dx};
     if (HW <= 84)

@@ -35,25 +35,46 @@ class _PinnedRing:
     reused only after the copy that last read it has completed (an event per slot), so the host may run several steps ahead."""
 
     SLOTS = 8
+    CAP_BYTES = 512 << 20  # pinned host memory the ring may hold; least-recently-used size classes are dropped beyond it
 
     def __init__(self) -> None:
-        self.slots: dict[tuple, list] = {}
+        import collections
+        import threading
+
+        # size class (bytes rounded up to a power of two, device) -> [next slot, [(pinned byte buffer, event)], [used]]: multi-aspect-
+        # ratio buckets and short last batches share a class instead of pinning a ring per shape (ADVICE r5)
+        self.slots: "collections.OrderedDict[tuple, list]" = collections.OrderedDict()
+        self.bytes = 0
+        self.lock = threading.Lock()  # (a prefetch thread and the training loop may both stage transfers)
 
     def put(self, t: Tensor, device: torch.device, dtype: torch.dtype) -> Tensor:
-        key = (tuple(t.shape), dtype, device)
-        ring = self.slots.get(key)
-        if ring is None:
-            n = self.SLOTS if t.numel() * t.element_size() <= (1 << 18) else 3  # (batch-sized tensors: three slots are enough)
-            ring = self.slots[key] = [0, [(torch.empty(t.shape, dtype=dtype).pin_memory(), torch.cuda.Event()) for _ in range(n)], [False] * n]
-        i = ring[0]
-        buf, ev = ring[1][i]
-        if ring[2][i]:
-            ev.synchronize()  # (eight transfers ago: completed long since unless the host is that far ahead)
-        buf.copy_(t)  # host-side conversion + copy into the pinned slot
-        out = buf.to(device, non_blocking=True)
-        ev.record(torch.cuda.current_stream(device))
-        ring[2][i] = True
-        ring[0] = (i + 1) % len(ring[1])
+        nbytes = t.numel() * torch.empty((), dtype=dtype).element_size()
+        cls = 1 << max(6, (nbytes - 1).bit_length())
+        key = (cls, device)
+        with self.lock:
+            ring = self.slots.get(key)
+            if ring is None:
+                n = self.SLOTS if cls <= (1 << 18) else 3  # (batch-sized tensors: three slots are enough)
+                while self.slots and self.bytes + n * cls > self.CAP_BYTES:
+                    _, old = self.slots.popitem(last=False)
+                    for (buf, ev), used in zip(old[1], old[2]):
+                        if used:
+                            ev.synchronize()  # (its last copy must have read the buffer before the memory is unpinned)
+                        self.bytes -= buf.numel()
+                ring = self.slots[key] = [0, [(torch.empty(cls, dtype=torch.uint8).pin_memory(), torch.cuda.Event()) for _ in range(n)], [False] * n]
+                self.bytes += n * cls
+            else:
+                self.slots.move_to_end(key)
+            i = ring[0]
+            raw, ev = ring[1][i]
+            if ring[2][i]:
+                ev.synchronize()  # (eight transfers ago: completed long since unless the host is that far ahead)
+            buf = raw[:nbytes].view(dtype).view(t.shape)
+            buf.copy_(t)  # host-side conversion + copy into the pinned slot
+            out = buf.to(device, non_blocking=True)
+            ev.record(torch.cuda.current_stream(device))
+            ring[2][i] = True
+            ring[0] = (i + 1) % len(ring[1])
         return out
 
 

@@ -367,9 +367,6 @@ class DiTEngine:
             if ops.v_in_place(N) and D <= 512 and M >= 32768 and type(self) is DiTEngine and tuning.on("DL_QK_INPLACE"):
                 w["qk_part"] = torch.empty(1024 * 2 * D, device=dev, dtype=f32)
                 w["dq"] = w["dk"] = None
-                if N == 256 and B <= 1024 and tuning.on("DL_ATTN_BWD_QKN"):  # the QK-norm backward as the attention backward's epilogue
-                    w["qkn_cpart"] = torch.empty(B * d.num_heads * 2 * N, device=dev, dtype=f32)
-                    w["qkn_sync"] = torch.zeros(2 * B + 1, device=dev, dtype=torch.int32)  # (zeroed once: the kernel resets it)
             else:
                 w["dq"], w["dk"] = z(B, d.num_heads, Nd, 64), z(B, d.num_heads, Nd, 64)
             w["dv"] = None if ops.v_in_place(N) else z(B, d.num_heads, Nd, 64)
@@ -521,7 +518,7 @@ class DiTEngine:
                     g_up=self.G(pre + "mlp_input.0.weight"), g_down=self.G(pre + "mlp_input.2.weight"),
                     g_ln1=self.G(pre + "norm_1.weight"), g_ln2=self.G(pre + "norm_2.weight"),
                     g_qk_scale=self.G(pre + "attention.qk_norm.query_norm.scale"), tn_slab=w.get("tn_slab"),
-                    qk_partials=w.get("qk_part"), qkn_cpart=w.get("qkn_cpart"), qkn_sync=w.get("qkn_sync"))
+                    qk_partials=w.get("qk_part"))
             blk.tn_slab_floats = w["tn_slab"].numel() if "tn_slab" in w else 0
         self._blk_cache[key] = blk
         return blk

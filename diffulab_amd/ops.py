@@ -526,14 +526,6 @@ def attn_bwd_tok(q, k, qkv, out, dout, lse, dqkv, B, H, N, dh, scale):
     _call("dl_attn_bwd_tok", _p(q), _p(k), _p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), B, H, N, dh, float(scale), _s())
 
 
-def attn_bwd_qkn(q, k, qkv, out, dout, lse, rrms, scale_q, scale_k, cos, sin, rot, dqkv, dscale, partials, cpart, sync, B, H, N, dh, scale) -> bool:
-    """attention backward + QK-norm / RoPE backward as ONE launch (256-token samples): dqkv leaves as the gradient of the pre-norm
-    qkv rows, dscale [2, D] += the scale gradients; cpart f32 [B*H*2*N] / sync int32 [2B+1] (zeroed once) are the exchange scratch.
-    False: not built for this shape"""
-    return _maybe("dl_attn_bwd_qkn", _p(q), _p(k), _p(qkv), _p(out), _p(dout), _p(lse), _p(rrms), _p(scale_q), _p(scale_k), _p(cos), _p(sin),
-                  rot, _p(dqkv), _p(dscale), _p(partials), _p(cpart), _p(sync), B, H, N, dh, float(scale), _s())
-
-
 def qk_inplace_ok(ws: dict, B: int, tokens: int) -> bool:
     """an engine with the partials scratch ws["qk_part"] takes the token-major attention backward + in-place QK-norm backward for
     this launch: V in place (<= 256 tokens per sample) and at least 32768 token rows (below that the two-kernel form is faster)"""

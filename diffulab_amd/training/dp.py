@@ -70,13 +70,14 @@ class GradReducer:
         # exchange after the backward costs its transfer time.  Which is cheaper depends on RCCL's residency on the node at hand:
         # synchronising steps 2-7 run overlapped, 8-13 with one exchange after the backward (median of the backward-to-finish
         # interval per mode, MAX over ranks); the overlapped default is only left when the single exchange wins by > 3 %.  "1" / "0" pin a mode.
-        # A pinned mode is still MEASURED against the other one during the same warm-up steps (both timings land in `tuned`), so the
-        # first run on a multi-GPU node yields the A/B whatever was pinned; the pin then decides.  DIFFULAB_DP_MEASURE=0 skips that.
+        # A pinned mode is a pin from the first step on: a user who sets "0" because overlapped collectives misbehave on their node
+        # must never run the overlapped schedule.  DIFFULAB_DP_MEASURE=1 opts a pinned run into timing BOTH schedules
+        # during the warm-up steps anyway (both timings land in `tuned`, the pin still decides afterwards).
         mode = os.environ.get("DIFFULAB_DP_OVERLAP", "auto")
         self.overlap = mode != "0"
         self._pinned: bool | None = None if mode == "auto" else (mode != "0")
         self.tuned: dict | None = None
-        measure = mode == "auto" or os.environ.get("DIFFULAB_DP_MEASURE", "1") != "0"
+        measure = mode == "auto" or os.environ.get("DIFFULAB_DP_MEASURE", "0") == "1"
         self._tune = {"step": 0, "marks": []} if (measure and self.enabled) else None
         if self._tune is not None:
             self.overlap = True  # the measurement starts with the overlapped schedule

@@ -20,10 +20,6 @@ SWITCHES: dict[str, tuple[str, str]] = {
     "DL_MLP_RECOMPUTE": ("1", "SwiGLU backward recomputes the MLP-up pre-activations instead of storing them in the forward"),
     "DL_ATTN_V_IN_PLACE": ("1", "attention reads V / writes dV inside the token-major qkv rows (N <= 256)"),
     "DL_QK_INPLACE": ("1", "attention backward writes dQ / dK token-major and the QK-norm backward runs in place on the dqkv rows"),
-    "DL_ATTN_BWD_QKN": ("0", "256-token samples: the QK-norm + RoPE backward runs as the attention backward's epilogue (dl_attn_bwd_qkn: row "
-                        "sums from the dS / S tiles, exchanged between the heads of a sample) instead of a pass of its own over dqkv -- "
-                        "parity-green, measured SLOWER (312 vs 228 us per launch, step 22.0 vs 21.0 ms: the rendezvous of a sample's six "
-                        "workgroups costs 48 us of slot time, the latency-bound in-kernel transform 98 us against the 62 us pass)"),
     "DL_WGRAD_GROUP": ("1", "the four weight gradients of a block as one atomics-free launch (dl_gemm_tn_group)"),
     "DL_WGRAD_INLINE": ("0", "grouped weight gradients on the main stream instead of the side stream"),
     "DL_WGRAD_SERIAL": ("0", "per-problem weight gradients on the main stream (engines without the grouped form)"),

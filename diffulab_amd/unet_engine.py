@@ -416,7 +416,10 @@ class UNetEngine:
         backward: only the last, small batch -- the high-resolution input blocks -- is left for the end) and once at the end."""
         pend = self.__dict__.get("_stage_pending")
         cs = self.__dict__.get("_colsum_pending")
-        if min_pending <= 1 and cs and not pend:  # (the end of a backward without staged convolutions: only column sums wait)
+        # only column sums wait: the end of a backward without staged convolutions -- or channel counts ConvFoldTable does not accept,
+        # where nothing is ever staged and the pending (dy, gradient) pairs would keep every output gradient of the backward alive
+        # until the end (ADVICE r5): flush them once 16 wait, whatever `min_pending` says
+        if cs and not pend and (min_pending <= 1 or len(cs) >= 16):
             self._colsum_pending = []
             if self._use_side:
                 with torch.cuda.stream(self._side_stream()):

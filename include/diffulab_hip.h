@@ -314,18 +314,6 @@ DL_API int dl_attn_bwd_sv(const void* q, const void* k, const void* v, int64_t v
  * head-major dq / dk buffers, and the QK-norm backward reads whole 2D-wide rows instead of H 128-byte segments per row. */
 DL_API int dl_attn_bwd_tok(const void* q, const void* k, const void* qkv, const void* out, const void* dout, const float* lse,
                            void* dqkv, int64_t B, int64_t H, int64_t N, int64_t dh, float scale, dl_stream_t stream);
-/* dl_attn_bwd_tok + dl_qk_norm_rope_bwd_inplace as ONE launch for 256-token samples (DiTAttention backward mmdit.py:81-100 with the
- * QKNorm / RoPE backward nn.py:345-353,427-475 as the attention kernel's epilogue): the D-wide row sums the RMSNorm backward needs
- * are formed from the attention's own dS and S tiles (sum_d q^ dq^ = sum_j dS S), exchanged between the H workgroups of a sample
- * through `cpart` (f32 [B*H*2*N]) and the counters `sync` (u32 [2B+1], ZEROED by the caller before the first call, self-resetting;
- * sync[2B] != 0 afterwards = a rendezvous timed out, results invalid), and every workgroup transforms the dq / dk rows it wrote in place.
- * q, k: normalised + rotated [B,H,N,64] of the forward; qkv: pre-norm rows [B*N, 3D]; dqkv out: gradient of qkv;
- * dscale f32 [2, D] += scale gradients (dscale_partials f32 [B, 2, D] scratch, folded in a fixed order).
- * Returns DL_ERR_UNSUPPORTED for N != 256. */
-DL_API int dl_attn_bwd_qkn(const void* q, const void* k, const void* qkv, const void* out, const void* dout, const float* lse,
-                           const float* rrms, const float* scale_q, const float* scale_k, const float* cos, const float* sin,
-                           int64_t rot, void* dqkv, float* dscale, float* dscale_partials, float* cpart, uint32_t* sync, int64_t B,
-                           int64_t H, int64_t N, int64_t dh, float scale, dl_stream_t stream);
 /* ---- QK-RMSNorm + RoPE without a pass of its own (round 4).  dl_gemm_nt_ssq: the plain bf16 product C = A B^T on the persistent
  * 256 x 384 tiles (the qkv GEMM, mmdit.py:81) whose epilogue also adds the per-row sums of squares of the rounded outputs of the first
  * `ssq_tiles` 384-wide column tiles into ssq f32 [M, ssq_tiles] (the caller zeroes it; two addends per element: bit-reproducible) --
@@ -760,9 +748,6 @@ enum {
                        * dV are written token-major into DQKV (dl_attn_bwd_tok) and DQ / DK are not used */
   DL_BLK_SSQ,         /* f32 [M, 2] ZEROED by the caller before dl_dit_block_fwd, or NULL; with it (row_gemms, V in place) the forward
                        * runs dl_gemm_nt_ssq + dl_attn_fwd_qkn: no QK-norm + RoPE pass of its own */
-  DL_BLK_QKN_CPART,   /* f32 [B * H * 2 * N] scratch, or NULL; with it and DL_BLK_QKN_SYNC (and QK_PARTIALS, N == 256) the attention backward and
-                       * the QK-norm + RoPE backward are ONE launch (dl_attn_bwd_qkn) */
-  DL_BLK_QKN_SYNC,    /* u32 [2 * B + 1] rendezvous counters of dl_attn_bwd_qkn: zeroed once by the caller, self-resetting */
   DL_BLK_NPTR
 };
 typedef struct dl_dit_block_t {

@@ -51,5 +51,9 @@ if N <= 256:  # the training step's pair: QK-norm + RoPE on load (forward), toke
     side = int(N ** 0.5)
     cos, sin = (z.to(dev) for z in rope_grid_tables(side, side, [32, 32], 10_000.0))
     rr = torch.empty(B * N, 2, device=dev)
-    us = timeit(lambda: ops.attn_fwd_qkn(qkv, ssq, sq, sk, cos, sin, q, k, rr, out, lse, B, H, N, dh, 64, scale))
-    print(f"attn_fwd_qkn N={N}: {us:7.1f} us")
+    for mode in (0, 1, 0, 1):  # LAB switch: 0 = chain form (one workgroup per head), 1 = persistent + pipelined where it applies
+        ops.lib().cdll.dl_lab_set_attn_pipe(mode)
+        us = timeit(lambda: ops.attn_fwd_qkn(qkv, ssq, sq, sk, cos, sin, q, k, rr, out, lse, B, H, N, dh, 64, scale))
+        us_i = timeit(lambda: ops.attn_fwd_qkn(qkv, ssq, sq, sk, cos, sin, None, None, None, out, lse, B, H, N, dh, 64, scale))
+        print(f"attn_fwd_qkn N={N} pipe={mode}: training {us:7.1f} us, inference (no q / k / rrms outputs) {us_i:7.1f} us")
+    ops.lib().cdll.dl_lab_set_attn_pipe(1)

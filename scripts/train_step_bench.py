@@ -54,6 +54,9 @@ RS = dict(depth=3, dim=1024, head_dim=64, num_heads=8, ff_mult=4, num_latents=25
 
 
 def main() -> None:
+    if os.environ.get("DL_LAB_ATTN_PIPE"):  # LAB A/B: 0 = the chain forms of the attention kernels everywhere
+        from diffulab_amd import ops
+        ops.lib().cdll.dl_lab_set_attn_pipe(int(os.environ["DL_LAB_ATTN_PIPE"]))
     ap = argparse.ArgumentParser()
     ap.add_argument("config", choices=list(CFG))
     ap.add_argument("--batch", type=int, default=32)

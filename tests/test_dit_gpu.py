@@ -62,7 +62,9 @@ def test_state_dict_contract_and_init():
 
 
 def test_small_model_against_reference_fixture(golden):
-    """flow loss / prediction / every parameter gradient vs the REFERENCE's outputs (dit_small16.npz)."""
+    """flow loss / prediction / every parameter gradient vs the REFERENCE's outputs (dit_small16.npz).  The per-tensor bound is 2e-2,
+    not SURVEY 8(c)'s 1e-2: the REFERENCE ITSELF under bf16 autocast is 9.5e-3 (median) ... 2e-2 off its own fp32 gradients on these
+    inputs (`dit_autocast.npz`, keys s16_*; tests/test_parity_bf16_gpu.py bounds the HIP error by 1.5 x those per tensor)."""
     from diffulab_amd import Diffuser
 
     g = golden("dit_small16")
@@ -214,7 +216,10 @@ def test_guided_step_as_one_paired_forward_equals_the_two_forwards(family, monke
 
 @pytest.mark.timeout(900)
 def test_dit_s2_against_reference_fixture(golden):
-    """BASELINE config dims (DiT-S/2, 4x32x32 latents, 256 tokens): loss, prediction and gradient norms vs reference."""
+    """BASELINE config dims (DiT-S/2, 4x32x32 latents, 256 tokens): loss, prediction and gradient norms vs reference.  Per-tensor
+    bounds 2e-2 (prediction) / 3e-2 (gradients) instead of SURVEY 8(c)'s 1e-2: on these inputs the REFERENCE under bf16 autocast loses
+    1.56e-2 (median) / 2.45e-2 (max) against its own fp32 gradients, 149 of 154 tensors above 1e-2 (`dit_autocast.npz`, keys s2_*);
+    tests/test_parity_bf16_gpu.py::test_hip_error_within_the_reference_s_own_autocast_error is the per-tensor statement."""
     from diffulab_amd import Diffuser
 
     g = golden("dit_s2")
@@ -261,10 +266,15 @@ def test_dit_s2_against_reference_fixture(golden):
 
 @pytest.mark.timeout(900)
 def test_loss_curve_against_reference(golden):
-    """20 AdamW steps of DiT-S/2 on fixed synthetic data: the loss curve of the HIP path vs the REFERENCE's own
-    fp32 curve.  north_star's 1e-4 is an fp32 target (the reference's own bf16-autocast loss differs from its fp32 loss by 1.5e-4
-    at step 0 already); the bf16 regime -- the only one this path has, see Trainer -- measures max 1.5e-3 / mean 4.2e-4 per step
-    (bench.py reports the same figures as config.loss_curve_rel_err) and is held to 2.5e-3 per step and 8e-4 on average."""
+    """20 AdamW steps of DiT-S/2 on fixed synthetic data: the loss curve of the HIP bf16 regime vs the
+    REFERENCE's own fp32 curve, bounded by what the REFERENCE ITSELF loses on the same loop under ``torch.autocast("cpu",
+    bfloat16)`` (`loss_curve_autocast.npz`, generated by make_golden.py curve_autocast from the imported reference: max 1.84e-3,
+    mean 4.7e-4 against its fp32 curve): the maximum within 1.5 x the reference's maximum, the mean within 1.5 x the reference's mean,
+    and per step ``max(1e-3, 1.5 x`` the reference's largest autocast error within two steps of that step ``)``.  (Point by point the
+    two error sequences are rounding noise of one scale and different sign patterns -- measured: step 1 HIP 1.14e-3 / reference
+    1.84e-3, step 3 HIP 1.53e-3 / reference 8.7e-4 -- so the per-step bound uses the reference's local envelope, not its value at
+    the same index; HIP max 1.5e-3 / mean 4.0e-4 against the reference's 1.84e-3 / 4.7e-4.)  north_star's 1e-4 is an fp32 target -- tests/test_fp32_gpu.py holds the fp32 regime
+    to it.  bench.py reports the same figures as config.loss_curve_rel_err(.reference_under_autocast)."""
     from diffulab_amd import Diffuser
     from diffulab_amd.training import FusedAdamW
 
@@ -288,8 +298,14 @@ def test_loss_curve_against_reference(golden):
         got.append(loss.item())
     got, ref = np.array(got), g["losses"]
     err = np.abs(got - ref) / ref
-    print("loss curve rel err per step:", err)
-    assert len(ref) == 20 and err.max() < 2.5e-3 and err.mean() < 8e-4, (err.max(), err.mean())
+    ra = golden("loss_curve_autocast")["rel_err_vs_fp32"]
+    env = np.array([ra[max(0, s - 2) : s + 3].max() for s in range(len(ra))])
+    bound = np.maximum(1e-3, 1.5 * env)
+    print("loss curve rel err per step:", err, "\nreference under autocast:", ra, "\nworst err/bound:", (err / bound).max())
+    assert len(ref) == 20 and len(ra) == 20
+    assert err.max() <= 1.5 * ra.max(), (err.max(), ra.max())
+    assert err.mean() <= 1.5 * ra.mean(), (err.mean(), ra.mean())
+    assert (err <= bound).all(), (err, bound)
 
 
 def test_cifar_dit_dims_against_oracle():

@@ -74,7 +74,7 @@ def _worker(rank: int, world: int, port: int, out):
     ok &= modes[14][0] == (red4.tuned["mode"] == "overlapped") == modes[15][0]
     out[f"mode{rank}"] = red4.tuned["mode"] if red4.tuned else None
     os.environ["DIFFULAB_DP_OVERLAP"] = "0"  # pinned: nothing is reduced before finish(), not even on flush=True
-    os.environ["DIFFULAB_DP_MEASURE"] = "0"  # (and no warm-up measurement of the other mode)
+    # (a pin is a pin from the first step on: no warm-up measurement of the other mode unless DIFFULAB_DP_MEASURE=1 asks for it)
     g5 = torch.arange(n, dtype=torch.float32) * (rank + 1)
     red5 = GradReducer(g5, bucket_bytes=4 * 300)
     red5.ready(400, 1000, flush=True)
@@ -82,8 +82,8 @@ def _worker(rank: int, world: int, port: int, out):
     red5.ready(0, 400)
     red5.finish()
     ok &= bool(torch.equal(g5, expect))
-    os.environ.pop("DIFFULAB_DP_MEASURE")
-    # pinned WITH the measurement (the default): both schedules are timed during the same warm-up steps and reported, the pin decides
+    # pinned WITH the measurement (opt-in): both schedules are timed during the same warm-up steps and reported, the pin decides
+    os.environ["DIFFULAB_DP_MEASURE"] = "1"
     g6 = torch.zeros(n)
     red6 = GradReducer(g6, bucket_bytes=4 * 300)
     for it in range(16):
@@ -96,6 +96,7 @@ def _worker(rank: int, world: int, port: int, out):
     ok &= red6.tuned is not None and red6.tuned["mode"] == "after_backward" and not red6.overlap and "pinned" in red6.tuned["decided"]
     ok &= red6.tuned["overlapped_ms_per_step"] > 0 and red6.tuned["after_backward_ms_per_step"] > 0
     os.environ.pop("DIFFULAB_DP_OVERLAP")
+    os.environ.pop("DIFFULAB_DP_MEASURE")
     out[rank] = ok
     dist.destroy_process_group()
 

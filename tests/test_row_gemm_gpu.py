@@ -239,3 +239,38 @@ def test_qkv_gemm_with_row_statistics_and_attention_with_qk_norm_on_load(ops, B,
     # shapes without the persistent 384-wide tiling decline (the engine keeps the launch pair)
     small = dev_bf(torch.zeros(8 * 256, D))
     assert not ops.gemm_nt_ssq(small, w, torch.empty(8 * 256, 3 * D, **bf), torch.zeros(8 * 256, 2, device=DEV))
+
+
+@pytest.mark.parametrize("B,axes,train", [(256, [32, 32], True), (130, [32, 32], True), (131, [16, 16], False), (128, None, True)])
+def test_pipelined_attention_forward_equals_the_chain_form_bit_for_bit(ops, B, axes, train):
+    """round 6: from three (sample, head) items per CU dl_attn_fwd_qkn runs `attn_fwd_qkn_pipe_k` -- one persistent workgroup per CU,
+    K / V tiles double-buffered, the next item's loads in flight under the current item's MFMAs, O stored one item late -- with the
+    arithmetic of the chain form `attn_fwd_qkn_k` in the same order: every output (O, lse, the normalised q / k, rrms) bit for bit
+    equal to the chain form (the lab switch dl_lab_set_attn_pipe selects it).  B = 130 / 131: item runs that end inside a sample and
+    workgroups with a shorter last run; train = False: the inference form (no q / k / rrms outputs)."""
+    H, dh, Nt = 6, 64, 256
+    M = B * Nt
+    bf = dict(device=DEV, dtype=torch.bfloat16)
+    qkv = dev_bf(synth.normal("pp.qkv", (M, 3 * D)))
+    ssq = torch.stack([qkv[:, :D].float().square().sum(1), qkv[:, D : 2 * D].float().square().sum(1)], 1).contiguous()
+    sq = (1 + synth.normal("pp.sq", (D,), std=0.1)).to(DEV)
+    sk = (1 + synth.normal("pp.sk", (D,), std=0.1)).to(DEV)
+    rot = sum(axes) if axes else 0
+    cos, sin = (t.to(DEV).contiguous() for t in odit.rope_tables(16, 16, axes, 10_000.0)) if axes else (None, None)
+
+    def run(mode):
+        ops.lib().cdll.dl_lab_set_attn_pipe(mode)
+        try:
+            q1, k1 = (torch.full((B, H, Nt, dh), 7.0, **bf) for _ in range(2)) if train else (None, None)
+            r1 = torch.full((M, 2), 7.0, device=DEV) if train else None
+            o1, l1 = torch.full((M, D), 7.0, **bf), torch.full((B, H, Nt), 7.0, device=DEV)
+            ops.attn_fwd_qkn(qkv, ssq, sq, sk, cos, sin, q1, k1, r1, o1, l1, B, H, Nt, dh, rot, dh**-0.5)
+            torch.cuda.synchronize()
+        finally:
+            ops.lib().cdll.dl_lab_set_attn_pipe(1)
+        return [t for t in (q1, k1, r1, o1, l1) if t is not None]
+
+    chain, pipe, again = run(0), run(1), run(1)
+    assert all(same(x, y) for x, y in zip(chain, pipe))
+    assert all(same(x, y) for x, y in zip(pipe, again))
+    assert float(pipe[-2].float().abs().max()) < 7.0  # (every O row was written)
