@@ -23,6 +23,25 @@ static int fork_to_side(hipStream_t main, hipStream_t side) {
   return hipStreamWaitEvent(side, g_blk_event, 0) == hipSuccess ? 0 : -1;
 }
 
+// the same hand-off for hosts that issue the launches themselves (the Python engines' side streams, launch plans): everything queued
+// on `waited` so far happens before anything queued on `waiter` from now on.  One thread-local event, re-recorded per call (a wait
+// refers to the record that precedes it).
+extern "C" int dl_stream_wait_stream(dl_stream_t waiter, dl_stream_t waited) {
+  if (fork_to_side((hipStream_t)waited, (hipStream_t)waiter) != 0) {
+    dl_set_error("dl_stream_wait_stream: %s", hipGetErrorString(hipGetLastError()));
+    return DL_ERR_LAUNCH;
+  }
+  return DL_OK;
+}
+extern "C" int dl_memset_zero(void* p, int64_t bytes, dl_stream_t stream) {
+  DL_CHECK_ARG(p && bytes >= 0, "dl_memset_zero: bad args");
+  if (bytes && hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream) != hipSuccess) {
+    dl_set_error("dl_memset_zero: %s", hipGetErrorString(hipGetLastError()));
+    return DL_ERR_LAUNCH;
+  }
+  return DL_OK;
+}
+
 #define P(k) (b->p[DL_BLK_##k])
 #define RUN(call)               \
   do {                          \

@@ -951,7 +951,10 @@ template <bool CONV>
 __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __restrict__ A, int64_t lda,
                                                                   const bf16_t* __restrict__ Bm, int64_t ldb,
                                                                   float* __restrict__ C, int64_t ldc, int M, int N,
-                                                                  int R, int steps_per_split, ConvGeom cg) {
+                                                                  int R, int steps_per_split, ConvGeom cg, int64_t part_stride) {
+  // part_stride > 0: split s stores its partial [M, N] image with plain stores at C + s * part_stride (every split owns at least
+  // one step, so every image is written in full; the caller folds the images in a fixed order: bit-reproducible, and a plain
+  // 128-byte row store costs a fraction of 32 f32 atomics); 0: the splits meet in C through f32 atomics
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // block -> (A-panel unit = (split, m-tile), n-tile): the tiles_n workgroups that read the same A panel get block
   // ids congruent mod 8, i.e. land on ONE XCD and share the panel in its L2 (one HBM read instead of tiles_n)
@@ -1080,7 +1083,10 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 96 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < M) unsafeAtomicAdd(&C[(int64_t)m * ldc + n], acc[i][j][r]);
+        if (m < M) {
+          if (part_stride > 0) C[(int64_t)split * part_stride + (int64_t)m * ldc + n] = acc[i][j][r];
+          else unsafeAtomicAdd(&C[(int64_t)m * ldc + n], acc[i][j][r]);
+        }
       }
     }
 }
@@ -1128,7 +1134,7 @@ extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t 
       splits = (nsteps + sps - 1) / sps;
       const int units = (tiles_m * splits + 7) & ~7;  // surplus units exit at once
       hipLaunchKernelGGL(gemm_tn_big_k<false>, units * (int)(N / WBN), BIG_THREADS, 2 * W_STAGE, (hipStream_t)stream,
-                         (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)R, sps, ConvGeom{});
+                         (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)R, sps, ConvGeom{}, (int64_t)0);
       DL_LAUNCH_CHECK();
       return DL_OK;
     }
@@ -1811,51 +1817,85 @@ extern "C" int dl_conv3x3_nt(const void* x, int64_t ldx, int64_t Bn, int64_t H, 
 }
 /* weight gradient, transposed: g[(tap, ci), co] += sum_p x[p + shift(tap), ci] * dY[p, co]; dY rows [R, ldy] with R a multiple
  * of 64 and rows >= B*H*W zero; g f32 [9*Ci, ldg] accumulated into (dl_conv3x3_wgrad_fold finishes the job). */
-extern "C" int dl_conv3x3_wgrad_tn(const void* x, int64_t ldx, int64_t Bn, int64_t H, int64_t W, int64_t Ci, const void* dY,
-                                   int64_t ldy, int64_t R, int64_t Co, float* g, int64_t ldg, const void* zero,
-                                   int max_workgroups, dl_stream_t stream) {
-  DL_CHECK_ARG(x && dY && g && zero && Bn > 0 && H > 0 && W > 0 && Co > 0, "dl_conv3x3_wgrad_tn: bad args");
-  if (Ci % 128 != 0) return DL_ERR_UNSUPPORTED;
-  DL_CHECK_ARG(R % BK == 0 && R >= Bn * H * W && Co % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldy >= Co && ldg >= Co,
-               "dl_conv3x3_wgrad_tn: dims");
-  DL_CHECK_ARG((((uintptr_t)x | (uintptr_t)dY | (uintptr_t)zero) & 15) == 0, "dl_conv3x3_wgrad_tn: 16-byte alignment");
-  const int64_t M = 9 * Ci, N = Co;
-  const ConvGeom cg = make_conv_geom(H, W, Ci, ldx, Bn * H * W, zero);
-  const int nsteps = (int)(R / BK);
-  {
-    static DevOnce once;
-    const int n_cu = dev_cus(once, [] {
-      (void)hipFuncSetAttribute((const void*)gemm_tn_big_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE);
-    });
+// split plan of the implicit-GEMM weight gradient: which kernel, how many R-splits, steps per split
+struct ConvWgradPlan {
+  bool big;
+  int splits, sps, tiles_m, tiles_n, ntile;
+};
+static ConvWgradPlan conv_wgrad_plan(int64_t M, int64_t N, int nsteps, int max_workgroups, int n_cu) {
+  ConvWgradPlan p{};
 #ifndef WGRAD_BIG_MIN_STEPS
 #define WGRAD_BIG_MIN_STEPS 64
 #endif
-    if (M % WBM == 0 && N % WBN == 0 && nsteps >= WGRAD_BIG_MIN_STEPS) {  // same unit / split budget as dl_gemm_tn
-      const int tiles_m = (int)(M / WBM), tiles_n = (int)(N / WBN);
-      const int budget = (max_workgroups > 0 && max_workgroups < n_cu) ? max_workgroups : n_cu;
-      int padded_max = (budget / tiles_n) & ~7;
-      if (padded_max < 8) padded_max = 8;
-      int splits = padded_max / tiles_m;
-      if (splits < 1) splits = 1;
-      if (splits > nsteps / 8) splits = nsteps / 8;
-      const int sps = (nsteps + splits - 1) / splits;
-      splits = (nsteps + sps - 1) / sps;
-      const int units = (tiles_m * splits + 7) & ~7;
-      hipLaunchKernelGGL(gemm_tn_big_k<true>, units * tiles_n, BIG_THREADS, 2 * W_STAGE, (hipStream_t)stream, (const bf16_t*)x,
-                         ldx, (const bf16_t*)dY, ldy, g, ldg, (int)M, (int)N, (int)R, sps, cg);
-      DL_LAUNCH_CHECK();
-      return DL_OK;
-    }
+  if (M % WBM == 0 && N % WBN == 0 && nsteps >= WGRAD_BIG_MIN_STEPS) {  // same unit / split budget as dl_gemm_tn
+    p.big = true;
+    p.tiles_m = (int)(M / WBM), p.tiles_n = (int)(N / WBN);
+    const int budget = (max_workgroups > 0 && max_workgroups < n_cu) ? max_workgroups : n_cu;
+    int padded_max = (budget / p.tiles_n) & ~7;
+    if (padded_max < 8) padded_max = 8;
+    int splits = padded_max / p.tiles_m;
+    if (splits < 1) splits = 1;
+    if (splits > nsteps / 8) splits = nsteps / 8;
+    p.sps = (nsteps + splits - 1) / splits;
+    p.splits = (nsteps + p.sps - 1) / p.sps;
+    return p;
   }
-  const int ntile = cdiv(M, BM) * cdiv(N, BN);
-  int splits = (1024 + ntile - 1) / ntile;
+  p.ntile = cdiv(M, BM) * cdiv(N, BN);
+  int splits = (1024 + p.ntile - 1) / p.ntile;
   if (splits > nsteps) splits = nsteps;
   if (splits < 1) splits = 1;
-  const int sps = (nsteps + splits - 1) / splits;
-  splits = (nsteps + sps - 1) / sps;
-  hipLaunchKernelGGL(gemm_tn_k<true>, ntile * splits, NT_THREADS, 65536, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                     (const bf16_t*)dY, ldy, g, ldg, (int)M, (int)N, (int)R, sps, cg, (int64_t)0);
+  p.sps = (nsteps + splits - 1) / splits;
+  p.splits = (nsteps + p.sps - 1) / p.sps;
+  return p;
+}
+static int conv_wgrad_cus() {
+  static DevOnce once;
+  return dev_cus(once, [] {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_big_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE);
+  });
+}
+static int conv_wgrad_launch(const void* x, int64_t ldx, int64_t Bn, int64_t H, int64_t W, int64_t Ci, const void* dY, int64_t ldy,
+                             int64_t R, int64_t Co, float* g, int64_t ldg, int64_t part_stride, int64_t max_parts, const void* zero,
+                             int max_workgroups, dl_stream_t stream, const char* who) {
+  DL_CHECK_ARG(x && dY && g && zero && Bn > 0 && H > 0 && W > 0 && Co > 0, "%s: bad args", who);
+  if (Ci % 128 != 0) return DL_ERR_UNSUPPORTED;
+  DL_CHECK_ARG(R % BK == 0 && R >= Bn * H * W && Co % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldy >= Co && ldg >= Co, "%s: dims", who);
+  DL_CHECK_ARG((((uintptr_t)x | (uintptr_t)dY | (uintptr_t)zero) & 15) == 0, "%s: 16-byte alignment", who);
+  const int64_t M = 9 * Ci, N = Co;
+  const ConvGeom cg = make_conv_geom(H, W, Ci, ldx, Bn * H * W, zero);
+  const int nsteps = (int)(R / BK);
+  const ConvWgradPlan p = conv_wgrad_plan(M, N, nsteps, max_workgroups, conv_wgrad_cus());
+  if (part_stride > 0)
+    DL_CHECK_ARG(p.splits <= max_parts && part_stride >= M * ldg, "%s: %d partial images of %lld floats needed, room for %lld of %lld", who,
+                 p.splits, (long long)(M * ldg), (long long)max_parts, (long long)part_stride);
+  if (p.big) {
+    const int units = (p.tiles_m * p.splits + 7) & ~7;
+    hipLaunchKernelGGL(gemm_tn_big_k<true>, units * p.tiles_n, BIG_THREADS, 2 * W_STAGE, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                       (const bf16_t*)dY, ldy, g, ldg, (int)M, (int)N, (int)R, p.sps, cg, part_stride);
+  } else {
+    hipLaunchKernelGGL(gemm_tn_k<true>, p.ntile * p.splits, NT_THREADS, 65536, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                       (const bf16_t*)dY, ldy, g, ldg, (int)M, (int)N, (int)R, p.sps, cg, part_stride);
+  }
   DL_LAUNCH_CHECK();
   return DL_OK;
+}
+extern "C" int dl_conv3x3_wgrad_tn(const void* x, int64_t ldx, int64_t Bn, int64_t H, int64_t W, int64_t Ci, const void* dY,
+                                   int64_t ldy, int64_t R, int64_t Co, float* g, int64_t ldg, const void* zero,
+                                   int max_workgroups, dl_stream_t stream) {
+  return conv_wgrad_launch(x, ldx, Bn, H, W, Ci, dY, ldy, R, Co, g, ldg, 0, 0, zero, max_workgroups, stream, "dl_conv3x3_wgrad_tn");
+}
+/* the same product WITHOUT atomics: the R-splits store `n_parts` partial images g + s * part_stride (f32 [9*Ci, ldg] each, written in
+ * full with plain stores; nothing is read, nothing needs zeroing) that dl_conv3x3_wgrad_fold_batched adds in a fixed order.
+ * dl_conv3x3_wgrad_tn_nparts = the number of images this shape produces on this device (0: Ci % 128 != 0, unsupported). */
+extern "C" int dl_conv3x3_wgrad_tn_nparts(int64_t Ci, int64_t Co, int64_t R, int max_workgroups) {
+  if (Ci % 128 != 0 || R % BK != 0 || Co <= 0) return 0;
+  return conv_wgrad_plan(9 * Ci, Co, (int)(R / BK), max_workgroups, conv_wgrad_cus()).splits;
+}
+extern "C" int dl_conv3x3_wgrad_tn_parts(const void* x, int64_t ldx, int64_t Bn, int64_t H, int64_t W, int64_t Ci, const void* dY,
+                                         int64_t ldy, int64_t R, int64_t Co, float* g, int64_t ldg, int64_t part_stride,
+                                         int64_t max_parts, const void* zero, int max_workgroups, dl_stream_t stream) {
+  DL_CHECK_ARG(part_stride > 0 && max_parts > 0, "dl_conv3x3_wgrad_tn_parts: part_stride / max_parts");
+  return conv_wgrad_launch(x, ldx, Bn, H, W, Ci, dY, ldy, R, Co, g, ldg, part_stride, max_parts, zero, max_workgroups, stream,
+                           "dl_conv3x3_wgrad_tn_parts");
 }
 

@@ -1050,11 +1050,18 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_fold_batched_k(const dl_fol
   const int co0 = (int)(t / tci) * CW_T, ci0 = (int)(t % tci) * CW_T;
   float* g = (float*)d.g;
   float* dw = (float*)d.dw;
+  const int n_img = d.n_img > 1 ? (int)d.n_img : 1;
   for (int i = threadIdx.x; i < CW_T * CW_T * 9; i += 256) {
     const int col = i & (CW_T - 1), rest = i / CW_T, cil = rest % CW_T, tap = rest / CW_T;
     float* src = g + (int64_t)(tap * Ci + ci0 + cil) * d.ldg + co0 + col;
-    tile[col * CW_P + cil * 9 + tap] = *src;
-    if (clear) *src = 0.f;
+    if (d.n_img >= 1) {  // partial images of dl_conv3x3_wgrad_tn_parts: added in image order, nothing to clear
+      float v = *src;
+      for (int s = 1; s < n_img; ++s) v += src[(int64_t)s * d.img_stride];
+      tile[col * CW_P + cil * 9 + tap] = v;
+    } else {
+      tile[col * CW_P + cil * 9 + tap] = *src;
+      if (clear) *src = 0.f;
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < CW_T * CW_T * 9; i += 256) {

@@ -50,6 +50,85 @@ def _call(name: str, *args) -> None:
     if _LIB is None:
         _LIB = lib()
     _LIB.call(name, *args)
+    if _REC is not None:
+        _REC.calls.append((_LIB._fns[name][0], args))
+
+
+# ------------------------------------------------------------------ launch plans
+class LaunchPlan:
+    """One engine pass (a training forward, a backward) as a flat list of C calls with their final arguments, recorded while the
+    pass runs once and re-issued by `replay()` afterwards: the launch sequence of an engine is static for a given input shape, and
+    on the host-bound configurations (the UNet at its configured batch: 716 launches, ~24 us of Python per launch against ~5 us
+    inside the HIP runtime) the step time IS the time the host needs to walk the engine's Python.  (A hipGraph of the same step
+    replays SLOWER than the eager launches on this runtime: DESIGN.md section 6, round 6.)  What makes a pass recordable: every
+    action is a C-ABI call with plain arguments -- kernels, `dl_memset_zero`, `dl_stream_wait_stream` -- or a registered host
+    closure (`rec`); every buffer the calls name is kept alive by the plan (`keep`); per-call inputs live in static buffers the
+    caller copies into before a replay."""
+
+    __slots__ = ("calls", "held", "state", "inputs", "out", "bwd")
+
+    def __init__(self) -> None:
+        self.calls: list = []
+        self.held: list = []
+        self.state = self.inputs = self.out = self.bwd = None
+
+    def replay(self) -> None:
+        for fn, args in self.calls:
+            if fn(*args):
+                raise RuntimeError(f"launch plan: a replayed call failed: {lib().cdll.dl_last_error().decode()}")
+
+
+_REC: LaunchPlan | None = None
+
+
+class recording:
+    """``with ops.recording(plan):`` every ops call inside is executed AND appended to the plan"""
+
+    def __init__(self, plan: LaunchPlan) -> None:
+        self.plan = plan
+
+    def __enter__(self) -> LaunchPlan:
+        global _REC
+        self.prev, _REC = _REC, self.plan
+        return self.plan
+
+    def __exit__(self, *exc) -> None:
+        global _REC
+        _REC = self.prev
+
+
+def is_recording() -> bool:
+    return _REC is not None
+
+
+def keep(obj):
+    """the plan being recorded (if any) holds a reference to `obj` (a buffer or table whose raw address a recorded call carries)"""
+    if _REC is not None:
+        _REC.held.append(obj)
+    return obj
+
+
+def rec(fn) -> None:
+    """run the host closure `fn` now; a plan being recorded re-runs it at the same position of every replay"""
+    fn()
+    if _REC is not None:
+        def again(f=fn):
+            f()
+            return 0
+        _REC.calls.append((again, ()))
+
+
+def zero_(t: Tensor) -> Tensor:
+    """t.zero_() as a C call on the current stream (recordable); t contiguous"""
+    assert t.is_contiguous()
+    _call("dl_memset_zero", _p(t), t.numel() * t.element_size(), _s())
+    return t
+
+
+def stream_wait(waiter: int, waited: int) -> None:
+    """raw stream handles: what is queued on `waited` so far happens before what is queued on `waiter` from now on"""
+    if waiter != waited:
+        _call("dl_stream_wait_stream", waiter, waited)
 
 
 # ------------------------------------------------------------------ diffusion heads
@@ -729,7 +808,8 @@ class ConvCastTable:
 
 class ConvFoldTable:
     """device table for dl_conv3x3_wgrad_fold_batched: every staged convolution weight gradient (g f32 [9 Ci, ldg], transposed as
-    dl_conv3x3_wgrad_tn leaves it) folded into its [Co, Ci, 3, 3] gradient by ONE launch.  entries: (g, dw)"""
+    dl_conv3x3_wgrad_tn leaves it, or f32 [n_img, 9 Ci, ldg]: the partial images of dl_conv3x3_wgrad_tn_parts, added in image
+    order) folded into its [Co, Ci, 3, 3] gradient by ONE launch.  entries: (g, dw)"""
 
     @staticmethod
     def accepts(co: int, ci: int) -> bool:
@@ -740,7 +820,7 @@ class ConvFoldTable:
 
         class Desc(ctypes.Structure):
             _fields_ = [("g", ctypes.c_void_p), ("ldg", ctypes.c_int64), ("dw", ctypes.c_void_p), ("Co", ctypes.c_int64),
-                        ("Ci", ctypes.c_int64), ("tile_begin", ctypes.c_int64)]
+                        ("Ci", ctypes.c_int64), ("tile_begin", ctypes.c_int64), ("n_img", ctypes.c_int64), ("img_stride", ctypes.c_int64)]
 
         arr = (Desc * len(entries))()
         tiles = 0
@@ -748,8 +828,12 @@ class ConvFoldTable:
         for i, (g, dw) in enumerate(entries):
             co, ci = dw.shape[0], dw.shape[1]
             assert dw.is_contiguous() and dw.dtype == torch.float32 and g.dtype == torch.float32 and self.accepts(co, ci)
-            assert g.shape[0] >= 9 * ci and g.stride(0) >= co
-            arr[i] = Desc(_p(g), g.stride(0), _p(dw), co, ci, tiles)
+            if g.dim() == 3:  # partial images
+                assert g.shape[1] >= 9 * ci and g.stride(1) >= co
+                arr[i] = Desc(_p(g), g.stride(1), _p(dw), co, ci, tiles, g.shape[0], g.stride(0))
+            else:
+                assert g.shape[0] >= 9 * ci and g.stride(0) >= co
+                arr[i] = Desc(_p(g), g.stride(0), _p(dw), co, ci, tiles, 0, 0)
             tiles += (co // 32) * (ci // 32)
         self.n, self.tiles = len(entries), tiles
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
@@ -817,11 +901,14 @@ def im2col3x3(x, cols, B, H, W, C):
 
 def _maybe(name: str, *args) -> bool:
     """call an entry point that may answer DL_ERR_UNSUPPORTED (-3): False then, True on success"""
-    rc = getattr(lib().cdll, name)(*args)
+    fn = getattr(lib().cdll, name)
+    rc = fn(*args)
     if rc == -3:
         return False
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {lib().cdll.dl_last_error().decode()}")
+    if _REC is not None:
+        _REC.calls.append((fn, args))
     return True
 
 
@@ -840,6 +927,18 @@ def conv3x3_wgrad_tn(x, B, H, W, ci, dy, co, g, zero, max_wgs: int = 0) -> bool:
     launches beside the convolution chain); False -> use im2col3x3 + gemm_tn"""
     return _maybe("dl_conv3x3_wgrad_tn", _p(x), x.stride(0), B, H, W, ci, _p(dy), dy.stride(0), dy.shape[0], co, _p(g),
                   g.stride(0), _p(zero), int(max_wgs), _s())
+
+
+def conv3x3_wgrad_nparts(ci: int, co: int, R: int, max_wgs: int = 0) -> int:
+    """partial images dl_conv3x3_wgrad_tn_parts writes for this shape on this device (0: shape not supported)"""
+    return int(lib().cdll.dl_conv3x3_wgrad_tn_nparts(ci, co, R, int(max_wgs)))
+
+
+def conv3x3_wgrad_tn_parts(x, B, H, W, ci, dy, co, g, zero, max_wgs: int = 0) -> None:
+    """the transposed weight gradient as partial images g[s] f32 [n_parts, 9 ci (padded), co]: plain stores, no atomics; folded in a
+    fixed order by ConvFoldTable"""
+    _call("dl_conv3x3_wgrad_tn_parts", _p(x), x.stride(0), B, H, W, ci, _p(dy), dy.stride(0), dy.shape[0], co, _p(g), g.stride(1),
+          g.stride(0), g.shape[0], _p(zero), int(max_wgs), _s())
 
 
 def cast_conv3x3_weight(w, wf, wd):

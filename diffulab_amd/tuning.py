@@ -37,12 +37,19 @@ SWITCHES: dict[str, tuple[str, str]] = {
     "DL_HIPGRAPH": ("1", "samplers replay the denoiser forward as a captured hipGraph"),
     "DL_CFG_PAIR": ("1", "guided sampler steps run the conditional and the label-dropped forward as ONE forward over [x ; x] "
                     "(class-conditional MMDiT / DDT / UNetModel: same values per row, the weights stream once)"),
+    "DL_LAUNCH_PLAN": ("1", "UNet (bf16 regime): a training forward / backward is recorded on its second run for a shape and re-issued as a "
+                       "flat list of C calls afterwards (ops.LaunchPlan: the host walks ~24 us of Python per launch otherwise, 716 "
+                       "launches per step)"),
     "DL_UNET_SIDE": ("1", "UNet weight gradients on a side stream"),
     "DL_UNET_SPLITK": ("1", "split-K convolutions at the UNet's low-resolution levels (partial images + fixed-order fold: -7 % per step)"),
     "DL_UNET_WGRAD_WGS": ("0", "workgroup cap of the UNet's side-stream convolution weight gradients (0 = one per CU; round 5, B = 128: "
                           "0 -> 28.2 ms/step, 224 -> 28.4, 192 -> 28.35, 160 -> 29.0; everything on one stream: 31.1)"),
     "DL_UNET_FOLD_BATCHED": ("1", "UNet convolution weight gradients stay in a persistent transposed staging arena during the backward; one "
                              "launch at its end folds all of them into the [Co, Ci, 3, 3] gradients (instead of a zero-fill and a fold per convolution)"),
+    "DL_UNET_WGRAD_PARTS": ("0", "UNet convolution weight gradients as partial images per R-split (plain stores + fixed-order fold in the batched "
+                            "fold launch: bit-reproducible) instead of f32 atomics into one image -- measured SLOWER (B = 128: 28.5 vs 26.8 ms "
+                            "per step, B = 64: 21.5 vs 20.1: up to 85 images of the small high-resolution gradients, 2.8 GB of stage "
+                            "written and read per step beside the main chain, against atomics the side stream hides)"),
     "DL_UNET_DET_COLSUM": ("0", "UNet bias gradients through the bit-reproducible column sum (measured 2 % slower)"),
 }
 

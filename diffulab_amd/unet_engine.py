@@ -317,8 +317,13 @@ class UNetEngine:
 
     # ------------------------------------------------------------------ small helpers
     def _new(self, *shape: int, dtype=torch.bfloat16, zero: bool = False) -> Tensor:
-        with torch.inference_mode(False):
-            return (torch.zeros if zero else torch.empty)(*shape, device=self.dev, dtype=dtype)
+        if torch.is_inference_mode_enabled():  # (samplers run under inference_mode; a training pass does not pay for the context)
+            with torch.inference_mode(False):
+                t = torch.empty(*shape, device=self.dev, dtype=dtype)
+        else:
+            t = torch.empty(*shape, device=self.dev, dtype=dtype)
+        ops.keep(t)  # (a launch plan being recorded owns every buffer its calls name)
+        return ops.zero_(t) if zero else t
 
     def _scr(self, key: str, numel: int, dtype=torch.bfloat16) -> Tensor:
         """grow-only scratch (im2col matrices, wgrad staging): reused by every conv, all launches are on one stream"""
@@ -327,6 +332,7 @@ class UNetEngine:
             with torch.inference_mode(False):
                 t = torch.empty(numel, device=self.dev, dtype=dtype)
             self._scratch[key] = t
+        ops.keep(t)  # (a later, larger request replaces the entry: a recorded plan keeps the buffer it was recorded on)
         return t[:numel]
 
     def _splitk(self, M: int, n: int) -> Tensor | None:
@@ -363,13 +369,13 @@ class UNetEngine:
         if not self._use_side:
             fn()
             return
-        main = torch.cuda.current_stream()
+        main = ops._s()
         side = self._side_stream()
-        ev = main.record_event()
-        for t in tensors:
-            t.record_stream(side)
+        if not ops.is_recording():  # (a plan owns its buffers: nothing is recycled under it)
+            for t in tensors:
+                t.record_stream(side)
+        ops.stream_wait(side.cuda_stream, main)  # (an event record + stream wait behind the C ABI: a recordable call)
         with torch.cuda.stream(side):
-            side.wait_event(ev)
             fn()
 
     def _side_stream(self) -> "torch.cuda.Stream":
@@ -399,15 +405,26 @@ class UNetEngine:
         else:
             ops.colsum(dy, self.Gr(bname), M, co)
 
-    def _wgrad_stage(self, name: str, ldk: int, co: int, ci: int) -> Tensor | None:
-        """this convolution's slice [ldk, co] f32 of the weight-gradient staging arena (zero between backwards), or None"""
+    def _wgrad_stage(self, name: str, ldk: int, co: int, ci: int, R: int) -> Tensor | None:
+        """this convolution's weight-gradient stage, or None.  Default (DL_UNET_WGRAD_PARTS): the partial images [n_parts, ldk, co]
+        f32 the R-splits of dl_conv3x3_wgrad_tn_parts STORE (no atomics, nothing to zero; the batched fold adds them in image order:
+        bit-reproducible); shapes the implicit-GEMM kernel does not take (Ci % 128) and DL_UNET_WGRAD_PARTS=0: one [ldk, co] image
+        the splits add into with f32 atomics (zero between backwards: the fold clears it)."""
         if not (tuning.on("DL_UNET_FOLD_BATCHED") and ops.ConvFoldTable.accepts(co, ci)):
             return None
+        nparts = 0
+        if tuning.on("DL_UNET_WGRAD_PARTS"):
+            cache = self.__dict__.setdefault("_nparts", {})
+            nparts = cache.get((ci, co, R))
+            if nparts is None:
+                nparts = cache[(ci, co, R)] = ops.conv3x3_wgrad_nparts(ci, co, R, tuning.integer("DL_UNET_WGRAD_WGS", 0))
         st = self.__dict__.setdefault("_stage", {})
-        g = st.get(name)
+        key = (name, nparts)
+        g = st.get(key)
         if g is None:
-            g = st[name] = self._new(ldk, co, dtype=torch.float32, zero=True)
-        self.__dict__.setdefault("_stage_pending", []).append(name)
+            g = st[key] = self._new(nparts, ldk, co, dtype=torch.float32) if nparts else self._new(ldk, co, dtype=torch.float32, zero=True)
+        ops.keep(g)
+        self.__dict__.setdefault("_stage_pending", []).append(key)
         return g
 
     def _fold_staged(self, min_pending: int = 1) -> None:
@@ -435,7 +452,8 @@ class UNetEngine:
         if table is None:
             if len(tables) > 64:  # (a re-bound gradient arena: the old tables hold dead pointers)
                 tables.clear()
-            table = tables[key] = ops.ConvFoldTable([(self._stage[n], self.Gr(n)) for n in pend])
+            table = tables[key] = ops.ConvFoldTable([(self._stage[k], self.Gr(k[0])) for k in pend])
+        ops.keep(table)
         self._stage_pending = []
         self._colsum_pending = []
         if self._use_side:
@@ -461,8 +479,11 @@ class UNetEngine:
             # the gradient lands transposed, [(tap, ci), co] f32 (9*Ci rows fit the 384-row wgrad tiles), in this convolution's slice of
             # a persistent staging arena; ONE launch at the end of the backward folds every slice into its [Co, Ci, 3, 3] gradient and
             # clears it (_fold_staged).  Channel counts off 32 (the first / last convolution): a temporary stage, folded here.
-            g = self._wgrad_stage(name, ldk, co, ci)
+            g = self._wgrad_stage(name, ldk, co, ci, Mp)
             staged = g is not None
+            if staged and g.dim() == 3:  # partial images: plain stores, folded in a fixed order
+                ops.conv3x3_wgrad_tn_parts(x, B, H, W, ci, dyp, co8, g, self._zero, max_wgs=tuning.integer("DL_UNET_WGRAD_WGS", 0))
+                return
             if not staged:
                 g = self._new(ldk, co8, dtype=torch.float32, zero=True)
             if not ops.conv3x3_wgrad_tn(x, B, H, W, ci, dyp, co8, g, self._zero, max_wgs=tuning.integer("DL_UNET_WGRAD_WGS", 0)):
@@ -753,8 +774,74 @@ class UNetEngine:
         return eo, dict(temb=temb, pre1=pre1, h1=h1, emb=emb, se=se)
 
     # ------------------------------------------------------------------ forward (unet.py:832-853)
+    # ---- launch plans (ops.LaunchPlan): a training pass is recorded on its second run for a given shape and re-issued as a flat list
+    #      of C calls afterwards.  The step of this network is ~716 launches; walking the engine's Python for them costs the host
+    #      ~17 ms, more than the GPU needs for the step at the configured batch of 64.
+    def _plans_on(self) -> bool:
+        return type(self) is UNetEngine and tuning.on("DL_LAUNCH_PLAN")
+
     def forward(self, x: Tensor, t: Tensor, y_eff: Tensor | None, train: bool, refresh: bool = True) -> Tensor:
         """x f32 [B, in_channels, H, W], t f32 [B], y_eff int64 [B] or None -> prediction f32 [B, out_channels, H, W]"""
+        if not (train and self._plans_on()) or ops.is_recording() or torch.is_inference_mode_enabled() or torch.cuda.is_current_stream_capturing():
+            return self._forward_pass(x, t, y_eff, train, refresh)
+        if refresh:
+            self.refresh_shadows(force=True)  # (outside the plan: whether the shadows are stale is per-call state)
+        key = (tuple(x.shape), x.dtype, t.dtype, None if y_eff is None else y_eff.dtype, ops._s(), self.params.data_ptr(),
+               0 if self.grads is None else self.grads.data_ptr(), id(self.reducer))
+        plans = self.__dict__.setdefault("_launch_plans", {})
+        ent = plans.get(key)
+        if ent is None or ent is False:  # first pass of this shape: eager (scratch buffers, tables and stages come into being)
+            if ent is None:
+                if len(plans) >= 4:  # (a plan holds a whole step's buffers: keep few)
+                    plans.clear()
+                plans[key] = 1
+            self._cur_plan = None
+            return self._forward_pass(x, t, y_eff, True, False)
+        if ent == 1:  # second pass: record it
+            lp = ops.LaunchPlan()
+            lp.inputs = (x.detach().clone(), t.detach().clone(), None if y_eff is None else y_eff.detach().clone())
+            try:
+                with ops.recording(lp):
+                    lp.out = self._forward_pass(*lp.inputs, True, False)
+            except Exception:
+                plans[key] = False
+                raise
+            lp.state = self._saved
+            plans[key] = self._cur_plan = lp
+            return lp.out
+        lp = ent
+        xs, ts, ys = lp.inputs
+        xs.copy_(x)
+        ts.copy_(t)
+        if ys is not None:
+            ys.copy_(y_eff)
+        lp.replay()
+        self._saved, self._cur_plan = lp.state, lp
+        return lp.out
+
+    def backward(self, dpred: Tensor, dfeats: dict | None = None) -> None:
+        """dpred f32 [B, out_channels, H, W]; accumulates every parameter gradient into the gradient arena"""
+        lp = self.__dict__.get("_cur_plan")
+        if lp is None or lp.state is not self._saved or self._saved is None or ops.is_recording():
+            return self._backward_pass(dpred, dfeats)
+        assert not dfeats, "the UNet engine exposes no intermediate features"
+        if lp.bwd is None:  # the backward that belongs to the recorded forward: record it on the forward's own buffers
+            bp = ops.LaunchPlan()
+            bp.inputs = dpred.detach().clone()
+            try:
+                with ops.recording(bp):
+                    self._backward_pass(bp.inputs, None)
+            except Exception:
+                self.__dict__["_launch_plans"] = {k: (False if v is lp else v) for k, v in self.__dict__.get("_launch_plans", {}).items()}
+                self._cur_plan = None
+                raise
+            lp.bwd = bp
+            return
+        lp.bwd.inputs.copy_(dpred)
+        lp.bwd.replay()
+        self._saved = None
+
+    def _forward_pass(self, x: Tensor, t: Tensor, y_eff: Tensor | None, train: bool, refresh: bool = True) -> Tensor:
         d, plan = self.d, self.plan
         B, Cin, H, W = x.shape
         assert (H, W) == tuple(d.image_size) and Cin == d.in_channels
@@ -790,8 +877,7 @@ class UNetEngine:
         return pred
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dpred: Tensor, dfeats: dict | None = None) -> None:
-        """dpred f32 [B, out_channels, H, W]; accumulates every parameter gradient into the gradient arena"""
+    def _backward_pass(self, dpred: Tensor, dfeats: dict | None = None) -> None:
         assert not dfeats, "the UNet engine exposes no intermediate features"
         s, d, plan = self._saved, self.d, self.plan
         assert s is not None, "backward without a train-mode forward"
@@ -835,10 +921,10 @@ class UNetEngine:
         self._cond_bwd(deo, s, B)
         self._fold_staged()
         if self._use_side:
-            torch.cuda.current_stream().wait_stream(self._side_stream())
+            ops.stream_wait(ops._s(), self._side_stream().cuda_stream)
         if self.reducer is not None:
-            self.reducer.ready(0, self.layout.size)
-            self.reducer.finish()
+            red = self.reducer
+            ops.rec(lambda: (red.ready(0, self.layout.size), red.finish()))
 
     def _cond_bwd(self, deo: Tensor, s: dict, B: int) -> None:
         d = self.d

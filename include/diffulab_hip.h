@@ -49,6 +49,13 @@ DL_API int dl_stream_create_masked(const uint32_t* cu_mask, int words, void** st
 /* a HIP stream of the device's lowest priority (side stream of the weight gradients); range_out (may be NULL) = {least, greatest} */
 DL_API int dl_stream_create_low_priority(void** stream_out, int* range_out);
 DL_API int dl_stream_destroy(void* stream);
+/* stream hand-off without host objects: everything queued on `waited` so far happens before anything queued on `waiter` from now
+ * on (event record + stream wait); dl_memset_zero = hipMemsetAsync(p, 0, bytes) on the caller's stream.  With these two every
+ * host-side action of an engine's training step is a C call with plain arguments, i.e. a step can be recorded once and re-issued
+ * as a list (diffulab_amd/ops.py::LaunchPlan) -- the host-bound configurations' answer to a graph launch that costs more than the
+ * eager launches on this runtime. */
+DL_API int dl_stream_wait_stream(dl_stream_t waiter, dl_stream_t waited);
+DL_API int dl_memset_zero(void* p, int64_t bytes, dl_stream_t stream);
 
 /* ------------------------------------------------------------------ diffusion heads (f32 images [B, chw]) */
 /* Flow.add_noise, diffuse/modelizations/flow.py:401-408:  z = (1 - t[b]) x + t[b] eps */
@@ -529,6 +536,14 @@ DL_API int dl_conv3x3_nt(const void* x, int64_t ldx, int64_t B, int64_t H, int64
 DL_API int dl_conv3x3_wgrad_tn(const void* x, int64_t ldx, int64_t B, int64_t H, int64_t W, int64_t Ci, const void* dY,
                                int64_t ldy, int64_t R, int64_t Co, float* g, int64_t ldg, const void* zero,
                                int max_workgroups, dl_stream_t stream);
+/* the same product without atomics (round 6): the R-splits store partial images g + s * part_stride (f32 [9*Ci, ldg] each, written
+ * in full with plain stores: nothing is read, nothing needs zeroing) for dl_conv3x3_wgrad_fold_batched (n_img / img_stride of its
+ * descriptor) to add in a fixed order -- bit-reproducible.  dl_conv3x3_wgrad_tn_nparts = the number of images the shape produces
+ * on this device with this workgroup cap (0: unsupported, Ci % 128 != 0); max_parts = the images the caller's buffer holds. */
+DL_API int dl_conv3x3_wgrad_tn_nparts(int64_t Ci, int64_t Co, int64_t R, int max_workgroups);
+DL_API int dl_conv3x3_wgrad_tn_parts(const void* x, int64_t ldx, int64_t B, int64_t H, int64_t W, int64_t Ci, const void* dY,
+                                     int64_t ldy, int64_t R, int64_t Co, float* g, int64_t ldg, int64_t part_stride,
+                                     int64_t max_parts, const void* zero, int max_workgroups, dl_stream_t stream);
 /* weight gradient from dl_gemm_tn(cols, dY) lands transposed as g f32 [(tap, ci), ldg >= Co]: dw[Co, Ci, 3, 3] += g^T */
 DL_API int dl_conv3x3_wgrad_fold(const float* g, int64_t ldg, float* dw, int64_t Co, int64_t Ci, dl_stream_t stream);
 /* The same fold for every convolution of a network in ONE launch (end of the backward): `desc_dev` = device array of n_desc
@@ -540,6 +555,8 @@ typedef struct dl_fold_conv_desc_t {
   void* dw;      /* f32 [Co, Ci, 3, 3]: accumulated (+=) */
   int64_t Co, Ci;
   int64_t tile_begin;
+  int64_t n_img;      /* 0: one accumulated image (the atomic form of dl_conv3x3_wgrad_tn; clear_stage applies); >= 1: that many partial */
+  int64_t img_stride; /* images of dl_conv3x3_wgrad_tn_parts, img_stride floats apart, added in image order (never cleared)      */
 } dl_fold_conv_desc_t;
 DL_API int dl_conv3x3_wgrad_fold_batched(const dl_fold_conv_desc_t* desc_dev, int n_desc, int64_t total_tiles, int clear_stage,
                                          dl_stream_t stream);

@@ -33,6 +33,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--graph", action="store_true", help="LAB: the whole step replayed as one hipGraph (scripts/lab/graph_step.py)")
     a = ap.parse_args()
     dev = "cuda"
     torch.manual_seed(0)
@@ -51,6 +52,19 @@ def main() -> None:
         opt.step()
         return loss
 
+    if a.graph:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab"))
+        from graph_step import GraphedTrainStep
+
+        gstep = GraphedTrainStep(gd, opt, warmup=3)
+
+        def step():  # noqa: F811
+            return gstep({"x": x0, "y": y, "p": 0.0}, gd.draw_timesteps(a.batch))["loss"]
+
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        print("graph captured:", [type(v).__name__ if v is False else "graph" for v in gstep._graphs.values()])
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
