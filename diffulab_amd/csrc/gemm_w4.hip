@@ -296,6 +296,9 @@ struct W4Prob {
   const bf16_t* B;
   int64_t off;  // float offset of the problem's [Mo, No] image inside a slab
   int lda, ldb, No, tiles_n, tile0;
+  int Mo;       // rows of the image: a last tile that would reach past Mo / No is shifted back to END at the edge (it recomputes a
+                // strip of its neighbour: the same products in the same order, i.e. the same bits, stored twice) -- widths that are
+                // not whole tiles (640-wide models on 256 x 256 tiles) need no masking and no padded operands
 };
 struct W4Group {
   W4Prob p[4];
@@ -315,7 +318,9 @@ __global__ __launch_bounds__(W4_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
   if (g.nprob > 2 && tile >= g.p[2].tile0) pr = g.p[2];
   if (g.nprob > 3 && tile >= g.p[3].tile0) pr = g.p[3];
   const int lt = tile - pr.tile0, mt = lt / pr.tiles_n, nt = lt - mt * pr.tiles_n;
-  const int m0 = mt * AM, n0 = nt * BNW;
+  int m0 = mt * AM, n0 = nt * BNW;
+  m0 = m0 + AM > pr.Mo ? pr.Mo - AM : m0;
+  n0 = n0 + BNW > pr.No ? pr.No - BNW : n0;
   const int s_begin = split * g.steps_per_split;
   int s_end = s_begin + g.steps_per_split;
   s_end = s_end < g.nsteps ? s_end : g.nsteps;  // (the host sizes the grid so that every range owns at least one stage)
@@ -405,9 +410,14 @@ extern "C" int dl_gemm_tn_group(const dl_wgrad_t* probs, int n_probs, int64_t R,
     t384 = t384 && probs[i].m_out % 384 == 0 && probs[i].n_in % 192 == 0;
     t256 = t256 && probs[i].m_out % 256 == 0 && probs[i].n_in % 256 == 0;
   }
-  if (!t384 && !t256) {
-    dl_set_error("dl_gemm_tn_group: the problems are neither all whole 384 x 192 tiles nor all whole 256 x 256 tiles");
-    return DL_ERR_UNSUPPORTED;
+  if (!t384 && !t256) {  // 256 x 256 tiles with the last tile of a row / column shifted back to the edge (see W4Prob::Mo)
+    bool edge = true;
+    for (int i = 0; i < n_probs; ++i)
+      edge = edge && probs[i].m_out % 8 == 0 && probs[i].n_in % 8 == 0 && probs[i].m_out >= 256 && probs[i].n_in >= 256;
+    if (!edge) {
+      dl_set_error("dl_gemm_tn_group: the problems are neither whole 384 x 192 tiles nor at least 256 x 256 with widths %% 8 == 0");
+      return DL_ERR_UNSUPPORTED;
+    }
   }
   const int AMt = t384 ? 384 : 256, BNt = t384 ? 192 : 256;
   for (int i = 0; i < n_probs; ++i) {
@@ -423,12 +433,13 @@ extern "C" int dl_gemm_tn_group(const dl_wgrad_t* probs, int n_probs, int64_t R,
     p.lda = (int)q.ld_dy;
     p.ldb = (int)q.ld_x;
     p.No = (int)q.n_in;
-    p.tiles_n = (int)(q.n_in / BNt);
+    p.Mo = (int)q.m_out;
+    p.tiles_n = (int)((q.n_in + BNt - 1) / BNt);
     p.tile0 = ntile;
     p.off = total;
     f.dst[i] = q.g;
     f.off[i] = total;
-    ntile += (int)(q.m_out / AMt) * p.tiles_n;
+    ntile += (int)((q.m_out + AMt - 1) / AMt) * p.tiles_n;
     total += q.m_out * q.n_in;
   }
   f.off[n_probs] = total;

@@ -278,3 +278,156 @@ extern "C" int dl_probe_attn_fwd_fp8(const void* q8, const void* k8, const void*
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
+
+
+// ================================================================================================ round 6: QK^T ONLY in fp8
+// "QK^T in MX-scaled e4m3, P.V stays bf16" -- the narrower variant: S^T = K Q^T on v_mfma_scale_f32_32x32x64_f8f6f4
+// (one issue per 32 x 32 tile instead of four bf16 ones), the probabilities stay f32 -> bf16 and meet a bf16 V tile exactly as in
+// attention.hip::attn_fwd_tiled_k (transposing LDS reads, 32x32x16 bf16 MFMAs).  K chunk: fp8 [256][64 B] as above; V chunk: bf16
+// [256][128 B] with attention.hip's 16-byte-slot swizzle.
+#define ROWB 128
+__device__ __forceinline__ int q_swz8(int row) {
+  const int v = (row >> 1) & 7;
+  return ((v & 1) << 2) | (v >> 1);
+}
+__device__ __forceinline__ bf16x8_t q_frag_cols(const char* tile, int rbase, int colbase, int lane) {
+  const int li = lane & 15, g = lane >> 4;
+  const int col = colbase + (g & 1) * 16 + (li & 3) * 4;
+  const int r0 = rbase + (g >> 1) * 4 + (li >> 2);
+  union {
+    s16x4_t h[2];
+    bf16x8_t v;
+  } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4_t*)(tile + r0 * ROWB + (((col >> 3) ^ q_swz8(r0)) << 4) + (col & 7) * 2));
+  const int r1 = r0 + 8;
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4_t*)(tile + r1 * ROWB + (((col >> 3) ^ q_swz8(r1)) << 4) + (col & 7) * 2));
+  return u.v;
+}
+__global__ __launch_bounds__(512) void attn_fwd_fp8qk_k(const uint8_t* __restrict__ q8, const uint8_t* __restrict__ k8,
+                                                        const bf16_t* __restrict__ v, const float* __restrict__ scales,
+                                                        bf16_t* __restrict__ out, float* __restrict__ lse, int H, int Nq, int Nk,
+                                                        float scale, const float* __restrict__ key_bias) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* kt = smem;                        // 16 KiB fp8 K chunk
+  char* vt = smem + FCH * DH;             // 32 KiB bf16 V chunk
+  float* bs = (float*)(vt + FCH * ROWB);  // key bias of the chunk (x log2 e)
+  const int lane = threadIdx.x & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nchq = Nq / FCH, nch = Nk / FCH;
+  const int bh = blockIdx.x / nchq, qc = blockIdx.x - bh * nchq, b = bh / H, h = bh - b * H;
+  const float sq = scales[bh * 3], sk = scales[bh * 3 + 1];
+  const int q0 = qc * FCH + wave * 32;
+  const v8i_t qf = *(const v8i_t*)(q8 + ((int64_t)bh * Nq + q0 + (lane & 31)) * DH + hi * 32);
+  const float c = scale * LOG2E * sq * sk;
+  f32x16_t o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[0][r] = o[1][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const uint8_t* kg = k8 + (int64_t)bh * Nk * DH;
+  const bf16_t* vg = v + (int64_t)bh * Nk * DH;
+  for (int kc = 0; kc < nch; ++kc) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = wave * 2 + i, key = ch * 16 + (lane >> 2), slot = (lane & 3) ^ ((key >> 2) & 3);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(kg + ((int64_t)kc * FCH + key) * DH + slot * 16), (lds_void_t*)(kt + ch * 1024), 16, 0, 0);
+    }
+    for (int cch = wave; cch < FCH / 8; cch += 8) {  // V: 8 rows = 1 KiB per wave-instruction
+      const int r = cch * 8 + (lane >> 3), qs = (lane & 7) ^ q_swz8(r);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(vg + ((int64_t)kc * FCH + r) * DH + qs * 8), (lds_void_t*)(vt + cch * 1024), 16, 0, 0);
+    }
+    for (int i = threadIdx.x; i < FCH; i += blockDim.x) bs[i] = key_bias ? key_bias[(int64_t)b * Nk + kc * FCH + i] * LOG2E : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kb = 0; kb < FCH; kb += 64) {
+      f32x16_t s[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int key = kb + t * 32 + (lane & 31);
+        const char* row = kt + key * DH;
+        const int sw = (key >> 2) & 3;
+        const u32x4_t k0 = *(const u32x4_t*)(row + (((2 * hi) ^ sw) << 4));
+        const u32x4_t k1 = *(const u32x4_t*)(row + (((2 * hi + 1) ^ sw) << 4));
+        const v8i_t kf = {(int)k0[0], (int)k0[1], (int)k0[2], (int)k0[3], (int)k1[0], (int)k1[1], (int)k1[2], (int)k1[3]};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+        s[t] = mfma_f8(kf, qf, s[t]);
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4_t b4 = *(const f32x4_t*)(bs + kb + t * 32 + g4 * 8 + hi * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = g4 * 4 + e;
+            s[t][r] = s[t][r] * c + b4[e];
+            mx = fmaxf(mx, s[t][r]);
+          }
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float m_new = fmaxf(m_run, mx);
+      if (m_new == -INFINITY) m_new = 0.f;
+      const float alpha = fast_exp2f8(m_run - m_new);
+      m_run = m_new;
+      float ps = 0.f;
+      float p[2][16];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          p[t][r] = fast_exp2f8(s[t][r] - m_new);
+          ps += p[t][r];
+        }
+      l_run = l_run * alpha + ps;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[0][r] *= alpha;
+        o[1][r] *= alpha;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int kg2 = 0; kg2 < 2; ++kg2) {
+          union {
+            u32x4_t u;
+            bf16x8_t v;
+          } pf;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pf.u[i] = pack2bf(p[t][kg2 * 8 + 2 * i], p[t][kg2 * 8 + 2 * i + 1]);
+          const int rbase = kb + t * 32 + kg2 * 16;
+          o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q_frag_cols(vt, rbase, 0, lane), pf.v, o[0], 0, 0, 0);
+          o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q_frag_cols(vt, rbase, 32, lane), pf.v, o[1], 0, 0, 0);
+        }
+    }
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qrow = q0 + (lane & 31);
+  bf16_t* op = out + ((int64_t)b * Nq + qrow) * (H * DH) + h * DH;
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      u32x2_t w2;
+      w2[0] = pack2bf(o[half][g4 * 4 + 0] * inv, o[half][g4 * 4 + 1] * inv);
+      w2[1] = pack2bf(o[half][g4 * 4 + 2] * inv, o[half][g4 * 4 + 3] * inv);
+      *(u32x2_t*)(op + half * 32 + g4 * 8 + hi * 4) = w2;
+    }
+  if (hi == 0) lse[(int64_t)bh * Nq + qrow] = (m_run + log2f(l_tot)) * LN2;
+}
+extern "C" int dl_probe_attn_fwd_fp8qk(const void* q8, const void* k8, const void* v, const float* scales, void* out, float* lse,
+                                       int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t dh, float scale, const float* key_bias,
+                                       dl_stream_t stream) {
+  DL_CHECK_ARG(q8 && k8 && v && scales && out && lse && B > 0 && H > 0, "dl_probe_attn_fwd_fp8qk: null operand");
+  DL_CHECK_ARG(dh == DH && Nq % FCH == 0 && Nk % FCH == 0 && Nq > 0 && Nk > 0 && Nq <= 4096 && Nk <= 4096,
+               "dl_probe_attn_fwd_fp8qk: dh = 64, Nq / Nk multiples of 256 up to 4096");
+  const int lds = FCH * DH + FCH * ROWB + FCH * (int)sizeof(float);
+  hipLaunchKernelGGL(attn_fwd_fp8qk_k, (int)(B * H * (Nq / FCH)), 512, lds, (hipStream_t)stream, (const uint8_t*)q8, (const uint8_t*)k8,
+                     (const bf16_t*)v, scales, (bf16_t*)out, lse, (int)H, (int)Nq, (int)Nk, scale, key_bias);
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}

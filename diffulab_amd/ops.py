@@ -378,8 +378,13 @@ class WgradGroups:
 
     @staticmethod
     def widths_ok(D: int, F: int) -> bool:
-        """the four linears of a block with inner width D and MLP width F are whole 384 x 192 tiles, or whole 256 x 256 tiles"""
-        return (D % 384 == 0 and F % 192 == 0) or (D % 256 == 0 and F % 256 == 0)
+        """the four linears of a block with inner width D and MLP width F are whole 384 x 192 tiles or whole 256 x 256 tiles -- or
+        (round 6: 640-wide models) at least one 256 x 256 tile in each direction with widths that are multiples of 8: the last tile of
+        a row / column is then shifted back to end at the edge"""
+        if (D % 384 == 0 and F % 192 == 0) or (D % 256 == 0 and F % 256 == 0):
+            return True
+        r256 = lambda v: (v + 255) // 256 * 256  # noqa: E731
+        return D % 8 == 0 and F % 8 == 0 and D >= 256 and F >= 256 and 4 * r256(D) <= 5 * D and 4 * r256(F) <= 5 * F  # (<= 25 % recomputed)
 
     @staticmethod
     def shapes_ok(D: int, F: int, rows: int) -> bool:

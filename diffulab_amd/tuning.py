@@ -37,9 +37,12 @@ SWITCHES: dict[str, tuple[str, str]] = {
     "DL_HIPGRAPH": ("1", "samplers replay the denoiser forward as a captured hipGraph"),
     "DL_CFG_PAIR": ("1", "guided sampler steps run the conditional and the label-dropped forward as ONE forward over [x ; x] "
                     "(class-conditional MMDiT / DDT / UNetModel: same values per row, the weights stream once)"),
-    "DL_LAUNCH_PLAN": ("1", "UNet (bf16 regime): a training forward / backward is recorded on its second run for a shape and re-issued as a "
-                       "flat list of C calls afterwards (ops.LaunchPlan: the host walks ~24 us of Python per launch otherwise, 716 "
-                       "launches per step)"),
+    "DL_LAUNCH_PLAN": ("0", "UNet (bf16 regime): a training forward / backward is recorded on its second run for a shape and re-issued as a "
+                       "flat list of C calls afterwards (ops.LaunchPlan: the engine's Python costs the host ~24 us per launch, 716 "
+                       "launches per step).  Measured (profiles/r06_e_*): the step at B = 64 is NOT host-bound -- its main queue is busy "
+                       "19.2 of 20.3 ms and `host_issue` is the full launch queue pushing back -- so the plan changes nothing there "
+                       "(20.03 vs 20.11 ms); it pays where the host is the slower side (under a profiler's per-launch overhead: 20.3 vs "
+                       "22.7 ms), hence opt-in"),
     "DL_UNET_SIDE": ("1", "UNet weight gradients on a side stream"),
     "DL_UNET_SPLITK": ("1", "split-K convolutions at the UNet's low-resolution levels (partial images + fixed-order fold: -7 % per step)"),
     "DL_UNET_WGRAD_WGS": ("0", "workgroup cap of the UNet's side-stream convolution weight gradients (0 = one per CU; round 5, B = 128: "

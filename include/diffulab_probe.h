@@ -62,6 +62,10 @@ DL_API int dl_probe_attn_fp8_quantize(const void* q, const void* k, const void* 
 DL_API int dl_probe_attn_fwd_fp8(const void* q8, const void* k8, const void* v8t, const float* scales, void* out, float* lse,
                            int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t dh, float scale, const float* key_bias,
                            dl_stream_t stream);
+/* round 6: QK^T only in fp8 (q8, k8 of dl_probe_attn_fp8_quantize), the probabilities and V stay bf16 (v bf16 [B,H,Nk,64]) */
+DL_API int dl_probe_attn_fwd_fp8qk(const void* q8, const void* k8, const void* v, const float* scales, void* out, float* lse,
+                                   int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t dh, float scale, const float* key_bias,
+                                   dl_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -18,8 +18,26 @@ import faulthandler  # noqa: E402
 faulthandler.enable(all_threads=True)
 
 
+def _host_threads() -> int:
+    """cores this process may really use (affinity mask, cgroup cpu quota), capped at 32 -- bench.py's rule for its CPU baseline"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle legs are most of the GPU suite's wall time, and torch sizes its thread pool by the host's LOGICAL cpu count: on a
+    # GPU box whose cgroup grants a fraction of a 256-thread host the oversubscribed pool is several times slower than a right-sized
+    # one (round 6: the B = 256 oracle leg ran at 2.2 images/s inside pytest against 15.8 images/s in bench.py's cpu_baseline)
+    import torch
+
+    torch.set_num_threads(_host_threads())
 
 
 def pytest_collection_modifyitems(config, items):

@@ -139,7 +139,10 @@ def test_gemm_tn_ring_kernel(ops, R, M, N, cap):
 
 @pytest.mark.parametrize("R,cap,ranges,D", [(4096 + 32 * 7, 0, 8, 384), (8192, 128, 8, 384), (2048, 64, 8, 384), (4096, 0, 1, 384),
                                             (16384, 0, 3, 384), (8192, 0, 8, 512), (2048 + 32 * 5, 192, 2, 512), (4096, 0, 8, 768),
-                                            (4096, 0, 8, 256)])
+                                            (4096, 0, 8, 256),
+                                            # round 6, widths that are not whole tiles (the 640-wide joint DDT of ddt_txt.yaml; 320):
+                                            # 256 x 256 tiles, the last tile of a row / column shifted back to end at the edge
+                                            (4096, 0, 8, 640), (2048 + 32 * 3, 96, 4, 320)])
 def test_gemm_tn_group_is_exact_and_bit_reproducible(ops, R, cap, ranges, D):
     """dl_gemm_tn_group (csrc/gemm_w4.hip): the four weight gradients of a DiT block (qkv, proj_out, MLP up / down) in ONE launch --
     32 tiles of 384 x 192 at D = 384 (768: 128 tiles), 64 tiles of 256 x 256 at D = 512 (the CIFAR / SPRINT / DDT width; 256: 16 tiles)
@@ -165,7 +168,7 @@ def test_gemm_tn_group_is_exact_and_bit_reproducible(ops, R, cap, ranges, D):
     for g0, g1, ref in zip(outs[0], outs[1], refs):
         assert rel(g0, ref) < 2e-5
         assert torch.equal(g0, g1)
-    # a shape the tile does not divide: nothing is launched, the caller keeps the per-problem path
+    # a shape below one tile: nothing is launched, the caller keeps the per-problem path
     g = torch.zeros(128, D, device=DEV)
     assert not ops.gemm_tn_group([(probs[0][0][:, :128], probs[0][1], g)], slab)
     assert float(g.abs().max()) == 0.0

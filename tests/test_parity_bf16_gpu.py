@@ -41,8 +41,11 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-def three_legs(cfgk, seed, B, H, tag, head="flow"):
-    """-> (loss, grads) of the fp32 oracle, the bf16-autocast oracle and the HIP path on identical inputs"""
+def three_legs(cfgk, seed, B, H, tag, head="flow", legs=("fp32", "bf16"), chunk=None):
+    """-> (loss, grads) of the fp32 oracle, the bf16-autocast oracle and the HIP path on identical inputs.  chunk: the oracle legs
+    run the batch in pieces of `chunk` samples and accumulate (the loss is a mean over samples and every sample's path through the
+    network is independent of its batch-mates, so loss and gradients are the batch's up to f32 summation order) -- at B = 256 the
+    one-piece autograd graph is ~100 GB of host memory and runs 7x slower per image than pieces of 32"""
     from diffulab_amd import Diffuser, MMDiT
 
     cfg = odit.DiTConfig(**cfgk)
@@ -52,15 +55,32 @@ def three_legs(cfgk, seed, B, H, tag, head="flow"):
     t = synth.uniform(f"{tag}.t", (B,), lo=0.05, hi=0.95)
     y = synth.integers(f"{tag}.y", (B,), cfgk["n_classes"])
     out = {}
-    for leg in ("fp32", "bf16"):
+    for leg in legs:
         Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
         t0 = time.time()
-        if leg == "bf16":
-            with odit.bf16_autocast():
-                loss = od.flow_loss(odit.dit_forward(Pr, od.flow_add_noise(x0, t, noise), t, y, cfg), x0, noise)
-        else:
-            loss = od.flow_loss(odit.dit_forward(Pr, od.flow_add_noise(x0, t, noise), t, y, cfg), x0, noise)
-        loss.backward()
+        step = chunk or B
+        assert B % step == 0
+        total = 0.0
+        for lo in range(0, B, step):
+            sl = slice(lo, lo + step)
+            xs, ns, ts, ys = x0[sl], noise[sl], t[sl], y[sl]
+            if leg == "bf16":
+                with odit.bf16_autocast():
+                    loss = od.flow_loss(odit.dit_forward(Pr, od.flow_add_noise(xs, ts, ns), ts, ys, cfg), xs, ns)
+            else:
+                loss = od.flow_loss(odit.dit_forward(Pr, od.flow_add_noise(xs, ts, ns), ts, ys, cfg), xs, ns)
+            loss = loss * (step / B)
+            loss.backward()  # (gradients accumulate in Pr[k].grad)
+            total += loss.item()
+
+        class _L:  # (what the callers read of the loss)
+            def __init__(self, v):
+                self.v = v
+
+            def item(self):
+                return self.v
+
+        loss = _L(total)
         out[leg] = (loss.item(), {k: v.grad for k, v in Pr.items()})
         print(f"{tag}: {leg} oracle leg {time.time() - t0:.1f} s")
     m = MMDiT(simple_dit=True, **cfgk)
@@ -74,13 +94,17 @@ def three_legs(cfgk, seed, B, H, tag, head="flow"):
     return out
 
 
-def check(out, tag):
+def check(out, tag, bf16_fixture=None):
+    """bf16_fixture: {"loss": the bf16 leg's loss, "err": {tensor: its relative L2 error against the fp32 leg}} recorded once for
+    these seeded inputs (tests/golden/make_b256_autocast.py) instead of running the bf16 leg here"""
     l32, g32 = out["fp32"]
-    e_loss_bf, e_loss_hip = abs(out["bf16"][0] - l32) / l32, abs(out["hip"][0] - l32) / l32
+    l_bf = out["bf16"][0] if bf16_fixture is None else bf16_fixture["loss"]
+    e_loss_bf, e_loss_hip = abs(l_bf - l32) / l32, abs(out["hip"][0] - l32) / l32
     assert e_loss_hip <= max(LOSS_BOUND, FACTOR * e_loss_bf), (tag, e_loss_hip, e_loss_bf)
     rows, relaxed = [], 0
     for k in g32:
-        e_bf, e_hip = rel(out["bf16"][1][k], g32[k]), rel(out["hip"][1][k], g32[k])
+        e_bf = rel(out["bf16"][1][k], g32[k]) if bf16_fixture is None else bf16_fixture["err"][k]
+        e_hip = rel(out["hip"][1][k], g32[k])
         bound = max(GRAD_BOUND, FACTOR * e_bf)
         relaxed += bound > GRAD_BOUND
         rows.append((e_hip / bound, k, e_hip, e_bf))
@@ -150,12 +174,22 @@ def test_full_training_step_at_the_benched_shape_b256():
     the 256x384 persistent NT tiles (plain and fused-SwiGLU epilogues), the 384x128 split-R weight-gradient kernel on the side
     stream with its 192-workgroup cap and f32 atomics, attention with V in place -- against the fp32 oracle on the same inputs,
     loss and EVERY parameter gradient (the benched kernels were never parity-checked at the benched shape)."""
-    out = three_legs(S2, seed=7, B=256, H=32, tag="pb.b256")
-    check(out, "DiT-S/2 B=256 (benched shape)")
+    import os
+
+    import numpy as np
+
+    # round 6: the bf16-autocast leg of these seeded inputs is a committed fixture (tests/golden/make_b256_autocast.py ran the SAME
+    # oracle leg once, on the GPU box's host: ~2 of this test's 3 minutes in every run of the suite before); the fp32 leg -- the
+    # expected values, every gradient tensor in full -- still runs here, and its loss must reproduce the fixture's (same inputs)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dit_b256_autocast.npz"))
+    fixture = {"loss": float(g["loss_bf16"]), "err": dict(zip(g["names"].tolist(), g["err"].tolist()))}
+    out = three_legs(S2, seed=7, B=256, H=32, tag="pb.b256", legs=("fp32",), chunk=32)
+    assert abs(out["fp32"][0] - float(g["loss_fp32"])) <= 1e-5 * abs(float(g["loss_fp32"]))
+    check(out, "DiT-S/2 B=256 (benched shape)", bf16_fixture=fixture)
     # whole-arena figure as well: one number for the report
-    flat = lambda g: torch.cat([g[k].flatten().double() for k in sorted(g)])  # noqa: E731
+    flat = lambda g_: torch.cat([g_[k].flatten().double() for k in sorted(g_)])  # noqa: E731
     e = ((flat(out["hip"][1]) - flat(out["fp32"][1])).norm() / flat(out["fp32"][1]).norm()).item()
-    e_bf = ((flat(out["bf16"][1]) - flat(out["fp32"][1])).norm() / flat(out["fp32"][1]).norm()).item()
+    e_bf = float(g["whole_grad_err"])
     print(f"B=256 whole-gradient rel-L2: hip {e:.3e}, bf16-autocast oracle {e_bf:.3e}")
     assert e <= max(GRAD_BOUND, FACTOR * e_bf)
 
