@@ -235,7 +235,9 @@ def roofline_replay(step, model, images_per_s_per_gpu: float) -> dict:
                 name, fl = "gemm_nt_big_k<384,2,3>", 2.0 * a.shape[0] * b.shape[0] * a.shape[1]
             elif kind == "attn_fwd_qkn":  # (qkv, ssq, sq, sk, cos, sin, q, k, rrms, out, lse, B, H, N, dh, rot, scale)
                 Bq, Hq, Nq, dq = rest[9], rest[10], rest[11], rest[12]
-                name, fl = "attn_fwd_qkn_k", 4.0 * Bq * Hq * Nq * Nq * dq
+                # (from three (sample, head) items per CU the entry point runs the persistent + pipelined form, csrc/attention.hip)
+                pipe = Nq == 256 and Bq * Hq >= 3 * torch.cuda.get_device_properties(0).multi_processor_count
+                name, fl = ("attn_fwd_qkn_pipe_k" if pipe else "attn_fwd_qkn_k"), 4.0 * Bq * Hq * Nq * Nq * dq
             elif kind == "gemm_nt_qk_norm_rope":
                 name, fl = "gemm_nt_rows_k<2>", 2.0 * a.shape[0] * b.shape[0] * a.shape[1]
             elif kind == "gemm_tn_group":  # (probs = [(dy, x, g), ...], slab): one launch + the fold

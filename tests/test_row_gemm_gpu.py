@@ -241,14 +241,16 @@ def test_qkv_gemm_with_row_statistics_and_attention_with_qk_norm_on_load(ops, B,
     assert not ops.gemm_nt_ssq(small, w, torch.empty(8 * 256, 3 * D, **bf), torch.zeros(8 * 256, 2, device=DEV))
 
 
-@pytest.mark.parametrize("B,axes,train", [(256, [32, 32], True), (130, [32, 32], True), (131, [16, 16], False), (128, None, True)])
-def test_pipelined_attention_forward_equals_the_chain_form_bit_for_bit(ops, B, axes, train):
+@pytest.mark.parametrize("B,H,axes,train", [(256, 6, [32, 32], True), (130, 6, [32, 32], True), (131, 6, [16, 16], False), (128, 6, None, True),
+                                            (100, 8, [32, 32], True), (65, 12, [32, 32], False)])  # (512- and 768-wide models)
+def test_pipelined_attention_forward_equals_the_chain_form_bit_for_bit(ops, B, H, axes, train):
     """round 6: from three (sample, head) items per CU dl_attn_fwd_qkn runs `attn_fwd_qkn_pipe_k` -- one persistent workgroup per CU,
     K / V tiles double-buffered, the next item's loads in flight under the current item's MFMAs, O stored one item late -- with the
     arithmetic of the chain form `attn_fwd_qkn_k` in the same order: every output (O, lse, the normalised q / k, rrms) bit for bit
     equal to the chain form (the lab switch dl_lab_set_attn_pipe selects it).  B = 130 / 131: item runs that end inside a sample and
     workgroups with a shorter last run; train = False: the inference form (no q / k / rrms outputs)."""
-    H, dh, Nt = 6, 64, 256
+    dh, Nt = 64, 256
+    D = H * dh  # noqa: N806 (shadows the module's 384 for the wider models)
     M = B * Nt
     bf = dict(device=DEV, dtype=torch.bfloat16)
     qkv = dev_bf(synth.normal("pp.qkv", (M, 3 * D)))
