@@ -360,6 +360,33 @@ def test_hipgraph_inference_matches_eager_and_tracks_parameter_updates(monkeypat
         assert torch.equal(f, m(x=x2, timesteps=t, y=y)["x"])
 
 
+def test_pipelined_attention_inside_the_captured_inference_forward(monkeypatch):
+    """round 6: at sampler batch sizes (>= 3 (sample, head) items per CU) the inference forward runs the persistent, pipelined
+    attention forward (attn_fwd_qkn_pipe_k, its inference form: no q / k / rrms outputs).  DiT-S/2 dims at depth 2, B = 160:
+    eager, captured-graph replay and the chain form of the kernel (lab switch) give the same bits."""
+    from diffulab_amd import ops
+
+    cfgk = dict(input_channels=4, output_channels=4, inner_dim=384, embedding_dim=384, num_heads=6, mlp_ratio=4, patch_size=2, depth=2,
+                n_classes=1000, classifier_free=True)
+    m, _ = build(cfgk, seed=3)
+    m.eval()
+    B = 160
+    x = synth.normal("pg.x", (B, 4, 32, 32)).to(DEV)
+    t = synth.uniform("pg.t", (B,)).to(DEV)
+    y = synth.integers("pg.y", (B,), 1000).to(DEV)
+    with torch.no_grad():
+        a = m(x=x, timesteps=t, y=y)["x"]  # eager run + capture
+        b = m(x=x, timesteps=t, y=y)["x"]  # replay
+        assert m._graphs and all(v is not False for v in m._graphs.values()), "capture failed"
+        monkeypatch.setenv("DL_HIPGRAPH", "0")
+        ops.lib().cdll.dl_lab_set_attn_pipe(0)
+        try:
+            c = m(x=x, timesteps=t, y=y)["x"]  # eager, chain form of the attention
+        finally:
+            ops.lib().cdll.dl_lab_set_attn_pipe(1)
+        assert torch.equal(a, b) and torch.equal(a, c) and bool(torch.isfinite(a).all())
+
+
 def test_dit_on_1024_tokens_against_oracle():
     """a 64x64 latent grid at patch 2 = 1024 tokens per image (e.g. 512-pixel images through an f8 VAE): the chunked attention
     kernels inside the full forward / backward, loss and gradients against the CPU oracle"""
