@@ -86,7 +86,13 @@ static ConvGeom make_conv_geom(int64_t H, int64_t W, int64_t Ci, int64_t ldx, in
   return cg;
 }
 
-template <bool CONV>
+// NSLOT = 2: two 32 KiB operand stages, the next one requested while the current one is consumed (two workgroups per CU cover each
+// other's waits).  NSLOT = 4 (round 6): launches of AT MOST ONE workgroup per CU -- the mid-size linears of the low-resolution UNet
+// levels and of small-batch DiT steps: 6 GFLOP problems, 256 tiles or fewer -- have nobody to cover a wait, and one stage of
+// prefetch is ~0.25 us of MFMAs against ~1.5 us of memory latency: every k-step then costs the latency.  Alone on its CU the
+// workgroup can have the LDS: a four-slot ring (128 KiB), three stages in flight, counted vmcnt waits and raw barriers as in
+// gemm_nt_big_k.
+template <bool CONV, int NSLOT = 2>
 __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restrict__ A, int64_t lda,
                                                              const bf16_t* __restrict__ Bm, int64_t ldb,
                                                              void* __restrict__ C, int64_t ldc, int M, int N, int K,
@@ -180,12 +186,28 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restr
   // partial tiles meet in C through f32 atomics (C zeroed by the launcher)
   const int nk_all = K / BK;
   const int k_lo = (int)((int64_t)nk_all * blockIdx.y / ksplit), nk = (int)((int64_t)nk_all * (blockIdx.y + 1) / ksplit);
-  if (k_lo < nk) stage(k_lo, k_lo & 1);
+  if (NSLOT == 2) {
+    if (k_lo < nk) stage(k_lo, k_lo & 1);
+  } else {
+#pragma unroll
+    for (int s = 0; s < NSLOT - 1; ++s)
+      if (k_lo + s < nk) stage(k_lo + s, (k_lo + s) % NSLOT);
+  }
   for (int kt = k_lo; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-    const char* ta = smem + (kt & 1) * 32768;
+    if (NSLOT == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    } else {
+      // stage kt must have landed; the (up to NSLOT - 2) younger stages stay in flight: 8 DMA instructions per wave and stage
+      const int younger = nk - 1 - kt < NSLOT - 2 ? nk - 1 - kt : NSLOT - 2;
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // raw: __syncthreads() would drain vmcnt (the DMA counts as an LDS write)
+      if (kt + NSLOT - 1 < nk) stage(kt + NSLOT - 1, (kt + NSLOT - 1) % NSLOT);  // into the slot consumed in iteration kt - 1
+    }
+    const char* ta = smem + (NSLOT == 2 ? (kt & 1) : kt % NSLOT) * 32768;
     const char* tb = ta + 16384;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -697,6 +719,22 @@ static int dispatch_big(const void* A, int64_t lda, const void* B, int64_t ldb, 
   return 1;
 }
 
+static int g_nt_deep = 1;  // LAB A/B switch (not in the header): 0 = the two-slot ring everywhere
+extern "C" __attribute__((visibility("default"))) void dl_lab_set_nt_deep(int on) { g_nt_deep = on; }
+// the 128 x 128 kernel: the four-slot ring when the launch is at most one workgroup per CU (and deep enough to have a steady state)
+template <bool CONV>
+static void launch_nt_small(dim3 grid, hipStream_t stream, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, void* C, int64_t ldc,
+                            int M, int N, int K, const NtEpilogue& ep, int ksplit, const ConvGeom& cg) {
+  static DevOnce once;
+  const int n_cu = dev_cus(once, [] {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_k<CONV, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+  });
+  if (g_nt_deep && (int64_t)grid.x * grid.y <= n_cu && K / BK / ksplit >= 4)
+    hipLaunchKernelGGL((gemm_nt_k<CONV, 4>), grid, NT_THREADS, 4 * 32768, stream, A, lda, B, ldb, C, ldc, M, N, K, ep, ksplit, cg);
+  else
+    hipLaunchKernelGGL((gemm_nt_k<CONV, 2>), grid, NT_THREADS, NT_LDS_BYTES, stream, A, lda, B, ldb, C, ldc, M, N, K, ep, ksplit, cg);
+}
+
 extern "C" int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                           int64_t N, int64_t K, const float* bias, int act, int out_dtype, void* pre_out,
                           const void* resid, int64_t ldr, const void* gate, int64_t ldg, int64_t rows_per_gate,
@@ -733,8 +771,8 @@ extern "C" int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb
       ksplit = 1;
     }
   }
-  hipLaunchKernelGGL(gemm_nt_k<false>, dim3(nwg, ksplit), NT_THREADS, NT_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)A, lda,
-                     (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep, ksplit, ConvGeom{});
+  launch_nt_small<false>(dim3(nwg, ksplit), (hipStream_t)stream, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep,
+                         ksplit, ConvGeom{});
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
@@ -1800,8 +1838,8 @@ extern "C" int dl_conv3x3_nt(const void* x, int64_t ldx, int64_t Bn, int64_t H, 
     NtEpilogue ep0{};
     ep0.rows_per_gate = 1;
     ep0.part_stride = M * Co;
-    hipLaunchKernelGGL(gemm_nt_k<true>, dim3(nwg, ksplit), NT_THREADS, NT_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                       (const bf16_t*)Wf, ldw, splitk_scratch, Co, (int)M, (int)Co, (int)K, ep0, ksplit, cg);
+    launch_nt_small<true>(dim3(nwg, ksplit), (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)Wf, ldw, splitk_scratch, Co, (int)M,
+                          (int)Co, (int)K, ep0, ksplit, cg);
     int64_t g = (M * (Co / 8) + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(conv_splitk_finalize_k, (int)g, 256, 0, (hipStream_t)stream, splitk_scratch, ksplit, M * Co, bias,
@@ -1810,8 +1848,8 @@ extern "C" int dl_conv3x3_nt(const void* x, int64_t ldx, int64_t Bn, int64_t H, 
     return DL_OK;
   }
   NtEpilogue ep{bias, DL_ACT_NONE, 0, nullptr, (const bf16_t*)resid, ldr, nullptr, 0, 1, nullptr, 0, 0};
-  hipLaunchKernelGGL(gemm_nt_k<true>, dim3(nwg, 1), NT_THREADS, NT_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                     (const bf16_t*)Wf, ldw, out, ldc, (int)M, (int)Co, (int)K, ep, 1, cg);
+  launch_nt_small<true>(dim3(nwg, 1), (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)Wf, ldw, out, ldc, (int)M, (int)Co, (int)K, ep, 1,
+                        cg);
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

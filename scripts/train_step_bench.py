@@ -57,6 +57,9 @@ def main() -> None:
     if os.environ.get("DL_LAB_ATTN_PIPE"):  # LAB A/B: 0 = the chain forms of the attention kernels everywhere
         from diffulab_amd import ops
         ops.lib().cdll.dl_lab_set_attn_pipe(int(os.environ["DL_LAB_ATTN_PIPE"]))
+    if os.environ.get("DL_LAB_NT_DEEP"):  # LAB A/B: 0 = the two-slot ring of the 128 x 128 GEMM kernel everywhere
+        from diffulab_amd import ops
+        ops.lib().cdll.dl_lab_set_nt_deep(int(os.environ["DL_LAB_NT_DEEP"]))
     ap = argparse.ArgumentParser()
     ap.add_argument("config", choices=list(CFG))
     ap.add_argument("--batch", type=int, default=32)

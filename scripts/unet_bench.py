@@ -29,6 +29,10 @@ def main() -> None:
         from diffulab_amd import ops
 
         ops.lib().cdll.dl_lab_set_gn_fused(int(os.environ["DL_LAB_GN_FUSED"]))
+    if os.environ.get("DL_LAB_NT_DEEP"):  # LAB A/B: 0 = the two-slot ring of the 128 x 128 GEMM kernel everywhere
+        from diffulab_amd import ops
+
+        ops.lib().cdll.dl_lab_set_nt_deep(int(os.environ["DL_LAB_NT_DEEP"]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--steps", type=int, default=10)

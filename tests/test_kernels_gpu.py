@@ -137,6 +137,32 @@ def test_gemm_tn_ring_kernel(ops, R, M, N, cap):
     assert rel(c, ref) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K,bias,resid", [(8192, 512, 512, True, True), (2048, 1024, 1024, False, False), (4096 + 40, 384, 256, True, False),
+                                              (1024, 3072, 1024, True, False), (640, 1000, 448, False, True)])
+def test_small_launch_gemm_on_the_four_slot_ring_equals_the_two_slot_form(ops, M, N, K, bias, resid):
+    """round 6: launches of at most one workgroup per CU of the 128 x 128 GEMM kernel (the mid-size linears of the low-resolution
+    UNet levels and of small-batch DiT steps) run `gemm_nt_k<CONV, 4>` -- a four-slot operand ring with counted waits: three stages in
+    flight instead of one, because a workgroup alone on its CU has nobody to cover its memory latency.  Same products in the same
+    order: bit-identical to the two-slot form (lab switch dl_lab_set_nt_deep), and against torch."""
+    a = dev_bf(bf(synth.normal(f"d4.a{M}", (M, K))))
+    w = dev_bf(bf(synth.normal(f"d4.w{N}", (N, K), std=K**-0.5)))
+    b_ = synth.normal("d4.b", (N,), std=0.1).to(DEV) if bias else None
+    r_ = dev_bf(bf(synth.normal(f"d4.r{M}", (M, N)))) if resid else None
+    outs = []
+    for mode in (0, 1, 1):
+        ops.lib().cdll.dl_lab_set_nt_deep(mode)
+        try:
+            o = torch.full((M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+            ops.gemm_nt(a, w, o, bias=b_, resid=r_)
+            torch.cuda.synchronize()
+        finally:
+            ops.lib().cdll.dl_lab_set_nt_deep(1)
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    ref = a.float() @ w.float().t() + (b_ if bias else 0) + (r_.float() if resid else 0)
+    assert rel(outs[1].float(), ref) < 5e-3
+
+
 @pytest.mark.parametrize("R,cap,ranges,D", [(4096 + 32 * 7, 0, 8, 384), (8192, 128, 8, 384), (2048, 64, 8, 384), (4096, 0, 1, 384),
                                             (16384, 0, 3, 384), (8192, 0, 8, 512), (2048 + 32 * 5, 192, 2, 512), (4096, 0, 8, 768),
                                             (4096, 0, 8, 256),
