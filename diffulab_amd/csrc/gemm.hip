@@ -1892,6 +1892,10 @@ static int conv_wgrad_cus() {
     (void)hipFuncSetAttribute((const void*)gemm_tn_big_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_STAGE);
   });
 }
+int launch_conv_wgrad_halo(const void* x, int64_t ldx, int64_t Bn, int64_t H, int64_t W, int64_t Ci, const void* dY, int64_t ldy, int64_t R,
+                           int64_t Co, float* g, int64_t ldg, int64_t part_stride, const void* zero, int max_workgroups, int n_cu,
+                           hipStream_t stream);  // conv_wgrad.hip
+int conv_wgrad_halo_splits(int64_t H, int64_t W, int64_t Ci, int64_t Co, int64_t R, int max_workgroups, int n_cu, int* sps_out);
 static int conv_wgrad_launch(const void* x, int64_t ldx, int64_t Bn, int64_t H, int64_t W, int64_t Ci, const void* dY, int64_t ldy,
                              int64_t R, int64_t Co, float* g, int64_t ldg, int64_t part_stride, int64_t max_parts, const void* zero,
                              int max_workgroups, dl_stream_t stream, const char* who) {
@@ -1900,6 +1904,17 @@ static int conv_wgrad_launch(const void* x, int64_t ldx, int64_t Bn, int64_t H, 
   DL_CHECK_ARG(R % BK == 0 && R >= Bn * H * W && Co % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldy >= Co && ldg >= Co, "%s: dims", who);
   DL_CHECK_ARG((((uintptr_t)x | (uintptr_t)dY | (uintptr_t)zero) & 15) == 0, "%s: 16-byte alignment", who);
   const int64_t M = 9 * Ci, N = Co;
+  {  // all nine taps from one staging of the activation rows (conv_wgrad.hip) where the geometry fits
+    const int hs = conv_wgrad_halo_splits(H, W, Ci, Co, R, max_workgroups, conv_wgrad_cus(), nullptr);
+    if (hs > 0) {
+      if (part_stride > 0)
+        DL_CHECK_ARG(hs <= max_parts && part_stride >= M * ldg, "%s: %d partial images of %lld floats needed, room for %lld of %lld", who, hs,
+                     (long long)(M * ldg), (long long)max_parts, (long long)part_stride);
+      const int rc = launch_conv_wgrad_halo(x, ldx, Bn, H, W, Ci, dY, ldy, R, Co, g, ldg, part_stride, zero, max_workgroups,
+                                            conv_wgrad_cus(), (hipStream_t)stream);
+      if (rc != 1) return rc;
+    }
+  }
   const ConvGeom cg = make_conv_geom(H, W, Ci, ldx, Bn * H * W, zero);
   const int nsteps = (int)(R / BK);
   const ConvWgradPlan p = conv_wgrad_plan(M, N, nsteps, max_workgroups, conv_wgrad_cus());
@@ -1924,9 +1939,11 @@ extern "C" int dl_conv3x3_wgrad_tn(const void* x, int64_t ldx, int64_t Bn, int64
 }
 /* the same product WITHOUT atomics: the R-splits store `n_parts` partial images g + s * part_stride (f32 [9*Ci, ldg] each, written in
  * full with plain stores; nothing is read, nothing needs zeroing) that dl_conv3x3_wgrad_fold_batched adds in a fixed order.
- * dl_conv3x3_wgrad_tn_nparts = the number of images this shape produces on this device (0: Ci % 128 != 0, unsupported). */
-extern "C" int dl_conv3x3_wgrad_tn_nparts(int64_t Ci, int64_t Co, int64_t R, int max_workgroups) {
+ * dl_conv3x3_wgrad_tn_nparts = the number of images this shape and map produce on this device (0: Ci % 128 != 0, unsupported). */
+extern "C" int dl_conv3x3_wgrad_tn_nparts(int64_t H, int64_t W, int64_t Ci, int64_t Co, int64_t R, int max_workgroups) {
   if (Ci % 128 != 0 || R % BK != 0 || Co <= 0) return 0;
+  const int hs = conv_wgrad_halo_splits(H, W, Ci, Co, R, max_workgroups, conv_wgrad_cus(), nullptr);
+  if (hs > 0) return hs;
   return conv_wgrad_plan(9 * Ci, Co, (int)(R / BK), max_workgroups, conv_wgrad_cus()).splits;
 }
 extern "C" int dl_conv3x3_wgrad_tn_parts(const void* x, int64_t ldx, int64_t Bn, int64_t H, int64_t W, int64_t Ci, const void* dY,

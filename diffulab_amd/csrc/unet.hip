@@ -1045,11 +1045,39 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_fold_batched_k(const dl_fol
     else hi = mid - 1;
   }
   const dl_fold_conv_desc_t d = desc[lo];
-  const int64_t t = (int64_t)blockIdx.x - d.tile_begin;
+  int64_t t = (int64_t)blockIdx.x - d.tile_begin;
   const int Ci = (int)d.Ci, tci = Ci / CW_T;
-  const int co0 = (int)(t / tci) * CW_T, ci0 = (int)(t % tci) * CW_T;
   float* g = (float*)d.g;
   float* dw = (float*)d.dw;
+  if (d.n_img >= DL_FOLD_TAP_SPLIT_MIN_IMAGES) {
+    // many partial images (the high-resolution layers: 16 - 32 channel tiles, 64 - 128 images of the whole chip's accumulators): one
+    // TAP of a channel tile per workgroup -- nine times the workgroups, 16 bytes per lane and image, the images still added in
+    // image order by one lane per element (bit-reproducible)
+    const int tap = (int)(t % 9);
+    t /= 9;
+    const int co0 = (int)(t / tci) * CW_T, ci0 = (int)(t % tci) * CW_T;
+    const int cil = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+    const float* src = g + (int64_t)(tap * Ci + ci0 + cil) * d.ldg + co0 + c4;
+    f32x4_t v = *(const f32x4_t*)src;
+    int s = 1;
+    for (; s + 8 <= (int)d.n_img; s += 8) {
+      f32x4_t u[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) u[e] = *(const f32x4_t*)(src + (int64_t)(s + e) * d.img_stride);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v += u[e];
+    }
+    for (; s < (int)d.n_img; ++s) v += *(const f32x4_t*)(src + (int64_t)s * d.img_stride);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[(c4 + e) * (CW_T + 1) + cil] = v[e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < CW_T * CW_T; i += 256) {
+      const int col = i >> 5, ci = i & (CW_T - 1);
+      dw[((int64_t)(co0 + col) * Ci + ci0 + ci) * 9 + tap] += tile[col * (CW_T + 1) + ci];
+    }
+    return;
+  }
+  const int co0 = (int)(t / tci) * CW_T, ci0 = (int)(t % tci) * CW_T;
   const int n_img = d.n_img > 1 ? (int)d.n_img : 1;
   for (int i = threadIdx.x; i < CW_T * CW_T * 9; i += 256) {
     const int col = i & (CW_T - 1), rest = i / CW_T, cil = rest % CW_T, tap = rest / CW_T;

@@ -816,6 +816,8 @@ class ConvFoldTable:
     dl_conv3x3_wgrad_tn leaves it, or f32 [n_img, 9 Ci, ldg]: the partial images of dl_conv3x3_wgrad_tn_parts, added in image
     order) folded into its [Co, Ci, 3, 3] gradient by ONE launch.  entries: (g, dw)"""
 
+    TAP_SPLIT_MIN_IMAGES = 8  # DL_FOLD_TAP_SPLIT_MIN_IMAGES of include/diffulab_hip.h
+
     @staticmethod
     def accepts(co: int, ci: int) -> bool:
         return co % 32 == 0 and ci % 32 == 0
@@ -836,6 +838,9 @@ class ConvFoldTable:
             if g.dim() == 3:  # partial images
                 assert g.shape[1] >= 9 * ci and g.stride(1) >= co
                 arr[i] = Desc(_p(g), g.stride(1), _p(dw), co, ci, tiles, g.shape[0], g.stride(0))
+                if g.shape[0] >= self.TAP_SPLIT_MIN_IMAGES:  # one tap of a channel tile per workgroup, 16-byte loads
+                    assert g.stride(1) % 4 == 0 and g.stride(0) % 4 == 0 and _p(g) % 16 == 0
+                    tiles += 8 * (co // 32) * (ci // 32)
             else:
                 assert g.shape[0] >= 9 * ci and g.stride(0) >= co
                 arr[i] = Desc(_p(g), g.stride(0), _p(dw), co, ci, tiles, 0, 0)
@@ -934,9 +939,9 @@ def conv3x3_wgrad_tn(x, B, H, W, ci, dy, co, g, zero, max_wgs: int = 0) -> bool:
                   g.stride(0), _p(zero), int(max_wgs), _s())
 
 
-def conv3x3_wgrad_nparts(ci: int, co: int, R: int, max_wgs: int = 0) -> int:
-    """partial images dl_conv3x3_wgrad_tn_parts writes for this shape on this device (0: shape not supported)"""
-    return int(lib().cdll.dl_conv3x3_wgrad_tn_nparts(ci, co, R, int(max_wgs)))
+def conv3x3_wgrad_nparts(H: int, W: int, ci: int, co: int, R: int, max_wgs: int = 0) -> int:
+    """partial images dl_conv3x3_wgrad_tn_parts writes for this shape and map on this device (0: shape not supported)"""
+    return int(lib().cdll.dl_conv3x3_wgrad_tn_nparts(H, W, ci, co, R, int(max_wgs)))
 
 
 def conv3x3_wgrad_tn_parts(x, B, H, W, ci, dy, co, g, zero, max_wgs: int = 0) -> None:

@@ -405,7 +405,7 @@ class UNetEngine:
         else:
             ops.colsum(dy, self.Gr(bname), M, co)
 
-    def _wgrad_stage(self, name: str, ldk: int, co: int, ci: int, R: int) -> Tensor | None:
+    def _wgrad_stage(self, name: str, ldk: int, co: int, ci: int, R: int, H: int, W: int) -> Tensor | None:
         """this convolution's weight-gradient stage, or None.  Default (DL_UNET_WGRAD_PARTS): the partial images [n_parts, ldk, co]
         f32 the R-splits of dl_conv3x3_wgrad_tn_parts STORE (no atomics, nothing to zero; the batched fold adds them in image order:
         bit-reproducible); shapes the implicit-GEMM kernel does not take (Ci % 128) and DL_UNET_WGRAD_PARTS=0: one [ldk, co] image
@@ -415,9 +415,9 @@ class UNetEngine:
         nparts = 0
         if tuning.on("DL_UNET_WGRAD_PARTS"):
             cache = self.__dict__.setdefault("_nparts", {})
-            nparts = cache.get((ci, co, R))
+            nparts = cache.get((H, W, ci, co, R))
             if nparts is None:
-                nparts = cache[(ci, co, R)] = ops.conv3x3_wgrad_nparts(ci, co, R, tuning.integer("DL_UNET_WGRAD_WGS", 0))
+                nparts = cache[(H, W, ci, co, R)] = ops.conv3x3_wgrad_nparts(H, W, ci, co, R, tuning.integer("DL_UNET_WGRAD_WGS", 0))
         st = self.__dict__.setdefault("_stage", {})
         key = (name, nparts)
         g = st.get(key)
@@ -479,7 +479,7 @@ class UNetEngine:
             # the gradient lands transposed, [(tap, ci), co] f32 (9*Ci rows fit the 384-row wgrad tiles), in this convolution's slice of
             # a persistent staging arena; ONE launch at the end of the backward folds every slice into its [Co, Ci, 3, 3] gradient and
             # clears it (_fold_staged).  Channel counts off 32 (the first / last convolution): a temporary stage, folded here.
-            g = self._wgrad_stage(name, ldk, co, ci, Mp)
+            g = self._wgrad_stage(name, ldk, co, ci, Mp, H, W)
             staged = g is not None
             if staged and g.dim() == 3:  # partial images: plain stores, folded in a fixed order
                 ops.conv3x3_wgrad_tn_parts(x, B, H, W, ci, dyp, co8, g, self._zero, max_wgs=tuning.integer("DL_UNET_WGRAD_WGS", 0))

@@ -538,17 +538,20 @@ DL_API int dl_conv3x3_wgrad_tn(const void* x, int64_t ldx, int64_t B, int64_t H,
                                int max_workgroups, dl_stream_t stream);
 /* the same product without atomics (round 6): the R-splits store partial images g + s * part_stride (f32 [9*Ci, ldg] each, written
  * in full with plain stores: nothing is read, nothing needs zeroing) for dl_conv3x3_wgrad_fold_batched (n_img / img_stride of its
- * descriptor) to add in a fixed order -- bit-reproducible.  dl_conv3x3_wgrad_tn_nparts = the number of images the shape produces
- * on this device with this workgroup cap (0: unsupported, Ci % 128 != 0); max_parts = the images the caller's buffer holds. */
-DL_API int dl_conv3x3_wgrad_tn_nparts(int64_t Ci, int64_t Co, int64_t R, int max_workgroups);
+ * descriptor) to add in a fixed order -- bit-reproducible.  dl_conv3x3_wgrad_tn_nparts = the number of images the shape and map
+ * produce on this device with this workgroup cap (0: unsupported, Ci % 128 != 0); max_parts = the images the caller's buffer holds. */
+DL_API int dl_conv3x3_wgrad_tn_nparts(int64_t H, int64_t W, int64_t Ci, int64_t Co, int64_t R, int max_workgroups);
 DL_API int dl_conv3x3_wgrad_tn_parts(const void* x, int64_t ldx, int64_t B, int64_t H, int64_t W, int64_t Ci, const void* dY,
                                      int64_t ldy, int64_t R, int64_t Co, float* g, int64_t ldg, int64_t part_stride,
                                      int64_t max_parts, const void* zero, int max_workgroups, dl_stream_t stream);
 /* weight gradient from dl_gemm_tn(cols, dY) lands transposed as g f32 [(tap, ci), ldg >= Co]: dw[Co, Ci, 3, 3] += g^T */
 DL_API int dl_conv3x3_wgrad_fold(const float* g, int64_t ldg, float* dw, int64_t Co, int64_t Ci, dl_stream_t stream);
 /* The same fold for every convolution of a network in ONE launch (end of the backward): `desc_dev` = device array of n_desc
- * descriptors, tile_begin = running sum of (Co/32)*(Ci/32) (Co, Ci multiples of 32); total_tiles = the sum over all entries.
+ * descriptors, tile_begin = running sum of the entries' workgroup counts: (Co/32)*(Ci/32) (Co, Ci multiples of 32), times 9 for an
+ * entry of DL_FOLD_TAP_SPLIT_MIN_IMAGES or more partial images (one tap of a channel tile per workgroup; such an entry needs
+ * ldg % 4 == 0, img_stride % 4 == 0 and a 16-byte aligned g); total_tiles = the sum over all entries.
  * clear_stage != 0 zeroes each staging tile as it is read (persistent staging buffers need no memset before the next backward). */
+#define DL_FOLD_TAP_SPLIT_MIN_IMAGES 8
 typedef struct dl_fold_conv_desc_t {
   void* g;       /* f32 [9*Ci, ldg]: the staged transposed gradient, row = tap * Ci + ci */
   int64_t ldg;

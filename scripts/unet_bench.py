@@ -33,6 +33,10 @@ def main() -> None:
         from diffulab_amd import ops
 
         ops.lib().cdll.dl_lab_set_nt_deep(int(os.environ["DL_LAB_NT_DEEP"]))
+    if os.environ.get("DL_LAB_WGRAD_HALO"):  # LAB A/B: 0 = the implicit-GEMM weight-gradient kernels of gemm.hip everywhere
+        from diffulab_amd import ops
+
+        ops.lib().cdll.dl_lab_set_wgrad_halo(int(os.environ["DL_LAB_WGRAD_HALO"]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--steps", type=int, default=10)
