@@ -1132,6 +1132,27 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_tn_big_k(const bf16_t* __
 
 int launch_tn_w4(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t R,
                  int max_workgroups, hipStream_t stream);  // gemm_w4.hip
+// How many ranges to split the contraction into when the ranges meet in C through f32 atomics.  Round 6 (profiles/r06_p_*): a
+// workgroup's read-modify-writes drain at ~1.45 TB/s over the whole chip whatever the contention (256 x 295 KB: 52 us), a fifth of
+// the plain-store rate, so "enough workgroups to fill the chip" is the wrong goal for small problems: M = N = 1024 over 2048 rows
+// (the UNet's 4 x 4 attention linears) ran as 1024 workgroups of TWO k-steps and 67 MB of atomics, 54 us for 4 GFLOP.  Model:
+// rounds(S) x ceil(nsteps / S) x step_us + S x image bytes / 1.45 TB/s; the smallest S within 3 % of the minimum.
+static bool g_tn_split_model = true;  // LAB switch (not in the header): false = the workgroup-count rules of rounds 1-5
+extern "C" __attribute__((visibility("default"))) void dl_lab_set_tn_split_model(int on) { g_tn_split_model = on != 0; }
+static int tn_pick_splits(int64_t ntile, int nsteps, int64_t out_elems, int wg_slots, double step_us, int max_splits) {
+  const double image_us = (double)out_elems * 4.0 / 1.45e6;
+  int best = 1;
+  double best_t = 1e30;
+  if (max_splits > nsteps) max_splits = nsteps;
+  for (int S = 1; S <= max_splits; ++S) {
+    const int sps = (nsteps + S - 1) / S;
+    if ((nsteps + sps - 1) / sps != S) continue;  // (not a split count the step rounding produces)
+    const int64_t rounds = (ntile * S + wg_slots - 1) / wg_slots;
+    const double t = (double)rounds * sps * step_us + S * image_us;
+    if (t < best_t * 0.97) best_t = t, best = S;
+  }
+  return best;
+}
 extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                              int64_t N, int64_t R, int max_workgroups, dl_stream_t stream);
 extern "C" int dl_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
@@ -1168,6 +1189,7 @@ extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t 
       int splits = padded_max / tiles_m;
       if (splits < 1) splits = 1;
       if (splits > nsteps / 8) splits = nsteps / 8;
+      if (g_tn_split_model) splits = tn_pick_splits((int64_t)tiles_m * tiles_n, nsteps, M * N, budget, 0.9, splits);
       const int sps = (nsteps + splits - 1) / splits;
       splits = (nsteps + sps - 1) / sps;
       const int units = (tiles_m * splits + 7) & ~7;  // surplus units exit at once
@@ -1182,6 +1204,7 @@ extern "C" int dl_gemm_tn_ex(const void* A, int64_t lda, const void* B, int64_t 
   int splits = (1024 + ntile - 1) / ntile;  // aim at >= 4 workgroups per CU
   if (splits > nsteps) splits = nsteps;
   if (splits < 1) splits = 1;
+  if (g_tn_split_model) splits = tn_pick_splits(ntile, nsteps, M * N, 512, 0.4, splits);  // (two workgroups per CU: 64 KiB of LDS each)
   const int sps = (nsteps + splits - 1) / splits;
   splits = (nsteps + sps - 1) / sps;
   hipLaunchKernelGGL(gemm_tn_k<false>, ntile * splits, NT_THREADS, 65536, (hipStream_t)stream, (const bf16_t*)A, lda,

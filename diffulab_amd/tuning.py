@@ -45,14 +45,18 @@ SWITCHES: dict[str, tuple[str, str]] = {
                        "22.7 ms), hence opt-in"),
     "DL_UNET_SIDE": ("1", "UNet weight gradients on a side stream"),
     "DL_UNET_SPLITK": ("1", "split-K convolutions at the UNet's low-resolution levels (partial images + fixed-order fold: -7 % per step)"),
-    "DL_UNET_WGRAD_WGS": ("0", "workgroup cap of the UNet's side-stream convolution weight gradients (0 = one per CU; round 5, B = 128: "
-                          "0 -> 28.2 ms/step, 224 -> 28.4, 192 -> 28.35, 160 -> 29.0; everything on one stream: 31.1)"),
+    "DL_UNET_WGRAD_WGS": ("128", "workgroup cap of the UNet's side-stream convolution weight gradients (0 = one per CU).  Round 6, with the "
+                          "tap-reusing kernel and partial images (every workgroup stores its 295 KB of accumulators once, so the cap also "
+                          "halves the stage bytes), B = 128: 0 -> 25.4 ms/step, 160 -> 24.1, 128 -> 23.9, 96 -> 24.4, 64 -> 25.0, 48 -> 26.8; "
+                          "B = 64: 0 -> 19.0, 128 -> 18.0 (profiles/r06_q_*).  Round 5 (implicit-GEMM kernels, atomics): 0 was best"),
     "DL_UNET_FOLD_BATCHED": ("1", "UNet convolution weight gradients stay in a persistent transposed staging arena during the backward; one "
                              "launch at its end folds all of them into the [Co, Ci, 3, 3] gradients (instead of a zero-fill and a fold per convolution)"),
-    "DL_UNET_WGRAD_PARTS": ("0", "UNet convolution weight gradients as partial images per R-split (plain stores + fixed-order fold in the batched "
-                            "fold launch: bit-reproducible) instead of f32 atomics into one image -- measured SLOWER (B = 128: 28.5 vs 26.8 ms "
-                            "per step, B = 64: 21.5 vs 20.1: up to 85 images of the small high-resolution gradients, 2.8 GB of stage "
-                            "written and read per step beside the main chain, against atomics the side stream hides)"),
+    "DL_UNET_WGRAD_PARTS": ("1", "UNet convolution weight gradients as partial images per pixel range (plain stores + fixed-order fold in the "
+                            "batched fold launch: bit-reproducible) instead of f32 atomics into one image.  With the tap-reusing kernel of "
+                            "round 6 (conv_wgrad.hip) the atomics were 56 % of a launch (1.45 TB/s of read-modify-writes against 6 TB/s of "
+                            "stores) and the fold takes one tap of a channel tile per workgroup when eight or more images wait: B = 128 "
+                            "24.7 -> 23.9 ms/step, B = 64 19.0 -> 18.0 (same workgroup cap).  With the implicit-GEMM kernels alone it was "
+                            "slower (28.5 vs 26.8 ms: session e)"),
     "DL_UNET_DET_COLSUM": ("0", "UNet bias gradients through the bit-reproducible column sum (measured 2 % slower)"),
 }
 

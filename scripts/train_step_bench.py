@@ -60,6 +60,9 @@ def main() -> None:
     if os.environ.get("DL_LAB_NT_DEEP"):  # LAB A/B: 0 = the two-slot ring of the 128 x 128 GEMM kernel everywhere
         from diffulab_amd import ops
         ops.lib().cdll.dl_lab_set_nt_deep(int(os.environ["DL_LAB_NT_DEEP"]))
+    if os.environ.get("DL_LAB_TN_SPLIT_MODEL"):  # LAB A/B: 0 = the workgroup-count split rules of the atomic weight-gradient GEMMs
+        from diffulab_amd import ops
+        ops.lib().cdll.dl_lab_set_tn_split_model(int(os.environ["DL_LAB_TN_SPLIT_MODEL"]))
     ap = argparse.ArgumentParser()
     ap.add_argument("config", choices=list(CFG))
     ap.add_argument("--batch", type=int, default=32)

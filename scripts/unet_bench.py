@@ -37,6 +37,10 @@ def main() -> None:
         from diffulab_amd import ops
 
         ops.lib().cdll.dl_lab_set_wgrad_halo(int(os.environ["DL_LAB_WGRAD_HALO"]))
+    if os.environ.get("DL_LAB_TN_SPLIT_MODEL"):  # LAB A/B: 0 = the workgroup-count split rules of the atomic weight-gradient GEMMs
+        from diffulab_amd import ops
+
+        ops.lib().cdll.dl_lab_set_tn_split_model(int(os.environ["DL_LAB_TN_SPLIT_MODEL"]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--steps", type=int, default=10)
