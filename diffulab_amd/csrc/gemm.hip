@@ -836,6 +836,9 @@ __device__ __forceinline__ void tr_landed(bf16x8_t (&a)[NA], bf16x8_t (&b)[NB]) 
   for (int j = 0; j < NB; ++j) asm volatile("" : "+v"(b[j]));
 }
 
+// (A four-slot ring for launches of at most one workgroup per CU -- what gemm_nt_k<CONV, 4> does -- was measured here in round 6 and
+// changes nothing, alone or in the UNet step: profiles/r06_t_tn_ring_and_split_sweep.txt; a lone workgroup's k-step costs 0.64 us
+// with either ring.)
 template <bool CONV>
 __global__ __launch_bounds__(NT_THREADS, 2) void gemm_tn_k(const bf16_t* __restrict__ A, int64_t lda,
                                                              const bf16_t* __restrict__ Bm, int64_t ldb,
@@ -1139,7 +1142,10 @@ int launch_tn_w4(const void* A, int64_t lda, const void* B, int64_t ldb, float* 
 // rounds(S) x ceil(nsteps / S) x step_us + S x image bytes / 1.45 TB/s; the smallest S within 3 % of the minimum.
 static bool g_tn_split_model = true;  // LAB switch (not in the header): false = the workgroup-count rules of rounds 1-5
 extern "C" __attribute__((visibility("default"))) void dl_lab_set_tn_split_model(int on) { g_tn_split_model = on != 0; }
+static int g_tn_force_splits = 0;  // LAB: > 0 = this split count (clamped to the k-steps) instead of the model's
+extern "C" __attribute__((visibility("default"))) void dl_lab_set_tn_force_splits(int n) { g_tn_force_splits = n; }
 static int tn_pick_splits(int64_t ntile, int nsteps, int64_t out_elems, int wg_slots, double step_us, int max_splits) {
+  if (g_tn_force_splits > 0) return g_tn_force_splits < nsteps ? g_tn_force_splits : nsteps;
   const double image_us = (double)out_elems * 4.0 / 1.45e6;
   int best = 1;
   double best_t = 1e30;

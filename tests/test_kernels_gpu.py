@@ -163,6 +163,33 @@ def test_small_launch_gemm_on_the_four_slot_ring_equals_the_two_slot_form(ops, M
     assert rel(outs[1].float(), ref) < 5e-3
 
 
+@pytest.mark.parametrize("M,N,R", [(512, 512, 8192), (1024, 1024, 2048), (128, 256, 131072), (1024, 512, 8192), (256, 768, 32768), (2048, 1024, 2048),
+                                   (200, 136, 4096 + 64), (28672, 512, 128), (64, 128, 16384)])
+def test_atomic_weight_gradient_gemm_split_rules(ops, M, N, R):
+    """round 6: dl_gemm_tn picks its split count from a cost model (k-steps per range + the ranges' f32 read-modify-writes at the rate
+    measured for them) instead of a workgroup count.  Both rules (lab switch) and a forced count of 3 are the same products in
+    another f32 summation order; accumulating on top of a non-zero C."""
+    a = dev_bf(bf(synth.normal(f"ts.a{M}", (R, M))))
+    b_ = dev_bf(bf(synth.normal(f"ts.b{N}", (R, N))))
+    ref = a.float().t() @ b_.float()
+    lib = ops.lib().cdll
+    outs = []
+    try:
+        for model, force in ((0, 0), (1, 0), (1, 3)):
+            lib.dl_lab_set_tn_split_model(model)
+            lib.dl_lab_set_tn_force_splits(force)
+            c = torch.full((M, N + 8), 0.5, device=DEV)
+            ops.gemm_tn(a, b_, c[:, :N], M=M, N=N)
+            assert bool((c[:, N:] == 0.5).all())
+            outs.append(c[:, :N] - 0.5)
+    finally:
+        lib.dl_lab_set_tn_split_model(1)
+        lib.dl_lab_set_tn_force_splits(0)
+    scale = ref.abs().max()
+    for o in outs:
+        assert float((o - ref).abs().max() / scale) < 2e-5 * (1 + R / 8192)
+
+
 @pytest.mark.parametrize("R,cap,ranges,D", [(4096 + 32 * 7, 0, 8, 384), (8192, 128, 8, 384), (2048, 64, 8, 384), (4096, 0, 1, 384),
                                             (16384, 0, 3, 384), (8192, 0, 8, 512), (2048 + 32 * 5, 192, 2, 512), (4096, 0, 8, 768),
                                             (4096, 0, 8, 256),
