@@ -186,6 +186,14 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restr
   // partial tiles meet in C through f32 atomics (C zeroed by the launcher)
   const int nk_all = K / BK;
   const int k_lo = (int)((int64_t)nk_all * blockIdx.y / ksplit), nk = (int)((int64_t)nk_all * (blockIdx.y + 1) / ksplit);
+  // the bias of this lane's eight output columns, requested BEFORE the first operand stage (the oldest loads in flight: the counted
+  // waits below only get stricter): in the epilogue the eight row passes used to fetch them again, one dependent round trip per
+  // two passes -- 4.5 us of an 18 us launch (round 6, scripts/lab/unet_nt_shapes.py: every shape with a bias)
+  const int erow = lane >> 3, ecol = (lane & 7) * 8;
+  const int en = n0 + wc * 64 + ecol;
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = (ep.bias && en + e < N) ? ep.bias[en + e] : 0.f;
   if (NSLOT == 2) {
     if (k_lo < nk) stage(k_lo, k_lo & 1);
   } else {
@@ -227,7 +235,22 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restr
   }
 
   // ---- epilogue: accumulators -> wave-private LDS slab (f32) -> row-contiguous 16-byte global stores
-  __syncthreads();  // every wave is done reading the operand buffers
+  // the residual rows of all eight passes requested at once, under the accumulators' trip through the slab (one round trip
+  // instead of four: cold operands cost 9 us of a 28 us launch)
+  // (compiler-visible vmcnt(0) -- every operand stage has landed long ago -- so that the waitcnt pass does not put one in front of
+  //  the slab's LDS traffic, behind the residual loads: it cannot tell LDS accesses from the DMA's targets otherwise)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  const bool efull = en + 8 <= N;
+  u32x4_t rv[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int m = m0 + wr * 64 + p * 8 + erow;
+    rv[p] = u32x4_t{0u, 0u, 0u, 0u};
+    if (ep.resid && efull && m < M) rv[p] = *(const u32x4_t*)(ep.resid + (int64_t)m * ep.ldr + en);
+  }
+  // every wave is done reading the operand buffers (its fragments were consumed by its MFMAs): a raw barrier -- __syncthreads()
+  // would drain the residual loads just issued
+  __builtin_amdgcn_s_barrier();
   float* slab = (float*)smem + wave * 64 * STAGE_PITCH;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -238,22 +261,22 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restr
         const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         slab[row * STAGE_PITCH + j * 32 + (lane & 31)] = acc[i][j][r];
       }
-  __syncthreads();
-  const int erow = lane >> 3, ecol = (lane & 7) * 8;
-#pragma unroll 2
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the slab is wave-private: lanes read what other lanes of the wave wrote
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
   for (int p = 0; p < 8; ++p) {
     const int row = p * 8 + erow;
     const int m = m0 + wr * 64 + row;
-    const int n = n0 + wc * 64 + ecol;
+    const int n = en;
     if (m >= M || n >= N) continue;
     float v[8];
     *(f32x4_t*)&v[0] = *(const f32x4_t*)&slab[row * STAGE_PITCH + ecol];
     *(f32x4_t*)&v[4] = *(const f32x4_t*)&slab[row * STAGE_PITCH + ecol + 4];
-    const bool full = (n + 8 <= N);
+    const bool full = efull;
     if (ep.bias) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (full || n + e < N) v[e] += ep.bias[n + e];
+      for (int e = 0; e < 8; ++e) v[e] += bv[e];
     }
     if (ep.pre_out) {
       bf16_t* po = ep.pre_out + (int64_t)m * ldc + n;
@@ -274,7 +297,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restr
       const bf16_t* rp = ep.resid + (int64_t)m * ep.ldr + n;
       float rr[8], gg[8];
       if (full) {
-        unpack8(*(const u32x4_t*)rp, rr);
+        unpack8(rv[p], rr);
       } else {
         for (int e = 0; e < 8; ++e) rr[e] = (n + e < N) ? bf2f(rp[e]) : 0.f;
       }
