@@ -85,23 +85,23 @@ struct CwCfg {
   static constexpr int brow(int kk, int tap) { return urow(kk) + delta(tap); }
 };
 
-// read stream of one step: B(0), A(0), A(1), then per item s = 9 kk + tap: [B(kk + 1) if tap == 6 and kk < 3], [A(s + 2) if s + 2 < 36].
-// Fragments (two transposing reads each) return in order: at item s, A(s) and B(kk) must have landed.
-constexpr int cw_frags_through(int s) {  // fragments issued up to and including item s (s = -1: the prologue)
-  int n = 3;
-  for (int u = 0; u <= s; ++u) n += ((u % 9 == 6 && u / 9 < 3) ? 1 : 0) + (u + 2 < 36 ? 1 : 0);
-  return n;
-}
-constexpr int cw_idx_a(int s) { return s < 2 ? 2 + s : cw_frags_through(s - 2); }
-constexpr int cw_idx_b(int kk) {
-  if (kk == 0) return 1;
-  const int u = (kk - 1) * 9 + 6;
-  return cw_frags_through(u) - (u + 2 < 36 ? 1 : 0);
-}
+// Read stream.  Item s = 9 kk + tap of a step is one MFMA: acc[tap] += A(s) . B(kk).  Fragments (two transposing reads each) return
+// in order.  The stream runs CW_D items ahead of the MFMAs and does not stop at a step boundary: item s issues A(s + D) -- of the
+// NEXT step's stage once s + D >= 36 -- and, at tap CW_BT, B(kk + 1) (kk = 3: the next step's B(0)), which therefore sits just in
+// front of the first A fragment of its block.  Before item s's MFMA at most `cw_younger_reads(s)` reads may be outstanding: the D
+// younger A fragments and the B fragments issued since A(s).  The ring of D + 1 A registers divides 36, so the register a fragment
+// lands in does not depend on the step.
+#define CW_D 5
+#define CW_BT (8 - CW_D)
+#define CW_MB 13  // item in front of which the NEXT stage is waited for (every wave's share) and the stage three steps ahead is requested
+constexpr int cw_mod9(int u) { return ((u % 9) + 9) % 9; }
 constexpr int cw_younger_reads(int s) {
-  const int a = cw_idx_a(s), b = cw_idx_b(s / 9);
-  return 2 * (cw_frags_through(s) - (a > b ? a : b));
+  int nb = 0;
+  for (int u = s - CW_D + 1; u <= s; ++u) nb += cw_mod9(u) == CW_BT ? 1 : 0;
+  return 2 * (CW_D + nb);
 }
+static_assert(36 % (CW_D + 1) == 0 && CW_BT >= 0 && 2 * (CW_D + 1) <= 15, "read stream");
+static_assert(CW_MB < 27 + CW_BT && CW_MB < 36 - CW_D, "the next stage is awaited before its first fragment is requested");
 
 struct CwArgs {
   const bf16_t* X;
@@ -215,59 +215,68 @@ __global__ __launch_bounds__(CW_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     bf16x8_t v;
   };
 
-  auto compute = [&](unsigned sb) __attribute__((always_inline)) {
-    unsigned ax[4], ax1[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      ax[v] = sb + lx[v];
-      ax1[v] = sb + lx1[v];
-    }
-    const unsigned bx = sb + boff;
-    Frag aq[3], bq[2];
-    auto read_a = [&](auto S_) __attribute__((always_inline)) {
-      constexpr int s = decltype(S_)::value, kk = s / 9, tap = s % 9;
-      constexpr int b = Cfg::brow(kk, tap), v = b & 3;
-      aq[s % 3].h[0] = tr16_cw<b * 128>(ax[v]);
-      if constexpr (Cfg::HALF_IMM) aq[s % 3].h[1] = tr16_cw<b * 128 + 512>(ax[v]);
-      else aq[s % 3].h[1] = tr16_cw<b * 128>(ax1[v]);
-    };
-    auto read_b = [&](auto K_) __attribute__((always_inline)) {
-      constexpr int kk = decltype(K_)::value;
-      bq[kk & 1].h[0] = tr16_cw<kk * 4096>(bx);
-      bq[kk & 1].h[1] = tr16_cw<kk * 4096 + 1024>(bx);
-    };
-    read_b(std::integral_constant<int, 0>{});
-    read_a(std::integral_constant<int, 0>{});
-    read_a(std::integral_constant<int, 1>{});
+  Frag aq[CW_D + 1], bq[2];
+  // fragment s (0 .. 35 + D: beyond 35 it belongs to the next step, stage base sn) / B block kk (4 = the next step's first)
+  auto read_a = [&](auto S_, unsigned sb, unsigned sn) __attribute__((always_inline)) {
+    constexpr int s = decltype(S_)::value, sm = s % 36, kk = sm / 9, tap = sm % 9;
+    constexpr int b = Cfg::brow(kk, tap), v = b & 3;
+    const unsigned base = s < 36 ? sb : sn;
+    aq[s % (CW_D + 1)].h[0] = tr16_cw<b * 128>(base + lx[v]);
+    if constexpr (Cfg::HALF_IMM) aq[s % (CW_D + 1)].h[1] = tr16_cw<b * 128 + 512>(base + lx[v]);
+    else aq[s % (CW_D + 1)].h[1] = tr16_cw<b * 128>(base + lx1[v]);
+  };
+  auto read_b = [&](auto K_, unsigned sb, unsigned sn) __attribute__((always_inline)) {
+    constexpr int kk = decltype(K_)::value;
+    const unsigned base = (kk < 4 ? sb : sn) + boff;
+    bq[kk & 1].h[0] = tr16_cw<(kk & 3) * 4096>(base);
+    bq[kk & 1].h[1] = tr16_cw<(kk & 3) * 4096 + 1024>(base);
+  };
+  // one step: 36 MFMAs of this wave on stage `it`; FULL: the stage three steps ahead exists (straight-line body)
+  auto step = [&](auto full_c, int it) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_c)::value;
+    const unsigned sb = lds0 + (it & (CW_NST - 1)) * STAGE, sn = lds0 + ((it + 1) & (CW_NST - 1)) * STAGE;
     static_for<0, 36>([&](auto S_) __attribute__((always_inline)) {
       constexpr int s = decltype(S_)::value, kk = s / 9, tap = s % 9;
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (tap == 6 && kk < 3) read_b(std::integral_constant<int, kk + 1>{});
-      if constexpr (s + 2 < 36) read_a(std::integral_constant<int, s + 2>{});
+      if constexpr (s == CW_MB) {
+        // stage it + 1 has landed (the one stage requested after it may stay in flight) for every wave, and every wave is past step
+        // it - 1: its slot takes stage it + 3
+        if (FULL) {
+          wait_vmcnt_cw<CHMIN>();
+          __builtin_amdgcn_s_barrier();
+          issue(it + CW_NST - 1);
+        } else if (it + 1 < n) {
+          wait_vmcnt_cw<0>();
+          __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (tap == CW_BT) read_b(std::integral_constant<int, kk + 1>{}, sb, sn);
+      read_a(std::integral_constant<int, s + CW_D>{}, sb, sn);
       wait_lgkm_cw<cw_younger_reads(s)>();
-      asm volatile("" : "+v"(aq[s % 3].v), "+v"(bq[kk & 1].v));  // no MFMA on these registers above the wait
-      acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[s % 3].v, bq[kk & 1].v, acc[tap], 0, 0, 0);
+      asm volatile("" : "+v"(aq[s % (CW_D + 1)].v), "+v"(bq[kk & 1].v));  // no MFMA on these registers above the wait
+      acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[s % (CW_D + 1)].v, bq[kk & 1].v, acc[tap], 0, 0, 0);
     });
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- ring: NST - 1 stages in flight
+  // ---- ring: stages 0 .. 2 requested, stage 0 awaited, the read stream primed with B(0), A(0 .. D - 1)
   {
     const int pre = n < CW_NST - 1 ? n : CW_NST - 1;
     for (int st = 0; st < pre; ++st) issue(st);
+    if (n >= CW_NST - 1) wait_vmcnt_cw<(CW_NST - 2) * CHMIN>();
+    else wait_vmcnt_cw<0>();
+    __builtin_amdgcn_s_barrier();
+    read_b(std::integral_constant<int, 0>{}, lds0, lds0);
+    static_for<0, CW_D>([&](auto S_) __attribute__((always_inline)) { read_a(S_, lds0, lds0); });
   }
   int it = 0;
-  for (; it + CW_NST - 1 < n; ++it) {
-    wait_vmcnt_cw<(CW_NST - 2) * CHMIN>();  // stage `it` landed; it+1, it+2 may stay in flight
-    __builtin_amdgcn_s_barrier();           // every wave's share landed; slot (it - 1) % NST has no readers left
-    issue(it + CW_NST - 1);
-    compute(lds0 + (it & (CW_NST - 1)) * STAGE);
-  }
-  for (; it < n; ++it) {
-    wait_vmcnt_cw<0>();
-    __builtin_amdgcn_s_barrier();
-    compute(lds0 + (it & (CW_NST - 1)) * STAGE);
-  }
+  for (; it + CW_NST - 1 < n; ++it) step(std::true_type{}, it);
+  for (; it < n; ++it) step(std::false_type{}, it);
+  // (the stream ran D fragments into a stage that does not exist: stale LDS, never used -- but they must land before their registers
+  //  are given to the epilogue)
+  wait_lgkm_cw<0>();
+  asm volatile("" ::: "memory");
 
   // ---- acc[tap][r] = g[(tap, ci0 + wi * 32 + m), n0 + wj * 32 + (lane & 31)], m from r and the lane half
   float* gp = a.G + (a.part_stride > 0 ? (int64_t)split * a.part_stride : 0) + n0 + wj * 32 + (lane & 31);
