@@ -29,7 +29,7 @@
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-namespace {
+namespace {  // helpers only: the kernel itself keeps external linkage so that profilers print its name
 
 __device__ __forceinline__ void glds16_cw(const void* gsrc, void* lds_dst_wave_base) {
   __builtin_amdgcn_global_load_lds((glb_void_t*)gsrc, (lds_void_t*)lds_dst_wave_base, 16, 0, 0);
@@ -102,6 +102,8 @@ constexpr int cw_younger_reads(int s) {
 }
 static_assert(36 % (CW_D + 1) == 0 && CW_BT >= 0 && 2 * (CW_D + 1) <= 15, "read stream");
 static_assert(CW_MB < 27 + CW_BT && CW_MB < 36 - CW_D, "the next stage is awaited before its first fragment is requested");
+
+}  // namespace
 
 struct CwArgs {
   const bf16_t* X;
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(CW_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 }
 
 template <int LW, int NROW>
-int launch_cw(const CwArgs& a, int grid, hipStream_t stream) {
+static int launch_cw(const CwArgs& a, int grid, hipStream_t stream) {
   using Cfg = CwCfg<LW, NROW>;
   static DevOnce once;
   (void)dev_cus(once, [] {
@@ -312,8 +314,6 @@ int launch_cw(const CwArgs& a, int grid, hipStream_t stream) {
   DL_LAUNCH_CHECK();
   return DL_OK;
 }
-
-}  // namespace
 
 static int g_wgrad_halo = 1;  // LAB switch (not in the header): 0 = the implicit-GEMM kernels of gemm.hip everywhere
 extern "C" __attribute__((visibility("default"))) void dl_lab_set_wgrad_halo(int on) { g_wgrad_halo = on; }
