@@ -1762,6 +1762,8 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void conv3x3_halo_k(const bf16_t* _
     wait_vmcnt<0>();
   }
 }
+static int g_conv_split128 = 1;  // LAB switch: 0 = split launches always take 256-wide tiles where Co allows (round 5)
+extern "C" __attribute__((visibility("default"))) void dl_lab_set_conv_split128(int on) { g_conv_split128 = on; }
 static int g_conv_halo_nst = 4;  // LAB: ring depth of the 128-wide halo kernel's weight stages
 extern "C" __attribute__((visibility("default"))) void dl_lab_set_conv_halo_nst(int n) { g_conv_halo_nst = n; }
 static int g_conv_halo = 1;  // LAB switch (not in the header): 0 = never, 1 = conv3x3_halo_k where the shape fits (default), 2 = also for small launches (tests)
@@ -1846,15 +1848,26 @@ extern "C" int dl_conv3x3_nt(const void* x, int64_t ldx, int64_t Bn, int64_t H, 
     }
     int ksplit = 1;
     if (tiles < (n_cu * 3) / 4) {
+      auto splits_for = [&](int64_t t) {
+        int ks = (int)((n_cu + t - 1) / t);
+        if (ks > 8) ks = 8;
+        if (ks > (int)(K / 1152)) ks = (int)(K / 1152);
+        if (!splitk_scratch || ks > scratch_floats / (M * Co)) ks = splitk_scratch ? (int)(scratch_floats / (M * Co)) : 1;
+        return ks < 2 ? 1 : ks;
+      };
+      // 256-wide tiles (128 FLOP per staged byte against 85) as long as their split still fills three quarters of the chip; the
+      // smallest maps (8 x 8 and 4 x 4 at the configured batch of 64: 16-32 wide tiles, at most 8 splits of >= 18 k-steps) do not --
+      // there the 128-wide tile's second half of the CUs is worth more than its bytes (round 6: 46-50 -> 35-40 us alone)
+      tn = 128;
+      tiles = mt * (Co / 128);
+      ksplit = splits_for(tiles);
       if (Co % 256 == 0) {
-        tn = 256;
-        tiles = mt * (Co / 256);
+        const int64_t t256 = mt * (Co / 256);
+        const int k256 = splits_for(t256);
+        // (an UNSPLIT launch of fewer than three quarters of the CUs stays with the 256-wide candidate and, failing the test below,
+        //  with the 128 x 128 kernel: 16 x 16, 128 -> 256 channels at B = 64 is 24 us there and 28 on 128 persistent workgroups)
+        if (t256 * k256 >= (n_cu * 3) / 4 || t256 * k256 >= tiles * ksplit || ksplit < 2 || !g_conv_split128) tn = 256, tiles = t256, ksplit = k256;
       }
-      ksplit = (int)((n_cu + tiles - 1) / tiles);
-      if (ksplit > 8) ksplit = 8;
-      if (ksplit > (int)(K / 1152)) ksplit = (int)(K / 1152);
-      if (!splitk_scratch || ksplit > scratch_floats / (M * Co)) ksplit = splitk_scratch ? (int)(scratch_floats / (M * Co)) : 1;
-      if (ksplit < 2) ksplit = 1;
     }
     if (tiles * ksplit >= n_cu / 2 || (g_conv_big == 2 && tiles * ksplit >= 8)) {  // (2 = LAB / tests: whenever the shape tiles)
       NtEpilogue ep{bias, DL_ACT_NONE, 0, nullptr, (const bf16_t*)resid, ldr, nullptr, 0, 1, nullptr, 0, 0};

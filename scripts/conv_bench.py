@@ -18,6 +18,10 @@ def timeit(fn, n=20):
 r64 = lambda v: (v + 63) // 64 * 64
 zero = torch.zeros(64, device=dev, dtype=BF)
 lib = ops.lib().cdll
+if os.environ.get("DL_LAB_CONV_SPLIT128"):
+    lib.dl_lab_set_conv_split128(int(os.environ["DL_LAB_CONV_SPLIT128"]))
+if os.environ.get("CONV_BENCH_B"):
+    B = int(os.environ["CONV_BENCH_B"])
 if os.environ.get("HALO_NST"):
     lib.dl_lab_set_conv_halo_nst(int(os.environ["HALO_NST"]))
 rows = []

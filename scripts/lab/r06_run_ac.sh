@@ -1,0 +1,8 @@
+# round 6, session ac: split convolution launches on 128-wide tiles where 256-wide ones leave the chip half empty
+export TMPDIR=/tmp
+OUT=gpurun_out/r06_ac; mkdir -p $OUT
+timeout 600 python -m pytest tests/test_unet_gpu.py -q -x -m gpu -k "conv3x3" 2>&1 | tail -2
+for b in 128 64 32; do for v in 0 1; do echo "== conv alone B=$b split128=$v"; CONV_BENCH_B=$b DL_LAB_CONV_SPLIT128=$v python scripts/conv_bench.py 2>&1 | grep -v amdgpu.ids | grep "16x16\|8x8\| 4x4" | cut -c1-120; done; done > $OUT/conv_alone.txt 2>&1; cat $OUT/conv_alone.txt
+{
+for b in 128 64; do for v in 0 1 0 1; do echo "unet B=$b split128=$v $(DL_LAB_CONV_SPLIT128=$v python scripts/unet_bench.py --batch $b --steps 30 --warmup 8 2>&1 | grep workload | cut -c58-120)"; done; done
+} > $OUT/step.txt 2>&1; cat $OUT/step.txt

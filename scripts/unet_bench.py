@@ -41,6 +41,10 @@ def main() -> None:
         from diffulab_amd import ops
 
         ops.lib().cdll.dl_lab_set_tn_split_model(int(os.environ["DL_LAB_TN_SPLIT_MODEL"]))
+    if os.environ.get("DL_LAB_CONV_SPLIT128"):  # LAB A/B: 0 = split convolution launches always on 256-wide tiles
+        from diffulab_amd import ops
+
+        ops.lib().cdll.dl_lab_set_conv_split128(int(os.environ["DL_LAB_CONV_SPLIT128"]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--steps", type=int, default=10)
