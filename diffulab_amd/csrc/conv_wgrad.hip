@@ -12,9 +12,14 @@
 //   * fragments come out of ds_read_b64_tr_b16 (both operands are contraction-major in memory); the halo row of (pixel, tap) is
 //     lane part + compile-time constant, and the 16-byte-slot swizzle is arranged so that the constant lands in the instruction's
 //     offset field: no address arithmetic per MFMA (below, "swizzle");
-//   * four-slot LDS ring (<= 136 KiB), three stages in flight under counted vmcnt waits, one barrier per 36 MFMAs of a wave;
-//   * the pixel range is split over workgroups (one per CU), the splits meet in g through f32 atomics like the older kernels
-//     (dl_conv3x3_wgrad_tn keeps its contract; the partial-image form stays on the older kernels).
+//   * four-slot LDS ring (<= 136 KiB), stages in flight under counted vmcnt waits, ONE barrier per 36 MFMAs of a wave -- in mid-step,
+//     where it admits the NEXT stage: the fragment read stream runs five fragments ahead of the MFMAs (counted lgkmcnt waits) and
+//     does not stop at a step boundary;
+//   * the pixel range is split over workgroups (one per CU at most, all tiles of a range on one XCD).  Two epilogues:
+//     dl_conv3x3_wgrad_tn -- the ranges meet in g through f32 atomics (its contract since round 2); dl_conv3x3_wgrad_tn_parts --
+//     every range STORES its image, the batched fold adds them in image order.  Measured (profiles/r06_p_*, r06_w_*): the loop runs
+//     at 1.19-1.3 PFLOP/s; the atomics of the first form are 56 % of a launch (they drain at 1.45 TB/s, plain rows at ~6), which is
+//     why the engine takes the second.
 // 8 waves as 2 (32-channel halves of the chunk) x 4 (32 output channels): a wave owns one 32 x 32 MFMA tile per tap.
 //
 // Swizzle.  Halo image: 128-byte rows; 16-byte slot s of row rho is stored at slot s ^ (key(rho) << 2), key(rho) = bit 1 of rho, so
@@ -318,8 +323,9 @@ static int launch_cw(const CwArgs& a, int grid, hipStream_t stream) {
 static int g_wgrad_halo = 1;  // LAB switch (not in the header): 0 = the implicit-GEMM kernels of gemm.hip everywhere
 extern "C" __attribute__((visibility("default"))) void dl_lab_set_wgrad_halo(int on) { g_wgrad_halo = on; }
 
-// 1: shape not taken (the caller falls back to the implicit-GEMM kernels); DL_OK / error otherwise.  Atomic form only (part_stride 0)
-// unless the caller has sized its partial images by conv_wgrad_halo_splits.
+// conv_wgrad_halo_splits: the pixel ranges (= partial images of the store form) this kernel uses for a shape, 0 = shape not taken
+// (the caller falls back to the implicit-GEMM kernels).  launch_conv_wgrad_halo: 1 = not taken; DL_OK / error otherwise; part_stride
+// > 0 selects the store form (the caller has sized its images by conv_wgrad_halo_splits).
 int conv_wgrad_halo_splits(int64_t H, int64_t W, int64_t Ci, int64_t Co, int64_t R, int max_workgroups, int n_cu, int* sps_out) {
   if (!g_wgrad_halo || Ci % CW_CK != 0 || Co % CW_CN != 0 || R % 64 != 0 || (H & (H - 1)) != 0) return 0;
   const bool geom = (W == 32 && H % 2 == 0) || (W == 16 && H % 4 == 0) || (W == 8 && H == 8) || (W == 4 && H == 4);
