@@ -54,6 +54,16 @@ struct NtEpilogue {
   // leave with the qkv GEMM.  Two addends per element (the tile's two column waves) on a zeroed word: order-independent.
   float* ssq;
   int ssq_tiles;
+  // 128x128 kernel only (dl_gemm_nt_pair): a SECOND, independent product in the same launch -- workgroups from `tiles0` on compute
+  // C2 = A2 B2^T (+ bias2, + resid2) with the same activation / output type; 0 = one product.  Two under-filled launches (the q and kv
+  // projections of a UNet AttentionBlock at the low-resolution levels: 64 + 128 tiles on 256 CUs) become one that fills the chip.
+  const bf16_t* A2;
+  const bf16_t* B2;
+  void* C2;
+  const float* bias2;
+  const bf16_t* resid2;
+  int64_t lda2, ldb2, ldc2, ldr2;
+  int M2, N2, K2, tiles0;
 };
 
 // implicit-GEMM view of a 3x3 / pad 1 convolution over NHWC rows: the A operand "cols[p, (tap, ci)]" is never materialised,
@@ -93,14 +103,23 @@ static ConvGeom make_conv_geom(int64_t H, int64_t W, int64_t Ci, int64_t ldx, in
 // workgroup can have the LDS: a four-slot ring (128 KiB), three stages in flight, counted vmcnt waits and raw barriers as in
 // gemm_nt_big_k.
 template <bool CONV, int NSLOT = 2>
-__global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restrict__ A, int64_t lda,
-                                                             const bf16_t* __restrict__ Bm, int64_t ldb,
-                                                             void* __restrict__ C, int64_t ldc, int M, int N, int K,
+__global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_k(const bf16_t* __restrict__ A_, int64_t lda_,
+                                                             const bf16_t* __restrict__ Bm_, int64_t ldb_,
+                                                             void* __restrict__ C_, int64_t ldc_, int M_, int N_, int K_,
                                                              NtEpilogue ep, int ksplit, ConvGeom cg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // (wave-uniform selection of the launch's first or second product: everything below sees one problem)
+  const bool second = !CONV && ep.tiles0 > 0 && (int)blockIdx.x >= ep.tiles0;
+  const bf16_t* __restrict__ A = second ? ep.A2 : A_;
+  const bf16_t* __restrict__ Bm = second ? ep.B2 : Bm_;
+  void* __restrict__ C = second ? ep.C2 : C_;
+  const int64_t lda = second ? ep.lda2 : lda_, ldb = second ? ep.ldb2 : ldb_, ldc = second ? ep.ldc2 : ldc_;
+  const int M = second ? ep.M2 : M_, N = second ? ep.N2 : N_, K = second ? ep.K2 : K_;
+  if (second) ep.bias = ep.bias2, ep.resid = ep.resid2, ep.ldr = ep.ldr2;
+  const int bid = second ? (int)blockIdx.x - ep.tiles0 : (int)blockIdx.x;
   const int tiles_n = (N + BN - 1) / BN;
   const int tiles_m = (M + BM - 1) / BM;
-  const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int lid = xcd_remap(bid, tiles_m * tiles_n);
   const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -796,6 +815,46 @@ extern "C" int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb
   }
   launch_nt_small<false>(dim3(nwg, ksplit), (hipStream_t)stream, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, (int)M, (int)N, (int)K, ep,
                          ksplit, ConvGeom{});
+  DL_LAUNCH_CHECK();
+  return DL_OK;
+}
+
+/* two independent products C_i = A_i B_i^T (+ bias_i, + resid_i), bf16 in / bf16 out, in ONE launch of the 128 x 128 kernel when both
+ * are small (together at most 1.5 workgroups per CU: neither would take a persistent tiling); otherwise -- and for n == 1 -- the two
+ * dl_gemm_nt calls it stands for.  Same products in the same order as those calls: bit-identical results. */
+extern "C" int dl_gemm_nt_pair(const dl_nt_problem_t* p, int n, dl_stream_t stream) {
+  DL_CHECK_ARG(p && (n == 1 || n == 2), "dl_gemm_nt_pair: one or two problems");
+  static DevOnce once;
+  const int n_cu = dev_cus(once, [] {});
+  int64_t nwg[2] = {0, 0};
+  bool small = n == 2;
+  for (int i = 0; i < n; ++i) {
+    const dl_nt_problem_t& q = p[i];
+    DL_CHECK_ARG(q.A && q.B && q.C && q.M > 0 && q.N > 0 && q.K > 0 && q.K % BK == 0, "dl_gemm_nt_pair: operand %d", i);
+    DL_CHECK_ARG(q.lda % 8 == 0 && q.ldb % 8 == 0 && q.ldc % 8 == 0 && q.lda >= q.K && q.ldb >= q.K && q.ldc >= q.N &&
+                     (!q.resid || q.ldr % 8 == 0) && q.M < (1ll << 31) && q.N < (1ll << 31),
+                 "dl_gemm_nt_pair: leading dims of problem %d", i);
+    DL_CHECK_ARG((((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C | (uintptr_t)q.resid) & 15) == 0, "dl_gemm_nt_pair: 16-byte alignment");
+    nwg[i] = (int64_t)cdiv(q.M, BM) * cdiv(q.N, BN);
+  }
+  if (small) small = nwg[0] + nwg[1] <= (3 * (int64_t)n_cu) / 2;
+  if (!small) {
+    for (int i = 0; i < n; ++i) {
+      const int rc = dl_gemm_nt(p[i].A, p[i].lda, p[i].B, p[i].ldb, p[i].C, p[i].ldc, p[i].M, p[i].N, p[i].K, p[i].bias, DL_ACT_NONE, DL_BF16,
+                                nullptr, p[i].resid, p[i].ldr, nullptr, 0, 1, stream);
+      if (rc != DL_OK) return rc;
+    }
+    return DL_OK;
+  }
+  // the product with the shallower contraction goes first: launch_nt_small picks the ring depth from the K it is given (a four-slot
+  // ring needs four k-steps to have a steady state)
+  const int f = p[0].K <= p[1].K ? 0 : 1, g = 1 - f;
+  NtEpilogue ep{p[f].bias, DL_ACT_NONE, 0, nullptr, (const bf16_t*)p[f].resid, p[f].ldr, nullptr, 0, 1, nullptr, 0, 0, 0, 0};
+  ep.A2 = (const bf16_t*)p[g].A, ep.B2 = (const bf16_t*)p[g].B, ep.C2 = p[g].C, ep.bias2 = p[g].bias, ep.resid2 = (const bf16_t*)p[g].resid;
+  ep.lda2 = p[g].lda, ep.ldb2 = p[g].ldb, ep.ldc2 = p[g].ldc, ep.ldr2 = p[g].ldr;
+  ep.M2 = (int)p[g].M, ep.N2 = (int)p[g].N, ep.K2 = (int)p[g].K, ep.tiles0 = (int)nwg[f];
+  launch_nt_small<false>(dim3((unsigned)(nwg[0] + nwg[1]), 1), (hipStream_t)stream, (const bf16_t*)p[f].A, p[f].lda, (const bf16_t*)p[f].B, p[f].ldb,
+                         p[f].C, p[f].ldc, (int)p[f].M, (int)p[f].N, (int)p[f].K, ep, 1, ConvGeom{});
   DL_LAUNCH_CHECK();
   return DL_OK;
 }

@@ -236,6 +236,28 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias: Tensor | None = None, ac
     return out
 
 
+class _NtProblem(ctypes.Structure):
+    """ctypes mirror of dl_nt_problem_t (include/diffulab_hip.h)"""
+
+    _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("B", ctypes.c_void_p), ("ldb", ctypes.c_int64), ("C", ctypes.c_void_p),
+                ("ldc", ctypes.c_int64), ("M", ctypes.c_int64), ("N", ctypes.c_int64), ("K", ctypes.c_int64), ("bias", ctypes.c_void_p),
+                ("resid", ctypes.c_void_p), ("ldr", ctypes.c_int64)]
+
+
+def gemm_nt_pair(problems: list[tuple]) -> None:
+    """two independent bf16 products out_i[M_i, N_i] = a_i[M_i, K_i] @ b_i[N_i, K_i]^T (+ bias_i, + resid_i) as ONE launch when both are
+    small (dl_gemm_nt_pair; otherwise the two gemm_nt launches it stands for): entries (a, b, out, bias, resid, M, N, K), M / N / K may
+    be None.  Bit-identical to the separate calls."""
+    arr = (_NtProblem * len(problems))()
+    for q, (a, b, out, bias, resid, M, N, K) in zip(arr, problems):
+        assert out.dtype == torch.bfloat16
+        q.A, q.lda, q.B, q.ldb, q.C, q.ldc = _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0)
+        q.M, q.N, q.K = (a.shape[0] if M is None else M), (b.shape[0] if N is None else N), (a.shape[1] if K is None else K)
+        q.bias, q.resid, q.ldr = _p(bias), _p(resid), (resid.stride(0) if resid is not None else 0)
+    keep(arr)
+    _call("dl_gemm_nt_pair", ctypes.addressof(arr), len(problems), _s())
+
+
 def gemm_nt_swiglu(x: Tensor, w_perm: Tensor, u: Tensor | None, h: Tensor) -> bool:
     """fused MLP-up GEMM + SwiGLU; u=None skips the pre-activation store (inference).  False when the shape has no fused
     kernel (caller falls back to gemm_nt + swiglu_fwd)"""

@@ -44,6 +44,8 @@ SWITCHES: dict[str, tuple[str, str]] = {
                        "(20.03 vs 20.11 ms); it pays where the host is the slower side (under a profiler's per-launch overhead: 20.3 vs "
                        "22.7 ms), hence opt-in"),
     "DL_UNET_SIDE": ("1", "UNet weight gradients on a side stream"),
+    "DL_UNET_NT_PAIR": ("1", "UNet AttentionBlock: the q and kv projections (and their data gradients) as one launch of the 128 x 128 GEMM "
+                        "kernel where both are small (dl_gemm_nt_pair: 64 + 128 tiles on 256 CUs at the 4 x 4 level); bit-identical"),
     "DL_UNET_SPLITK": ("1", "split-K convolutions at the UNet's low-resolution levels (partial images + fixed-order fold: -7 % per step)"),
     "DL_UNET_WGRAD_WGS": ("128", "workgroup cap of the UNet's side-stream convolution weight gradients (0 = one per CU).  Round 6, with the "
                           "tap-reusing kernel and partial images (every workgroup stores its 295 KB of accumulators once, so the cap also "

@@ -513,6 +513,32 @@ class UNetEngine:
         ops.gemm_nt(xp, self.sh[name + "|f"], out, bias=self.P(name[:-6] + "bias"), resid=resid, M=M, N=co, K=K)
         return out
 
+    def _lin_fwd_pair(self, x0: Tensor, name0: str, co0: int, x1: Tensor, name1: str, co1: int, ci: int) -> tuple[Tensor, Tensor]:
+        """two Linear forwards on different inputs as ONE launch where both are small (ops.gemm_nt_pair: the q and kv projections of an
+        AttentionBlock at the low-resolution levels are 64 + 128 tiles on 256 CUs); bit-identical to two _lin_fwd calls"""
+        if not tuning.on("DL_UNET_NT_PAIR"):
+            return self._lin_fwd(x0, name0, co0, ci), self._lin_fwd(x1, name1, co1, ci)
+        M, K = x0.shape[0], _rup(ci, 64)
+        xp0, xp1 = self._padded(x0, M, K), self._padded(x1, M, K)
+        o0, o1 = self._new(M, co0), self._new(M, co1)
+        ops.gemm_nt_pair([(xp0, self.sh[name0 + "|f"], o0, self.P(name0[:-6] + "bias"), None, M, co0, K),
+                          (xp1, self.sh[name1 + "|f"], o1, self.P(name1[:-6] + "bias"), None, M, co1, K)])
+        return o0, o1
+
+    def _lin_bwd_pair(self, dy0: Tensor, x0: Tensor, name0: str, co0: int, dy1: Tensor, x1: Tensor, name1: str, co1: int,
+                      ci: int) -> tuple[Tensor, Tensor]:
+        """the backward of _lin_fwd_pair: both weight gradients off the chain as before, the two data gradients as one launch"""
+        if not tuning.on("DL_UNET_NT_PAIR"):
+            return self._lin_bwd(dy0, x0, name0, co0, ci), self._lin_bwd(dy1, x1, name1, co1, ci)
+        self._lin_bwd(dy0, x0, name0, co0, ci, need_dx=False)
+        self._lin_bwd(dy1, x1, name1, co1, ci, need_dx=False)
+        M = dy0.shape[0]
+        K0, K1 = _rup(co0, 64), _rup(co1, 64)
+        d0, d1 = self._new(M, ci), self._new(M, ci)
+        ops.gemm_nt_pair([(self._padded(dy0, M, K0), self.sh[name0 + "|t"], d0, None, None, M, ci, K0),
+                          (self._padded(dy1, M, K1), self.sh[name1 + "|t"], d1, None, None, M, ci, K1)])
+        return d0, d1
+
     def _lin_bwd(self, dy: Tensor, x: Tensor, name: str, co: int, ci: int, need_dx: bool = True) -> Tensor | None:
         M = dy.shape[0]
         Mp = _rup(M, 64)
@@ -692,8 +718,7 @@ class UNetEngine:
         nh = self.d.num_heads
         nx, st = self._gn(x, B, n, c, p + "norm_x.", silu=False)
         nc, _ = self._gn(x, B, n, c, p + "norm_context.", silu=False, stats=st)  # context = x: same statistics
-        q = self._lin_fwd(nx, p + "to_q.weight", c, c)
-        kv = self._lin_fwd(nc, p + "to_kv.weight", 2 * c, c)
+        q, kv = self._lin_fwd_pair(nx, p + "to_q.weight", c, nc, p + "to_kv.weight", 2 * c, c)
         att = self._new(B * n, c)
         probs = self._new(B, nh, n, n, dtype=torch.float32)
         self._attn_core_fwd(q, kv, att, probs, B, n, nh, c)
@@ -710,8 +735,7 @@ class UNetEngine:
         datt = self._lin_bwd(dout, att, p + "to_out.0.weight", c, c)
         dq, dkv = self._new(B * n, c), self._new(B * n, 2 * c)
         self._attn_core_bwd(q, kv, datt, probs, dq, dkv, B, n, nh, c)
-        dnx = self._lin_bwd(dq, nx, p + "to_q.weight", c, c)
-        dnc = self._lin_bwd(dkv, nc, p + "to_kv.weight", 2 * c, c)
+        dnx, dnc = self._lin_bwd_pair(dq, nx, p + "to_q.weight", c, dkv, nc, p + "to_kv.weight", 2 * c, c)
         dx = self._gn_bwd(dnx, x, st, B, n, c, p + "norm_x.", silu=False, dres=dout)
         return self._gn_bwd(dnc, x, st, B, n, c, p + "norm_context.", silu=False, dres=dx)
 

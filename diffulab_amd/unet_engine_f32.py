@@ -143,6 +143,12 @@ class UNetEngineF32(UNetEngine):
         ops.f32_col2im3x3(dcols, dx, B, H, W, ci)
         return dx
 
+    def _lin_fwd_pair(self, x0: Tensor, name0: str, co0: int, x1: Tensor, name1: str, co1: int, ci: int):
+        return self._lin_fwd(x0, name0, co0, ci), self._lin_fwd(x1, name1, co1, ci)  # (the paired launch is a bf16 kernel)
+
+    def _lin_bwd_pair(self, dy0: Tensor, x0: Tensor, name0: str, co0: int, dy1: Tensor, x1: Tensor, name1: str, co1: int, ci: int):
+        return self._lin_bwd(dy0, x0, name0, co0, ci), self._lin_bwd(dy1, x1, name1, co1, ci)
+
     def _lin_fwd(self, x: Tensor, name: str, co: int, ci: int, resid: Tensor | None = None, out: Tensor | None = None) -> Tensor:
         M = x.shape[0]
         out = self._new(M, co) if out is None else out

@@ -119,6 +119,23 @@ DL_API int dl_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, vo
                       int64_t N, int64_t K, const float* bias, int act, int out_dtype, void* pre_out,
                       const void* resid, int64_t ldr, const void* gate, int64_t ldg, int64_t rows_per_gate,
                       dl_stream_t stream);
+/* Two independent bf16 products C_i = A_i B_i^T (+ bias_i f32 [N_i], + resid_i bf16 rows) in ONE launch when both are small (together
+ * at most 1.5 of the 128 x 128 kernel's workgroups per CU); otherwise, and for n == 1, exactly the dl_gemm_nt calls it stands for.
+ * Bit-identical to those calls.  (The q and kv projections of a UNet AttentionBlock -- unet.py:497-533 -- and their data gradients at
+ * the low-resolution levels: 64 + 128 tiles on 256 CUs.) */
+typedef struct dl_nt_problem_t {
+  const void* A;      /* bf16 [M, lda >= K] */
+  int64_t lda;
+  const void* B;      /* bf16 [N, ldb >= K] */
+  int64_t ldb;
+  void* C;            /* bf16 [M, ldc >= N] */
+  int64_t ldc;
+  int64_t M, N, K;    /* K % 64 == 0 */
+  const float* bias;  /* f32 [N] or NULL */
+  const void* resid;  /* bf16 [M, ldr] or NULL */
+  int64_t ldr;
+} dl_nt_problem_t;
+DL_API int dl_gemm_nt_pair(const dl_nt_problem_t* problems, int n, dl_stream_t stream);
 /* mlp_input[0] + PackedSwiGLU fused (mmdit.py:260-264, nn.py:484-486): U[M,2F] = X Wp^T written in the reference
  * layout [x1 | x3] (kept for the backward; U == NULL skips it: inference / sampler loops) and H[M,F] = silu(x1) * x3, in
  * ONE pass over the accumulators.

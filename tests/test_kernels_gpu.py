@@ -163,6 +163,33 @@ def test_small_launch_gemm_on_the_four_slot_ring_equals_the_two_slot_form(ops, M
     assert rel(outs[1].float(), ref) < 5e-3
 
 
+@pytest.mark.parametrize("M,N0,N1,K0,K1,bias,resid", [(1024, 1024, 2048, 1024, 1024, True, False), (4096, 512, 1024, 512, 512, True, True),
+                                                      (2048, 1024, 1024, 1024, 2048, False, False), (1000, 136, 264, 64, 192, True, True),
+                                                      (16384, 256, 512, 256, 256, True, False), (64, 128, 128, 128, 64, False, True)])
+def test_two_small_products_in_one_launch_equal_their_separate_launches(ops, M, N0, N1, K0, K1, bias, resid):
+    """dl_gemm_nt_pair (round 6): two independent products -- the q and kv projections of a UNet AttentionBlock and their data gradients
+    -- as ONE launch of the 128 x 128 kernel when both are small (workgroups from `tiles0` on compute the second); larger pairs fall
+    back to the two dl_gemm_nt calls.  Either way bit-identical to those calls; outputs are column slices of wider buffers."""
+    def mk(tag, N, K):
+        a = dev_bf(bf(synth.normal(f"pr.a{tag}{M}", (M, K))))
+        w = dev_bf(bf(synth.normal(f"pr.w{tag}{N}", (N, K), std=K**-0.5)))
+        b_ = synth.normal(f"pr.b{tag}", (N,), std=0.1).to(DEV) if bias else None
+        r_ = dev_bf(bf(synth.normal(f"pr.r{tag}{M}", (M, N)))) if resid else None
+        return a, w, b_, r_
+    p0, p1 = mk("0", N0, K0), mk("1", N1, K1)
+    sep = []
+    for a, w, b_, r_ in (p0, p1):
+        o = torch.full((M, w.shape[0] + 8), 7.0, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(a, w, o[:, : w.shape[0]], bias=b_, resid=r_)
+        sep.append(o)
+    outs = [torch.full((M, N0 + 8), 7.0, device=DEV, dtype=torch.bfloat16), torch.full((M, N1 + 8), 7.0, device=DEV, dtype=torch.bfloat16)]
+    ops.gemm_nt_pair([(p0[0], p0[1], outs[0][:, :N0], p0[2], p0[3], None, None, None), (p1[0], p1[1], outs[1][:, :N1], p1[2], p1[3], None, None, None)])
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], sep[0]) and torch.equal(outs[1], sep[1])
+    ref = p1[0].float() @ p1[1].float().t() + (p1[2] if bias else 0) + (p1[3].float() if resid else 0)
+    assert rel(outs[1][:, :N1].float(), ref) < 5e-3
+
+
 @pytest.mark.parametrize("M,N,R", [(512, 512, 8192), (1024, 1024, 2048), (128, 256, 131072), (1024, 512, 8192), (256, 768, 32768), (2048, 1024, 2048),
                                    (200, 136, 4096 + 64), (28672, 512, 128), (64, 128, 16384)])
 def test_atomic_weight_gradient_gemm_split_rules(ops, M, N, R):
